@@ -1,0 +1,222 @@
+/*
+ * faqcs_mi.h -- C ABI of libfaqcs_mi.so: the MI355X (gfx950) implementation of the FaQCs per-read
+ * trim / filter / accumulate hot path.
+ *
+ * Drop-in boundary.  The reference (LANL-Bioinformatics/FaQCs v2.10) has no FFI; the seam this
+ * library replaces is the C++ function
+ *
+ *     void trim(std::vector<Read>&, std::vector<size_t>& filter_stats,
+ *               MAP<std::string, std::pair<size_t,size_t>>& adapter_stats,
+ *               MAP<Word,size_t>& kmer_table, PlotInfo&, Options&);        // FaQCs.h:245-248
+ *
+ * whose six call sites are FaQCs.cpp:287,290,424,427 (paired) and :628,:692 (unpaired).  One
+ * reference trim() call == one *segment* of a faqcs_batch here.  integration/trim_shim.cpp is the
+ * ~150-line C++ adapter a maintainer would compile in place of trim.o.
+ *
+ * Conventions: plain pointers and sizes only, no C++ / torch types; the caller owns every host
+ * buffer; the library owns device memory and HIP streams; every entry point returns 0 or a negative
+ * FAQCS_E_* code and faqcs_last_error() gives the text; no exceptions cross the boundary.
+ */
+#ifndef FAQCS_MI_H
+#define FAQCS_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FAQCS_ABI_VERSION 1
+
+/* FilterStat enum order, FaQCs.h:46-75 */
+enum {
+    FAQCS_TOTAL_COUNT = 0, FAQCS_TOTAL_NUMBER, FAQCS_TOTAL_LENGTH, FAQCS_TOTAL_TRIMMED_NUMBER,
+    FAQCS_TOTAL_TRIMMED_LENGTH, FAQCS_PAIRED_READ_NUMBER, FAQCS_PAIRED_BASE_LENGTH, FAQCS_READ_LENGTH,
+    FAQCS_BASE_LENGTH, FAQCS_READ_NN, FAQCS_BASE_NN, FAQCS_READ_PHIX, FAQCS_BASE_PHIX,
+    FAQCS_READ_ADAPTER, FAQCS_BASE_ADAPTER, FAQCS_READ_AVG_Q, FAQCS_BASE_AVG_Q, FAQCS_READ_QUAL_TRIM,
+    FAQCS_BASE_QUAL_TRIM, FAQCS_READ_LOW_COMPLEXITY, FAQCS_BASE_LOW_COMPLEXITY, FAQCS_N_TO_A,
+    FAQCS_N_TO_T, FAQCS_N_TO_G, FAQCS_N_TO_C, FAQCS_NUM_STAT
+};
+
+#define FAQCS_NQ 42            /* MAX_QUALITY_SCORE + 1, fastq.h:15 */
+#define FAQCS_NBASE 5          /* A,T,C,G,N -- enum order FaQCs.h:35-42 */
+#define FAQCS_NCOMP_BIN 10001  /* NUM_COMPOSITION_BIN, FaQCs.h:20 */
+#define FAQCS_NCOMP_KIND 6     /* NucleotideCount fields A,T,C,G,N,GC, FaQCs.h:167-174 */
+#define FAQCS_SEGMENT_READS 32768 /* buffer_size, FaQCs.cpp:232,585 */
+#define FAQCS_MAX_READ_LENGTH 4096
+#define FAQCS_MAX_ADAPTERS 64
+#define FAQCS_MAX_ADAPTER_LENGTH 8192
+
+enum { FAQCS_MODE_HARD = 0, FAQCS_MODE_BWA = 1, FAQCS_MODE_BWA_PLUS = 2 }; /* Options::Mode, FaQCs.h:90-95 */
+
+/* error codes */
+enum {
+    FAQCS_OK = 0,
+    FAQCS_E_INVAL = -1,      /* bad argument / unsupported size */
+    FAQCS_E_NODEVICE = -2,   /* no HIP device or HIP runtime failure */
+    FAQCS_E_QUALITY = -3,    /* a quality score > 41 after the offset (fastq.h:31-33 throws) */
+    FAQCS_E_BASE = -4,       /* non-IUPAC base reached the aligner (seq_overlap.cpp:409 throws) */
+    FAQCS_E_NOMEM = -5,
+    FAQCS_E_KMER_FULL = -6   /* device k-mer table exhausted */
+};
+
+/* The subset of the reference's Options (FaQCs.h:77-144) the hot path reads, flattened to a POD.
+ * The host resolves everything the reference resolves before/around trim(): quality-offset
+ * auto-detect (trim.cpp:599-617), the NextSeq -q bump (trim.cpp:619-626, FaQCs.cpp:404-414) and the
+ * adapter list (options.cpp:576-694). */
+typedef struct faqcs_params {
+    uint32_t abi_version;                 /* FAQCS_ABI_VERSION */
+    int32_t  mode;                        /* FAQCS_MODE_* */
+    int32_t  quality;                     /* -q ; Options::quality is a (signed) char */
+    int32_t  input_quality_offset;        /* 33 / 64 (already auto-detected) */
+    int32_t  output_quality_offset;
+    uint32_t min_read_length;             /* --min_L */
+    uint32_t max_num_poly_N;              /* -n */
+    uint32_t trim_5;                      /* --5end */
+    uint32_t trim_3;                      /* --3end */
+    uint32_t replace_to_N_q;              /* --replace_to_N_q */
+    float    average_quality;             /* --avg_q */
+    float    low_complexity_cutoff_ratio; /* --lc  (float in the reference: FaQCs.h:115) */
+    float    filterAdapterMismatchRate;   /* --rate */
+    uint32_t protect_5;                   /* --5trim_off */
+    uint32_t qc_only;                     /* --qc_only */
+    uint32_t kmer_rarefaction;            /* --kmer_rarefaction */
+    uint32_t kmer;                        /* -m, 2..31 */
+    uint32_t split_size;                  /* --split_size */
+    uint32_t num_subsample;               /* --subset (already doubled per options.cpp:506-523) */
+    uint32_t max_read_length;             /* capacity R of the per-position matrices (<= FAQCS_MAX_READ_LENGTH) */
+    uint32_t n_adapters;                  /* 0 == !(filter_adapter || filter_phiX) */
+    const char *const *adapter_seq;       /* n_adapters NUL-terminated IUPAC strings (Options::adapter[j].second) */
+    uint64_t kmer_table_slots;            /* device hash-table capacity (0 = library default) */
+} faqcs_params;
+
+/* One submission: reads packed back to back in two byte arenas (structure of arrays).
+ * Read i occupies seq[offset[i] .. offset[i+1]) and qual[offset[i] .. offset[i+1]) -- the reference
+ * rejects |seq| != |qual| at parse time (fastq.cpp:117-121) so one offset array serves both.
+ * Both arenas must be readable for 16 bytes before offset[0]&~15 .. past offset[n] rounded up to 16
+ * (the kernels use aligned 16-byte loads).  segment_start[] partitions the reads into reference
+ * trim() calls (adapter groups of 8 restart at a segment start, trim.cpp:977-1071; k-mer rarefaction
+ * points are taken at segment ends, trim.cpp:157-185). */
+typedef struct faqcs_batch {
+    const uint8_t  *seq;
+    const uint8_t  *qual;
+    const uint32_t *offset;         /* n_reads + 1 entries, non-decreasing */
+    uint32_t        n_reads;
+    uint32_t        n_segments;     /* >= 1 when n_reads > 0 */
+    const uint32_t *segment_start;  /* n_segments + 1 entries; [0] = 0, [n_segments] = n_reads */
+} faqcs_batch;
+
+/* Per-read outcome (8 bytes).  For a valid read the reference's output record is
+ *   seq  = in.seq [start, start+len)  with 'G' -> 'N' where Q < replace_to_N_q   (trim.cpp:390-403)
+ *   qual = in.qual[start, start+len)  with the read's leading / trailing upper-case-'N' runs set to
+ *          the input offset (trim.cpp:1191-1216) and then re-based input->output offset (trim.cpp:516-525)
+ * faqcs_apply_edits() performs exactly these byte edits on the host. */
+typedef struct faqcs_read_result {
+    uint16_t start;   /* == offset_5 of trim_read() for a valid read */
+    uint16_t len;
+    uint16_t flags;   /* FAQCS_F_* */
+    uint16_t adapter; /* 1 + index of the adapter credited for this read (trim.cpp:1036-1064), 0 = none */
+} faqcs_read_result;
+
+#define FAQCS_F_VALID        0x0001u
+#define FAQCS_F_FILTER_MASK  0x000eu /* which filter fired first (trim_read short-circuit order) */
+#define FAQCS_F_FILTER_SHIFT 1
+enum { FAQCS_FILT_NONE = 0, FAQCS_FILT_LENGTH_PRE = 1, FAQCS_FILT_LENGTH_POST = 2, FAQCS_FILT_POLY_N = 3,
+       FAQCS_FILT_AVG_Q = 4, FAQCS_FILT_LOW_COMPLEXITY = 5 };
+#define FAQCS_F_QUAL_TRIMMED 0x0010u /* READ_QUAL_TRIM counted for this read */
+#define FAQCS_F_ADAPTER      0x0020u /* start_length changed by the adapter pre-pass */
+#define FAQCS_F_POLY_N_SEEN  0x0040u /* READ_NN counted (qc_only keeps the read valid, trim.cpp:368-370) */
+#define FAQCS_F_ERR_QUALITY  0x0100u
+#define FAQCS_F_ERR_BASE     0x0200u
+
+/* Layout (in uint64 units) of the additive counter block.  Everything the reference accumulates in
+ * filter_stats / PlotInfo / adapter_stats is a sum of per-read integers, so one block == one
+ * all-reduce(sum).  Matrices are row-major [position][column] exactly like matrix<size_t>
+ * (matrix.h:56-64); the reference's "rows grow on demand" is recovered on the host as
+ * 1 + (last non-zero row) -- see faqcs_counter_rows(). */
+typedef struct faqcs_layout {
+    uint32_t max_read_length; /* R */
+    uint32_t n_adapters;
+    uint64_t filter_stats;    /* [FAQCS_NUM_STAT] */
+    uint64_t pre_read_qhist, pre_base_qhist, post_read_qhist, post_base_qhist; /* [42] each */
+    uint64_t pre_len_hist, post_len_hist;   /* [R+1] */
+    uint64_t pre_qual, post_qual;           /* [R][42] */
+    uint64_t pre_base, post_base;           /* [R][5]  */
+    uint64_t pre_comp, post_comp;           /* [10001][6]  (A,T,C,G,N,GC) */
+    uint64_t adapter_stats;                 /* [n_adapters][2] = (reads, bases) */
+    uint64_t total;                         /* number of uint64 in the block */
+} faqcs_layout;
+
+typedef struct faqcs_rarefaction { uint64_t num_seq, distinct_kmer, total_kmer; } faqcs_rarefaction; /* FaQCs.h:194-199 */
+
+typedef struct faqcs_ctx faqcs_ctx;
+
+/* ---- layout / host helpers (no GPU needed) ---- */
+int  faqcs_abi_version(void);
+int  faqcs_counters_layout(uint32_t max_read_length, uint32_t n_adapters, faqcs_layout *out);
+/* rows the reference's growing matrix<size_t> would have: 1 + last non-zero row (0 if all zero) */
+uint32_t faqcs_counter_rows(const uint64_t *matrix, uint32_t max_rows, uint32_t n_cols);
+/* applies the rule-based byte edits documented at faqcs_read_result; out_* need res->len bytes */
+int  faqcs_apply_edits(const faqcs_params *p, const uint8_t *seq, const uint8_t *qual, uint32_t read_len,
+                       const faqcs_read_result *res, uint8_t *out_seq, uint8_t *out_qual);
+/* trim.cpp:599-617 -- returns 33, 64 or 0 (undecided: the reference throws) */
+int  faqcs_auto_detect_quality_offset(const uint8_t *qual, const uint32_t *offset, uint32_t n_reads);
+const char *faqcs_last_error(void);
+
+/* ---- device path ---- */
+/* device_id < 0 selects the current HIP device.  Copies the adapter strings. */
+int  faqcs_create(const faqcs_params *params, int device_id, faqcs_ctx **out);
+void faqcs_destroy(faqcs_ctx *ctx);
+
+/* Process one batch whose arrays live in HOST memory: async H2D on the context's copy stream, kernels
+ * on its compute stream, async D2H of the per-read results into `results` (n_reads entries).  Returns
+ * when the work is enqueued; faqcs_sync() waits.  Counters accumulate on the device. */
+int  faqcs_submit(faqcs_ctx *ctx, const faqcs_batch *batch, faqcs_read_result *results);
+
+/* Same, but batch->seq/qual/offset and d_results are DEVICE pointers (inputs already resident in HBM:
+ * the configuration bench.py times).  segment_start stays a host pointer. d_results may be NULL. */
+int  faqcs_submit_device(faqcs_ctx *ctx, const faqcs_batch *batch, faqcs_read_result *d_results);
+
+int  faqcs_sync(faqcs_ctx *ctx);
+
+/* Options::quality is mutable during a run: the NextSeq check bumps -q to 20 (FaQCs.cpp:272-277,404-414).
+ * Takes effect for batches submitted afterwards. */
+int  faqcs_set_quality(faqcs_ctx *ctx, int quality);
+
+/* Device address + length (uint64 units) of the additive counter block, so the host can run the one
+ * collective this path needs -- all-reduce(sum, uint64) over RCCL -- in place before faqcs_finish(). */
+int  faqcs_counters_device(faqcs_ctx *ctx, void **d_ptr, uint64_t *n_u64);
+
+/* Copies the counter block to the host (layout: faqcs_counters_layout); syncs first.
+ * Raises FAQCS_E_QUALITY / FAQCS_E_BASE if any read tripped the reference's throw sites. */
+int  faqcs_finish(faqcs_ctx *ctx, uint64_t *counters, uint64_t n_u64);
+int  faqcs_reset_counters(faqcs_ctx *ctx);
+
+/* k-mer rarefaction (trim.cpp:157-185, FaQCs.cpp:518-537).  Points are appended at segment ends during
+ * submit; after faqcs_sync():  */
+int  faqcs_kmer_points(faqcs_ctx *ctx, faqcs_rarefaction *out, uint32_t cap, uint32_t *n_points);
+/* (count, number of keys with that count) pairs, ascending count -- PlotInfo::kmer_frequency_histogram */
+int  faqcs_kmer_histogram(faqcs_ctx *ctx, uint64_t *count, uint64_t *nkeys, uint64_t cap, uint64_t *n_pairs);
+/* distinct keys / sum of counts currently in the table (the FaQCs.cpp:523-537 fallback point) */
+int  faqcs_kmer_totals(faqcs_ctx *ctx, uint64_t *distinct, uint64_t *total);
+/* Options::kmer_rarefaction is switched off by trim() once the curve is complete (trim.cpp:180-184) */
+int  faqcs_kmer_active(faqcs_ctx *ctx);
+/* End of a process_paired()/process_unpaired() pass (FaQCs.cpp:518-537, :737-756): folds the table into the
+ * count histogram, appends the guaranteed single rarefaction point if none was taken, and starts a fresh
+ * table (each process_* owns its own MAP<Word,size_t>, FaQCs.cpp:235,588). */
+int  faqcs_kmer_end_table(faqcs_ctx *ctx);
+
+/* ---- measurement helpers (used by bench.py; not part of the reference seam) ---- */
+/* Fills device arenas with the SURVEY section-8(d) synthetic reads (counter-based PRNG keyed by
+ * (seed, first_read + i)); stride == L (packed).  d_offset gets n_reads+1 entries. */
+int  faqcs_synth_fill(int device_id, uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads,
+                      uint32_t L, uint64_t seed, uint64_t first_read, float adapter_frac);
+/* average duration (ms) of the dominant kernel over the launches since the last call, measured with
+ * HIP events recorded on the compute stream around each launch */
+int  faqcs_kernel_time_ms(faqcs_ctx *ctx, double *avg_ms, uint64_t *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAQCS_MI_H */

@@ -1,0 +1,65 @@
+"""Shared helpers for the golden-vector tests (CPU: OracleEngine, GPU: HipEngine)."""
+import hashlib
+import io
+import json
+import os
+
+import make_fixtures
+from make_golden import ARTIFACT_FASTA, CASES_DIR, HERE as GOLDEN_DIR, md5_file
+
+from faqcs_amd import driver
+
+
+def case_names(slow=True):
+    names = sorted(f[:-5] for f in os.listdir(CASES_DIR) if f.endswith(".json"))
+    return names
+
+
+def load_case(name):
+    with open(os.path.join(CASES_DIR, name + ".json")) as f:
+        return json.load(f)
+
+
+def fixture_paths(fixture, cache):
+    if fixture == "example":
+        return os.path.join(GOLDEN_DIR, "example_1.fastq.gz"), os.path.join(GOLDEN_DIR, "example_2.fastq.gz")
+    return make_fixtures.materialise(fixture, cache)
+
+
+def run_case(case, cache, tmp_path, engine_factory, **kw):
+    """Runs our host driver with the given engine on the case's command line; returns a list of
+    human-readable mismatches against the reference outputs stored in the case (empty == parity)."""
+    p1, p2 = fixture_paths(case["fixture"], cache)
+    assert [md5_file(p1), md5_file(p2)] == case["fixture_md5"], "fixture generator drifted: " + case["fixture"]
+    outdir = os.path.join(str(tmp_path), "out")
+    m = {"{1}": p1, "{2}": p2, "{U}": p1, "{D}": outdir, "{ART}": ARTIFACT_FASTA}
+    argv = [m.get(a, a) for a in case["args"]]
+    err = io.StringIO()
+    rc = driver.run(argv, engine_factory=engine_factory, err=err, **kw)
+    bad = []
+    if rc != case["exit_code"]:
+        bad.append("exit code %d != %d (%s)" % (rc, case["exit_code"], err.getvalue()[-300:]))
+    have = set(os.listdir(outdir)) if os.path.isdir(outdir) else set()
+    for fn, text in case["text"].items():
+        if fn not in have:
+            bad.append("missing " + fn)
+            continue
+        with open(os.path.join(outdir, fn), errors="replace") as f:
+            got = f.read()
+        if got != text:
+            gl, tl = got.splitlines(), text.splitlines()
+            k = next((i for i in range(min(len(gl), len(tl))) if gl[i] != tl[i]), min(len(gl), len(tl)))
+            bad.append("%s differs at line %d: got %r want %r" % (fn, k + 1, gl[k:k + 1], tl[k:k + 1]))
+    for fn, meta in case["fastq"].items():
+        if fn not in have:
+            bad.append("missing " + fn)
+            continue
+        with open(os.path.join(outdir, fn), "rb") as f:
+            data = f.read()
+        if hashlib.md5(data).hexdigest() != meta["md5"]:
+            bad.append("%s: md5 mismatch (records %d vs %d, bytes %d vs %d)" % (
+                fn, data.count(b"\n") // 4, meta["records"], len(data), meta["bytes"]))
+    extra = {f for f in have if not f.endswith(".pdf")} - set(case["text"]) - set(case["fastq"])
+    if extra:
+        bad.append("unexpected files: %s" % sorted(extra))
+    return bad
