@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the FaQCs per-read hot path on MI355X.
+
+A *step* is one pass of trim_filter_accumulate (+ adapter_overlap for --config adapter) over the whole
+synthetic data set resident in HBM: BASELINE.json configs[1] (100 M pairs of 2x150 bp, BWA_plus -q 5
+--min_L 50) per GPU, generated on the device by faqcs_synth_fill.  Inputs are in HBM
+when the timed region starts; every step ends with the job's one collective, the all-reduce of the counter
+block (world_size > 1).  value = reads processed by all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see the task contract), including
+  roofline     algorithmic bytes (2L + 4 + 8 per read) / average kernel time measured with HIP
+               events on the library's compute stream; peak = 8 TB/s HBM3E
+  cpu_baseline the real reference binary (oracle/_ref/FaQCs_ref -t <cores>, kind "reference") or the plain-C
+               port (kind "port") timed on a bounded sample of the same workload on this host.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_PAIRS", 100e6)),
+                    help="pairs per GPU resident in HBM (default: the 100 M pairs of BASELINE configs[1])")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--config", choices=["plain", "adapter"], default="plain")
+    ap.add_argument("--batch-reads", type=int, default=1 << 24, help="reads per submission (u32 offsets: < 4 GiB arena)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(opt_args, hs, hq, L, n_sample):
+    """Times the reference (or the oracle port) on a bounded sample: returns the cpu_baseline object."""
+    cores = os.cpu_count() or 1
+    ref = os.path.join(ROOT, "oracle", "_ref", "FaQCs_ref")
+    port = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_engine import OracleEngine
+
+        from faqcs_amd.options import parse_args
+
+        opt = parse_args(["-1", "a", "-2", "b", "-d", "x", "--ascii", "33"] + opt_args)
+        m = min(n_sample, 200000)
+        eng = OracleEngine(opt, 256, 33)
+        off = (np.arange(m + 1, dtype=np.uint64) * L).astype(np.uint32)
+        t0 = time.perf_counter()
+        eng.process(hs, hq, off, np.array([0, m], dtype=np.uint32))
+        port = m / (time.perf_counter() - t0) / 1e6
+    except Exception as e:  # the checker is optional for the bench
+        print("cpu_baseline: oracle port unavailable (%s)" % e, file=sys.stderr)
+    if os.path.exists(ref):
+        try:
+            tmp = tempfile.mkdtemp(prefix="faqcs_bench_")
+            half = n_sample // 2
+            for mate, lo in ((1, 0), (2, half)):
+                with open(os.path.join(tmp, "r%d.fq" % mate), "wb") as f:
+                    chunk = []
+                    for i in range(half):
+                        a = (lo + i) * L
+                        chunk.append(b"@SYN:%d/%d\n" % (i, mate) + hs[a:a + L].tobytes() + b"\n+\n" + hq[a:a + L].tobytes() + b"\n")
+                    f.write(b"".join(chunk))
+            cmd = [ref, "-1", os.path.join(tmp, "r1.fq"), "-2", os.path.join(tmp, "r2.fq"), "-d", os.path.join(tmp, "out"),
+                   "-t", str(cores), "--ascii", "33", "--trim_only"] + opt_args
+            t0 = time.perf_counter()
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=600)
+            dt = time.perf_counter() - t0
+            subprocess.run(["rm", "-rf", tmp])
+            return {"value": round(2 * half / dt / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "reference",
+                    "sample": "%d pairs of the same synthetic 2x%d workload as uncompressed FASTQ, whole-process wall clock of "
+                              "FaQCs v2.10 -t %d --trim_only (parse+trim+write; the reference cannot separate them)" % (half, L, cores),
+                    "port_value": None if port is None else round(port, 4)}
+        except Exception as e:
+            print("cpu_baseline: reference run failed (%s)" % e, file=sys.stderr)
+    if port is not None:
+        return {"value": round(port, 4), "unit": "M reads/s", "cores": 1, "kind": "port",
+                "sample": "%d reads of the same workload through oracle/faqcs_oracle.c (single thread, compute only)" % min(n_sample, 200000)}
+    return None
+
+
+def main():
+    a = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import __graft_entry__ as g
+
+    if rank == 0:
+        g.build()
+    if world > 1:
+        dist.barrier()
+
+    from faqcs_amd import _capi as capi
+    from faqcs_amd import parallel
+    from faqcs_amd.engine import HipEngine, _check
+    from faqcs_amd.options import parse_args
+
+    L = a.read_len
+    opt_args = ["--adapter", "--polyA"] if a.config == "adapter" else []
+    opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
+    eng = HipEngine(opt, 256, 33, device=local)
+    lib = eng.lib
+
+    # ---- resident synthetic data set ---------------------------------------------------------------------
+    n_reads = int(2 * a.pairs)
+    free, _ = torch.cuda.mem_get_info(dev)
+    need = n_reads * (2 * L + 12) + (1 << 30)
+    if need > free * 0.9:
+        n_reads = int((free * 0.9 - (1 << 30)) // (2 * L + 12))
+    batch = min(a.batch_reads, (0xFFFFFFFF - 4096) // L)
+    batches = []
+    first = rank * n_reads
+    done = 0
+    adapter_frac = 0.05 if a.config == "adapter" else 0.0
+    while done < n_reads:
+        m = min(batch, n_reads - done)
+        seq = torch.empty(m * L + 64, dtype=torch.uint8, device=dev)
+        qual = torch.empty(m * L + 64, dtype=torch.uint8, device=dev)
+        off = torch.empty(m + 1, dtype=torch.int32, device=dev)
+        res = torch.empty((m, 4), dtype=torch.int16, device=dev)
+        _check(lib, lib.faqcs_synth_fill(local, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, L, 20260101, first + done, adapter_frac))
+        # the reference's 32 768-read trim() granularity only matters to the adapter pre-pass (groups of 8)
+        seg = np.arange(0, m + capi.SEGMENT_READS, capi.SEGMENT_READS, dtype=np.uint32)
+        seg[-1] = m
+        if len(seg) > 1 and seg[-2] >= m:
+            seg = seg[:-1]
+        bt = capi.Batch(seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, len(seg) - 1, seg.ctypes.data, L)
+        batches.append((seq, qual, off, res, seg, bt, m))
+        done += m
+    torch.cuda.synchronize()
+
+    def step():
+        for (_s, _q, _o, res, _seg, bt, _m) in batches:
+            _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(bt), res.data_ptr()))
+        if world > 1:
+            parallel.allreduce_counters_device(eng)
+        else:
+            eng.sync()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    avg_ms, nl = C.c_double(), C.c_uint64()
+    lib.faqcs_kernel_time_ms(eng.ctx, C.byref(avg_ms), C.byref(nl))  # reset the kernel timer
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    _check(lib, lib.faqcs_kernel_time_ms(eng.ctx, C.byref(avg_ms), C.byref(nl)))
+
+    if rank == 0:
+        total_reads = n_reads * world * a.steps
+        value = total_reads / dt / 1e6
+        reads_per_launch = n_reads / max(1, len(batches))
+        alg_bytes = reads_per_launch * (2 * L + 4 + 8)
+        achieved = alg_bytes / (avg_ms.value * 1e-3) / 1e9 if avg_ms.value > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config)
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "M reads/sec (paired 2x%dbp)" % L, "value": round(value, 3), "unit": "M reads/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "synthetic %.0fM-pair 2x%dbp Q33 reads resident in HBM per GPU, BWA_plus -q 5 --min_L 50%s, "
+                                   "1 step = 1 pass (trim_filter_accumulate%s + counter all-reduce)"
+                                   % (n_reads / 2e6, L, " --adapter --polyA (5%% read-through)" if a.config == "adapter" else "",
+                                      " after adapter_overlap" if a.config == "adapter" else ""),
+                       "pairs_per_gpu": n_reads // 2, "read_len": L, "launches_per_step": len(batches) * (2 if a.config == "adapter" else 1),
+                       "M_pairs_per_s": round(value / 2, 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "trim_filter_accumulate",
+                         "kernel_ms": round(avg_ms.value, 4), "launches": int(nl.value),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            ns = min(400000, batches[0][6])
+            hs = batches[0][0][: ns * L].cpu().numpy()
+            hq = batches[0][1][: ns * L].cpu().numpy()
+            pad = np.zeros(64, np.uint8)
+            out["cpu_baseline"] = cpu_baseline(opt_args, np.concatenate([hs, pad]), np.concatenate([hq, pad]), L, ns)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,7 +48,7 @@ class Params(C.Structure):
 class Batch(C.Structure):
     _fields_ = [
         ("seq", C.c_void_p), ("qual", C.c_void_p), ("offset", C.c_void_p), ("n_reads", C.c_uint32),
-        ("n_segments", C.c_uint32), ("segment_start", C.c_void_p),
+        ("n_segments", C.c_uint32), ("segment_start", C.c_void_p), ("max_read_len", C.c_uint32),
     ]
 
 

@@ -1,0 +1,188 @@
+// faqcs_adapter_kernel.hip -- adapter_overlap: the adapter / primer / PhiX pre-pass (gfx950, wave64).
+//
+// Replaces trim_adapters_and_phiX(vector<Read>&,...) (trim.cpp:961-1142), SO::SeqOverlap's ungapped
+// Smith-Waterman (seq_overlap.cpp:46-370, seq_overlap.h:370-411,519-549) and find_mask_range
+// (trim.cpp:1144-1189).  The reference packs 8 reads into int16 SSE lanes and sweeps the DP matrix row by
+// row; here ONE wavefront owns ONE read and its 64 lanes own 64 DIAGONALS of the (read x adapter) matrix.
+// Ungapped local alignment decouples along diagonals: M(i,j) = max(M(i-1,j-1),0) + s(i,j) is a Kadane
+// recurrence per diagonal, kept entirely in registers; the read's 4-bit IUPAC masks sit in LDS, the
+// adapter's in scalar registers (uniform index).  The reference's "last row-major cell among maxima wins"
+// (seq_overlap.cpp:338-354) becomes a wave max-reduce on the key (M, i, j).
+//
+// Reference quirks reproduced: Q1 group-of-8 threshold from the LAST read of the
+// group / tail group without the min (defined as -t 1 behaviour), Q3 start survives diagonals touching 0,
+// Q4 literal find_mask_range, Q5 IUPAC bit-overlap matching, H2 stale range carried from the previous
+// adapter of the same read when no cell reaches M >= 0.
+#include "faqcs_dev.h"
+
+struct AdapterDev {
+    const uint8_t *bits;     // concatenated 4-bit IUPAC masks, one byte per base
+    const uint32_t *start;   // [n_adapters + 1]
+    uint32_t n_adapters;
+    float match_rate;        // float(1.0 - filterAdapterMismatchRate), trim.cpp:969
+};
+
+// seq_overlap.cpp:372-411 na_to_bits() as a table over 'a'..'z' (case folded); 0 == the reference throws
+// "Unknown base!".  NA bit masks: A=1 C=2 G=4 T=8 (seq_overlap.h:133-150).
+__device__ const uint8_t k_iupac[26] = {
+    /*a*/ 1, /*b*/ 14, /*c*/ 2, /*d*/ 13, /*e*/ 0, /*f*/ 0, /*g*/ 4, /*h*/ 11, /*i*/ 0, /*j*/ 0, /*k*/ 12, /*l*/ 0, /*m*/ 3,
+    /*n*/ 15, /*o*/ 0, /*p*/ 0, /*q*/ 0, /*r*/ 5, /*s*/ 6, /*t*/ 8, /*u*/ 0, /*v*/ 7, /*w*/ 9, /*x*/ 0, /*y*/ 10, /*z*/ 0};
+__device__ __forceinline__ uint32_t na_bits(uint32_t c)
+{
+    if (c == '-') return 16u;
+    const uint32_t l = (c | 0x20u) - 'a';
+    const bool letter = ((c & 0xdfu) >= 'A') && ((c & 0xdfu) <= 'Z');
+    return letter ? (uint32_t)k_iupac[l] : 0u;
+}
+
+template <int NW, int MAXLEN>
+__global__ __launch_bounds__(NW * 64) void adapter_overlap(
+    const AdapterDev A, const uint8_t *__restrict__ seq, const uint32_t *__restrict__ off, const uint32_t n_reads,
+    const uint32_t *__restrict__ seg_start, const uint32_t n_segments, uint32_t *__restrict__ ad_sl,
+    uint16_t *__restrict__ ad_hit, uint64_t *__restrict__ adapter_stats, uint32_t *__restrict__ err)
+{
+    __shared__ uint8_t s_q[NW][MAXLEN];       // the read's IUPAC masks
+    __shared__ uint8_t s_mask[NW][MAXLEN];    // vector<bool> mask of trim.cpp:991 (1 = unmasked)
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(threadIdx.x >> 6);
+    volatile uint8_t *q = s_q[wave];
+    volatile uint8_t *mk = s_mask[wave];
+    const uint32_t n_waves = gridDim.x * NW;
+
+#pragma unroll 1
+    for (uint32_t r = blockIdx.x * NW + wave; r < n_reads; r += n_waves) {
+        const uint32_t o = off[r];
+        const int qlen = (int)(off[r + 1] - o);
+        // ---- which reference group of 8 is this read in? (trim.cpp:977-1071, -t 1 semantics) ----------
+        uint32_t lo = 0, hi = n_segments; // segment s with seg_start[s] <= r < seg_start[s+1]
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= r) lo = mid; else hi = mid; }
+        const uint32_t s0 = seg_start[lo], s1 = seg_start[lo + 1];
+        const uint32_t g_last = s0 + (((r - s0) >> 3) << 3) + 7; // last slot of the group
+        const bool tail = g_last >= s1;
+        const int len8 = tail ? 0 : (int)(off[g_last + 1] - off[g_last]);
+
+        // ---- pack_query: bases -> IUPAC bit masks in LDS --------------------------------------------------
+        bool badbase = false;
+        for (int p = lane; p < qlen; p += 64) {
+            const uint32_t bits = na_bits(seq[(size_t)o + p]);
+            badbase |= bits == 0u;
+            q[p] = (uint8_t)bits;
+            mk[p] = 1;
+        }
+        const bool read_bad = __any(badbase);
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS writes are visible to itself in order
+        __builtin_amdgcn_wave_barrier();
+
+        int best_score = 0, best_j = -1;
+        bool have = false;
+        int rs = 0, re = 0;
+        if (!read_bad && qlen > 0) {
+#pragma unroll 1
+            for (uint32_t j = 0; j < A.n_adapters; ++j) {
+                const uint32_t t0 = A.start[j];
+                const int tlen = (int)(A.start[j + 1] - t0);
+                const int m = tail ? tlen : (len8 < tlen ? len8 : tlen);
+                const int thr = (int)__fmul_rn(A.match_rate, (float)m);      // trim.cpp:1007-1008 / :1082
+                // ---- align(): best (M, i, j) over all diagonals ------------------------------------------
+                int gM = -1, gI = 0, gJ = 0, gS = 0;
+                const int ndiag = qlen + tlen - 1;
+#pragma unroll 1
+                for (int dd0 = 0; dd0 < ndiag; dd0 += 64) {
+                    const int d = dd0 + lane - (qlen - 1);                   // j_t - i on this lane's diagonal
+                    const int dlo = dd0 - (qlen - 1), dhi = dlo + 63;
+                    const int jt_lo = dlo > 0 ? dlo : 0;
+                    const int jt_hi = (dhi + qlen - 1) < (tlen - 1) ? (dhi + qlen - 1) : (tlen - 1);
+                    int M = -1, st = 0, bM = -1, bS = 0, bI = 0;
+#pragma unroll 1
+                    for (int jt = jt_lo; jt <= jt_hi; ++jt) {
+                        const uint32_t tb = A.bits[t0 + jt];                 // uniform -> scalar load
+                        const int i = jt - d;
+                        const bool valid = (unsigned)i < (unsigned)qlen;
+                        const uint32_t qb = valid ? q[i] : 0u;
+                        const int s = (qb & tb) ? 1 : -1;                    // seq_overlap.cpp:157-161
+                        const int nS = (M < 0) ? i : st;                     // seq_overlap.cpp:255,272-275
+                        const int nM = (M > 0 ? M : 0) + s;                  // seq_overlap.cpp:185-188
+                        M = valid ? nM : -1;
+                        st = nS;
+                        const bool up = valid && nM >= 0 && nM >= bM;        // seq_overlap.cpp:338-354 (>=: later cell wins)
+                        bM = up ? nM : bM; bS = up ? nS : bS; bI = up ? i : bI;
+                    }
+                    const int Mx = (int)wave_max_u32((uint32_t)(bM + 1)) - 1;
+                    if (Mx >= 0) {
+                        const uint32_t key = (bM == Mx) ? ((((uint32_t)bI << 13) | (uint32_t)(bI + d)) + 1u) : 0u;
+                        const uint32_t K = wave_max_u32(key) - 1u;
+                        const int wi = (int)(K >> 13), wj = (int)(K & 8191u);
+                        const int wl = wj - wi + (qlen - 1) - dd0;           // lane that owns the winning diagonal
+                        const int ws = __builtin_amdgcn_readlane(bS, wl);
+                        const bool better = Mx > gM || (Mx == gM && (wi > gI || (wi == gI && wj > gJ)));
+                        if (better) { gM = Mx; gI = wi; gJ = wj; gS = ws; }
+                    }
+                }
+                int score = 0;
+                if (gM >= 0) { have = true; rs = gS; re = gI; score = gM; }
+                else if (!have) continue;                                    // H2: unknown stale state -> no hit
+                const int match_length = re - rs + 1;
+                const int num_match = (match_length + score) / 2;            // trim.cpp:1024-1025
+                if (num_match >= thr) {
+                    for (int p = rs + lane; p <= re; p += 64) mk[p] = 0;     // trim.cpp:1032-1034
+                    if (score > best_score) { best_score = score; best_j = (int)j; }
+                }
+            }
+        }
+
+        uint32_t first = 0, second = (uint32_t)qlen;
+        if (best_score > 0) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // find_mask_range, trim.cpp:1144-1189, literal
+            uint32_t longest_run_start = 0, longest_run_length = 0, run_start = 0, run_length = 0;
+#pragma unroll 1
+            for (int p = 0; p < qlen; ++p) {
+                if (!mk[p]) {
+                    if (run_length > longest_run_length) { longest_run_length = run_length; longest_run_start = run_start; run_length = 0; }
+                } else {
+                    if (run_length == 0) run_start = (uint32_t)p;
+                    ++run_length;
+                }
+            }
+            if (run_length > longest_run_length) { longest_run_length = run_length; longest_run_start = run_start; }
+            first = longest_run_length ? longest_run_start : 0u;
+            second = longest_run_length;
+            if (lane == 0) {
+                atomicAdd((unsigned long long *)&adapter_stats[2 * best_j], 1ull);                          // trim.cpp:1061-1064
+                atomicAdd((unsigned long long *)&adapter_stats[2 * best_j + 1], (unsigned long long)((uint32_t)qlen - second));
+            }
+        }
+        if (lane == 0) {
+            ad_sl[r] = first | (second << 16);
+            ad_hit[r] = (uint16_t)(best_score > 0 ? best_j + 1 : 0);
+            if (read_bad) atomicOr(err, 2u);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
+                                uint32_t max_len, const uint32_t *seg_start, uint32_t n_segments, uint32_t *ad_sl,
+                                uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, int n_cu, hipStream_t st)
+{
+    if (n_reads == 0) return hipSuccess;
+    if (max_len <= 256) {
+        constexpr int NW = 8;
+        uint32_t grid = (n_reads + NW - 1) / NW;
+        const uint32_t cap = (uint32_t)n_cu * 4u;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL((adapter_overlap<NW, 256>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
+                           n_segments, ad_sl, ad_hit, adapter_stats, err);
+    } else if (max_len <= 4096) {
+        constexpr int NW = 4;
+        uint32_t grid = (n_reads + NW - 1) / NW;
+        const uint32_t cap = (uint32_t)n_cu * 4u;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL((adapter_overlap<NW, 4096>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
+                           n_segments, ad_sl, ad_hit, adapter_stats, err);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

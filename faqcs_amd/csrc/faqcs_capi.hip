@@ -1,0 +1,633 @@
+// faqcs_capi.hip -- host side of libfaqcs_mi.so: the C ABI declared in include/faqcs_mi.h.
+//
+// One faqcs_ctx == the (filter_stats, adapter_stats, PlotInfo, Options) quadruple the reference keeps in
+// main() (FaQCs.cpp:67-69) plus the device state: a compute stream, a copy stream, device staging arenas,
+// the additive u64 counter block, the adapter tables and the k-mer hash table.
+// There is NO CPU implementation of the hot path in this library: without a HIP device faqcs_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "faqcs_dev.h"
+
+// kernels (other translation units)
+struct AdapterDev {
+    const uint8_t *bits;
+    const uint32_t *start;
+    uint32_t n_adapters;
+    float match_rate;
+};
+struct KmerTable {
+    unsigned long long *keys;
+    uint32_t *counts;
+    uint64_t mask;
+    unsigned long long *stats;
+};
+hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
+                             uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
+                             faqcs_read_result *out, uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st);
+hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
+                                uint32_t max_len, const uint32_t *seg_start, uint32_t n_segments, uint32_t *ad_sl,
+                                uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, int n_cu, hipStream_t st);
+hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T, const uint8_t *seq, const uint8_t *qual,
+                             const uint32_t *off, uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results,
+                             int n_cu, hipStream_t st);
+hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
+                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
+                                       hipStream_t st);
+hipError_t faqcs_launch_synth(uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads, uint32_t L,
+                              uint64_t seed, uint64_t first_read, float adapter_frac, hipStream_t st);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                         \
+    do {                                                                                                  \
+        hipError_t e_ = (x);                                                                              \
+        if (e_ != hipSuccess)                                                                             \
+            return fail(FAQCS_E_NODEVICE, std::string(#x) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+namespace {
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0; // elements
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Timing { hipEvent_t a, b; };
+
+} // namespace
+
+struct faqcs_ctx {
+    faqcs_params prm;
+    int device = 0, n_cu = 256;
+    hipStream_t compute = nullptr, copy = nullptr;
+    hipEvent_t copied = nullptr;
+    DevParams dp;
+    faqcs_layout lay;
+    // device tables
+    uint16_t *d_mono = nullptr, *d_di = nullptr;
+    uint32_t *d_avgq = nullptr;
+    float *d_norm = nullptr;
+    uint64_t *d_magic = nullptr;
+    uint64_t *d_counters = nullptr;
+    uint32_t *d_err = nullptr;
+    // adapters
+    std::vector<std::string> adapters;
+    uint8_t *d_abits = nullptr;
+    uint32_t *d_astart = nullptr;
+    float match_rate = 0.f;
+    // staging for host submissions
+    DevBuf<uint8_t> s_seq, s_qual;
+    DevBuf<uint32_t> s_off, s_seg, s_sl;
+    DevBuf<uint16_t> s_hit;
+    DevBuf<faqcs_read_result> s_res;
+    // rarefaction state (trim.cpp:157-185): host-deterministic from read counts, values filled from the device
+    uint64_t total_number = 0;
+    int kmer_active = 0;
+    std::vector<faqcs_rarefaction> points;
+    struct PendingPoint { size_t point_index; size_t snap_index; };
+    std::vector<PendingPoint> pending;
+    KmerTable kt{nullptr, nullptr, 0, nullptr};
+    unsigned long long *d_snaps = nullptr; // [snap_cap][2]
+    size_t snap_cap = 0, n_snaps = 0;
+    std::map<uint64_t, uint64_t> kmer_hist; // PlotInfo::kmer_frequency_histogram
+    // kernel timing
+    std::vector<Timing> timings;
+    size_t timing_used = 0;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// layout + host helpers
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int faqcs_abi_version(void) { return FAQCS_ABI_VERSION; }
+
+extern "C" int faqcs_counters_layout(uint32_t R, uint32_t n_adapters, faqcs_layout *L)
+{
+    if (!L || R == 0 || R > FAQCS_MAX_READ_LENGTH || n_adapters > FAQCS_MAX_ADAPTERS) return fail(FAQCS_E_INVAL, "faqcs_counters_layout: bad size");
+    uint64_t o = 0;
+    memset(L, 0, sizeof(*L));
+    L->max_read_length = R;
+    L->n_adapters = n_adapters;
+    L->filter_stats = o;    o += 32;
+    L->pre_read_qhist = o;  o += FAQCS_NQ;
+    L->pre_base_qhist = o;  o += FAQCS_NQ;
+    L->post_read_qhist = o; o += FAQCS_NQ;
+    L->post_base_qhist = o; o += FAQCS_NQ;
+    L->pre_len_hist = o;    o += (uint64_t)R + 1;
+    L->post_len_hist = o;   o += (uint64_t)R + 1;
+    L->pre_qual = o;        o += (uint64_t)R * FAQCS_NQ;
+    L->post_qual = o;       o += (uint64_t)R * FAQCS_NQ;
+    L->pre_base = o;        o += (uint64_t)R * FAQCS_NBASE;
+    L->post_base = o;       o += (uint64_t)R * FAQCS_NBASE;
+    L->pre_comp = o;        o += (uint64_t)FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND;
+    L->post_comp = o;       o += (uint64_t)FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND;
+    L->adapter_stats = o;   o += (uint64_t)n_adapters * 2;
+    L->total = o;
+    return 0;
+}
+
+extern "C" uint32_t faqcs_counter_rows(const uint64_t *m, uint32_t max_rows, uint32_t n_cols)
+{
+    for (uint32_t r = max_rows; r > 0; --r)
+        for (uint32_t c = 0; c < n_cols; ++c)
+            if (m[(uint64_t)(r - 1) * n_cols + c]) return r;
+    return 0;
+}
+
+extern "C" int faqcs_apply_edits(const faqcs_params *p, const uint8_t *seq, const uint8_t *qual, uint32_t read_len,
+                                 const faqcs_read_result *res, uint8_t *out_seq, uint8_t *out_qual)
+{
+    if (!p || !res || (uint32_t)res->start + res->len > read_len) return fail(FAQCS_E_INVAL, "faqcs_apply_edits: window outside the read");
+    uint32_t lead = 0, trail = read_len; // [lead, trail) keeps its quality (trim.cpp:1191-1216)
+    while (lead < read_len && seq[lead] == 'N') ++lead;
+    while (trail > 0 && seq[trail - 1] == 'N') --trail;
+    const int in = p->input_quality_offset, out = p->output_quality_offset;
+    for (uint32_t k = 0; k < res->len; ++k) {
+        const uint32_t i = res->start + k;
+        const int raw = (i < lead || i >= trail) ? in : (int)(int8_t)qual[i];
+        int qs = raw - in;
+        if (qs < 0) qs = 0;
+        uint8_t b = seq[i];
+        if (p->replace_to_N_q > 0 && b == 'G' && qs < (int)p->replace_to_N_q) b = 'N'; // trim.cpp:390-403
+        out_seq[k] = b;
+        out_qual[k] = (in != out) ? (uint8_t)(qs + out) : (uint8_t)raw;                  // trim.cpp:516-525
+    }
+    return 0;
+}
+
+extern "C" int faqcs_auto_detect_quality_offset(const uint8_t *qual, const uint32_t *offset, uint32_t n_reads)
+{
+    if (!n_reads) return 0;
+    for (uint32_t i = offset[0]; i < offset[n_reads]; ++i) { // trim.cpp:599-617
+        const int c = (int)(int8_t)qual[i];
+        if (c > 74) return 64;
+        if (c < 59) return 33;
+    }
+    return 0;
+}
+
+extern "C" const char *faqcs_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side integer tables (the reference's float32 expressions, evaluated once per length)
+// ---------------------------------------------------------------------------------------------------------
+static uint8_t na_to_bits_host(char c)
+{
+    switch (c) { // seq_overlap.cpp:372-411
+    case 'A': case 'a': return 1;  case 'C': case 'c': return 2;  case 'G': case 'g': return 4;
+    case 'T': case 't': return 8;  case 'M': case 'm': return 3;  case 'R': case 'r': return 5;
+    case 'S': case 's': return 6;  case 'V': case 'v': return 7;  case 'W': case 'w': return 9;
+    case 'Y': case 'y': return 10; case 'H': case 'h': return 11; case 'K': case 'k': return 12;
+    case 'D': case 'd': return 13; case 'B': case 'b': return 14; case 'N': case 'n': return 15;
+    case '-': return 16;
+    }
+    return 0;
+}
+
+static void build_tables(const faqcs_params &p, std::vector<uint16_t> &mono, std::vector<uint16_t> &di,
+                         std::vector<uint32_t> &avgq, std::vector<float> &norm, std::vector<uint64_t> &magic)
+{
+    const int N = FAQCS_TAB_LEN + 1;
+    mono.assign(N, 0xffff); di.assign(N, 0xffff); avgq.assign(N, 0); norm.assign(N, 0.f); magic.assign(N, 0);
+    const volatile float lc = p.low_complexity_cutoff_ratio;
+    const volatile float avg = p.average_quality;
+    for (int len = 1; len < N; ++len) {
+        volatile float nrm = (float)(1.0 / (double)len);                 // trim.cpp:483
+        for (int c = 0; c <= len; ++c) { volatile float v = (float)(unsigned)c * nrm; if (v > lc) { mono[len] = (uint16_t)c; break; } }
+        volatile float nrm2 = (float)((double)nrm * 2.0);                // trim.cpp:499
+        for (int c = 0; c <= len; ++c) { volatile float v = (float)(unsigned)c * nrm2; if (v > lc) { di[len] = (uint16_t)c; break; } }
+        norm[len] = (float)(FAQCS_NCOMP_BIN - 1) / (float)len;           // trim.cpp:860
+        magic[len] = ((1ull << 44) + (uint64_t)len - 1) / (uint64_t)len;
+        if (avg > 0.0f) {
+            // smallest biased sum S_b = sum(raw + 128) for which NOT(ave_Q < avg); ave_Q per trim.cpp:568-572
+            auto pass = [&](uint32_t sb) {
+                volatile float t = (float)((int)sb - 128 * len) / (float)len;
+                volatile float v = t - (float)p.input_quality_offset;
+                const float a = v > 0.0f ? v : 0.0f;
+                return !(a < avg);
+            };
+            uint32_t lo = 0, hi = 256u * (uint32_t)len; // pass(hi) may still be false -> UINT32_MAX
+            if (!pass(hi)) avgq[len] = 0xffffffffu;
+            else { while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pass(mid)) hi = mid; else lo = mid + 1; } avgq[len] = lo; }
+        }
+    }
+}
+
+template <class T> static hipError_t upload(T **dst, const std::vector<T> &v)
+{
+    hipError_t e = hipMalloc((void **)dst, v.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// create / destroy
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **out)
+{
+    if (!p || !out) return fail(FAQCS_E_INVAL, "faqcs_create: null argument");
+    if (p->abi_version != FAQCS_ABI_VERSION) return fail(FAQCS_E_INVAL, "faqcs_create: ABI version mismatch");
+    if (p->max_read_length == 0 || p->max_read_length > FAQCS_MAX_READ_LENGTH) return fail(FAQCS_E_INVAL, "faqcs_create: max_read_length out of range");
+    if (p->n_adapters > FAQCS_MAX_ADAPTERS) return fail(FAQCS_E_INVAL, "faqcs_create: too many adapters");
+    if (p->mode < 0 || p->mode > 2) return fail(FAQCS_E_INVAL, "trim.cpp:trim_read: Undefined trimming mode!");
+    if (p->kmer_rarefaction && (p->kmer < 2 || p->kmer > 31 || p->split_size == 0)) return fail(FAQCS_E_INVAL, "faqcs_create: kmer / split_size out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FAQCS_E_NODEVICE, "faqcs_create: no HIP device (the FaQCs MI355X hot path has no CPU fallback)");
+    if (device_id < 0) HIPCHK(hipGetDevice(&device_id));
+    HIPCHK(hipSetDevice(device_id));
+    faqcs_ctx *c = new faqcs_ctx();
+    c->prm = *p;
+    c->prm.adapter_seq = nullptr;
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->copied, hipEventDisableTiming));
+    faqcs_counters_layout(p->max_read_length, p->n_adapters, &c->lay);
+
+    std::vector<uint16_t> mono, di; std::vector<uint32_t> avgq; std::vector<float> norm; std::vector<uint64_t> magic;
+    build_tables(*p, mono, di, avgq, norm, magic);
+    HIPCHK(upload(&c->d_mono, mono)); HIPCHK(upload(&c->d_di, di)); HIPCHK(upload(&c->d_avgq, avgq));
+    HIPCHK(upload(&c->d_norm, norm)); HIPCHK(upload(&c->d_magic, magic));
+    HIPCHK(hipMalloc((void **)&c->d_counters, c->lay.total * sizeof(uint64_t)));
+    HIPCHK(hipMemset(c->d_counters, 0, c->lay.total * sizeof(uint64_t)));
+    HIPCHK(hipMalloc((void **)&c->d_err, 64));
+    HIPCHK(hipMemset(c->d_err, 0, 64));
+
+    if (p->n_adapters) {
+        std::vector<uint8_t> bits; std::vector<uint32_t> start(1, 0);
+        for (uint32_t j = 0; j < p->n_adapters; ++j) {
+            const char *s = p->adapter_seq[j];
+            const size_t L = strlen(s);
+            if (L == 0 || L > FAQCS_MAX_ADAPTER_LENGTH) { delete c; return fail(FAQCS_E_INVAL, "faqcs_create: adapter length out of range"); }
+            c->adapters.emplace_back(s);
+            for (size_t k = 0; k < L; ++k) {
+                const uint8_t b = na_to_bits_host(s[k]);
+                if (!b) { delete c; return fail(FAQCS_E_BASE, "seq_overlap.cpp:na_to_bits: Unknown base!"); }
+                bits.push_back(b);
+            }
+            start.push_back((uint32_t)bits.size());
+        }
+        HIPCHK(upload(&c->d_abits, bits)); HIPCHK(upload(&c->d_astart, start));
+        c->match_rate = (float)(1.0 - (double)p->filterAdapterMismatchRate); // trim.cpp:969
+    }
+
+    DevParams &d = c->dp;
+    memset(&d, 0, sizeof(d));
+    d.mode = p->mode; d.Q = p->quality; d.in_off = p->input_quality_offset; d.out_off = p->output_quality_offset;
+    d.min_len = p->min_read_length; d.max_poly_n = p->max_num_poly_N; d.trim5 = p->trim_5; d.trim3 = p->trim_3;
+    d.replace_q = p->replace_to_N_q; d.protect5 = p->protect_5; d.qc_only = p->qc_only;
+    d.has_adapters = p->n_adapters ? 1 : 0; d.avgq_on = p->average_quality > 0.0f ? 1 : 0;
+    d.R = p->max_read_length; d.n_adapters = p->n_adapters;
+    d.mono_thr = c->d_mono; d.di_thr = c->d_di; d.avgq_min_sum = c->d_avgq; d.comp_norm = c->d_norm; d.div_magic = c->d_magic;
+    d.lay = c->lay;
+
+    c->kmer_active = p->kmer_rarefaction ? 1 : 0;
+    if (p->kmer_rarefaction) {
+        uint64_t slots = p->kmer_table_slots ? p->kmer_table_slots : (1ull << 28);
+        uint64_t pow2 = 1; while (pow2 < slots) pow2 <<= 1;
+        c->kt.mask = pow2 - 1;
+        HIPCHK(hipMalloc((void **)&c->kt.keys, pow2 * 8));
+        HIPCHK(hipMalloc((void **)&c->kt.counts, pow2 * 4));
+        HIPCHK(hipMalloc((void **)&c->kt.stats, 64));
+        HIPCHK(hipMemset(c->kt.keys, 0xff, pow2 * 8));
+        HIPCHK(hipMemset(c->kt.counts, 0, pow2 * 4));
+        HIPCHK(hipMemset(c->kt.stats, 0, 64));
+        c->snap_cap = 4096;
+        HIPCHK(hipMalloc((void **)&c->d_snaps, c->snap_cap * 16));
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void faqcs_destroy(faqcs_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->compute) (void)hipStreamSynchronize(c->compute);
+    if (c->copy) (void)hipStreamSynchronize(c->copy);
+    for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    void *ptrs[] = {c->d_mono, c->d_di, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart,
+                    c->kt.keys, c->kt.counts, c->kt.stats, c->d_snaps};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    c->s_seq.release(); c->s_qual.release(); c->s_off.release(); c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
+    if (c->copied) (void)hipEventDestroy(c->copied);
+    if (c->compute) (void)hipStreamDestroy(c->compute);
+    if (c->copy) (void)hipStreamDestroy(c->copy);
+    delete c;
+}
+
+extern "C" int faqcs_set_quality(faqcs_ctx *c, int quality)
+{
+    if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    c->prm.quality = quality;
+    c->dp.Q = quality;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// submission
+// ---------------------------------------------------------------------------------------------------------
+// seq/qual/off are device pointers valid for indices off[0]..off[n]; host_off is the host copy of the offsets
+// (needed for the max read length and k-mer bookkeeping), d_res a device result array.
+static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, const uint32_t *d_off, uint32_t n,
+                   uint32_t max_len, const uint32_t *seg, uint32_t n_seg, faqcs_read_result *d_res)
+{
+    const faqcs_params &p = c->prm;
+    uint32_t *d_sl = nullptr; uint16_t *d_hit = nullptr;
+    if (n && p.n_adapters) {
+        HIPCHK(c->s_sl.reserve(n)); HIPCHK(c->s_hit.reserve(n)); HIPCHK(c->s_seg.reserve(n_seg + 1));
+        d_sl = c->s_sl.p; d_hit = c->s_hit.p;
+        HIPCHK(hipMemcpyAsync(c->s_seg.p, seg, (n_seg + 1) * 4, hipMemcpyHostToDevice, c->compute));
+        AdapterDev A{c->d_abits, c->d_astart, p.n_adapters, c->match_rate};
+        HIPCHK(faqcs_launch_adapter(A, d_seq, d_off, n, max_len, c->s_seg.p, n_seg, d_sl, d_hit,
+                                    c->d_counters + c->lay.adapter_stats, c->d_err, c->n_cu, c->compute));
+    }
+    if (n) {
+        if (c->timing_used == c->timings.size()) {
+            Timing t; HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b)); c->timings.push_back(t);
+        }
+        Timing &t = c->timings[c->timing_used++];
+        HIPCHK(hipEventRecord(t.a, c->compute));
+        HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, c->d_counters, c->d_err, c->n_cu, c->compute));
+        HIPCHK(hipEventRecord(t.b, c->compute));
+    }
+    // ---- rarefaction bookkeeping per reference trim() call (trim.cpp:157-185) -------------------------------
+    for (uint32_t s = 0; s < n_seg; ++s) {
+        const uint32_t r0 = seg[s], r1 = seg[s + 1];
+        if (c->kmer_active) {
+            HIPCHK(faqcs_launch_kmer(c->dp, p.kmer, c->kt, d_seq, d_qual, d_off, r0, r1, d_res, c->n_cu, c->compute));
+        }
+        c->total_number += (r1 - r0);
+        if (c->kmer_active) {
+            const uint64_t index = c->total_number / p.split_size;
+            const size_t num_rarefaction = c->points.size();
+            if (index > num_rarefaction && num_rarefaction < p.num_subsample) {
+                if (c->n_snaps == c->snap_cap) { // drain the snapshots taken so far
+                    HIPCHK(hipStreamSynchronize(c->compute));
+                    std::vector<unsigned long long> h(c->n_snaps * 2);
+                    HIPCHK(hipMemcpy(h.data(), c->d_snaps, c->n_snaps * 16, hipMemcpyDeviceToHost));
+                    for (auto &pp : c->pending) { c->points[pp.point_index].distinct_kmer = h[2 * pp.snap_index]; c->points[pp.point_index].total_kmer = h[2 * pp.snap_index + 1]; }
+                    c->pending.clear(); c->n_snaps = 0;
+                }
+                HIPCHK(hipMemcpyAsync(c->d_snaps + 2 * c->n_snaps, c->kt.stats, 16, hipMemcpyDeviceToDevice, c->compute));
+                faqcs_rarefaction pt{c->total_number, 0, 0};
+                c->points.push_back(pt);
+                c->pending.push_back({c->points.size() - 1, c->n_snaps});
+                ++c->n_snaps;
+            }
+            if (num_rarefaction >= p.num_subsample) c->kmer_active = 0; // trim.cpp:180-184
+        }
+    }
+    return 0;
+}
+
+static int scan_offsets(const uint32_t *off, uint32_t n, uint32_t cap, uint32_t *max_len)
+{
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (off[i + 1] < off[i]) return fail(FAQCS_E_INVAL, "faqcs_submit: offsets must be non-decreasing");
+        const uint32_t l = off[i + 1] - off[i];
+        m = l > m ? l : m;
+    }
+    if (m > cap) return fail(FAQCS_E_INVAL, "faqcs_submit: read longer than max_read_length");
+    if (m > 256) return fail(FAQCS_E_INVAL, "faqcs_submit: reads longer than 256 bases are not supported by this build of the HIP kernels");
+    *max_len = m;
+    return 0;
+}
+
+static int check_segments(const faqcs_batch *b)
+{
+    if (!b || !b->offset) return fail(FAQCS_E_INVAL, "faqcs_submit: null batch");
+    if (!b->segment_start || b->segment_start[0] != 0 || b->segment_start[b->n_segments] != b->n_reads)
+        return fail(FAQCS_E_INVAL, "faqcs_submit: segment_start must span [0, n_reads]");
+    for (uint32_t s = 0; s < b->n_segments; ++s)
+        if (b->segment_start[s + 1] < b->segment_start[s]) return fail(FAQCS_E_INVAL, "faqcs_submit: segment_start must be non-decreasing");
+    return 0;
+}
+
+extern "C" int faqcs_submit(faqcs_ctx *c, const faqcs_batch *b, faqcs_read_result *results)
+{
+    if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    if (int rc = check_segments(b)) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t n = b->n_reads;
+    uint32_t max_len = 0;
+    if (int rc = scan_offsets(b->offset, n, c->prm.max_read_length, &max_len)) return rc;
+    const uint32_t o0 = b->offset[0], o1 = b->offset[n];
+    const size_t bytes = (size_t)(o1 - o0);
+    // one compute-stream sync keeps the single staging set safe to overwrite (double buffering: next round)
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(c->s_seq.reserve(bytes + 64)); HIPCHK(c->s_qual.reserve(bytes + 64));
+    HIPCHK(c->s_off.reserve((size_t)n + 1)); HIPCHK(c->s_res.reserve((size_t)n + 1));
+    // arena bytes land 16 bytes into the staging buffer; the kernels index with the ORIGINAL offsets
+    if (bytes) {
+        HIPCHK(hipMemcpyAsync(c->s_seq.p + 16, b->seq + o0, bytes, hipMemcpyHostToDevice, c->copy));
+        HIPCHK(hipMemcpyAsync(c->s_qual.p + 16, b->qual + o0, bytes, hipMemcpyHostToDevice, c->copy));
+    }
+    HIPCHK(hipMemcpyAsync(c->s_off.p, b->offset, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->copy));
+    HIPCHK(hipEventRecord(c->copied, c->copy));
+    HIPCHK(hipStreamWaitEvent(c->compute, c->copied, 0));
+    const uint8_t *d_seq = c->s_seq.p + 16 - o0, *d_qual = c->s_qual.p + 16 - o0;
+    if (int rc = enqueue(c, d_seq, d_qual, c->s_off.p, n, max_len, b->segment_start, b->n_segments, c->s_res.p)) return rc;
+    if (n && results) HIPCHK(hipMemcpyAsync(results, c->s_res.p, (size_t)n * sizeof(faqcs_read_result), hipMemcpyDeviceToHost, c->compute));
+    return 0;
+}
+
+extern "C" int faqcs_submit_device(faqcs_ctx *c, const faqcs_batch *b, faqcs_read_result *d_results)
+{
+    if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    if (!b || !b->segment_start) return fail(FAQCS_E_INVAL, "faqcs_submit_device: null batch");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t n = b->n_reads;
+    // offsets live on the device: the caller vouches for max_read_length; pick the kernel from the ctx capacity
+    uint32_t max_len = b->max_read_len ? b->max_read_len : c->prm.max_read_length;
+    if (max_len > c->prm.max_read_length) return fail(FAQCS_E_INVAL, "faqcs_submit_device: max_read_len exceeds the context capacity");
+    if (max_len > 256) return fail(FAQCS_E_INVAL, "faqcs_submit_device: reads longer than 256 bases are not supported by this build of the HIP kernels");
+    if (!d_results) { HIPCHK(c->s_res.reserve((size_t)n + 1)); d_results = c->s_res.p; }
+    return enqueue(c, b->seq, b->qual, b->offset, n, max_len, b->segment_start, b->n_segments, d_results);
+}
+
+static int resolve_points(faqcs_ctx *c)
+{
+    if (c->pending.empty()) return 0;
+    std::vector<unsigned long long> h(c->n_snaps * 2);
+    HIPCHK(hipMemcpy(h.data(), c->d_snaps, c->n_snaps * 16, hipMemcpyDeviceToHost));
+    for (auto &pp : c->pending) {
+        c->points[pp.point_index].distinct_kmer = h[2 * pp.snap_index];
+        c->points[pp.point_index].total_kmer = h[2 * pp.snap_index + 1];
+    }
+    c->pending.clear();
+    c->n_snaps = 0;
+    return 0;
+}
+
+extern "C" int faqcs_sync(faqcs_ctx *c)
+{
+    if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->copy));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    for (size_t i = 0; i < c->timing_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->timings[i].a, c->timings[i].b) == hipSuccess) { c->kernel_ms += ms; ++c->kernel_launches; }
+    }
+    c->timing_used = 0;
+    if (int rc = resolve_points(c)) return rc;
+    uint32_t e = 0;
+    HIPCHK(hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
+    if (e & 1u) return fail(FAQCS_E_QUALITY, "fastq.h:quality_score: Found a quality score value that is greater than the maximum allowed quality score");
+    if (e & 2u) return fail(FAQCS_E_BASE, "seq_overlap.cpp:na_to_bits: Unknown base!");
+    if (c->kt.stats) {
+        unsigned long long st[3];
+        HIPCHK(hipMemcpy(st, c->kt.stats, 24, hipMemcpyDeviceToHost));
+        if (st[2]) return fail(FAQCS_E_KMER_FULL, "faqcs: device k-mer table is full (raise faqcs_params.kmer_table_slots)");
+    }
+    return 0;
+}
+
+extern "C" int faqcs_counters_device(faqcs_ctx *c, void **d_ptr, uint64_t *n_u64)
+{
+    if (!c || !d_ptr || !n_u64) return fail(FAQCS_E_INVAL, "null argument");
+    *d_ptr = c->d_counters;
+    *n_u64 = c->lay.total;
+    return 0;
+}
+
+extern "C" int faqcs_finish(faqcs_ctx *c, uint64_t *counters, uint64_t n_u64)
+{
+    if (!c || !counters || n_u64 < c->lay.total) return fail(FAQCS_E_INVAL, "faqcs_finish: counter buffer too small");
+    if (int rc = faqcs_sync(c)) return rc;
+    HIPCHK(hipMemcpy(counters, c->d_counters, c->lay.total * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int faqcs_reset_counters(faqcs_ctx *c)
+{
+    if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, c->lay.total * sizeof(uint64_t), c->compute));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k-mer rarefaction results
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int faqcs_kmer_active(faqcs_ctx *c) { return c ? c->kmer_active : 0; }
+
+extern "C" int faqcs_kmer_points(faqcs_ctx *c, faqcs_rarefaction *out, uint32_t cap, uint32_t *n_points)
+{
+    if (!c || !n_points) return fail(FAQCS_E_INVAL, "null argument");
+    if (int rc = faqcs_sync(c)) return rc;
+    *n_points = (uint32_t)c->points.size();
+    for (uint32_t i = 0; out && i < cap && i < c->points.size(); ++i) out[i] = c->points[i];
+    return 0;
+}
+
+extern "C" int faqcs_kmer_totals(faqcs_ctx *c, uint64_t *distinct, uint64_t *total)
+{
+    if (!c || !distinct || !total) return fail(FAQCS_E_INVAL, "null argument");
+    *distinct = *total = 0;
+    if (!c->kt.stats) return 0;
+    if (int rc = faqcs_sync(c)) return rc;
+    unsigned long long st[2];
+    HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    *distinct = st[0]; *total = st[1];
+    return 0;
+}
+
+extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
+{
+    if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    if (!c->kt.stats) return 0;
+    if (int rc = faqcs_sync(c)) return rc;
+    unsigned long long st[2];
+    HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    if (st[0]) { // ++kmer_frequency_histogram[count] for every key, FaQCs.cpp:518-521
+        const uint32_t DENSE = 1u << 16, BIGCAP = 1u << 20;
+        unsigned long long *d_dense = nullptr, *d_big = nullptr, *d_nbig = nullptr;
+        HIPCHK(hipMalloc((void **)&d_dense, DENSE * 8)); HIPCHK(hipMalloc((void **)&d_big, (size_t)BIGCAP * 8)); HIPCHK(hipMalloc((void **)&d_nbig, 8));
+        HIPCHK(hipMemsetAsync(d_dense, 0, DENSE * 8, c->compute)); HIPCHK(hipMemsetAsync(d_nbig, 0, 8, c->compute));
+        HIPCHK(faqcs_launch_kmer_histogram(c->kt, d_dense, DENSE, d_big, d_nbig, BIGCAP, c->n_cu, c->compute));
+        HIPCHK(hipStreamSynchronize(c->compute));
+        std::vector<unsigned long long> dense(DENSE);
+        unsigned long long nbig = 0;
+        HIPCHK(hipMemcpy(dense.data(), d_dense, DENSE * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&nbig, d_nbig, 8, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < DENSE; ++i) if (dense[i]) c->kmer_hist[i] += dense[i];
+        if (nbig > BIGCAP) { (void)hipFree(d_dense); (void)hipFree(d_big); (void)hipFree(d_nbig); return fail(FAQCS_E_NOMEM, "faqcs_kmer_end_table: too many k-mers with count >= 65536"); }
+        if (nbig) {
+            std::vector<unsigned long long> big(nbig);
+            HIPCHK(hipMemcpy(big.data(), d_big, nbig * 8, hipMemcpyDeviceToHost));
+            for (auto v : big) c->kmer_hist[v] += 1;
+        }
+        (void)hipFree(d_dense); (void)hipFree(d_big); (void)hipFree(d_nbig);
+    }
+    if (c->kmer_active && c->points.empty()) { // FaQCs.cpp:523-537
+        faqcs_rarefaction pt{c->total_number, st[0], st[1]};
+        c->points.push_back(pt);
+    }
+    HIPCHK(hipMemsetAsync(c->kt.keys, 0xff, (c->kt.mask + 1) * 8, c->compute));
+    HIPCHK(hipMemsetAsync(c->kt.counts, 0, (c->kt.mask + 1) * 4, c->compute));
+    HIPCHK(hipMemsetAsync(c->kt.stats, 0, 64, c->compute));
+    return 0;
+}
+
+extern "C" int faqcs_kmer_histogram(faqcs_ctx *c, uint64_t *count, uint64_t *nkeys, uint64_t cap, uint64_t *n_pairs)
+{
+    if (!c || !n_pairs) return fail(FAQCS_E_INVAL, "null argument");
+    *n_pairs = c->kmer_hist.size();
+    uint64_t i = 0;
+    for (auto &kv : c->kmer_hist) {
+        if (i >= cap || !count || !nkeys) break;
+        count[i] = kv.first; nkeys[i] = kv.second; ++i;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// measurement helpers
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int faqcs_synth_fill(int device_id, uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads,
+                                uint32_t L, uint64_t seed, uint64_t first_read, float adapter_frac)
+{
+    if (device_id >= 0) HIPCHK(hipSetDevice(device_id));
+    if ((uint64_t)n_reads * L + L > 0xffffffffull) return fail(FAQCS_E_INVAL, "faqcs_synth_fill: arena exceeds 32-bit offsets");
+    HIPCHK(faqcs_launch_synth(d_seq, d_qual, d_offset, n_reads, L, seed, first_read, adapter_frac, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" int faqcs_kernel_time_ms(faqcs_ctx *c, double *avg_ms, uint64_t *n_launches)
+{
+    if (!c || !avg_ms || !n_launches) return fail(FAQCS_E_INVAL, "null argument");
+    if (int rc = faqcs_sync(c)) return rc;
+    *n_launches = c->kernel_launches;
+    *avg_ms = c->kernel_launches ? c->kernel_ms / (double)c->kernel_launches : 0.0;
+    c->kernel_ms = 0.0; c->kernel_launches = 0;
+    return 0;
+}

@@ -1,0 +1,148 @@
+// faqcs_kmer_kernel.hip -- kmer_count: canonical k-mer counting into a device hash table (gfx950, wave64).
+//
+// Replaces update_kmer() (trim.cpp:887-931) and the std::unordered_map<size_t,size_t> tables
+// (trim.cpp:82,133-135) whose serial merge dominates the reference's k-mer mode.  One wavefront per read,
+// lane = position inside a 64-base chunk.  Per chunk three ballots give the 2-bit code planes (bit0, bit1)
+// and the "valid ACGT inside the kept window" plane as 64-bit scalars; lane l extracts the k-bit windows
+// ending at its position with 64-bit funnel shifts -- no LDS, no per-base loop.
+//
+// Key encoding: the reference keys its map by min(w, comp) of 2-bit-packed words.  Only the PARTITION of
+// k-mer occurrences into {k-mer, reverse complement} classes is observable (distinct / total / histogram of
+// counts), so any injective encoding with a consistent class representative yields identical integers.
+// Here enc = plane1 << 32 | plane0 (window bit t = t-th base), rc = reversed planes with plane0 inverted
+// (codes A=0,T=1,C=2,G=3: complement flips bit0, trim.cpp:904-917), key = min(enc, enc_rc).
+#include "faqcs_dev.h"
+
+struct KmerTable {
+    unsigned long long *keys;  // [slots], empty = ~0
+    uint32_t *counts;          // [slots]
+    uint64_t mask;             // slots - 1
+    unsigned long long *stats; // [0] distinct keys, [1] total occurrences, [2] overflow flag
+};
+
+__device__ __forceinline__ uint64_t kmer_mix(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+// bits [p-k+1, p] (p = 64*c + lane) of the bit string whose 64-bit words are ... prev, cur
+__device__ __forceinline__ uint32_t window_bits(uint64_t cur, uint64_t prev, int lane, int k)
+{
+    const int lo = lane - (k - 1); // first bit relative to cur's bit 0 (may be negative: comes from prev)
+    uint64_t w;
+    if (lo >= 0) w = cur >> lo;
+    else w = (cur << (-lo)) | (prev >> (64 + lo));
+    return (uint32_t)(w & ((1ull << k) - 1ull));
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void kmer_count(
+    const DevParams P, const uint32_t k, const KmerTable T, const uint8_t *__restrict__ seq,
+    const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off, const uint32_t r_begin, const uint32_t r_end,
+    const uint2 *__restrict__ results)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * NW;
+    unsigned long long my_total = 0, my_new = 0;
+    bool full = false;
+#pragma unroll 1
+    for (uint32_t r = r_begin + blockIdx.x * NW + wave; r < r_end; r += n_waves) {
+        const uint32_t o = off[r];
+        const int len = (int)(off[r + 1] - o);
+        int a = 0, n = len;
+        if (!P.qc_only) { // trimmed read of a valid record (trim.cpp:545-547); raw read under --qc_only (:260-262)
+            const uint2 res = results[r];
+            if (!(res.y & FAQCS_F_VALID)) continue;
+            a = (int)(res.x & 0xffffu);
+            n = (int)(res.x >> 16);
+        }
+        uint64_t pv = 0, p0 = 0, p1 = 0;
+        const int c_begin = a >> 6, c_end = (a + n + 63) >> 6;
+#pragma unroll 1
+        for (int c = c_begin; c < c_end; ++c) {
+            const int p = c * 64 + lane;
+            const bool in = p >= a && p < a + n;
+            uint32_t b = in ? seq[(size_t)o + p] : 0u;
+            if (in && !P.qc_only && P.replace_q > 0 && b == 'G') { // G -> N precedes k-mer counting (trim.cpp:390-403)
+                int qv = (int)(int8_t)qual[(size_t)o + p] - P.in_off;
+                qv = qv < 0 ? 0 : qv;
+                if (qv < (int)P.replace_q) b = 'N';
+            }
+            const uint32_t l = b | 0x20u;
+            const bool isA = l == 'a', isT = l == 't', isC = l == 'c', isG = l == 'g';
+            const uint64_t cv = __ballot(isA | isT | isC | isG);
+            const uint64_t c0 = __ballot(isT | isG); // codes A=0 T=1 C=2 G=3 (FaQCs.h:35-42)
+            const uint64_t c1 = __ballot(isC | isG);
+            const uint32_t wv = window_bits(cv, pv, lane, (int)k);
+            const uint32_t w0 = window_bits(c0, p0, lane, (int)k);
+            const uint32_t w1 = window_bits(c1, p1, lane, (int)k);
+            pv = cv; p0 = c0; p1 = c1;
+            const uint32_t kmask = (uint32_t)((1ull << k) - 1ull);
+            const bool ok = wv == kmask; // k valid bases ending here (word_len >= k, trim.cpp:924)
+            if (ok) {
+                const uint32_t r0 = __brev(~w0 & kmask) >> (32 - k), r1 = __brev(w1) >> (32 - k);
+                const uint64_t fwd = ((uint64_t)w1 << 32) | w0, rc = ((uint64_t)r1 << 32) | r0;
+                const uint64_t key = fwd < rc ? fwd : rc;
+                uint64_t h = kmer_mix(key) & T.mask;
+                bool done = false;
+#pragma unroll 1
+                for (uint32_t probe = 0; probe < 4096 && !done; ++probe) {
+                    const unsigned long long old = atomicCAS(&T.keys[h], ~0ull, (unsigned long long)key);
+                    if (old == ~0ull) ++my_new;
+                    if (old == ~0ull || old == key) { atomicAdd(&T.counts[h], 1u); done = true; }
+                    else h = (h + 1) & T.mask;
+                }
+                if (done) ++my_total; else full = true;
+            }
+        }
+    }
+    // one atomic per wave for the two rarefaction sums
+    const unsigned long long tot = (unsigned long long)wave_sum_i32((int)my_total);
+    const unsigned long long nw = (unsigned long long)wave_sum_i32((int)my_new);
+    if (lane == 0) {
+        if (nw) atomicAdd(&T.stats[0], nw);
+        if (tot) atomicAdd(&T.stats[1], tot);
+    }
+    if (__any(full) && lane == 0) atomicOr(&T.stats[2], 1ull);
+}
+
+// histogram of counts over the table (FaQCs.cpp:518-521): dense[c] for c < dense_n, (count) list otherwise
+__global__ void kmer_count_histogram(const KmerTable T, unsigned long long *dense, uint32_t dense_n,
+                                     unsigned long long *big, unsigned long long *n_big, uint32_t big_cap)
+{
+    const uint64_t slots = T.mask + 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (T.keys[i] != ~0ull) {
+            const uint32_t c = T.counts[i];
+            if (c < dense_n) atomicAdd(&dense[c], 1ull);
+            else {
+                const unsigned long long s = atomicAdd(n_big, 1ull);
+                if (s < big_cap) big[s] = c;
+            }
+        }
+    }
+}
+
+hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T, const uint8_t *seq, const uint8_t *qual,
+                             const uint32_t *off, uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results,
+                             int n_cu, hipStream_t st)
+{
+    if (r_end <= r_begin) return hipSuccess;
+    constexpr int NW = 4;
+    uint32_t grid = (r_end - r_begin + NW - 1) / NW;
+    const uint32_t cap = (uint32_t)n_cu * 8u;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL((kmer_count<NW>), dim3(grid), dim3(NW * 64), 0, st, P, k, T, seq, qual, off, r_begin, r_end,
+                       reinterpret_cast<const uint2 *>(results));
+    return hipGetLastError();
+}
+
+hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
+                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
+                                       hipStream_t st)
+{
+    hipLaunchKernelGGL(kmer_count_histogram, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap);
+    return hipGetLastError();
+}

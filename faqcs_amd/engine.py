@@ -48,7 +48,7 @@ class HipEngine:
         n = len(offset) - 1
         res = np.zeros(n, dtype=capi.RESULT_DTYPE)
         b = capi.Batch(seq.ctypes.data, qual.ctypes.data, offset.ctypes.data, n, len(segment_start) - 1,
-                       segment_start.ctypes.data)
+                       segment_start.ctypes.data, 0)
         _check(self.lib, self.lib.faqcs_submit(self.ctx, C.byref(b), res.ctypes.data))
         _check(self.lib, self.lib.faqcs_sync(self.ctx))
         return res

@@ -105,6 +105,9 @@ typedef struct faqcs_batch {
     uint32_t        n_reads;
     uint32_t        n_segments;     /* >= 1 when n_reads > 0 */
     const uint32_t *segment_start;  /* n_segments + 1 entries; [0] = 0, [n_segments] = n_reads */
+    uint32_t        max_read_len;   /* upper bound on the read lengths of this batch (selects the kernel
+                                       variant); 0 = unknown: faqcs_submit() scans the offsets,
+                                       faqcs_submit_device() falls back to the context capacity */
 } faqcs_batch;
 
 /* Per-read outcome (8 bytes).  For a valid read the reference's output record is

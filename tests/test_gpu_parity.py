@@ -1,0 +1,234 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+libfaqcs_mi.so, against (1) the committed golden vectors produced by the real reference and (2) the CPU
+oracle on seeded random batches, bit-exact; plus size-independent properties at larger sizes."""
+import numpy as np
+import pytest
+
+from faqcs_amd import _capi as capi
+from faqcs_amd.options import parse_args
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_factory(opt, max_read_length, in_off):
+    from faqcs_amd.engine import HipEngine
+
+    return HipEngine(opt, max_read_length, in_off, kmer_table_slots=1 << 24)
+
+
+def _native_loaded():
+    with open("/proc/self/maps") as f:
+        return "libfaqcs_mi.so" in f.read()
+
+
+def random_batch(rng, n, maxlen, kind):
+    """Ragged random reads exercising every branch: N runs at ends / inside, lower case, low-complexity,
+    adapters, empty and tiny reads, low-quality heads / tails."""
+    import make_fixtures
+
+    reads = []
+    for _ in range(n):
+        if kind == "adv":
+            s, q = make_fixtures._adv_read(rng, maxlen)
+        else:
+            L = int(rng.integers(0, maxlen + 1))
+            s = np.frombuffer(b"ACGTNacgtnRY", np.uint8)[rng.choice(12, L, p=[.22, .22, .22, .22, .04, .02, .02, .01, .01, .005, .0025, .0025])].copy()
+            q = (rng.integers(0, 42, L) + 33).astype(np.uint8)
+            if L and rng.random() < 0.5:
+                cut = int(rng.integers(0, L))
+                q[cut:] = 33 + rng.integers(0, 6, L - cut)
+        reads.append((b"@x", s.tobytes(), q.tobytes()))
+    return reads
+
+
+def compare_engines(opt, reads, R=256, in_off=33, seg_size=None):
+    from oracle_engine import OracleEngine
+
+    from faqcs_amd import driver
+
+    seg_size = seg_size or len(reads)
+    bufs = [reads[i:i + seg_size] for i in range(0, len(reads), seg_size)] or [[]]
+    seq, qual, offset, seg = driver.pack_segments(bufs)
+    hip = hip_factory(opt, R, in_off)
+    ora = OracleEngine(opt, R, in_off)
+    r1 = hip.process(seq, qual, offset, seg)
+    r2 = ora.process(seq, qual, offset, seg)
+    bad = np.nonzero(r1 != r2)[0]
+    assert len(bad) == 0, "first differing read %d: hip=%s oracle=%s seq=%r qual=%r" % (
+        bad[0], r1[bad[0]], r2[bad[0]], reads[bad[0]][1], reads[bad[0]][2])
+    c1, c2 = hip.counters(), ora.counters()
+    if not (c1 == c2).all():
+        lay = capi.python_layout(R, hip.holder.n_adapters)
+        k = int(np.nonzero(c1 != c2)[0][0])
+        name = [nm for nm, v in lay.items() if nm != "total" and v[0] <= k < v[0] + v[1]][0]
+        raise AssertionError("counter block differs in %s[%d]: hip=%d oracle=%d" % (name, k - lay[name][0], c1[k], c2[k]))
+    assert _native_loaded()
+    return hip, ora
+
+
+OPTION_SETS = [
+    [],
+    ["--mode", "BWA"],
+    ["--mode", "HARD", "-q", "10"],
+    ["--mode", "HARD", "-q", "10", "--5trim_off"],
+    ["--5trim_off"],
+    ["-q", "20", "--min_L", "30"],
+    ["-q", "0", "--min_L", "1"],
+    ["-q", "41"],
+    ["--5end", "3", "--3end", "5"],
+    ["--5end", "60", "--3end", "100", "--min_L", "10"],
+    ["--avg_q", "25"],
+    ["--avg_q", "12.5", "-n", "1"],
+    ["-n", "0"],
+    ["-n", "3"],
+    ["-n", "7", "--min_L", "5"],
+    ["--lc", "0.5"],
+    ["--lc", "0.2", "--min_L", "5"],
+    ["--lc", "1.0"],
+    ["--replace_to_N_q", "15"],
+    ["--replace_to_N_q", "30", "--lc", "0.4", "-n", "4"],
+    ["--out_ascii", "64"],
+    ["--qc_only"],
+    ["--adapter"],
+    ["--adapter", "--polyA"],
+    ["--adapter", "--polyA", "--rate", "0.3", "--qc_only"],
+    ["--adapter", "--5end", "4", "--3end", "2", "--min_L", "20"],
+]
+
+
+@pytest.mark.parametrize("args", OPTION_SETS, ids=lambda a: " ".join(a) or "default")
+@pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 64), ("ragged", 250), ("adv", 100)])
+def test_random_batches_match_oracle(args, kind, maxlen):
+    rng = np.random.Generator(np.random.PCG64(hash((kind, maxlen, len(args))) & 0xffff))
+    opt = parse_args(["-u", "x", "-d", "y"] + args)
+    n = 700 if "--adapter" in args else 3000
+    reads = random_batch(rng, n, maxlen, kind)
+    compare_engines(opt, reads, seg_size=517)  # ragged segments: tail groups of the adapter pre-pass
+
+
+def test_edge_reads():
+    opt = parse_args(["-u", "x", "-d", "y", "--min_L", "1", "--adapter", "--polyA"])
+    Q = lambda s: bytes([33 + c for c in s])  # noqa: E731
+    reads = [
+        (b"@e", b"", b""),
+        (b"@e", b"A", Q([40])),
+        (b"@e", b"N", Q([40])),
+        (b"@e", b"NN", Q([40, 40])),
+        (b"@e", b"NNNNNNNNNN", Q([30] * 10)),
+        (b"@e", b"ACGT", Q([2, 2, 2, 2])),
+        (b"@e", b"ACGTA", Q([41, 0, 41, 0, 41])),
+        (b"@e", b"ACGTAC", Q([0, 0, 0, 41, 41, 41])),
+        (b"@e", b"A" * 150, Q([38] * 150)),
+        (b"@e", b"AT" * 75, Q([38] * 150)),
+        (b"@e", b"ACG" * 50, Q([38] * 150)),
+        (b"@e", b"G" * 150, Q([38] * 150)),
+        (b"@e", b"N" + b"ACGT" * 37 + b"N", Q([38] * 150)),
+        (b"@e", b"acgtn" * 30, Q([38] * 150)),
+        (b"@e", (b"ACGT" * 64)[:250], Q([38] * 250)),
+        (b"@e", (b"ACGT" * 64), Q(([38] * 200) + [2] * 56)),
+    ]
+    for k in range(1, 12):
+        reads.append((b"@e", (b"ACGGTCA" * 3)[:k], Q([2 + 3 * (i % 7) for i in range(k)])))
+    compare_engines(opt, reads)
+
+
+def test_quality_error_is_reported():
+    from faqcs_amd.engine import FaqcsError
+
+    opt = parse_args(["-u", "x", "-d", "y"])
+    reads = [(b"@e", b"ACGT" * 10, bytes([33 + 30] * 39 + [33 + 42]))]
+    with pytest.raises(FaqcsError) as ei:
+        compare_engines(opt, reads)
+    assert ei.value.code == capi.E_QUALITY
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").case_names())
+def test_golden_cases_on_gpu(name, fixture_cache, tmp_path):
+    """The reference's own outputs (QC.stats.txt, trimmed FASTQ, --debug tables) reproduced by the HIP path."""
+    from golden_util import load_case, run_case
+
+    bad = run_case(load_case(name), fixture_cache, tmp_path, hip_factory, max_read_length=512)
+    assert not bad, "\n".join(bad)
+    assert _native_loaded()
+
+
+def test_kmer_matches_oracle():
+    rng = np.random.Generator(np.random.PCG64(99))
+    import make_fixtures
+
+    for args in (["--kmer_rarefaction", "--split_size", "300"], ["--kmer_rarefaction", "--split_size", "400", "--qc_only", "--subset", "2"],
+                 ["--kmer_rarefaction", "--split_size", "250", "-m", "5", "--replace_to_N_q", "20"]):
+        opt = parse_args(["-u", "x", "-d", "y"] + args)
+        reads = random_batch(rng, 2500, 150, "adv")
+        hip, ora = compare_engines(opt, reads, seg_size=333)
+        hip.kmer_end_table()
+        ora.kmer_end_table()
+        assert (hip.kmer_points() == ora.kmer_points()).all()
+        h1, h2 = hip.kmer_histogram(), ora.kmer_histogram()
+        assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] shape at a size the oracle cannot follow: size-independent invariants of the
+    counter block, device-resident submission == host submission, and idempotence of trimming."""
+    import ctypes as C
+
+    import torch
+
+    from faqcs_amd.engine import HipEngine, _check
+
+    n, L = 4_000_000, 150
+    opt = parse_args(["-u", "x", "-d", "y", "--ascii", "33"])
+    eng = HipEngine(opt, 256, 33, device=0)
+    lib = eng.lib
+    dev = torch.device("cuda:0")
+    seq = torch.empty(n * L + 64, dtype=torch.uint8, device=dev)
+    qual = torch.empty(n * L + 64, dtype=torch.uint8, device=dev)
+    off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    res = torch.empty((n, 4), dtype=torch.int16, device=dev)
+    _check(lib, lib.faqcs_synth_fill(0, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), n, L, 20260101, 0, 0.0))
+    seg = np.array([0, n], dtype=np.uint32)
+    b = capi.Batch(seq.data_ptr(), qual.data_ptr(), off.data_ptr(), n, 1, seg.ctypes.data, L)
+    _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(b), res.data_ptr()))
+    blk = eng.counters()
+    lay = capi.python_layout(256, 0)
+    V = lambda name: blk[lay[name][0]:lay[name][0] + lay[name][1]]  # noqa: E731
+    fs = V("filter_stats")
+    assert fs[capi.TOTAL_NUMBER] == n and fs[capi.TOTAL_LENGTH] == n * L
+    assert V("pre_len_hist")[L] == n and V("pre_len_hist").sum() == n
+    pq = V("pre_qual").reshape(256, 42)
+    assert (pq[:L].sum(axis=1) == n).all() and pq[L:].sum() == 0
+    assert V("pre_read_qhist").sum() == n and V("pre_base_qhist").sum() == n * L
+    r = res.cpu().numpy().view(np.uint16)
+    valid = (r[:, 2] & 1) != 0
+    assert fs[capi.TOTAL_TRIMMED_NUMBER] == valid.sum()
+    assert fs[capi.TOTAL_TRIMMED_LENGTH] == r[valid, 1].astype(np.int64).sum()
+    assert V("post_len_hist").sum() == valid.sum()
+    assert V("post_qual").sum() == fs[capi.TOTAL_TRIMMED_LENGTH]
+    discarded = n - int(valid.sum())
+    assert discarded == fs[capi.READ_LENGTH] + fs[capi.READ_NN] + fs[capi.READ_LOW_COMPLEXITY] + fs[capi.READ_AVG_Q]
+    comp = V("pre_comp").reshape(-1, 6)
+    assert (comp.sum(axis=0) == n).all()
+    # host submission of a slice must equal the oracle AND the device-resident result for the same reads
+    m = 20000
+    hs = np.concatenate([seq[: m * L + 64].cpu().numpy()])
+    hq = np.concatenate([qual[: m * L + 64].cpu().numpy()])
+    ho = off[: m + 1].cpu().numpy().view(np.uint32)
+    from oracle_engine import OracleEngine
+
+    ora = OracleEngine(opt, 256, 33)
+    r2 = ora.process(hs, hq, ho, np.array([0, m], dtype=np.uint32))
+    assert (r[:m].view(capi.RESULT_DTYPE).ravel() == r2).all()
+    # linearity: the counter block is additive over any split of the reads (what the multi-GPU all-reduce
+    # relies on) and per-read results do not depend on how a batch is cut
+    eng2 = HipEngine(opt, 256, 33, device=0)
+    res2 = torch.empty((n, 4), dtype=torch.int16, device=dev)
+    cut = 1_234_567
+    off_b = off[cut:]
+    for lo_, hi_, o_ptr, r_ptr in ((0, cut, off.data_ptr(), res2.data_ptr()),
+                                   (cut, n, off_b.data_ptr(), res2[cut:].data_ptr())):
+        sg = np.array([0, hi_ - lo_], dtype=np.uint32)
+        bb = capi.Batch(seq.data_ptr(), qual.data_ptr(), o_ptr, hi_ - lo_, 1, sg.ctypes.data, L)
+        _check(lib, lib.faqcs_submit_device(eng2.ctx, C.byref(bb), r_ptr))
+    assert (eng2.counters() == blk).all()
+    assert bool((res2 == res).all())
