@@ -32,7 +32,10 @@ struct KmerTable {
 };
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
-                             faqcs_read_result *out, uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st);
+                             faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
+                             uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st);
+hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, const float *comp_norm, uint64_t *dst,
+                                    int n_cu, hipStream_t st);
 hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
                                 uint32_t max_len, const uint32_t *seg_start, uint32_t n_segments, uint32_t *ad_sl,
                                 uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, int n_cu, hipStream_t st);
@@ -84,10 +87,9 @@ struct faqcs_ctx {
     DevParams dp;
     faqcs_layout lay;
     // device tables
-    uint16_t *d_mono = nullptr, *d_di = nullptr;
-    uint32_t *d_avgq = nullptr;
+    uint32_t *d_lcthr = nullptr, *d_magic = nullptr, *d_basetab = nullptr;
+    int32_t *d_avgq = nullptr;
     float *d_norm = nullptr;
-    uint64_t *d_magic = nullptr;
     uint64_t *d_counters = nullptr;
     uint32_t *d_err = nullptr;
     // adapters
@@ -100,6 +102,7 @@ struct faqcs_ctx {
     DevBuf<uint32_t> s_off, s_seg, s_sl;
     DevBuf<uint16_t> s_hit;
     DevBuf<faqcs_read_result> s_res;
+    DevBuf<unsigned long long> s_rec_pre, s_rec_post; // per-read composition records (trim kernel -> composition_histogram)
     // rarefaction state (trim.cpp:157-185): host-deterministic from read counts, values filled from the device
     uint64_t total_number = 0;
     int kmer_active = 0;
@@ -205,33 +208,46 @@ static uint8_t na_to_bits_host(char c)
     return 0;
 }
 
-static void build_tables(const faqcs_params &p, std::vector<uint16_t> &mono, std::vector<uint16_t> &di,
-                         std::vector<uint32_t> &avgq, std::vector<float> &norm, std::vector<uint64_t> &magic)
+static void build_tables(const faqcs_params &p, std::vector<uint32_t> &lcthr, std::vector<int32_t> &avgq,
+                         std::vector<float> &norm, std::vector<uint32_t> &magic, std::vector<uint32_t> &base)
 {
     const int N = FAQCS_TAB_LEN + 1;
-    mono.assign(N, 0xffff); di.assign(N, 0xffff); avgq.assign(N, 0); norm.assign(N, 0.f); magic.assign(N, 0);
+    lcthr.assign(N, 0xffffffffu); avgq.assign(N, 0); norm.assign(512, 0.f); magic.assign(N, 0);
     const volatile float lc = p.low_complexity_cutoff_ratio;
     const volatile float avg = p.average_quality;
     for (int len = 1; len < N; ++len) {
+        uint32_t mono = 0xffff, di = 0xffff;
         volatile float nrm = (float)(1.0 / (double)len);                 // trim.cpp:483
-        for (int c = 0; c <= len; ++c) { volatile float v = (float)(unsigned)c * nrm; if (v > lc) { mono[len] = (uint16_t)c; break; } }
+        for (int c = 0; c <= len; ++c) { volatile float v = (float)(unsigned)c * nrm; if (v > lc) { mono = (uint32_t)c; break; } }
         volatile float nrm2 = (float)((double)nrm * 2.0);                // trim.cpp:499
-        for (int c = 0; c <= len; ++c) { volatile float v = (float)(unsigned)c * nrm2; if (v > lc) { di[len] = (uint16_t)c; break; } }
+        for (int c = 0; c <= len; ++c) { volatile float v = (float)(unsigned)c * nrm2; if (v > lc) { di = (uint32_t)c; break; } }
+        lcthr[len] = mono | (di << 16);
         norm[len] = (float)(FAQCS_NCOMP_BIN - 1) / (float)len;           // trim.cpp:860
-        magic[len] = ((1ull << 44) + (uint64_t)len - 1) / (uint64_t)len;
+        magic[len] = (uint32_t)((1ull << 32) / (uint64_t)len) + 1u;      // exact floor(V/len) for V < 2^16, len >= 2
         if (avg > 0.0f) {
-            // smallest biased sum S_b = sum(raw + 128) for which NOT(ave_Q < avg); ave_Q per trim.cpp:568-572
-            auto pass = [&](uint32_t sb) {
-                volatile float t = (float)((int)sb - 128 * len) / (float)len;
+            // smallest V = sum(raw - offset) >= 0 for which NOT(ave_Q < avg); ave_Q per trim.cpp:568-572.
+            // (V < 0 gives ave_Q = 0 < avg, and V < table[len] is then true as well.)
+            auto pass = [&](int V) {
+                volatile float t = (float)(V + p.input_quality_offset * len) / (float)len;
                 volatile float v = t - (float)p.input_quality_offset;
                 const float a = v > 0.0f ? v : 0.0f;
                 return !(a < avg);
             };
-            uint32_t lo = 0, hi = 256u * (uint32_t)len; // pass(hi) may still be false -> UINT32_MAX
-            if (!pass(hi)) avgq[len] = 0xffffffffu;
-            else { while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pass(mid)) hi = mid; else lo = mid + 1; } avgq[len] = lo; }
+            int lo = 0, hi = 256 * len;
+            if (!pass(hi)) avgq[len] = 0x7fffffff;
+            else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (pass(mid)) hi = mid; else lo = mid + 1; } avgq[len] = lo; }
         }
     }
+    // per input byte: 6-bit count fields in FaQCs enum order A,T,C,G,N (FaQCs.h:35-42), case-insensitive like
+    // update_base_statistics (trim.cpp:831-857); flag bits for the case-sensitive tests (trim.cpp:396,586,1196)
+    base.assign(256, 0u);
+    const char *letters = "ATCGN";
+    for (int k = 0; k < 5; ++k) {
+        base[(unsigned char)letters[k]] = 1u << BT_SHIFT(k);
+        base[(unsigned char)(letters[k] | 0x20)] = 1u << BT_SHIFT(k);
+    }
+    base['N'] |= BT_IS_NU;
+    base['G'] |= BT_IS_GU;
 }
 
 template <class T> static hipError_t upload(T **dst, const std::vector<T> &v)
@@ -269,10 +285,10 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     HIPCHK(hipEventCreateWithFlags(&c->copied, hipEventDisableTiming));
     faqcs_counters_layout(p->max_read_length, p->n_adapters, &c->lay);
 
-    std::vector<uint16_t> mono, di; std::vector<uint32_t> avgq; std::vector<float> norm; std::vector<uint64_t> magic;
-    build_tables(*p, mono, di, avgq, norm, magic);
-    HIPCHK(upload(&c->d_mono, mono)); HIPCHK(upload(&c->d_di, di)); HIPCHK(upload(&c->d_avgq, avgq));
-    HIPCHK(upload(&c->d_norm, norm)); HIPCHK(upload(&c->d_magic, magic));
+    std::vector<uint32_t> lcthr, magic, basetab; std::vector<int32_t> avgq; std::vector<float> norm;
+    build_tables(*p, lcthr, avgq, norm, magic, basetab);
+    HIPCHK(upload(&c->d_lcthr, lcthr)); HIPCHK(upload(&c->d_avgq, avgq)); HIPCHK(upload(&c->d_norm, norm));
+    HIPCHK(upload(&c->d_magic, magic)); HIPCHK(upload(&c->d_basetab, basetab));
     HIPCHK(hipMalloc((void **)&c->d_counters, c->lay.total * sizeof(uint64_t)));
     HIPCHK(hipMemset(c->d_counters, 0, c->lay.total * sizeof(uint64_t)));
     HIPCHK(hipMalloc((void **)&c->d_err, 64));
@@ -303,7 +319,8 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     d.replace_q = p->replace_to_N_q; d.protect5 = p->protect_5; d.qc_only = p->qc_only;
     d.has_adapters = p->n_adapters ? 1 : 0; d.avgq_on = p->average_quality > 0.0f ? 1 : 0;
     d.R = p->max_read_length; d.n_adapters = p->n_adapters;
-    d.mono_thr = c->d_mono; d.di_thr = c->d_di; d.avgq_min_sum = c->d_avgq; d.comp_norm = c->d_norm; d.div_magic = c->d_magic;
+    if (const char *e = getenv("FAQCS_DBG")) d.dbg = (uint32_t)strtoul(e, nullptr, 0);
+    d.lc_thr = c->d_lcthr; d.avgq_min_v = c->d_avgq; d.comp_norm = c->d_norm; d.div_magic = c->d_magic; d.base_tab = c->d_basetab;
     d.lay = c->lay;
 
     c->kmer_active = p->kmer_rarefaction ? 1 : 0;
@@ -331,10 +348,11 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->compute) (void)hipStreamSynchronize(c->compute);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    void *ptrs[] = {c->d_mono, c->d_di, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart,
+    void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart,
                     c->kt.keys, c->kt.counts, c->kt.stats, c->d_snaps};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     c->s_seq.release(); c->s_qual.release(); c->s_off.release(); c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
+    c->s_rec_pre.release(); c->s_rec_post.release();
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -373,8 +391,14 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         }
         Timing &t = c->timings[c->timing_used++];
         HIPCHK(hipEventRecord(t.a, c->compute));
-        HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, c->d_counters, c->d_err, c->n_cu, c->compute));
+        HIPCHK(c->s_rec_pre.reserve(n)); HIPCHK(c->s_rec_post.reserve(n));
+        HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, c->s_rec_pre.p, c->s_rec_post.p,
+                                 c->d_counters, c->d_err, c->n_cu, c->compute));
         HIPCHK(hipEventRecord(t.b, c->compute));
+        if (!(c->dp.dbg & 1u)) {
+            HIPCHK(faqcs_launch_composition(c->s_rec_pre.p, n, c->d_norm, c->d_counters + c->lay.pre_comp, c->n_cu, c->compute));
+            HIPCHK(faqcs_launch_composition(c->s_rec_post.p, n, c->d_norm, c->d_counters + c->lay.post_comp, c->n_cu, c->compute));
+        }
     }
     // ---- rarefaction bookkeeping per reference trim() call (trim.cpp:157-185) -------------------------------
     for (uint32_t s = 0; s < n_seg; ++s) {

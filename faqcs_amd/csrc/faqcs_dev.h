@@ -6,6 +6,7 @@
 //   adapter_sl      u32[n]   (only with adapters) : first | second << 16  (Read::start_length, FaQCs.h:154)
 //   adapter_hit     u16[n]   1 + credited adapter index
 //   result          faqcs_read_result[n]  (8 B)
+//   comp_pre/post   u64[n]   per-read composition record: valid<<63 | len | nA<<9 | nT<<18 | nC<<27 | nG<<36 | nN<<45
 //   counters        u64[layout.total]     additive block (include/faqcs_mi.h faqcs_layout)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -14,7 +15,7 @@
 #include "../../include/faqcs_mi.h"
 
 #define FAQCS_WAVE 64
-#define FAQCS_TAB_LEN 4096 /* per-length lookup tables cover every supported read length */
+#define FAQCS_TAB_LEN 256 /* per-length lookup tables: every length the row kernels support */
 
 // Everything the kernels need from faqcs_params + host-precomputed integer lookup tables, passed by value.
 struct DevParams {
@@ -23,30 +24,36 @@ struct DevParams {
     uint32_t protect5, qc_only, has_adapters, avgq_on;
     uint32_t R;                   // row capacity of the global matrices
     uint32_t n_adapters;
+    uint32_t dbg;                 // FAQCS_DBG ablation bits (diagnostics only; 0 in production)
     // per-length tables, index 0..FAQCS_TAB_LEN (float32 semantics folded into integers on the host)
-    const uint16_t *mono_thr;     // min base count that trips `count*float(1.0/len) > lc`        (trim.cpp:483-488)
-    const uint16_t *di_thr;       // min transition count that trips `dc*(norm*2) > lc`             (trim.cpp:499-503)
-    const uint32_t *avgq_min_sum; // min biased quality sum with NOT(ave_Q < --avg_q)               (trim.cpp:376)
-    const float    *comp_norm;    // float(10000)/len                                               (trim.cpp:860)
-    const uint64_t *div_magic;    // ceil(2^44/len): floor(S/len) == (S*magic)>>44 for S < 2^20.. (trim.cpp:572 int())
+    const uint32_t *lc_thr;       // lo16: min base count that trips `count*float(1.0/len) > lc` (trim.cpp:483-488)
+                                  // hi16: min transition count that trips `dc*(norm*2) > lc`     (trim.cpp:499-503)
+    const int32_t  *avgq_min_v;   // min V = sum(raw - offset) with NOT(ave_Q < --avg_q)          (trim.cpp:376)
+    const uint32_t *div_magic;    // floor(2^32/len)+1: floor(V/len) == mulhi(V, magic), V < 2^16 (trim.cpp:254,539 int())
+    const float    *comp_norm;    // float(10000)/len                                             (trim.cpp:860)
+    const uint32_t *base_tab;     // [256] per input byte: 6-bit count fields A,T,C,G,N | isN<<30 | isG<<31
     faqcs_layout lay;
 };
 
-// per-wave filter-stat accumulators kept in LDS per block, flushed with one global atomic each
 enum { FS_SLOTS = 32 };
 
-// composition / small-histogram updates go through an LDS hash table: key = slot | bin << 5
-enum {
-    HS_PRE_COMP = 0,   // +kind (0..5)   bin = composition bin
-    HS_POST_COMP = 6,  // +kind
-    HS_PRE_LEN = 12, HS_POST_LEN = 13, HS_PRE_RQ = 14, HS_POST_RQ = 15, HS_PRE_BQ = 16, HS_POST_BQ = 17,
-    HS_NSLOT = 18
-};
-#define HS_EMPTY 0xffffffffu
+// base_tab fields (6 bits each so a lane can sum up to 63 reads before flushing)
+#define BT_SHIFT(code) (6 * (code))
+#define BT_FIELDS 0x3fffffffu
+#define BT_IS_NU (1u << 30) /* upper-case 'N' exactly (count_poly_n / terminal-N masking are case sensitive) */
+#define BT_IS_GU (1u << 31) /* upper-case 'G' exactly (--replace_to_N_q) */
+
+// composition record
+#define CR_VALID (1ull << 63)
 
 #ifdef __HIPCC__
-// ---- wave64 primitives on DPP (no LDS traffic) ---------------------------------------------------------
-#define FAQCS_DPP(op, v, ctrl, rm) op(v, __builtin_amdgcn_update_dpp(0, v, ctrl, rm, 0xf, false))
+// ---- DPP primitives ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// full-wave (64 lanes)
 __device__ __forceinline__ int wave_incl_scan_add(int v)
 {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
@@ -57,8 +64,6 @@ __device__ __forceinline__ int wave_incl_scan_add(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31
     return v;
 }
-__device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
-// max over the wave of an unsigned key (identity 0); result is wave-uniform
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
     v = umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
@@ -70,6 +75,31 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_add(v), 63); }
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// 16-lane rows: every lane of a row ends up with the row's result (butterfly: xor1, xor2, half-mirror, mirror)
+#define FAQCS_ROW_ALL(OP)                                                              \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));                \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));                \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));               \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+__device__ __forceinline__ int op_add_(int a, int b) { return a + b; }
+__device__ __forceinline__ int op_or_(int a, int b) { return a | b; }
+__device__ __forceinline__ int op_umax_(int a, int b) { return (int)umax_((uint32_t)a, (uint32_t)b); }
+__device__ __forceinline__ int op_imax_(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int row_all_sum(int v) { FAQCS_ROW_ALL(op_add_) return v; }
+__device__ __forceinline__ uint32_t row_all_or(uint32_t x) { int v = (int)x; FAQCS_ROW_ALL(op_or_) return (uint32_t)v; }
+__device__ __forceinline__ uint32_t row_all_umax(uint32_t x) { int v = (int)x; FAQCS_ROW_ALL(op_umax_) return (uint32_t)v; }
+__device__ __forceinline__ int row_all_imax(int v) { FAQCS_ROW_ALL(op_imax_) return v; }
+// inclusive prefix sum inside each row of 16 lanes
+__device__ __forceinline__ int row_incl_scan_add(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    return v;
+}
+// value of the next / previous lane of the same row (0 at the row edge)
+__device__ __forceinline__ uint32_t row_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t row_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); }
 #endif

@@ -1,21 +1,32 @@
-// faqcs_trim_kernel.hip -- trim_filter_accumulate: the fused per-read kernel (gfx950, wave64).
+// faqcs_trim_kernel.hip -- trim_filter_accumulate + composition_histogram (gfx950, wave64).
 //
 // Replaces trim_read() and its helpers (trim.cpp:225-551, :553-597, :629-885, :1191-1216) for every read
-// of a batch.  One wavefront owns one read at a time; lane l owns the C consecutive positions
-// [l*C, l*C+C) (C = ceil(max_len/64) <= 4), fetched with ONE unaligned dword load per arena.  Everything
-// per-read is then either
-//   * a per-lane byte op (C-way unrolled),
-//   * a 64-bit ballot (v_cmp -> SGPR pair) + scalar bit logic / popcount, or
-//   * one DPP prefix scan / max-reduce (6 v_*_dpp, no LDS).
-// The BWA_plus sequential state machine (trim.cpp:714-793) is evaluated in closed form from ONE prefix
-// sum of (Q - q[i]) -- see bwa_plus() below and SURVEY.md section 8 a-5.
+// of a batch.
 //
-// Accumulators: position x quality and position x base matrices live in LDS, pre- and post-trim counts
-// packed in the low / high 16 bits of one dword so a position costs ONE ds_add for both (the post-trim
-// quality of a kept base equals its pre-trim quality: trim.cpp:516-533).  Column = j*64 + lane, so the 32
-// lanes of a half-wave always hit 32 different banks.  Sparse accumulators (composition bins, length and
-// average-quality histograms) go through a small LDS hash table.  A block flushes to the global u64 block
-// with atomics before any 16-bit field can overflow (every <= 65535 reads per block).
+// Mapping.  A wavefront is FOUR DPP rows of 16 lanes; each row owns one read at a time (4 reads per wave in
+// flight) and lane l of a row owns the C consecutive positions [l*C, l*C+C), C = ceil(max_len/16) (10 for
+// 150 bp, 16 for 250 bp), fetched with ONE unaligned global_load_dwordx{D} per arena.  Every per-read
+// scalar (length, window, cut points, filter decision) is a row-uniform VGPR value: there are no ballots
+// and no scalar-ALU bit logic in the loop (round-1 profiling showed the ballot formulation was SALU-bound
+// at ~900 scalar instructions per read).  Cross-lane work is DPP only: row_shr prefix scans and
+// quad_perm/row_mirror butterflies, 4 instructions each and shared by the 4 reads of the wave.
+//
+// BWA_plus (trim.cpp:714-793) in closed form from ONE prefix sum P of (Q - q[i]) over the window
+// (SURVEY.md section 8 a-5):
+//   3' pass: reset[i] = (i > 2) & (T - Pin[i] >= 0); the walk stops at the first i (descending) with
+//            !reset[i] & !reset[i+1] & reset[i+2] (or after min(5,n) steps if no reset occurs in them);
+//            final_pos_3 = argmax_{visited i} (T - Pex[i]) (largest i on ties, only if > 0) - 1
+//   5' pass: mirror image with reset[i] = (i < final_pos_3 - 2) & (Pex[i] >= 0) and argmax of Pin[i].
+//
+// Accumulators.  position x quality: LDS [42][W] dwords, pre-trim count in the low and post-trim count in
+// the high 16 bits so a base costs ONE ds_add for both (the post-trim quality of a kept base equals its
+// pre-trim quality, trim.cpp:516-533).  position x base: a lane always owns the same positions, so the
+// matrix is privatised in REGISTERS (6-bit fields A,T,C,G,N per position, one v_add per base) and spilled
+// to LDS every 48 reads.  Length / average-quality histograms are small dense LDS arrays.  Composition
+// bins (10 001 x 6, sparse and data dependent) are NOT accumulated here: the kernel emits one 8-byte record
+// per read (length + 5 base counts, pre and post) and composition_histogram folds the records with the
+// whole LDS as a 16-bit table.  A block flushes LDS to the global u64 block with atomics before a 16-bit
+// field can overflow (every <= 65 535 reads per block).
 //
 // Float semantics of the reference are folded into integer lookup tables built on the host
 // (DevParams); the only float op left is the composition-bin multiply, an exact IEEE v_mul_f32.
@@ -23,416 +34,360 @@
 
 namespace {
 
-constexpr int KEY_BIAS = 1 << 16; // |sum of (Q - q)| <= 256 * 168 < 2^16 for C <= 4
+constexpr int KEY_BIAS = 1 << 16; // |sum of (Q - q)| <= 256 * 168 < 2^16
 
-template <int C> struct TrimCfg {
-    static constexpr int W = 64 * C;          // columns of the LDS matrices
-    static constexpr int HQ = FAQCS_NQ * W;   // dwords
+template <int C> struct RowCfg {
+    static constexpr int D = (C + 3) / 4;          // dwords per lane per arena
+    static constexpr int W = 16 * C;               // positions covered by a row == columns of the LDS matrices
+    static constexpr int HQ = FAQCS_NQ * W;
     static constexpr int HB = FAQCS_NBASE * W;
+    static constexpr int O_HQ = 0;
+    static constexpr int O_HB = O_HQ + HQ;
+    static constexpr int O_LEN = O_HB + HB;        // [W+1] lo16 pre / hi16 post
+    static constexpr int O_RQ = O_LEN + W + 2;     // [42]  lo16 pre / hi16 post
+    static constexpr int O_BQPRE = O_RQ + 42;      // [42]
+    static constexpr int O_BQPOST = O_BQPRE + 42;  // [42]
+    static constexpr int O_FS = O_BQPOST + 42;     // [32]
+    static constexpr int N_ZERO = O_FS + FS_SLOTS; // everything above is zero-initialised and flushed
+    static constexpr int O_TBASE = N_ZERO;         // [256] base table
+    static constexpr int O_TLC = O_TBASE + 256;    // [W+1]
+    static constexpr int O_TAVGQ = O_TLC + W + 1;  // [W+1]
+    static constexpr int O_TMAGIC = O_TAVGQ + W + 1;
+    static constexpr int LDS_DWORDS = O_TMAGIC + W + 1;
 };
 
-// position p+m seen from slot j of the same lane: returns the ballot word whose bit l answers "mask at
-// position (l*C+j)+m".  m in {1,2} (next) ; implemented per call site with compile-time j.
-template <int C, int M> __device__ __forceinline__ uint64_t next_mask(const uint64_t (&R)[C], int j)
-{
-    const int jj = (j + M) % C, sh = (j + M) / C;
-    return R[jj] >> sh;
-}
-template <int C, int M> __device__ __forceinline__ uint64_t prev_mask(const uint64_t (&R)[C], int j)
-{
-    // position p-M: slot (j-M) mod C, lane shift = ceil((M-j)/C) when j < M
-    const int t = j - M;
-    const int jj = ((t % C) + C) % C;
-    const int sh = t >= 0 ? 0 : (-t + C - 1) / C;
-    return R[jj] << sh;
-}
+template <int D> struct __attribute__((packed, aligned(1))) PackedBytes { uint32_t w[D]; };
 
-template <int C> __device__ __forceinline__ int hi_pos(const uint64_t (&R)[C])
-{ // highest position with a set bit, -1 if none
-    int best = -1;
-#pragma unroll
-    for (int j = 0; j < C; ++j)
-        if (R[j]) { const int p = (63 - __builtin_clzll(R[j])) * C + j; best = p > best ? p : best; }
-    return best;
-}
-template <int C> __device__ __forceinline__ int lo_pos(const uint64_t (&R)[C])
-{ // lowest position with a set bit, INT_MAX if none
-    int best = 0x7fffffff;
-#pragma unroll
-    for (int j = 0; j < C; ++j)
-        if (R[j]) { const int p = __builtin_ctzll(R[j]) * C + j; best = p < best ? p : best; }
-    return best;
-}
-template <int C> __device__ __forceinline__ bool any_mask(const uint64_t (&R)[C])
-{
-    uint64_t o = 0;
-#pragma unroll
-    for (int j = 0; j < C; ++j) o |= R[j];
-    return o != 0;
-}
-template <int C> __device__ __forceinline__ int pop_mask(const uint64_t (&R)[C])
-{
-    int c = 0;
-#pragma unroll
-    for (int j = 0; j < C; ++j) c += __popcll(R[j]);
-    return c;
-}
+__device__ __forceinline__ int med3i(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-__device__ __forceinline__ void hash_add(uint32_t *hkey, uint32_t *hval, int hsize_mask, uint32_t key, uint32_t val,
-                                         const DevParams &P, uint64_t *counters);
-
-__device__ __forceinline__ uint64_t *hs_dest(const DevParams &P, uint64_t *ctr, uint32_t slot, uint32_t bin)
+// bits j in [0, C) with lo <= pbase + j < hi
+template <int C> __device__ __forceinline__ uint32_t range_mask(int lo, int hi, int pbase)
 {
-    const faqcs_layout &L = P.lay;
-    if (slot < 6) return ctr + L.pre_comp + (uint64_t)bin * FAQCS_NCOMP_KIND + slot;
-    if (slot < 12) return ctr + L.post_comp + (uint64_t)bin * FAQCS_NCOMP_KIND + (slot - 6);
-    switch (slot) {
-    case HS_PRE_LEN: return ctr + L.pre_len_hist + bin;
-    case HS_POST_LEN: return ctr + L.post_len_hist + bin;
-    case HS_PRE_RQ: return ctr + L.pre_read_qhist + bin;
-    case HS_POST_RQ: return ctr + L.post_read_qhist + bin;
-    case HS_PRE_BQ: return ctr + L.pre_base_qhist + bin;
-    default: return ctr + L.post_base_qhist + bin;
-    }
+    const int s = med3i(lo - pbase, 0, C);
+    int e = med3i(hi - pbase, 0, C);
+    e = e > s ? e : s;
+    return ((1u << (e - s)) - 1u) << s;
 }
-
-// insert (key -> += val) into the block's LDS hash table; falls through to a global atomic when the
-// probe sequence is exhausted (table full of other keys)
-__device__ __forceinline__ void hash_add(uint32_t *hkey, uint32_t *hval, int hmask, uint32_t key, uint32_t val,
-                                         const DevParams &P, uint64_t *counters)
-{
-    uint32_t h = (key * 2654435761u) >> 16;
-    bool done = false;
-#pragma unroll 1
-    for (int probe = 0; probe < 8 && !done; ++probe) {
-        const uint32_t s = (h + probe) & hmask;
-        const uint32_t old = atomicCAS(&hkey[s], HS_EMPTY, key);
-        if (old == HS_EMPTY || old == key) { atomicAdd(&hval[s], val); done = true; }
-    }
-    if (!done) atomicAdd((unsigned long long *)hs_dest(P, counters, key & 31u, key >> 5), (unsigned long long)val);
-}
+__device__ __forceinline__ int bit_m1(uint32_t mask, int j) { return -(int)((mask >> j) & 1u); } // 0 / -1
 
 } // namespace
 
-template <int C, int NW, int HSIZE>
+template <int C, int NW>
 __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
-    const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, uint64_t *__restrict__ counters,
-    uint32_t *__restrict__ err)
+    const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
+    unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err)
 {
-    using Cfg = TrimCfg<C>;
-    constexpr int W = Cfg::W;
+    using Cfg = RowCfg<C>;
+    constexpr int D = Cfg::D, W = Cfg::W;
+    constexpr uint32_t CMASK = (1u << C) - 1u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *hq = smem;                 // [42][W]  lo16 = pre, hi16 = post
-    uint32_t *hb = hq + Cfg::HQ;         // [5][W]
-    uint32_t *hkey = hb + Cfg::HB;       // [HSIZE]
-    uint32_t *hval = hkey + HSIZE;       // [HSIZE]
-    uint32_t *lfs = hval + HSIZE;        // [FS_SLOTS]
-    constexpr int LDS_DWORDS = Cfg::HQ + Cfg::HB + 2 * HSIZE + FS_SLOTS;
+    uint32_t *hq = smem + Cfg::O_HQ, *hb = smem + Cfg::O_HB, *hlen = smem + Cfg::O_LEN, *hrq = smem + Cfg::O_RQ;
+    uint32_t *hbqpre = smem + Cfg::O_BQPRE, *hbqpost = smem + Cfg::O_BQPOST, *lfs = smem + Cfg::O_FS;
+    const uint32_t *t_base = smem + Cfg::O_TBASE, *t_lc = smem + Cfg::O_TLC, *t_magic = smem + Cfg::O_TMAGIC;
+    const int32_t *t_avgq = (const int32_t *)(smem + Cfg::O_TAVGQ);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const int rl = lane & 15;       // lane inside the row
+    const int rowb = lane & 48;     // first lane of the row
     const int wave = uni(tid >> 6);
+    const int pbase = rl * C;
 
-    for (int i = tid; i < LDS_DWORDS; i += NW * 64) smem[i] = (i >= Cfg::HQ + Cfg::HB && i < Cfg::HQ + Cfg::HB + HSIZE) ? HS_EMPTY : 0u;
+    for (int i = tid; i < Cfg::N_ZERO; i += NW * 64) smem[i] = 0u;
+    for (int i = tid; i < 256; i += NW * 64) smem[Cfg::O_TBASE + i] = P.base_tab[i];
+    for (int i = tid; i <= W; i += NW * 64) {
+        smem[Cfg::O_TLC + i] = P.lc_thr[i];
+        smem[Cfg::O_TAVGQ + i] = (uint32_t)P.avgq_min_v[i];
+        smem[Cfg::O_TMAGIC + i] = P.div_magic[i];
+    }
     __syncthreads();
-
-    int pos[C];
-#pragma unroll
-    for (int j = 0; j < C; ++j) pos[j] = lane * C + j;
 
     const uint32_t total_chunks = (n_reads + 63) >> 6;
     const uint32_t chunks_per_iter = gridDim.x * NW;
     const uint32_t n_iter = (total_chunks + chunks_per_iter - 1) / chunks_per_iter;
     constexpr uint32_t FLUSH_EVERY = 65535u / (NW * 64) > 0 ? 65535u / (NW * 64) : 1;
+    constexpr uint32_t REG_FLUSH_EVERY = 3; // 3 chunks x 16 reads per row = 48 <= 63 (6-bit fields)
 
     const int in_off = P.in_off, Q = P.Q;
+    const bool do_trim = !P.qc_only && !(P.dbg & 4u);
+    uint32_t bpre[C], bpost[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { bpre[j] = 0; bpost[j] = 0; }
+    uint32_t any_err = 0;
 
 #pragma unroll 1
     for (uint32_t it = 0; it < n_iter; ++it) {
         const uint32_t chunk = (it * gridDim.x + blockIdx.x) * NW + wave;
         if (chunk < total_chunks) {
             const uint32_t base = chunk << 6;
-            const uint32_t cnt = uniu(n_reads - base < 64u ? n_reads - base : 64u);
-            const uint32_t my = base + lane < n_reads ? base + lane : n_reads;
-            const uint32_t v_off = off[my];
-            const uint32_t v_len = off[my < n_reads ? my + 1 : n_reads] - v_off;
-            const uint32_t v_sl = (ad_sl && base + lane < n_reads) ? ad_sl[base + lane] : 0u;
-            const uint32_t v_hit = (ad_hit && base + lane < n_reads) ? ad_hit[base + lane] : 0u;
+            const uint32_t my = base + lane;
+            const bool mine = my < n_reads;
+            const uint32_t v_off = mine ? off[my] : 0u;
+            const uint32_t v_len = mine ? off[my + 1] - v_off : 0u;
+            const uint32_t v_sl = (ad_sl && mine) ? ad_sl[my] : (v_len << 16);
+            const uint32_t v_hit = (ad_hit && mine) ? ad_hit[my] : 0u;
             uint32_t res_lo = 0, res_hi = 0;
+            unsigned long long rpre = 0, rpost = 0;
+            // FilterStat accumulators (row-uniform values; lane 0 of each row publishes them)
+            uint32_t fs_cnt = 0, fs_total_len = 0, fs_trim_num = 0, fs_trim_len = 0, fs_rlen = 0, fs_blen = 0, fs_rnn = 0,
+                     fs_bnn = 0, fs_ravg = 0, fs_bavg = 0, fs_rqt = 0, fs_bqt = 0, fs_rlc = 0, fs_blc = 0;
 
-            // per-wave FilterStat accumulators (wave-uniform -> SGPRs)
-            uint32_t fs_total_len = 0, fs_trim_num = 0, fs_trim_len = 0, fs_rlen = 0, fs_blen = 0, fs_rnn = 0, fs_bnn = 0,
-                     fs_ravg = 0, fs_bavg = 0, fs_rqt = 0, fs_bqt = 0, fs_rlc = 0, fs_blc = 0;
-            uint32_t any_err = 0;
-
-            // software prefetch of read 0
-            // (a lane only loads when its first position is inside the read: the over-read is <= 3 bytes)
-            uint32_t o_cur = uniu(__builtin_amdgcn_readlane((int)v_off, 0));
-            const int len0 = (int)uniu((uint32_t)__builtin_amdgcn_readlane((int)v_len, 0));
-            typedef uint32_t __attribute__((aligned(1))) u32u;
-            uint32_t wseq = 0, wqual = 0;
-            if (lane * C < len0) {
-                wseq = *(const u32u *)(seq + (size_t)o_cur + lane * C);
-                wqual = *(const u32u *)(qual + (size_t)o_cur + lane * C);
+            // ---- software prefetch of the row's read 0 ---------------------------------------------------
+            PackedBytes<D> nseq, nqual;
+            int n_len = __shfl((int)v_len, rowb);
+            {
+                const uint32_t o = (uint32_t)__shfl((int)v_off, rowb);
+#pragma unroll
+                for (int k = 0; k < D; ++k) { nseq.w[k] = 0; nqual.w[k] = 0; }
+                if (pbase < n_len) {
+                    nseq = *(const PackedBytes<D> *)(seq + (size_t)o + pbase);
+                    nqual = *(const PackedBytes<D> *)(qual + (size_t)o + pbase);
+                }
             }
 
 #pragma unroll 1
-            for (uint32_t r = 0; r < cnt; ++r) {
-                const int len = (int)uniu((uint32_t)__builtin_amdgcn_readlane((int)v_len, r));
-                const uint32_t cseq = wseq, cqual = wqual;
-                if (r + 1 < cnt) {
-                    const uint32_t o_n = uniu((uint32_t)__builtin_amdgcn_readlane((int)v_off, r + 1));
-                    const int len_n = (int)uniu((uint32_t)__builtin_amdgcn_readlane((int)v_len, r + 1));
-                    wseq = 0; wqual = 0;
-                    if (lane * C < len_n) {
-                        wseq = *(const u32u *)(seq + (size_t)o_n + lane * C);
-                        wqual = *(const u32u *)(qual + (size_t)o_n + lane * C);
+            for (int t = 0; t < 16; ++t) {
+                if (base + (uint32_t)t >= n_reads) break; // wave-uniform: no row has a read left
+                const int len = n_len;
+                const bool act = base + (uint32_t)(rowb + t) < n_reads;
+                uint32_t ws[D], wq[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { ws[k] = nseq.w[k]; wq[k] = nqual.w[k]; }
+                const uint32_t sl = (uint32_t)__shfl((int)v_sl, rowb + t);
+                if (t + 1 < 16) {
+                    n_len = __shfl((int)v_len, rowb + t + 1);
+                    const uint32_t o = (uint32_t)__shfl((int)v_off, rowb + t + 1);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { nseq.w[k] = 0; nqual.w[k] = 0; }
+                    if (pbase < n_len) {
+                        nseq = *(const PackedBytes<D> *)(seq + (size_t)o + pbase);
+                        nqual = *(const PackedBytes<D> *)(qual + (size_t)o + pbase);
                     }
                 }
-
-                // ---- unpack this lane's C bases / quality bytes ------------------------------------
-                uint32_t b[C];
-                int rq[C], qs[C];
-                bool inr[C];
+                // zero the bytes past the end of the read (the last dword of a lane may over-read 1..3 bytes)
+                {
+                    const int vb = med3i(len - pbase, 0, C);
 #pragma unroll
-                for (int j = 0; j < C; ++j) {
-                    inr[j] = pos[j] < len;
-                    b[j] = inr[j] ? ((cseq >> (8 * j)) & 0xffu) : 0u;
-                    rq[j] = inr[j] ? (int)(int8_t)((cqual >> (8 * j)) & 0xffu) : in_off;
+                    for (int k = 0; k < D; ++k) {
+                        const int nb = med3i(vb - 4 * k, 0, 4);
+                        const uint32_t m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+                        ws[k] &= m; wq[k] &= m;
+                    }
                 }
-
-                // ---- mask_quality_terminal_N (trim.cpp:1191-1216): upper-case 'N' runs at either end ---
-                uint64_t NU[C];
-                bool term = false;
-#pragma unroll
-                for (int j = 0; j < C; ++j) {
-                    NU[j] = __ballot(b[j] == 'N');
-                    term |= (b[j] == 'N') && (pos[j] == 0 || pos[j] == len - 1);
-                }
-                if (__any(term)) {
-                    uint64_t NON[C];
-#pragma unroll
-                    for (int j = 0; j < C; ++j) NON[j] = __ballot(inr[j] && b[j] != 'N');
-                    const int fn = lo_pos<C>(NON), ln = hi_pos<C>(NON);
-                    const int lead = fn == 0x7fffffff ? len : fn;
-                    const int trail_start = ln + 1;
-#pragma unroll
-                    for (int j = 0; j < C; ++j)
-                        if (inr[j] && (pos[j] < lead || pos[j] >= trail_start)) rq[j] = in_off;
-                }
-
-                // ---- quality_score (fastq.h:17-36) -----------------------------------------------------
-                bool bad = false;
-                int sum_lane = 0;
-#pragma unroll
-                for (int j = 0; j < C; ++j) {
-                    const int v = rq[j] - in_off;
-                    qs[j] = v < 0 ? 0 : v;
-                    bad |= qs[j] > 41;
-                    qs[j] = qs[j] > 41 ? 41 : qs[j];
-                    sum_lane += inr[j] ? rq[j] + 128 : 0;
-                }
-                const bool read_err = __any(bad);
-                const uint32_t S_pre = (uint32_t)wave_sum_i32(sum_lane);
-
-                // ---- base classes (case-insensitive A,T,C,G,N -> 0..4, else 5) ---------------------------
-                // perfect hash on the lower-cased byte: h = (c>>1)&7 : a->0 c->1 t->2 g->3 n->7
-                uint32_t code[C];
-                uint64_t MA[C], MT[C], MC[C], MG[C], MN[C];
-#pragma unroll
-                for (int j = 0; j < C; ++j) {
-                    const uint32_t lc = b[j] | 0x20u;
-                    const uint32_t h = (lc >> 1) & 7u;
-                    const uint32_t want = (uint32_t)((0x6e00000067746361ull >> (8 * h)) & 0xffu);
-                    const uint32_t cd = (0x40003120u >> (4 * h)) & 7u; // a->0 c->2 t->1 g->3 n->4
-                    code[j] = (want == lc) ? cd : 5u;
-                    MA[j] = __ballot(code[j] == 0u);
-                    MT[j] = __ballot(code[j] == 1u);
-                    MC[j] = __ballot(code[j] == 2u);
-                    MG[j] = __ballot(code[j] == 3u);
-                    MN[j] = __ballot(code[j] == 4u);
-                }
-                const uint32_t pA = pop_mask<C>(MA), pT = pop_mask<C>(MT), pC = pop_mask<C>(MC), pG = pop_mask<C>(MG),
-                               pN = pop_mask<C>(MN);
 
                 // ---- window after the adapter pre-pass and --5end/--3end (trim.cpp:270-314) --------------
                 int a = 0, n = len;
                 uint32_t flags = 0, filt = 0;
-                bool ret = true;
                 if (P.has_adapters) {
-                    const uint32_t sl = uniu((uint32_t)__builtin_amdgcn_readlane((int)v_sl, r));
                     const int first = (int)(sl & 0xffffu), second = (int)(sl >> 16);
-                    if (len != second) { a = first; n = second; flags |= FAQCS_F_ADAPTER; }
+                    const bool mod = len != second;
+                    a = mod ? first : 0; n = mod ? second : len;
+                    flags = mod ? FAQCS_F_ADAPTER : 0u;
                 }
                 if (P.trim5 && !P.qc_only) {
-                    if ((int)P.trim5 > n) n = 0; else { a += (int)P.trim5; n -= (int)P.trim5; }
+                    const bool over = (int)P.trim5 > n;
+                    a = over ? a : a + (int)P.trim5;
+                    n = over ? 0 : n - (int)P.trim5;
                 }
-                if (P.trim3 && !P.qc_only) {
-                    if ((int)P.trim3 > n) n = 0; else n -= (int)P.trim3;
-                }
-                if (n < (int)P.min_len || n == 0) { fs_blen += n; ++fs_rlen; ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
+                if (P.trim3 && !P.qc_only) n = (int)P.trim3 > n ? 0 : n - (int)P.trim3;
+                bool ret = act;
+                if (ret && (n < (int)P.min_len || n == 0)) { fs_blen += n; ++fs_rlen; ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
 
-                // ---- quality trim (trim.cpp:325-360) -----------------------------------------------------
-                if (!P.qc_only && ret) {
-                    bool inw[C];
-                    int d[C], Pin[C], Pex[C];
-                    int run = 0;
+                // ---- pass 1 over the lane's C positions ---------------------------------------------------
+                uint32_t inc[C];
+                int vq[C], d[C], Pin[C];
+                int run, sumv, T, E;
+                uint32_t cntpack, nubits, maxq;
+                const int pa = pbase - a;
+#pragma unroll 1
+                for (int attempt = 0; attempt < 2; ++attempt) {
+#pragma unroll
+                    for (int j = 0; j < C; ++j) inc[j] = t_base[(ws[j >> 2] >> (8 * (j & 3))) & 0xffu];
+                    run = 0; sumv = 0; cntpack = 0; nubits = 0; maxq = 0;
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
-                        inw[j] = (unsigned)(pos[j] - a) < (unsigned)n;
-                        d[j] = inw[j] ? Q - qs[j] : 0;
+                        const int sq = (int)(int8_t)((wq[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                        const int v = sq - in_off;                              // quality_score() before the clamp
+                        const int q = v < 0 ? 0 : v;                            // fastq.h:29
+                        vq[j] = v;
+                        sumv += v;
+                        maxq = umax_(maxq, (uint32_t)q);
+                        const bool inw = (unsigned)(pa + j) < (unsigned)n;
+                        d[j] = inw ? Q - q : 0;
                         run += d[j];
                         Pin[j] = run;
+                        cntpack += inc[j];
+                        nubits |= ((inc[j] >> 30) & 1u) << j;
                     }
-                    const int incl = wave_incl_scan_add(run);
-                    const int T = __builtin_amdgcn_readlane(incl, 63);
-                    const int E = incl - run;
+                    if (attempt == 1) break;
+                    // mask_quality_terminal_N (trim.cpp:1191-1216): upper-case 'N' runs at either end get Q0.
+                    // Rare: detect after the fact, patch the quality bytes and redo the pass.
+                    const int lastj = len - 1 - pbase;
+                    const bool term = ((rl == 0) && (nubits & 1u)) || ((unsigned)lastj < (unsigned)C && ((nubits >> lastj) & 1u));
+                    if (!__any(term)) break;
+                    const uint32_t inr = range_mask<C>(0, len, pbase);
+                    const uint32_t non = inr & ~nubits;
+                    const uint32_t fn_l = non ? (uint32_t)(1023 - (pbase + __builtin_ctz(non))) : 0u;
+                    const uint32_t ln_l = non ? (uint32_t)(pbase + (31 - __builtin_clz(non)) + 1) : 0u;
+                    const uint32_t fn_m = row_all_umax(fn_l), ln_m = row_all_umax(ln_l);
+                    const int lead = fn_m ? 1023 - (int)fn_m : len;   // first non-N position (len if the read is all N)
+                    const int trail_start = (int)ln_m;                // 1 + last non-N position (0 if none)
 #pragma unroll
-                    for (int j = 0; j < C; ++j) { Pin[j] += E; Pex[j] = Pin[j] - d[j]; }
+                    for (int j = 0; j < C; ++j) {
+                        const int p = pbase + j;
+                        if (p < len && (p < lead || p >= trail_start)) {
+                            const uint32_t sh = 8 * (j & 3);
+                            wq[j >> 2] = (wq[j >> 2] & ~(0xffu << sh)) | (((uint32_t)in_off & 0xffu) << sh);
+                        }
+                    }
+                }
+                {
+                    const int incl = row_incl_scan_add(run);
+                    E = incl - run;
+                    T = row_all_sum(run);
+                }
+#pragma unroll
+                for (int j = 0; j < C; ++j) Pin[j] += E;
+                // whole-read sums: base counts (A,T | C,G as 16-bit pairs), N count and sum(raw - offset)
+                uint32_t pAT, pCG, pN;
+                int V_pre;
+                {
+                    const uint32_t c = cntpack & BT_FIELDS;
+                    const uint32_t at = (c & 63u) | (((c >> 6) & 63u) << 16), cg = ((c >> 12) & 63u) | (((c >> 18) & 63u) << 16);
+                    pAT = (uint32_t)row_all_sum((int)at);
+                    pCG = (uint32_t)row_all_sum((int)cg);
+                    // positions past the read contributed (0 - in_off) each: add them back
+                    const int vb = med3i(len - pbase, 0, C);
+                    const int both = row_all_sum((((int)((c >> 24) & 63u)) << 20) + (sumv + in_off * (C - vb) + (1 << 14)));
+                    pN = (uint32_t)both >> 20;
+                    V_pre = (int)((uint32_t)both & 0xfffffu) - (16 << 14);
+                }
+                const bool read_err = row_all_umax(maxq) > 41u;
 
-                    int fp3, fp5 = 0; // window-local indices
+                // ---- quality trim (trim.cpp:325-360) -----------------------------------------------------
+                if (do_trim) {
+                    int fp3 = n - 1, fp5 = 0;
+                    const int a5 = n < 5 ? n : 5, nan2 = n < 2 ? n : 2;
                     if (P.mode == FAQCS_MODE_BWA_PLUS) {
-                        const int a5 = n < 5 ? n : 5, nan2 = n < 2 ? n : 2;
-                        // 3' pass: reset[p] = (i > nan) && area_before >= 0, area_before(i) = S[i+1] = T - Pin[i]
-                        uint64_t R3[C], F5[C];
+                        uint32_t nn = 0;
 #pragma unroll
-                        for (int j = 0; j < C; ++j) {
-                            R3[j] = __ballot(inw[j] && (pos[j] - a > nan2) && (T - Pin[j] >= 0));
-                            F5[j] = R3[j] & __ballot(pos[j] >= a + n - a5);
-                        }
-                        int pstar;
-                        if (any_mask<C>(F5)) {
-                            uint64_t C3[C];
-#pragma unroll
-                            for (int j = 0; j < C; ++j) C3[j] = ~R3[j] & ~next_mask<C, 1>(R3, j) & next_mask<C, 2>(R3, j);
-                            pstar = hi_pos<C>(C3);
-                        } else {
-                            pstar = a + n - a5;
-                        }
+                        for (int j = C - 1; j >= 0; --j) nn = (nn << 1) | (uint32_t)((T - Pin[j]) >= 0);
+                        const uint32_t r3 = nn & range_mask<C>(a + nan2 + 1, a + n, pbase);
+                        const uint32_t f5 = r3 & range_mask<C>(a + n - a5, a + n, pbase);
+                        const uint32_t ext = r3 | (row_next(r3) << C);
+                        const uint32_t c3 = ~ext & ~(ext >> 1) & (ext >> 2) & CMASK;
+                        // one butterfly for both: bit 16 = "a reset happens within the first min(5,n) steps", low = 1 + max c3 pos
+                        const uint32_t red = row_all_umax((c3 ? (uint32_t)(pbase + (31 - __builtin_clz(c3)) + 1) : 0u));
+                        const bool early = row_all_or(f5) != 0u;
+                        const int pstar = early ? (int)red - 1 : a + n - a5;
+                        const uint32_t vis = range_mask<C>(pstar > a ? pstar : a, a + n, pbase);
                         uint32_t key = 0;
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t k = ((uint32_t)(T - Pex[j] + KEY_BIAS) << 9) | (uint32_t)(pos[j] - a);
-                            key = umax_(key, (inw[j] && pos[j] >= pstar) ? k : 0u);
+                            const uint32_t k = ((uint32_t)(T - Pin[j] + d[j] + KEY_BIAS) << 9) + (uint32_t)(pa + j);
+                            key = umax_(key, k & (uint32_t)bit_m1(vis, j));
                         }
-                        const uint32_t K3 = wave_max_u32(key);
+                        const uint32_t K3 = row_all_umax(key);
                         fp3 = ((int)(K3 >> 9) - KEY_BIAS > 0) ? (int)(K3 & 511u) - 1 : n - 1;
                         if (!P.protect5) {
-                            const int lim = fp3 - nan2;
-                            uint64_t R5[C], G5[C];
+                            uint32_t np = 0;
 #pragma unroll
-                            for (int j = 0; j < C; ++j) {
-                                R5[j] = __ballot(inw[j] && (pos[j] - a < lim) && (Pex[j] >= 0));
-                                G5[j] = R5[j] & __ballot(pos[j] - a < a5);
-                            }
-                            int pstar5;
-                            if (any_mask<C>(G5)) {
-                                uint64_t C5[C];
-#pragma unroll
-                                for (int j = 0; j < C; ++j) C5[j] = ~R5[j] & ~prev_mask<C, 1>(R5, j) & prev_mask<C, 2>(R5, j);
-                                pstar5 = lo_pos<C>(C5);
-                            } else {
-                                pstar5 = a + a5 - 1;
-                            }
+                            for (int j = C - 1; j >= 0; --j) np = (np << 1) | (uint32_t)((Pin[j] - d[j]) >= 0);
+                            const uint32_t r5 = np & range_mask<C>(a, a + fp3 - nan2, pbase);
+                            const uint32_t g5 = r5 & range_mask<C>(a, a + a5, pbase);
+                            const uint32_t ext5 = (r5 << 2) | ((row_prev(r5) >> (C - 2)) & 3u); // bit k <-> position pbase + k - 2
+                            const uint32_t c5 = ~(ext5 >> 2) & ~(ext5 >> 1) & ext5 & CMASK;
+                            const uint32_t red5 = row_all_umax(c5 ? (uint32_t)(1023 - (pbase + __builtin_ctz(c5))) : 0u);
+                            const bool early5 = row_all_or(g5) != 0u;
+                            const int pstar5 = early5 ? 1023 - (int)red5 : a + a5 - 1;
+                            const uint32_t vis5 = range_mask<C>(a, (pstar5 + 1 < a + n) ? pstar5 + 1 : a + n, pbase);
                             uint32_t key5 = 0;
 #pragma unroll
                             for (int j = 0; j < C; ++j) {
-                                const uint32_t k = ((uint32_t)(Pin[j] + KEY_BIAS) << 9) | (uint32_t)(511 - (pos[j] - a));
-                                key5 = umax_(key5, (inw[j] && pos[j] <= pstar5) ? k : 0u);
+                                const uint32_t k = ((uint32_t)(Pin[j] + KEY_BIAS) << 9) + (uint32_t)(511 - (pa + j));
+                                key5 = umax_(key5, k & (uint32_t)bit_m1(vis5, j));
                             }
-                            const uint32_t K5 = wave_max_u32(key5);
+                            const uint32_t K5 = row_all_umax(key5);
                             fp5 = ((int)(K5 >> 9) - KEY_BIAS > 0) ? 511 - (int)(K5 & 511u) + 1 : 0;
                         }
                     } else if (P.mode == FAQCS_MODE_BWA) { // trim.cpp:675-709
-                        uint64_t NEG[C];
+                        uint32_t neg = 0;
 #pragma unroll
-                        for (int j = 0; j < C; ++j) NEG[j] = __ballot(inw[j] && (T - Pin[j] < 0));
-                        const int pf = hi_pos<C>(NEG); // absolute position of the first failing step, or -1
+                        for (int j = C - 1; j >= 0; --j) neg = (neg << 1) | (uint32_t)((T - Pin[j]) < 0);
+                        neg &= range_mask<C>(a, a + n, pbase);
+                        const int pf = (int)row_all_umax(neg ? (uint32_t)(pbase + (31 - __builtin_clz(neg)) + 1) : 0u) - 1; // -1: none
                         const int lo = (pf < a ? a : pf) + 1;
+                        const uint32_t vis = range_mask<C>(lo, a + n, pbase);
                         uint32_t key = 0;
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t k = ((uint32_t)(T - Pex[j] + KEY_BIAS) << 9) | (uint32_t)(pos[j] - a);
-                            key = umax_(key, (inw[j] && pos[j] >= lo) ? k : 0u);
+                            const uint32_t k = ((uint32_t)(T - Pin[j] + d[j] + KEY_BIAS) << 9) + (uint32_t)(pa + j);
+                            key = umax_(key, k & (uint32_t)bit_m1(vis, j));
                         }
-                        const uint32_t K3 = wave_max_u32(key);
+                        const uint32_t K3 = row_all_umax(key);
                         fp3 = ((int)(K3 >> 9) - KEY_BIAS > 0) ? (int)(K3 & 511u) - 1 : n - 1;
                     } else { // HARD, trim.cpp:629-672
-                        uint64_t H1[C], H0[C];
+                        uint32_t h0 = 0;
 #pragma unroll
-                        for (int j = 0; j < C; ++j) {
-                            H0[j] = __ballot(inw[j] && Q < qs[j]);
-                            H1[j] = H0[j] & __ballot(pos[j] - a >= 1);
-                        }
-                        const int h = hi_pos<C>(H1);
+                        for (int j = C - 1; j >= 0; --j) h0 = (h0 << 1) | (uint32_t)(Q < (vq[j] < 0 ? 0 : vq[j]));
+                        h0 &= range_mask<C>(a, a + n, pbase);
+                        const uint32_t h1 = h0 & range_mask<C>(a + 1, a + n, pbase);
+                        const int h = (int)row_all_umax(h1 ? (uint32_t)(pbase + (31 - __builtin_clz(h1)) + 1) : 0u) - 1;
                         int pos3 = 0;
-                        fp3 = n - 1;
                         if (h >= 0) { fp3 = h - a; pos3 = fp3; }
                         if (!P.protect5) {
-                            const int l = lo_pos<C>(H0);
-                            if (l != 0x7fffffff && l - a < pos3) fp5 = l - a;
+                            const uint32_t lm = row_all_umax(h0 ? (uint32_t)(1023 - (pbase + __builtin_ctz(h0))) : 0u);
+                            const int l = lm ? 1023 - (int)lm - a : 0x7fffffff;
+                            if (l < pos3) fp5 = l;
                         }
                     }
-                    int kept = (P.mode == FAQCS_MODE_BWA_PLUS && fp3 <= fp5) ? 0 : fp3 - fp5 + 1;
-                    if (kept != n) { fs_bqt += (uint32_t)(n - kept); ++fs_rqt; flags |= FAQCS_F_QUAL_TRIMMED; }
-                    a += fp5;
-                    n = kept;
-                    if (n < (int)P.min_len || n == 0) { fs_blen += n; ++fs_rlen; ret = false; filt = FAQCS_FILT_LENGTH_POST; }
+                    if (ret) {
+                        const int kept = (P.mode == FAQCS_MODE_BWA_PLUS && fp3 <= fp5) ? 0 : fp3 - fp5 + 1;
+                        if (kept != n) { fs_bqt += (uint32_t)(n - kept); ++fs_rqt; flags |= FAQCS_F_QUAL_TRIMMED; }
+                        a += fp5;
+                        n = kept;
+                        if (n < (int)P.min_len || n == 0) { fs_blen += n; ++fs_rlen; ret = false; filt = FAQCS_FILT_LENGTH_POST; }
+                    }
                 }
 
-                // ---- final window predicate --------------------------------------------------------------
-                bool inw2[C];
-                uint64_t W2[C];
-#pragma unroll
-                for (int j = 0; j < C; ++j) {
-                    inw2[j] = (unsigned)(pos[j] - a) < (unsigned)n;
-                    W2[j] = __ballot(inw2[j]);
-                }
+                // ---- final window: poly-N, counts, sum(raw - offset) ---------------------------------------
+                const uint32_t win2 = range_mask<C>(a, a + n, pbase);
                 const bool whole = (a == 0 && n == len);
-
-                // ---- poly-N filter (trim.cpp:363-371, :578-597) -- upper-case 'N' only --------------------
-                if (ret) {
-                    uint64_t NW2[C];
-#pragma unroll
-                    for (int j = 0; j < C; ++j) NW2[j] = NU[j] & W2[j];
-                    bool trip;
+                if (ret) { // poly-N filter (trim.cpp:363-371, :578-597): upper-case 'N' runs only
                     const uint32_t K = P.max_poly_n;
+                    const uint32_t nw = nubits & win2;
+                    bool trip;
                     if (K == 0) trip = true;
-                    else if (!any_mask<C>(NW2)) trip = false;
-                    else if (K == 1) trip = true;
                     else {
-                        uint64_t X[C];
-#pragma unroll
-                        for (int j = 0; j < C; ++j) X[j] = NW2[j] & next_mask<C, 1>(NW2, j);
-                        const bool any2 = any_mask<C>(X);
-                        if (K == 2) trip = any2;
-                        else if (!any2) trip = false;
-                        else { // exact longest run: run ending at p = p - (last non-N position <= p)
+                        const uint32_t e2 = nw | (row_next(nw) << C);
+                        const uint32_t pairs = e2 & (e2 >> 1) & CMASK;
+                        const uint32_t red = row_all_or((nw ? 1u : 0u) | (pairs ? 2u : 0u));
+                        if (K == 1) trip = (red & 1u) != 0;
+                        else if (K == 2) trip = (red & 2u) != 0;
+                        else if (!(red & 2u)) trip = false;
+                        else { // exact longest run (rare): run ending at p = p - (last non-N position <= p)
                             uint32_t loc[C], m = 0;
 #pragma unroll
                             for (int j = 0; j < C; ++j) {
-                                const bool isn = inw2[j] && b[j] == 'N';
-                                m = umax_(m, (inw2[j] && !isn) ? (uint32_t)pos[j] + 1u : 0u);
+                                const bool isn = (nw >> j) & 1u, in = (win2 >> j) & 1u;
+                                m = umax_(m, (in && !isn) ? (uint32_t)(pbase + j) + 1u : 0u);
                                 loc[j] = m;
                             }
-                            uint32_t s = m;
-                            s = umax_(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, false));
-                            s = umax_(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false));
-                            s = umax_(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false));
-                            s = umax_(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xf, false));
-                            s = umax_(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, false));
-                            s = umax_(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, false));
-                            const uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x138, 0xf, 0xf, false); // wave_shr:1
+                            int s = (int)m; // inclusive max-scan over the row
+                            s = op_umax_(s, __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, false));
+                            s = op_umax_(s, __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, false));
+                            s = op_umax_(s, __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, false));
+                            s = op_umax_(s, __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, false));
+                            const uint32_t excl = row_prev((uint32_t)s);
                             uint32_t best = 0;
 #pragma unroll
                             for (int j = 0; j < C; ++j) {
-                                const bool isn = inw2[j] && b[j] == 'N';
                                 const uint32_t lastnon = umax_(umax_(excl, loc[j]), (uint32_t)a);
-                                best = umax_(best, isn ? (uint32_t)pos[j] + 1u - lastnon : 0u);
+                                best = umax_(best, ((nw >> j) & 1u) ? (uint32_t)(pbase + j) + 1u - lastnon : 0u);
                             }
-                            trip = wave_max_u32(best) >= K;
+                            trip = row_all_umax(best) >= K;
                         }
                     }
                     if (trip) {
@@ -441,152 +396,171 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                     }
                 }
 
-                // ---- average quality (trim.cpp:374-382, :553-576) -----------------------------------------
-                uint32_t S_post = S_pre;
-                if (ret && !whole) {
-                    int sl = 0;
-#pragma unroll
-                    for (int j = 0; j < C; ++j) sl += inw2[j] ? rq[j] + 128 : 0;
-                    S_post = (uint32_t)wave_sum_i32(sl);
-                }
-                if (ret && P.avgq_on && S_post < P.avgq_min_sum[n]) {
-                    fs_bavg += n; ++fs_ravg; ret = false; filt = FAQCS_FILT_AVG_Q;
-                }
-
-                // ---- G -> N (trim.cpp:390-403) and the low-complexity filter (trim.cpp:405-513) -----------
-                uint64_t REP[C];
-#pragma unroll
-                for (int j = 0; j < C; ++j) REP[j] = 0;
-                uint32_t cA = pA, cT = pT, cC = pC, cG = pG, cN = pN;
-                if (ret) {
-                    if (P.replace_q > 0) {
-#pragma unroll
-                        for (int j = 0; j < C; ++j) REP[j] = __ballot(inw2[j] && b[j] == 'G' && qs[j] < (int)P.replace_q);
-                    }
-                    uint64_t XA[C], XT[C], XC[C], XG[C];
+                // counts inside the final window, after G -> N (trim.cpp:390-403); inc2[] = per-position class word
+                uint32_t cAT = pAT, cCG = pCG, cN = pN;
+                int V_post = V_pre;
+                uint32_t inc2[C];
+                {
+                    uint32_t cp = 0;
+                    int sv = 0;
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
-                        XA[j] = MA[j] & W2[j]; XT[j] = MT[j] & W2[j]; XC[j] = MC[j] & W2[j];
-                        XG[j] = MG[j] & W2[j] & ~REP[j];
-                    }
-                    if (!whole || P.replace_q > 0) {
-                        cA = pop_mask<C>(XA); cT = pop_mask<C>(XT); cC = pop_mask<C>(XC); cG = pop_mask<C>(XG);
-                        uint64_t XN[C];
-#pragma unroll
-                        for (int j = 0; j < C; ++j) XN[j] = (MN[j] & W2[j]) | REP[j];
-                        cN = pop_mask<C>(XN);
-                    }
-                    const uint32_t mthr = P.mono_thr[n];
-                    bool trip = cA >= mthr || cT >= mthr || cG >= mthr || cC >= mthr;
-                    if (!trip) {
-                        const uint32_t dthr = P.di_thr[n];
-                        // dc[X->Y] <= min(count X, count Y): only pairs whose two counts both reach dthr can trip
-                        const uint32_t cc[4] = {cA, cT, cC, cG};
-                        const uint32_t nbig = (cA >= dthr) + (cT >= dthr) + (cC >= dthr) + (cG >= dthr);
-                        if (nbig >= 2) {
-#define FAQCS_PAIR(X, Y, cx, cy)                                                                          \
-    if (!trip && cx >= dthr && cy >= dthr) {                                                              \
-        int dc = 0;                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < C; ++j) dc += __popcll(prev_mask<C, 1>(X, j) & Y[j]);       \
-        trip = (uint32_t)dc >= dthr;                                                                      \
-    }
-                            FAQCS_PAIR(XA, XT, cA, cT) FAQCS_PAIR(XT, XA, cT, cA) FAQCS_PAIR(XA, XC, cA, cC)
-                            FAQCS_PAIR(XC, XA, cC, cA) FAQCS_PAIR(XA, XG, cA, cG) FAQCS_PAIR(XG, XA, cG, cA)
-                            FAQCS_PAIR(XT, XC, cT, cC) FAQCS_PAIR(XC, XT, cC, cT) FAQCS_PAIR(XT, XG, cT, cG)
-                            FAQCS_PAIR(XG, XT, cG, cT) FAQCS_PAIR(XC, XG, cC, cG) FAQCS_PAIR(XG, XC, cG, cC)
-#undef FAQCS_PAIR
+                        uint32_t w = inc[j] & BT_FIELDS;
+                        if (P.replace_q > 0) {
+                            const int q = vq[j] < 0 ? 0 : vq[j];
+                            if ((inc[j] & BT_IS_GU) && q < (int)P.replace_q) w = 1u << BT_SHIFT(4);
                         }
-                        (void)cc;
+                        const uint32_t m = (uint32_t)bit_m1(win2, j);
+                        inc2[j] = w & m;
+                        cp += inc2[j];
+                        sv += vq[j] & (int)m;
+                    }
+                    if (__any(ret && (!whole || P.replace_q > 0))) {
+                        const uint32_t at = (cp & 63u) | (((cp >> 6) & 63u) << 16), cg = ((cp >> 12) & 63u) | (((cp >> 18) & 63u) << 16);
+                        cAT = (uint32_t)row_all_sum((int)at);
+                        cCG = (uint32_t)row_all_sum((int)cg);
+                        const int both = row_all_sum((((int)((cp >> 24) & 63u)) << 20) + (sv + (1 << 14)));
+                        cN = (uint32_t)both >> 20;
+                        V_post = (int)((uint32_t)both & 0xfffffu) - (16 << 14);
+                    }
+                }
+                const uint32_t cA = cAT & 0xffffu, cT = cAT >> 16, cC = cCG & 0xffffu, cG = cCG >> 16;
+
+                // ---- average quality (trim.cpp:374-382) ----------------------------------------------------
+                if (ret && P.avgq_on && V_post < t_avgq[n]) { fs_bavg += n; ++fs_ravg; ret = false; filt = FAQCS_FILT_AVG_Q; }
+
+                // ---- low-complexity filter (trim.cpp:405-513) ----------------------------------------------
+                if (ret) {
+                    const uint32_t thr = t_lc[n];
+                    const uint32_t mthr = thr & 0xffffu, dthr = thr >> 16;
+                    bool trip = cA >= mthr || cT >= mthr || cG >= mthr || cC >= mthr;
+                    // dc[X->Y] <= min(count X, count Y): only pairs whose two counts both reach dthr can trip
+                    const uint32_t nbig = (cA >= dthr) + (cT >= dthr) + (cC >= dthr) + (cG >= dthr);
+                    if (__any(!trip && nbig >= 2)) {
+                        // class index per position (0..3 = A,T,C,G inside the window, 7 = anything else)
+                        uint32_t cls[C];
+#pragma unroll
+                        for (int j = 0; j < C; ++j) {
+                            const uint32_t w = inc2[j] & 0xffffffu;
+                            cls[j] = w ? (uint32_t)(__builtin_ctz(w) / 6) : 7u;
+                        }
+                        const uint32_t prev_last = row_prev(cls[C - 1] + 1u); // 0 at the row edge
+                        const uint32_t cnts[4] = {cA, cT, cC, cG};
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+#pragma unroll
+                            for (int y = 0; y < 4; ++y)
+                                if (x != y) {
+                                    int dc = 0;
+#pragma unroll
+                                    for (int j = 0; j < C; ++j) {
+                                        const uint32_t pv = j ? cls[j - 1] : prev_last - 1u; // row edge: 0xffffffff
+                                        dc += (pv == (uint32_t)x && cls[j] == (uint32_t)y) ? 1 : 0;
+                                    }
+                                    dc = row_all_sum(dc);
+                                    trip = trip || (cnts[x] >= dthr && cnts[y] >= dthr && (uint32_t)dc >= dthr);
+                                }
                     }
                     if (trip) { fs_blc += n; ++fs_rlc; ret = false; filt = FAQCS_FILT_LOW_COMPLEXITY; }
                 }
-
                 if (ret) { fs_trim_len += n; ++fs_trim_num; }
-                fs_total_len += len;
+                if (act) { fs_total_len += len; ++fs_cnt; }
 
-                // ---- position matrices: one LDS atomic per base for pre+post ------------------------------
-                if (!read_err) {
+                // ---- accumulate: position x quality (LDS) and position x base (registers) -----------------
+                if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
+                if (!(P.dbg & 2u)) {
+                    const uint32_t inr = (act && !read_err) ? range_mask<C>(0, len, pbase) : 0u;
+                    const uint32_t postm = ret ? win2 : 0u;
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
-                        if (inr[j]) {
-                            const uint32_t post = (ret && inw2[j]) ? 0x10000u : 0u;
-                            const int col = j * 64 + lane;
-                            atomicAdd(&hq[qs[j] * W + col], 1u | post);
-                            const bool rep = (REP[j] >> lane) & 1ull;
-                            if (code[j] < 5u) atomicAdd(&hb[code[j] * W + col], 1u | (rep ? 0u : post));
-                            if (rep && post) atomicAdd(&hb[4 * W + col], post);
+                        if ((inr >> j) & 1u) {
+                            const int q = vq[j] < 0 ? 0 : vq[j];
+                            const uint32_t post = (postm >> j) & 1u;
+                            atomicAdd(&hq[q * W + pbase + j], 1u | (post << 16));
+                            bpre[j] += inc[j] & BT_FIELDS;
+                            bpost[j] += post ? inc2[j] : 0u;
                         }
                     }
-                } else {
-                    any_err = 1;
-                    flags |= FAQCS_F_ERR_QUALITY;
                 }
 
-                // ---- composition bins + sparse histograms through the LDS hash (lanes 0..17) --------------
+                // ---- per-read scalars: int(average_quality) bins, small histograms, records, result --------
                 {
-                    // int(average_quality) == max(0, floor(S/len) - offset): floor via host magic (exact)
-                    const uint32_t qdiv_pre = len ? (uint32_t)(((uint64_t)S_pre * P.div_magic[len]) >> 44) : 0u;
-                    const uint32_t qdiv_post = (ret && n) ? (uint32_t)(((uint64_t)S_post * P.div_magic[n]) >> 44) : 0u;
-                    int qb_pre = (int)qdiv_pre - 128 - in_off, qb_post = (int)qdiv_post - 128 - in_off;
-                    qb_pre = (len == 0 || qb_pre < 0) ? 0 : (qb_pre > 41 ? 41 : qb_pre);
-                    qb_post = qb_post < 0 ? 0 : (qb_post > 41 ? 41 : qb_post);
-                    const float norm_pre = P.comp_norm[len], norm_post = P.comp_norm[ret ? n : 0];
-                    uint32_t cv = 0;
-                    cv = lane == 0 ? pA : cv; cv = lane == 1 ? pT : cv; cv = lane == 2 ? pC : cv;
-                    cv = lane == 3 ? pG : cv; cv = lane == 4 ? pN : cv;
-                    cv = lane == 6 ? cA : cv; cv = lane == 7 ? cT : cv; cv = lane == 8 ? cC : cv;
-                    cv = lane == 9 ? cG : cv; cv = lane == 10 ? cN : cv;
-                    const float nv = lane < 6 ? norm_pre : norm_post;
-                    uint32_t bin = (uint32_t)__fmul_rn(nv, (float)cv);
-                    const uint32_t gc_pre = (uint32_t)__builtin_amdgcn_readlane((int)bin, 3) + (uint32_t)__builtin_amdgcn_readlane((int)bin, 2);
-                    const uint32_t gc_post = (uint32_t)__builtin_amdgcn_readlane((int)bin, 9) + (uint32_t)__builtin_amdgcn_readlane((int)bin, 8);
-                    bin = lane == 5 ? gc_pre : bin;
-                    bin = lane == 11 ? gc_post : bin;
-                    bin = lane == HS_PRE_LEN ? (uint32_t)len : bin;
-                    bin = lane == HS_POST_LEN ? (uint32_t)n : bin;
-                    bin = (lane == HS_PRE_RQ || lane == HS_PRE_BQ) ? (uint32_t)qb_pre : bin;
-                    bin = (lane == HS_POST_RQ || lane == HS_POST_BQ) ? (uint32_t)qb_post : bin;
-                    uint32_t val = 1;
-                    val = lane == HS_PRE_BQ ? (uint32_t)len : val;
-                    val = lane == HS_POST_BQ ? (uint32_t)n : val;
-                    const bool is_post = (lane >= 6 && lane < 12) || lane == HS_POST_LEN || lane == HS_POST_RQ || lane == HS_POST_BQ;
-                    if (lane < HS_NSLOT && !read_err && (!is_post || ret) && val != 0)
-                        hash_add(hkey, hval, HSIZE - 1, (uint32_t)lane | (bin << 5), val, P, counters);
+                    // int(ave_Q) == max(0, floor(V / len)), V = sum(raw - offset); floor via mulhi with a host magic
+                    int qb_pre = 0, qb_post = 0;
+                    if (len > 0 && V_pre > 0) qb_pre = len == 1 ? V_pre : (int)__umulhi((uint32_t)V_pre, t_magic[len]);
+                    if (ret && V_post > 0) qb_post = n == 1 ? V_post : (int)__umulhi((uint32_t)V_post, t_magic[n]);
+                    qb_pre = qb_pre > 41 ? 41 : qb_pre;
+                    qb_post = qb_post > 41 ? 41 : qb_post;
+                    if (!(P.dbg & 2u) && !read_err) {
+                        // lanes 0..5 of the row each issue one small-histogram update
+                        uint32_t *dst = hlen + len;
+                        uint32_t val = 1u;
+                        bool on = act;
+                        if (rl == 1) { dst = hlen + n; val = 0x10000u; on = ret; }
+                        if (rl == 2) { dst = hrq + qb_pre; }
+                        if (rl == 3) { dst = hrq + qb_post; val = 0x10000u; on = ret; }
+                        if (rl == 4) { dst = hbqpre + qb_pre; val = (uint32_t)len; }
+                        if (rl == 5) { dst = hbqpost + qb_post; val = (uint32_t)n; on = ret; }
+                        if (rl < 6 && on && val) atomicAdd(dst, val);
+                    }
+                    const unsigned long long rp = CR_VALID | (unsigned long long)len | ((unsigned long long)(pAT & 0xffffu) << 9) |
+                                                  ((unsigned long long)(pAT >> 16) << 18) | ((unsigned long long)(pCG & 0xffffu) << 27) |
+                                                  ((unsigned long long)(pCG >> 16) << 36) | ((unsigned long long)pN << 45);
+                    const unsigned long long rq = CR_VALID | (unsigned long long)n | ((unsigned long long)cA << 9) | ((unsigned long long)cT << 18) |
+                                                  ((unsigned long long)cC << 27) | ((unsigned long long)cG << 36) | ((unsigned long long)cN << 45);
+                    const uint32_t lo = ret ? ((uint32_t)a | ((uint32_t)n << 16)) : 0u;
+                    const uint32_t hi = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT);
+                    if (rl == t) {
+                        res_lo = lo; res_hi = hi;
+                        rpre = (act && !read_err) ? rp : 0ull;
+                        rpost = (ret && !read_err) ? rq : 0ull;
+                    }
                 }
-
-                // ---- per-read result ----------------------------------------------------------------------
-                const uint32_t hit = uniu((uint32_t)__builtin_amdgcn_readlane((int)v_hit, r));
-                const uint32_t lo = ret ? ((uint32_t)a | ((uint32_t)n << 16)) : 0u;
-                const uint32_t hi = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT) | (hit << 16);
-                res_lo = lane == (int)r ? lo : res_lo;
-                res_hi = lane == (int)r ? hi : res_hi;
             }
 
-            if ((uint32_t)lane < cnt) out[base + lane] = make_uint2(res_lo, res_hi);
-            if (lane == 0) {
-                atomicAdd(&lfs[FAQCS_TOTAL_COUNT], cnt);
-                atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], cnt);
-                atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], fs_total_len);
+            if (mine) {
+                out[my] = make_uint2(res_lo, res_hi | (v_hit << 16));
+                rec_pre[my] = rpre;
+                rec_post[my] = rpost;
+            }
+            if (rl == 0) {
+                if (fs_cnt) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], fs_cnt); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], fs_cnt); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], fs_total_len); }
                 if (fs_trim_num) { atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_NUMBER], fs_trim_num); atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_LENGTH], fs_trim_len); }
                 if (fs_rlen) { atomicAdd(&lfs[FAQCS_READ_LENGTH], fs_rlen); atomicAdd(&lfs[FAQCS_BASE_LENGTH], fs_blen); }
                 if (fs_rnn) { atomicAdd(&lfs[FAQCS_READ_NN], fs_rnn); atomicAdd(&lfs[FAQCS_BASE_NN], fs_bnn); }
                 if (fs_ravg) { atomicAdd(&lfs[FAQCS_READ_AVG_Q], fs_ravg); atomicAdd(&lfs[FAQCS_BASE_AVG_Q], fs_bavg); }
                 if (fs_rqt) { atomicAdd(&lfs[FAQCS_READ_QUAL_TRIM], fs_rqt); atomicAdd(&lfs[FAQCS_BASE_QUAL_TRIM], fs_bqt); }
                 if (fs_rlc) { atomicAdd(&lfs[FAQCS_READ_LOW_COMPLEXITY], fs_rlc); atomicAdd(&lfs[FAQCS_BASE_LOW_COMPLEXITY], fs_blc); }
-                if (any_err) atomicOr(err, 1u);
             }
         }
 
-        // ---- flush before a 16-bit field can overflow, and at the end -----------------------------------
-        if (((it + 1) % FLUSH_EVERY) == 0 || it + 1 == n_iter) {
+        // ---- spill the register-privatised base matrix to LDS before a 6-bit field can overflow ----------
+        const bool block_flush = ((it + 1) % FLUSH_EVERY) == 0 || it + 1 == n_iter;
+        if (((it + 1) % REG_FLUSH_EVERY) == 0 || block_flush) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const uint32_t x = bpre[j], y = bpost[j];
+                if (x) {
+#pragma unroll
+                    for (int c = 0; c < FAQCS_NBASE; ++c) {
+                        const uint32_t v = ((x >> BT_SHIFT(c)) & 63u) | (((y >> BT_SHIFT(c)) & 63u) << 16);
+                        if (v) atomicAdd(&hb[c * W + pbase + j], v);
+                    }
+                }
+                bpre[j] = 0; bpost[j] = 0;
+            }
+        }
+
+        // ---- flush LDS -> global before a 16-bit field can overflow, and at the end ----------------------
+        if (block_flush) {
             __syncthreads();
             const faqcs_layout &L = P.lay;
             for (int i = tid; i < Cfg::HQ; i += NW * 64) {
                 const uint32_t v = hq[i];
                 if (v) {
                     hq[i] = 0;
-                    const int q = i / W, col = i % W, p = (col & 63) * C + (col >> 6);
-                    if ((uint32_t)p < P.R) {
+                    const uint32_t q = i / W, p = i % W;
+                    if (p < P.R) {
                         if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)(v & 0xffffu));
                         if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)(v >> 16));
                     }
@@ -596,62 +570,151 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                 const uint32_t v = hb[i];
                 if (v) {
                     hb[i] = 0;
-                    const int c = i / W, col = i % W, p = (col & 63) * C + (col >> 6);
-                    if ((uint32_t)p < P.R) {
+                    const uint32_t c = i / W, p = i % W;
+                    if (p < P.R) {
                         if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_base + (uint64_t)p * FAQCS_NBASE + c), (unsigned long long)(v & 0xffffu));
                         if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_base + (uint64_t)p * FAQCS_NBASE + c), (unsigned long long)(v >> 16));
                     }
                 }
             }
-            for (int i = tid; i < HSIZE; i += NW * 64) {
-                const uint32_t k = hkey[i];
-                if (k != HS_EMPTY) {
-                    atomicAdd((unsigned long long *)hs_dest(P, counters, k & 31u, k >> 5), (unsigned long long)hval[i]);
-                    hkey[i] = HS_EMPTY;
-                    hval[i] = 0;
+            for (int i = tid; i <= W; i += NW * 64) {
+                const uint32_t v = hlen[i];
+                if (v && (uint32_t)i <= P.R) {
+                    hlen[i] = 0;
+                    if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_len_hist + i), (unsigned long long)(v & 0xffffu));
+                    if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_len_hist + i), (unsigned long long)(v >> 16));
                 }
             }
-            if (tid < FAQCS_NUM_STAT) {
-                const uint32_t v = lfs[tid];
-                if (v) { atomicAdd((unsigned long long *)(counters + L.filter_stats + tid), (unsigned long long)v); lfs[tid] = 0; }
+            if (tid < FAQCS_NQ) {
+                const uint32_t v = hrq[tid], x = hbqpre[tid], y = hbqpost[tid];
+                hrq[tid] = 0; hbqpre[tid] = 0; hbqpost[tid] = 0;
+                if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_read_qhist + tid), (unsigned long long)(v & 0xffffu));
+                if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_read_qhist + tid), (unsigned long long)(v >> 16));
+                if (x) atomicAdd((unsigned long long *)(counters + L.pre_base_qhist + tid), (unsigned long long)x);
+                if (y) atomicAdd((unsigned long long *)(counters + L.post_base_qhist + tid), (unsigned long long)y);
+            }
+            if (tid >= 64 && tid < 64 + FAQCS_NUM_STAT) {
+                const int k = tid - 64;
+                const uint32_t v = lfs[k];
+                if (v) { atomicAdd((unsigned long long *)(counters + L.filter_stats + k), (unsigned long long)v); lfs[k] = 0; }
+            }
+            __syncthreads();
+        }
+    }
+    if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// composition_histogram: update_base_statistics()'s composition part (trim.cpp:860-874) from the per-read
+// records.  One thread per record; the block's LDS holds the whole 10 001 x 6 table as 16-bit counters
+// (two per dword), flushed to the global u64 block before any of them can overflow.
+// ---------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void composition_histogram(const unsigned long long *__restrict__ rec, const uint32_t n,
+                                                            const float *__restrict__ comp_norm,
+                                                            uint64_t *__restrict__ dst /* counters + L.{pre,post}_comp */)
+{
+    constexpr int NE = FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND; // 60 006 16-bit counters
+    constexpr int ND = (NE + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ND; i += NT) tab[i] = 0;
+    __syncthreads();
+    const uint32_t per_round = gridDim.x * NT;
+    const uint32_t rounds = (n + per_round - 1) / per_round;
+    constexpr uint32_t FLUSH_EVERY = 65535u / NT;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = (r * gridDim.x + blockIdx.x) * NT + tid;
+        if (i < n) {
+            const unsigned long long x = rec[i];
+            if (x & CR_VALID) {
+                const uint32_t len = (uint32_t)(x & 511u);
+                const float norm = comp_norm[len];
+                uint32_t idx[6];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) idx[k] = (uint32_t)__fmul_rn(norm, (float)(uint32_t)((x >> (9 + 9 * k)) & 511u)); // :862-872
+                idx[5] = idx[3] + idx[2];                                                                                  // :874 (G + C)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const uint32_t e = idx[k] * FAQCS_NCOMP_KIND + k;
+                    atomicAdd(&tab[e >> 1], 1u << (16 * (e & 1u)));
+                }
+            }
+        }
+        if (((r + 1) % FLUSH_EVERY) == 0 || r + 1 == rounds) {
+            __syncthreads();
+            for (int d = tid; d < ND; d += NT) {
+                const uint32_t v = tab[d];
+                if (v) {
+                    tab[d] = 0;
+                    if (v & 0xffffu) atomicAdd((unsigned long long *)(dst + 2 * d), (unsigned long long)(v & 0xffffu));
+                    if (v >> 16) atomicAdd((unsigned long long *)(dst + 2 * d + 1), (unsigned long long)(v >> 16));
+                }
             }
             __syncthreads();
         }
     }
 }
 
-// ---- launch wrapper -------------------------------------------------------------------------------------
-template <int C, int NW, int HSIZE>
+// ---- launch wrappers ---------------------------------------------------------------------------------------
+template <int C, int NW>
 static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                 uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
-                                uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
+                                unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
+                                int n_cu, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)(TrimCfg<C>::HQ + TrimCfg<C>::HB + 2 * HSIZE + FS_SLOTS) * 4;
+    constexpr size_t lds = (size_t)RowCfg<C>::LDS_DWORDS * 4;
     static bool attr_set = false;
-    auto kern = trim_filter_accumulate<C, NW, HSIZE>;
+    auto kern = trim_filter_accumulate<C, NW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const uint32_t chunks = (n_reads + 63) / 64;
-    const int blocks_per_cu = (lds * 2 <= 160 * 1024) ? 2 : 1;
+    int blocks_per_cu = (int)((160 * 1024) / lds);
+    const int by_waves = 16 / NW; // aim at <= 16 resident waves per CU (VGPR-bound kernel)
+    if (blocks_per_cu > by_waves) blocks_per_cu = by_waves;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint32_t grid = (chunks + NW - 1) / NW;
     const uint32_t cap = (uint32_t)(n_cu * blocks_per_cu);
     if (grid > cap) grid = cap;
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
-                       reinterpret_cast<uint2 *>(out), counters, err);
+                       reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err);
     return hipGetLastError();
 }
 
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
-                             faqcs_read_result *out, uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
+                             faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
+                             uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
 {
-    if (max_len <= 64) return launch_trim_t<1, 16, 4096>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, counters, err, n_cu, st);
-    if (max_len <= 128) return launch_trim_t<2, 16, 4096>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, counters, err, n_cu, st);
-    if (max_len <= 192) return launch_trim_t<3, 16, 4096>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, counters, err, n_cu, st);
-    if (max_len <= 256) return launch_trim_t<4, 16, 2048>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, counters, err, n_cu, st);
+#define FAQCS_TRIM_CASE(C, NW) return launch_trim_t<C, NW>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st)
+    if (max_len <= 64) FAQCS_TRIM_CASE(4, 8);
+    if (max_len <= 112) FAQCS_TRIM_CASE(7, 8);
+    if (max_len <= 160) FAQCS_TRIM_CASE(10, 8);
+    if (max_len <= 208) FAQCS_TRIM_CASE(13, 8);
+    if (max_len <= 256) FAQCS_TRIM_CASE(16, 8);
+#undef FAQCS_TRIM_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, const float *comp_norm, uint64_t *dst,
+                                    int n_cu, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    constexpr int NT = 1024;
+    constexpr size_t lds = (size_t)((FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND + 1) / 2) * 4;
+    static bool attr_set = false;
+    auto kern = composition_histogram<NT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    uint32_t grid = (n + NT - 1) / NT;
+    if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, rec, n, comp_norm, dst);
+    return hipGetLastError();
 }

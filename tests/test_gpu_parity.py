@@ -32,7 +32,7 @@ def random_batch(rng, n, maxlen, kind):
             s, q = make_fixtures._adv_read(rng, maxlen)
         else:
             L = int(rng.integers(0, maxlen + 1))
-            s = np.frombuffer(b"ACGTNacgtnRY", np.uint8)[rng.choice(12, L, p=[.22, .22, .22, .22, .04, .02, .02, .01, .01, .005, .0025, .0025])].copy()
+            s = np.frombuffer(b"ACGTNacgtnRY", np.uint8)[rng.choice(12, L, p=[.22, .22, .22, .22, .05, .02, .02, .01, .01, .005, .0025, .0025])].copy()
             q = (rng.integers(0, 42, L) + 33).astype(np.uint8)
             if L and rng.random() < 0.5:
                 cut = int(rng.integers(0, L))
@@ -99,7 +99,7 @@ OPTION_SETS = [
 @pytest.mark.parametrize("args", OPTION_SETS, ids=lambda a: " ".join(a) or "default")
 @pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 64), ("ragged", 250), ("adv", 100)])
 def test_random_batches_match_oracle(args, kind, maxlen):
-    rng = np.random.Generator(np.random.PCG64(hash((kind, maxlen, len(args))) & 0xffff))
+    rng = np.random.Generator(np.random.PCG64([len(kind), maxlen, OPTION_SETS.index(args)]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     n = 700 if "--adapter" in args else 3000
     reads = random_batch(rng, n, maxlen, kind)
