@@ -63,3 +63,48 @@ def run_case(case, cache, tmp_path, engine_factory, **kw):
     if extra:
         bad.append("unexpected files: %s" % sorted(extra))
     return bad
+
+
+def compare_outputs(case, outdir, rc, err_text):
+    bad = []
+    if rc != case["exit_code"]:
+        bad.append("exit code %d != %d (%s)" % (rc, case["exit_code"], err_text[-300:]))
+    have = set(os.listdir(outdir)) if os.path.isdir(outdir) else set()
+    for fn, text in case["text"].items():
+        if fn not in have:
+            bad.append("missing " + fn)
+            continue
+        with open(os.path.join(outdir, fn), errors="replace") as f:
+            got = f.read()
+        if got != text:
+            gl, tl = got.splitlines(), text.splitlines()
+            k = next((i for i in range(min(len(gl), len(tl))) if gl[i] != tl[i]), min(len(gl), len(tl)))
+            bad.append("%s differs at line %d: got %r want %r" % (fn, k + 1, gl[k:k + 1], tl[k:k + 1]))
+    for fn, meta in case["fastq"].items():
+        if fn not in have:
+            bad.append("missing " + fn)
+            continue
+        with open(os.path.join(outdir, fn), "rb") as f:
+            data = f.read()
+        if hashlib.md5(data).hexdigest() != meta["md5"]:
+            bad.append("%s: md5 mismatch (records %d vs %d)" % (fn, data.count(b"\n") // 4, meta["records"]))
+    return bad
+
+
+def run_case_binary(case, cache, tmp_path, binary):
+    """Runs a FaQCs-compatible executable (the reference driver linked against integration/trim_shim.cpp) on the
+    case's command line and compares every output file with the reference's own outputs."""
+    import subprocess
+
+    p1, p2 = fixture_paths(case["fixture"], cache)
+    outdir = os.path.join(str(tmp_path), "out")
+    m = {"{1}": p1, "{2}": p2, "{U}": p1, "{D}": outdir, "{ART}": ARTIFACT_FASTA}
+    argv = [m.get(a, a) for a in case["args"]]
+    for _ in range(6):  # the reference driver can die of SIGPIPE feeding the absent R (see make_golden.py)
+        import shutil
+
+        shutil.rmtree(outdir, ignore_errors=True)
+        proc = subprocess.run([binary] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if proc.returncode != -13:
+            break
+    return compare_outputs(case, outdir, proc.returncode, proc.stderr.decode(errors="replace"))

@@ -232,3 +232,21 @@ def test_full_size_properties():
         _check(lib, lib.faqcs_submit_device(eng2.ctx, C.byref(bb), r_ptr))
     assert (eng2.counters() == blk).all()
     assert bool((res2 == res).all())
+
+
+_SHIM_BIN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),
+                                       "oracle", "_ref", "FaQCs_hip")
+
+
+@pytest.mark.parametrize("name", [n for n in __import__("golden_util").case_names() if "kmer" not in n])
+def test_reference_driver_with_hip_trim(name, fixture_cache, tmp_path):
+    """the reference's OWN driver (FaQCs.cpp, options.cpp, fastq.cpp, plot.cpp compiled from where
+    they lie) linked against integration/trim_shim.cpp -> libfaqcs_mi.so must reproduce the reference's outputs."""
+    import os
+
+    from golden_util import load_case, run_case_binary
+
+    if not os.path.exists(_SHIM_BIN):
+        pytest.skip("oracle/_ref/FaQCs_hip not built (needs /root/reference at build time: make -C oracle ref_hip)")
+    bad = run_case_binary(load_case(name), fixture_cache, tmp_path, _SHIM_BIN)
+    assert not bad, "\n".join(bad)
