@@ -5,19 +5,30 @@
 // (trim.cpp:1144-1189).  The reference packs 8 reads into int16 SSE lanes and sweeps the DP matrix row by
 // row; here ONE wavefront owns ONE read and its 64 lanes own 64 DIAGONALS of the (read x adapter) matrix.
 // Ungapped local alignment decouples along diagonals: M(i,j) = max(M(i-1,j-1),0) + s(i,j) is a Kadane
-// recurrence per diagonal, kept entirely in registers; the read's 4-bit IUPAC masks sit in LDS, the
-// adapter's in scalar registers (uniform index).  The reference's "last row-major cell among maxima wins"
-// (seq_overlap.cpp:338-354) becomes a wave max-reduce on the key (M, i, j).
+// recurrence per diagonal.
+//
+// Two stages per (read, adapter):
+//  1. bit-parallel PREFILTER (exact skip test).  match(i,j) = OR_b Qb[i] & Tb[j] over the four base bit-planes
+//     b in {A,C,G,T} of the 4-bit IUPAC masks (seq_overlap.h:133-150).  The read's planes sit in LDS, the
+//     adapter's 32-bit plane words come from scalar loads; a lane builds 32 match bits of its diagonal with
+//     8 LDS reads + 4 v_alignbit + 7 logic ops and popcounts them.  A local alignment of score B has
+//     num_match = (len + B)/2 <= (min(|read|,|adapter|) + matches_on_diagonal)/2, so when that bound is below
+//     the reference's threshold for every diagonal the adapter can neither mask nor be credited
+//     (trim.cpp:1024-1041) and stage 2 is skipped.  Random 150-mers almost never pass.
+//  2. exact per-cell Kadane with start tracking on the surviving (read, adapter) pairs; the reference's
+//     "last row-major cell among maxima wins" (seq_overlap.cpp:338-354) is a wave max-reduce on (M, i, j).
 //
 // Reference quirks reproduced: Q1 group-of-8 threshold from the LAST read of the
 // group / tail group without the min (defined as -t 1 behaviour), Q3 start survives diagonals touching 0,
 // Q4 literal find_mask_range, Q5 IUPAC bit-overlap matching, H2 stale range carried from the previous
-// adapter of the same read when no cell reaches M >= 0.
+// adapter of the same read when no cell reaches M >= 0 (the carried range is computed on demand).
 #include "faqcs_dev.h"
 
 struct AdapterDev {
     const uint8_t *bits;     // concatenated 4-bit IUPAC masks, one byte per base
-    const uint32_t *start;   // [n_adapters + 1]
+    const uint32_t *start;   // [n_adapters + 1] base offsets into bits
+    const uint32_t *planes;  // per adapter word w: 4 dwords = bit-planes A,C,G,T of bases [32w, 32w+32)
+    const uint32_t *wstart;  // [n_adapters + 1] word offsets into planes (in units of words)
     uint32_t n_adapters;
     float match_rate;        // float(1.0 - filterAdapterMismatchRate), trim.cpp:969
 };
@@ -35,19 +46,35 @@ __device__ __forceinline__ uint32_t na_bits(uint32_t c)
     return letter ? (uint32_t)k_iupac[l] : 0u;
 }
 
+// a wave's LDS operations execute in order; this only stops the compiler from moving them across the point
+__device__ __forceinline__ void lds_sync_wave()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int NW, int MAXLEN>
 __global__ __launch_bounds__(NW * 64) void adapter_overlap(
     const AdapterDev A, const uint8_t *__restrict__ seq, const uint32_t *__restrict__ off, const uint32_t n_reads,
     const uint32_t *__restrict__ seg_start, const uint32_t n_segments, uint32_t *__restrict__ ad_sl,
-    uint16_t *__restrict__ ad_hit, uint64_t *__restrict__ adapter_stats, uint32_t *__restrict__ err)
+    uint16_t *__restrict__ ad_hit, uint64_t *__restrict__ adapter_stats, uint32_t *__restrict__ err, const uint32_t dbg)
 {
-    __shared__ uint8_t s_q[NW][MAXLEN];       // the read's IUPAC masks
-    __shared__ uint8_t s_mask[NW][MAXLEN];    // vector<bool> mask of trim.cpp:991 (1 = unmasked)
+    constexpr int QW = MAXLEN / 32;            // data dwords per plane
+    constexpr int PW = QW + 4;                 // + two zero dwords on each side
+    __shared__ uint8_t s_q[NW][MAXLEN];        // the read's IUPAC masks (stage 2)
+    __shared__ uint8_t s_mask[NW][MAXLEN];     // vector<bool> mask of trim.cpp:991 (1 = unmasked)
+    __shared__ uint32_t s_pl[NW][4][PW];       // the read's four base bit-planes, position ordered (stage 1)
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
-    volatile uint8_t *q = s_q[wave];
-    volatile uint8_t *mk = s_mask[wave];
+    // plain (non-volatile) pointers so the accesses stay ds_* instructions (a volatile generic pointer degrades
+    // to flat_load); ordering between the wave's own LDS writes and reads is pinned by lds_sync_wave()
+    uint8_t *q = s_q[wave];
+    uint8_t *mk = s_mask[wave];
+    uint32_t *pl = &s_pl[wave][0][0];
     const uint32_t n_waves = gridDim.x * NW;
+
+    for (int i = lane; i < 4 * PW; i += 64) pl[i] = 0u; // pads stay zero for the whole kernel
+    lds_sync_wave();
 
 #pragma unroll 1
     for (uint32_t r = blockIdx.x * NW + wave; r < n_reads; r += n_waves) {
@@ -61,66 +88,123 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
         const bool tail = g_last >= s1;
         const int len8 = tail ? 0 : (int)(off[g_last + 1] - off[g_last]);
 
-        // ---- pack_query: bases -> IUPAC bit masks in LDS --------------------------------------------------
+        // ---- pack_query: bases -> IUPAC bit masks (bytes) and the four bit-planes ----------------------------
         bool badbase = false;
-        for (int p = lane; p < qlen; p += 64) {
-            const uint32_t bits = na_bits(seq[(size_t)o + p]);
-            badbase |= bits == 0u;
-            q[p] = (uint8_t)bits;
-            mk[p] = 1;
+#pragma unroll 1
+        for (int c = 0; c * 64 < MAXLEN; ++c) {
+            const int p = c * 64 + lane;
+            uint32_t bits = 0;
+            if (p < qlen) {
+                bits = na_bits(seq[(size_t)o + p]);
+                badbase |= bits == 0u;
+                q[p] = (uint8_t)bits;
+                mk[p] = 1;
+            }
+            // every chunk is rewritten (zeros past the read) so nothing of the previous read survives
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint64_t m = __ballot((bits >> b) & 1u);
+                if (lane == 0) { pl[b * PW + 2 + 2 * c] = (uint32_t)m; pl[b * PW + 3 + 2 * c] = (uint32_t)(m >> 32); }
+            }
         }
         const bool read_bad = __any(badbase);
-        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS writes are visible to itself in order
-        __builtin_amdgcn_wave_barrier();
+        lds_sync_wave();
+
+        // exact alignment of adapter j: best (M, i, j) over all diagonals -> (score or -1, start, stop)
+        auto align_exact = [&](uint32_t j, int &gM, int &gS, int &gI) {
+            const uint32_t t0 = A.start[j];
+            const int tlen = (int)(A.start[j + 1] - t0);
+            gM = -1; gI = 0; gS = 0;
+            int gJ = 0;
+            const int ndiag = qlen + tlen - 1;
+#pragma unroll 1
+            for (int dd0 = 0; dd0 < ndiag; dd0 += 64) {
+                const int d = dd0 + lane - (qlen - 1);                   // j_t - i on this lane's diagonal
+                const int dlo = dd0 - (qlen - 1), dhi = dlo + 63;
+                const int jt_lo = dlo > 0 ? dlo : 0;
+                const int jt_hi = (dhi + qlen - 1) < (tlen - 1) ? (dhi + qlen - 1) : (tlen - 1);
+                int M = -1, st = 0, bM = -1, bS = 0, bI = 0;
+#pragma unroll 1
+                for (int jt = jt_lo; jt <= jt_hi; ++jt) {
+                    const uint32_t tb = A.bits[t0 + jt];                 // uniform -> scalar load
+                    const int i = jt - d;
+                    const bool valid = (unsigned)i < (unsigned)qlen;
+                    const uint32_t qb = valid ? q[i] : 0u;
+                    const int s = (qb & tb) ? 1 : -1;                    // seq_overlap.cpp:157-161
+                    const int nS = (M < 0) ? i : st;                     // seq_overlap.cpp:255,272-275
+                    const int nM = (M > 0 ? M : 0) + s;                  // seq_overlap.cpp:185-188
+                    M = valid ? nM : -1;
+                    st = nS;
+                    const bool up = valid && nM >= 0 && nM >= bM;        // seq_overlap.cpp:338-354 (>=: later cell wins)
+                    bM = up ? nM : bM; bS = up ? nS : bS; bI = up ? i : bI;
+                }
+                const int Mx = (int)wave_max_u32((uint32_t)(bM + 1)) - 1;
+                if (Mx >= 0) {
+                    const uint32_t key = (bM == Mx) ? ((((uint32_t)bI << 13) | (uint32_t)(bI + d)) + 1u) : 0u;
+                    const uint32_t K = wave_max_u32(key) - 1u;
+                    const int wi = (int)(K >> 13), wj = (int)(K & 8191u);
+                    const int wl = wj - wi + (qlen - 1) - dd0;           // lane that owns the winning diagonal
+                    const int ws = __builtin_amdgcn_readlane(bS, wl);
+                    const bool better = Mx > gM || (Mx == gM && (wi > gI || (wi == gI && wj > gJ)));
+                    if (better) { gM = Mx; gI = wi; gJ = wj; gS = ws; }
+                }
+            }
+        };
 
         int best_score = 0, best_j = -1;
-        bool have = false;
+        bool have = false, known = false;
+        uint32_t last_j = 0;
         int rs = 0, re = 0;
         if (!read_bad && qlen > 0) {
 #pragma unroll 1
             for (uint32_t j = 0; j < A.n_adapters; ++j) {
-                const uint32_t t0 = A.start[j];
-                const int tlen = (int)(A.start[j + 1] - t0);
+                const int tlen = (int)(A.start[j + 1] - A.start[j]);
                 const int m = tail ? tlen : (len8 < tlen ? len8 : tlen);
                 const int thr = (int)__fmul_rn(A.match_rate, (float)m);      // trim.cpp:1007-1008 / :1082
-                // ---- align(): best (M, i, j) over all diagonals ------------------------------------------
-                int gM = -1, gI = 0, gJ = 0, gS = 0;
-                const int ndiag = qlen + tlen - 1;
+                // ---- stage 1: per-diagonal match popcounts -------------------------------------------------
+                bool any_match = true, may_pass = true;
+                if (!(dbg & 8u)) {
+                    const uint32_t w0 = A.wstart[j];
+                    const int nw = (int)(A.wstart[j + 1] - w0);
+                    const int ndiag = qlen + tlen - 1;
+                    uint32_t maxcnt = 0;
 #pragma unroll 1
-                for (int dd0 = 0; dd0 < ndiag; dd0 += 64) {
-                    const int d = dd0 + lane - (qlen - 1);                   // j_t - i on this lane's diagonal
-                    const int dlo = dd0 - (qlen - 1), dhi = dlo + 63;
-                    const int jt_lo = dlo > 0 ? dlo : 0;
-                    const int jt_hi = (dhi + qlen - 1) < (tlen - 1) ? (dhi + qlen - 1) : (tlen - 1);
-                    int M = -1, st = 0, bM = -1, bS = 0, bI = 0;
+                    for (int dd0 = 0; dd0 < ndiag; dd0 += 64) {
+                        const int d = dd0 + lane - (qlen - 1);
+                        uint32_t cnt = 0;
 #pragma unroll 1
-                    for (int jt = jt_lo; jt <= jt_hi; ++jt) {
-                        const uint32_t tb = A.bits[t0 + jt];                 // uniform -> scalar load
-                        const int i = jt - d;
-                        const bool valid = (unsigned)i < (unsigned)qlen;
-                        const uint32_t qb = valid ? q[i] : 0u;
-                        const int s = (qb & tb) ? 1 : -1;                    // seq_overlap.cpp:157-161
-                        const int nS = (M < 0) ? i : st;                     // seq_overlap.cpp:255,272-275
-                        const int nM = (M > 0 ? M : 0) + s;                  // seq_overlap.cpp:185-188
-                        M = valid ? nM : -1;
-                        st = nS;
-                        const bool up = valid && nM >= 0 && nM >= bM;        // seq_overlap.cpp:338-354 (>=: later cell wins)
-                        bM = up ? nM : bM; bS = up ? nS : bS; bI = up ? i : bI;
+                        for (int w = 0; w < nw; ++w) {
+                            const uint32_t tA = A.planes[4 * (w0 + w) + 0], tC = A.planes[4 * (w0 + w) + 1];
+                            const uint32_t tG = A.planes[4 * (w0 + w) + 2], tT = A.planes[4 * (w0 + w) + 3];
+                            const int i0 = 32 * w - d;                   // read position facing adapter base 32w
+                            int idx = i0 >> 5;
+                            idx = idx < -2 ? -2 : (idx > QW ? QW : idx);
+                            const uint32_t sh = (uint32_t)i0 & 31u;
+                            const uint32_t *pp = pl + idx + 2;
+                            const uint32_t qa = __builtin_amdgcn_alignbit(pp[1], pp[0], sh);
+                            const uint32_t qc = __builtin_amdgcn_alignbit(pp[PW + 1], pp[PW], sh);
+                            const uint32_t qg = __builtin_amdgcn_alignbit(pp[2 * PW + 1], pp[2 * PW], sh);
+                            const uint32_t qt = __builtin_amdgcn_alignbit(pp[3 * PW + 1], pp[3 * PW], sh);
+                            cnt += __popc((qa & tA) | (qc & tC) | (qg & tG) | (qt & tT));
+                        }
+                        maxcnt = umax_(maxcnt, cnt);
                     }
-                    const int Mx = (int)wave_max_u32((uint32_t)(bM + 1)) - 1;
-                    if (Mx >= 0) {
-                        const uint32_t key = (bM == Mx) ? ((((uint32_t)bI << 13) | (uint32_t)(bI + d)) + 1u) : 0u;
-                        const uint32_t K = wave_max_u32(key) - 1u;
-                        const int wi = (int)(K >> 13), wj = (int)(K & 8191u);
-                        const int wl = wj - wi + (qlen - 1) - dd0;           // lane that owns the winning diagonal
-                        const int ws = __builtin_amdgcn_readlane(bS, wl);
-                        const bool better = Mx > gM || (Mx == gM && (wi > gI || (wi == gI && wj > gJ)));
-                        if (better) { gM = Mx; gI = wi; gJ = wj; gS = ws; }
-                    }
+                    const int bound = (int)wave_max_u32(maxcnt);             // >= best local-alignment score
+                    any_match = bound > 0;
+                    const int mcap = qlen < tlen ? qlen : tlen;
+                    may_pass = (mcap + bound) / 2 >= thr;
                 }
                 int score = 0;
-                if (gM >= 0) { have = true; rs = gS; re = gI; score = gM; }
-                else if (!have) continue;                                    // H2: unknown stale state -> no hit
+                if (any_match) {
+                    if (!may_pass) { have = true; known = false; last_j = j; continue; } // cannot mask, cannot be credited
+                    int gM, gS, gI;
+                    align_exact(j, gM, gS, gI);
+                    if (gM >= 0) { have = true; known = true; last_j = j; rs = gS; re = gI; score = gM; }
+                    else if (!have) continue;                                // (only reachable with the prefilter disabled)
+                } else {
+                    if (!have) continue;                                     // H2: unknown stale state -> no hit
+                    if (!known) { int gM, gS, gI; align_exact(last_j, gM, gS, gI); rs = gS; re = gI; known = true; }
+                }
                 const int match_length = re - rs + 1;
                 const int num_match = (match_length + score) / 2;            // trim.cpp:1024-1025
                 if (num_match >= thr) {
@@ -132,8 +216,7 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
 
         uint32_t first = 0, second = (uint32_t)qlen;
         if (best_score > 0) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
+            lds_sync_wave();
             // find_mask_range, trim.cpp:1144-1189, literal
             uint32_t longest_run_start = 0, longest_run_length = 0, run_start = 0, run_length = 0;
 #pragma unroll 1
@@ -158,13 +241,13 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
             ad_hit[r] = (uint16_t)(best_score > 0 ? best_j + 1 : 0);
             if (read_bad) atomicOr(err, 2u);
         }
-        __builtin_amdgcn_wave_barrier();
+        lds_sync_wave();
     }
 }
 
 hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
                                 uint32_t max_len, const uint32_t *seg_start, uint32_t n_segments, uint32_t *ad_sl,
-                                uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, int n_cu, hipStream_t st)
+                                uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, uint32_t dbg, int n_cu, hipStream_t st)
 {
     if (n_reads == 0) return hipSuccess;
     if (max_len <= 256) {
@@ -173,14 +256,7 @@ hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const u
         const uint32_t cap = (uint32_t)n_cu * 4u;
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((adapter_overlap<NW, 256>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
-                           n_segments, ad_sl, ad_hit, adapter_stats, err);
-    } else if (max_len <= 4096) {
-        constexpr int NW = 4;
-        uint32_t grid = (n_reads + NW - 1) / NW;
-        const uint32_t cap = (uint32_t)n_cu * 4u;
-        if (grid > cap) grid = cap;
-        hipLaunchKernelGGL((adapter_overlap<NW, 4096>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
-                           n_segments, ad_sl, ad_hit, adapter_stats, err);
+                           n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
     } else {
         return hipErrorInvalidValue;
     }

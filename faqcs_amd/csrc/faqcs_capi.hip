@@ -21,6 +21,8 @@
 struct AdapterDev {
     const uint8_t *bits;
     const uint32_t *start;
+    const uint32_t *planes;
+    const uint32_t *wstart;
     uint32_t n_adapters;
     float match_rate;
 };
@@ -38,7 +40,7 @@ hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, c
                                     int n_cu, hipStream_t st);
 hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
                                 uint32_t max_len, const uint32_t *seg_start, uint32_t n_segments, uint32_t *ad_sl,
-                                uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, int n_cu, hipStream_t st);
+                                uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, uint32_t dbg, int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T, const uint8_t *seq, const uint8_t *qual,
                              const uint32_t *off, uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results,
                              int n_cu, hipStream_t st);
@@ -95,7 +97,7 @@ struct faqcs_ctx {
     // adapters
     std::vector<std::string> adapters;
     uint8_t *d_abits = nullptr;
-    uint32_t *d_astart = nullptr;
+    uint32_t *d_astart = nullptr, *d_aplanes = nullptr, *d_awstart = nullptr;
     float match_rate = 0.f;
     // staging for host submissions
     DevBuf<uint8_t> s_seq, s_qual;
@@ -308,7 +310,20 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
             }
             start.push_back((uint32_t)bits.size());
         }
+        // bit-planes for the prefilter: per adapter word w, 4 dwords (A,C,G,T) over bases [32w, 32w+32)
+        std::vector<uint32_t> planes, wstart(1, 0);
+        for (uint32_t j = 0; j < p->n_adapters; ++j) {
+            const uint32_t L = start[j + 1] - start[j], nw = (L + 31) / 32;
+            for (uint32_t w = 0; w < nw; ++w) {
+                uint32_t pl[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < 32 && 32 * w + k < L; ++k)
+                    for (int b = 0; b < 4; ++b) pl[b] |= (uint32_t)((bits[start[j] + 32 * w + k] >> b) & 1u) << k;
+                planes.insert(planes.end(), pl, pl + 4);
+            }
+            wstart.push_back(wstart.back() + nw);
+        }
         HIPCHK(upload(&c->d_abits, bits)); HIPCHK(upload(&c->d_astart, start));
+        HIPCHK(upload(&c->d_aplanes, planes)); HIPCHK(upload(&c->d_awstart, wstart));
         c->match_rate = (float)(1.0 - (double)p->filterAdapterMismatchRate); // trim.cpp:969
     }
 
@@ -348,7 +363,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->compute) (void)hipStreamSynchronize(c->compute);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart,
+    void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
                     c->kt.keys, c->kt.counts, c->kt.stats, c->d_snaps};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     c->s_seq.release(); c->s_qual.release(); c->s_off.release(); c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
@@ -381,9 +396,9 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         HIPCHK(c->s_sl.reserve(n)); HIPCHK(c->s_hit.reserve(n)); HIPCHK(c->s_seg.reserve(n_seg + 1));
         d_sl = c->s_sl.p; d_hit = c->s_hit.p;
         HIPCHK(hipMemcpyAsync(c->s_seg.p, seg, (n_seg + 1) * 4, hipMemcpyHostToDevice, c->compute));
-        AdapterDev A{c->d_abits, c->d_astart, p.n_adapters, c->match_rate};
+        AdapterDev A{c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart, p.n_adapters, c->match_rate};
         HIPCHK(faqcs_launch_adapter(A, d_seq, d_off, n, max_len, c->s_seg.p, n_seg, d_sl, d_hit,
-                                    c->d_counters + c->lay.adapter_stats, c->d_err, c->n_cu, c->compute));
+                                    c->d_counters + c->lay.adapter_stats, c->d_err, c->dp.dbg, c->n_cu, c->compute));
     }
     if (n) {
         if (c->timing_used == c->timings.size()) {

@@ -72,7 +72,9 @@ __device__ __forceinline__ int bit_m1(uint32_t mask, int j) { return -(int)((mas
 
 } // namespace
 
-template <int C, int NW>
+// WINDOWED: an adapter pre-pass or --5end/--3end can move the window off [0, len); when false (the headline
+// configuration) the prefix sum runs over all positions without per-position window tests.
+template <int C, int NW, bool WINDOWED>
 __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
@@ -196,30 +198,32 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                 if (ret && (n < (int)P.min_len || n == 0)) { fs_blen += n; ++fs_rlen; ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
 
                 // ---- pass 1 over the lane's C positions ---------------------------------------------------
-                uint32_t inc[C];
-                int vq[C], d[C], Pin[C];
+                uint32_t incf[C];          // class word of the base (6-bit count fields A,T,C,G,N)
+                int q[C], Pin[C];          // clamped quality; inclusive prefix sum of (Q - q) up to this position
                 int run, sumv, T, E;
-                uint32_t cntpack, nubits, maxq;
+                uint32_t cntpack, nubits, gubits, maxq;
                 const int pa = pbase - a;
 #pragma unroll 1
                 for (int attempt = 0; attempt < 2; ++attempt) {
+                    uint32_t inc[C];
 #pragma unroll
                     for (int j = 0; j < C; ++j) inc[j] = t_base[(ws[j >> 2] >> (8 * (j & 3))) & 0xffu];
-                    run = 0; sumv = 0; cntpack = 0; nubits = 0; maxq = 0;
+                    run = 0; sumv = 0; cntpack = 0; nubits = 0; gubits = 0; maxq = 0;
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
                         const int sq = (int)(int8_t)((wq[j >> 2] >> (8 * (j & 3))) & 0xffu);
                         const int v = sq - in_off;                              // quality_score() before the clamp
-                        const int q = v < 0 ? 0 : v;                            // fastq.h:29
-                        vq[j] = v;
+                        q[j] = v < 0 ? 0 : v;                                   // fastq.h:29
                         sumv += v;
-                        maxq = umax_(maxq, (uint32_t)q);
-                        const bool inw = (unsigned)(pa + j) < (unsigned)n;
-                        d[j] = inw ? Q - q : 0;
-                        run += d[j];
+                        maxq = umax_(maxq, (uint32_t)q[j]);
+                        int dq = Q - q[j];
+                        if (WINDOWED) dq = ((unsigned)(pa + j) < (unsigned)n) ? dq : 0;
+                        run += dq;
                         Pin[j] = run;
                         cntpack += inc[j];
+                        incf[j] = inc[j] & BT_FIELDS;
                         nubits |= ((inc[j] >> 30) & 1u) << j;
+                        if (P.replace_q > 0) gubits |= (inc[j] >> 31) << j;
                     }
                     if (attempt == 1) break;
                     // mask_quality_terminal_N (trim.cpp:1191-1216): upper-case 'N' runs at either end get Q0.
@@ -245,12 +249,14 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                 }
                 {
                     const int incl = row_incl_scan_add(run);
-                    E = incl - run;
+                    E = incl - run;                                  // prefix before this lane's first position
                     T = row_all_sum(run);
+                    // without window masks the zero bytes past the read contributed (Q - 0) each
+                    if (!WINDOWED) T -= Q * (16 * C - len);
                 }
 #pragma unroll
                 for (int j = 0; j < C; ++j) Pin[j] += E;
-                // whole-read sums: base counts (A,T | C,G as 16-bit pairs), N count and sum(raw - offset)
+                // whole-read sums: base counts (A,T | C,G as 16-bit pairs), N count and V = sum(raw - offset)
                 uint32_t pAT, pCG, pN;
                 int V_pre;
                 {
@@ -267,34 +273,41 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                 const bool read_err = row_all_umax(maxq) > 41u;
 
                 // ---- quality trim (trim.cpp:325-360) -----------------------------------------------------
+                int hi_sum = 0, lo_sum = 0;     // BWA_plus by-products: prefix sums of (Q - q) at the two cut points
+                bool have_sums = false;
                 if (do_trim) {
                     int fp3 = n - 1, fp5 = 0;
                     const int a5 = n < 5 ? n : 5, nan2 = n < 2 ? n : 2;
+                    hi_sum = 0; lo_sum = 0;
                     if (P.mode == FAQCS_MODE_BWA_PLUS) {
+                        // Pex[j] (prefix before position j) is Pin[j-1], or E for the lane's first position
                         uint32_t nn = 0;
 #pragma unroll
-                        for (int j = C - 1; j >= 0; --j) nn = (nn << 1) | (uint32_t)((T - Pin[j]) >= 0);
+                        for (int j = C - 1; j >= 0; --j) nn = (nn << 1) | (uint32_t)(Pin[j] <= T);
                         const uint32_t r3 = nn & range_mask<C>(a + nan2 + 1, a + n, pbase);
                         const uint32_t f5 = r3 & range_mask<C>(a + n - a5, a + n, pbase);
                         const uint32_t ext = r3 | (row_next(r3) << C);
                         const uint32_t c3 = ~ext & ~(ext >> 1) & (ext >> 2) & CMASK;
-                        // one butterfly for both: bit 16 = "a reset happens within the first min(5,n) steps", low = 1 + max c3 pos
                         const uint32_t red = row_all_umax((c3 ? (uint32_t)(pbase + (31 - __builtin_clz(c3)) + 1) : 0u));
                         const bool early = row_all_or(f5) != 0u;
                         const int pstar = early ? (int)red - 1 : a + n - a5;
                         const uint32_t vis = range_mask<C>(pstar > a ? pstar : a, a + n, pbase);
-                        uint32_t key = 0;
+                        // lane-local argmax of S = T - Pex (largest position on ties), then one row max
+                        const int TB = T + KEY_BIAS;
+                        uint32_t kl = 0;
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t k = ((uint32_t)(T - Pin[j] + d[j] + KEY_BIAS) << 9) + (uint32_t)(pa + j);
-                            key = umax_(key, k & (uint32_t)bit_m1(vis, j));
+                            const uint32_t k = ((uint32_t)(TB - (j ? Pin[j - 1] : E)) << 4) | (uint32_t)j;
+                            kl = umax_(kl, k & (uint32_t)bit_m1(vis, j));
                         }
-                        const uint32_t K3 = row_all_umax(key);
-                        fp3 = ((int)(K3 >> 9) - KEY_BIAS > 0) ? (int)(K3 & 511u) - 1 : n - 1;
+                        const uint32_t K3 = row_all_umax(kl ? (((kl >> 4) << 9) + (uint32_t)(pa + (int)(kl & 15u))) : 0u);
+                        const int S3 = (int)(K3 >> 9) - KEY_BIAS;
+                        fp3 = (S3 > 0) ? (int)(K3 & 511u) - 1 : n - 1;
+                        hi_sum = (S3 > 0) ? T - S3 : T;                       // sum of (Q-q) over window positions <= fp3
                         if (!P.protect5) {
                             uint32_t np = 0;
 #pragma unroll
-                            for (int j = C - 1; j >= 0; --j) np = (np << 1) | (uint32_t)((Pin[j] - d[j]) >= 0);
+                            for (int j = C - 1; j >= 0; --j) np = (np << 1) | (uint32_t)((j ? Pin[j - 1] : E) >= 0);
                             const uint32_t r5 = np & range_mask<C>(a, a + fp3 - nan2, pbase);
                             const uint32_t g5 = r5 & range_mask<C>(a, a + a5, pbase);
                             const uint32_t ext5 = (r5 << 2) | ((row_prev(r5) >> (C - 2)) & 3u); // bit k <-> position pbase + k - 2
@@ -303,19 +316,22 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                             const bool early5 = row_all_or(g5) != 0u;
                             const int pstar5 = early5 ? 1023 - (int)red5 : a + a5 - 1;
                             const uint32_t vis5 = range_mask<C>(a, (pstar5 + 1 < a + n) ? pstar5 + 1 : a + n, pbase);
-                            uint32_t key5 = 0;
+                            uint32_t kl5 = 0;
 #pragma unroll
                             for (int j = 0; j < C; ++j) {
-                                const uint32_t k = ((uint32_t)(Pin[j] + KEY_BIAS) << 9) + (uint32_t)(511 - (pa + j));
-                                key5 = umax_(key5, k & (uint32_t)bit_m1(vis5, j));
+                                const uint32_t k = ((uint32_t)(Pin[j] + KEY_BIAS) << 4) | (uint32_t)(15 - j);
+                                kl5 = umax_(kl5, k & (uint32_t)bit_m1(vis5, j));
                             }
-                            const uint32_t K5 = row_all_umax(key5);
-                            fp5 = ((int)(K5 >> 9) - KEY_BIAS > 0) ? 511 - (int)(K5 & 511u) + 1 : 0;
+                            const uint32_t K5 = row_all_umax(kl5 ? (((kl5 >> 4) << 9) + (uint32_t)(511 - (pa + 15 - (int)(kl5 & 15u)))) : 0u);
+                            const int S5 = (int)(K5 >> 9) - KEY_BIAS;
+                            fp5 = (S5 > 0) ? 511 - (int)(K5 & 511u) + 1 : 0;
+                            lo_sum = (S5 > 0) ? S5 : 0;                       // sum of (Q-q) over window positions < fp5
                         }
+                        have_sums = true;
                     } else if (P.mode == FAQCS_MODE_BWA) { // trim.cpp:675-709
                         uint32_t neg = 0;
 #pragma unroll
-                        for (int j = C - 1; j >= 0; --j) neg = (neg << 1) | (uint32_t)((T - Pin[j]) < 0);
+                        for (int j = C - 1; j >= 0; --j) neg = (neg << 1) | (uint32_t)(Pin[j] > T);
                         neg &= range_mask<C>(a, a + n, pbase);
                         const int pf = (int)row_all_umax(neg ? (uint32_t)(pbase + (31 - __builtin_clz(neg)) + 1) : 0u) - 1; // -1: none
                         const int lo = (pf < a ? a : pf) + 1;
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                         uint32_t key = 0;
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t k = ((uint32_t)(T - Pin[j] + d[j] + KEY_BIAS) << 9) + (uint32_t)(pa + j);
+                            const uint32_t k = ((uint32_t)(T - (j ? Pin[j - 1] : E) + KEY_BIAS) << 9) + (uint32_t)(pa + j);
                             key = umax_(key, k & (uint32_t)bit_m1(vis, j));
                         }
                         const uint32_t K3 = row_all_umax(key);
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                     } else { // HARD, trim.cpp:629-672
                         uint32_t h0 = 0;
 #pragma unroll
-                        for (int j = C - 1; j >= 0; --j) h0 = (h0 << 1) | (uint32_t)(Q < (vq[j] < 0 ? 0 : vq[j]));
+                        for (int j = C - 1; j >= 0; --j) h0 = (h0 << 1) | (uint32_t)(Q < q[j]);
                         h0 &= range_mask<C>(a, a + n, pbase);
                         const uint32_t h1 = h0 & range_mask<C>(a + 1, a + n, pbase);
                         const int h = (int)row_all_umax(h1 ? (uint32_t)(pbase + (31 - __builtin_clz(h1)) + 1) : 0u) - 1;
@@ -396,32 +412,39 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                     }
                 }
 
-                // counts inside the final window, after G -> N (trim.cpp:390-403); inc2[] = per-position class word
+                // counts inside the final window, after G -> N (trim.cpp:390-403)
                 uint32_t cAT = pAT, cCG = pCG, cN = pN;
                 int V_post = V_pre;
-                uint32_t inc2[C];
-                {
+                uint32_t repbits = 0;           // positions whose 'G' becomes 'N'
+                if (P.replace_q > 0) {
+#pragma unroll
+                    for (int j = 0; j < C; ++j) repbits |= (uint32_t)(q[j] < (int)P.replace_q) << j;
+                    repbits &= gubits & win2;
+                }
+                if (__any(ret && (!whole || repbits))) {
                     uint32_t cp = 0;
-                    int sv = 0;
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
-                        uint32_t w = inc[j] & BT_FIELDS;
-                        if (P.replace_q > 0) {
-                            const int q = vq[j] < 0 ? 0 : vq[j];
-                            if ((inc[j] & BT_IS_GU) && q < (int)P.replace_q) w = 1u << BT_SHIFT(4);
-                        }
-                        const uint32_t m = (uint32_t)bit_m1(win2, j);
-                        inc2[j] = w & m;
-                        cp += inc2[j];
-                        sv += vq[j] & (int)m;
+                        const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
+                        cp += w & (uint32_t)bit_m1(win2, j);
                     }
-                    if (__any(ret && (!whole || P.replace_q > 0))) {
-                        const uint32_t at = (cp & 63u) | (((cp >> 6) & 63u) << 16), cg = ((cp >> 12) & 63u) | (((cp >> 18) & 63u) << 16);
-                        cAT = (uint32_t)row_all_sum((int)at);
-                        cCG = (uint32_t)row_all_sum((int)cg);
-                        const int both = row_all_sum((((int)((cp >> 24) & 63u)) << 20) + (sv + (1 << 14)));
-                        cN = (uint32_t)both >> 20;
-                        V_post = (int)((uint32_t)both & 0xfffffu) - (16 << 14);
+                    const uint32_t at = (cp & 63u) | (((cp >> 6) & 63u) << 16), cg = ((cp >> 12) & 63u) | (((cp >> 18) & 63u) << 16);
+                    cAT = (uint32_t)row_all_sum((int)at);
+                    cCG = (uint32_t)row_all_sum((int)cg);
+                    cN = (uint32_t)row_all_sum((int)((cp >> 24) & 63u));
+                    // V_post = sum over the final window of (raw - offset).  With no raw byte below the offset it is
+                    // n*Q - sum(Q - q), and BWA_plus already produced both partial sums; otherwise re-add per position.
+                    const bool clean = V_pre == len * Q - (WINDOWED ? 0 : T) && !WINDOWED; // all v == q over the whole read
+                    if (__all(!ret || (clean && have_sums))) {
+                        V_post = n * Q - (hi_sum - lo_sum);
+                    } else {
+                        int sv = 0;
+#pragma unroll
+                        for (int j = 0; j < C; ++j) {
+                            const int sq = (int)(int8_t)((wq[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                            sv += (sq - in_off) & bit_m1(win2, j);
+                        }
+                        V_post = row_all_sum(sv);
                     }
                 }
                 const uint32_t cA = cAT & 0xffffu, cT = cAT >> 16, cC = cCG & 0xffffu, cG = cCG >> 16;
@@ -441,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                         uint32_t cls[C];
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t w = inc2[j] & 0xffffffu;
+                            const uint32_t w = (((repbits >> j) & 1u) ? 0u : incf[j] & 0xffffffu) & (uint32_t)bit_m1(win2, j);
                             cls[j] = w ? (uint32_t)(__builtin_ctz(w) / 6) : 7u;
                         }
                         const uint32_t prev_last = row_prev(cls[C - 1] + 1u); // 0 at the row edge
@@ -469,17 +492,17 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                 // ---- accumulate: position x quality (LDS) and position x base (registers) -----------------
                 if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
                 if (!(P.dbg & 2u)) {
+                    // branch-free: a position outside the read adds 0 to a valid address
                     const uint32_t inr = (act && !read_err) ? range_mask<C>(0, len, pbase) : 0u;
-                    const uint32_t postm = ret ? win2 : 0u;
+                    const uint32_t postm = ret ? (win2 & inr) : 0u;
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
-                        if ((inr >> j) & 1u) {
-                            const int q = vq[j] < 0 ? 0 : vq[j];
-                            const uint32_t post = (postm >> j) & 1u;
-                            atomicAdd(&hq[q * W + pbase + j], 1u | (post << 16));
-                            bpre[j] += inc[j] & BT_FIELDS;
-                            bpost[j] += post ? inc2[j] : 0u;
-                        }
+                        const uint32_t in1 = (inr >> j) & 1u, post = (postm >> j) & 1u;
+                        const int qq = read_err ? 0 : q[j];
+                        atomicAdd(&hq[qq * W + pbase + j], in1 | (post << 16));
+                        bpre[j] += incf[j] & (uint32_t)(-(int)in1);
+                        const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
+                        bpost[j] += w & (uint32_t)(-(int)post);
                     }
                 }
 
@@ -657,7 +680,7 @@ __global__ __launch_bounds__(NT) void composition_histogram(const unsigned long 
 }
 
 // ---- launch wrappers ---------------------------------------------------------------------------------------
-template <int C, int NW>
+template <int C, int NW, bool WINDOWED>
 static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                 uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
                                 unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
@@ -665,7 +688,7 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
 {
     constexpr size_t lds = (size_t)RowCfg<C>::LDS_DWORDS * 4;
     static bool attr_set = false;
-    auto kern = trim_filter_accumulate<C, NW>;
+    auto kern = trim_filter_accumulate<C, NW, WINDOWED>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -690,7 +713,10 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
                              uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
 {
-#define FAQCS_TRIM_CASE(C, NW) return launch_trim_t<C, NW>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st)
+    const bool windowed = P.has_adapters || ((P.trim5 || P.trim3) && !P.qc_only);
+#define FAQCS_TRIM_CASE(C, NW)                                                                                                       \
+    return windowed ? launch_trim_t<C, NW, true>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st) \
+                    : launch_trim_t<C, NW, false>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st)
     if (max_len <= 64) FAQCS_TRIM_CASE(4, 8);
     if (max_len <= 112) FAQCS_TRIM_CASE(7, 8);
     if (max_len <= 160) FAQCS_TRIM_CASE(10, 8);
