@@ -108,7 +108,8 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfaqcs_mi.so")
+    # FAQCS_MI_LIB lets a tuning run point at an alternative build of the same library
+    return os.environ.get("FAQCS_MI_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfaqcs_mi.so")
 
 
 def load_library():

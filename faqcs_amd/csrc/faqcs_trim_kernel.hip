@@ -72,10 +72,17 @@ __device__ __forceinline__ int bit_m1(uint32_t mask, int j) { return -(int)((mas
 
 } // namespace
 
+#ifndef FAQCS_TRIM_NW
+#define FAQCS_TRIM_NW 4        /* waves per block (A/B on MI355X: 4 waves x 3 blocks/CU beat 8 x 1 by 9 %) */
+#endif
+#ifndef FAQCS_TRIM_MINWAVES
+#define FAQCS_TRIM_MINWAVES 3  /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
+#endif
+
 // WINDOWED: an adapter pre-pass or --5end/--3end can move the window off [0, len); when false (the headline
 // configuration) the prefix sum runs over all positions without per-position window tests.
 template <int C, int NW, bool WINDOWED>
-__global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
+__global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accumulate(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
@@ -493,16 +500,28 @@ __global__ __launch_bounds__(NW * 64) void trim_filter_accumulate(
                 if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
                 if (!(P.dbg & 2u)) {
                     // branch-free: a position outside the read adds 0 to a valid address
+                    // (bytes past the read are zero -> class word 0 and quality column 0 with increment 0; a read with
+                    //  Q > 41 aborts the whole run, fastq.h:31-33, so its row only has to stay inside the tables)
                     const uint32_t inr = (act && !read_err) ? range_mask<C>(0, len, pbase) : 0u;
                     const uint32_t postm = ret ? (win2 & inr) : 0u;
+                    const uint32_t both = inr | (postm << 16);
+                    if (P.replace_q > 0) {
 #pragma unroll
-                    for (int j = 0; j < C; ++j) {
-                        const uint32_t in1 = (inr >> j) & 1u, post = (postm >> j) & 1u;
-                        const int qq = read_err ? 0 : q[j];
-                        atomicAdd(&hq[qq * W + pbase + j], in1 | (post << 16));
-                        bpre[j] += incf[j] & (uint32_t)(-(int)in1);
-                        const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
-                        bpost[j] += w & (uint32_t)(-(int)post);
+                        for (int j = 0; j < C; ++j) {
+                            const int qq = read_err ? 0 : q[j];
+                            atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
+                            bpre[j] += read_err ? 0u : incf[j];
+                            const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
+                            bpost[j] += w & (uint32_t)bit_m1(postm, j);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < C; ++j) {
+                            const int qq = read_err ? 0 : q[j];
+                            atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
+                            bpre[j] += read_err ? 0u : incf[j];
+                            bpost[j] += incf[j] & (uint32_t)bit_m1(postm, j);
+                        }
                     }
                 }
 
@@ -696,7 +715,7 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
     }
     const uint32_t chunks = (n_reads + 63) / 64;
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    const int by_waves = 16 / NW; // aim at <= 16 resident waves per CU (VGPR-bound kernel)
+    const int by_waves = (4 * (FAQCS_TRIM_MINWAVES > 2 ? FAQCS_TRIM_MINWAVES : 2) + NW - 1) / NW; // resident waves per CU the registers allow
     if (blocks_per_cu > by_waves) blocks_per_cu = by_waves;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint32_t grid = (chunks + NW - 1) / NW;
@@ -717,11 +736,11 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
 #define FAQCS_TRIM_CASE(C, NW)                                                                                                       \
     return windowed ? launch_trim_t<C, NW, true>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st) \
                     : launch_trim_t<C, NW, false>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st)
-    if (max_len <= 64) FAQCS_TRIM_CASE(4, 8);
-    if (max_len <= 112) FAQCS_TRIM_CASE(7, 8);
-    if (max_len <= 160) FAQCS_TRIM_CASE(10, 8);
-    if (max_len <= 208) FAQCS_TRIM_CASE(13, 8);
-    if (max_len <= 256) FAQCS_TRIM_CASE(16, 8);
+    if (max_len <= 64) FAQCS_TRIM_CASE(4, FAQCS_TRIM_NW);
+    if (max_len <= 112) FAQCS_TRIM_CASE(7, FAQCS_TRIM_NW);
+    if (max_len <= 160) FAQCS_TRIM_CASE(10, FAQCS_TRIM_NW);
+    if (max_len <= 208) FAQCS_TRIM_CASE(13, FAQCS_TRIM_NW);
+    if (max_len <= 256) FAQCS_TRIM_CASE(16, FAQCS_TRIM_NW);
 #undef FAQCS_TRIM_CASE
     return hipErrorInvalidValue;
 }
