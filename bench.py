@@ -193,7 +193,9 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config)
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                # measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied);
+                # stored per read, scaled to this run's launch size
+                traffic = int(json.load(open(tf))["hbm_bytes_per_read"] * reads_per_launch)
             except Exception:
                 traffic = None
         out = {
@@ -202,7 +204,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synthetic %.0fM-pair 2x%dbp Q33 reads resident in HBM per GPU, BWA_plus -q 5 --min_L 50%s, "
                                    "1 step = 1 pass (trim_filter_accumulate%s + counter all-reduce)"
-                                   % (n_reads / 2e6, L, " --adapter --polyA (5%% read-through)" if a.config == "adapter" else "",
+                                   % (n_reads / 2e6, L, " --adapter --polyA (5 percent read-through)" if a.config == "adapter" else "",
                                       " after adapter_overlap" if a.config == "adapter" else ""),
                        "pairs_per_gpu": n_reads // 2, "read_len": L, "launches_per_step": len(batches) * (2 if a.config == "adapter" else 1),
                        "M_pairs_per_s": round(value / 2, 3)},

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 // ---- final window: poly-N, counts, sum(raw - offset) ---------------------------------------
                 const uint32_t win2 = range_mask<C>(a, a + n, pbase);
                 const bool whole = (a == 0 && n == len);
-                if (ret) { // poly-N filter (trim.cpp:363-371, :578-597): upper-case 'N' runs only
+                if (ret && !(P.dbg & 16u)) { // poly-N filter (trim.cpp:363-371, :578-597): upper-case 'N' runs only
                     const uint32_t K = P.max_poly_n;
                     const uint32_t nw = nubits & win2;
                     bool trip;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     for (int j = 0; j < C; ++j) repbits |= (uint32_t)(q[j] < (int)P.replace_q) << j;
                     repbits &= gubits & win2;
                 }
-                if (__any(ret && (!whole || repbits))) {
+                if (!(P.dbg & 16u) && __any(ret && (!whole || repbits))) {
                     uint32_t cp = 0;
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 if (ret && P.avgq_on && V_post < t_avgq[n]) { fs_bavg += n; ++fs_ravg; ret = false; filt = FAQCS_FILT_AVG_Q; }
 
                 // ---- low-complexity filter (trim.cpp:405-513) ----------------------------------------------
-                if (ret) {
+                if (ret && !(P.dbg & 16u)) {
                     const uint32_t thr = t_lc[n];
                     const uint32_t mthr = thr & 0xffffu, dthr = thr >> 16;
                     bool trip = cA >= mthr || cT >= mthr || cG >= mthr || cC >= mthr;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     if (ret && V_post > 0) qb_post = n == 1 ? V_post : (int)__umulhi((uint32_t)V_post, t_magic[n]);
                     qb_pre = qb_pre > 41 ? 41 : qb_pre;
                     qb_post = qb_post > 41 ? 41 : qb_post;
-                    if (!(P.dbg & 2u) && !read_err) {
+                    if (!(P.dbg & 34u) && !read_err) {
                         // lanes 0..5 of the row each issue one small-histogram update
                         uint32_t *dst = hlen + len;
                         uint32_t val = 1u;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                                                   ((unsigned long long)cC << 27) | ((unsigned long long)cG << 36) | ((unsigned long long)cN << 45);
                     const uint32_t lo = ret ? ((uint32_t)a | ((uint32_t)n << 16)) : 0u;
                     const uint32_t hi = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT);
-                    if (rl == t) {
+                    if (rl == t && !(P.dbg & 32u)) {
                         res_lo = lo; res_hi = hi;
                         rpre = (act && !read_err) ? rp : 0ull;
                         rpost = (ret && !read_err) ? rq : 0ull;
