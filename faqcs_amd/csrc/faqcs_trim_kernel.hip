@@ -81,7 +81,9 @@ __device__ __forceinline__ int bit_m1(uint32_t mask, int j) { return -(int)((mas
 
 // WINDOWED: an adapter pre-pass or --5end/--3end can move the window off [0, len); when false (the headline
 // configuration) the prefix sum runs over all positions without per-position window tests.
-template <int C, int NW, bool WINDOWED>
+// GENERIC: false = the headline option set (BWA_plus, 5' trimming on, not --qc_only, no --replace_to_N_q, no
+// --avg_q, -n 2) is compiled in, so those tests and their live scalars disappear from the loop.
+template <int C, int NW, bool WINDOWED, bool GENERIC>
 __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accumulate(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
@@ -120,7 +122,14 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
     constexpr uint32_t REG_FLUSH_EVERY = 3; // 3 chunks x 16 reads per row = 48 <= 63 (6-bit fields)
 
     const int in_off = P.in_off, Q = P.Q;
-    const bool do_trim = !P.qc_only && !(P.dbg & 4u);
+    const int o_mode = GENERIC ? P.mode : (int)FAQCS_MODE_BWA_PLUS;
+    const bool o_protect5 = GENERIC ? P.protect5 != 0 : false;
+    const bool o_qc_only = GENERIC ? P.qc_only != 0 : false;
+    const uint32_t o_replace_q = GENERIC ? P.replace_q : 0u;
+    const bool o_avgq_on = GENERIC ? P.avgq_on != 0 : false;
+    const uint32_t o_dbg = GENERIC ? P.dbg : 0u;
+    const uint32_t o_max_poly_n = GENERIC ? P.max_poly_n : 2u;
+    const bool do_trim = !o_qc_only && !(o_dbg & 4u);
     uint32_t bpre[C], bpost[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) { bpre[j] = 0; bpost[j] = 0; }
@@ -195,12 +204,12 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     a = mod ? first : 0; n = mod ? second : len;
                     flags = mod ? FAQCS_F_ADAPTER : 0u;
                 }
-                if (P.trim5 && !P.qc_only) {
+                if (P.trim5 && !o_qc_only) {
                     const bool over = (int)P.trim5 > n;
                     a = over ? a : a + (int)P.trim5;
                     n = over ? 0 : n - (int)P.trim5;
                 }
-                if (P.trim3 && !P.qc_only) n = (int)P.trim3 > n ? 0 : n - (int)P.trim3;
+                if (P.trim3 && !o_qc_only) n = (int)P.trim3 > n ? 0 : n - (int)P.trim3;
                 bool ret = act;
                 if (ret && (n < (int)P.min_len || n == 0)) { fs_blen += n; ++fs_rlen; ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
 
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         cntpack += inc[j];
                         incf[j] = inc[j] & BT_FIELDS;
                         nubits |= ((inc[j] >> 30) & 1u) << j;
-                        if (P.replace_q > 0) gubits |= (inc[j] >> 31) << j;
+                        if (o_replace_q > 0) gubits |= (inc[j] >> 31) << j;
                     }
                     if (attempt == 1) break;
                     // mask_quality_terminal_N (trim.cpp:1191-1216): upper-case 'N' runs at either end get Q0.
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     int fp3 = n - 1, fp5 = 0;
                     const int a5 = n < 5 ? n : 5, nan2 = n < 2 ? n : 2;
                     hi_sum = 0; lo_sum = 0;
-                    if (P.mode == FAQCS_MODE_BWA_PLUS) {
+                    if (o_mode == FAQCS_MODE_BWA_PLUS) {
                         // Pex[j] (prefix before position j) is Pin[j-1], or E for the lane's first position
                         uint32_t nn = 0;
 #pragma unroll
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         const int S3 = (int)(K3 >> 9) - KEY_BIAS;
                         fp3 = (S3 > 0) ? (int)(K3 & 511u) - 1 : n - 1;
                         hi_sum = (S3 > 0) ? T - S3 : T;                       // sum of (Q-q) over window positions <= fp3
-                        if (!P.protect5) {
+                        if (!o_protect5) {
                             uint32_t np = 0;
 #pragma unroll
                             for (int j = C - 1; j >= 0; --j) np = (np << 1) | (uint32_t)((j ? Pin[j - 1] : E) >= 0);
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                             lo_sum = (S5 > 0) ? S5 : 0;                       // sum of (Q-q) over window positions < fp5
                         }
                         have_sums = true;
-                    } else if (P.mode == FAQCS_MODE_BWA) { // trim.cpp:675-709
+                    } else if (o_mode == FAQCS_MODE_BWA) { // trim.cpp:675-709
                         uint32_t neg = 0;
 #pragma unroll
                         for (int j = C - 1; j >= 0; --j) neg = (neg << 1) | (uint32_t)(Pin[j] > T);
@@ -360,14 +369,14 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         const int h = (int)row_all_umax(h1 ? (uint32_t)(pbase + (31 - __builtin_clz(h1)) + 1) : 0u) - 1;
                         int pos3 = 0;
                         if (h >= 0) { fp3 = h - a; pos3 = fp3; }
-                        if (!P.protect5) {
+                        if (!o_protect5) {
                             const uint32_t lm = row_all_umax(h0 ? (uint32_t)(1023 - (pbase + __builtin_ctz(h0))) : 0u);
                             const int l = lm ? 1023 - (int)lm - a : 0x7fffffff;
                             if (l < pos3) fp5 = l;
                         }
                     }
                     if (ret) {
-                        const int kept = (P.mode == FAQCS_MODE_BWA_PLUS && fp3 <= fp5) ? 0 : fp3 - fp5 + 1;
+                        const int kept = (o_mode == FAQCS_MODE_BWA_PLUS && fp3 <= fp5) ? 0 : fp3 - fp5 + 1;
                         if (kept != n) { fs_bqt += (uint32_t)(n - kept); ++fs_rqt; flags |= FAQCS_F_QUAL_TRIMMED; }
                         a += fp5;
                         n = kept;
@@ -378,8 +387,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 // ---- final window: poly-N, counts, sum(raw - offset) ---------------------------------------
                 const uint32_t win2 = range_mask<C>(a, a + n, pbase);
                 const bool whole = (a == 0 && n == len);
-                if (ret && !(P.dbg & 16u)) { // poly-N filter (trim.cpp:363-371, :578-597): upper-case 'N' runs only
-                    const uint32_t K = P.max_poly_n;
+                if (ret && !(o_dbg & 16u)) { // poly-N filter (trim.cpp:363-371, :578-597): upper-case 'N' runs only
+                    const uint32_t K = o_max_poly_n;
                     const uint32_t nw = nubits & win2;
                     bool trip;
                     if (K == 0) trip = true;
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     }
                     if (trip) {
                         fs_bnn += n; ++fs_rnn; flags |= FAQCS_F_POLY_N_SEEN;
-                        if (!P.qc_only) { ret = false; filt = FAQCS_FILT_POLY_N; }
+                        if (!o_qc_only) { ret = false; filt = FAQCS_FILT_POLY_N; }
                     }
                 }
 
@@ -423,12 +432,12 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 uint32_t cAT = pAT, cCG = pCG, cN = pN;
                 int V_post = V_pre;
                 uint32_t repbits = 0;           // positions whose 'G' becomes 'N'
-                if (P.replace_q > 0) {
+                if (o_replace_q > 0) {
 #pragma unroll
-                    for (int j = 0; j < C; ++j) repbits |= (uint32_t)(q[j] < (int)P.replace_q) << j;
+                    for (int j = 0; j < C; ++j) repbits |= (uint32_t)(q[j] < (int)o_replace_q) << j;
                     repbits &= gubits & win2;
                 }
-                if (!(P.dbg & 16u) && __any(ret && (!whole || repbits))) {
+                if (!(o_dbg & 16u) && __any(ret && (!whole || repbits))) {
                     uint32_t cp = 0;
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
@@ -457,10 +466,10 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 const uint32_t cA = cAT & 0xffffu, cT = cAT >> 16, cC = cCG & 0xffffu, cG = cCG >> 16;
 
                 // ---- average quality (trim.cpp:374-382) ----------------------------------------------------
-                if (ret && P.avgq_on && V_post < t_avgq[n]) { fs_bavg += n; ++fs_ravg; ret = false; filt = FAQCS_FILT_AVG_Q; }
+                if (ret && o_avgq_on && V_post < t_avgq[n]) { fs_bavg += n; ++fs_ravg; ret = false; filt = FAQCS_FILT_AVG_Q; }
 
                 // ---- low-complexity filter (trim.cpp:405-513) ----------------------------------------------
-                if (ret && !(P.dbg & 16u)) {
+                if (ret && !(o_dbg & 16u)) {
                     const uint32_t thr = t_lc[n];
                     const uint32_t mthr = thr & 0xffffu, dthr = thr >> 16;
                     bool trip = cA >= mthr || cT >= mthr || cG >= mthr || cC >= mthr;
@@ -498,14 +507,14 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 
                 // ---- accumulate: position x quality (LDS) and position x base (registers) -----------------
                 if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
-                if (!(P.dbg & 2u)) {
+                if (!(o_dbg & 2u)) {
                     // branch-free: a position outside the read adds 0 to a valid address
                     // (bytes past the read are zero -> class word 0 and quality column 0 with increment 0; a read with
                     //  Q > 41 aborts the whole run, fastq.h:31-33, so its row only has to stay inside the tables)
                     const uint32_t inr = (act && !read_err) ? range_mask<C>(0, len, pbase) : 0u;
                     const uint32_t postm = ret ? (win2 & inr) : 0u;
                     const uint32_t both = inr | (postm << 16);
-                    if (P.replace_q > 0) {
+                    if (o_replace_q > 0) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = read_err ? 0 : q[j];
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     if (ret && V_post > 0) qb_post = n == 1 ? V_post : (int)__umulhi((uint32_t)V_post, t_magic[n]);
                     qb_pre = qb_pre > 41 ? 41 : qb_pre;
                     qb_post = qb_post > 41 ? 41 : qb_post;
-                    if (!(P.dbg & 34u) && !read_err) {
+                    if (!(o_dbg & 34u) && !read_err) {
                         // lanes 0..5 of the row each issue one small-histogram update
                         uint32_t *dst = hlen + len;
                         uint32_t val = 1u;
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                                                   ((unsigned long long)cC << 27) | ((unsigned long long)cG << 36) | ((unsigned long long)cN << 45);
                     const uint32_t lo = ret ? ((uint32_t)a | ((uint32_t)n << 16)) : 0u;
                     const uint32_t hi = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT);
-                    if (rl == t && !(P.dbg & 32u)) {
+                    if (rl == t && !(o_dbg & 32u)) {
                         res_lo = lo; res_hi = hi;
                         rpre = (act && !read_err) ? rp : 0ull;
                         rpost = (ret && !read_err) ? rq : 0ull;
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(NT) void composition_histogram(const unsigned long 
 }
 
 // ---- launch wrappers ---------------------------------------------------------------------------------------
-template <int C, int NW, bool WINDOWED>
+template <int C, int NW, bool WINDOWED, bool GENERIC>
 static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                 uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
                                 unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
@@ -707,7 +716,7 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
 {
     constexpr size_t lds = (size_t)RowCfg<C>::LDS_DWORDS * 4;
     static bool attr_set = false;
-    auto kern = trim_filter_accumulate<C, NW, WINDOWED>;
+    auto kern = trim_filter_accumulate<C, NW, WINDOWED, GENERIC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -733,15 +742,19 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
                              uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
 {
     const bool windowed = P.has_adapters || ((P.trim5 || P.trim3) && !P.qc_only);
-#define FAQCS_TRIM_CASE(C, NW)                                                                                                       \
-    return windowed ? launch_trim_t<C, NW, true>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st) \
-                    : launch_trim_t<C, NW, false>(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st)
+    const bool generic = !(P.mode == FAQCS_MODE_BWA_PLUS && !P.protect5 && !P.qc_only && P.replace_q == 0 && !P.avgq_on &&
+                           P.max_poly_n == 2 && P.dbg == 0);
+#define FAQCS_TRIM_ARGS P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st
+#define FAQCS_TRIM_CASE(C, NW)                                                                              \
+    return windowed ? (generic ? launch_trim_t<C, NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, NW, true, false>(FAQCS_TRIM_ARGS)) \
+                    : (generic ? launch_trim_t<C, NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, NW, false, false>(FAQCS_TRIM_ARGS))
     if (max_len <= 64) FAQCS_TRIM_CASE(4, FAQCS_TRIM_NW);
     if (max_len <= 112) FAQCS_TRIM_CASE(7, FAQCS_TRIM_NW);
     if (max_len <= 160) FAQCS_TRIM_CASE(10, FAQCS_TRIM_NW);
     if (max_len <= 208) FAQCS_TRIM_CASE(13, FAQCS_TRIM_NW);
     if (max_len <= 256) FAQCS_TRIM_CASE(16, FAQCS_TRIM_NW);
 #undef FAQCS_TRIM_CASE
+#undef FAQCS_TRIM_ARGS
     return hipErrorInvalidValue;
 }
 
