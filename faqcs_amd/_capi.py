@@ -137,6 +137,10 @@ def load_library():
         "faqcs_submit": (i32, [vp, C.POINTER(Batch), vp]),
         "faqcs_submit_device": (i32, [vp, C.POINTER(Batch), vp]),
         "faqcs_sync": (i32, [vp]),
+        "faqcs_submit_async": (i32, [vp, C.POINTER(Batch), vp, C.POINTER(u64)]),
+        "faqcs_wait": (i32, [vp, u64]),
+        "faqcs_host_alloc": (vp, [C.c_size_t]),
+        "faqcs_host_free": (None, [vp]),
         "faqcs_counters_device": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
         "faqcs_finish": (i32, [vp, vp, u64]),
         "faqcs_reset_counters": (i32, [vp]),

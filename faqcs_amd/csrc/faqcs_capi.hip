@@ -99,9 +99,12 @@ struct faqcs_ctx {
     uint8_t *d_abits = nullptr;
     uint32_t *d_astart = nullptr, *d_aplanes = nullptr, *d_awstart = nullptr;
     float match_rate = 0.f;
-    // staging for host submissions
-    DevBuf<uint8_t> s_seq, s_qual;
-    DevBuf<uint32_t> s_off, s_seg, s_sl;
+    // staging for host submissions: two input slots so the H2D copy of batch k+1 overlaps the kernels of batch k
+    struct Slot { DevBuf<uint8_t> seq, qual; DevBuf<uint32_t> off; hipEvent_t done = nullptr; bool used = false; };
+    Slot slot[2];
+    uint64_t n_submits = 0;
+    hipEvent_t ticket_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf<uint32_t> s_seg, s_sl;
     DevBuf<uint16_t> s_hit;
     DevBuf<faqcs_read_result> s_res;
     DevBuf<unsigned long long> s_rec_pre, s_rec_post; // per-read composition records (trim kernel -> composition_histogram)
@@ -285,6 +288,8 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->copied, hipEventDisableTiming));
+    for (auto &sl : c->slot) HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    for (auto &e : c->ticket_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     faqcs_counters_layout(p->max_read_length, p->n_adapters, &c->lay);
 
     std::vector<uint32_t> lcthr, magic, basetab; std::vector<int32_t> avgq; std::vector<float> norm;
@@ -366,7 +371,9 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
                     c->kt.keys, c->kt.counts, c->kt.stats, c->d_snaps};
     for (void *q : ptrs) if (q) (void)hipFree(q);
-    c->s_seq.release(); c->s_qual.release(); c->s_off.release(); c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
+    for (auto &sl : c->slot) { sl.seq.release(); sl.qual.release(); sl.off.release(); if (sl.done) (void)hipEventDestroy(sl.done); }
+    for (auto &e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
+    c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
     c->s_rec_pre.release(); c->s_rec_post.release();
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->compute) (void)hipStreamDestroy(c->compute);
@@ -469,7 +476,7 @@ static int check_segments(const faqcs_batch *b)
     return 0;
 }
 
-extern "C" int faqcs_submit(faqcs_ctx *c, const faqcs_batch *b, faqcs_read_result *results)
+extern "C" int faqcs_submit_async(faqcs_ctx *c, const faqcs_batch *b, faqcs_read_result *results, uint64_t *ticket)
 {
     if (!c) return fail(FAQCS_E_INVAL, "null ctx");
     if (int rc = check_segments(b)) return rc;
@@ -479,22 +486,61 @@ extern "C" int faqcs_submit(faqcs_ctx *c, const faqcs_batch *b, faqcs_read_resul
     if (int rc = scan_offsets(b->offset, n, c->prm.max_read_length, &max_len)) return rc;
     const uint32_t o0 = b->offset[0], o1 = b->offset[n];
     const size_t bytes = (size_t)(o1 - o0);
-    // one compute-stream sync keeps the single staging set safe to overwrite (double buffering: next round)
-    HIPCHK(hipStreamSynchronize(c->compute));
-    HIPCHK(c->s_seq.reserve(bytes + 64)); HIPCHK(c->s_qual.reserve(bytes + 64));
-    HIPCHK(c->s_off.reserve((size_t)n + 1)); HIPCHK(c->s_res.reserve((size_t)n + 1));
+    faqcs_ctx::Slot &sl = c->slot[c->n_submits & 1];
+    hipEvent_t tk = c->ticket_ev[c->n_submits & 7];
+    if (c->n_submits >= 8) HIPCHK(hipEventSynchronize(tk)); // the ticket ring is 8 deep
+    // the slot may still feed the kernels of submission k-2: growing it (hipFree) needs them finished, reusing it
+    // only needs the copy stream to wait for them
+    if (sl.used) {
+        if (bytes + 64 > sl.seq.cap || (size_t)n + 1 > sl.off.cap) HIPCHK(hipEventSynchronize(sl.done));
+        else HIPCHK(hipStreamWaitEvent(c->copy, sl.done, 0));
+    }
+    HIPCHK(sl.seq.reserve(bytes + 64)); HIPCHK(sl.qual.reserve(bytes + 64)); HIPCHK(sl.off.reserve((size_t)n + 1));
+    if ((size_t)n + 1 > c->s_res.cap) HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(c->s_res.reserve((size_t)n + 1));
     // arena bytes land 16 bytes into the staging buffer; the kernels index with the ORIGINAL offsets
     if (bytes) {
-        HIPCHK(hipMemcpyAsync(c->s_seq.p + 16, b->seq + o0, bytes, hipMemcpyHostToDevice, c->copy));
-        HIPCHK(hipMemcpyAsync(c->s_qual.p + 16, b->qual + o0, bytes, hipMemcpyHostToDevice, c->copy));
+        HIPCHK(hipMemcpyAsync(sl.seq.p + 16, b->seq + o0, bytes, hipMemcpyHostToDevice, c->copy));
+        HIPCHK(hipMemcpyAsync(sl.qual.p + 16, b->qual + o0, bytes, hipMemcpyHostToDevice, c->copy));
     }
-    HIPCHK(hipMemcpyAsync(c->s_off.p, b->offset, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->copy));
+    HIPCHK(hipMemcpyAsync(sl.off.p, b->offset, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->copy));
     HIPCHK(hipEventRecord(c->copied, c->copy));
     HIPCHK(hipStreamWaitEvent(c->compute, c->copied, 0));
-    const uint8_t *d_seq = c->s_seq.p + 16 - o0, *d_qual = c->s_qual.p + 16 - o0;
-    if (int rc = enqueue(c, d_seq, d_qual, c->s_off.p, n, max_len, b->segment_start, b->n_segments, c->s_res.p)) return rc;
+    const uint8_t *d_seq = sl.seq.p + 16 - o0, *d_qual = sl.qual.p + 16 - o0;
+    if (int rc = enqueue(c, d_seq, d_qual, sl.off.p, n, max_len, b->segment_start, b->n_segments, c->s_res.p)) return rc;
     if (n && results) HIPCHK(hipMemcpyAsync(results, c->s_res.p, (size_t)n * sizeof(faqcs_read_result), hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipEventRecord(sl.done, c->compute));
+    HIPCHK(hipEventRecord(tk, c->compute));
+    sl.used = true;
+    if (ticket) *ticket = c->n_submits;
+    ++c->n_submits;
     return 0;
+}
+
+extern "C" int faqcs_submit(faqcs_ctx *c, const faqcs_batch *b, faqcs_read_result *results)
+{
+    return faqcs_submit_async(c, b, results, nullptr);
+}
+
+extern "C" int faqcs_wait(faqcs_ctx *c, uint64_t ticket)
+{
+    if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    if (ticket >= c->n_submits) return fail(FAQCS_E_INVAL, "faqcs_wait: unknown ticket");
+    if (ticket + 8 < c->n_submits) return 0; // its event slot has been recycled: the submission finished long ago
+    HIPCHK(hipEventSynchronize(c->ticket_ev[ticket & 7]));
+    return 0;
+}
+
+extern "C" void *faqcs_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void faqcs_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 extern "C" int faqcs_submit_device(faqcs_ctx *c, const faqcs_batch *b, faqcs_read_result *d_results)

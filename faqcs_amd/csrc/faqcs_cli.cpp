@@ -1,0 +1,810 @@
+// faqcs_cli.cpp -- `faqcs_mi`: a FaQCs-compatible command line on top of libfaqcs_mi.so (host code only).
+//
+// Process contract of the reference (FaQCs.cpp:36-151, process_paired :153-538, process_unpaired :540-757,
+// write_stats :759-1034, the --debug tables of plot.cpp:540-733, options.cpp:72-774) with a different
+// architecture: one reader thread per input file parses (gz) FASTQ straight into pinned structure-of-arrays
+// buffers of 32 768 reads (the reference's trim() granularity), the main thread pairs them up and submits
+// them through the pipelined C ABI (faqcs_submit_async), and a writer thread emits the survivors in input
+// order while later buffers are parsed and trimmed.  The per-read hot path runs ONLY on the GPU library.
+#include <zlib.h>
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/faqcs_mi.h"
+
+namespace {
+
+const char *VERSION = "2.10";
+constexpr uint32_t BUF_READS = FAQCS_SEGMENT_READS;
+const int AUTO_OFFSET = -128;
+
+struct Fatal : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// ---------------------------------------------------------------------------------------------------------
+// options (options.cpp:72-774)
+// ---------------------------------------------------------------------------------------------------------
+struct Opt {
+    bool print_usage = false, protect_5 = false, replace_N = false, kmer_rarefaction = false, discard_output = false;
+    bool qc_only = false, trim_only = false, filter_adapter = false, filter_phiX = false, debug = false, version = false;
+    int mode = FAQCS_MODE_BWA_PLUS;
+    std::string prefix = "QC", plots_file, stats_file, in1, in2, inu, out1, out2, outu, outd, output_dir, artifact_file;
+    float average_quality = 0.0f, lc = 0.85f, rate = 0.2f;
+    int in_off = AUTO_OFFSET, out_off = 33, quality = 5;
+    unsigned num_thread = 0, min_len = 50, max_poly_n = 2, kmer = 31, num_subsample = 10, trim_5 = 0, trim_3 = 0, split_size = 1000000,
+             replace_to_N_q = 0;
+    std::vector<std::pair<std::string, std::string>> adapter;
+    std::vector<std::string> messages;
+    bool adapters_active() const { return filter_adapter || filter_phiX; }
+};
+
+const std::pair<const char *, const char *> BUILTIN_ADAPTERS[] = { // options.cpp:583-617
+    {"cre-loxp-forward", "TCGTATAACTTCGTATAATGTATGCTATACGAAGTTATTACG"},
+    {"cre-loxp-reverse", "AGCATATTGAAGCATATTACATACGATATGCTTCAATAATGC"},
+    {"TruSeq-adapter-1", "GGGGTAGTGTGGATCCTCCTCTAGGCAGTTGGGTTATTCTAGAAGCAGATGTGTTGGCTGTTTCTGAAACTCTGGAAAA"},
+    {"TruSeq-adapter-3", "CAACAGCCGGTCAAAACATCTGGAGGGTAAGCCATAAACACCTCAACAGAAAA"},
+    {"PCR-primer-1", "CGATAACTTCGTATAATGTATGCTATACGAAGTTATTACG"},
+    {"PCR-primer-2", "GCATAACTTCGTATAGCATACATTATACGAAGTTATACGA"},
+    {"Nextera-primer-adapter-1", "GATCGGAAGAGCACACGTCTGAACTCCAGTCAC"},
+    {"Nextera-primer-adapter-2", "GATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"},
+    {"Nextera-junction-adapter-1", "CTGTCTCTTATACACATCTAGATGTGTATAAGAGACAG"},
+};
+
+unsigned strtou(const std::string &s)
+{
+    for (char c : s) if (c < '0' || c > '9') throw Fatal("options.cpp:strtou: Invalid character");
+    return s.empty() ? 0u : (unsigned)strtoull(s.c_str(), nullptr, 10);
+}
+
+std::string reverse_complement(const std::string &s) // options.cpp:894-996
+{
+    static const char *from = "ATGCatgcMRSVWYHKDBNmrsvwyhkdbn", *to = "TACGtacgKYSBWRDMHVNkysbwrdmhvn";
+    std::string r(s.rbegin(), s.rend());
+    for (char &c : r) { const char *p = strchr(from, c); if (p && c) c = to[p - from]; }
+    return r;
+}
+
+std::string exe_dir()
+{
+    char buf[4096];
+    ssize_t n = readlink("/proc/self/exe", buf, sizeof(buf) - 1);
+    if (n <= 0) return ".";
+    buf[n] = 0;
+    std::string s(buf);
+    return s.substr(0, s.rfind('/'));
+}
+
+std::string phix_sequence()
+{
+    const std::string path = exe_dir() + "/data/phix174_nc_001422.txt";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) throw Fatal("Unable to open the PhiX174 sequence file " + path);
+    std::string seq; char line[256];
+    while (fgets(line, sizeof(line), f)) {
+        if (line[0] == '#') continue;
+        for (char *p = line; *p; ++p) if (*p > ' ') seq.push_back(*p);
+    }
+    fclose(f);
+    return seq;
+}
+
+void parse_artifact_file(const std::string &path, std::vector<std::pair<std::string, std::string>> &out) // options.cpp:820-891
+{
+    gzFile fin = gzopen(path.c_str(), "r");
+    if (!fin) { fprintf(stderr, "Unable to open %s for loading artifact sequences\n", path.c_str()); throw Fatal("I/O error"); }
+    char buffer[4096];
+    std::string defline, data;
+    while (gzgets(fin, buffer, sizeof(buffer))) {
+        char *ptr = strchr(buffer, '>');
+        if (ptr) {
+            if (!data.empty()) out.emplace_back(defline, data);
+            data.clear();
+            ++ptr;
+            for (char *p = ptr; *p; ++p) if (*p == '\n' || *p == '\r') *p = 0;
+            defline = ptr;
+        } else {
+            for (char *p = buffer; *p; ++p) if (!isspace((unsigned char)*p)) data.push_back(*p);
+        }
+    }
+    if (!data.empty()) out.emplace_back(defline, data);
+    gzclose(fin);
+}
+
+struct LongOpt { const char *name; bool arg; };
+const LongOpt LONG_OPTS[] = {
+    {"mode", true}, {"5end", true}, {"3end", true}, {"adapter", false}, {"rate", true}, {"polyA", false}, {"artifactFile", true},
+    {"min_L", true}, {"avg_q", true}, {"lc", true}, {"phiX", false}, {"ascii", true}, {"out_ascii", true}, {"prefix", true},
+    {"stats", true}, {"split_size", true}, {"qc_only", false}, {"kmer_rarefaction", false}, {"subset", true}, {"discard", false},
+    {"substitute", false}, {"trim_only", false}, {"5trim_off", false}, {"debug", false}, {"version", false}, {"R1", true},
+    {"R2", true}, {"Ru", false}, {"Rd", false}, {"QRpdf", false}, {"replace_to_N_q", true}};
+
+Opt parse_args(int argc, char **argv)
+{
+    Opt o;
+    o.print_usage = argc == 1;
+    bool trim_polyA = false;
+    for (int i = 1; i < argc;) {
+        std::string a = argv[i++];
+        if (a.size() < 2 || a[0] != '-') continue;
+        std::string name = a.substr(a[1] == '-' ? 2 : 1), val;
+        bool has_val = false;
+        const size_t eq = name.find('=');
+        if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); has_val = true; }
+        bool need = false, known = false;
+        for (const LongOpt &lo : LONG_OPTS) if (name == lo.name) { need = lo.arg; known = true; }
+        const std::string shorts = "dtn12pqum";
+        if (!known && name.size() == 1 && (shorts.find(name[0]) != std::string::npos || name == "h" || name == "?")) {
+            known = true; need = shorts.find(name[0]) != std::string::npos;
+        }
+        if (!known && a[1] != '-' && name.size() > 1 && shorts.find(name[0]) != std::string::npos) { // -q5
+            val = name.substr(1); name = name.substr(0, 1); has_val = true; known = true; need = true;
+        }
+        if (!known) { // unique abbreviation, getopt_long_only style
+            const LongOpt *hit = nullptr; int nhit = 0;
+            for (const LongOpt &lo : LONG_OPTS) if (std::string(lo.name).compare(0, name.size(), name) == 0) { hit = &lo; ++nhit; }
+            if (nhit == 1) { name = hit->name; need = hit->arg; known = true; }
+        }
+        if (!known) { o.print_usage = true; continue; }
+        if (need && !has_val) {
+            if (i >= argc) { o.print_usage = true; break; }
+            val = argv[i++];
+        }
+        auto fl = [&](const std::string &v) { return (float)atof(v.c_str()); };
+        if (name == "mode") {
+            std::string m = val; for (char &c : m) c = (char)tolower(c);
+            o.mode = m == "hard" ? FAQCS_MODE_HARD : m == "bwa" ? FAQCS_MODE_BWA : m == "bwa_plus" ? FAQCS_MODE_BWA_PLUS : -1;
+        } else if (name == "5end") o.trim_5 = strtou(val);
+        else if (name == "3end") o.trim_3 = strtou(val);
+        else if (name == "adapter") o.filter_adapter = true;
+        else if (name == "rate") o.rate = fl(val);
+        else if (name == "polyA") trim_polyA = true;
+        else if (name == "artifactFile") { o.artifact_file = val; o.filter_adapter = true; }
+        else if (name == "min_L") o.min_len = strtou(val);
+        else if (name == "avg_q") o.average_quality = fl(val);
+        else if (name == "lc") o.lc = fl(val);
+        else if (name == "phiX") o.filter_phiX = true;
+        else if (name == "ascii") o.in_off = atoi(val.c_str());
+        else if (name == "out_ascii") o.out_off = atoi(val.c_str());
+        else if (name == "prefix") o.prefix = val;
+        else if (name == "stats") o.stats_file = val;
+        else if (name == "split_size") o.split_size = strtou(val);
+        else if (name == "qc_only") o.qc_only = true;
+        else if (name == "kmer_rarefaction") o.kmer_rarefaction = true;
+        else if (name == "subset") o.num_subsample = strtou(val);
+        else if (name == "discard") o.discard_output = true;
+        else if (name == "substitute") o.replace_N = true;
+        else if (name == "trim_only") o.trim_only = true;
+        else if (name == "5trim_off") o.protect_5 = true;
+        else if (name == "debug") o.debug = true;
+        else if (name == "version") o.version = true;
+        else if (name == "R1" || name == "1") o.in1 = val;
+        else if (name == "R2" || name == "2") o.in2 = val;
+        else if (name == "replace_to_N_q") o.replace_to_N_q = strtou(val);
+        else if (name == "u") o.inu = val;
+        else if (name == "d") o.output_dir = val;
+        else if (name == "m") o.kmer = strtou(val);
+        else if (name == "n") o.max_poly_n = strtou(val);
+        else if (name == "q") o.quality = atoi(val.c_str());
+        else if (name == "t") o.num_thread = strtou(val);
+        else if (name == "h" || name == "?") o.print_usage = true;
+    }
+    if (o.print_usage) return o;
+    if (o.version) { o.messages.push_back(std::string("Version: ") + VERSION); o.print_usage = true; return o; }
+    if (o.in1.empty() != o.in2.empty()) { o.print_usage = true; return o; }      // options.cpp:506-518
+    o.num_subsample *= 2;                                                          // options.cpp:519-523 (quirk b)
+    if (o.inu.empty() && o.in1.empty()) { o.print_usage = true; return o; }
+    if (o.kmer < 2 || o.kmer > 31 || o.lc > 1.0f || o.lc < 0.0f || o.rate > 1.0f || o.rate < 0.0f || o.split_size == 0 || o.num_subsample == 0) {
+        o.print_usage = true; return o;
+    }
+    if (o.replace_N) o.messages.push_back("**Warning** \"-substitue\" is not currently implemented");
+    if (o.filter_adapter) for (auto &a : BUILTIN_ADAPTERS) o.adapter.emplace_back(a.first, a.second);
+    if (trim_polyA) o.adapter.emplace_back("polyA", std::string(20, 'A'));
+    if (o.filter_phiX) {
+        const std::string px = phix_sequence();
+        o.adapter.emplace_back("__PhiX174_NC_001422__", px);
+        o.adapter.emplace_back("__PhiX174_NC_001422_complement__", reverse_complement(px));
+    }
+    if (!o.artifact_file.empty()) parse_artifact_file(o.artifact_file, o.adapter);
+    const std::string d = o.output_dir + "/" + o.prefix;
+    if (!o.in1.empty() && !o.in2.empty()) {
+        if (o.out1.empty()) o.out1 = d + ".1.trimmed.fastq";
+        if (o.out2.empty()) o.out2 = d + ".2.trimmed.fastq";
+        if (o.outu.empty()) o.outu = d + ".unpaired.trimmed.fastq";
+        if (o.outd.empty()) o.outd = d + ".discard.trimmed.fastq";
+    }
+    if (!o.inu.empty()) {
+        if (o.outu.empty()) o.outu = d + ".unpaired.trimmed.fastq";
+        if (o.outd.empty()) o.outd = d + ".discard.trimmed.fastq";
+    }
+    if (o.plots_file.empty()) o.plots_file = o.output_dir + "/" + o.prefix + "_qc_report.pdf";
+    if (!o.discard_output) o.outd.clear();
+    if (o.stats_file.empty()) o.stats_file = d + ".stats.txt";
+    if (o.mode == -1) {
+        o.mode = FAQCS_MODE_BWA_PLUS;
+        if (!o.qc_only) o.messages.push_back("Not recognized mode. Bwa extension trimming algorithm is used.");
+    } else if (!o.qc_only) {
+        o.messages.push_back(o.mode == FAQCS_MODE_HARD ? "Hard trimming is used." : o.mode == FAQCS_MODE_BWA ? "Bwa trimming is used." : "Bwa extension trimming is used.");
+    }
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// record buffers + reader threads (fastq.cpp:8-125)
+// ---------------------------------------------------------------------------------------------------------
+struct RecBuf {
+    uint32_t n = 0;
+    bool eof = false;
+    std::string error;           // a parse error is reported when the buffer is consumed (keeps input order)
+    uint8_t *seq = nullptr, *qual = nullptr;
+    size_t cap = 0;              // bytes in seq / qual (pinned)
+    uint32_t *off = nullptr;     // BUF_READS + 1 (pinned)
+    faqcs_read_result *res = nullptr; // BUF_READS (pinned)
+    std::string defs;
+    std::vector<uint32_t> def_off; // n + 1
+    uint64_t ticket = 0;
+
+    void init(size_t bytes)
+    {
+        cap = bytes;
+        seq = (uint8_t *)faqcs_host_alloc(cap + 64); qual = (uint8_t *)faqcs_host_alloc(cap + 64);
+        off = (uint32_t *)faqcs_host_alloc((BUF_READS + 1) * sizeof(uint32_t));
+        res = (faqcs_read_result *)faqcs_host_alloc(BUF_READS * sizeof(faqcs_read_result));
+        if (!seq || !qual || !off || !res) throw Fatal("faqcs_mi: unable to allocate pinned host memory");
+        memset(seq, 0, cap + 64); memset(qual, 0, cap + 64);
+    }
+    void grow(size_t need)
+    {
+        size_t nc = cap * 2;
+        while (nc < need) nc *= 2;
+        uint8_t *s = (uint8_t *)faqcs_host_alloc(nc + 64), *q = (uint8_t *)faqcs_host_alloc(nc + 64);
+        if (!s || !q) throw Fatal("faqcs_mi: unable to allocate pinned host memory");
+        memset(s, 0, nc + 64); memset(q, 0, nc + 64);
+        memcpy(s, seq, cap); memcpy(q, qual, cap);
+        faqcs_host_free(seq); faqcs_host_free(qual);
+        seq = s; qual = q; cap = nc;
+    }
+    void release() { faqcs_host_free(seq); faqcs_host_free(qual); faqcs_host_free(off); faqcs_host_free(res); }
+};
+
+template <class T> class Queue {
+    std::mutex m; std::condition_variable cv; std::deque<T> q;
+public:
+    void push(T v) { { std::lock_guard<std::mutex> l(m); q.push_back(v); } cv.notify_one(); }
+    T pop() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty(); }); T v = q.front(); q.pop_front(); return v; }
+};
+
+class LineReader { // gz or plain, arbitrary line length, \n or \r terminators (fastq.cpp:32-52)
+    gzFile f; std::vector<char> buf; size_t pos = 0, end = 0; bool at_eof = false;
+public:
+    explicit LineReader(gzFile g) : f(g), buf(8 << 20) {}
+    // returns false at EOF with nothing read; the line (without terminator) is appended to `out`
+    template <class Sink> bool line(Sink &&sink, bool &terminated)
+    {
+        bool any = false; terminated = false;
+        for (;;) {
+            if (pos == end) {
+                if (at_eof) return any;
+                const int got = gzread(f, buf.data(), (unsigned)buf.size());
+                if (got <= 0) { at_eof = true; return any; }
+                pos = 0; end = (size_t)got;
+            }
+            char *b = buf.data() + pos;
+            const size_t avail = end - pos;
+            char *nl = (char *)memchr(b, '\n', avail);
+            const size_t take = nl ? (size_t)(nl - b) : avail;
+            // strpbrk("\n\r"): a '\r' also ends the line for the reference
+            char *cr = (char *)memchr(b, '\r', take);
+            sink(b, cr ? (size_t)(cr - b) : take);
+            any = true;
+            pos += take + (nl ? 1 : 0);
+            if (nl) { terminated = true; return true; }
+        }
+    }
+};
+
+struct Source {
+    std::string path;
+    gzFile gz = nullptr;
+    Queue<RecBuf *> free_q, full_q;
+    std::thread th;
+    std::vector<RecBuf> bufs;
+
+    void start(const std::string &p, int nbuf)
+    {
+        path = p;
+        gz = gzopen(p.c_str(), "r");
+        if (!gz) throw Fatal("I/O error");
+        gzbuffer(gz, 1 << 20);
+        bufs.resize(nbuf);
+        for (auto &b : bufs) { b.init((size_t)BUF_READS * 320); free_q.push(&b); }
+        th = std::thread([this] { run(); });
+    }
+    void run()
+    {
+        LineReader lr(gz);
+        bool done = false;
+        while (!done) {
+            RecBuf *b = free_q.pop();
+            b->n = 0; b->eof = false; b->error.clear(); b->defs.clear(); b->def_off.assign(1, 0);
+            size_t o = 32; // slack in front of the first read
+            b->off[0] = (uint32_t)o;
+            while (b->n < BUF_READS) {
+                bool term;
+                const size_t d0 = b->defs.size();
+                if (!lr.line([&](const char *p, size_t n) { b->defs.append(p, n); }, term)) { b->eof = true; done = true; break; }
+                size_t slen = 0, qlen = 0;
+                auto put = [&](uint8_t *&arena, size_t &len) {
+                    return [&](const char *p, size_t n) {
+                        if (o + len + n + 64 > b->cap) b->grow(o + len + n + 64);
+                        memcpy(arena + o + len, p, n); len += n;
+                    };
+                };
+                if (!lr.line(put(b->seq, slen), term)) { b->error = "fastq.cpp:next_read: Unable to read sequence"; done = true; break; }
+                bool plus_term;
+                if (!lr.line([](const char *, size_t) {}, plus_term)) { b->error = "fastq.cpp:next_read: Unable to read '+'"; done = true; break; }
+                if (!plus_term) { b->error = "fastq.cpp:next_read: Error reading '+' delimiter"; done = true; break; }
+                if (!lr.line(put(b->qual, qlen), term)) { b->error = "fastq.cpp:next_read: Unable to read quality"; done = true; break; }
+                if (slen != qlen) { b->error = "fastq.cpp:next_read: |Sequence| != |Quality|"; done = true; break; }
+                (void)d0;
+                o += slen;
+                b->def_off.push_back((uint32_t)b->defs.size());
+                ++b->n;
+                b->off[b->n] = (uint32_t)o;
+            }
+            full_q.push(b);
+        }
+    }
+    void stop() { if (th.joinable()) th.join(); if (gz) gzclose(gz); for (auto &b : bufs) b.release(); }
+};
+
+std::string parse_id(const char *d, size_t len) // trim.cpp:188-222
+{
+    const char *sp = (const char *)memchr(d, ' ', len);
+    size_t loc = sp ? (size_t)(sp - d) : len;
+    if (loc > 1 && isdigit((unsigned char)d[loc - 1]) && (d[loc - 2] == '.' || d[loc - 2] == '/')) loc -= 2;
+    return std::string(d, loc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// run state
+// ---------------------------------------------------------------------------------------------------------
+struct OutFile {
+    FILE *f = nullptr; std::vector<char> buf;
+    void open(const std::string &p) { f = fopen(p.c_str(), "wb"); if (!f) throw Fatal("I/O error"); buf.reserve(8 << 20); }
+    void put(const char *p, size_t n) { buf.insert(buf.end(), p, p + n); if (buf.size() > (6u << 20)) flush(); }
+    void flush() { if (f && !buf.empty()) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); } }
+    void close() { flush(); if (f) fclose(f); f = nullptr; }
+};
+
+struct Run {
+    Opt &opt;
+    faqcs_ctx *ctx = nullptr;
+    faqcs_params prm;
+    std::vector<const char *> adapter_ptr;
+    uint32_t R = 512;
+    int in_off, quality;
+    uint64_t paired_read_number = 0, paired_base_length = 0;
+    explicit Run(Opt &o) : opt(o), in_off(o.in_off), quality(o.quality) { memset(&prm, 0, sizeof(prm)); }
+
+    static void check(int rc)
+    {
+        if (rc == FAQCS_E_QUALITY) throw Fatal("fastq.h:quality_score: Found a quality score value that is greater than the maximum allowed quality score");
+        if (rc == FAQCS_E_BASE) throw Fatal("seq_overlap.cpp:na_to_bits: Unknown base!");
+        if (rc) throw Fatal(faqcs_last_error());
+    }
+    void ensure_ctx()
+    {
+        if (ctx) return;
+        prm.abi_version = FAQCS_ABI_VERSION; prm.mode = opt.mode; prm.quality = quality; prm.input_quality_offset = in_off;
+        prm.output_quality_offset = opt.out_off; prm.min_read_length = opt.min_len; prm.max_num_poly_N = opt.max_poly_n;
+        prm.trim_5 = opt.trim_5; prm.trim_3 = opt.trim_3; prm.replace_to_N_q = opt.replace_to_N_q; prm.average_quality = opt.average_quality;
+        prm.low_complexity_cutoff_ratio = opt.lc; prm.filterAdapterMismatchRate = opt.rate; prm.protect_5 = opt.protect_5;
+        prm.qc_only = opt.qc_only; prm.kmer_rarefaction = opt.kmer_rarefaction; prm.kmer = opt.kmer; prm.split_size = opt.split_size;
+        prm.num_subsample = opt.num_subsample; prm.max_read_length = R;
+        if (opt.adapters_active()) {
+            for (auto &a : opt.adapter) adapter_ptr.push_back(a.second.c_str());
+            prm.n_adapters = (uint32_t)opt.adapter.size(); prm.adapter_seq = adapter_ptr.data();
+        }
+        check(faqcs_create(&prm, -1, &ctx));
+    }
+    void nextseq_check(const RecBuf *b) // trim.cpp:619-626, FaQCs.cpp:272-277,404-414
+    {
+        if (quality < 20 && b->n > 0 && b->defs.compare(0, 3, "@NS") == 0) {
+            fprintf(stderr, "The input looks like NextSeq data and the quality level (-q) is adjusted to 20 for trimming.\n");
+            quality = 20;
+            if (ctx) check(faqcs_set_quality(ctx, quality)); else prm.quality = quality;
+        }
+    }
+    int detect(const RecBuf *b)
+    {
+        const int r = faqcs_auto_detect_quality_offset(b->qual, b->off, b->n);
+        if (!r) throw Fatal("trim.cpp:auto_detect_quality_offset: Unknown quality format!");
+        return r;
+    }
+    void submit(RecBuf *b)
+    {
+        const uint32_t seg[2] = {0, b->n};
+        faqcs_batch bt; memset(&bt, 0, sizeof(bt));
+        bt.seq = b->seq; bt.qual = b->qual; bt.offset = b->off; bt.n_reads = b->n; bt.n_segments = 1; bt.segment_start = seg;
+        check(faqcs_submit_async(ctx, &bt, b->res, &b->ticket));
+    }
+    // writes one surviving record with the reference's byte edits (trim.cpp:390-403,516-525,1191-1216; fastq.cpp:127-138)
+    void write_read(OutFile &f, const RecBuf *b, uint32_t i, std::string &s, std::string &q)
+    {
+        const faqcs_read_result &x = b->res[i];
+        const uint32_t o = b->off[i], len = b->off[i + 1] - o;
+        s.resize(x.len); q.resize(x.len);
+        faqcs_apply_edits(&prm, b->seq + o, b->qual + o, len, &x, (uint8_t *)&s[0], (uint8_t *)&q[0]);
+        f.put(b->defs.data() + b->def_off[i], b->def_off[i + 1] - b->def_off[i]); f.put("\n", 1);
+        f.put(s.data(), s.size()); f.put("\n+\n", 3); f.put(q.data(), q.size()); f.put("\n", 1);
+    }
+    static void write_raw(OutFile &f, const RecBuf *b, uint32_t i)
+    {
+        const uint32_t o = b->off[i], len = b->off[i + 1] - o;
+        f.put(b->defs.data() + b->def_off[i], b->def_off[i + 1] - b->def_off[i]); f.put("\n", 1);
+        f.put((const char *)b->seq + o, len); f.put("\n+\n", 3); f.put((const char *)b->qual + o, len); f.put("\n", 1);
+    }
+};
+
+struct Work { RecBuf *b1 = nullptr, *b2 = nullptr; bool last = false; };
+
+// FaQCs.cpp:153-538
+void process_paired(Run &r)
+{
+    Opt &opt = r.opt;
+    Source s1, s2;
+    try { s1.start(opt.in1, 6); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read one sequences\n", opt.in1.c_str()); throw; }
+    try { s2.start(opt.in2, 6); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read two sequences\n", opt.in2.c_str()); throw; }
+    OutFile f1, f2, fu, fd;
+    if (!opt.qc_only) { f1.open(opt.out1); f2.open(opt.out2); fu.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); }
+    Queue<Work> wq;
+    std::string werr;
+    std::thread writer([&] {
+        std::string s, q;
+        try {
+            for (;;) {
+                Work w = wq.pop();
+                if (!w.b1) break;
+                Run::check(faqcs_wait(r.ctx, w.b1->ticket));
+                Run::check(faqcs_wait(r.ctx, w.b2->ticket));
+                for (uint32_t i = 0; i < w.b1->n; ++i) {
+                    const bool v1 = w.b1->res[i].flags & FAQCS_F_VALID, v2 = w.b2->res[i].flags & FAQCS_F_VALID;
+                    if (v1 && v2) { r.paired_read_number += 2; r.paired_base_length += w.b1->res[i].len + w.b2->res[i].len; }
+                    if (opt.qc_only) continue;
+                    if (v1 && v2) { r.write_read(f1, w.b1, i, s, q); r.write_read(f2, w.b2, i, s, q); }
+                    else {
+                        if (v1) r.write_read(fu, w.b1, i, s, q);
+                        else if (v2) r.write_read(fu, w.b2, i, s, q);
+                        if (fd.f) { if (!v1) Run::write_raw(fd, w.b1, i); if (!v2) Run::write_raw(fd, w.b2, i); }
+                    }
+                }
+                s1.free_q.push(w.b1); s2.free_q.push(w.b2);
+                if (w.last) break;
+            }
+        } catch (std::exception &e) { werr = e.what(); }
+    });
+    bool check_for_next_seq = true;
+    std::string merr;
+    try {
+        for (;;) {
+            RecBuf *b1 = s1.full_q.pop(), *b2 = s2.full_q.pop();
+            const uint32_t n = std::min(b1->n, b2->n);
+            for (uint32_t i = 0; i < n; ++i) { // FaQCs.cpp:383-389
+                const std::string i1 = parse_id(b1->defs.data() + b1->def_off[i], b1->def_off[i + 1] - b1->def_off[i]);
+                const std::string i2 = parse_id(b2->defs.data() + b2->def_off[i], b2->def_off[i + 1] - b2->def_off[i]);
+                if (i1 != i2) {
+                    fprintf(stderr, "Read one id (%s)\ndoes not match\nread two id (%s)\n", i1.c_str(), i2.c_str());
+                    throw Fatal("FaQCs.cpp:trim: I/O error");
+                }
+            }
+            if (b1->n != b2->n) { // FaQCs.cpp:370-380
+                const RecBuf *lng = b1->n > b2->n ? b1 : b2;
+                fprintf(stderr, "Did not find a match to read %s: %.*s\n", b1->n > b2->n ? "one" : "two",
+                        (int)(lng->def_off[n + 1] - lng->def_off[n]), lng->defs.data() + lng->def_off[n]);
+                throw Fatal("FaQCs.cppI/O error");
+            }
+            if (!b1->error.empty()) throw Fatal(b1->error);
+            if (!b2->error.empty()) throw Fatal(b2->error);
+            const bool last = b1->eof;
+            if (r.in_off == AUTO_OFFSET) { // FaQCs.cpp:261-270,393-402
+                r.in_off = r.detect(b1);
+                if (r.in_off != r.detect(b2)) { fprintf(stderr, "Inconsistent quality offset detection between reads one and two\n"); throw Fatal("FaQCs.cpp:process_paired: I/O Error"); }
+            }
+            if (last || check_for_next_seq) { r.nextseq_check(b1); check_for_next_seq = false; } // Q16: also on the last buffer
+            r.ensure_ctx();
+            r.submit(b1); r.submit(b2);
+            Work w; w.b1 = b1; w.b2 = b2; w.last = last;
+            wq.push(w);
+            if (last) break;
+        }
+    } catch (std::exception &e) { merr = e.what(); wq.push(Work()); }
+    writer.join();
+    if (!merr.empty() || !werr.empty()) { // unblock the readers, then report like the reference's catch in main()
+        std::thread([&] { for (;;) { RecBuf *b = s1.full_q.pop(); if (b->eof || !b->error.empty()) break; s1.free_q.push(b); } }).detach();
+        std::thread([&] { for (;;) { RecBuf *b = s2.full_q.pop(); if (b->eof || !b->error.empty()) break; s2.free_q.push(b); } }).detach();
+        f1.close(); f2.close(); fu.close(); fd.close();
+        throw Fatal(!merr.empty() ? merr : werr);
+    }
+    s1.stop(); s2.stop();
+    f1.close(); f2.close(); fu.close(); fd.close();
+    if (r.ctx) Run::check(faqcs_kmer_end_table(r.ctx)); // FaQCs.cpp:518-537
+}
+
+// FaQCs.cpp:540-757
+void process_unpaired(Run &r)
+{
+    Opt &opt = r.opt;
+    Source s;
+    try { s.start(opt.inu, 8); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading unpaired read sequences\n", opt.inu.c_str()); throw; }
+    OutFile fo, fd;
+    if (!opt.qc_only) { fo.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); } // "wT": truncates process_paired's singletons (Q17)
+    Queue<Work> wq;
+    std::string werr;
+    std::thread writer([&] {
+        std::string sq, qq;
+        try {
+            for (;;) {
+                Work w = wq.pop();
+                if (!w.b1) break;
+                Run::check(faqcs_wait(r.ctx, w.b1->ticket));
+                if (!opt.qc_only)
+                    for (uint32_t i = 0; i < w.b1->n; ++i) {
+                        if (w.b1->res[i].flags & FAQCS_F_VALID) r.write_read(fo, w.b1, i, sq, qq);
+                        else if (fd.f) Run::write_raw(fd, w.b1, i);
+                    }
+                s.free_q.push(w.b1);
+                if (w.last) break;
+            }
+        } catch (std::exception &e) { werr = e.what(); }
+    });
+    bool check_for_next_seq = true;
+    std::string merr;
+    try {
+        for (;;) {
+            RecBuf *b = s.full_q.pop();
+            if (!b->error.empty()) throw Fatal(b->error);
+            const bool last = b->eof;
+            if (r.in_off == AUTO_OFFSET) r.in_off = r.detect(b);
+            if (last || check_for_next_seq) { r.nextseq_check(b); check_for_next_seq = false; }
+            r.ensure_ctx();
+            r.submit(b);
+            Work w; w.b1 = b; w.last = last;
+            wq.push(w);
+            if (last) break;
+        }
+    } catch (std::exception &e) { merr = e.what(); wq.push(Work()); }
+    writer.join();
+    if (!merr.empty() || !werr.empty()) {
+        std::thread([&] { for (;;) { RecBuf *b = s.full_q.pop(); if (b->eof || !b->error.empty()) break; s.free_q.push(b); } }).detach();
+        fo.close(); fd.close();
+        throw Fatal(!merr.empty() ? merr : werr);
+    }
+    s.stop();
+    fo.close(); fd.close();
+    if (r.ctx) Run::check(faqcs_kmer_end_table(r.ctx));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// report: QC.stats.txt (FaQCs.cpp:759-1034) and the --debug tables (plot.cpp:540-733)
+// ---------------------------------------------------------------------------------------------------------
+std::string fmt(const char *f, ...)
+{
+    char buf[512]; va_list ap; va_start(ap, f); vsnprintf(buf, sizeof(buf), f, ap); va_end(ap); return buf;
+}
+std::string pct(double a, double b) { return fmt("%.2f", (100.0 * a) / b); }
+std::string f2(double x, int prec = 2) { return fmt("%.*f", prec, x); }
+
+void adapter_lines(std::string &out, const uint64_t *fs, std::map<std::string, std::pair<uint64_t, uint64_t>> &ast)
+{
+    std::vector<std::pair<uint64_t, std::string>> v;
+    for (auto &kv : ast) v.emplace_back(kv.second.first, kv.first);
+    std::sort(v.begin(), v.end());
+    for (auto it = v.rbegin(); it != v.rend(); ++it) {
+        const auto &st = ast[it->second];
+        out += "    " + it->second + " " + std::to_string(st.first) + " reads (" + pct((double)st.first, (double)fs[FAQCS_TOTAL_NUMBER]) + " %) " +
+               std::to_string(st.second) + " bases (" + pct((double)st.second, (double)fs[FAQCS_TOTAL_LENGTH]) + " %)\n";
+    }
+}
+
+std::string stats_text(const Opt &o, const uint64_t *fs, std::map<std::string, std::pair<uint64_t, uint64_t>> &ast, int quality)
+{
+    auto T = [&](int k) { return (unsigned long long)fs[k]; };
+    auto D = [&](int k) { return (double)fs[k]; };
+    std::string s;
+    if (o.qc_only) {
+        s += "\n";
+        s += fmt("Reads #: %llu\n", T(FAQCS_TOTAL_COUNT));
+        s += fmt("Total bases: %llu\n", T(FAQCS_TOTAL_LENGTH));
+        s += "Reads Length: " + f2((double)((float)fs[FAQCS_TOTAL_LENGTH] / (float)fs[FAQCS_TOTAL_COUNT])) + "\n";
+        s += fmt("Processed %llu reads for quality check only\n", T(FAQCS_TOTAL_NUMBER));
+        s += fmt("  Reads length < %u bp: %llu (", o.min_len, T(FAQCS_READ_LENGTH)) + pct(D(FAQCS_READ_LENGTH), D(FAQCS_TOTAL_NUMBER)) + " %)\n";
+        s += fmt("  Reads have %u continuous base \"N\": %llu (", o.max_poly_n, T(FAQCS_READ_NN)) + pct(D(FAQCS_READ_NN), D(FAQCS_TOTAL_NUMBER)) + " %)\n";
+        s += "  Low complexity Reads  (>" + f2((double)o.lc * 100.0) + fmt("%% mono/di-nucleotides): %llu (", T(FAQCS_READ_LOW_COMPLEXITY)) +
+             pct(D(FAQCS_READ_LOW_COMPLEXITY), D(FAQCS_TOTAL_NUMBER)) + " %)\n";
+        s += "  Reads < average quality " + f2((double)o.average_quality) + fmt(": %llu (", T(FAQCS_READ_AVG_Q)) + pct(D(FAQCS_READ_AVG_Q), D(FAQCS_TOTAL_NUMBER)) + " %)\n";
+        if (o.filter_phiX) s += fmt("  Reads hits to phiX sequence: %llu (", T(FAQCS_READ_PHIX)) + pct(D(FAQCS_READ_PHIX), D(FAQCS_TOTAL_NUMBER)) + " %)\n";
+        if (o.filter_adapter) {
+            s += fmt("  Reads with Adapters/Primers: %llu (", T(FAQCS_READ_ADAPTER)) + pct(D(FAQCS_READ_ADAPTER), D(FAQCS_TOTAL_NUMBER)) + " %)\n";
+            adapter_lines(s, fs, ast);
+        }
+        return s;
+    }
+    const double tn = D(FAQCS_TOTAL_NUMBER), tl = D(FAQCS_TOTAL_LENGTH), ttn = D(FAQCS_TOTAL_TRIMMED_NUMBER), ttl = D(FAQCS_TOTAL_TRIMMED_LENGTH);
+    s += "Before Trimming\n";
+    s += fmt("Reads #: %llu\n", T(FAQCS_TOTAL_NUMBER));
+    s += fmt("Total bases: %llu\n", T(FAQCS_TOTAL_LENGTH));
+    s += "Reads Length: " + f2((double)((float)fs[FAQCS_TOTAL_LENGTH] / (float)fs[FAQCS_TOTAL_NUMBER])) + "\n";
+    s += "\nAfter Trimming\n";
+    s += fmt("Reads #: %llu (", T(FAQCS_TOTAL_TRIMMED_NUMBER)) + pct(ttn, tn) + " %)\n";
+    s += fmt("Total bases: %llu (", T(FAQCS_TOTAL_TRIMMED_LENGTH)) + pct(ttl, tl) + " %)\n";
+    if (fs[FAQCS_TOTAL_TRIMMED_NUMBER] > 0) s += "Mean Reads Length: " + f2((double)((float)fs[FAQCS_TOTAL_TRIMMED_LENGTH] / (float)fs[FAQCS_TOTAL_TRIMMED_NUMBER])) + "\n";
+    else s += "Mean Reads Length: 0\n";
+    if (!o.in1.empty()) {
+        const double prn = D(FAQCS_PAIRED_READ_NUMBER), pbl = D(FAQCS_PAIRED_BASE_LENGTH);
+        s += fmt("  Paired Reads #: %llu (", T(FAQCS_PAIRED_READ_NUMBER)) + pct(prn, ttn) + " %)\n";
+        s += fmt("  Paired total bases: %llu (", T(FAQCS_PAIRED_BASE_LENGTH)) + pct(pbl, ttl) + " %)\n";
+        s += fmt("  Unpaired Reads #: %llu (", T(FAQCS_TOTAL_TRIMMED_NUMBER) - T(FAQCS_PAIRED_READ_NUMBER)) + pct(ttn - prn, ttn) + " %)\n";
+        s += fmt("  Unpaired total bases: %llu (", T(FAQCS_TOTAL_TRIMMED_LENGTH) - T(FAQCS_PAIRED_BASE_LENGTH)) + pct(ttl - pbl, ttl) + " %)\n";
+    }
+    s += fmt("\nDiscarded reads #: %llu (", T(FAQCS_TOTAL_NUMBER) - T(FAQCS_TOTAL_TRIMMED_NUMBER)) + pct(tn - ttn, tn) + " %)\n";
+    s += fmt("Trimmed bases: %llu (", T(FAQCS_TOTAL_LENGTH) - T(FAQCS_TOTAL_TRIMMED_LENGTH)) + pct(tl - ttl, tl) + " %)\n";
+    s += fmt("  Reads Filtered by length cutoff (%u bp): %llu (", o.min_len, T(FAQCS_READ_LENGTH)) + pct(D(FAQCS_READ_LENGTH), tn) + " %)\n";
+    s += fmt("  Bases Filtered by length cutoff: %llu (", T(FAQCS_BASE_LENGTH)) + pct(D(FAQCS_BASE_LENGTH), tl) + " %)\n";
+    s += fmt("  Reads Filtered by continuous base \"N\" (%u): %llu (", o.max_poly_n, T(FAQCS_READ_NN)) + pct(D(FAQCS_READ_NN), tn) + " %)\n";
+    s += fmt("  Bases Filtered by continuous base \"N\": %llu (", T(FAQCS_BASE_NN)) + pct(D(FAQCS_BASE_NN), tl) + " %)\n";
+    s += "  Reads Filtered by low complexity ratio (" + f2((double)o.lc, 1) + fmt("): %llu (", T(FAQCS_READ_LOW_COMPLEXITY)) + pct(D(FAQCS_READ_LOW_COMPLEXITY), tn) + " %)\n";
+    s += fmt("  Bases Filtered by low complexity ratio: %llu (", T(FAQCS_BASE_LOW_COMPLEXITY)) + pct(D(FAQCS_BASE_LOW_COMPLEXITY), tl) + " %)\n";
+    if (o.average_quality > 0.0f) {
+        s += "  Reads Filtered by avg quality (" + f2((double)o.average_quality) + fmt("): %llu (", T(FAQCS_READ_AVG_Q)) + pct(D(FAQCS_READ_AVG_Q), tn) + " %)\n";
+        s += fmt("  Bases Filtered by avg quality: %llu (", T(FAQCS_BASE_AVG_Q)) + pct(D(FAQCS_BASE_AVG_Q), tl) + " %)\n";
+    }
+    if (o.filter_phiX) {
+        s += fmt("  Reads Filtered by phiX sequence: %llu (", T(FAQCS_READ_PHIX)) + pct(D(FAQCS_READ_PHIX), tn) + " %)\n";
+        s += fmt("  Bases Filtered by phiX sequence: %llu (", T(FAQCS_BASE_PHIX)) + pct(D(FAQCS_BASE_PHIX), tl) + " %)\n";
+    }
+    s += "  Reads Trimmed by quality (" + f2((double)(float)quality, 1) + fmt("): %llu (", T(FAQCS_READ_QUAL_TRIM)) + pct(D(FAQCS_READ_QUAL_TRIM), tn) + " %)\n";
+    s += fmt("  Bases Trimmed by quality: %llu (", T(FAQCS_BASE_QUAL_TRIM)) + pct(D(FAQCS_BASE_QUAL_TRIM), tl) + " %)\n";
+    if (o.trim_5 > 0) s += fmt("  Reads Trimmed with %u bp from 5' end\n", o.trim_5);
+    if (o.trim_3 > 0) s += fmt("  Reads Trimmed with %u bp from 3' end\n", o.trim_3);
+    if (o.filter_adapter) {
+        s += fmt("  Reads Trimmed with Adapters/Primers: %llu (", T(FAQCS_READ_ADAPTER)) + pct(D(FAQCS_READ_ADAPTER), tn) + " %)\n";
+        s += fmt("  Bases Trimmed with Adapters/Primers: %llu (", T(FAQCS_BASE_ADAPTER)) + pct(D(FAQCS_BASE_ADAPTER), tl) + " %)\n";
+        adapter_lines(s, fs, ast);
+    }
+    if (o.replace_N) s += fmt("\nN base random substitution: A %llu, T %llu, C %llu, G %llu\n", T(FAQCS_N_TO_A), T(FAQCS_N_TO_T), T(FAQCS_N_TO_C), T(FAQCS_N_TO_G));
+    return s;
+}
+
+void put_file(const std::string &path, const std::string &text) { FILE *f = fopen(path.c_str(), "w"); if (f) { fwrite(text.data(), 1, text.size(), f); fclose(f); } }
+
+void write_tables(const Opt &o, const faqcs_layout &L, const uint64_t *c, uint32_t R, faqcs_ctx *ctx)
+{
+    const std::string d = o.output_dir + "/", p = o.prefix;
+    const uint32_t rows_pre = faqcs_counter_rows(c + L.pre_qual, R, FAQCS_NQ), rows_post = faqcs_counter_rows(c + L.post_qual, R, FAQCS_NQ);
+    auto matrix = [&](const std::string &name, const uint64_t *m, uint32_t rows, uint32_t cols) { // plot.cpp:613-640
+        if (!rows) return;
+        std::string t;
+        for (uint32_t r = 0; r < rows; ++r) for (uint32_t k = 0; k < cols; ++k) { t += std::to_string(m[(size_t)r * cols + k]); t += k + 1 < cols ? '\t' : '\n'; }
+        put_file(d + name, t);
+    };
+    matrix("qa." + p + ".quality.matrix", c + L.pre_qual, rows_pre, FAQCS_NQ);
+    matrix(p + ".quality.matrix", c + L.post_qual, rows_post, FAQCS_NQ);
+    matrix("qa." + p + ".base.matrix", c + L.pre_base, rows_pre, FAQCS_NBASE);
+    matrix(p + ".base.matrix", c + L.post_base, rows_post, FAQCS_NBASE);
+    auto qhist = [&](const std::string &name, const uint64_t *rh, const uint64_t *bh) { // plot.cpp:642-663
+        std::string t = "Score\treadsNum\treadsBases\n";
+        for (int i = FAQCS_NQ - 1; i >= 0; --i) t += fmt("%d\t%llu\t%llu\n", i, (unsigned long long)rh[i], (unsigned long long)bh[i]);
+        put_file(d + name, t);
+    };
+    qhist("qa." + p + ".for_qual_histogram.txt", c + L.pre_read_qhist, c + L.pre_base_qhist);
+    qhist(p + ".for_qual_histogram.txt", c + L.post_read_qhist, c + L.post_base_qhist);
+    auto comp = [&](const std::string &name, const uint64_t *m) { // plot.cpp:540-611
+        static const char *kind[6] = {"A", "T", "C", "G", "N", "GC"};
+        std::string t;
+        for (int k = 0; k < 6; ++k) for (uint32_t i = 0; i < FAQCS_NCOMP_BIN; ++i) { const uint64_t v = m[(size_t)i * 6 + k]; if (v) t += fmt("%s\t%.2f\t%llu\n", kind[k], i * 0.01, (unsigned long long)v); }
+        put_file(d + name, t);
+    };
+    comp("qa." + p + ".base_content.txt", c + L.pre_comp);
+    comp(p + ".base_content.txt", c + L.post_comp);
+    auto lenhist = [&](const std::string &name, const uint64_t *h) { // plot.cpp:665-681
+        uint32_t size = 0;
+        for (uint32_t i = 0; i <= R; ++i) if (h[i]) size = i + 1;
+        std::string t;
+        for (uint32_t i = 1; i < size; ++i) t += fmt("%u\t%llu\n", i, (unsigned long long)h[i]);
+        put_file(d + name, t);
+    };
+    lenhist("qa." + p + ".length_count.txt", c + L.pre_len_hist);
+    lenhist(p + ".length_count.txt", c + L.post_len_hist);
+    uint64_t npairs = 0;
+    faqcs_kmer_histogram(ctx, nullptr, nullptr, 0, &npairs);
+    if (npairs) { // plot.cpp:683-733
+        std::vector<uint64_t> cnt(npairs), nk(npairs);
+        faqcs_kmer_histogram(ctx, cnt.data(), nk.data(), npairs, &npairs);
+        std::string t;
+        for (uint64_t i = 0; i < npairs; ++i) t += fmt("%llu %llu\n", (unsigned long long)cnt[i], (unsigned long long)nk[i]);
+        put_file(d + p + ".kmerH.txt", t);
+        uint32_t np = 0;
+        faqcs_kmer_points(ctx, nullptr, 0, &np);
+        std::vector<faqcs_rarefaction> pts(np ? np : 1);
+        faqcs_kmer_points(ctx, pts.data(), np, &np);
+        t.clear();
+        uint64_t lastn = 0;
+        for (uint32_t i = 0; i < np; ++i) { t += fmt("%llu\t%llu\t%llu\n", (unsigned long long)(pts[i].num_seq - lastn), (unsigned long long)pts[i].distinct_kmer, (unsigned long long)pts[i].total_kmer); lastn = pts[i].num_seq; }
+        put_file(d + p + ".Kmercount.txt", t);
+    }
+}
+
+void remove_file(const std::string &p)
+{
+    struct stat st;
+    if (!p.empty() && stat(p.c_str(), &st) == 0) { fprintf(stderr, "The output %s file exists and will be overwritten.\n", p.c_str()); unlink(p.c_str()); }
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    try {
+        Opt opt = parse_args(argc, argv);
+        for (auto &m : opt.messages) fprintf(stderr, "%s\n", m.c_str());
+        if (opt.print_usage) {
+            if (!opt.version) fprintf(stderr, "faqcs_mi (FaQCs %s command line on the MI355X hot path): same flags as FaQCs; see the reference usage text\n", VERSION);
+            return EXIT_FAILURE;
+        }
+        struct stat st;
+        if (!(stat(opt.output_dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) && mkdir(opt.output_dir.c_str(), 0700) != 0) {
+            fprintf(stderr, "Unable to create requested output directory: \"%s\"\n", opt.output_dir.c_str());
+            return EXIT_FAILURE;
+        }
+        remove_file(opt.plots_file); remove_file(opt.stats_file); remove_file(opt.out1); remove_file(opt.out2); remove_file(opt.outu); remove_file(opt.outd);
+        Run r(opt);
+        if (!opt.in1.empty()) process_paired(r);
+        if (!opt.inu.empty()) process_unpaired(r);
+        r.ensure_ctx();
+        faqcs_layout L;
+        faqcs_counters_layout(r.R, r.prm.n_adapters, &L);
+        std::vector<uint64_t> c(L.total);
+        Run::check(faqcs_finish(r.ctx, c.data(), c.size()));
+        uint64_t fs[FAQCS_NUM_STAT];
+        for (int k = 0; k < FAQCS_NUM_STAT; ++k) fs[k] = c[L.filter_stats + k];
+        fs[FAQCS_PAIRED_READ_NUMBER] += r.paired_read_number;
+        fs[FAQCS_PAIRED_BASE_LENGTH] += r.paired_base_length;
+        std::map<std::string, std::pair<uint64_t, uint64_t>> ast; // FaQCs.cpp:89-127
+        for (uint32_t j = 0; j < L.n_adapters; ++j) {
+            const uint64_t reads = c[L.adapter_stats + 2 * j], bases = c[L.adapter_stats + 2 * j + 1];
+            if (reads) { auto &e = ast[opt.adapter[j].first]; e.first += reads; e.second += bases; }
+        }
+        if (opt.filter_phiX)
+            for (const char *k : {"__PhiX174_NC_001422__", "__PhiX174_NC_001422_complement__"}) {
+                auto it = ast.find(k);
+                if (it != ast.end()) { fs[FAQCS_READ_PHIX] += it->second.first; fs[FAQCS_BASE_PHIX] += it->second.second; ast.erase(it); }
+            }
+        if (opt.filter_adapter) for (auto &kv : ast) { fs[FAQCS_READ_ADAPTER] += kv.second.first; fs[FAQCS_BASE_ADAPTER] += kv.second.second; }
+        {
+            FILE *f = fopen(opt.stats_file.c_str(), "w");
+            if (!f) fprintf(stderr, "Unable to open %s for writing filtering statistics\n", opt.stats_file.c_str());
+            else { const std::string t = stats_text(opt, fs, ast, r.quality); fwrite(t.data(), 1, t.size(), f); fclose(f); }
+        }
+        if (!opt.trim_only && opt.debug) write_tables(opt, L, c.data(), r.R, r.ctx);
+        faqcs_destroy(r.ctx);
+    } catch (std::exception &e) {
+        fprintf(stderr, "Caught the error %s\n", e.what());
+        return EXIT_FAILURE;
+    }
+    return EXIT_SUCCESS;
+}

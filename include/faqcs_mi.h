@@ -183,6 +183,15 @@ int  faqcs_submit_device(faqcs_ctx *ctx, const faqcs_batch *batch, faqcs_read_re
 
 int  faqcs_sync(faqcs_ctx *ctx);
 
+/* Pipelined form of faqcs_submit(): returns a ticket; faqcs_wait(ticket) blocks until THAT batch's results have
+ * landed in `results` (later batches may still be in flight: two input staging slots let the H2D copy of batch
+ * k+1 overlap the kernels of batch k).  Host arenas / result arrays obtained from faqcs_host_alloc() are pinned,
+ * which makes both copies true asynchronous DMA. */
+int  faqcs_submit_async(faqcs_ctx *ctx, const faqcs_batch *batch, faqcs_read_result *results, uint64_t *ticket);
+int  faqcs_wait(faqcs_ctx *ctx, uint64_t ticket);
+void *faqcs_host_alloc(size_t bytes);
+void faqcs_host_free(void *p);
+
 /* Options::quality is mutable during a run: the NextSeq check bumps -q to 20 (FaQCs.cpp:272-277,404-414).
  * Takes effect for batches submitted afterwards. */
 int  faqcs_set_quality(faqcs_ctx *ctx, int quality);

@@ -250,3 +250,17 @@ def test_reference_driver_with_hip_trim(name, fixture_cache, tmp_path):
         pytest.skip("oracle/_ref/FaQCs_hip not built (needs /root/reference at build time: make -C oracle ref_hip)")
     bad = run_case_binary(load_case(name), fixture_cache, tmp_path, _SHIM_BIN)
     assert not bad, "\n".join(bad)
+
+
+_CLI_BIN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),
+                                      "faqcs_amd", "faqcs_mi")
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").case_names())
+def test_native_cli_reproduces_reference(name, fixture_cache, tmp_path):
+    """faqcs_amd/faqcs_mi (C++ driver: threaded FASTQ readers -> pinned SoA buffers -> pipelined C ABI -> ordered
+    writer) against the reference's own outputs, including the k-mer rarefaction cases."""
+    from golden_util import load_case, run_case_binary
+
+    bad = run_case_binary(load_case(name), fixture_cache, tmp_path, _CLI_BIN)
+    assert not bad, "\n".join(bad)
