@@ -2,8 +2,9 @@
 //
 // Process contract of the reference (FaQCs.cpp:36-151, process_paired :153-538, process_unpaired :540-757,
 // write_stats :759-1034, the --debug tables of plot.cpp:540-733, options.cpp:72-774) with a different
-// architecture: one reader thread per input file parses (gz) FASTQ straight into pinned structure-of-arrays
-// buffers of 32 768 reads (the reference's trim() granularity), the main thread pairs them up and submits
+// architecture: per input file an I/O thread cuts the (gz) byte stream into blocks of 32 768 records and a pool of
+// parser threads turns them into pinned structure-of-arrays buffers (the reference's trim() granularity,
+// delivered in file order); the main thread pairs them up and submits
 // them through the pipelined C ABI (faqcs_submit_async), and a writer thread emits the survivors in input
 // order while later buffers are parsed and trimmed.  The per-read hot path runs ONLY on the GPU library.
 #include <zlib.h>
@@ -288,43 +289,34 @@ public:
     T pop() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty(); }); T v = q.front(); q.pop_front(); return v; }
 };
 
-class LineReader { // gz or plain, arbitrary line length, \n or \r terminators (fastq.cpp:32-52)
-    gzFile f; std::vector<char> buf; size_t pos = 0, end = 0; bool at_eof = false;
-public:
-    explicit LineReader(gzFile g) : f(g), buf(8 << 20) {}
-    // returns false at EOF with nothing read; the line (without terminator) is appended to `out`
-    template <class Sink> bool line(Sink &&sink, bool &terminated)
-    {
-        bool any = false; terminated = false;
-        for (;;) {
-            if (pos == end) {
-                if (at_eof) return any;
-                const int got = gzread(f, buf.data(), (unsigned)buf.size());
-                if (got <= 0) { at_eof = true; return any; }
-                pos = 0; end = (size_t)got;
-            }
-            char *b = buf.data() + pos;
-            const size_t avail = end - pos;
-            char *nl = (char *)memchr(b, '\n', avail);
-            const size_t take = nl ? (size_t)(nl - b) : avail;
-            // strpbrk("\n\r"): a '\r' also ends the line for the reference
-            char *cr = (char *)memchr(b, '\r', take);
-            sink(b, cr ? (size_t)(cr - b) : take);
-            any = true;
-            pos += take + (nl ? 1 : 0);
-            if (nl) { terminated = true; return true; }
-        }
-    }
+// A block of raw FASTQ text holding up to BUF_READS records (exactly 4 lines each), cut by the I/O thread.
+struct TextBlock {
+    std::vector<char> text;
+    uint64_t seq_no = 0;
+    uint32_t n_lines = 0;
+    struct RecBuf *buf = nullptr; // destination, assigned by the I/O thread IN FILE ORDER (so the oldest block always owns one)
+    bool eof = false;        // last block of the file
+    bool unterminated = false; // the file ended without a final newline
 };
 
+// One input file: an I/O thread reads (gz or plain) and cuts the byte stream into blocks of 4 * BUF_READS lines by
+// counting newlines only; a small pool of parser threads turns blocks into pinned structure-of-arrays RecBufs
+// (fastq.cpp:8-125 semantics: four lines per record, a '\r' also ends a line, |seq| must equal |qual|); buffers are
+// handed to the consumer strictly in file order.
 struct Source {
     std::string path;
     gzFile gz = nullptr;
-    Queue<RecBuf *> free_q, full_q;
-    std::thread th;
+    Queue<RecBuf *> free_q;
+    Queue<TextBlock *> block_free, block_full;
+    std::thread io_th;
+    std::vector<std::thread> parsers;
+    int n_parsers = 0;
     std::vector<RecBuf> bufs;
+    std::vector<TextBlock> blocks;
+    // ordered delivery
+    std::mutex om; std::condition_variable ocv; std::map<uint64_t, RecBuf *> ready; uint64_t next_out = 0;
 
-    void start(const std::string &p, int nbuf)
+    void start(const std::string &p, int nbuf, int nparse)
     {
         path = p;
         gz = gzopen(p.c_str(), "r");
@@ -332,52 +324,136 @@ struct Source {
         gzbuffer(gz, 1 << 20);
         bufs.resize(nbuf);
         for (auto &b : bufs) { b.init((size_t)BUF_READS * 320); free_q.push(&b); }
-        th = std::thread([this] { run(); });
+        blocks.resize(nparse + 2);
+        for (auto &t : blocks) block_free.push(&t);
+        n_parsers = nparse;
+        io_th = std::thread([this] { io_run(); });
+        for (int i = 0; i < nparse; ++i) parsers.emplace_back([this] { parse_run(); });
     }
-    void run()
+
+    void io_run()
     {
-        LineReader lr(gz);
-        bool done = false;
-        while (!done) {
-            RecBuf *b = free_q.pop();
-            b->n = 0; b->eof = false; b->error.clear(); b->defs.clear(); b->def_off.assign(1, 0);
-            size_t o = 32; // slack in front of the first read
-            b->off[0] = (uint32_t)o;
-            while (b->n < BUF_READS) {
-                bool term;
-                const size_t d0 = b->defs.size();
-                if (!lr.line([&](const char *p, size_t n) { b->defs.append(p, n); }, term)) { b->eof = true; done = true; break; }
-                size_t slen = 0, qlen = 0;
-                auto put = [&](uint8_t *&arena, size_t &len) {
-                    return [&](const char *p, size_t n) {
-                        if (o + len + n + 64 > b->cap) b->grow(o + len + n + 64);
-                        memcpy(arena + o + len, p, n); len += n;
-                    };
-                };
-                if (!lr.line(put(b->seq, slen), term)) { b->error = "fastq.cpp:next_read: Unable to read sequence"; done = true; break; }
-                bool plus_term;
-                if (!lr.line([](const char *, size_t) {}, plus_term)) { b->error = "fastq.cpp:next_read: Unable to read '+'"; done = true; break; }
-                if (!plus_term) { b->error = "fastq.cpp:next_read: Error reading '+' delimiter"; done = true; break; }
-                if (!lr.line(put(b->qual, qlen), term)) { b->error = "fastq.cpp:next_read: Unable to read quality"; done = true; break; }
-                if (slen != qlen) { b->error = "fastq.cpp:next_read: |Sequence| != |Quality|"; done = true; break; }
-                (void)d0;
-                o += slen;
-                b->def_off.push_back((uint32_t)b->defs.size());
-                ++b->n;
-                b->off[b->n] = (uint32_t)o;
+        std::vector<char> io(16 << 20);
+        uint64_t seq_no = 0;
+        TextBlock *cur = block_free.pop();
+        cur->text.clear(); cur->n_lines = 0; cur->eof = false; cur->unterminated = false; cur->seq_no = seq_no;
+        cur->buf = free_q.pop();
+        const uint32_t want = 4 * BUF_READS;
+        for (;;) {
+            const int got = gzread(gz, io.data(), (unsigned)io.size());
+            if (got <= 0) break;
+            const char *p = io.data(), *end = p + got;
+            while (p < end) {
+                // take whole lines until the block holds `want` of them
+                const char *q = p;
+                uint32_t lines = cur->n_lines;
+                while (q < end && lines < want) {
+                    const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q));
+                    if (!nl) { q = end; break; }
+                    q = nl + 1; ++lines;
+                }
+                cur->text.insert(cur->text.end(), p, q);
+                cur->n_lines = lines;
+                p = q;
+                if (lines == want) {
+                    block_full.push(cur);
+                    cur = block_free.pop();
+                    cur->text.clear(); cur->n_lines = 0; cur->eof = false; cur->unterminated = false; cur->seq_no = ++seq_no;
+                    cur->buf = free_q.pop();
+                }
             }
-            full_q.push(b);
+        }
+        if (!cur->text.empty() && cur->text.back() != '\n') { cur->unterminated = true; ++cur->n_lines; }
+        cur->eof = true;
+        block_full.push(cur);
+        for (int i = 1; i < n_parsers; ++i) block_full.push(nullptr); // wake the other parsers up to exit
+    }
+
+    static const char *line_end(const char *p, const char *end, const char *&next, bool &terminated)
+    { // [p, return) is the line content: up to the first '\n' or '\r' (strpbrk in the reference); next = after '\n'
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        terminated = nl != nullptr;
+        const char *stop = nl ? nl : end;
+        next = nl ? nl + 1 : end;
+        const char *cr = (const char *)memchr(p, '\r', (size_t)(stop - p));
+        return cr ? cr : stop;
+    }
+
+    void parse_block(const TextBlock *t, RecBuf *b)
+    {
+        b->n = 0; b->eof = t->eof; b->error.clear(); b->defs.clear(); b->def_off.assign(1, 0);
+        size_t o = 32; // slack in front of the first read
+        b->off[0] = (uint32_t)o;
+        const char *p = t->text.data(), *end = p + t->text.size();
+        if (t->text.size() + 128 > b->cap) b->grow(t->text.size() + 128);
+        while (p < end) {
+            const char *nx; bool term;
+            const char *e = line_end(p, end, nx, term);
+            b->defs.append(p, (size_t)(e - p));
+            p = nx;
+            if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read sequence"; break; }
+            e = line_end(p, end, nx, term);
+            const size_t slen = (size_t)(e - p);
+            memcpy(b->seq + o, p, slen);
+            p = nx;
+            if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read '+'"; break; }
+            (void)line_end(p, end, nx, term);
+            if (!term) { b->error = "fastq.cpp:next_read: Error reading '+' delimiter"; break; }
+            p = nx;
+            if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read quality"; break; }
+            e = line_end(p, end, nx, term);
+            const size_t qlen = (size_t)(e - p);
+            if (slen != qlen) { b->error = "fastq.cpp:next_read: |Sequence| != |Quality|"; break; }
+            memcpy(b->qual + o, p, qlen);
+            p = nx;
+            o += slen;
+            b->def_off.push_back((uint32_t)b->defs.size());
+            ++b->n;
+            b->off[b->n] = (uint32_t)o;
         }
     }
-    void stop() { if (th.joinable()) th.join(); if (gz) gzclose(gz); for (auto &b : bufs) b.release(); }
+
+    void parse_run()
+    {
+        for (;;) {
+            TextBlock *t = block_full.pop();
+            if (!t) return;
+            RecBuf *b = t->buf;
+            parse_block(t, b);
+            const uint64_t sn = t->seq_no;
+            const bool last = t->eof;
+            block_free.push(t);
+            { std::lock_guard<std::mutex> l(om); ready[sn] = b; }
+            ocv.notify_all();
+            if (last) return;
+        }
+    }
+
+    RecBuf *pop() // next buffer in file order
+    {
+        std::unique_lock<std::mutex> l(om);
+        ocv.wait(l, [&] { return ready.count(next_out) != 0; });
+        RecBuf *b = ready[next_out];
+        ready.erase(next_out++);
+        return b;
+    }
+
+    void stop()
+    {
+        if (io_th.joinable()) io_th.join();
+        for (auto &t : parsers) if (t.joinable()) t.join();
+        if (gz) gzclose(gz);
+        for (auto &b : bufs) b.release();
+    }
 };
 
-std::string parse_id(const char *d, size_t len) // trim.cpp:188-222
+// trim.cpp:188-222: length of the id part of a defline (up to the first space, minus a trailing ".N" / "/N")
+size_t id_len(const char *d, size_t len)
 {
     const char *sp = (const char *)memchr(d, ' ', len);
     size_t loc = sp ? (size_t)(sp - d) : len;
     if (loc > 1 && isdigit((unsigned char)d[loc - 1]) && (d[loc - 2] == '.' || d[loc - 2] == '/')) loc -= 2;
-    return std::string(d, loc);
+    return loc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -399,7 +475,14 @@ struct Run {
     uint32_t R = 512;
     int in_off, quality;
     uint64_t paired_read_number = 0, paired_base_length = 0;
-    explicit Run(Opt &o) : opt(o), in_off(o.in_off), quality(o.quality) { memset(&prm, 0, sizeof(prm)); }
+    int n_parse = 4; // parser threads per input file (-t N caps the total)
+    explicit Run(Opt &o) : opt(o), in_off(o.in_off), quality(o.quality)
+    {
+        memset(&prm, 0, sizeof(prm));
+        const unsigned hw = std::thread::hardware_concurrency();
+        unsigned budget = o.num_thread ? o.num_thread : (hw ? hw : 8);
+        n_parse = (int)std::max(1u, std::min(8u, budget / 4));
+    }
 
     static void check(int rc)
     {
@@ -448,9 +531,15 @@ struct Run {
     {
         const faqcs_read_result &x = b->res[i];
         const uint32_t o = b->off[i], len = b->off[i + 1] - o;
-        s.resize(x.len); q.resize(x.len);
-        faqcs_apply_edits(&prm, b->seq + o, b->qual + o, len, &x, (uint8_t *)&s[0], (uint8_t *)&q[0]);
         f.put(b->defs.data() + b->def_off[i], b->def_off[i + 1] - b->def_off[i]); f.put("\n", 1);
+        const uint8_t *sp = b->seq + o, *qp = b->qual + o;
+        if (prm.replace_to_N_q == 0 && prm.input_quality_offset == prm.output_quality_offset && len && sp[0] != 'N' && sp[len - 1] != 'N') {
+            // no byte of this record is edited (trim.cpp:390-403,516-525,1191-1216): copy the kept window
+            f.put((const char *)sp + x.start, x.len); f.put("\n+\n", 3); f.put((const char *)qp + x.start, x.len); f.put("\n", 1);
+            return;
+        }
+        s.resize(x.len); q.resize(x.len);
+        faqcs_apply_edits(&prm, sp, qp, len, &x, (uint8_t *)&s[0], (uint8_t *)&q[0]);
         f.put(s.data(), s.size()); f.put("\n+\n", 3); f.put(q.data(), q.size()); f.put("\n", 1);
     }
     static void write_raw(OutFile &f, const RecBuf *b, uint32_t i)
@@ -468,8 +557,8 @@ void process_paired(Run &r)
 {
     Opt &opt = r.opt;
     Source s1, s2;
-    try { s1.start(opt.in1, 6); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read one sequences\n", opt.in1.c_str()); throw; }
-    try { s2.start(opt.in2, 6); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read two sequences\n", opt.in2.c_str()); throw; }
+    try { s1.start(opt.in1, 12, r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read one sequences\n", opt.in1.c_str()); throw; }
+    try { s2.start(opt.in2, 12, r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read two sequences\n", opt.in2.c_str()); throw; }
     OutFile f1, f2, fu, fd;
     if (!opt.qc_only) { f1.open(opt.out1); f2.open(opt.out2); fu.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); }
     Queue<Work> wq;
@@ -502,13 +591,13 @@ void process_paired(Run &r)
     std::string merr;
     try {
         for (;;) {
-            RecBuf *b1 = s1.full_q.pop(), *b2 = s2.full_q.pop();
+            RecBuf *b1 = s1.pop(), *b2 = s2.pop();
             const uint32_t n = std::min(b1->n, b2->n);
             for (uint32_t i = 0; i < n; ++i) { // FaQCs.cpp:383-389
-                const std::string i1 = parse_id(b1->defs.data() + b1->def_off[i], b1->def_off[i + 1] - b1->def_off[i]);
-                const std::string i2 = parse_id(b2->defs.data() + b2->def_off[i], b2->def_off[i + 1] - b2->def_off[i]);
-                if (i1 != i2) {
-                    fprintf(stderr, "Read one id (%s)\ndoes not match\nread two id (%s)\n", i1.c_str(), i2.c_str());
+                const char *d1 = b1->defs.data() + b1->def_off[i], *d2 = b2->defs.data() + b2->def_off[i];
+                const size_t l1 = id_len(d1, b1->def_off[i + 1] - b1->def_off[i]), l2 = id_len(d2, b2->def_off[i + 1] - b2->def_off[i]);
+                if (l1 != l2 || memcmp(d1, d2, l1) != 0) {
+                    fprintf(stderr, "Read one id (%.*s)\ndoes not match\nread two id (%.*s)\n", (int)l1, d1, (int)l2, d2);
                     throw Fatal("FaQCs.cpp:trim: I/O error");
                 }
             }
@@ -535,10 +624,9 @@ void process_paired(Run &r)
     } catch (std::exception &e) { merr = e.what(); wq.push(Work()); }
     writer.join();
     if (!merr.empty() || !werr.empty()) { // unblock the readers, then report like the reference's catch in main()
-        std::thread([&] { for (;;) { RecBuf *b = s1.full_q.pop(); if (b->eof || !b->error.empty()) break; s1.free_q.push(b); } }).detach();
-        std::thread([&] { for (;;) { RecBuf *b = s2.full_q.pop(); if (b->eof || !b->error.empty()) break; s2.free_q.push(b); } }).detach();
         f1.close(); f2.close(); fu.close(); fd.close();
-        throw Fatal(!merr.empty() ? merr : werr);
+        fprintf(stderr, "Caught the error %s\n", (!merr.empty() ? merr : werr).c_str());
+        _exit(EXIT_FAILURE); // reader / parser threads may be blocked on their queues: leave like the reference's catch in main()
     }
     s1.stop(); s2.stop();
     f1.close(); f2.close(); fu.close(); fd.close();
@@ -550,7 +638,7 @@ void process_unpaired(Run &r)
 {
     Opt &opt = r.opt;
     Source s;
-    try { s.start(opt.inu, 8); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading unpaired read sequences\n", opt.inu.c_str()); throw; }
+    try { s.start(opt.inu, 16, 2 * r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading unpaired read sequences\n", opt.inu.c_str()); throw; }
     OutFile fo, fd;
     if (!opt.qc_only) { fo.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); } // "wT": truncates process_paired's singletons (Q17)
     Queue<Work> wq;
@@ -576,7 +664,7 @@ void process_unpaired(Run &r)
     std::string merr;
     try {
         for (;;) {
-            RecBuf *b = s.full_q.pop();
+            RecBuf *b = s.pop();
             if (!b->error.empty()) throw Fatal(b->error);
             const bool last = b->eof;
             if (r.in_off == AUTO_OFFSET) r.in_off = r.detect(b);
@@ -590,9 +678,9 @@ void process_unpaired(Run &r)
     } catch (std::exception &e) { merr = e.what(); wq.push(Work()); }
     writer.join();
     if (!merr.empty() || !werr.empty()) {
-        std::thread([&] { for (;;) { RecBuf *b = s.full_q.pop(); if (b->eof || !b->error.empty()) break; s.free_q.push(b); } }).detach();
         fo.close(); fd.close();
-        throw Fatal(!merr.empty() ? merr : werr);
+        fprintf(stderr, "Caught the error %s\n", (!merr.empty() ? merr : werr).c_str());
+        _exit(EXIT_FAILURE);
     }
     s.stop();
     fo.close(); fd.close();
