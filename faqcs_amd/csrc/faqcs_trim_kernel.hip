@@ -72,6 +72,78 @@ __device__ __forceinline__ int bit_m1(uint32_t mask, int j) { return -(int)((mas
 
 } // namespace
 
+// LDS -> global u64 block.  Deliberately NOT inlined: the counter-block layout (a dozen 64-bit offsets) would
+// otherwise stay live in SGPRs across the whole read loop and push the kernel into scalar-register spills.
+template <int C, int NW>
+__device__ __noinline__ void flush_block(uint32_t *smem, uint64_t *counters, const uint32_t R, const int tid)
+{
+    using Cfg = RowCfg<C>;
+    constexpr int W = Cfg::W;
+    uint32_t *hq = smem + Cfg::O_HQ, *hb = smem + Cfg::O_HB, *hlen = smem + Cfg::O_LEN, *hrq = smem + Cfg::O_RQ;
+    uint32_t *hbqpre = smem + Cfg::O_BQPRE, *hbqpost = smem + Cfg::O_BQPOST, *lfs = smem + Cfg::O_FS;
+    // faqcs_counters_layout() restated (include/faqcs_mi.h): only R is needed for the offsets used here
+    faqcs_layout L;
+    {
+        uint64_t o = 0;
+        L.filter_stats = o;    o += 32;
+        L.pre_read_qhist = o;  o += FAQCS_NQ;
+        L.pre_base_qhist = o;  o += FAQCS_NQ;
+        L.post_read_qhist = o; o += FAQCS_NQ;
+        L.post_base_qhist = o; o += FAQCS_NQ;
+        L.pre_len_hist = o;    o += (uint64_t)R + 1;
+        L.post_len_hist = o;   o += (uint64_t)R + 1;
+        L.pre_qual = o;        o += (uint64_t)R * FAQCS_NQ;
+        L.post_qual = o;       o += (uint64_t)R * FAQCS_NQ;
+        L.pre_base = o;        o += (uint64_t)R * FAQCS_NBASE;
+        L.post_base = o;
+    }
+    __syncthreads();
+    for (int i = tid; i < Cfg::HQ; i += NW * 64) {
+        const uint32_t v = hq[i];
+        if (v) {
+            hq[i] = 0;
+            const uint32_t q = i / W, p = i % W;
+            if (p < R) {
+                if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)(v & 0xffffu));
+                if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)(v >> 16));
+            }
+        }
+    }
+    for (int i = tid; i < Cfg::HB; i += NW * 64) {
+        const uint32_t v = hb[i];
+        if (v) {
+            hb[i] = 0;
+            const uint32_t c = i / W, p = i % W;
+            if (p < R) {
+                if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_base + (uint64_t)p * FAQCS_NBASE + c), (unsigned long long)(v & 0xffffu));
+                if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_base + (uint64_t)p * FAQCS_NBASE + c), (unsigned long long)(v >> 16));
+            }
+        }
+    }
+    for (int i = tid; i <= W; i += NW * 64) {
+        const uint32_t v = hlen[i];
+        if (v && (uint32_t)i <= R) {
+            hlen[i] = 0;
+            if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_len_hist + i), (unsigned long long)(v & 0xffffu));
+            if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_len_hist + i), (unsigned long long)(v >> 16));
+        }
+    }
+    if (tid < FAQCS_NQ) {
+        const uint32_t v = hrq[tid], x = hbqpre[tid], y = hbqpost[tid];
+        hrq[tid] = 0; hbqpre[tid] = 0; hbqpost[tid] = 0;
+        if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_read_qhist + tid), (unsigned long long)(v & 0xffffu));
+        if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_read_qhist + tid), (unsigned long long)(v >> 16));
+        if (x) atomicAdd((unsigned long long *)(counters + L.pre_base_qhist + tid), (unsigned long long)x);
+        if (y) atomicAdd((unsigned long long *)(counters + L.post_base_qhist + tid), (unsigned long long)y);
+    }
+    if (tid >= 64 && tid < 64 + FAQCS_NUM_STAT) {
+        const int k = tid - 64;
+        const uint32_t v = lfs[k];
+        if (v) { atomicAdd((unsigned long long *)(counters + L.filter_stats + k), (unsigned long long)v); lfs[k] = 0; }
+    }
+    __syncthreads();
+}
+
 #ifndef FAQCS_TRIM_NW
 #define FAQCS_TRIM_NW 4        /* waves per block (A/B on MI355X: 4 waves x 3 blocks/CU beat 8 x 1 by 9 %) */
 #endif
@@ -603,54 +675,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
         }
 
         // ---- flush LDS -> global before a 16-bit field can overflow, and at the end ----------------------
-        if (block_flush) {
-            __syncthreads();
-            const faqcs_layout &L = P.lay;
-            for (int i = tid; i < Cfg::HQ; i += NW * 64) {
-                const uint32_t v = hq[i];
-                if (v) {
-                    hq[i] = 0;
-                    const uint32_t q = i / W, p = i % W;
-                    if (p < P.R) {
-                        if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)(v & 0xffffu));
-                        if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)(v >> 16));
-                    }
-                }
-            }
-            for (int i = tid; i < Cfg::HB; i += NW * 64) {
-                const uint32_t v = hb[i];
-                if (v) {
-                    hb[i] = 0;
-                    const uint32_t c = i / W, p = i % W;
-                    if (p < P.R) {
-                        if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_base + (uint64_t)p * FAQCS_NBASE + c), (unsigned long long)(v & 0xffffu));
-                        if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_base + (uint64_t)p * FAQCS_NBASE + c), (unsigned long long)(v >> 16));
-                    }
-                }
-            }
-            for (int i = tid; i <= W; i += NW * 64) {
-                const uint32_t v = hlen[i];
-                if (v && (uint32_t)i <= P.R) {
-                    hlen[i] = 0;
-                    if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_len_hist + i), (unsigned long long)(v & 0xffffu));
-                    if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_len_hist + i), (unsigned long long)(v >> 16));
-                }
-            }
-            if (tid < FAQCS_NQ) {
-                const uint32_t v = hrq[tid], x = hbqpre[tid], y = hbqpost[tid];
-                hrq[tid] = 0; hbqpre[tid] = 0; hbqpost[tid] = 0;
-                if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_read_qhist + tid), (unsigned long long)(v & 0xffffu));
-                if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_read_qhist + tid), (unsigned long long)(v >> 16));
-                if (x) atomicAdd((unsigned long long *)(counters + L.pre_base_qhist + tid), (unsigned long long)x);
-                if (y) atomicAdd((unsigned long long *)(counters + L.post_base_qhist + tid), (unsigned long long)y);
-            }
-            if (tid >= 64 && tid < 64 + FAQCS_NUM_STAT) {
-                const int k = tid - 64;
-                const uint32_t v = lfs[k];
-                if (v) { atomicAdd((unsigned long long *)(counters + L.filter_stats + k), (unsigned long long)v); lfs[k] = 0; }
-            }
-            __syncthreads();
-        }
+        if (block_flush) flush_block<C, NW>(smem, counters, P.R, tid);
     }
     if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
 }
