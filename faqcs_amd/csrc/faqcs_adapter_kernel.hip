@@ -257,6 +257,13 @@ hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const u
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((adapter_overlap<NW, 256>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
                            n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
+    } else if (max_len <= 1024) {
+        constexpr int NW = 8;
+        uint32_t grid = (n_reads + NW - 1) / NW;
+        const uint32_t cap = (uint32_t)n_cu * 4u;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL((adapter_overlap<NW, 1024>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
+                           n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
     } else {
         return hipErrorInvalidValue;
     }

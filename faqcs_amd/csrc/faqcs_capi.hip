@@ -217,7 +217,7 @@ static void build_tables(const faqcs_params &p, std::vector<uint32_t> &lcthr, st
                          std::vector<float> &norm, std::vector<uint32_t> &magic, std::vector<uint32_t> &base)
 {
     const int N = FAQCS_TAB_LEN + 1;
-    lcthr.assign(N, 0xffffffffu); avgq.assign(N, 0); norm.assign(512, 0.f); magic.assign(N, 0);
+    lcthr.assign(N, 0xffffffffu); avgq.assign(N, 0); norm.assign(N, 0.f); magic.assign(N, 0);
     const volatile float lc = p.low_complexity_cutoff_ratio;
     const volatile float avg = p.average_quality;
     for (int len = 1; len < N; ++len) {
@@ -417,7 +417,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, c->s_rec_pre.p, c->s_rec_post.p,
                                  c->d_counters, c->d_err, c->n_cu, c->compute));
         HIPCHK(hipEventRecord(t.b, c->compute));
-        if (!(c->dp.dbg & 1u)) {
+        if (!(c->dp.dbg & 1u) && max_len <= 256) { // the long-read kernels bin the composition themselves
             HIPCHK(faqcs_launch_composition(c->s_rec_pre.p, n, c->d_norm, c->d_counters + c->lay.pre_comp, c->n_cu, c->compute));
             HIPCHK(faqcs_launch_composition(c->s_rec_post.p, n, c->d_norm, c->d_counters + c->lay.post_comp, c->n_cu, c->compute));
         }
@@ -461,7 +461,7 @@ static int scan_offsets(const uint32_t *off, uint32_t n, uint32_t cap, uint32_t 
         m = l > m ? l : m;
     }
     if (m > cap) return fail(FAQCS_E_INVAL, "faqcs_submit: read longer than max_read_length");
-    if (m > 256) return fail(FAQCS_E_INVAL, "faqcs_submit: reads longer than 256 bases are not supported by this build of the HIP kernels");
+    if (m > FAQCS_MAX_READ_LENGTH) return fail(FAQCS_E_INVAL, "faqcs_submit: reads longer than FAQCS_MAX_READ_LENGTH bases are not supported by the HIP kernels");
     *max_len = m;
     return 0;
 }
@@ -552,7 +552,7 @@ extern "C" int faqcs_submit_device(faqcs_ctx *c, const faqcs_batch *b, faqcs_rea
     // offsets live on the device: the caller vouches for max_read_length; pick the kernel from the ctx capacity
     uint32_t max_len = b->max_read_len ? b->max_read_len : c->prm.max_read_length;
     if (max_len > c->prm.max_read_length) return fail(FAQCS_E_INVAL, "faqcs_submit_device: max_read_len exceeds the context capacity");
-    if (max_len > 256) return fail(FAQCS_E_INVAL, "faqcs_submit_device: reads longer than 256 bases are not supported by this build of the HIP kernels");
+    if (max_len > FAQCS_MAX_READ_LENGTH) return fail(FAQCS_E_INVAL, "faqcs_submit_device: reads longer than FAQCS_MAX_READ_LENGTH bases are not supported by the HIP kernels");
     if (!d_results) { HIPCHK(c->s_res.reserve((size_t)n + 1)); d_results = c->s_res.p; }
     return enqueue(c, b->seq, b->qual, b->offset, n, max_len, b->segment_start, b->n_segments, d_results);
 }

@@ -472,7 +472,7 @@ struct Run {
     faqcs_ctx *ctx = nullptr;
     faqcs_params prm;
     std::vector<const char *> adapter_ptr;
-    uint32_t R = 512;
+    uint32_t R = FAQCS_MAX_READ_LENGTH;
     int in_off, quality;
     uint64_t paired_read_number = 0, paired_base_length = 0;
     int n_parse = 4; // parser threads per input file (-t N caps the total)

@@ -7,6 +7,7 @@
 //   adapter_hit     u16[n]   1 + credited adapter index
 //   result          faqcs_read_result[n]  (8 B)
 //   comp_pre/post   u64[n]   per-read composition record: valid<<63 | len | nA<<9 | nT<<18 | nC<<27 | nG<<36 | nN<<45
+//                            (reads <= 256 bases; the long-read kernels bin the composition themselves)
 //   counters        u64[layout.total]     additive block (include/faqcs_mi.h faqcs_layout)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,7 +16,7 @@
 #include "../../include/faqcs_mi.h"
 
 #define FAQCS_WAVE 64
-#define FAQCS_TAB_LEN 256 /* per-length lookup tables: every length the row kernels support */
+#define FAQCS_TAB_LEN FAQCS_MAX_READ_LENGTH /* per-length lookup tables: every length the kernels support */
 
 // Everything the kernels need from faqcs_params + host-precomputed integer lookup tables, passed by value.
 struct DevParams {
@@ -102,4 +103,62 @@ __device__ __forceinline__ int row_incl_scan_add(int v)
 // value of the next / previous lane of the same row (0 at the row edge)
 __device__ __forceinline__ uint32_t row_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t row_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t row_incl_scan_umax(uint32_t x)
+{
+    int v = (int)x;
+    v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    return (uint32_t)v;
+}
+
+// The trim kernel is written against RowOps<LPR>: LPR = lanes that share one read.  16 = one DPP row per read
+// (4 reads per wave, reads <= 256 bases), 64 = the whole wave on one read (long reads, <= 1024 bases).
+template <int LPR> struct RowOps;
+template <> struct RowOps<16> {
+    static __device__ __forceinline__ int all_sum(int v) { return row_all_sum(v); }
+    static __device__ __forceinline__ uint32_t all_or(uint32_t v) { return row_all_or(v); }
+    static __device__ __forceinline__ uint32_t all_umax(uint32_t v) { return row_all_umax(v); }
+    static __device__ __forceinline__ int incl_scan_add(int v) { return row_incl_scan_add(v); }
+    static __device__ __forceinline__ uint32_t incl_scan_umax(uint32_t v) { return row_incl_scan_umax(v); }
+    static __device__ __forceinline__ uint32_t next(uint32_t v) { return row_next(v); }
+    static __device__ __forceinline__ uint32_t prev(uint32_t v) { return row_prev(v); }
+};
+template <> struct RowOps<64> {
+    static __device__ __forceinline__ int all_sum(int v) { return wave_sum_i32(v); }
+    static __device__ __forceinline__ uint32_t all_umax(uint32_t v) { return wave_max_u32(v); }
+    static __device__ __forceinline__ uint32_t all_or(uint32_t x)
+    {
+        int v = (int)x;
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+        return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+    }
+    static __device__ __forceinline__ int incl_scan_add(int v) { return wave_incl_scan_add(v); }
+    static __device__ __forceinline__ uint32_t incl_scan_umax(uint32_t x)
+    {
+        int v = (int)row_incl_scan_umax(x);
+        v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+        v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+        return (uint32_t)v;
+    }
+    // value of lane +/- 1 across the whole wave, 0 at the wave edge (ds_bpermute: the long-read path is not DPP-tuned)
+    static __device__ __forceinline__ uint32_t next(uint32_t v)
+    {
+        const int l = (int)(threadIdx.x & 63u);
+        const uint32_t x = (uint32_t)__shfl((int)v, (l + 1) & 63);
+        return l == 63 ? 0u : x;
+    }
+    static __device__ __forceinline__ uint32_t prev(uint32_t v)
+    {
+        const int l = (int)(threadIdx.x & 63u);
+        const uint32_t x = (uint32_t)__shfl((int)v, (l + 63) & 63);
+        return l == 0 ? 0u : x;
+    }
+};
 #endif

@@ -34,12 +34,17 @@
 
 namespace {
 
-constexpr int KEY_BIAS = 1 << 16; // |sum of (Q - q)| <= 256 * 168 < 2^16
-
-template <int C> struct RowCfg {
+template <int C, int LPR> struct RowCfg {
     static constexpr int D = (C + 3) / 4;          // dwords per lane per arena
-    static constexpr int W = 16 * C;               // positions covered by a row == columns of the LDS matrices
-    static constexpr int HQ = FAQCS_NQ * W;
+    static constexpr int W = LPR * C;              // positions covered by a row == columns of the LDS matrices
+    // position x quality lives in LDS while it fits next to the other tables (W <= 512); beyond that the kernel
+    // adds straight into the global u64 matrices
+    static constexpr bool HQ_LDS = W <= 512;
+    static constexpr int HQ = HQ_LDS ? FAQCS_NQ * W : 0;
+    // |sum of (Q - q)| <= W * 168: key bias and the bit width of a position field inside the argmax keys
+    static constexpr int KEY_BIAS = LPR == 16 ? (1 << 16) : (1 << 18);
+    static constexpr int PB = LPR == 16 ? 9 : 11;
+    static constexpr int FK = 2 * W;               // "first position" keys are FK - p (0 == none)
     static constexpr int HB = FAQCS_NBASE * W;
     static constexpr int O_HQ = 0;
     static constexpr int O_HB = O_HQ + HQ;
@@ -74,10 +79,10 @@ __device__ __forceinline__ int bit_m1(uint32_t mask, int j) { return -(int)((mas
 
 // LDS -> global u64 block.  Deliberately NOT inlined: the counter-block layout (a dozen 64-bit offsets) would
 // otherwise stay live in SGPRs across the whole read loop and push the kernel into scalar-register spills.
-template <int C, int NW>
+template <int C, int LPR, int NW>
 __device__ __noinline__ void flush_block(uint32_t *smem, uint64_t *counters, const uint32_t R, const int tid)
 {
-    using Cfg = RowCfg<C>;
+    using Cfg = RowCfg<C, LPR>;
     constexpr int W = Cfg::W;
     uint32_t *hq = smem + Cfg::O_HQ, *hb = smem + Cfg::O_HB, *hlen = smem + Cfg::O_LEN, *hrq = smem + Cfg::O_RQ;
     uint32_t *hbqpre = smem + Cfg::O_BQPRE, *hbqpost = smem + Cfg::O_BQPOST, *lfs = smem + Cfg::O_FS;
@@ -155,15 +160,17 @@ __device__ __noinline__ void flush_block(uint32_t *smem, uint64_t *counters, con
 // configuration) the prefix sum runs over all positions without per-position window tests.
 // GENERIC: false = the headline option set (BWA_plus, 5' trimming on, not --qc_only, no --replace_to_N_q, no
 // --avg_q, -n 2) is compiled in, so those tests and their live scalars disappear from the loop.
-template <int C, int NW, bool WINDOWED, bool GENERIC>
+template <int C, int LPR, int NW, bool WINDOWED, bool GENERIC>
 __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accumulate(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
     unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err)
 {
-    using Cfg = RowCfg<C>;
-    constexpr int D = Cfg::D, W = Cfg::W;
+    using Cfg = RowCfg<C, LPR>;
+    using RW = RowOps<LPR>;
+    constexpr int D = Cfg::D, W = Cfg::W, KEY_BIAS = Cfg::KEY_BIAS, PB = Cfg::PB, FK = Cfg::FK;
+    constexpr uint32_t PMX = (1u << PB) - 1u;
     constexpr uint32_t CMASK = (1u << C) - 1u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *hq = smem + Cfg::O_HQ, *hb = smem + Cfg::O_HB, *hlen = smem + Cfg::O_LEN, *hrq = smem + Cfg::O_RQ;
@@ -173,8 +180,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int rl = lane & 15;       // lane inside the row
-    const int rowb = lane & 48;     // first lane of the row
+    const int rl = lane & (LPR - 1);    // lane inside the row
+    const int rowb = lane & (64 - LPR); // first lane of the row
     const int wave = uni(tid >> 6);
     const int pbase = rl * C;
 
@@ -191,7 +198,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
     const uint32_t chunks_per_iter = gridDim.x * NW;
     const uint32_t n_iter = (total_chunks + chunks_per_iter - 1) / chunks_per_iter;
     constexpr uint32_t FLUSH_EVERY = 65535u / (NW * 64) > 0 ? 65535u / (NW * 64) : 1;
-    constexpr uint32_t REG_FLUSH_EVERY = 3; // 3 chunks x 16 reads per row = 48 <= 63 (6-bit fields)
+    // 6-bit fields: 3 chunks x 16 reads per row = 48 <= 63; a 64-lane row sees 64 reads per chunk and spills mid-chunk too
+    constexpr uint32_t REG_FLUSH_EVERY = LPR == 16 ? 3 : 1;
 
     const int in_off = P.in_off, Q = P.Q;
     const int o_mode = GENERIC ? P.mode : (int)FAQCS_MODE_BWA_PLUS;
@@ -206,6 +214,25 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 #pragma unroll
     for (int j = 0; j < C; ++j) { bpre[j] = 0; bpost[j] = 0; }
     uint32_t any_err = 0;
+    // global offsets the long-read variants add into directly (faqcs_counters_layout restated, see flush_block)
+    const uint64_t g_pre_qual = 32 + 4 * FAQCS_NQ + 2 * ((uint64_t)P.R + 1), g_post_qual = g_pre_qual + (uint64_t)P.R * FAQCS_NQ;
+    const uint64_t g_pre_comp = g_post_qual + (uint64_t)P.R * FAQCS_NQ + 2 * (uint64_t)P.R * FAQCS_NBASE;
+    const uint64_t g_post_comp = g_pre_comp + (uint64_t)FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND;
+    // spill of the register-privatised base matrix to LDS (before a 6-bit field can overflow)
+    auto spill_base_regs = [&]() {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t x = bpre[j], y = bpost[j];
+            if (x) {
+#pragma unroll
+                for (int c = 0; c < FAQCS_NBASE; ++c) {
+                    const uint32_t v = ((x >> BT_SHIFT(c)) & 63u) | (((y >> BT_SHIFT(c)) & 63u) << 16);
+                    if (v) atomicAdd(&hb[c * W + pbase + j], v);
+                }
+            }
+            bpre[j] = 0; bpost[j] = 0;
+        }
+    };
 
 #pragma unroll 1
     for (uint32_t it = 0; it < n_iter; ++it) {
@@ -238,15 +265,16 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
             }
 
 #pragma unroll 1
-            for (int t = 0; t < 16; ++t) {
+            for (int t = 0; t < LPR; ++t) {
                 if (base + (uint32_t)t >= n_reads) break; // wave-uniform: no row has a read left
+                if (LPR == 64 && t == 32) spill_base_regs();
                 const int len = n_len;
                 const bool act = base + (uint32_t)(rowb + t) < n_reads;
                 uint32_t ws[D], wq[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) { ws[k] = nseq.w[k]; wq[k] = nqual.w[k]; }
                 const uint32_t sl = (uint32_t)__shfl((int)v_sl, rowb + t);
-                if (t + 1 < 16) {
+                if (t + 1 < LPR) {
                     n_len = __shfl((int)v_len, rowb + t + 1);
                     const uint32_t o = (uint32_t)__shfl((int)v_off, rowb + t + 1);
 #pragma unroll
@@ -321,10 +349,10 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     if (!__any(term)) break;
                     const uint32_t inr = range_mask<C>(0, len, pbase);
                     const uint32_t non = inr & ~nubits;
-                    const uint32_t fn_l = non ? (uint32_t)(1023 - (pbase + __builtin_ctz(non))) : 0u;
+                    const uint32_t fn_l = non ? (uint32_t)(FK - (pbase + __builtin_ctz(non))) : 0u;
                     const uint32_t ln_l = non ? (uint32_t)(pbase + (31 - __builtin_clz(non)) + 1) : 0u;
-                    const uint32_t fn_m = row_all_umax(fn_l), ln_m = row_all_umax(ln_l);
-                    const int lead = fn_m ? 1023 - (int)fn_m : len;   // first non-N position (len if the read is all N)
+                    const uint32_t fn_m = RW::all_umax(fn_l), ln_m = RW::all_umax(ln_l);
+                    const int lead = fn_m ? FK - (int)fn_m : len;   // first non-N position (len if the read is all N)
                     const int trail_start = (int)ln_m;                // 1 + last non-N position (0 if none)
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
@@ -336,11 +364,11 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     }
                 }
                 {
-                    const int incl = row_incl_scan_add(run);
+                    const int incl = RW::incl_scan_add(run);
                     E = incl - run;                                  // prefix before this lane's first position
-                    T = row_all_sum(run);
+                    T = RW::all_sum(run);
                     // without window masks the zero bytes past the read contributed (Q - 0) each
-                    if (!WINDOWED) T -= Q * (16 * C - len);
+                    if (!WINDOWED) T -= Q * (LPR * C - len);
                 }
 #pragma unroll
                 for (int j = 0; j < C; ++j) Pin[j] += E;
@@ -350,15 +378,15 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 {
                     const uint32_t c = cntpack & BT_FIELDS;
                     const uint32_t at = (c & 63u) | (((c >> 6) & 63u) << 16), cg = ((c >> 12) & 63u) | (((c >> 18) & 63u) << 16);
-                    pAT = (uint32_t)row_all_sum((int)at);
-                    pCG = (uint32_t)row_all_sum((int)cg);
+                    pAT = (uint32_t)RW::all_sum((int)at);
+                    pCG = (uint32_t)RW::all_sum((int)cg);
                     // positions past the read contributed (0 - in_off) each: add them back
                     const int vb = med3i(len - pbase, 0, C);
-                    const int both = row_all_sum((((int)((c >> 24) & 63u)) << 20) + (sumv + in_off * (C - vb) + (1 << 14)));
+                    const int both = RW::all_sum((((int)((c >> 24) & 63u)) << 20) + (sumv + in_off * (C - vb) + (1 << 12)));
                     pN = (uint32_t)both >> 20;
-                    V_pre = (int)((uint32_t)both & 0xfffffu) - (16 << 14);
+                    V_pre = (int)((uint32_t)both & 0xfffffu) - (LPR << 12);
                 }
-                const bool read_err = row_all_umax(maxq) > 41u;
+                const bool read_err = RW::all_umax(maxq) > 41u;
 
                 // ---- quality trim (trim.cpp:325-360) -----------------------------------------------------
                 int hi_sum = 0, lo_sum = 0;     // BWA_plus by-products: prefix sums of (Q - q) at the two cut points
@@ -374,10 +402,10 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         for (int j = C - 1; j >= 0; --j) nn = (nn << 1) | (uint32_t)(Pin[j] <= T);
                         const uint32_t r3 = nn & range_mask<C>(a + nan2 + 1, a + n, pbase);
                         const uint32_t f5 = r3 & range_mask<C>(a + n - a5, a + n, pbase);
-                        const uint32_t ext = r3 | (row_next(r3) << C);
+                        const uint32_t ext = r3 | (RW::next(r3) << C);
                         const uint32_t c3 = ~ext & ~(ext >> 1) & (ext >> 2) & CMASK;
-                        const uint32_t red = row_all_umax((c3 ? (uint32_t)(pbase + (31 - __builtin_clz(c3)) + 1) : 0u));
-                        const bool early = row_all_or(f5) != 0u;
+                        const uint32_t red = RW::all_umax((c3 ? (uint32_t)(pbase + (31 - __builtin_clz(c3)) + 1) : 0u));
+                        const bool early = RW::all_or(f5) != 0u;
                         const int pstar = early ? (int)red - 1 : a + n - a5;
                         const uint32_t vis = range_mask<C>(pstar > a ? pstar : a, a + n, pbase);
                         // lane-local argmax of S = T - Pex (largest position on ties), then one row max
@@ -388,9 +416,9 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                             const uint32_t k = ((uint32_t)(TB - (j ? Pin[j - 1] : E)) << 4) | (uint32_t)j;
                             kl = umax_(kl, k & (uint32_t)bit_m1(vis, j));
                         }
-                        const uint32_t K3 = row_all_umax(kl ? (((kl >> 4) << 9) + (uint32_t)(pa + (int)(kl & 15u))) : 0u);
-                        const int S3 = (int)(K3 >> 9) - KEY_BIAS;
-                        fp3 = (S3 > 0) ? (int)(K3 & 511u) - 1 : n - 1;
+                        const uint32_t K3 = RW::all_umax(kl ? (((kl >> 4) << PB) + (uint32_t)(pa + (int)(kl & 15u))) : 0u);
+                        const int S3 = (int)(K3 >> PB) - KEY_BIAS;
+                        fp3 = (S3 > 0) ? (int)(K3 & PMX) - 1 : n - 1;
                         hi_sum = (S3 > 0) ? T - S3 : T;                       // sum of (Q-q) over window positions <= fp3
                         if (!o_protect5) {
                             uint32_t np = 0;
@@ -398,11 +426,11 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                             for (int j = C - 1; j >= 0; --j) np = (np << 1) | (uint32_t)((j ? Pin[j - 1] : E) >= 0);
                             const uint32_t r5 = np & range_mask<C>(a, a + fp3 - nan2, pbase);
                             const uint32_t g5 = r5 & range_mask<C>(a, a + a5, pbase);
-                            const uint32_t ext5 = (r5 << 2) | ((row_prev(r5) >> (C - 2)) & 3u); // bit k <-> position pbase + k - 2
+                            const uint32_t ext5 = (r5 << 2) | ((RW::prev(r5) >> (C - 2)) & 3u); // bit k <-> position pbase + k - 2
                             const uint32_t c5 = ~(ext5 >> 2) & ~(ext5 >> 1) & ext5 & CMASK;
-                            const uint32_t red5 = row_all_umax(c5 ? (uint32_t)(1023 - (pbase + __builtin_ctz(c5))) : 0u);
-                            const bool early5 = row_all_or(g5) != 0u;
-                            const int pstar5 = early5 ? 1023 - (int)red5 : a + a5 - 1;
+                            const uint32_t red5 = RW::all_umax(c5 ? (uint32_t)(FK - (pbase + __builtin_ctz(c5))) : 0u);
+                            const bool early5 = RW::all_or(g5) != 0u;
+                            const int pstar5 = early5 ? FK - (int)red5 : a + a5 - 1;
                             const uint32_t vis5 = range_mask<C>(a, (pstar5 + 1 < a + n) ? pstar5 + 1 : a + n, pbase);
                             uint32_t kl5 = 0;
 #pragma unroll
@@ -410,9 +438,9 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                                 const uint32_t k = ((uint32_t)(Pin[j] + KEY_BIAS) << 4) | (uint32_t)(15 - j);
                                 kl5 = umax_(kl5, k & (uint32_t)bit_m1(vis5, j));
                             }
-                            const uint32_t K5 = row_all_umax(kl5 ? (((kl5 >> 4) << 9) + (uint32_t)(511 - (pa + 15 - (int)(kl5 & 15u)))) : 0u);
-                            const int S5 = (int)(K5 >> 9) - KEY_BIAS;
-                            fp5 = (S5 > 0) ? 511 - (int)(K5 & 511u) + 1 : 0;
+                            const uint32_t K5 = RW::all_umax(kl5 ? (((kl5 >> 4) << PB) + (uint32_t)((int)PMX - (pa + 15 - (int)(kl5 & 15u)))) : 0u);
+                            const int S5 = (int)(K5 >> PB) - KEY_BIAS;
+                            fp5 = (S5 > 0) ? (int)PMX - (int)(K5 & PMX) + 1 : 0;
                             lo_sum = (S5 > 0) ? S5 : 0;                       // sum of (Q-q) over window positions < fp5
                         }
                         have_sums = true;
@@ -421,29 +449,29 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 #pragma unroll
                         for (int j = C - 1; j >= 0; --j) neg = (neg << 1) | (uint32_t)(Pin[j] > T);
                         neg &= range_mask<C>(a, a + n, pbase);
-                        const int pf = (int)row_all_umax(neg ? (uint32_t)(pbase + (31 - __builtin_clz(neg)) + 1) : 0u) - 1; // -1: none
+                        const int pf = (int)RW::all_umax(neg ? (uint32_t)(pbase + (31 - __builtin_clz(neg)) + 1) : 0u) - 1; // -1: none
                         const int lo = (pf < a ? a : pf) + 1;
                         const uint32_t vis = range_mask<C>(lo, a + n, pbase);
                         uint32_t key = 0;
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t k = ((uint32_t)(T - (j ? Pin[j - 1] : E) + KEY_BIAS) << 9) + (uint32_t)(pa + j);
+                            const uint32_t k = ((uint32_t)(T - (j ? Pin[j - 1] : E) + KEY_BIAS) << PB) + (uint32_t)(pa + j);
                             key = umax_(key, k & (uint32_t)bit_m1(vis, j));
                         }
-                        const uint32_t K3 = row_all_umax(key);
-                        fp3 = ((int)(K3 >> 9) - KEY_BIAS > 0) ? (int)(K3 & 511u) - 1 : n - 1;
+                        const uint32_t K3 = RW::all_umax(key);
+                        fp3 = ((int)(K3 >> PB) - KEY_BIAS > 0) ? (int)(K3 & PMX) - 1 : n - 1;
                     } else { // HARD, trim.cpp:629-672
                         uint32_t h0 = 0;
 #pragma unroll
                         for (int j = C - 1; j >= 0; --j) h0 = (h0 << 1) | (uint32_t)(Q < q[j]);
                         h0 &= range_mask<C>(a, a + n, pbase);
                         const uint32_t h1 = h0 & range_mask<C>(a + 1, a + n, pbase);
-                        const int h = (int)row_all_umax(h1 ? (uint32_t)(pbase + (31 - __builtin_clz(h1)) + 1) : 0u) - 1;
+                        const int h = (int)RW::all_umax(h1 ? (uint32_t)(pbase + (31 - __builtin_clz(h1)) + 1) : 0u) - 1;
                         int pos3 = 0;
                         if (h >= 0) { fp3 = h - a; pos3 = fp3; }
                         if (!o_protect5) {
-                            const uint32_t lm = row_all_umax(h0 ? (uint32_t)(1023 - (pbase + __builtin_ctz(h0))) : 0u);
-                            const int l = lm ? 1023 - (int)lm - a : 0x7fffffff;
+                            const uint32_t lm = RW::all_umax(h0 ? (uint32_t)(FK - (pbase + __builtin_ctz(h0))) : 0u);
+                            const int l = lm ? FK - (int)lm - a : 0x7fffffff;
                             if (l < pos3) fp5 = l;
                         }
                     }
@@ -465,9 +493,9 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     bool trip;
                     if (K == 0) trip = true;
                     else {
-                        const uint32_t e2 = nw | (row_next(nw) << C);
+                        const uint32_t e2 = nw | (RW::next(nw) << C);
                         const uint32_t pairs = e2 & (e2 >> 1) & CMASK;
-                        const uint32_t red = row_all_or((nw ? 1u : 0u) | (pairs ? 2u : 0u));
+                        const uint32_t red = RW::all_or((nw ? 1u : 0u) | (pairs ? 2u : 0u));
                         if (K == 1) trip = (red & 1u) != 0;
                         else if (K == 2) trip = (red & 2u) != 0;
                         else if (!(red & 2u)) trip = false;
@@ -479,19 +507,14 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                                 m = umax_(m, (in && !isn) ? (uint32_t)(pbase + j) + 1u : 0u);
                                 loc[j] = m;
                             }
-                            int s = (int)m; // inclusive max-scan over the row
-                            s = op_umax_(s, __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, false));
-                            s = op_umax_(s, __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, false));
-                            s = op_umax_(s, __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, false));
-                            s = op_umax_(s, __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, false));
-                            const uint32_t excl = row_prev((uint32_t)s);
+                            const uint32_t excl = RW::prev(RW::incl_scan_umax(m)); // max-scan over the lanes before this one
                             uint32_t best = 0;
 #pragma unroll
                             for (int j = 0; j < C; ++j) {
                                 const uint32_t lastnon = umax_(umax_(excl, loc[j]), (uint32_t)a);
                                 best = umax_(best, ((nw >> j) & 1u) ? (uint32_t)(pbase + j) + 1u - lastnon : 0u);
                             }
-                            trip = row_all_umax(best) >= K;
+                            trip = RW::all_umax(best) >= K;
                         }
                     }
                     if (trip) {
@@ -517,9 +540,9 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         cp += w & (uint32_t)bit_m1(win2, j);
                     }
                     const uint32_t at = (cp & 63u) | (((cp >> 6) & 63u) << 16), cg = ((cp >> 12) & 63u) | (((cp >> 18) & 63u) << 16);
-                    cAT = (uint32_t)row_all_sum((int)at);
-                    cCG = (uint32_t)row_all_sum((int)cg);
-                    cN = (uint32_t)row_all_sum((int)((cp >> 24) & 63u));
+                    cAT = (uint32_t)RW::all_sum((int)at);
+                    cCG = (uint32_t)RW::all_sum((int)cg);
+                    cN = (uint32_t)RW::all_sum((int)((cp >> 24) & 63u));
                     // V_post = sum over the final window of (raw - offset).  With no raw byte below the offset it is
                     // n*Q - sum(Q - q), and BWA_plus already produced both partial sums; otherwise re-add per position.
                     const bool clean = V_pre == len * Q - (WINDOWED ? 0 : T) && !WINDOWED; // all v == q over the whole read
@@ -532,7 +555,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                             const int sq = (int)(int8_t)((wq[j >> 2] >> (8 * (j & 3))) & 0xffu);
                             sv += (sq - in_off) & bit_m1(win2, j);
                         }
-                        V_post = row_all_sum(sv);
+                        V_post = RW::all_sum(sv);
                     }
                 }
                 const uint32_t cA = cAT & 0xffffu, cT = cAT >> 16, cC = cCG & 0xffffu, cG = cCG >> 16;
@@ -555,7 +578,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                             const uint32_t w = (((repbits >> j) & 1u) ? 0u : incf[j] & 0xffffffu) & (uint32_t)bit_m1(win2, j);
                             cls[j] = w ? (uint32_t)(__builtin_ctz(w) / 6) : 7u;
                         }
-                        const uint32_t prev_last = row_prev(cls[C - 1] + 1u); // 0 at the row edge
+                        const uint32_t prev_last = RW::prev(cls[C - 1] + 1u); // 0 at the row edge
                         const uint32_t cnts[4] = {cA, cT, cC, cG};
 #pragma unroll
                         for (int x = 0; x < 4; ++x)
@@ -568,7 +591,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                                         const uint32_t pv = j ? cls[j - 1] : prev_last - 1u; // row edge: 0xffffffff
                                         dc += (pv == (uint32_t)x && cls[j] == (uint32_t)y) ? 1 : 0;
                                     }
-                                    dc = row_all_sum(dc);
+                                    dc = RW::all_sum(dc);
                                     trip = trip || (cnts[x] >= dthr && cnts[y] >= dthr && (uint32_t)dc >= dthr);
                                 }
                     }
@@ -586,11 +609,20 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     const uint32_t inr = (act && !read_err) ? range_mask<C>(0, len, pbase) : 0u;
                     const uint32_t postm = ret ? (win2 & inr) : 0u;
                     const uint32_t both = inr | (postm << 16);
+                    if (!Cfg::HQ_LDS) {
+                        // long rows: the matrix does not fit in LDS, add straight into the global u64 block
+#pragma unroll
+                        for (int j = 0; j < C; ++j) {
+                            const uint64_t cell = (uint64_t)(pbase + j) * FAQCS_NQ + (uint32_t)q[j];
+                            if ((inr >> j) & 1u) atomicAdd((unsigned long long *)(counters + g_pre_qual + cell), 1ull);
+                            if ((postm >> j) & 1u) atomicAdd((unsigned long long *)(counters + g_post_qual + cell), 1ull);
+                        }
+                    }
                     if (o_replace_q > 0) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = read_err ? 0 : q[j];
-                            atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
+                            if (Cfg::HQ_LDS) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
                             bpre[j] += read_err ? 0u : incf[j];
                             const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
                             bpost[j] += w & (uint32_t)bit_m1(postm, j);
@@ -599,7 +631,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = read_err ? 0 : q[j];
-                            atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
+                            if (Cfg::HQ_LDS) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
                             bpre[j] += read_err ? 0u : incf[j];
                             bpost[j] += incf[j] & (uint32_t)bit_m1(postm, j);
                         }
@@ -638,13 +670,31 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         rpre = (act && !read_err) ? rp : 0ull;
                         rpost = (ret && !read_err) ? rq : 0ull;
                     }
+                    if (LPR == 64 && !(o_dbg & 33u) && !read_err) {
+                        // update_base_statistics' composition bins (trim.cpp:860-874) straight into the global block:
+                        // a record's 9-bit fields cannot hold these lengths.  Lanes 8..13 bin the raw read, 16..21
+                        // the trimmed one; kind 5 is the G bin index plus the C bin index (:874).
+                        const bool post = rl >= 16;
+                        const int kind = rl - (post ? 16 : 8);
+                        if ((unsigned)kind < 6u && (post ? ret : act)) {
+                            const uint32_t cnt5[5] = {post ? cA : (pAT & 0xffffu), post ? cT : (pAT >> 16), post ? cC : (pCG & 0xffffu),
+                                                      post ? cG : (pCG >> 16), post ? cN : pN};
+                            const float norm = P.comp_norm[post ? n : len];
+                            uint32_t idx = 0;
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) {
+                                const uint32_t b = (uint32_t)__fmul_rn(norm, (float)cnt5[k]);
+                                idx = (kind == k || (kind == 5 && (k == 2 || k == 3))) ? idx + b : idx;
+                            }
+                            atomicAdd((unsigned long long *)(counters + (post ? g_post_comp : g_pre_comp) + (uint64_t)idx * FAQCS_NCOMP_KIND + kind), 1ull);
+                        }
+                    }
                 }
             }
 
             if (mine) {
                 out[my] = make_uint2(res_lo, res_hi | (v_hit << 16));
-                rec_pre[my] = rpre;
-                rec_post[my] = rpost;
+                if (LPR == 16) { rec_pre[my] = rpre; rec_post[my] = rpost; }
             }
             if (rl == 0) {
                 if (fs_cnt) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], fs_cnt); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], fs_cnt); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], fs_total_len); }
@@ -659,23 +709,10 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 
         // ---- spill the register-privatised base matrix to LDS before a 6-bit field can overflow ----------
         const bool block_flush = ((it + 1) % FLUSH_EVERY) == 0 || it + 1 == n_iter;
-        if (((it + 1) % REG_FLUSH_EVERY) == 0 || block_flush) {
-#pragma unroll
-            for (int j = 0; j < C; ++j) {
-                const uint32_t x = bpre[j], y = bpost[j];
-                if (x) {
-#pragma unroll
-                    for (int c = 0; c < FAQCS_NBASE; ++c) {
-                        const uint32_t v = ((x >> BT_SHIFT(c)) & 63u) | (((y >> BT_SHIFT(c)) & 63u) << 16);
-                        if (v) atomicAdd(&hb[c * W + pbase + j], v);
-                    }
-                }
-                bpre[j] = 0; bpost[j] = 0;
-            }
-        }
+        if (((it + 1) % REG_FLUSH_EVERY) == 0 || block_flush) spill_base_regs();
 
         // ---- flush LDS -> global before a 16-bit field can overflow, and at the end ----------------------
-        if (block_flush) flush_block<C, NW>(smem, counters, P.R, tid);
+        if (block_flush) flush_block<C, LPR, NW>(smem, counters, P.R, tid);
     }
     if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
 }
@@ -733,15 +770,15 @@ __global__ __launch_bounds__(NT) void composition_histogram(const unsigned long 
 }
 
 // ---- launch wrappers ---------------------------------------------------------------------------------------
-template <int C, int NW, bool WINDOWED, bool GENERIC>
+template <int C, int LPR, int NW, bool WINDOWED, bool GENERIC>
 static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                 uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
                                 unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
                                 int n_cu, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)RowCfg<C>::LDS_DWORDS * 4;
+    constexpr size_t lds = (size_t)RowCfg<C, LPR>::LDS_DWORDS * 4;
     static bool attr_set = false;
-    auto kern = trim_filter_accumulate<C, NW, WINDOWED, GENERIC>;
+    auto kern = trim_filter_accumulate<C, LPR, NW, WINDOWED, GENERIC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -771,13 +808,17 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
                            P.max_poly_n == 2 && P.dbg == 0);
 #define FAQCS_TRIM_ARGS P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st
 #define FAQCS_TRIM_CASE(C, NW)                                                                              \
-    return windowed ? (generic ? launch_trim_t<C, NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, NW, true, false>(FAQCS_TRIM_ARGS)) \
-                    : (generic ? launch_trim_t<C, NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, NW, false, false>(FAQCS_TRIM_ARGS))
+    return windowed ? (generic ? launch_trim_t<C, 16, NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 16, NW, true, false>(FAQCS_TRIM_ARGS)) \
+                    : (generic ? launch_trim_t<C, 16, NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 16, NW, false, false>(FAQCS_TRIM_ARGS))
     if (max_len <= 64) FAQCS_TRIM_CASE(4, FAQCS_TRIM_NW);
     if (max_len <= 112) FAQCS_TRIM_CASE(7, FAQCS_TRIM_NW);
     if (max_len <= 160) FAQCS_TRIM_CASE(10, FAQCS_TRIM_NW);
     if (max_len <= 208) FAQCS_TRIM_CASE(13, FAQCS_TRIM_NW);
     if (max_len <= 256) FAQCS_TRIM_CASE(16, FAQCS_TRIM_NW);
+    // long reads: the whole wave on one read, one superset variant per width (MiSeq 2x300 -> C = 5)
+    if (max_len <= 320) return launch_trim_t<5, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
+    if (max_len <= 512) return launch_trim_t<8, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
+    if (max_len <= 1024) return launch_trim_t<16, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
 #undef FAQCS_TRIM_CASE
 #undef FAQCS_TRIM_ARGS
     return hipErrorInvalidValue;

@@ -44,7 +44,7 @@ enum {
 #define FAQCS_NCOMP_BIN 10001  /* NUM_COMPOSITION_BIN, FaQCs.h:20 */
 #define FAQCS_NCOMP_KIND 6     /* NucleotideCount fields A,T,C,G,N,GC, FaQCs.h:167-174 */
 #define FAQCS_SEGMENT_READS 32768 /* buffer_size, FaQCs.cpp:232,585 */
-#define FAQCS_MAX_READ_LENGTH 4096
+#define FAQCS_MAX_READ_LENGTH 1024 /* longest read the HIP kernels take (the reference: int16 aligner, < 32 768) */
 #define FAQCS_MAX_ADAPTERS 64
 #define FAQCS_MAX_ADAPTER_LENGTH 8192
 

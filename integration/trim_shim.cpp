@@ -40,7 +40,7 @@ struct Shim {
     vector<uint64_t> prev, cur;
     vector<string> adapter_names;
     int quality = 0;
-    uint32_t R = 512; // row capacity of the per-position matrices (the HIP kernels take reads up to 256 bases)
+    uint32_t R = FAQCS_MAX_READ_LENGTH; // row capacity of the per-position matrices == longest read the HIP kernels take
     // reusable host arenas
     vector<uint8_t> seq, qual;
     vector<uint32_t> off;

@@ -176,6 +176,10 @@ def materialise(name, outdir):
         r1, r2 = headline(3000, 150, adapter_frac=0.05)
     elif name == "head250":
         r1, r2 = headline(1200, 250)
+    elif name == "long300":  # MiSeq 2x300: past the 256-base row kernels
+        r1, r2 = adversarial(700, seed=21, maxlen=300, id_prefix="M")
+    elif name == "long1000":  # ragged 20..1000-base reads (Ion Torrent / 454 lengths)
+        r1, r2 = adversarial(260, seed=23, maxlen=1000, id_prefix="L")
     else:
         raise KeyError(name)
     write_fastq(p1, r1)

@@ -62,6 +62,13 @@ CASES = [
     ("head150_default", "head150", P + ["--min_L", "50", "-q", "5"]),
     ("head150_adapter_polyA", "head150", P + ["--adapter", "--polyA"]),
     ("head250_default", "head250", P),
+    ("long300_default", "long300", P),
+    ("long300_adapter_polyA", "long300", P + ["--adapter", "--polyA"]),
+    ("long300_kmer_q20", "long300", P + ["--kmer_rarefaction", "--split_size", "300", "-q", "20", "--replace_to_N_q", "12"]),
+    ("long1000_default", "long1000", P),
+    ("long1000_bwa_avgq", "long1000", P + ["--mode", "BWA", "--avg_q", "20", "-n", "3"]),
+    ("long1000_hard_lc", "long1000", P + ["--mode", "HARD", "-q", "12", "--lc", "0.6", "--5end", "7", "--3end", "9"]),
+    ("long1000_adapter_polyA", "long1000", P + ["--adapter", "--polyA", "--discard"]),
     ("example_fixed_point", "example", P),
     ("advbig_default", "advbig", P),
     ("advbig_adapter_polyA", "advbig", P + ["--adapter", "--polyA"]),

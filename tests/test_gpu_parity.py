@@ -106,6 +106,30 @@ def test_random_batches_match_oracle(args, kind, maxlen):
     compare_engines(opt, reads, seg_size=517)  # ragged segments: tail groups of the adapter pre-pass
 
 
+@pytest.mark.parametrize("args", OPTION_SETS, ids=lambda a: " ".join(a) or "default")
+@pytest.mark.parametrize("kind,maxlen", [("adv", 300), ("ragged", 500), ("adv", 1024)])
+def test_long_reads_match_oracle(args, kind, maxlen):
+    """Reads past the 256-base row kernels: the 64-lanes-per-read variants (widths 320 / 512 / 1024)."""
+    rng = np.random.Generator(np.random.PCG64([7, len(kind), maxlen, OPTION_SETS.index(args)]))
+    opt = parse_args(["-u", "x", "-d", "y"] + args)
+    n = 150 if "--adapter" in args else 500
+    reads = random_batch(rng, n, maxlen, kind)
+    compare_engines(opt, reads, R=1024, seg_size=117)
+
+
+def test_long_read_limits():
+    """Exactly FAQCS_MAX_READ_LENGTH bases is accepted, one more is refused loudly (no silent truncation)."""
+    from faqcs_amd.engine import FaqcsError
+
+    opt = parse_args(["-u", "x", "-d", "y", "--min_L", "1"])
+    L = capi.MAX_READ_LENGTH
+    ok = [(b"@e", (b"ACGT" * 300)[:L], bytes([33 + 38] * (L - 40) + [35] * 40)), (b"@e", b"N" * L, bytes([33 + 20] * L))]
+    compare_engines(opt, ok, R=L)
+    with pytest.raises(FaqcsError) as ei:
+        compare_engines(opt, [(b"@e", b"A" * (L + 1), bytes([70] * (L + 1)))], R=L)
+    assert ei.value.code == capi.E_INVAL
+
+
 def test_edge_reads():
     opt = parse_args(["-u", "x", "-d", "y", "--min_L", "1", "--adapter", "--polyA"])
     Q = lambda s: bytes([33 + c for c in s])  # noqa: E731
@@ -147,7 +171,7 @@ def test_golden_cases_on_gpu(name, fixture_cache, tmp_path):
     """The reference's own outputs (QC.stats.txt, trimmed FASTQ, --debug tables) reproduced by the HIP path."""
     from golden_util import load_case, run_case
 
-    bad = run_case(load_case(name), fixture_cache, tmp_path, hip_factory, max_read_length=512)
+    bad = run_case(load_case(name), fixture_cache, tmp_path, hip_factory, max_read_length=1024)
     assert not bad, "\n".join(bad)
     assert _native_loaded()
 

@@ -7,5 +7,5 @@ from oracle_engine import oracle_factory
 
 @pytest.mark.parametrize("name", case_names())
 def test_oracle_matches_reference(name, fixture_cache, tmp_path):
-    bad = run_case(load_case(name), fixture_cache, tmp_path, oracle_factory, max_read_length=512)
+    bad = run_case(load_case(name), fixture_cache, tmp_path, oracle_factory, max_read_length=1024)
     assert not bad, "\n".join(bad)
