@@ -27,7 +27,7 @@ def test_exports_every_declared_symbol(lib):
     assert lib.faqcs_abi_version() == capi.ABI_VERSION
 
 
-@pytest.mark.parametrize("R,na", [(150, 0), (256, 10), (4096, 12)])
+@pytest.mark.parametrize("R,na", [(150, 0), (256, 10), (1024, 12)])
 def test_layout_agrees(lib, R, na):
     lay = capi.Layout()
     assert lib.faqcs_counters_layout(R, na, C.byref(lay)) == 0
