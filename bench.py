@@ -123,7 +123,7 @@ def main():
     L = a.read_len
     opt_args = ["--adapter", "--polyA"] if a.config == "adapter" else []
     opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
-    eng = HipEngine(opt, 256, 33, device=local)
+    eng = HipEngine(opt, 256 if L <= 256 else capi.MAX_READ_LENGTH, 33, device=local)
     lib = eng.lib
 
     # ---- resident synthetic data set ---------------------------------------------------------------------

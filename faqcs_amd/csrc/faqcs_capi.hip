@@ -36,7 +36,7 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
                              uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st);
-hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, const float *comp_norm, uint64_t *dst,
+hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, bool wide, const float *comp_norm, uint64_t *dst,
                                     int n_cu, hipStream_t st);
 hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
                                 uint32_t max_len, const uint32_t *seg_start, uint32_t n_segments, uint32_t *ad_sl,
@@ -413,13 +413,14 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         }
         Timing &t = c->timings[c->timing_used++];
         HIPCHK(hipEventRecord(t.a, c->compute));
-        HIPCHK(c->s_rec_pre.reserve(n)); HIPCHK(c->s_rec_post.reserve(n));
+        const bool wide = max_len > 256; // the long-read kernels write two-word composition records
+        HIPCHK(c->s_rec_pre.reserve((size_t)n * (wide ? 2 : 1))); HIPCHK(c->s_rec_post.reserve((size_t)n * (wide ? 2 : 1)));
         HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, c->s_rec_pre.p, c->s_rec_post.p,
                                  c->d_counters, c->d_err, c->n_cu, c->compute));
         HIPCHK(hipEventRecord(t.b, c->compute));
-        if (!(c->dp.dbg & 1u) && max_len <= 256) { // the long-read kernels bin the composition themselves
-            HIPCHK(faqcs_launch_composition(c->s_rec_pre.p, n, c->d_norm, c->d_counters + c->lay.pre_comp, c->n_cu, c->compute));
-            HIPCHK(faqcs_launch_composition(c->s_rec_post.p, n, c->d_norm, c->d_counters + c->lay.post_comp, c->n_cu, c->compute));
+        if (!(c->dp.dbg & 1u)) {
+            HIPCHK(faqcs_launch_composition(c->s_rec_pre.p, n, wide, c->d_norm, c->d_counters + c->lay.pre_comp, c->n_cu, c->compute));
+            HIPCHK(faqcs_launch_composition(c->s_rec_post.p, n, wide, c->d_norm, c->d_counters + c->lay.post_comp, c->n_cu, c->compute));
         }
     }
     // ---- rarefaction bookkeeping per reference trim() call (trim.cpp:157-185) -------------------------------

@@ -7,7 +7,7 @@
 //   adapter_hit     u16[n]   1 + credited adapter index
 //   result          faqcs_read_result[n]  (8 B)
 //   comp_pre/post   u64[n]   per-read composition record: valid<<63 | len | nA<<9 | nT<<18 | nC<<27 | nG<<36 | nN<<45
-//                            (reads <= 256 bases; the long-read kernels bin the composition themselves)
+//                            (reads <= 256 bases; the long-read kernels write two words with 11-bit fields)
 //   counters        u64[layout.total]     additive block (include/faqcs_mi.h faqcs_layout)
 #pragma once
 #include <hip/hip_runtime.h>

@@ -37,10 +37,12 @@ namespace {
 template <int C, int LPR> struct RowCfg {
     static constexpr int D = (C + 3) / 4;          // dwords per lane per arena
     static constexpr int W = LPR * C;              // positions covered by a row == columns of the LDS matrices
-    // position x quality lives in LDS while it fits next to the other tables (W <= 512); beyond that the kernel
-    // adds straight into the global u64 matrices
-    static constexpr bool HQ_LDS = W <= 512;
-    static constexpr int HQ = HQ_LDS ? FAQCS_NQ * W : 0;
+    // position x quality in LDS: one dword per cell (pre count lo16 / post count hi16) while that fits next to the
+    // other tables (W <= 512); wider rows pack two cells per dword as 8-bit pre/post counters and the block flushes
+    // them every 16 reads per wave (HQ8_EVERY x NW <= 255 increments per cell between flushes)
+    static constexpr bool HQ8 = W > 512;
+    static constexpr int HQ8_EVERY = 16;
+    static constexpr int HQ = HQ8 ? FAQCS_NQ * W / 2 : FAQCS_NQ * W;
     // |sum of (Q - q)| <= W * 168: key bias and the bit width of a position field inside the argmax keys
     static constexpr int KEY_BIAS = LPR == 16 ? (1 << 16) : (1 << 18);
     static constexpr int PB = LPR == 16 ? 9 : 11;
@@ -103,7 +105,7 @@ __device__ __noinline__ void flush_block(uint32_t *smem, uint64_t *counters, con
         L.post_base = o;
     }
     __syncthreads();
-    for (int i = tid; i < Cfg::HQ; i += NW * 64) {
+    for (int i = tid; i < (Cfg::HQ8 ? 0 : Cfg::HQ); i += NW * 64) {
         const uint32_t v = hq[i];
         if (v) {
             hq[i] = 0;
@@ -149,6 +151,33 @@ __device__ __noinline__ void flush_block(uint32_t *smem, uint64_t *counters, con
     __syncthreads();
 }
 
+// 8-bit packed position x quality cells (rows wider than 512) -> global u64 block; called by the whole block
+template <int C, int LPR, int NW>
+__device__ __noinline__ void flush_hq8(uint32_t *smem, uint64_t *counters, const uint32_t R, const int tid)
+{
+    using Cfg = RowCfg<C, LPR>;
+    constexpr int HW = Cfg::W / 2;
+    uint32_t *hq = smem + Cfg::O_HQ;
+    const uint64_t pre_qual = 32 + 4 * FAQCS_NQ + 2 * ((uint64_t)R + 1), post_qual = pre_qual + (uint64_t)R * FAQCS_NQ;
+    __syncthreads();
+    for (int i = tid; i < Cfg::HQ; i += NW * 64) {
+        const uint32_t v = hq[i];
+        if (v) {
+            hq[i] = 0;
+            const uint32_t q = i / HW, p = 2u * (uint32_t)(i % HW);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t a = (v >> (16 * h)) & 0xffu, b = (v >> (16 * h + 8)) & 0xffu;
+                if (p + h < R) {
+                    if (a) atomicAdd((unsigned long long *)(counters + pre_qual + (uint64_t)(p + h) * FAQCS_NQ + q), (unsigned long long)a);
+                    if (b) atomicAdd((unsigned long long *)(counters + post_qual + (uint64_t)(p + h) * FAQCS_NQ + q), (unsigned long long)b);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 #ifndef FAQCS_TRIM_NW
 #define FAQCS_TRIM_NW 4        /* waves per block (A/B on MI355X: 4 waves x 3 blocks/CU beat 8 x 1 by 9 %) */
 #endif
@@ -171,6 +200,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
     using RW = RowOps<LPR>;
     constexpr int D = Cfg::D, W = Cfg::W, KEY_BIAS = Cfg::KEY_BIAS, PB = Cfg::PB, FK = Cfg::FK;
     constexpr uint32_t PMX = (1u << PB) - 1u;
+    static_assert(!Cfg::HQ8 || NW * Cfg::HQ8_EVERY <= 255, "an 8-bit cell must not overflow between two flushes");
     constexpr uint32_t CMASK = (1u << C) - 1u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *hq = smem + Cfg::O_HQ, *hb = smem + Cfg::O_HB, *hlen = smem + Cfg::O_LEN, *hrq = smem + Cfg::O_RQ;
@@ -214,10 +244,6 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 #pragma unroll
     for (int j = 0; j < C; ++j) { bpre[j] = 0; bpost[j] = 0; }
     uint32_t any_err = 0;
-    // global offsets the long-read variants add into directly (faqcs_counters_layout restated, see flush_block)
-    const uint64_t g_pre_qual = 32 + 4 * FAQCS_NQ + 2 * ((uint64_t)P.R + 1), g_post_qual = g_pre_qual + (uint64_t)P.R * FAQCS_NQ;
-    const uint64_t g_pre_comp = g_post_qual + (uint64_t)P.R * FAQCS_NQ + 2 * (uint64_t)P.R * FAQCS_NBASE;
-    const uint64_t g_post_comp = g_pre_comp + (uint64_t)FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND;
     // spill of the register-privatised base matrix to LDS (before a 6-bit field can overflow)
     auto spill_base_regs = [&]() {
 #pragma unroll
@@ -237,7 +263,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 #pragma unroll 1
     for (uint32_t it = 0; it < n_iter; ++it) {
         const uint32_t chunk = (it * gridDim.x + blockIdx.x) * NW + wave;
-        if (chunk < total_chunks) {
+        // (the 8-bit variant has block barriers inside the read loop: a wave without a chunk runs it with no reads)
+        if (Cfg::HQ8 || chunk < total_chunks) {
             const uint32_t base = chunk << 6;
             const uint32_t my = base + lane;
             const bool mine = my < n_reads;
@@ -246,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
             const uint32_t v_sl = (ad_sl && mine) ? ad_sl[my] : (v_len << 16);
             const uint32_t v_hit = (ad_hit && mine) ? ad_hit[my] : 0u;
             uint32_t res_lo = 0, res_hi = 0;
-            unsigned long long rpre = 0, rpost = 0;
+            unsigned long long rpre = 0, rpost = 0, rpre1 = 0, rpost1 = 0; // (the second words: long-read records)
             // FilterStat accumulators (row-uniform values; lane 0 of each row publishes them)
             uint32_t fs_cnt = 0, fs_total_len = 0, fs_trim_num = 0, fs_trim_len = 0, fs_rlen = 0, fs_blen = 0, fs_rnn = 0,
                      fs_bnn = 0, fs_ravg = 0, fs_bavg = 0, fs_rqt = 0, fs_bqt = 0, fs_rlc = 0, fs_blc = 0;
@@ -266,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 
 #pragma unroll 1
             for (int t = 0; t < LPR; ++t) {
-                if (base + (uint32_t)t >= n_reads) break; // wave-uniform: no row has a read left
+                if (!Cfg::HQ8 && base + (uint32_t)t >= n_reads) break; // wave-uniform: no row has a read left
                 if (LPR == 64 && t == 32) spill_base_regs();
                 const int len = n_len;
                 const bool act = base + (uint32_t)(rowb + t) < n_reads;
@@ -609,20 +636,19 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     const uint32_t inr = (act && !read_err) ? range_mask<C>(0, len, pbase) : 0u;
                     const uint32_t postm = ret ? (win2 & inr) : 0u;
                     const uint32_t both = inr | (postm << 16);
-                    if (!Cfg::HQ_LDS) {
-                        // long rows: the matrix does not fit in LDS, add straight into the global u64 block
+                    if (Cfg::HQ8) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint64_t cell = (uint64_t)(pbase + j) * FAQCS_NQ + (uint32_t)q[j];
-                            if ((inr >> j) & 1u) atomicAdd((unsigned long long *)(counters + g_pre_qual + cell), 1ull);
-                            if ((postm >> j) & 1u) atomicAdd((unsigned long long *)(counters + g_post_qual + cell), 1ull);
+                            const int qq = read_err ? 0 : q[j];
+                            const uint32_t x = (both >> j) & 0x10001u;          // pre -> byte 0, post -> byte 1 of the cell
+                            atomicAdd(&hq[qq * (W / 2) + ((pbase + j) >> 1)], ((x | (x >> 8)) & 0x101u) << (16 * ((pbase + j) & 1)));
                         }
                     }
                     if (o_replace_q > 0) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = read_err ? 0 : q[j];
-                            if (Cfg::HQ_LDS) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
+                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
                             bpre[j] += read_err ? 0u : incf[j];
                             const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
                             bpost[j] += w & (uint32_t)bit_m1(postm, j);
@@ -631,7 +657,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = read_err ? 0 : q[j];
-                            if (Cfg::HQ_LDS) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
+                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
                             bpre[j] += read_err ? 0u : incf[j];
                             bpost[j] += incf[j] & (uint32_t)bit_m1(postm, j);
                         }
@@ -670,31 +696,27 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         rpre = (act && !read_err) ? rp : 0ull;
                         rpost = (ret && !read_err) ? rq : 0ull;
                     }
-                    if (LPR == 64 && !(o_dbg & 33u) && !read_err) {
-                        // update_base_statistics' composition bins (trim.cpp:860-874) straight into the global block:
-                        // a record's 9-bit fields cannot hold these lengths.  Lanes 8..13 bin the raw read, 16..21
-                        // the trimmed one; kind 5 is the G bin index plus the C bin index (:874).
-                        const bool post = rl >= 16;
-                        const int kind = rl - (post ? 16 : 8);
-                        if ((unsigned)kind < 6u && (post ? ret : act)) {
-                            const uint32_t cnt5[5] = {post ? cA : (pAT & 0xffffu), post ? cT : (pAT >> 16), post ? cC : (pCG & 0xffffu),
-                                                      post ? cG : (pCG >> 16), post ? cN : pN};
-                            const float norm = P.comp_norm[post ? n : len];
-                            uint32_t idx = 0;
-#pragma unroll
-                            for (int k = 0; k < 5; ++k) {
-                                const uint32_t b = (uint32_t)__fmul_rn(norm, (float)cnt5[k]);
-                                idx = (kind == k || (kind == 5 && (k == 2 || k == 3))) ? idx + b : idx;
-                            }
-                            atomicAdd((unsigned long long *)(counters + (post ? g_post_comp : g_pre_comp) + (uint64_t)idx * FAQCS_NCOMP_KIND + kind), 1ull);
-                        }
+                    if (LPR == 64 && rl == t && !(o_dbg & 32u)) {
+                        // reads past 511 bases do not fit the 9-bit record: 11-bit fields over two words
+                        const unsigned long long w0 = CR_VALID | (unsigned long long)len | ((unsigned long long)(pAT & 0xffffu) << 11) |
+                                                      ((unsigned long long)(pAT >> 16) << 22) | ((unsigned long long)(pCG & 0xffffu) << 33);
+                        const unsigned long long x0 = CR_VALID | (unsigned long long)n | ((unsigned long long)cA << 11) |
+                                                      ((unsigned long long)cT << 22) | ((unsigned long long)cC << 33);
+                        const bool pre_on = act && !read_err, post_on = ret && !read_err;
+                        rpre = pre_on ? w0 : 0ull;   rpre1 = pre_on ? ((unsigned long long)(pCG >> 16) | ((unsigned long long)pN << 11)) : 0ull;
+                        rpost = post_on ? x0 : 0ull; rpost1 = post_on ? ((unsigned long long)cG | ((unsigned long long)cN << 11)) : 0ull;
                     }
                 }
+                if (Cfg::HQ8 && (t % Cfg::HQ8_EVERY) == Cfg::HQ8_EVERY - 1) flush_hq8<C, LPR, NW>(smem, counters, P.R, tid);
             }
 
             if (mine) {
                 out[my] = make_uint2(res_lo, res_hi | (v_hit << 16));
                 if (LPR == 16) { rec_pre[my] = rpre; rec_post[my] = rpost; }
+                else {
+                    reinterpret_cast<ulonglong2 *>(rec_pre)[my] = make_ulonglong2(rpre, rpre1);
+                    reinterpret_cast<ulonglong2 *>(rec_post)[my] = make_ulonglong2(rpost, rpost1);
+                }
             }
             if (rl == 0) {
                 if (fs_cnt) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], fs_cnt); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], fs_cnt); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], fs_total_len); }
@@ -722,7 +744,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 // records.  One thread per record; the block's LDS holds the whole 10 001 x 6 table as 16-bit counters
 // (two per dword), flushed to the global u64 block before any of them can overflow.
 // ---------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool WIDE>
 __global__ __launch_bounds__(NT) void composition_histogram(const unsigned long long *__restrict__ rec, const uint32_t n,
                                                             const float *__restrict__ comp_norm,
                                                             uint64_t *__restrict__ dst /* counters + L.{pre,post}_comp */)
@@ -739,13 +761,24 @@ __global__ __launch_bounds__(NT) void composition_histogram(const unsigned long 
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t i = (r * gridDim.x + blockIdx.x) * NT + tid;
         if (i < n) {
-            const unsigned long long x = rec[i];
+            unsigned long long x, y = 0;
+            if (WIDE) { const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(rec)[i]; x = v.x; y = v.y; }
+            else x = rec[i];
             if (x & CR_VALID) {
-                const uint32_t len = (uint32_t)(x & 511u);
+                uint32_t len, cnt[5];
+                if (WIDE) {
+                    len = (uint32_t)(x & 2047u);
+                    cnt[0] = (uint32_t)(x >> 11) & 2047u; cnt[1] = (uint32_t)(x >> 22) & 2047u; cnt[2] = (uint32_t)(x >> 33) & 2047u;
+                    cnt[3] = (uint32_t)y & 2047u; cnt[4] = (uint32_t)(y >> 11) & 2047u;
+                } else {
+                    len = (uint32_t)(x & 511u);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) cnt[k] = (uint32_t)(x >> (9 + 9 * k)) & 511u;
+                }
                 const float norm = comp_norm[len];
                 uint32_t idx[6];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) idx[k] = (uint32_t)__fmul_rn(norm, (float)(uint32_t)((x >> (9 + 9 * k)) & 511u)); // :862-872
+                for (int k = 0; k < 5; ++k) idx[k] = (uint32_t)__fmul_rn(norm, (float)cnt[k]); // :862-872
                 idx[5] = idx[3] + idx[2];                                                                                  // :874 (G + C)
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
@@ -818,22 +851,24 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
     // long reads: the whole wave on one read, one superset variant per width (MiSeq 2x300 -> C = 5)
     if (max_len <= 320) return launch_trim_t<5, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
     if (max_len <= 512) return launch_trim_t<8, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
-    if (max_len <= 1024) return launch_trim_t<16, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
+    if (max_len <= 1024) return launch_trim_t<16, 64, 8, true, true>(FAQCS_TRIM_ARGS); // 8 x 16 reads <= 255 per 8-bit cell
 #undef FAQCS_TRIM_CASE
 #undef FAQCS_TRIM_ARGS
     return hipErrorInvalidValue;
 }
 
-hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, const float *comp_norm, uint64_t *dst,
+// wide: the two-word records of the long-read kernels (max_len > 256)
+hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, bool wide, const float *comp_norm, uint64_t *dst,
                                     int n_cu, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     constexpr int NT = 1024;
     constexpr size_t lds = (size_t)((FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND + 1) / 2) * 4;
     static bool attr_set = false;
-    auto kern = composition_histogram<NT>;
+    auto kern = wide ? composition_histogram<NT, true> : composition_histogram<NT, false>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(composition_histogram<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(composition_histogram<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }

@@ -125,6 +125,9 @@ def test_long_read_limits():
     L = capi.MAX_READ_LENGTH
     ok = [(b"@e", (b"ACGT" * 300)[:L], bytes([33 + 38] * (L - 40) + [35] * 40)), (b"@e", b"N" * L, bytes([33 + 20] * L))]
     compare_engines(opt, ok, R=L)
+    # constant quality (FASTA converted to FASTQ): every read hits the same position x quality cells, the worst case for
+    # the 8-bit packed LDS counters of the 1024-wide kernel
+    compare_engines(opt, [(b"@e", (b"ACGGT" * 205)[:L], bytes([33 + 40] * L))] * 1500 + [(b"@e", b"ACGT" * 150, bytes([33 + 40] * 600))] * 300, R=L)
     with pytest.raises(FaqcsError) as ei:
         compare_engines(opt, [(b"@e", b"A" * (L + 1), bytes([70] * (L + 1)))], R=L)
     assert ei.value.code == capi.E_INVAL
