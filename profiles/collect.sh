@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU box (run through gpurun from the repo root):
+#   bash profiles/collect.sh <tag>            -> gpurun_out/<tag>/...   (copy what you want judged into profiles/<tag>/)
+# 1. bench.py default line (BASELINE configs[1], 100 M pairs) and the adapter configuration
+# 2. rocprofv3 --kernel-trace --stats over a shorter bench run (same kernels, same launch size)
+# 3. HBM traffic: separate --pmc passes for FETCH_SIZE and WRITE_SIZE (never combined with other trace domains)
+set -u
+tag=${1:-r1}
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+if [ "${SKIP_BENCH:-0}" != 1 ]; then
+python3 bench.py > $out/bench_plain_100Mpairs.json 2> $out/bench_plain.err
+python3 bench.py --config adapter --pairs 20e6 --no-cpu-baseline > $out/bench_adapter_20Mpairs.json 2> $out/bench_adapter.err
+python3 bench.py --read-len 250 --pairs 40e6 --no-cpu-baseline > $out/bench_plain_250bp_40Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 300 --pairs 20e6 --no-cpu-baseline > $out/bench_plain_300bp_20Mpairs.json 2>> $out/bench_plain.err
+fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_plain -o plain -- python3 bench.py --pairs 25165824 --steps 3 --no-cpu-baseline > $out/prof_plain.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_adapter -o adapter -- python3 bench.py --config adapter --pairs 4e6 --steps 3 --no-cpu-baseline > $out/prof_adapter.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python3 tests/ablate.py 0 16e6 > $out/pmc_$c.log 2>&1
+done
+python3 profiles/pmc_traffic.py $out 16000000 > $out/traffic_plain.json 2> $out/traffic.err
+find $out -name "*kernel_stats.csv" -exec sh -c 'cp "$1" '$out'/$(basename $(dirname $(dirname "$1")))_kernel_stats.csv' _ {} \;
+ls -la $out
