@@ -75,7 +75,14 @@ template <int C> __device__ __forceinline__ uint32_t range_mask(int lo, int hi, 
     e = e > s ? e : s;
     return ((1u << (e - s)) - 1u) << s;
 }
-__device__ __forceinline__ int bit_m1(uint32_t mask, int j) { return -(int)((mask >> j) & 1u); } // 0 / -1
+// 0 / -1 from bit j of mask.  Pinned to ONE v_bfe_i32: left to itself the compiler rewrites `x & -(bit)` into
+// and + compare + select (3 instructions per use, ~40 uses per read in a VALU-bound kernel).
+__device__ __forceinline__ int bit_m1(uint32_t mask, int j)
+{
+    int r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(mask), "n"(j));
+    return r;
+}
 
 } // namespace
 
