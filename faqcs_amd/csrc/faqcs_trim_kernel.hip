@@ -431,9 +431,16 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     hi_sum = 0; lo_sum = 0;
                     if (o_mode == FAQCS_MODE_BWA_PLUS) {
                         // Pex[j] (prefix before position j) is Pin[j-1], or E for the lane's first position
+                        // D[j] = T - Pin[j] = suffix sum after position j: its sign is the 3' reset flag, and D[j-1] the
+                        // argmax value of position j.  Sign bits are shifted in with one v_alignbit each.
+                        int Dv[C];
                         uint32_t nn = 0;
 #pragma unroll
-                        for (int j = C - 1; j >= 0; --j) nn = (nn << 1) | (uint32_t)(Pin[j] <= T);
+                        for (int j = C - 1; j >= 0; --j) {
+                            Dv[j] = T - Pin[j];
+                            nn = __builtin_amdgcn_alignbit(nn, (uint32_t)Dv[j], 31); // (nn << 1) | (D < 0)
+                        }
+                        nn = ~nn;
                         const uint32_t r3 = nn & range_mask<C>(a + nan2 + 1, a + n, pbase);
                         const uint32_t f5 = r3 & range_mask<C>(a + n - a5, a + n, pbase);
                         const uint32_t ext = r3 | (RW::next(r3) << C);
@@ -443,11 +450,10 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         const int pstar = early ? (int)red - 1 : a + n - a5;
                         const uint32_t vis = range_mask<C>(pstar > a ? pstar : a, a + n, pbase);
                         // lane-local argmax of S = T - Pex (largest position on ties), then one row max
-                        const int TB = T + KEY_BIAS;
                         uint32_t kl = 0;
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t k = ((uint32_t)(TB - (j ? Pin[j - 1] : E)) << 4) | (uint32_t)j;
+                            const uint32_t k = ((uint32_t)(j ? Dv[j - 1] : T - E) << 4) + (uint32_t)((KEY_BIAS << 4) | j);
                             kl = umax_(kl, k & (uint32_t)bit_m1(vis, j));
                         }
                         const uint32_t K3 = RW::all_umax(kl ? (((kl >> 4) << PB) + (uint32_t)(pa + (int)(kl & 15u))) : 0u);
@@ -457,7 +463,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         if (!o_protect5) {
                             uint32_t np = 0;
 #pragma unroll
-                            for (int j = C - 1; j >= 0; --j) np = (np << 1) | (uint32_t)((j ? Pin[j - 1] : E) >= 0);
+                            for (int j = C - 1; j >= 0; --j) np = __builtin_amdgcn_alignbit(np, (uint32_t)(j ? Pin[j - 1] : E), 31);
+                            np = ~np; // bit j = (prefix before position j >= 0)
                             const uint32_t r5 = np & range_mask<C>(a, a + fp3 - nan2, pbase);
                             const uint32_t g5 = r5 & range_mask<C>(a, a + a5, pbase);
                             const uint32_t ext5 = (r5 << 2) | ((RW::prev(r5) >> (C - 2)) & 3u); // bit k <-> position pbase + k - 2
@@ -469,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                             uint32_t kl5 = 0;
 #pragma unroll
                             for (int j = 0; j < C; ++j) {
-                                const uint32_t k = ((uint32_t)(Pin[j] + KEY_BIAS) << 4) | (uint32_t)(15 - j);
+                                const uint32_t k = ((uint32_t)Pin[j] << 4) + (uint32_t)((KEY_BIAS << 4) | (15 - j));
                                 kl5 = umax_(kl5, k & (uint32_t)bit_m1(vis5, j));
                             }
                             const uint32_t K5 = RW::all_umax(kl5 ? (((kl5 >> 4) << PB) + (uint32_t)((int)PMX - (pa + 15 - (int)(kl5 & 15u)))) : 0u);
