@@ -279,11 +279,11 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
             const uint32_t v_len = mine ? off[my + 1] - v_off : 0u;
             const uint32_t v_sl = (ad_sl && mine) ? ad_sl[my] : (v_len << 16);
             const uint32_t v_hit = (ad_hit && mine) ? ad_hit[my] : 0u;
-            uint32_t res_lo = 0, res_hi = 0;
-            unsigned long long rpre = 0, rpost = 0, rpre1 = 0, rpost1 = 0; // (the second words: long-read records)
-            // FilterStat accumulators (row-uniform values; lane 0 of each row publishes them)
-            uint32_t fs_cnt = 0, fs_total_len = 0, fs_trim_num = 0, fs_trim_len = 0, fs_rlen = 0, fs_blen = 0, fs_rnn = 0,
-                     fs_bnn = 0, fs_ravg = 0, fs_bavg = 0, fs_rqt = 0, fs_bqt = 0, fs_rlc = 0, fs_blc = 0;
+            // Per-read outcome, parked in the lane that owns the read (lane rowb + t): everything that is a function of
+            // these scalars alone -- FilterStat sums, the small histograms, composition records, the result word -- is
+            // done ONCE per chunk after the read loop, 64 reads wide, instead of 16 times per chunk on row-uniform values.
+            uint32_t st_an = 0, st_fl = 0, st_pAT = 0, st_pCG = 0, st_cAT = 0, st_cCG = 0, st_N = 0;
+            int st_Vpre = 0, st_Vpost = 0;
 
             // ---- software prefetch of the row's read 0 ---------------------------------------------------
             PackedBytes<D> nseq, nqual;
@@ -345,7 +345,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 }
                 if (P.trim3 && !o_qc_only) n = (int)P.trim3 > n ? 0 : n - (int)P.trim3;
                 bool ret = act;
-                if (ret && (n < (int)P.min_len || n == 0)) { fs_blen += n; ++fs_rlen; ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
+                if (ret && (n < (int)P.min_len || n == 0)) { ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
+                uint32_t qt_removed = 0;        // bases removed by the quality trim (BASE_QUAL_TRIM)
 
                 // ---- pass 1 over the lane's C positions ---------------------------------------------------
                 uint32_t incf[C];          // class word of the base (6-bit count fields A,T,C,G,N)
@@ -518,10 +519,10 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     }
                     if (ret) {
                         const int kept = (o_mode == FAQCS_MODE_BWA_PLUS && fp3 <= fp5) ? 0 : fp3 - fp5 + 1;
-                        if (kept != n) { fs_bqt += (uint32_t)(n - kept); ++fs_rqt; flags |= FAQCS_F_QUAL_TRIMMED; }
+                        if (kept != n) { qt_removed = (uint32_t)(n - kept); flags |= FAQCS_F_QUAL_TRIMMED; }
                         a += fp5;
                         n = kept;
-                        if (n < (int)P.min_len || n == 0) { fs_blen += n; ++fs_rlen; ret = false; filt = FAQCS_FILT_LENGTH_POST; }
+                        if (n < (int)P.min_len || n == 0) { ret = false; filt = FAQCS_FILT_LENGTH_POST; }
                     }
                 }
 
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         }
                     }
                     if (trip) {
-                        fs_bnn += n; ++fs_rnn; flags |= FAQCS_F_POLY_N_SEEN;
+                        flags |= FAQCS_F_POLY_N_SEEN;
                         if (!o_qc_only) { ret = false; filt = FAQCS_FILT_POLY_N; }
                     }
                 }
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 const uint32_t cA = cAT & 0xffffu, cT = cAT >> 16, cC = cCG & 0xffffu, cG = cCG >> 16;
 
                 // ---- average quality (trim.cpp:374-382) ----------------------------------------------------
-                if (ret && o_avgq_on && V_post < t_avgq[n]) { fs_bavg += n; ++fs_ravg; ret = false; filt = FAQCS_FILT_AVG_Q; }
+                if (ret && o_avgq_on && V_post < t_avgq[n]) { ret = false; filt = FAQCS_FILT_AVG_Q; }
 
                 // ---- low-complexity filter (trim.cpp:405-513) ----------------------------------------------
                 if (ret && !(o_dbg & 16u)) {
@@ -636,10 +637,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                                     trip = trip || (cnts[x] >= dthr && cnts[y] >= dthr && (uint32_t)dc >= dthr);
                                 }
                     }
-                    if (trip) { fs_blc += n; ++fs_rlc; ret = false; filt = FAQCS_FILT_LOW_COMPLEXITY; }
+                    if (trip) { ret = false; filt = FAQCS_FILT_LOW_COMPLEXITY; }
                 }
-                if (ret) { fs_trim_len += n; ++fs_trim_num; }
-                if (act) { fs_total_len += len; ++fs_cnt; }
 
                 // ---- accumulate: position x quality (LDS) and position x base (registers) -----------------
                 if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
@@ -678,68 +677,73 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     }
                 }
 
-                // ---- per-read scalars: int(average_quality) bins, small histograms, records, result --------
-                {
-                    // int(ave_Q) == max(0, floor(V / len)), V = sum(raw - offset); floor via mulhi with a host magic
-                    int qb_pre = 0, qb_post = 0;
-                    if (len > 0 && V_pre > 0) qb_pre = len == 1 ? V_pre : (int)__umulhi((uint32_t)V_pre, t_magic[len]);
-                    if (ret && V_post > 0) qb_post = n == 1 ? V_post : (int)__umulhi((uint32_t)V_post, t_magic[n]);
-                    qb_pre = qb_pre > 41 ? 41 : qb_pre;
-                    qb_post = qb_post > 41 ? 41 : qb_post;
-                    if (!(o_dbg & 34u) && !read_err) {
-                        // lanes 0..5 of the row each issue one small-histogram update
-                        uint32_t *dst = hlen + len;
-                        uint32_t val = 1u;
-                        bool on = act;
-                        if (rl == 1) { dst = hlen + n; val = 0x10000u; on = ret; }
-                        if (rl == 2) { dst = hrq + qb_pre; }
-                        if (rl == 3) { dst = hrq + qb_post; val = 0x10000u; on = ret; }
-                        if (rl == 4) { dst = hbqpre + qb_pre; val = (uint32_t)len; }
-                        if (rl == 5) { dst = hbqpost + qb_post; val = (uint32_t)n; on = ret; }
-                        if (rl < 6 && on && val) atomicAdd(dst, val);
-                    }
-                    const unsigned long long rp = CR_VALID | (unsigned long long)len | ((unsigned long long)(pAT & 0xffffu) << 9) |
-                                                  ((unsigned long long)(pAT >> 16) << 18) | ((unsigned long long)(pCG & 0xffffu) << 27) |
-                                                  ((unsigned long long)(pCG >> 16) << 36) | ((unsigned long long)pN << 45);
-                    const unsigned long long rq = CR_VALID | (unsigned long long)n | ((unsigned long long)cA << 9) | ((unsigned long long)cT << 18) |
-                                                  ((unsigned long long)cC << 27) | ((unsigned long long)cG << 36) | ((unsigned long long)cN << 45);
-                    const uint32_t lo = ret ? ((uint32_t)a | ((uint32_t)n << 16)) : 0u;
-                    const uint32_t hi = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT);
-                    if (rl == t && !(o_dbg & 32u)) {
-                        res_lo = lo; res_hi = hi;
-                        rpre = (act && !read_err) ? rp : 0ull;
-                        rpost = (ret && !read_err) ? rq : 0ull;
-                    }
-                    if (LPR == 64 && rl == t && !(o_dbg & 32u)) {
-                        // reads past 511 bases do not fit the 9-bit record: 11-bit fields over two words
-                        const unsigned long long w0 = CR_VALID | (unsigned long long)len | ((unsigned long long)(pAT & 0xffffu) << 11) |
-                                                      ((unsigned long long)(pAT >> 16) << 22) | ((unsigned long long)(pCG & 0xffffu) << 33);
-                        const unsigned long long x0 = CR_VALID | (unsigned long long)n | ((unsigned long long)cA << 11) |
-                                                      ((unsigned long long)cT << 22) | ((unsigned long long)cC << 33);
-                        const bool pre_on = act && !read_err, post_on = ret && !read_err;
-                        rpre = pre_on ? w0 : 0ull;   rpre1 = pre_on ? ((unsigned long long)(pCG >> 16) | ((unsigned long long)pN << 11)) : 0ull;
-                        rpost = post_on ? x0 : 0ull; rpost1 = post_on ? ((unsigned long long)cG | ((unsigned long long)cN << 11)) : 0ull;
-                    }
+                // ---- park the read's outcome in its owner lane (see the chunk epilogue) ----------------------
+                if (rl == t) {
+                    st_an = (uint32_t)a | ((uint32_t)n << 16);
+                    st_fl = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT) | (qt_removed << 20);
+                    st_pAT = pAT; st_pCG = pCG; st_cAT = cAT; st_cCG = cCG; st_N = pN | (cN << 16);
+                    st_Vpre = V_pre; st_Vpost = V_post;
                 }
                 if (Cfg::HQ8 && (t % Cfg::HQ8_EVERY) == Cfg::HQ8_EVERY - 1) flush_hq8<C, LPR, NW>(smem, counters, P.R, tid);
             }
 
-            if (mine) {
-                out[my] = make_uint2(res_lo, res_hi | (v_hit << 16));
-                if (LPR == 16) { rec_pre[my] = rpre; rec_post[my] = rpost; }
-                else {
-                    reinterpret_cast<ulonglong2 *>(rec_pre)[my] = make_ulonglong2(rpre, rpre1);
-                    reinterpret_cast<ulonglong2 *>(rec_post)[my] = make_ulonglong2(rpost, rpost1);
+            // ---- chunk epilogue: one read per lane ----------------------------------------------------------
+            if (!(o_dbg & 32u)) {
+                const bool e_ret = (st_fl & FAQCS_F_VALID) != 0, e_err = (st_fl & FAQCS_F_ERR_QUALITY) != 0;
+                const uint32_t e_len = v_len, e_n = st_an >> 16, e_filt = (st_fl & FAQCS_F_FILTER_MASK) >> FAQCS_F_FILTER_SHIFT;
+                // int(ave_Q) == max(0, floor(V / len)), V = sum(raw - offset); floor via mulhi with a host magic
+                int qb_pre = 0, qb_post = 0;
+                if (mine && e_len > 0 && st_Vpre > 0) qb_pre = e_len == 1 ? st_Vpre : (int)__umulhi((uint32_t)st_Vpre, t_magic[e_len]);
+                if (e_ret && st_Vpost > 0) qb_post = e_n == 1 ? st_Vpost : (int)__umulhi((uint32_t)st_Vpost, t_magic[e_n]);
+                qb_pre = qb_pre > 41 ? 41 : qb_pre;
+                qb_post = qb_post > 41 ? 41 : qb_post;
+                if (!(o_dbg & 2u) && mine && !e_err) { // length and int(average quality) histograms (trim.cpp:254-258,539-543,877-885)
+                    atomicAdd(hlen + e_len, 1u);
+                    atomicAdd(hrq + qb_pre, 1u);
+                    if (e_len) atomicAdd(hbqpre + qb_pre, e_len);
+                    if (e_ret) {
+                        atomicAdd(hlen + e_n, 0x10000u);
+                        atomicAdd(hrq + qb_post, 0x10000u);
+                        atomicAdd(hbqpost + qb_post, e_n);
+                    }
                 }
-            }
-            if (rl == 0) {
-                if (fs_cnt) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], fs_cnt); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], fs_cnt); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], fs_total_len); }
-                if (fs_trim_num) { atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_NUMBER], fs_trim_num); atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_LENGTH], fs_trim_len); }
-                if (fs_rlen) { atomicAdd(&lfs[FAQCS_READ_LENGTH], fs_rlen); atomicAdd(&lfs[FAQCS_BASE_LENGTH], fs_blen); }
-                if (fs_rnn) { atomicAdd(&lfs[FAQCS_READ_NN], fs_rnn); atomicAdd(&lfs[FAQCS_BASE_NN], fs_bnn); }
-                if (fs_ravg) { atomicAdd(&lfs[FAQCS_READ_AVG_Q], fs_ravg); atomicAdd(&lfs[FAQCS_BASE_AVG_Q], fs_bavg); }
-                if (fs_rqt) { atomicAdd(&lfs[FAQCS_READ_QUAL_TRIM], fs_rqt); atomicAdd(&lfs[FAQCS_BASE_QUAL_TRIM], fs_bqt); }
-                if (fs_rlc) { atomicAdd(&lfs[FAQCS_READ_LOW_COMPLEXITY], fs_rlc); atomicAdd(&lfs[FAQCS_BASE_LOW_COMPLEXITY], fs_blc); }
+                if (mine) {
+                    out[my] = make_uint2(e_ret ? st_an : 0u, (st_fl & 0x3ffu) | (v_hit << 16));
+                    const bool pre_on = !e_err, post_on = e_ret && !e_err;
+                    const unsigned long long pA = st_pAT & 0xffffu, pT = st_pAT >> 16, pC = st_pCG & 0xffffu, pG = st_pCG >> 16, pn = st_N & 0xffffu;
+                    const unsigned long long cA = st_cAT & 0xffffu, cT = st_cAT >> 16, cC = st_cCG & 0xffffu, cG = st_cCG >> 16, cn = st_N >> 16;
+                    if (LPR == 16) {
+                        rec_pre[my] = pre_on ? (CR_VALID | e_len | (pA << 9) | (pT << 18) | (pC << 27) | (pG << 36) | (pn << 45)) : 0ull;
+                        rec_post[my] = post_on ? (CR_VALID | e_n | (cA << 9) | (cT << 18) | (cC << 27) | (cG << 36) | (cn << 45)) : 0ull;
+                    } else { // reads past 511 bases do not fit 9-bit fields: 11-bit fields over two words
+                        reinterpret_cast<ulonglong2 *>(rec_pre)[my] =
+                            pre_on ? make_ulonglong2(CR_VALID | e_len | (pA << 11) | (pT << 22) | (pC << 33), pG | (pn << 11)) : make_ulonglong2(0ull, 0ull);
+                        reinterpret_cast<ulonglong2 *>(rec_post)[my] =
+                            post_on ? make_ulonglong2(CR_VALID | e_n | (cA << 11) | (cT << 22) | (cC << 33), cG | (cn << 11)) : make_ulonglong2(0ull, 0ull);
+                    }
+                }
+                // FilterStat (trim.cpp:238-240,317-323,325-387,505-513,527-531): a read count in the high and a base
+                // count in the low 20 bits, summed over the 64 reads of the chunk (64 x 1024 bases < 2^20)
+                const bool e_rlen = e_filt == FAQCS_FILT_LENGTH_PRE || e_filt == FAQCS_FILT_LENGTH_POST;
+                const uint32_t one = 1u << 20;
+                const uint32_t s_tot = (uint32_t)wave_sum_i32((int)(mine ? one | e_len : 0u));
+                const uint32_t s_trim = (uint32_t)wave_sum_i32((int)(e_ret ? one | e_n : 0u));
+                const uint32_t s_len = (uint32_t)wave_sum_i32((int)(e_rlen ? one | e_n : 0u));
+                const uint32_t s_nn = (uint32_t)wave_sum_i32((int)((st_fl & FAQCS_F_POLY_N_SEEN) ? one | e_n : 0u));
+                const uint32_t s_qt = (uint32_t)wave_sum_i32((int)((st_fl & FAQCS_F_QUAL_TRIMMED) ? one | (st_fl >> 20) : 0u));
+                const uint32_t s_lc = (uint32_t)wave_sum_i32((int)(e_filt == FAQCS_FILT_LOW_COMPLEXITY ? one | e_n : 0u));
+                uint32_t s_avg = 0;
+                if (o_avgq_on) s_avg = (uint32_t)wave_sum_i32((int)(e_filt == FAQCS_FILT_AVG_Q ? one | e_n : 0u));
+                if (lane == 0) {
+                    const uint32_t m = one - 1u;
+                    if (s_tot) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], s_tot & m); }
+                    if (s_trim) { atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_NUMBER], s_trim >> 20); atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_LENGTH], s_trim & m); }
+                    if (s_len) { atomicAdd(&lfs[FAQCS_READ_LENGTH], s_len >> 20); atomicAdd(&lfs[FAQCS_BASE_LENGTH], s_len & m); }
+                    if (s_nn) { atomicAdd(&lfs[FAQCS_READ_NN], s_nn >> 20); atomicAdd(&lfs[FAQCS_BASE_NN], s_nn & m); }
+                    if (s_avg) { atomicAdd(&lfs[FAQCS_READ_AVG_Q], s_avg >> 20); atomicAdd(&lfs[FAQCS_BASE_AVG_Q], s_avg & m); }
+                    if (s_qt) { atomicAdd(&lfs[FAQCS_READ_QUAL_TRIM], s_qt >> 20); atomicAdd(&lfs[FAQCS_BASE_QUAL_TRIM], s_qt & m); }
+                    if (s_lc) { atomicAdd(&lfs[FAQCS_READ_LOW_COMPLEXITY], s_lc >> 20); atomicAdd(&lfs[FAQCS_BASE_LOW_COMPLEXITY], s_lc & m); }
+                }
             }
         }
 
