@@ -73,7 +73,9 @@ template <int C> __device__ __forceinline__ uint32_t range_mask(int lo, int hi, 
     const int s = med3i(lo - pbase, 0, C);
     int e = med3i(hi - pbase, 0, C);
     e = e > s ? e : s;
-    return ((1u << (e - s)) - 1u) << s;
+    uint32_t m; // ((1 << (e - s)) - 1) << s in one instruction
+    asm("v_bfm_b32 %0, %1, %2" : "=v"(m) : "v"(e - s), "v"(s));
+    return m;
 }
 // 0 / -1 from bit j of mask.  Pinned to ONE v_bfe_i32: left to itself the compiler rewrites `x & -(bit)` into
 // and + compare + select (3 instructions per use, ~40 uses per read in a VALU-bound kernel).
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
             const bool mine = my < n_reads;
             const uint32_t v_off = mine ? off[my] : 0u;
             const uint32_t v_len = mine ? off[my + 1] - v_off : 0u;
-            const uint32_t v_sl = (ad_sl && mine) ? ad_sl[my] : (v_len << 16);
+            const uint32_t v_sl = (WINDOWED && ad_sl && mine) ? ad_sl[my] : (v_len << 16);
             const uint32_t v_hit = (ad_hit && mine) ? ad_hit[my] : 0u;
             // Per-read outcome, parked in the lane that owns the read (lane rowb + t): everything that is a function of
             // these scalars alone -- FilterStat sums, the small histograms, composition records, the result word -- is
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 uint32_t ws[D], wq[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) { ws[k] = nseq.w[k]; wq[k] = nqual.w[k]; }
-                const uint32_t sl = (uint32_t)__shfl((int)v_sl, rowb + t);
+                const uint32_t sl = WINDOWED ? (uint32_t)__shfl((int)v_sl, rowb + t) : 0u;
                 if (t + 1 < LPR) {
                     n_len = __shfl((int)v_len, rowb + t + 1);
                     const uint32_t o = (uint32_t)__shfl((int)v_off, rowb + t + 1);
@@ -332,18 +334,18 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 // ---- window after the adapter pre-pass and --5end/--3end (trim.cpp:270-314) --------------
                 int a = 0, n = len;
                 uint32_t flags = 0, filt = 0;
-                if (P.has_adapters) {
+                if (WINDOWED && P.has_adapters) {
                     const int first = (int)(sl & 0xffffu), second = (int)(sl >> 16);
                     const bool mod = len != second;
                     a = mod ? first : 0; n = mod ? second : len;
                     flags = mod ? FAQCS_F_ADAPTER : 0u;
                 }
-                if (P.trim5 && !o_qc_only) {
+                if (WINDOWED && P.trim5 && !o_qc_only) {
                     const bool over = (int)P.trim5 > n;
                     a = over ? a : a + (int)P.trim5;
                     n = over ? 0 : n - (int)P.trim5;
                 }
-                if (P.trim3 && !o_qc_only) n = (int)P.trim3 > n ? 0 : n - (int)P.trim3;
+                if (WINDOWED && P.trim3 && !o_qc_only) n = (int)P.trim3 > n ? 0 : n - (int)P.trim3;
                 bool ret = act;
                 if (ret && (n < (int)P.min_len || n == 0)) { ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
                 uint32_t qt_removed = 0;        // bases removed by the quality trim (BASE_QUAL_TRIM)
