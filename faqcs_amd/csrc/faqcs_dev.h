@@ -32,7 +32,7 @@ struct DevParams {
     const int32_t  *avgq_min_v;   // min V = sum(raw - offset) with NOT(ave_Q < --avg_q)          (trim.cpp:376)
     const uint32_t *div_magic;    // floor(2^32/len)+1: floor(V/len) == mulhi(V, magic), V < 2^16 (trim.cpp:254,539 int())
     const float    *comp_norm;    // float(10000)/len                                             (trim.cpp:860)
-    const uint32_t *base_tab;     // [256] per input byte: 6-bit count fields A,T,C,G,N | isN<<30 | isG<<31
+    const uint32_t *base_tab;     // [256] per input byte: 6-bit count fields A,T,C,G,N | isG<<30 | isN<<31
     faqcs_layout lay;
 };
 
@@ -41,8 +41,9 @@ enum { FS_SLOTS = 32 };
 // base_tab fields (6 bits each so a lane can sum up to 63 reads before flushing)
 #define BT_SHIFT(code) (6 * (code))
 #define BT_FIELDS 0x3fffffffu
-#define BT_IS_NU (1u << 30) /* upper-case 'N' exactly (count_poly_n / terminal-N masking are case sensitive) */
-#define BT_IS_GU (1u << 31) /* upper-case 'G' exactly (--replace_to_N_q) */
+#define BT_IS_NU (1u << 31) /* upper-case 'N' exactly (count_poly_n / terminal-N masking are case sensitive); the sign
+                               bit so that one v_alignbit per position gathers the flags into a bit mask */
+#define BT_IS_GU (1u << 30) /* upper-case 'G' exactly (--replace_to_N_q) */
 
 // composition record
 #define CR_VALID (1ull << 63)

@@ -60,7 +60,8 @@ template <int C, int LPR> struct RowCfg {
     static constexpr int O_TLC = O_TBASE + 256;    // [W+1]
     static constexpr int O_TAVGQ = O_TLC + W + 1;  // [W+1]
     static constexpr int O_TMAGIC = O_TAVGQ + W + 1;
-    static constexpr int LDS_DWORDS = O_TMAGIC + W + 1;
+    static constexpr int O_TBM = (O_TMAGIC + W + 1 + 3) & ~3; // [C+1][4] byte masks "first vb bytes of the lane's dwords"
+    static constexpr int LDS_DWORDS = O_TBM + 4 * (C + 1);
 };
 
 template <int D> struct __attribute__((packed, aligned(1))) PackedBytes { uint32_t w[D]; };
@@ -79,6 +80,26 @@ template <int C> __device__ __forceinline__ uint32_t range_mask(int lo, int hi, 
 }
 // 0 / -1 from bit j of mask.  Pinned to ONE v_bfe_i32: left to itself the compiler rewrites `x & -(bit)` into
 // and + compare + select (3 instructions per use, ~40 uses per read in a VALU-bound kernel).
+// 4 * byte K of w in ONE instruction (SDWA source select): the LDS byte offset of a base-table lookup
+template <int K> __device__ __forceinline__ uint32_t byte_times4(uint32_t w, uint32_t two)
+{
+    uint32_t r;
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
+    else if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w));
+    else if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
+    return r;
+}
+template <int C, int J> struct BaseLookup {
+    static __device__ __forceinline__ void run(const uint32_t *t_base, const uint32_t *ws, uint32_t two, uint32_t *inc)
+    {
+        inc[J] = *(const uint32_t *)((const char *)t_base + byte_times4<J & 3>(ws[J >> 2], two));
+        BaseLookup<C, J + 1>::run(t_base, ws, two, inc);
+    }
+};
+template <int C> struct BaseLookup<C, C> {
+    static __device__ __forceinline__ void run(const uint32_t *, const uint32_t *, uint32_t, uint32_t *) {}
+};
 __device__ __forceinline__ int bit_m1(uint32_t mask, int j)
 {
     int r;
@@ -216,6 +237,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
     uint32_t *hbqpre = smem + Cfg::O_BQPRE, *hbqpost = smem + Cfg::O_BQPOST, *lfs = smem + Cfg::O_FS;
     const uint32_t *t_base = smem + Cfg::O_TBASE, *t_lc = smem + Cfg::O_TLC, *t_magic = smem + Cfg::O_TMAGIC;
     const int32_t *t_avgq = (const int32_t *)(smem + Cfg::O_TAVGQ);
+    const uint32_t *t_bm = smem + Cfg::O_TBM;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -231,6 +253,12 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
         smem[Cfg::O_TAVGQ + i] = (uint32_t)P.avgq_min_v[i];
         smem[Cfg::O_TMAGIC + i] = P.div_magic[i];
     }
+    for (int i = tid; i < 4 * (C + 1); i += NW * 64) {
+        const int nb = med3i((i >> 2) - 4 * (i & 3), 0, 4);
+        smem[Cfg::O_TBM + i] = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+    }
+    uint32_t two = 2u;
+    asm volatile("" : "+v"(two)); // a VGPR operand for the SDWA shifts
     __syncthreads();
 
     const uint32_t total_chunks = (n_reads + 63) >> 6;
@@ -323,12 +351,10 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 // zero the bytes past the end of the read (the last dword of a lane may over-read 1..3 bytes)
                 {
                     const int vb = med3i(len - pbase, 0, C);
+                    const uint4 bm = *reinterpret_cast<const uint4 *>(t_bm + 4 * vb); // one ds_read_b128
+                    const uint32_t m[4] = {bm.x, bm.y, bm.z, bm.w};
 #pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const int nb = med3i(vb - 4 * k, 0, 4);
-                        const uint32_t m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
-                        ws[k] &= m; wq[k] &= m;
-                    }
+                    for (int k = 0; k < D; ++k) { ws[k] &= m[k]; wq[k] &= m[k]; }
                 }
 
                 // ---- window after the adapter pre-pass and --5end/--3end (trim.cpp:270-314) --------------
@@ -359,9 +385,10 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 #pragma unroll 1
                 for (int attempt = 0; attempt < 2; ++attempt) {
                     uint32_t inc[C];
-#pragma unroll
-                    for (int j = 0; j < C; ++j) inc[j] = t_base[(ws[j >> 2] >> (8 * (j & 3))) & 0xffu];
+                    BaseLookup<C, 0>::run(t_base, ws, two, inc);
                     run = 0; sumv = 0; cntpack = 0; nubits = 0; gubits = 0; maxq = 0;
+#pragma unroll
+                    for (int j = C - 1; j >= 0; --j) nubits = __builtin_amdgcn_alignbit(nubits, inc[j], 31); // bit j = BT_IS_NU of j
 #pragma unroll
                     for (int j = 0; j < C; ++j) {
                         const int sq = (int)(int8_t)((wq[j >> 2] >> (8 * (j & 3))) & 0xffu);
@@ -375,8 +402,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         Pin[j] = run;
                         cntpack += inc[j];
                         incf[j] = inc[j] & BT_FIELDS;
-                        nubits |= ((inc[j] >> 30) & 1u) << j;
-                        if (o_replace_q > 0) gubits |= (inc[j] >> 31) << j;
+                        if (o_replace_q > 0) gubits |= ((inc[j] >> 30) & 1u) << j;
                     }
                     if (attempt == 1) break;
                     // mask_quality_terminal_N (trim.cpp:1191-1216): upper-case 'N' runs at either end get Q0.
