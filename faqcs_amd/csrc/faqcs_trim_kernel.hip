@@ -100,6 +100,12 @@ template <int C, int J> struct BaseLookup {
 template <int C> struct BaseLookup<C, C> {
     static __device__ __forceinline__ void run(const uint32_t *, const uint32_t *, uint32_t, uint32_t *) {}
 };
+__device__ __forceinline__ uint32_t umax3_(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int bit_m1(uint32_t mask, int j)
 {
     int r;
@@ -377,7 +383,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 uint32_t qt_removed = 0;        // bases removed by the quality trim (BASE_QUAL_TRIM)
 
                 // ---- pass 1 over the lane's C positions ---------------------------------------------------
-                uint32_t incf[C];          // class word of the base (6-bit count fields A,T,C,G,N)
+                uint32_t incf[C];          // class word of the base: 6-bit count fields A,T,C,G,N; the two flag bits above them
+                                           // ride along (sums only ever carry them out of the word; every reader masks)
                 int q[C], Pin[C];          // clamped quality; inclusive prefix sum of (Q - q) up to this position
                 int run, sumv, T, E;
                 uint32_t cntpack, nubits, gubits, maxq;
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         run += dq;
                         Pin[j] = run;
                         cntpack += inc[j];
-                        incf[j] = inc[j] & BT_FIELDS;
+                        incf[j] = inc[j];
                         if (o_replace_q > 0) gubits |= ((inc[j] >> 30) & 1u) << j;
                     }
                     if (attempt == 1) break;
@@ -479,12 +486,15 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         const int pstar = early ? (int)red - 1 : a + n - a5;
                         const uint32_t vis = range_mask<C>(pstar > a ? pstar : a, a + n, pbase);
                         // lane-local argmax of S = T - Pex (largest position on ties), then one row max
-                        uint32_t kl = 0;
+                        uint32_t kl = 0, kx[C];
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const uint32_t k = ((uint32_t)(j ? Dv[j - 1] : T - E) << 4) + (uint32_t)((KEY_BIAS << 4) | j);
-                            kl = umax_(kl, k & (uint32_t)bit_m1(vis, j));
+                            kx[j] = k & (uint32_t)bit_m1(vis, j);
                         }
+#pragma unroll
+                        for (int j = 0; j + 1 < C; j += 2) kl = umax3_(kl, kx[j], kx[j + 1]);
+                        if (C & 1) kl = umax_(kl, kx[C - 1]);
                         const uint32_t K3 = RW::all_umax(kl ? (((kl >> 4) << PB) + (uint32_t)(pa + (int)(kl & 15u))) : 0u);
                         const int S3 = (int)(K3 >> PB) - KEY_BIAS;
                         fp3 = (S3 > 0) ? (int)(K3 & PMX) - 1 : n - 1;
@@ -502,12 +512,15 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                             const bool early5 = RW::all_or(g5) != 0u;
                             const int pstar5 = early5 ? FK - (int)red5 : a + a5 - 1;
                             const uint32_t vis5 = range_mask<C>(a, (pstar5 + 1 < a + n) ? pstar5 + 1 : a + n, pbase);
-                            uint32_t kl5 = 0;
+                            uint32_t kl5 = 0, ky[C];
 #pragma unroll
                             for (int j = 0; j < C; ++j) {
                                 const uint32_t k = ((uint32_t)Pin[j] << 4) + (uint32_t)((KEY_BIAS << 4) | (15 - j));
-                                kl5 = umax_(kl5, k & (uint32_t)bit_m1(vis5, j));
+                                ky[j] = k & (uint32_t)bit_m1(vis5, j);
                             }
+#pragma unroll
+                            for (int j = 0; j + 1 < C; j += 2) kl5 = umax3_(kl5, ky[j], ky[j + 1]);
+                            if (C & 1) kl5 = umax_(kl5, ky[C - 1]);
                             const uint32_t K5 = RW::all_umax(kl5 ? (((kl5 >> 4) << PB) + (uint32_t)((int)PMX - (pa + 15 - (int)(kl5 & 15u)))) : 0u);
                             const int S5 = (int)(K5 >> PB) - KEY_BIAS;
                             fp5 = (S5 > 0) ? (int)PMX - (int)(K5 & PMX) + 1 : 0;
@@ -674,13 +687,17 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     // branch-free: a position outside the read adds 0 to a valid address
                     // (bytes past the read are zero -> class word 0 and quality column 0 with increment 0; a read with
                     //  Q > 41 aborts the whole run, fastq.h:31-33, so its row only has to stay inside the tables)
+                    if (__any(read_err)) { // rare: keep the row's table indices in range, count nothing
+#pragma unroll
+                        for (int j = 0; j < C; ++j) { q[j] = read_err ? 0 : q[j]; incf[j] = read_err ? 0u : incf[j]; }
+                    }
                     const uint32_t inr = (act && !read_err) ? range_mask<C>(0, len, pbase) : 0u;
                     const uint32_t postm = ret ? (win2 & inr) : 0u;
                     const uint32_t both = inr | (postm << 16);
                     if (Cfg::HQ8) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const int qq = read_err ? 0 : q[j];
+                            const int qq = q[j];
                             const uint32_t x = (both >> j) & 0x10001u;          // pre -> byte 0, post -> byte 1 of the cell
                             atomicAdd(&hq[qq * (W / 2) + ((pbase + j) >> 1)], ((x | (x >> 8)) & 0x101u) << (16 * ((pbase + j) & 1)));
                         }
@@ -688,18 +705,18 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     if (o_replace_q > 0) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const int qq = read_err ? 0 : q[j];
+                            const int qq = q[j];
                             if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
-                            bpre[j] += read_err ? 0u : incf[j];
+                            bpre[j] += incf[j];
                             const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
                             bpost[j] += w & (uint32_t)bit_m1(postm, j);
                         }
                     } else {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const int qq = read_err ? 0 : q[j];
+                            const int qq = q[j];
                             if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
-                            bpre[j] += read_err ? 0u : incf[j];
+                            bpre[j] += incf[j];
                             bpost[j] += incf[j] & (uint32_t)bit_m1(postm, j);
                         }
                     }
