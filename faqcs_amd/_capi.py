@@ -23,6 +23,7 @@ F_VALID, F_FILTER_MASK, F_FILTER_SHIFT = 0x1, 0xE, 1
 F_QUAL_TRIMMED, F_ADAPTER, F_POLY_N_SEEN, F_ERR_QUALITY, F_ERR_BASE = 0x10, 0x20, 0x40, 0x100, 0x200
 
 E_INVAL, E_NODEVICE, E_QUALITY, E_BASE, E_NOMEM, E_KMER_FULL = -1, -2, -3, -4, -5, -6
+EPOCH_NONE = 0xFFFFFFFF
 
 # the messages the reference throws at the corresponding sites (fastq.h:32, seq_overlap.cpp:409)
 ERR_TEXT = {
@@ -150,6 +151,11 @@ def load_library():
         "faqcs_kmer_totals": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "faqcs_kmer_active": (i32, [vp]),
         "faqcs_kmer_end_table": (i32, [vp]),
+        "faqcs_kmer_partition": (i32, [vp, u32, u32, u32]),
+        "faqcs_kmer_set_epochs": (i32, [vp, vp, u32]),
+        "faqcs_kmer_outbox": (i32, [vp, C.POINTER(vp), vp]),
+        "faqcs_kmer_insert_device": (i32, [vp, vp, u64]),
+        "faqcs_kmer_epoch_counts": (i32, [vp, vp, vp, u32]),
         "faqcs_synth_fill": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, C.c_float]),
         "faqcs_kernel_time_ms": (i32, [vp, C.POINTER(C.c_double), C.POINTER(u64)]),
     }

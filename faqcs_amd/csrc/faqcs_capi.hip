@@ -31,7 +31,21 @@ struct KmerTable {
     uint32_t *counts;
     uint64_t mask;
     unsigned long long *stats;
+    uint32_t *first_epoch;
 };
+struct KmerOutbox {
+    ulonglong2 *items;
+    unsigned long long *dest_count, *dest_offset, *dest_cursor;
+    uint32_t world;
+};
+hipError_t faqcs_launch_kmer_extract(const DevParams &P, uint32_t k, const KmerOutbox &O, bool fill, const uint8_t *seq,
+                                     const uint8_t *qual, const uint32_t *off, uint32_t r_begin, uint32_t r_end,
+                                     const faqcs_read_result *results, uint32_t epoch, int n_cu, hipStream_t st);
+hipError_t faqcs_launch_kmer_outbox_offsets(const KmerOutbox &O, hipStream_t st);
+hipError_t faqcs_launch_kmer_insert_items(const KmerTable &T, const void *items, unsigned long long n,
+                                          unsigned long long *tot_by_epoch, uint32_t n_epochs, int n_cu, hipStream_t st);
+hipError_t faqcs_launch_kmer_first_epoch_histogram(const KmerTable &T, unsigned long long *hist, uint32_t n_epochs, int n_cu,
+                                                   hipStream_t st);
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
@@ -114,7 +128,14 @@ struct faqcs_ctx {
     std::vector<faqcs_rarefaction> points;
     struct PendingPoint { size_t point_index; size_t snap_index; };
     std::vector<PendingPoint> pending;
-    KmerTable kt{nullptr, nullptr, 0, nullptr};
+    KmerTable kt{nullptr, nullptr, 0, nullptr, nullptr};
+    // owner-partitioned multi-GPU k-mer mode (faqcs_kmer_partition)
+    bool partitioned = false;
+    uint32_t part_rank = 0, part_world = 1, n_epochs = 0;
+    std::vector<uint32_t> seg_epoch;             // epochs of the NEXT submission's segments
+    DevBuf<ulonglong2> ob_items;
+    unsigned long long *d_ob = nullptr;          // [3 * world]: dest_count, dest_offset, dest_cursor
+    unsigned long long *d_tot_by_epoch = nullptr, *d_first_hist = nullptr; // [n_epochs] each
     unsigned long long *d_snaps = nullptr; // [snap_cap][2]
     size_t snap_cap = 0, n_snaps = 0;
     std::map<uint64_t, uint64_t> kmer_hist; // PlotInfo::kmer_frequency_histogram
@@ -369,12 +390,12 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
-                    c->kt.keys, c->kt.counts, c->kt.stats, c->d_snaps};
+                    c->kt.keys, c->kt.counts, c->kt.stats, c->d_snaps, c->kt.first_epoch, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (auto &sl : c->slot) { sl.seq.release(); sl.qual.release(); sl.off.release(); if (sl.done) (void)hipEventDestroy(sl.done); }
     for (auto &e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
     c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
-    c->s_rec_pre.release(); c->s_rec_post.release();
+    c->s_rec_pre.release(); c->s_rec_post.release(); c->ob_items.release();
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -422,6 +443,31 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
             HIPCHK(faqcs_launch_composition(c->s_rec_pre.p, n, wide, c->d_norm, c->d_counters + c->lay.pre_comp, c->n_cu, c->compute));
             HIPCHK(faqcs_launch_composition(c->s_rec_post.p, n, wide, c->d_norm, c->d_counters + c->lay.post_comp, c->n_cu, c->compute));
         }
+    }
+    // ---- owner-partitioned k-mer mode: bucket this shard's (key, epoch) pairs by owner rank; the caller exchanges them
+    if (c->partitioned) {
+        if (!c->kmer_active || n == 0) { c->seg_epoch.clear(); return 0; }
+        if (c->seg_epoch.size() != n_seg) return fail(FAQCS_E_INVAL, "faqcs_submit: faqcs_kmer_set_epochs() must give one epoch per segment of the submission");
+        // an occurrence starts at a distinct base, so the arena size bounds the item count (host copy of the last offset
+        // is not available for device-resident batches: use the per-read bound n * max_len)
+        const size_t cap = (size_t)n * (size_t)(max_len > p.kmer ? max_len - p.kmer + 1 : 0) + 1;
+        HIPCHK(c->ob_items.reserve(cap));
+        KmerOutbox O{c->ob_items.p, c->d_ob, c->d_ob + c->part_world, c->d_ob + 2 * c->part_world, c->part_world};
+        HIPCHK(hipMemsetAsync(c->d_ob, 0, 3 * c->part_world * 8, c->compute));
+        for (int fill = 0; fill < 2; ++fill) {
+            uint32_t s = 0;
+            while (s < n_seg) { // one launch per run of segments with the same epoch
+                uint32_t e = s + 1;
+                while (e < n_seg && c->seg_epoch[e] == c->seg_epoch[s]) ++e;
+                if (c->seg_epoch[s] != 0xffffffffu)
+                    HIPCHK(faqcs_launch_kmer_extract(c->dp, p.kmer, O, fill != 0, d_seq, d_qual, d_off, seg[s], seg[e], d_res,
+                                                     c->seg_epoch[s], c->n_cu, c->compute));
+                s = e;
+            }
+            if (!fill) HIPCHK(faqcs_launch_kmer_outbox_offsets(O, c->compute));
+        }
+        c->seg_epoch.clear();
+        return 0;
     }
     // ---- rarefaction bookkeeping per reference trim() call (trim.cpp:157-185) -------------------------------
     for (uint32_t s = 0; s < n_seg; ++s) {
@@ -673,13 +719,82 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
         }
         (void)hipFree(d_dense); (void)hipFree(d_big); (void)hipFree(d_nbig);
     }
-    if (c->kmer_active && c->points.empty()) { // FaQCs.cpp:523-537
+    if (c->partitioned) { // the points belong to the driver (faqcs_kmer_epoch_counts); only the table restarts here
+        HIPCHK(hipMemsetAsync(c->kt.first_epoch, 0xff, (c->kt.mask + 1) * 4, c->compute));
+        HIPCHK(hipMemsetAsync(c->d_tot_by_epoch, 0, (size_t)c->n_epochs * 8, c->compute));
+    } else if (c->kmer_active && c->points.empty()) { // FaQCs.cpp:523-537
         faqcs_rarefaction pt{c->total_number, st[0], st[1]};
         c->points.push_back(pt);
     }
     HIPCHK(hipMemsetAsync(c->kt.keys, 0xff, (c->kt.mask + 1) * 8, c->compute));
     HIPCHK(hipMemsetAsync(c->kt.counts, 0, (c->kt.mask + 1) * 4, c->compute));
     HIPCHK(hipMemsetAsync(c->kt.stats, 0, 64, c->compute));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// owner-partitioned k-mers across GPUs
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int faqcs_kmer_partition(faqcs_ctx *c, uint32_t rank, uint32_t world, uint32_t n_epochs)
+{
+    if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    if (!c->kt.keys) return fail(FAQCS_E_INVAL, "faqcs_kmer_partition: the context was created without kmer_rarefaction");
+    if (world == 0 || world > 64 || rank >= world || n_epochs == 0) return fail(FAQCS_E_INVAL, "faqcs_kmer_partition: bad rank / world / n_epochs");
+    if (c->n_submits || c->total_number || c->partitioned) return fail(FAQCS_E_INVAL, "faqcs_kmer_partition: must be the first call on a fresh context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc((void **)&c->kt.first_epoch, (c->kt.mask + 1) * 4));
+    HIPCHK(hipMemset(c->kt.first_epoch, 0xff, (c->kt.mask + 1) * 4));
+    HIPCHK(hipMalloc((void **)&c->d_ob, 3 * (size_t)world * 8));
+    HIPCHK(hipMalloc((void **)&c->d_tot_by_epoch, (size_t)n_epochs * 8));
+    HIPCHK(hipMalloc((void **)&c->d_first_hist, (size_t)n_epochs * 8));
+    HIPCHK(hipMemset(c->d_tot_by_epoch, 0, (size_t)n_epochs * 8));
+    c->partitioned = true; c->part_rank = rank; c->part_world = world; c->n_epochs = n_epochs;
+    return 0;
+}
+
+extern "C" int faqcs_kmer_set_epochs(faqcs_ctx *c, const uint32_t *segment_epoch, uint32_t n_segments)
+{
+    if (!c || (!segment_epoch && n_segments)) return fail(FAQCS_E_INVAL, "null argument");
+    if (!c->partitioned) return fail(FAQCS_E_INVAL, "faqcs_kmer_set_epochs: call faqcs_kmer_partition first");
+    for (uint32_t s = 0; s < n_segments; ++s)
+        if (segment_epoch[s] != 0xffffffffu && segment_epoch[s] >= c->n_epochs) return fail(FAQCS_E_INVAL, "faqcs_kmer_set_epochs: epoch out of range");
+    c->seg_epoch.assign(segment_epoch, segment_epoch + n_segments);
+    return 0;
+}
+
+extern "C" int faqcs_kmer_outbox(faqcs_ctx *c, void **d_items, uint64_t *counts)
+{
+    if (!c || !d_items || !counts) return fail(FAQCS_E_INVAL, "null argument");
+    if (!c->partitioned) return fail(FAQCS_E_INVAL, "faqcs_kmer_outbox: call faqcs_kmer_partition first");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    std::vector<unsigned long long> h(c->part_world);
+    HIPCHK(hipMemcpy(h.data(), c->d_ob, (size_t)c->part_world * 8, hipMemcpyDeviceToHost));
+    for (uint32_t d = 0; d < c->part_world; ++d) counts[d] = h[d];
+    *d_items = c->ob_items.p;
+    return 0;
+}
+
+extern "C" int faqcs_kmer_insert_device(faqcs_ctx *c, const void *d_items, uint64_t n_items)
+{
+    if (!c || (!d_items && n_items)) return fail(FAQCS_E_INVAL, "null argument");
+    if (!c->partitioned) return fail(FAQCS_E_INVAL, "faqcs_kmer_insert_device: call faqcs_kmer_partition first");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(faqcs_launch_kmer_insert_items(c->kt, d_items, n_items, c->d_tot_by_epoch, c->n_epochs, c->n_cu, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute)); // the caller may recycle d_items as soon as this returns
+    return 0;
+}
+
+extern "C" int faqcs_kmer_epoch_counts(faqcs_ctx *c, uint64_t *distinct_by_first_epoch, uint64_t *total_by_epoch, uint32_t cap)
+{
+    if (!c || !distinct_by_first_epoch || !total_by_epoch) return fail(FAQCS_E_INVAL, "null argument");
+    if (!c->partitioned || cap < c->n_epochs) return fail(FAQCS_E_INVAL, "faqcs_kmer_epoch_counts: not partitioned / buffers too small");
+    if (int rc = faqcs_sync(c)) return rc;
+    HIPCHK(hipMemsetAsync(c->d_first_hist, 0, (size_t)c->n_epochs * 8, c->compute));
+    HIPCHK(faqcs_launch_kmer_first_epoch_histogram(c->kt, c->d_first_hist, c->n_epochs, c->n_cu, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemcpy(distinct_by_first_epoch, c->d_first_hist, (size_t)c->n_epochs * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(total_by_epoch, c->d_tot_by_epoch, (size_t)c->n_epochs * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -18,12 +18,27 @@ struct KmerTable {
     uint32_t *counts;          // [slots]
     uint64_t mask;             // slots - 1
     unsigned long long *stats; // [0] distinct keys, [1] total occurrences, [2] overflow flag
+    uint32_t *first_epoch;     // [slots] owner-partitioned (multi-GPU) mode only: smallest epoch that inserted the key
+};
+
+// multi-GPU exchange buffers of one submission (owner-partitioned mode)
+struct KmerOutbox {
+    ulonglong2 *items;              // (key, epoch) pairs, grouped by destination rank
+    unsigned long long *dest_count; // [world]  occurrences per destination (pass 1)
+    unsigned long long *dest_offset;// [world]  exclusive prefix of dest_count
+    unsigned long long *dest_cursor;// [world]  fill cursors (pass 2)
+    uint32_t world;
 };
 
 __device__ __forceinline__ uint64_t kmer_mix(uint64_t x)
 {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
     return x;
+}
+// owner rank of a key: the HIGH half of the mix (the slot index uses the low bits), multiply-shift into [0, world)
+__device__ __forceinline__ uint32_t kmer_owner(uint64_t key, uint32_t world)
+{
+    return (uint32_t)(((kmer_mix(key) >> 32) * (uint64_t)world) >> 32);
 }
 
 // bits [p-k+1, p] (p = 64*c + lane) of the bit string whose 64-bit words are ... prev, cur
@@ -34,6 +49,70 @@ __device__ __forceinline__ uint32_t window_bits(uint64_t cur, uint64_t prev, int
     if (lo >= 0) w = cur >> lo;
     else w = (cur << (-lo)) | (prev >> (64 + lo));
     return (uint32_t)(w & ((1ull << k) - 1ull));
+}
+
+// Calls emit(ok, key) once per 64-base chunk of read r in EVERY lane (ok = a canonical k-mer ends at this lane's
+// position), so emit may use wave-wide ballots.
+template <class F>
+__device__ __forceinline__ void kmer_enumerate(const DevParams &P, const uint32_t k, const uint8_t *__restrict__ seq,
+                                               const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off,
+                                               const uint32_t r, const uint2 *__restrict__ results, const int lane, F &&emit)
+{
+    const uint32_t o = off[r];
+    const int len = (int)(off[r + 1] - o);
+    int a = 0, n = len;
+    if (!P.qc_only) { // trimmed read of a valid record (trim.cpp:545-547); raw read under --qc_only (:260-262)
+        const uint2 res = results[r];
+        if (!(res.y & FAQCS_F_VALID)) return;
+        a = (int)(res.x & 0xffffu);
+        n = (int)(res.x >> 16);
+    }
+    uint64_t pv = 0, p0 = 0, p1 = 0;
+    const int c_begin = a >> 6, c_end = (a + n + 63) >> 6;
+#pragma unroll 1
+    for (int c = c_begin; c < c_end; ++c) {
+        const int p = c * 64 + lane;
+        const bool in = p >= a && p < a + n;
+        uint32_t b = in ? seq[(size_t)o + p] : 0u;
+        if (in && !P.qc_only && P.replace_q > 0 && b == 'G') { // G -> N precedes k-mer counting (trim.cpp:390-403)
+            int qv = (int)(int8_t)qual[(size_t)o + p] - P.in_off;
+            qv = qv < 0 ? 0 : qv;
+            if (qv < (int)P.replace_q) b = 'N';
+        }
+        const uint32_t l = b | 0x20u;
+        const bool isA = l == 'a', isT = l == 't', isC = l == 'c', isG = l == 'g';
+        const uint64_t cv = __ballot(isA | isT | isC | isG);
+        const uint64_t c0 = __ballot(isT | isG); // codes A=0 T=1 C=2 G=3 (FaQCs.h:35-42)
+        const uint64_t c1 = __ballot(isC | isG);
+        const uint32_t wv = window_bits(cv, pv, lane, (int)k);
+        const uint32_t w0 = window_bits(c0, p0, lane, (int)k);
+        const uint32_t w1 = window_bits(c1, p1, lane, (int)k);
+        pv = cv; p0 = c0; p1 = c1;
+        const uint32_t kmask = (uint32_t)((1ull << k) - 1ull);
+        const bool ok = wv == kmask; // k valid bases ending here (word_len >= k, trim.cpp:924)
+        const uint32_t r0 = __brev(~w0 & kmask) >> (32 - k), r1 = __brev(w1) >> (32 - k);
+        const uint64_t fwd = ((uint64_t)w1 << 32) | w0, rc = ((uint64_t)r1 << 32) | r0;
+        emit(ok, fwd < rc ? fwd : rc);
+    }
+}
+
+// open-addressing insert; returns false when the probe budget is exhausted (table full)
+__device__ __forceinline__ bool kmer_insert(const KmerTable &T, const uint64_t key, const uint32_t epoch, bool &is_new)
+{
+    uint64_t h = kmer_mix(key) & T.mask;
+    is_new = false;
+#pragma unroll 1
+    for (uint32_t probe = 0; probe < 4096; ++probe) {
+        const unsigned long long old = atomicCAS(&T.keys[h], ~0ull, (unsigned long long)key);
+        if (old == ~0ull) is_new = true;
+        if (old == ~0ull || old == key) {
+            atomicAdd(&T.counts[h], 1u);
+            if (T.first_epoch) atomicMin(&T.first_epoch[h], epoch);
+            return true;
+        }
+        h = (h + 1) & T.mask;
+    }
+    return false;
 }
 
 template <int NW>
@@ -49,54 +128,13 @@ __global__ __launch_bounds__(NW * 64) void kmer_count(
     bool full = false;
 #pragma unroll 1
     for (uint32_t r = r_begin + blockIdx.x * NW + wave; r < r_end; r += n_waves) {
-        const uint32_t o = off[r];
-        const int len = (int)(off[r + 1] - o);
-        int a = 0, n = len;
-        if (!P.qc_only) { // trimmed read of a valid record (trim.cpp:545-547); raw read under --qc_only (:260-262)
-            const uint2 res = results[r];
-            if (!(res.y & FAQCS_F_VALID)) continue;
-            a = (int)(res.x & 0xffffu);
-            n = (int)(res.x >> 16);
-        }
-        uint64_t pv = 0, p0 = 0, p1 = 0;
-        const int c_begin = a >> 6, c_end = (a + n + 63) >> 6;
-#pragma unroll 1
-        for (int c = c_begin; c < c_end; ++c) {
-            const int p = c * 64 + lane;
-            const bool in = p >= a && p < a + n;
-            uint32_t b = in ? seq[(size_t)o + p] : 0u;
-            if (in && !P.qc_only && P.replace_q > 0 && b == 'G') { // G -> N precedes k-mer counting (trim.cpp:390-403)
-                int qv = (int)(int8_t)qual[(size_t)o + p] - P.in_off;
-                qv = qv < 0 ? 0 : qv;
-                if (qv < (int)P.replace_q) b = 'N';
-            }
-            const uint32_t l = b | 0x20u;
-            const bool isA = l == 'a', isT = l == 't', isC = l == 'c', isG = l == 'g';
-            const uint64_t cv = __ballot(isA | isT | isC | isG);
-            const uint64_t c0 = __ballot(isT | isG); // codes A=0 T=1 C=2 G=3 (FaQCs.h:35-42)
-            const uint64_t c1 = __ballot(isC | isG);
-            const uint32_t wv = window_bits(cv, pv, lane, (int)k);
-            const uint32_t w0 = window_bits(c0, p0, lane, (int)k);
-            const uint32_t w1 = window_bits(c1, p1, lane, (int)k);
-            pv = cv; p0 = c0; p1 = c1;
-            const uint32_t kmask = (uint32_t)((1ull << k) - 1ull);
-            const bool ok = wv == kmask; // k valid bases ending here (word_len >= k, trim.cpp:924)
+        kmer_enumerate(P, k, seq, qual, off, r, results, lane, [&](bool ok, uint64_t key) {
             if (ok) {
-                const uint32_t r0 = __brev(~w0 & kmask) >> (32 - k), r1 = __brev(w1) >> (32 - k);
-                const uint64_t fwd = ((uint64_t)w1 << 32) | w0, rc = ((uint64_t)r1 << 32) | r0;
-                const uint64_t key = fwd < rc ? fwd : rc;
-                uint64_t h = kmer_mix(key) & T.mask;
-                bool done = false;
-#pragma unroll 1
-                for (uint32_t probe = 0; probe < 4096 && !done; ++probe) {
-                    const unsigned long long old = atomicCAS(&T.keys[h], ~0ull, (unsigned long long)key);
-                    if (old == ~0ull) ++my_new;
-                    if (old == ~0ull || old == key) { atomicAdd(&T.counts[h], 1u); done = true; }
-                    else h = (h + 1) & T.mask;
-                }
-                if (done) ++my_total; else full = true;
+                bool is_new;
+                if (kmer_insert(T, key, 0u, is_new)) { ++my_total; my_new += is_new ? 1u : 0u; }
+                else full = true;
             }
-        }
+        });
     }
     // one atomic per wave for the two rarefaction sums
     const unsigned long long tot = (unsigned long long)wave_sum_i32((int)my_total);
@@ -106,6 +144,99 @@ __global__ __launch_bounds__(NW * 64) void kmer_count(
         if (tot) atomicAdd(&T.stats[1], tot);
     }
     if (__any(full) && lane == 0) atomicOr(&T.stats[2], 1ull);
+}
+
+// ---- owner-partitioned (multi-GPU) mode -----------------------------------------------------------------------
+// distinct counts are not additive, so every canonical k-mer has ONE owner rank
+// (kmer_owner).  A rank enumerates the k-mers of its shard, buckets (key, epoch) by owner (two passes: count, then
+// fill at device-computed offsets), the buckets travel by all-to-all, and the owner inserts them keeping the smallest
+// epoch per key.  epoch = index of the first rarefaction point that includes the read's trim() call.
+template <int NW, bool FILL>
+__global__ __launch_bounds__(NW * 64) void kmer_extract(
+    const DevParams P, const uint32_t k, const KmerOutbox O, const uint8_t *__restrict__ seq,
+    const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off, const uint32_t r_begin, const uint32_t r_end,
+    const uint2 *__restrict__ results, const uint32_t epoch)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * NW;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    unsigned long long my_count = 0; // pass 1: lane d accumulates the count for destination d
+#pragma unroll 1
+    for (uint32_t r = r_begin + blockIdx.x * NW + wave; r < r_end; r += n_waves) {
+        kmer_enumerate(P, k, seq, qual, off, r, results, lane, [&](bool ok, uint64_t key) {
+            const uint32_t dest = ok ? kmer_owner(key, O.world) : 0xffffffffu;
+#pragma unroll 1
+            for (uint32_t d = 0; d < O.world; ++d) {
+                const uint64_t m = __ballot(dest == d);
+                if (m == 0) continue;
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                if (!FILL) {
+                    if ((uint32_t)lane == d) my_count += cnt;
+                } else {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(&O.dest_cursor[d], (unsigned long long)cnt);
+                    base = (unsigned long long)__shfl((long long)base, 0);
+                    if (dest == d) O.items[O.dest_offset[d] + base + (unsigned long long)__popcll(m & lt)] = make_ulonglong2(key, (unsigned long long)epoch);
+                }
+            }
+        });
+    }
+    if (!FILL && (uint32_t)lane < O.world && my_count) atomicAdd(&O.dest_count[lane], my_count);
+}
+
+__global__ void kmer_outbox_offsets(const KmerOutbox O)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long o = 0;
+        for (uint32_t d = 0; d < O.world; ++d) { O.dest_offset[d] = o; o += O.dest_count[d]; O.dest_cursor[d] = 0; }
+    }
+}
+
+// owner side: insert received (key, epoch) pairs; tot_by_epoch[e] += occurrences (wave-aggregated per distinct epoch)
+__global__ __launch_bounds__(256) void kmer_insert_items(const KmerTable T, const ulonglong2 *__restrict__ items,
+                                                         const unsigned long long n, unsigned long long *tot_by_epoch,
+                                                         const uint32_t n_epochs)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long my_new = 0;
+    bool full = false;
+    for (unsigned long long i0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n;
+         i0 += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long i = i0 + lane;
+        const bool on = i < n;
+        ulonglong2 it = make_ulonglong2(0, 0);
+        if (on) it = items[i];
+        uint32_t e = on ? (uint32_t)it.y : 0xffffffffu;
+        if (on) {
+            bool is_new;
+            if (kmer_insert(T, it.x, e, is_new)) my_new += is_new ? 1u : 0u;
+            else full = true;
+        }
+        uint64_t todo = __ballot(on);
+        while (todo) { // one atomic per distinct epoch in the wave
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t e0 = (uint32_t)__shfl((int)e, leader);
+            const uint64_t m = __ballot(on && e == e0);
+            if (lane == leader && e0 < n_epochs) atomicAdd(&tot_by_epoch[e0], (unsigned long long)__popcll(m));
+            todo &= ~m;
+        }
+    }
+    const unsigned long long nw = (unsigned long long)wave_sum_i32((int)my_new);
+    if (lane == 0 && nw) atomicAdd(&T.stats[0], nw);
+    if (__any(full) && lane == 0) atomicOr(&T.stats[2], 1ull);
+}
+
+// owner side: distinct_by_first_epoch[e] = number of keys whose smallest epoch is e
+__global__ void kmer_first_epoch_histogram(const KmerTable T, unsigned long long *hist, const uint32_t n_epochs)
+{
+    const uint64_t slots = T.mask + 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (T.keys[i] != ~0ull) {
+            const uint32_t e = T.first_epoch[i];
+            if (e < n_epochs) atomicAdd(&hist[e], 1ull);
+        }
+    }
 }
 
 // histogram of counts over the table (FaQCs.cpp:518-521): dense[c] for c < dense_n, (count) list otherwise
@@ -144,5 +275,48 @@ hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *d
                                        hipStream_t st)
 {
     hipLaunchKernelGGL(kmer_count_histogram, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap);
+    return hipGetLastError();
+}
+
+hipError_t faqcs_launch_kmer_extract(const DevParams &P, uint32_t k, const KmerOutbox &O, bool fill, const uint8_t *seq,
+                                     const uint8_t *qual, const uint32_t *off, uint32_t r_begin, uint32_t r_end,
+                                     const faqcs_read_result *results, uint32_t epoch, int n_cu, hipStream_t st)
+{
+    if (r_end <= r_begin) return hipSuccess;
+    constexpr int NW = 4;
+    uint32_t grid = (r_end - r_begin + NW - 1) / NW;
+    const uint32_t cap = (uint32_t)n_cu * 8u;
+    if (grid > cap) grid = cap;
+    if (fill)
+        hipLaunchKernelGGL((kmer_extract<NW, true>), dim3(grid), dim3(NW * 64), 0, st, P, k, O, seq, qual, off, r_begin, r_end,
+                           reinterpret_cast<const uint2 *>(results), epoch);
+    else
+        hipLaunchKernelGGL((kmer_extract<NW, false>), dim3(grid), dim3(NW * 64), 0, st, P, k, O, seq, qual, off, r_begin, r_end,
+                           reinterpret_cast<const uint2 *>(results), epoch);
+    return hipGetLastError();
+}
+
+hipError_t faqcs_launch_kmer_outbox_offsets(const KmerOutbox &O, hipStream_t st)
+{
+    hipLaunchKernelGGL(kmer_outbox_offsets, dim3(1), dim3(64), 0, st, O);
+    return hipGetLastError();
+}
+
+hipError_t faqcs_launch_kmer_insert_items(const KmerTable &T, const void *items, unsigned long long n,
+                                          unsigned long long *tot_by_epoch, uint32_t n_epochs, int n_cu, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    unsigned long long blocks = (n + 255) / 256;
+    const unsigned long long cap = (unsigned long long)n_cu * 16ull;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(kmer_insert_items, dim3((uint32_t)blocks), dim3(256), 0, st, T, reinterpret_cast<const ulonglong2 *>(items), n,
+                       tot_by_epoch, n_epochs);
+    return hipGetLastError();
+}
+
+hipError_t faqcs_launch_kmer_first_epoch_histogram(const KmerTable &T, unsigned long long *hist, uint32_t n_epochs, int n_cu,
+                                                   hipStream_t st)
+{
+    hipLaunchKernelGGL(kmer_first_epoch_histogram, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, hist, n_epochs);
     return hipGetLastError();
 }

@@ -99,6 +99,32 @@ class HipEngine:
             _check(self.lib, self.lib.faqcs_kmer_histogram(self.ctx, c.ctypes.data, k.ctypes.data, n.value, C.byref(n)))
         return c, k
 
+    # -- k-mers across GPUs (owner-partitioned tables; faqcs_amd/parallel.py drives the exchange) --------------
+    def kmer_partition(self, rank, world, n_epochs):
+        self._part = (rank, world, n_epochs)
+        _check(self.lib, self.lib.faqcs_kmer_partition(self.ctx, rank, world, n_epochs))
+
+    def kmer_set_epochs(self, epochs):
+        e = np.ascontiguousarray(epochs, dtype=np.uint32)
+        _check(self.lib, self.lib.faqcs_kmer_set_epochs(self.ctx, e.ctypes.data, len(e)))
+
+    def kmer_outbox(self):
+        """(device pointer to the (key, epoch) pairs grouped by destination, pairs per destination)."""
+        ptr = C.c_void_p()
+        counts = np.zeros(self._part[1], dtype=np.uint64)
+        _check(self.lib, self.lib.faqcs_kmer_outbox(self.ctx, C.byref(ptr), counts.ctypes.data))
+        return ptr.value, counts
+
+    def kmer_insert_device(self, d_items, n_items):
+        _check(self.lib, self.lib.faqcs_kmer_insert_device(self.ctx, d_items, int(n_items)))
+
+    def kmer_epoch_counts(self):
+        n = self._part[2]
+        d = np.zeros(n, dtype=np.uint64)
+        t = np.zeros(n, dtype=np.uint64)
+        _check(self.lib, self.lib.faqcs_kmer_epoch_counts(self.ctx, d.ctypes.data, t.ctypes.data, n))
+        return d, t
+
     def close(self):
         if self.ctx:
             self.lib.faqcs_destroy(self.ctx)

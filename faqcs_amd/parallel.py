@@ -1,6 +1,7 @@
-"""Multi-GPU plumbing: one process per GPU, reads shard embarrassingly, and the ONLY collective of the path is
-one all-reduce(sum) of the additive u64 counter block -- RCCL over xGMI when the
-process group is `nccl`, gloo in the CPU tests.
+"""Multi-GPU plumbing: one process per GPU, reads shard embarrassingly, and the only collective of the plain path
+is one all-reduce(sum) of the additive u64 counter block -- RCCL over xGMI when the
+process group is `nccl`, gloo in the CPU tests.  The k-mer rarefaction path is the one real exchange step:
+owner-partitioned tables fed by an all-to-all of (key, epoch) pairs (KmerExchange below).
 
 The reference has no counterpart (it is a single OpenMP process whose only reduction is the `omp critical`
 merge at trim.cpp:120-154); this is what that merge becomes across devices.
@@ -45,3 +46,97 @@ def allreduce_counters_host(block, group=None):
     t = torch.from_numpy(np.ascontiguousarray(block).view(np.int64).copy())
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.numpy().view(np.uint64)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# k-mer rarefaction across ranks
+# ---------------------------------------------------------------------------------------------------------------
+EPOCH_NONE = 0xFFFFFFFF
+
+
+def rarefaction_schedule(segment_sizes, split_size, num_subsample):
+    """Host restatement of the reference's sampling rule (trim.cpp:157-185) over the GLOBAL sequence of trim()
+    calls: returns (epoch per segment, num_seq of every point).  A segment's k-mers are in the table when point
+    number `epoch` is taken (and in every later one); EPOCH_NONE = the curve was complete, nothing is counted."""
+    epochs, points, total, active = [], [], 0, True
+    for size in segment_sizes:
+        epochs.append(len(points) if active else EPOCH_NONE)
+        total += int(size)
+        if active:
+            n_points = len(points)
+            if total // split_size > n_points and n_points < num_subsample:
+                points.append(total)
+            if n_points >= num_subsample:
+                active = False  # trim.cpp:180-184 (tested on the count BEFORE this call's point)
+    return epochs, points
+
+
+class KmerExchange:
+    """Drives the owner-partitioned k-mer tables of one rank: after every engine submission call exchange();
+    at the end of a process_paired()/process_unpaired() pass call finish() on every rank."""
+
+    def __init__(self, engine, rank, world, num_subsample, group=None):
+        self.engine, self.rank, self.world, self.group = engine, rank, world, group
+        self.n_epochs = num_subsample + 1  # the segment after the last point is still counted (in no point)
+        engine.kmer_partition(rank, world, self.n_epochs)
+
+    def exchange(self):
+        import torch
+        import torch.distributed as dist
+
+        ptr, counts = self.engine.kmer_outbox()
+        send = torch.from_numpy(counts.astype(np.int64))
+        recv = torch.empty(self.world, dtype=torch.int64)
+        on_device = dist.get_backend(self.group) == "nccl"
+        if on_device:
+            send_d, recv_d = send.cuda(), recv.cuda()
+            dist.all_to_all_single(recv_d, send_d, group=self.group)
+            recv = recv_d.cpu()
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
+        n_send, n_recv = int(send.sum()), int(recv.sum())
+        items = torch.as_tensor(_DevArray(ptr, max(1, 2 * n_send)), device="cuda")[: 2 * n_send] if n_send else torch.empty(0, dtype=torch.int64, device="cuda")
+        in_splits = [2 * int(x) for x in send]
+        out_splits = [2 * int(x) for x in recv]
+        if on_device:
+            got = torch.empty(2 * n_recv, dtype=torch.int64, device="cuda")
+            dist.all_to_all_single(got, items, out_splits, in_splits, group=self.group)
+        else:  # gloo: stage through the host
+            got_h = torch.empty(2 * n_recv, dtype=torch.int64)
+            dist.all_to_all_single(got_h, items.cpu(), out_splits, in_splits, group=self.group)
+            got = got_h.cuda()
+        torch.cuda.synchronize()
+        if n_recv:
+            self.engine.kmer_insert_device(got.data_ptr(), n_recv)
+        return n_send, n_recv
+
+    def finish(self, points_num_seq, total_reads):
+        """All-reduces the two additive epoch histograms and returns the rarefaction points as
+        [(num_seq, distinct, total)] plus the merged count histogram {count: keys}.  With no scheduled point the
+        reference still emits one for the whole pass (FaQCs.cpp:523-537)."""
+        import torch
+        import torch.distributed as dist
+
+        d, t = self.engine.kmer_epoch_counts()
+        both = torch.from_numpy(np.concatenate([d, t]).astype(np.int64))
+        if dist.get_backend(self.group) == "nccl":
+            both_d = both.cuda()
+            dist.all_reduce(both_d, group=self.group)
+            both = both_d.cpu()
+        else:
+            dist.all_reduce(both, group=self.group)
+        d = np.cumsum(both[: self.n_epochs].numpy())
+        t = np.cumsum(both[self.n_epochs:].numpy())
+        points = [(int(ns), int(d[i]), int(t[i])) for i, ns in enumerate(points_num_seq)]
+        if not points:
+            points = [(int(total_reads), int(d[-1]), int(t[-1]))]
+        self.engine.kmer_end_table()
+        c, k = self.engine.kmer_histogram()
+        mine = {int(a): int(b) for a, b in zip(c, k)}
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, mine, group=self.group)
+        hist = {}
+        for g in gathered:
+            for a, b in g.items():
+                hist[a] = hist.get(a, 0) + b
+        return points, hist

@@ -219,6 +219,28 @@ int  faqcs_kmer_active(faqcs_ctx *ctx);
  * table (each process_* owns its own MAP<Word,size_t>, FaQCs.cpp:235,588). */
 int  faqcs_kmer_end_table(faqcs_ctx *ctx);
 
+/* ---- k-mers across GPUs --------------------------------------------------------------
+ * The reference keeps ONE MAP<Word,size_t> per process (trim.cpp:82,133-135) and samples (distinct, total) after
+ * trim() calls (trim.cpp:157-185); distinct counts are not additive over shards.  In this mode every canonical
+ * k-mer has one owner rank; a rank buckets the (key, epoch) pairs of its shard by owner, the caller moves the
+ * buckets with an all-to-all (RCCL: faqcs_amd/parallel.py), and the owner inserts them keeping the smallest epoch
+ * per key.  epoch = index of the first rarefaction point that includes the segment (a host function of the GLOBAL
+ * read counts only, trim.cpp:157-185); FAQCS_EPOCH_NONE = the curve was already complete.  Then
+ *   distinct(point i) = sum over ranks of #{keys with first epoch <= i},  total(point i) = sum of occurrences with
+ *   epoch <= i -- both additive, i.e. one all-reduce of 2 x n_epochs integers. */
+#define FAQCS_EPOCH_NONE 0xffffffffu
+/* First call on a fresh kmer_rarefaction context.  n_epochs = number of epoch slots (num_subsample + 1). */
+int  faqcs_kmer_partition(faqcs_ctx *ctx, uint32_t rank, uint32_t world, uint32_t n_epochs);
+/* Epoch of every segment of the NEXT submission (which then buckets instead of inserting). */
+int  faqcs_kmer_set_epochs(faqcs_ctx *ctx, const uint32_t *segment_epoch, uint32_t n_segments);
+/* After a submission: device array of (u64 key, u64 epoch) pairs grouped by destination rank 0..world-1 and the
+ * number of pairs per destination (counts[world]).  Valid until the next submission. */
+int  faqcs_kmer_outbox(faqcs_ctx *ctx, void **d_items, uint64_t *counts);
+/* Owner side: inserts n_items received pairs (device pointer; returns when the buffer may be reused). */
+int  faqcs_kmer_insert_device(faqcs_ctx *ctx, const void *d_items, uint64_t n_items);
+/* Owner side: keys by first epoch and occurrences by epoch of THIS rank's table ([n_epochs] each, cap >= n_epochs). */
+int  faqcs_kmer_epoch_counts(faqcs_ctx *ctx, uint64_t *distinct_by_first_epoch, uint64_t *total_by_epoch, uint32_t cap);
+
 /* ---- measurement helpers (used by bench.py; not part of the reference seam) ---- */
 /* Fills device arenas with the SURVEY section-8(d) synthetic reads (counter-based PRNG keyed by
  * (seed, first_read + i)); stride == L (packed).  d_offset gets n_reads+1 entries. */

@@ -76,3 +76,49 @@ def test_shard_bounds_cover_everything():
             spans = [parallel.shard_bounds(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+@pytest.mark.parametrize("split,subset,seg", [(300, 4, 333), (700, 10, 333), (5000, 10, 100), (100, 3, 64), (64, 50, 64)])
+def test_rarefaction_schedule_matches_the_oracle(split, subset, seg):
+    """parallel.rarefaction_schedule (the host rule the multi-GPU k-mer path runs on GLOBAL read counts) against the
+    points of the single-process oracle (trim.cpp:157-185), and the epoch identity the exchange relies on:
+    distinct(point i) = #{keys whose first epoch <= i}, total(point i) = #{occurrences with epoch <= i}."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_fixtures
+    from oracle_engine import OracleEngine
+
+    from faqcs_amd import driver, parallel
+    from faqcs_amd.options import parse_args
+
+    opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", str(split), "--subset", str(subset), "--qc_only", "-m", "9"])
+    rng = np.random.Generator(np.random.PCG64(5))
+    reads = []
+    for _ in range(1500):
+        s, q = make_fixtures._adv_read(rng, 60)
+        reads.append((b"@r", s.tobytes(), q.tobytes()))
+    segs = [reads[i:i + seg] for i in range(0, len(reads), seg)]
+    epochs, points = parallel.rarefaction_schedule([len(x) for x in segs], opt.split_size, opt.num_subsample)
+    ora = OracleEngine(opt, 256, 33)
+    ora.process(*driver.pack_segments(segs))
+    got = ora.kmer_points()
+    assert [int(p["num_seq"]) for p in got] == points
+    # epoch identity with plain python sets (k = 9, --qc_only: the raw reads are counted)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    first, total_by_epoch = {}, {}
+    for e, sg in zip(epochs, segs):
+        if e == parallel.EPOCH_NONE:
+            continue
+        for _d, sq, _q in sg:
+            u = sq.upper()
+            for i in range(len(u) - 8):
+                w = u[i:i + 9]
+                if w.strip(b"ACGT"):
+                    continue
+                key = min(w, w.translate(comp)[::-1])
+                first[key] = min(first.get(key, e), e)
+                total_by_epoch[e] = total_by_epoch.get(e, 0) + 1
+    for i, p in enumerate(got):
+        assert int(p["distinct_kmer"]) == sum(1 for v in first.values() if v <= i)
+        assert int(p["total_kmer"]) == sum(v for k, v in total_by_epoch.items() if k <= i)

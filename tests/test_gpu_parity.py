@@ -195,6 +195,74 @@ def test_kmer_matches_oracle():
         assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
 
 
+def _kmer_rank(rank, world, port, args, n_reads, seg_size, out):
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for d in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        sys.path.insert(0, d)
+    import torch
+
+    torch.cuda.init()  # before libfaqcs_mi.so (torch ships its own HIP runtime)
+    import torch.distributed as dist
+    from oracle_engine import OracleEngine
+
+    from faqcs_amd import driver, parallel
+    from faqcs_amd.engine import HipEngine
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    opt = parse_args(["-u", "x", "-d", "y"] + args)
+    rng = np.random.Generator(np.random.PCG64(4242))
+    reads = random_batch(rng, n_reads, 150, "adv")
+    segs = [reads[i:i + seg_size] for i in range(0, n_reads, seg_size)]
+    epochs, points = parallel.rarefaction_schedule([len(s) for s in segs], opt.split_size, opt.num_subsample)
+    lo, hi = parallel.shard_bounds(len(segs), rank, world)
+    eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << 22)
+    ex = parallel.KmerExchange(eng, rank, world, opt.num_subsample)
+    mid = (lo + hi) // 2
+    for a, b in ((lo, mid), (mid, hi)):  # every rank makes the same number of (collective) exchanges
+        if b > a:
+            seq, qual, offset, seg = driver.pack_segments(segs[a:b])
+            eng.kmer_set_epochs(epochs[a:b])
+            eng.process(seq, qual, offset, seg)
+        ex.exchange()
+    pts, hist = ex.finish(points, n_reads)
+    if rank == 0:
+        ora = OracleEngine(opt, 256, 33)
+        s2, q2, o2, g2 = driver.pack_segments(segs)
+        ora.process(s2, q2, o2, g2)
+        ora.kmer_end_table()
+        want = [(int(p["num_seq"]), int(p["distinct_kmer"]), int(p["total_kmer"])) for p in ora.kmer_points()]
+        hc, hk = ora.kmer_histogram()
+        want_hist = {int(a): int(b) for a, b in zip(hc, hk)}
+        with open(out, "w") as f:
+            f.write("ok" if (pts == want and hist == want_hist and len(want) > 0) else "mismatch:\n%r\n%r" % (pts, want))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("args,n_reads", [
+    (["--kmer_rarefaction", "--split_size", "300", "--subset", "4"], 3000),   # curve completes mid-run
+    (["--kmer_rarefaction", "--split_size", "700"], 2600),                       # curve still open at the end
+    (["--kmer_rarefaction", "--split_size", "5000", "--qc_only"], 1500),         # no scheduled point: the fallback one
+], ids=["complete", "open", "fallback"])
+def test_two_rank_kmer_exchange(args, n_reads, tmp_path):
+    """owner-partitioned k-mer tables, (key, epoch) all-to-all (gloo here, two ranks sharing the
+    one GPU of the box), additive epoch histograms -> the same rarefaction points and count histogram as one process."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_kmer_rank, args=(2, port, args, n_reads, 333, out), nprocs=2, join=True)
+    assert open(out).read() == "ok", open(out).read()
+
+
 def test_full_size_properties():
     """BASELINE configs[1] shape at a size the oracle cannot follow: size-independent invariants of the
     counter block, device-resident submission == host submission, and idempotence of trimming."""
