@@ -38,12 +38,12 @@ struct AdapterDev {
 __device__ const uint8_t k_iupac[26] = {
     /*a*/ 1, /*b*/ 14, /*c*/ 2, /*d*/ 13, /*e*/ 0, /*f*/ 0, /*g*/ 4, /*h*/ 11, /*i*/ 0, /*j*/ 0, /*k*/ 12, /*l*/ 0, /*m*/ 3,
     /*n*/ 15, /*o*/ 0, /*p*/ 0, /*q*/ 0, /*r*/ 5, /*s*/ 6, /*t*/ 8, /*u*/ 0, /*v*/ 7, /*w*/ 9, /*x*/ 0, /*y*/ 10, /*z*/ 0};
-__device__ __forceinline__ uint32_t na_bits(uint32_t c)
+__device__ __forceinline__ uint32_t na_bits(uint32_t c, const uint8_t *iupac /* LDS copy of k_iupac */)
 {
     if (c == '-') return 16u;
     const uint32_t l = (c | 0x20u) - 'a';
     const bool letter = ((c & 0xdfu) >= 'A') && ((c & 0xdfu) <= 'Z');
-    return letter ? (uint32_t)k_iupac[l] : 0u;
+    return letter ? (uint32_t)iupac[l & 31u] : 0u;
 }
 
 // a wave's LDS operations execute in order; this only stops the compiler from moving them across the point
@@ -53,6 +53,35 @@ __device__ __forceinline__ void lds_sync_wave()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Register-blocked prefilter of one (read, adapter) pair with |read| <= 256 and |adapter| <= 128.
+// A lane's diagonal in block b faces adapter word w at read bit 32 w - 64 b - lane + |read| - 1: the bit shift never
+// changes and the dword index is idx00 + w - 2 b, so the lane's shifted read windows R[plane][e], e = w - 2 b + 10, are
+// built ONCE per read (56 v_alignbit) and every (block, word) step is 4 and/or + 1 popcount on registers -- no LDS read,
+// no shift.  Returns the largest per-diagonal match count of this lane.
+constexpr int PF_E = 14; // e = w - 2 b + 10 for w in [0, 4), b in [0, 6)
+template <int NB>
+__device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][PF_E], const uint32_t *tpl, const int nw)
+{
+    uint32_t cnt[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) cnt[b] = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < nw) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(tpl + 4 * w); // the adapter's planes of bases [32w, 32w+32): LDS broadcast
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int e = w - 2 * b + 10;
+                cnt[b] += __popc((R[0][e] & t.x) | (R[1][e] & t.y) | (R[2][e] & t.z) | (R[3][e] & t.w));
+            }
+        }
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) m = umax_(m, cnt[b]);
+    return m;
+}
+
 template <int NW, int MAXLEN>
 __global__ __launch_bounds__(NW * 64) void adapter_overlap(
     const AdapterDev A, const uint8_t *__restrict__ seq, const uint32_t *__restrict__ off, const uint32_t n_reads,
@@ -60,10 +89,16 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
     uint16_t *__restrict__ ad_hit, uint64_t *__restrict__ adapter_stats, uint32_t *__restrict__ err, const uint32_t dbg)
 {
     constexpr int QW = MAXLEN / 32;            // data dwords per plane
-    constexpr int PW = QW + 4;                 // + two zero dwords on each side
+    constexpr int PADL = 12;                   // zero dwords on each side: the register-blocked stage 1 reads up to 12 dwords
+    constexpr int PW = QW + 2 * PADL;          // before / after the data without clamping its index
+    constexpr int TPL_CAP = 4096;              // adapter plane dwords cached in LDS (16 KB: every built-in set incl. PhiX)
+    constexpr int NBLK = 6;                    // 64-diagonal blocks kept in registers: |read| <= 256, |adapter| <= 128
     __shared__ uint8_t s_q[NW][MAXLEN];        // the read's IUPAC masks (stage 2)
     __shared__ uint8_t s_mask[NW][MAXLEN];     // vector<bool> mask of trim.cpp:991 (1 = unmasked)
     __shared__ uint32_t s_pl[NW][4][PW];       // the read's four base bit-planes, position ordered (stage 1)
+    __shared__ __attribute__((aligned(16))) uint32_t s_tpl[TPL_CAP]; // the adapters' bit-planes (4 dwords per 32 bases)
+    __shared__ uint8_t s_iupac[32];
+    __shared__ uint32_t s_start[FAQCS_MAX_ADAPTERS + 1], s_wstart[FAQCS_MAX_ADAPTERS + 1]; // adapter table of contents
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
     // plain (non-volatile) pointers so the accesses stay ds_* instructions (a volatile generic pointer degrades
@@ -74,7 +109,12 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
     const uint32_t n_waves = gridDim.x * NW;
 
     for (int i = lane; i < 4 * PW; i += 64) pl[i] = 0u; // pads stay zero for the whole kernel
-    lds_sync_wave();
+    for (uint32_t i = threadIdx.x; i <= A.n_adapters; i += NW * 64) { s_start[i] = A.start[i]; s_wstart[i] = A.wstart[i]; }
+    const uint32_t tpl_dwords = 4u * A.wstart[A.n_adapters];
+    const bool tpl_cached = tpl_dwords <= (uint32_t)TPL_CAP;
+    if (tpl_cached) for (uint32_t i = threadIdx.x; i < tpl_dwords; i += NW * 64) s_tpl[i] = A.planes[i];
+    if (threadIdx.x < 32) s_iupac[threadIdx.x] = threadIdx.x < 26 ? k_iupac[threadIdx.x] : (uint8_t)0;
+    __syncthreads();
 
 #pragma unroll 1
     for (uint32_t r = blockIdx.x * NW + wave; r < n_reads; r += n_waves) {
@@ -82,6 +122,10 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
         const int qlen = (int)(off[r + 1] - o);
         // ---- which reference group of 8 is this read in? (trim.cpp:977-1071, -t 1 semantics) ----------
         uint32_t lo = 0, hi = n_segments; // segment s with seg_start[s] <= r < seg_start[s+1]
+        {   // segments are FAQCS_SEGMENT_READS long except the tails: try that guess before searching
+            const uint32_t g = r / FAQCS_SEGMENT_READS;
+            if (g < n_segments && seg_start[g] <= r && r < seg_start[g + 1]) { lo = g; hi = g + 1; }
+        }
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= r) lo = mid; else hi = mid; }
         const uint32_t s0 = seg_start[lo], s1 = seg_start[lo + 1];
         const uint32_t g_last = s0 + (((r - s0) >> 3) << 3) + 7; // last slot of the group
@@ -95,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
             const int p = c * 64 + lane;
             uint32_t bits = 0;
             if (p < qlen) {
-                bits = na_bits(seq[(size_t)o + p]);
+                bits = na_bits(seq[(size_t)o + p], s_iupac);
                 badbase |= bits == 0u;
                 q[p] = (uint8_t)bits;
                 mk[p] = 1;
@@ -104,16 +148,26 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const uint64_t m = __ballot((bits >> b) & 1u);
-                if (lane == 0) { pl[b * PW + 2 + 2 * c] = (uint32_t)m; pl[b * PW + 3 + 2 * c] = (uint32_t)(m >> 32); }
+                if (lane == 0) { pl[b * PW + PADL + 2 * c] = (uint32_t)m; pl[b * PW + PADL + 1 + 2 * c] = (uint32_t)(m >> 32); }
             }
         }
         const bool read_bad = __any(badbase);
         lds_sync_wave();
+        uint32_t R[4][PF_E];
+        if (MAXLEN == 256 && tpl_cached) {
+            const int i00 = (qlen - 1) - lane;                       // read bit facing adapter base 0 on block 0's diagonal
+            const uint32_t sh = (uint32_t)i00 & 31u;
+            const uint32_t *pp = pl + (i00 >> 5) + PADL - 10;        // e = 0
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int e = 0; e < PF_E; ++e) R[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
+        }
 
         // exact alignment of adapter j: best (M, i, j) over all diagonals -> (score or -1, start, stop)
         auto align_exact = [&](uint32_t j, int &gM, int &gS, int &gI) {
-            const uint32_t t0 = A.start[j];
-            const int tlen = (int)(A.start[j + 1] - t0);
+            const uint32_t t0 = s_start[j];
+            const int tlen = (int)(s_start[j + 1] - t0);
             gM = -1; gI = 0; gS = 0;
             int gJ = 0;
             const int ndiag = qlen + tlen - 1;
@@ -155,17 +209,29 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
         bool have = false, known = false;
         uint32_t last_j = 0;
         int rs = 0, re = 0;
+        // ---- stage 1 for every adapter: two bits per adapter (any cell matches / the threshold is reachable) ---------
+        uint64_t m_any = 0, m_pass = 0;
         if (!read_bad && qlen > 0) {
 #pragma unroll 1
             for (uint32_t j = 0; j < A.n_adapters; ++j) {
-                const int tlen = (int)(A.start[j + 1] - A.start[j]);
+                const int tlen = (int)(s_start[j + 1] - s_start[j]);
                 const int m = tail ? tlen : (len8 < tlen ? len8 : tlen);
                 const int thr = (int)__fmul_rn(A.match_rate, (float)m);      // trim.cpp:1007-1008 / :1082
-                // ---- stage 1: per-diagonal match popcounts -------------------------------------------------
                 bool any_match = true, may_pass = true;
-                if (!(dbg & 8u)) {
-                    const uint32_t w0 = A.wstart[j];
-                    const int nw = (int)(A.wstart[j + 1] - w0);
+                const int mcap = qlen < tlen ? qlen : tlen;
+                if (!(dbg & 8u) && MAXLEN == 256 && tlen <= 128 && tpl_cached) {
+                    const uint32_t *tpl = s_tpl + 4 * s_wstart[j];
+                    const int nw = (tlen + 31) >> 5;
+                    const int nb = (qlen + tlen - 1 + 63) >> 6;              // blocks past the last diagonal would only add zeros
+                    const uint32_t maxcnt = nb <= 3 ? prefilter_max<3>(R, tpl, nw) : nb == 4 ? prefilter_max<4>(R, tpl, nw)
+                                          : nb == 5 ? prefilter_max<5>(R, tpl, nw) : prefilter_max<6>(R, tpl, nw);
+                    // bound = max over diagonals; only two threshold tests of it are needed
+                    const int need = 2 * thr - mcap;                          // (mcap + bound) / 2 >= thr  <=>  bound >= need
+                    any_match = __any(maxcnt > 0u);
+                    may_pass = __any((int)maxcnt >= need);
+                } else if (!(dbg & 8u)) {
+                    const uint32_t w0 = s_wstart[j];
+                    const int nw = (int)(s_wstart[j + 1] - w0);
                     const int ndiag = qlen + tlen - 1;
                     uint32_t maxcnt = 0;
 #pragma unroll 1
@@ -180,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
                             int idx = i0 >> 5;
                             idx = idx < -2 ? -2 : (idx > QW ? QW : idx);
                             const uint32_t sh = (uint32_t)i0 & 31u;
-                            const uint32_t *pp = pl + idx + 2;
+                            const uint32_t *pp = pl + idx + PADL;
                             const uint32_t qa = __builtin_amdgcn_alignbit(pp[1], pp[0], sh);
                             const uint32_t qc = __builtin_amdgcn_alignbit(pp[PW + 1], pp[PW], sh);
                             const uint32_t qg = __builtin_amdgcn_alignbit(pp[2 * PW + 1], pp[2 * PW], sh);
@@ -191,9 +257,22 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
                     }
                     const int bound = (int)wave_max_u32(maxcnt);             // >= best local-alignment score
                     any_match = bound > 0;
-                    const int mcap = qlen < tlen ? qlen : tlen;
                     may_pass = (mcap + bound) / 2 >= thr;
                 }
+                m_any |= (uint64_t)any_match << j;
+                m_pass |= (uint64_t)may_pass << j;
+            }
+        }
+        // ---- stage 2 + the reference's sequential state (stale range, mask, credit), trim.cpp:1003-1071.  With every
+        // adapter matching somewhere and none able to reach its threshold (the bulk of the reads) nothing can happen.
+        const uint64_t m_all = A.n_adapters >= 64 ? ~0ull : ((1ull << A.n_adapters) - 1ull);
+        if (!read_bad && qlen > 0 && !(m_pass == 0 && m_any == m_all)) {
+#pragma unroll 1
+            for (uint32_t j = 0; j < A.n_adapters; ++j) {
+                const int tlen = (int)(s_start[j + 1] - s_start[j]);
+                const int m = tail ? tlen : (len8 < tlen ? len8 : tlen);
+                const int thr = (int)__fmul_rn(A.match_rate, (float)m);      // trim.cpp:1007-1008 / :1082
+                const bool any_match = (m_any >> j) & 1ull, may_pass = (m_pass >> j) & 1ull;
                 int score = 0;
                 if (any_match) {
                     if (!may_pass) { have = true; known = false; last_j = j; continue; } // cannot mask, cannot be credited
@@ -251,7 +330,7 @@ hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const u
 {
     if (n_reads == 0) return hipSuccess;
     if (max_len <= 256) {
-        constexpr int NW = 8;
+        constexpr int NW = 8; // (A/B on MI355X: 4-wave blocks at 5 waves/SIMD were 9 % slower)
         uint32_t grid = (n_reads + NW - 1) / NW;
         const uint32_t cap = (uint32_t)n_cu * 4u;
         if (grid > cap) grid = cap;
