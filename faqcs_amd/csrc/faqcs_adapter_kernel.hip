@@ -24,6 +24,8 @@
 // adapter of the same read when no cell reaches M >= 0 (the carried range is computed on demand).
 #include "faqcs_dev.h"
 
+#include <type_traits>
+
 struct AdapterDev {
     const uint8_t *bits;     // concatenated 4-bit IUPAC masks, one byte per base
     const uint32_t *start;   // [n_adapters + 1] base offsets into bits
@@ -55,12 +57,12 @@ __device__ __forceinline__ void lds_sync_wave()
 
 // Register-blocked prefilter of one (read, adapter) pair with |read| <= 256 and |adapter| <= 128.
 // A lane's diagonal in block b faces adapter word w at read bit 32 w - 64 b - lane + |read| - 1: the bit shift never
-// changes and the dword index is idx00 + w - 2 b, so the lane's shifted read windows R[plane][e], e = w - 2 b + 10, are
-// built ONCE per read (56 v_alignbit) and every (block, word) step is 4 and/or + 1 popcount on registers -- no LDS read,
+// changes and the dword index is idx00 + w - 2 b, so the lane's shifted read windows R[plane][e], e = w - 2 b + const, are
+// built ONCE per read (40 or 56 v_alignbit) and every (block, word) step is 4 and/or + 1 popcount on registers -- no LDS read,
 // no shift.  Returns the largest per-diagonal match count of this lane.
-constexpr int PF_E = 14; // e = w - 2 b + 10 for w in [0, 4), b in [0, 6)
-template <int NB>
-__device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][PF_E], const uint32_t *tpl, const int nw)
+// NBR = blocks the window array covers (4 when |read| + |longest short adapter| - 1 <= 256, else 6): e = w - 2 b + 2 (NBR - 1)
+template <int NB, int NBR>
+__device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][2 * NBR + 2], const uint32_t *tpl, const int nw)
 {
     uint32_t cnt[NB];
 #pragma unroll
@@ -71,7 +73,7 @@ __device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][PF_E], 
             const uint4 t = *reinterpret_cast<const uint4 *>(tpl + 4 * w); // the adapter's planes of bases [32w, 32w+32): LDS broadcast
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const int e = w - 2 * b + 10;
+                const int e = w - 2 * b + 2 * (NBR - 1);
                 cnt[b] += __popc((R[0][e] & t.x) | (R[1][e] & t.y) | (R[2][e] & t.z) | (R[3][e] & t.w));
             }
         }
@@ -83,7 +85,7 @@ __device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][PF_E], 
 }
 
 template <int NW, int MAXLEN>
-__global__ __launch_bounds__(NW * 64) void adapter_overlap(
+__global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
     const AdapterDev A, const uint8_t *__restrict__ seq, const uint32_t *__restrict__ off, const uint32_t n_reads,
     const uint32_t *__restrict__ seg_start, const uint32_t n_segments, uint32_t *__restrict__ ad_sl,
     uint16_t *__restrict__ ad_hit, uint64_t *__restrict__ adapter_stats, uint32_t *__restrict__ err, const uint32_t dbg)
@@ -98,7 +100,9 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
     __shared__ uint32_t s_pl[NW][4][PW];       // the read's four base bit-planes, position ordered (stage 1)
     __shared__ __attribute__((aligned(16))) uint32_t s_tpl[TPL_CAP]; // the adapters' bit-planes (4 dwords per 32 bases)
     __shared__ uint8_t s_iupac[32];
+    __shared__ uint8_t s_na[256];              // na_to_bits() of every byte value (0 = the reference throws)
     __shared__ uint32_t s_start[FAQCS_MAX_ADAPTERS + 1], s_wstart[FAQCS_MAX_ADAPTERS + 1]; // adapter table of contents
+    __shared__ __attribute__((aligned(16))) uint4 s_meta[FAQCS_MAX_ADAPTERS]; // {|adapter|, first plane word, int(rate * |adapter|), 0}
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
     // plain (non-volatile) pointers so the accesses stay ds_* instructions (a volatile generic pointer degrades
@@ -114,56 +118,91 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
     const bool tpl_cached = tpl_dwords <= (uint32_t)TPL_CAP;
     if (tpl_cached) for (uint32_t i = threadIdx.x; i < tpl_dwords; i += NW * 64) s_tpl[i] = A.planes[i];
     if (threadIdx.x < 32) s_iupac[threadIdx.x] = threadIdx.x < 26 ? k_iupac[threadIdx.x] : (uint8_t)0;
+    for (uint32_t i = threadIdx.x; i < A.n_adapters; i += NW * 64) {
+        const uint32_t tl = A.start[i + 1] - A.start[i];
+        s_meta[i] = make_uint4(tl, A.wstart[i], (uint32_t)(int)__fmul_rn(A.match_rate, (float)(int)tl), 0u);
+    }
     __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256; i += NW * 64) s_na[i] = (uint8_t)na_bits(i, s_iupac);
+    __syncthreads();
+    int prev_qlen = 0; // longest span of plane words the previous read of this wave left behind
+    int short_tlen_max = 0; // longest adapter the register-blocked prefilter handles (<= 128 bases)
+    for (uint32_t i = 0; i < A.n_adapters; ++i) { const int tl = (int)s_meta[i].x; if (tl <= 128 && tl > short_tlen_max) short_tlen_max = tl; }
+    short_tlen_max = uni(short_tlen_max);
 
+    // A wave takes chunks of 64 consecutive reads: offsets load and results store as one coalesced vector per chunk,
+    // per-read scalars come out of the lanes with v_readlane, and the bases of read t+1 are fetched while read t is
+    // processed -- no dependent global load sits in front of a read.
+    constexpr int NCH = MAXLEN / 64;
+    const uint32_t total_chunks = (n_reads + 63u) >> 6;
 #pragma unroll 1
-    for (uint32_t r = blockIdx.x * NW + wave; r < n_reads; r += n_waves) {
-        const uint32_t o = off[r];
-        const int qlen = (int)(off[r + 1] - o);
-        // ---- which reference group of 8 is this read in? (trim.cpp:977-1071, -t 1 semantics) ----------
-        uint32_t lo = 0, hi = n_segments; // segment s with seg_start[s] <= r < seg_start[s+1]
-        {   // segments are FAQCS_SEGMENT_READS long except the tails: try that guess before searching
-            const uint32_t g = r / FAQCS_SEGMENT_READS;
-            if (g < n_segments && seg_start[g] <= r && r < seg_start[g + 1]) { lo = g; hi = g + 1; }
+    for (uint32_t chunk = blockIdx.x * NW + wave; chunk < total_chunks; chunk += n_waves) {
+      const uint32_t base = chunk << 6;
+      const uint32_t my = base + lane;
+      const bool mine = my < n_reads;
+      const uint32_t v_off = mine ? off[my] : 0u;
+      const uint32_t v_len = mine ? off[my + 1] - v_off : 0u;
+      uint32_t res_sl = 0, res_hit = 0;
+      // ---- which reference segment holds the chunk's first read? (later reads advance it) ------------------
+      uint32_t lo = 0, hi = n_segments; // segment s with seg_start[s] <= base < seg_start[s+1]
+      {   // segments are FAQCS_SEGMENT_READS long except the tails: try that guess before searching
+          const uint32_t g = base / FAQCS_SEGMENT_READS;
+          if (g < n_segments && seg_start[g] <= base && base < seg_start[g + 1]) { lo = g; hi = g + 1; }
+      }
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= base) lo = mid; else hi = mid; }
+      uint32_t s0 = seg_start[lo], s1 = seg_start[lo + 1];
+      uint32_t nbyte[NCH]; // bases of the next read, one byte per lane per 64-base chunk
+      {
+          const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)v_off, 0);
+          const int l0 = __builtin_amdgcn_readlane((int)v_len, 0);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) nbyte[c] = (c * 64 + lane < l0) ? (uint32_t)seq[(size_t)o0 + c * 64 + lane] : 0u;
+      }
+#pragma unroll 1
+      for (int t = 0; t < 64; ++t) {
+        const uint32_t r = base + (uint32_t)t;
+        if (r >= n_reads) break;
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)v_off, t);
+        const int qlen = __builtin_amdgcn_readlane((int)v_len, t);
+        uint32_t cbyte[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) cbyte[c] = nbyte[c];
+        if (t + 1 < 64 && r + 1 < n_reads) {
+            const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)v_off, t + 1);
+            const int l1 = __builtin_amdgcn_readlane((int)v_len, t + 1);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) nbyte[c] = (c * 64 + lane < l1) ? (uint32_t)seq[(size_t)o1 + c * 64 + lane] : 0u;
         }
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= r) lo = mid; else hi = mid; }
-        const uint32_t s0 = seg_start[lo], s1 = seg_start[lo + 1];
+        // ---- which reference group of 8 is this read in? (trim.cpp:977-1071, -t 1 semantics) ----------
+        while (r >= s1) { ++lo; s0 = s1; s1 = seg_start[lo + 1]; }   // (empty segments are skipped the same way)
         const uint32_t g_last = s0 + (((r - s0) >> 3) << 3) + 7; // last slot of the group
         const bool tail = g_last >= s1;
-        const int len8 = tail ? 0 : (int)(off[g_last + 1] - off[g_last]);
+        int len8 = 0;
+        if (!tail) len8 = (g_last - base < 64u) ? __builtin_amdgcn_readlane((int)v_len, (int)(g_last - base)) : (int)(off[g_last + 1] - off[g_last]);
 
-        // ---- pack_query: bases -> IUPAC bit masks (bytes) and the four bit-planes ----------------------------
+        // ---- pack_query: bases -> the four bit-planes (the per-base arrays of stage 2 are filled on demand) --------
         bool badbase = false;
-#pragma unroll 1
-        for (int c = 0; c * 64 < MAXLEN; ++c) {
-            const int p = c * 64 + lane;
-            uint32_t bits = 0;
-            if (p < qlen) {
-                bits = na_bits(seq[(size_t)o + p], s_iupac);
-                badbase |= bits == 0u;
-                q[p] = (uint8_t)bits;
-                mk[p] = 1;
-            }
-            // every chunk is rewritten (zeros past the read) so nothing of the previous read survives
+        const int span = qlen > prev_qlen ? qlen : prev_qlen;
+        prev_qlen = qlen;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint64_t m = __ballot((bits >> b) & 1u);
-                if (lane == 0) { pl[b * PW + PADL + 2 * c] = (uint32_t)m; pl[b * PW + PADL + 1 + 2 * c] = (uint32_t)(m >> 32); }
+        for (int c = 0; c < NCH; ++c) {
+            if (c * 64 < span) {
+                const int p = c * 64 + lane;
+                uint32_t bits = 0;
+                if (p < qlen) {
+                    bits = s_na[cbyte[c]];
+                    badbase |= bits == 0u;
+                }
+                // every chunk the previous read touched is rewritten (zeros past this read) so nothing of it survives
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint64_t m = __ballot((bits >> b) & 1u);
+                    if (lane == 0) { pl[b * PW + PADL + 2 * c] = (uint32_t)m; pl[b * PW + PADL + 1 + 2 * c] = (uint32_t)(m >> 32); }
+                }
             }
         }
         const bool read_bad = __any(badbase);
         lds_sync_wave();
-        uint32_t R[4][PF_E];
-        if (MAXLEN == 256 && tpl_cached) {
-            const int i00 = (qlen - 1) - lane;                       // read bit facing adapter base 0 on block 0's diagonal
-            const uint32_t sh = (uint32_t)i00 & 31u;
-            const uint32_t *pp = pl + (i00 >> 5) + PADL - 10;        // e = 0
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int e = 0; e < PF_E; ++e) R[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
-        }
-
         // exact alignment of adapter j: best (M, i, j) over all diagonals -> (score or -1, start, stop)
         auto align_exact = [&](uint32_t j, int &gM, int &gS, int &gI) {
             const uint32_t t0 = s_start[j];
@@ -211,20 +250,33 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
         int rs = 0, re = 0;
         // ---- stage 1 for every adapter: two bits per adapter (any cell matches / the threshold is reachable) ---------
         uint64_t m_any = 0, m_pass = 0;
-        if (!read_bad && qlen > 0) {
+        auto stage1 = [&](auto nbr_tag) {
+            constexpr int NBR = decltype(nbr_tag)::value;
+            uint32_t R[4][2 * NBR + 2];
+            if (MAXLEN == 256 && tpl_cached) {
+                const int i00 = (qlen - 1) - lane;                       // read bit facing adapter base 0 on block 0's diagonal
+                const uint32_t sh = (uint32_t)i00 & 31u;
+                const uint32_t *pp = pl + (i00 >> 5) + PADL - 2 * (NBR - 1); // e = 0
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int e = 0; e < 2 * NBR + 2; ++e) R[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
+            }
 #pragma unroll 1
             for (uint32_t j = 0; j < A.n_adapters; ++j) {
-                const int tlen = (int)(s_start[j + 1] - s_start[j]);
+                const uint4 meta = s_meta[j];
+                const int tlen = uni((int)meta.x);
                 const int m = tail ? tlen : (len8 < tlen ? len8 : tlen);
-                const int thr = (int)__fmul_rn(A.match_rate, (float)m);      // trim.cpp:1007-1008 / :1082
+                const int thr = m == tlen ? uni((int)meta.z) : (int)__fmul_rn(A.match_rate, (float)m); // trim.cpp:1007-1008 / :1082
                 bool any_match = true, may_pass = true;
                 const int mcap = qlen < tlen ? qlen : tlen;
                 if (!(dbg & 8u) && MAXLEN == 256 && tlen <= 128 && tpl_cached) {
-                    const uint32_t *tpl = s_tpl + 4 * s_wstart[j];
+                    const uint32_t *tpl = s_tpl + 4 * uniu(meta.y);
                     const int nw = (tlen + 31) >> 5;
                     const int nb = (qlen + tlen - 1 + 63) >> 6;              // blocks past the last diagonal would only add zeros
-                    const uint32_t maxcnt = nb <= 3 ? prefilter_max<3>(R, tpl, nw) : nb == 4 ? prefilter_max<4>(R, tpl, nw)
-                                          : nb == 5 ? prefilter_max<5>(R, tpl, nw) : prefilter_max<6>(R, tpl, nw);
+                    uint32_t maxcnt;
+                    if (NBR == 4) maxcnt = nb <= 3 ? prefilter_max<3, NBR>(R, tpl, nw) : prefilter_max<4, NBR>(R, tpl, nw);
+                    else maxcnt = nb <= 4 ? prefilter_max<4, NBR>(R, tpl, nw) : prefilter_max<(NBR > 4 ? 6 : 4), NBR>(R, tpl, nw);
                     // bound = max over diagonals; only two threshold tests of it are needed
                     const int need = 2 * thr - mcap;                          // (mcap + bound) / 2 >= thr  <=>  bound >= need
                     any_match = __any(maxcnt > 0u);
@@ -262,11 +314,18 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
                 m_any |= (uint64_t)any_match << j;
                 m_pass |= (uint64_t)may_pass << j;
             }
+        };
+        if (!read_bad && qlen > 0) {
+            if (qlen + short_tlen_max - 1 <= 256) stage1(std::integral_constant<int, 4>{});
+            else stage1(std::integral_constant<int, 6>{});
         }
         // ---- stage 2 + the reference's sequential state (stale range, mask, credit), trim.cpp:1003-1071.  With every
         // adapter matching somewhere and none able to reach its threshold (the bulk of the reads) nothing can happen.
         const uint64_t m_all = A.n_adapters >= 64 ? ~0ull : ((1ull << A.n_adapters) - 1ull);
         if (!read_bad && qlen > 0 && !(m_pass == 0 && m_any == m_all)) {
+            // the per-base arrays of stage 2 are only needed here (a few percent of the reads)
+            for (int p = lane; p < qlen; p += 64) { q[p] = s_na[seq[(size_t)o + p]]; mk[p] = 1; }
+            lds_sync_wave();
 #pragma unroll 1
             for (uint32_t j = 0; j < A.n_adapters; ++j) {
                 const int tlen = (int)(s_start[j + 1] - s_start[j]);
@@ -315,12 +374,11 @@ __global__ __launch_bounds__(NW * 64) void adapter_overlap(
                 atomicAdd((unsigned long long *)&adapter_stats[2 * best_j + 1], (unsigned long long)((uint32_t)qlen - second));
             }
         }
-        if (lane == 0) {
-            ad_sl[r] = first | (second << 16);
-            ad_hit[r] = (uint16_t)(best_score > 0 ? best_j + 1 : 0);
-            if (read_bad) atomicOr(err, 2u);
-        }
+        if (lane == t) { res_sl = first | (second << 16); res_hit = (uint32_t)(best_score > 0 ? best_j + 1 : 0); }
+        if (read_bad && lane == 0) atomicOr(err, 2u);
         lds_sync_wave();
+      }
+      if (mine) { ad_sl[my] = res_sl; ad_hit[my] = (uint16_t)res_hit; }
     }
 }
 
