@@ -26,12 +26,12 @@ struct AdapterDev {
     uint32_t n_adapters;
     float match_rate;
 };
+struct __attribute__((aligned(16))) KmerSlot { unsigned long long key; uint32_t count_m1, first_epoch; };
 struct KmerTable {
-    unsigned long long *keys;
-    uint32_t *counts;
+    KmerSlot *slots;
     uint64_t mask;
     unsigned long long *stats;
-    uint32_t *first_epoch;
+    uint32_t partitioned;
 };
 struct KmerOutbox {
     ulonglong2 *items;
@@ -128,7 +128,7 @@ struct faqcs_ctx {
     std::vector<faqcs_rarefaction> points;
     struct PendingPoint { size_t point_index; size_t snap_index; };
     std::vector<PendingPoint> pending;
-    KmerTable kt{nullptr, nullptr, 0, nullptr, nullptr};
+    KmerTable kt{nullptr, 0, nullptr, 0};
     // owner-partitioned multi-GPU k-mer mode (faqcs_kmer_partition)
     bool partitioned = false;
     uint32_t part_rank = 0, part_world = 1, n_epochs = 0;
@@ -369,11 +369,9 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
         uint64_t slots = p->kmer_table_slots ? p->kmer_table_slots : (1ull << 28);
         uint64_t pow2 = 1; while (pow2 < slots) pow2 <<= 1;
         c->kt.mask = pow2 - 1;
-        HIPCHK(hipMalloc((void **)&c->kt.keys, pow2 * 8));
-        HIPCHK(hipMalloc((void **)&c->kt.counts, pow2 * 4));
+        HIPCHK(hipMalloc((void **)&c->kt.slots, pow2 * sizeof(KmerSlot)));
         HIPCHK(hipMalloc((void **)&c->kt.stats, 64));
-        HIPCHK(hipMemset(c->kt.keys, 0xff, pow2 * 8));
-        HIPCHK(hipMemset(c->kt.counts, 0, pow2 * 4));
+        HIPCHK(hipMemset(c->kt.slots, 0xff, pow2 * sizeof(KmerSlot))); // empty key, count - 1, no epoch
         HIPCHK(hipMemset(c->kt.stats, 0, 64));
         c->snap_cap = 4096;
         HIPCHK(hipMalloc((void **)&c->d_snaps, c->snap_cap * 16));
@@ -390,7 +388,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
-                    c->kt.keys, c->kt.counts, c->kt.stats, c->d_snaps, c->kt.first_epoch, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
+                    c->kt.slots, c->kt.stats, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (auto &sl : c->slot) { sl.seq.release(); sl.qual.release(); sl.off.release(); if (sl.done) (void)hipEventDestroy(sl.done); }
     for (auto &e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
@@ -720,14 +718,12 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
         (void)hipFree(d_dense); (void)hipFree(d_big); (void)hipFree(d_nbig);
     }
     if (c->partitioned) { // the points belong to the driver (faqcs_kmer_epoch_counts); only the table restarts here
-        HIPCHK(hipMemsetAsync(c->kt.first_epoch, 0xff, (c->kt.mask + 1) * 4, c->compute));
         HIPCHK(hipMemsetAsync(c->d_tot_by_epoch, 0, (size_t)c->n_epochs * 8, c->compute));
     } else if (c->kmer_active && c->points.empty()) { // FaQCs.cpp:523-537
         faqcs_rarefaction pt{c->total_number, st[0], st[1]};
         c->points.push_back(pt);
     }
-    HIPCHK(hipMemsetAsync(c->kt.keys, 0xff, (c->kt.mask + 1) * 8, c->compute));
-    HIPCHK(hipMemsetAsync(c->kt.counts, 0, (c->kt.mask + 1) * 4, c->compute));
+    HIPCHK(hipMemsetAsync(c->kt.slots, 0xff, (c->kt.mask + 1) * sizeof(KmerSlot), c->compute));
     HIPCHK(hipMemsetAsync(c->kt.stats, 0, 64, c->compute));
     return 0;
 }
@@ -738,12 +734,11 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
 extern "C" int faqcs_kmer_partition(faqcs_ctx *c, uint32_t rank, uint32_t world, uint32_t n_epochs)
 {
     if (!c) return fail(FAQCS_E_INVAL, "null ctx");
-    if (!c->kt.keys) return fail(FAQCS_E_INVAL, "faqcs_kmer_partition: the context was created without kmer_rarefaction");
+    if (!c->kt.slots) return fail(FAQCS_E_INVAL, "faqcs_kmer_partition: the context was created without kmer_rarefaction");
     if (world == 0 || world > 64 || rank >= world || n_epochs == 0) return fail(FAQCS_E_INVAL, "faqcs_kmer_partition: bad rank / world / n_epochs");
     if (c->n_submits || c->total_number || c->partitioned) return fail(FAQCS_E_INVAL, "faqcs_kmer_partition: must be the first call on a fresh context");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMalloc((void **)&c->kt.first_epoch, (c->kt.mask + 1) * 4));
-    HIPCHK(hipMemset(c->kt.first_epoch, 0xff, (c->kt.mask + 1) * 4));
+    c->kt.partitioned = 1;
     HIPCHK(hipMalloc((void **)&c->d_ob, 3 * (size_t)world * 8));
     HIPCHK(hipMalloc((void **)&c->d_tot_by_epoch, (size_t)n_epochs * 8));
     HIPCHK(hipMalloc((void **)&c->d_first_hist, (size_t)n_epochs * 8));

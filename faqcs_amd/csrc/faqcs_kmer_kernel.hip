@@ -13,12 +13,19 @@
 // (codes A=0,T=1,C=2,G=3: complement flips bit0, trim.cpp:904-917), key = min(enc, enc_rc).
 #include "faqcs_dev.h"
 
+// One 16-byte slot per key so that a probe touches ONE 64-byte sector (key CAS, count add and epoch min all land in it;
+// separate key / count arrays cost two random sectors per insert).  The table is initialised with 0xff bytes: key = ~0 is
+// "empty", the count is stored minus one (0xffffffff + 1 wraps to 0) and the epoch starts at "none".
+struct __attribute__((aligned(16))) KmerSlot {
+    unsigned long long key;
+    uint32_t count_m1;     // occurrences - 1 (mod 2^32)
+    uint32_t first_epoch;  // owner-partitioned (multi-GPU) mode: smallest epoch that inserted the key
+};
 struct KmerTable {
-    unsigned long long *keys;  // [slots], empty = ~0
-    uint32_t *counts;          // [slots]
+    KmerSlot *slots;           // [mask + 1]
     uint64_t mask;             // slots - 1
     unsigned long long *stats; // [0] distinct keys, [1] total occurrences, [2] overflow flag
-    uint32_t *first_epoch;     // [slots] owner-partitioned (multi-GPU) mode only: smallest epoch that inserted the key
+    uint32_t partitioned;      // maintain first_epoch
 };
 
 // multi-GPU exchange buffers of one submission (owner-partitioned mode)
@@ -103,11 +110,11 @@ __device__ __forceinline__ bool kmer_insert(const KmerTable &T, const uint64_t k
     is_new = false;
 #pragma unroll 1
     for (uint32_t probe = 0; probe < 4096; ++probe) {
-        const unsigned long long old = atomicCAS(&T.keys[h], ~0ull, (unsigned long long)key);
+        const unsigned long long old = atomicCAS(&T.slots[h].key, ~0ull, (unsigned long long)key);
         if (old == ~0ull) is_new = true;
         if (old == ~0ull || old == key) {
-            atomicAdd(&T.counts[h], 1u);
-            if (T.first_epoch) atomicMin(&T.first_epoch[h], epoch);
+            atomicAdd(&T.slots[h].count_m1, 1u);
+            if (T.partitioned) atomicMin(&T.slots[h].first_epoch, epoch);
             return true;
         }
         h = (h + 1) & T.mask;
@@ -232,8 +239,9 @@ __global__ void kmer_first_epoch_histogram(const KmerTable T, unsigned long long
 {
     const uint64_t slots = T.mask + 1;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (T.keys[i] != ~0ull) {
-            const uint32_t e = T.first_epoch[i];
+        const KmerSlot sl = T.slots[i];
+        if (sl.key != ~0ull) {
+            const uint32_t e = sl.first_epoch;
             if (e < n_epochs) atomicAdd(&hist[e], 1ull);
         }
     }
@@ -245,8 +253,9 @@ __global__ void kmer_count_histogram(const KmerTable T, unsigned long long *dens
 {
     const uint64_t slots = T.mask + 1;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (T.keys[i] != ~0ull) {
-            const uint32_t c = T.counts[i];
+        const KmerSlot sl = T.slots[i];
+        if (sl.key != ~0ull) {
+            const uint32_t c = sl.count_m1 + 1u;
             if (c < dense_n) atomicAdd(&dense[c], 1ull);
             else {
                 const unsigned long long s = atomicAdd(n_big, 1ull);

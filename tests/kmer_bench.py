@@ -17,7 +17,8 @@ from faqcs_amd.options import parse_args  # noqa: E402
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 250
 opt = parse_args(["-u", "x", "-d", "y", "--ascii", "33", "--kmer_rarefaction", "--split_size", "1000000", "--subset", "100000"])
-eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << 30)
+slots = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << slots)
 lib = eng.lib
 dev = torch.device("cuda:0")
 seq = torch.empty(n * L + 64, dtype=torch.uint8, device=dev)
