@@ -499,7 +499,13 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         const int S3 = (int)(K3 >> PB) - KEY_BIAS;
                         fp3 = (S3 > 0) ? (int)(K3 & PMX) - 1 : n - 1;
                         hi_sum = (S3 > 0) ? T - S3 : T;                       // sum of (Q-q) over window positions <= fp3
-                        if (!o_protect5) {
+                        // 5' pass.  Its cut is the argmax of the prefix sums over the visited positions and only counts when that
+                        // maximum is positive (trim.cpp:760-790): with no positive prefix sum anywhere in any of the wave's
+                        // reads -- the usual case, a read that starts at Q >= -q -- the whole pass is skipped.
+                        int pmax = Pin[0];
+#pragma unroll
+                        for (int j = 1; j < C; ++j) pmax = pmax > Pin[j] ? pmax : Pin[j];
+                        if (!o_protect5 && __any(pmax > 0)) {
                             uint32_t np = 0;
 #pragma unroll
                             for (int j = C - 1; j >= 0; --j) np = __builtin_amdgcn_alignbit(np, (uint32_t)(j ? Pin[j - 1] : E), 31);
