@@ -440,8 +440,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     // without window masks the zero bytes past the read contributed (Q - 0) each
                     if (!WINDOWED) T -= Q * (LPR * C - len);
                 }
-#pragma unroll
-                for (int j = 0; j < C; ++j) Pin[j] += E;
+                // Pin[] stays LANE-LOCAL (prefix inside the lane); E is folded into whoever needs the row-wide prefix
+                const int TE = T - E;
                 // whole-read sums: base counts (A,T | C,G as 16-bit pairs), N count and V = sum(raw - offset)
                 uint32_t pAT, pCG, pN;
                 int V_pre;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         uint32_t nn = 0;
 #pragma unroll
                         for (int j = C - 1; j >= 0; --j) {
-                            Dv[j] = T - Pin[j];
+                            Dv[j] = TE - Pin[j];
                             nn = __builtin_amdgcn_alignbit(nn, (uint32_t)Dv[j], 31); // (nn << 1) | (D < 0)
                         }
                         nn = ~nn;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         uint32_t kl = 0, kx[C];
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t k = ((uint32_t)(j ? Dv[j - 1] : T - E) << 4) + (uint32_t)((KEY_BIAS << 4) | j);
+                            const uint32_t k = ((uint32_t)(j ? Dv[j - 1] : TE) << 4) + (uint32_t)((KEY_BIAS << 4) | j);
                             kx[j] = k & (uint32_t)bit_m1(vis, j);
                         }
 #pragma unroll
@@ -505,7 +505,9 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         int pmax = Pin[0];
 #pragma unroll
                         for (int j = 1; j < C; ++j) pmax = pmax > Pin[j] ? pmax : Pin[j];
-                        if (!o_protect5 && __any(pmax > 0)) {
+                        if (!o_protect5 && __any(pmax + E > 0)) {
+#pragma unroll
+                            for (int j = 0; j < C; ++j) Pin[j] += E; // (rare path: row-wide prefixes from here on)
                             uint32_t np = 0;
 #pragma unroll
                             for (int j = C - 1; j >= 0; --j) np = __builtin_amdgcn_alignbit(np, (uint32_t)(j ? Pin[j - 1] : E), 31);
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     } else if (o_mode == FAQCS_MODE_BWA) { // trim.cpp:675-709
                         uint32_t neg = 0;
 #pragma unroll
-                        for (int j = C - 1; j >= 0; --j) neg = (neg << 1) | (uint32_t)(Pin[j] > T);
+                        for (int j = C - 1; j >= 0; --j) neg = (neg << 1) | (uint32_t)(Pin[j] > TE);
                         neg &= range_mask<C>(a, a + n, pbase);
                         const int pf = (int)RW::all_umax(neg ? (uint32_t)(pbase + (31 - __builtin_clz(neg)) + 1) : 0u) - 1; // -1: none
                         const int lo = (pf < a ? a : pf) + 1;
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         uint32_t key = 0;
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t k = ((uint32_t)(T - (j ? Pin[j - 1] : E) + KEY_BIAS) << PB) + (uint32_t)(pa + j);
+                            const uint32_t k = ((uint32_t)(TE - (j ? Pin[j - 1] : 0) + KEY_BIAS) << PB) + (uint32_t)(pa + j);
                             key = umax_(key, k & (uint32_t)bit_m1(vis, j));
                         }
                         const uint32_t K3 = RW::all_umax(key);
