@@ -126,6 +126,44 @@ template <> struct RowOps<16> {
     static __device__ __forceinline__ uint32_t next(uint32_t v) { return row_next(v); }
     static __device__ __forceinline__ uint32_t prev(uint32_t v) { return row_prev(v); }
 };
+// 8 lanes per read (8 reads per wave, reads <= 160 bases): the row-uniform scalar work is shared by twice as many reads.
+// Reductions are three butterfly steps (xor 1, xor 2, mirror inside the half row); scans and neighbour shifts mask the
+// lanes whose source would sit in the other read of the 16-lane DPP row.
+template <> struct RowOps<8> {
+#define FAQCS_HALF_ALL(OP)                                                             \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));                \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));                \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+    static __device__ __forceinline__ int all_sum(int v) { FAQCS_HALF_ALL(op_add_) return v; }
+    static __device__ __forceinline__ uint32_t all_or(uint32_t x) { int v = (int)x; FAQCS_HALF_ALL(op_or_) return (uint32_t)v; }
+    static __device__ __forceinline__ uint32_t all_umax(uint32_t x) { int v = (int)x; FAQCS_HALF_ALL(op_umax_) return (uint32_t)v; }
+#undef FAQCS_HALF_ALL
+    // -1 when the lane's position inside its 8-lane group is >= k
+    static __device__ __forceinline__ int ge_(int k) { return ((int)(threadIdx.x & 7u) >= k) ? -1 : 0; }
+    static __device__ __forceinline__ int incl_scan_add(int v)
+    {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false) & ge_(1);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false) & ge_(2);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xa, false); // row_shr:4 into banks 1 and 3 only (lanes 4-7, 12-15)
+        return v;
+    }
+    static __device__ __forceinline__ uint32_t incl_scan_umax(uint32_t x)
+    {
+        int v = (int)x;
+        v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false) & ge_(1));
+        v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false) & ge_(2));
+        v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false) & ge_(4));
+        return (uint32_t)v;
+    }
+    static __device__ __forceinline__ uint32_t next(uint32_t v)
+    {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, false) & (((threadIdx.x & 7u) == 7u) ? 0u : 0xffffffffu);
+    }
+    static __device__ __forceinline__ uint32_t prev(uint32_t v)
+    {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false) & (uint32_t)ge_(1);
+    }
+};
 template <> struct RowOps<64> {
     static __device__ __forceinline__ int all_sum(int v) { return wave_sum_i32(v); }
     static __device__ __forceinline__ uint32_t all_umax(uint32_t v) { return wave_max_u32(v); }

@@ -32,6 +32,8 @@
 // (DevParams); the only float op left is the composition-bin multiply, an exact IEEE v_mul_f32.
 #include "faqcs_dev.h"
 
+#include <stdlib.h>
+
 namespace {
 
 template <int C, int LPR> struct RowCfg {
@@ -44,8 +46,8 @@ template <int C, int LPR> struct RowCfg {
     static constexpr int HQ8_EVERY = 16;
     static constexpr int HQ = HQ8 ? FAQCS_NQ * W / 2 : FAQCS_NQ * W;
     // |sum of (Q - q)| <= W * 168: key bias and the bit width of a position field inside the argmax keys
-    static constexpr int KEY_BIAS = LPR == 16 ? (1 << 16) : (1 << 18);
-    static constexpr int PB = LPR == 16 ? 9 : 11;
+    static constexpr int KEY_BIAS = LPR <= 16 ? (1 << 16) : (1 << 18);
+    static constexpr int PB = LPR <= 16 ? 9 : 11;
     static constexpr int FK = 2 * W;               // "first position" keys are FK - p (0 == none)
     static constexpr int HB = FAQCS_NBASE * W;
     static constexpr int O_HQ = 0;
@@ -60,8 +62,10 @@ template <int C, int LPR> struct RowCfg {
     static constexpr int O_TLC = O_TBASE + 256;    // [W+1]
     static constexpr int O_TAVGQ = O_TLC + W + 1;  // [W+1]
     static constexpr int O_TMAGIC = O_TAVGQ + W + 1;
-    static constexpr int O_TBM = (O_TMAGIC + W + 1 + 3) & ~3; // [C+1][4] byte masks "first vb bytes of the lane's dwords"
-    static constexpr int LDS_DWORDS = O_TBM + 4 * (C + 1);
+    static constexpr int BMW = D <= 4 ? 4 : 8;     // dwords per byte-mask row (one or two ds_read_b128)
+    static constexpr int O_TBM = (O_TMAGIC + W + 1 + 3) & ~3; // [C+1][BMW] byte masks "first vb bytes of the lane's dwords"
+    static constexpr int LDS_DWORDS = O_TBM + BMW * (C + 1);
+    static constexpr int JB = C > 16 ? 5 : 4;      // bits of a position index inside the lane-local argmax keys
 };
 
 template <int D> struct __attribute__((packed, aligned(1))) PackedBytes { uint32_t w[D]; };
@@ -226,7 +230,7 @@ __device__ __noinline__ void flush_hq8(uint32_t *smem, uint64_t *counters, const
 // GENERIC: false = the headline option set (BWA_plus, 5' trimming on, not --qc_only, no --replace_to_N_q, no
 // --avg_q, -n 2) is compiled in, so those tests and their live scalars disappear from the loop.
 template <int C, int LPR, int NW, bool WINDOWED, bool GENERIC>
-__global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accumulate(
+__global__ __launch_bounds__(NW * 64, LPR == 8 ? 2 : FAQCS_TRIM_MINWAVES) void trim_filter_accumulate(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
@@ -236,6 +240,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
     using RW = RowOps<LPR>;
     constexpr int D = Cfg::D, W = Cfg::W, KEY_BIAS = Cfg::KEY_BIAS, PB = Cfg::PB, FK = Cfg::FK;
     constexpr uint32_t PMX = (1u << PB) - 1u;
+    constexpr int JB = Cfg::JB;
+    constexpr uint32_t JM = (1u << JB) - 1u;
     static_assert(!Cfg::HQ8 || NW * Cfg::HQ8_EVERY <= 255, "an 8-bit cell must not overflow between two flushes");
     constexpr uint32_t CMASK = (1u << C) - 1u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -259,8 +265,8 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
         smem[Cfg::O_TAVGQ + i] = (uint32_t)P.avgq_min_v[i];
         smem[Cfg::O_TMAGIC + i] = P.div_magic[i];
     }
-    for (int i = tid; i < 4 * (C + 1); i += NW * 64) {
-        const int nb = med3i((i >> 2) - 4 * (i & 3), 0, 4);
+    for (int i = tid; i < Cfg::BMW * (C + 1); i += NW * 64) {
+        const int nb = med3i((i / Cfg::BMW) - 4 * (i % Cfg::BMW), 0, 4);
         smem[Cfg::O_TBM + i] = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
     }
     uint32_t two = 2u;
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
     const uint32_t n_iter = (total_chunks + chunks_per_iter - 1) / chunks_per_iter;
     constexpr uint32_t FLUSH_EVERY = 65535u / (NW * 64) > 0 ? 65535u / (NW * 64) : 1;
     // 6-bit fields: 3 chunks x 16 reads per row = 48 <= 63; a 64-lane row sees 64 reads per chunk and spills mid-chunk too
-    constexpr uint32_t REG_FLUSH_EVERY = LPR == 16 ? 3 : 1;
+    constexpr uint32_t REG_FLUSH_EVERY = LPR == 16 ? 3 : (LPR == 8 ? 7 : 1);
 
     const int in_off = P.in_off, Q = P.Q;
     const int o_mode = GENERIC ? P.mode : (int)FAQCS_MODE_BWA_PLUS;
@@ -357,8 +363,12 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                 // zero the bytes past the end of the read (the last dword of a lane may over-read 1..3 bytes)
                 {
                     const int vb = med3i(len - pbase, 0, C);
-                    const uint4 bm = *reinterpret_cast<const uint4 *>(t_bm + 4 * vb); // one ds_read_b128
-                    const uint32_t m[4] = {bm.x, bm.y, bm.z, bm.w};
+                    const uint4 bm = *reinterpret_cast<const uint4 *>(t_bm + Cfg::BMW * vb); // one ds_read_b128
+                    uint32_t m[8] = {bm.x, bm.y, bm.z, bm.w, 0u, 0u, 0u, 0u};
+                    if (D > 4) {
+                        const uint4 bm2 = *reinterpret_cast<const uint4 *>(t_bm + Cfg::BMW * vb + 4);
+                        m[4] = bm2.x; m[5] = bm2.y; m[6] = bm2.z; m[7] = bm2.w;
+                    }
 #pragma unroll
                     for (int k = 0; k < D; ++k) { ws[k] &= m[k]; wq[k] &= m[k]; }
                 }
@@ -489,13 +499,13 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                         uint32_t kl = 0, kx[C];
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
-                            const uint32_t k = ((uint32_t)(j ? Dv[j - 1] : TE) << 4) + (uint32_t)((KEY_BIAS << 4) | j);
+                            const uint32_t k = ((uint32_t)(j ? Dv[j - 1] : TE) << JB) + (uint32_t)((KEY_BIAS << JB) | j);
                             kx[j] = k & (uint32_t)bit_m1(vis, j);
                         }
 #pragma unroll
                         for (int j = 0; j + 1 < C; j += 2) kl = umax3_(kl, kx[j], kx[j + 1]);
                         if (C & 1) kl = umax_(kl, kx[C - 1]);
-                        const uint32_t K3 = RW::all_umax(kl ? (((kl >> 4) << PB) + (uint32_t)(pa + (int)(kl & 15u))) : 0u);
+                        const uint32_t K3 = RW::all_umax(kl ? (((kl >> JB) << PB) + (uint32_t)(pa + (int)(kl & JM))) : 0u);
                         const int S3 = (int)(K3 >> PB) - KEY_BIAS;
                         fp3 = (S3 > 0) ? (int)(K3 & PMX) - 1 : n - 1;
                         hi_sum = (S3 > 0) ? T - S3 : T;                       // sum of (Q-q) over window positions <= fp3
@@ -523,13 +533,13 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                             uint32_t kl5 = 0, ky[C];
 #pragma unroll
                             for (int j = 0; j < C; ++j) {
-                                const uint32_t k = ((uint32_t)Pin[j] << 4) + (uint32_t)((KEY_BIAS << 4) | (15 - j));
+                                const uint32_t k = ((uint32_t)Pin[j] << JB) + (uint32_t)((KEY_BIAS << JB) | ((int)JM - j));
                                 ky[j] = k & (uint32_t)bit_m1(vis5, j);
                             }
 #pragma unroll
                             for (int j = 0; j + 1 < C; j += 2) kl5 = umax3_(kl5, ky[j], ky[j + 1]);
                             if (C & 1) kl5 = umax_(kl5, ky[C - 1]);
-                            const uint32_t K5 = RW::all_umax(kl5 ? (((kl5 >> 4) << PB) + (uint32_t)((int)PMX - (pa + 15 - (int)(kl5 & 15u)))) : 0u);
+                            const uint32_t K5 = RW::all_umax(kl5 ? (((kl5 >> JB) << PB) + (uint32_t)((int)PMX - (pa + (int)JM - (int)(kl5 & JM)))) : 0u);
                             const int S5 = (int)(K5 >> PB) - KEY_BIAS;
                             fp5 = (S5 > 0) ? (int)PMX - (int)(K5 & PMX) + 1 : 0;
                             lo_sum = (S5 > 0) ? S5 : 0;                       // sum of (Q-q) over window positions < fp5
@@ -701,20 +711,19 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     }
                     const uint32_t inr = (act && !read_err) ? range_mask<C>(0, len, pbase) : 0u;
                     const uint32_t postm = ret ? (win2 & inr) : 0u;
-                    const uint32_t both = inr | (postm << 16);
                     if (Cfg::HQ8) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = q[j];
-                            const uint32_t x = (both >> j) & 0x10001u;          // pre -> byte 0, post -> byte 1 of the cell
-                            atomicAdd(&hq[qq * (W / 2) + ((pbase + j) >> 1)], ((x | (x >> 8)) & 0x101u) << (16 * ((pbase + j) & 1)));
+                            const uint32_t x = ((inr >> j) & 1u) | ((uint32_t)bit_m1(postm, j) & 0x100u); // pre -> byte 0, post -> byte 1
+                            atomicAdd(&hq[qq * (W / 2) + ((pbase + j) >> 1)], x << (16 * ((pbase + j) & 1)));
                         }
                     }
                     if (o_replace_q > 0) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = q[j];
-                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
+                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], ((inr >> j) & 1u) | ((uint32_t)bit_m1(postm, j) & 0x10000u));
                             bpre[j] += incf[j];
                             const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
                             bpost[j] += w & (uint32_t)bit_m1(postm, j);
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = q[j];
-                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], (both >> j) & 0x10001u);
+                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], ((inr >> j) & 1u) | ((uint32_t)bit_m1(postm, j) & 0x10000u));
                             bpre[j] += incf[j];
                             bpost[j] += incf[j] & (uint32_t)bit_m1(postm, j);
                         }
@@ -765,7 +774,7 @@ __global__ __launch_bounds__(NW * 64, FAQCS_TRIM_MINWAVES) void trim_filter_accu
                     const bool pre_on = !e_err, post_on = e_ret && !e_err;
                     const unsigned long long pA = st_pAT & 0xffffu, pT = st_pAT >> 16, pC = st_pCG & 0xffffu, pG = st_pCG >> 16, pn = st_N & 0xffffu;
                     const unsigned long long cA = st_cAT & 0xffffu, cT = st_cAT >> 16, cC = st_cCG & 0xffffu, cG = st_cCG >> 16, cn = st_N >> 16;
-                    if (LPR == 16) {
+                    if (LPR <= 16) {
                         rec_pre[my] = pre_on ? (CR_VALID | e_len | (pA << 9) | (pT << 18) | (pC << 27) | (pG << 36) | (pn << 45)) : 0ull;
                         rec_post[my] = post_on ? (CR_VALID | e_n | (cA << 9) | (cT << 18) | (cC << 27) | (cG << 36) | (cn << 45)) : 0ull;
                     } else { // reads past 511 bases do not fit 9-bit fields: 11-bit fields over two words
@@ -890,7 +899,8 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
     }
     const uint32_t chunks = (n_reads + 63) / 64;
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    const int by_waves = (4 * (FAQCS_TRIM_MINWAVES > 2 ? FAQCS_TRIM_MINWAVES : 2) + NW - 1) / NW; // resident waves per CU the registers allow
+    constexpr int minwaves = LPR == 8 ? 2 : (FAQCS_TRIM_MINWAVES > 2 ? FAQCS_TRIM_MINWAVES : 2);
+    const int by_waves = (4 * minwaves + NW - 1) / NW; // resident waves per CU the registers allow
     if (blocks_per_cu > by_waves) blocks_per_cu = by_waves;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint32_t grid = (chunks + NW - 1) / NW;
@@ -914,6 +924,12 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
 #define FAQCS_TRIM_CASE(C, NW)                                                                              \
     return windowed ? (generic ? launch_trim_t<C, 16, NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 16, NW, true, false>(FAQCS_TRIM_ARGS)) \
                     : (generic ? launch_trim_t<C, 16, NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 16, NW, false, false>(FAQCS_TRIM_ARGS))
+    {   // 8 lanes per read: the headline shape (reads <= 160 bases, default option set); FAQCS_TRIM_LPR8=0 switches it off
+        static const bool lpr8 = [] { const char *e = getenv("FAQCS_TRIM_LPR8"); return !e || atoi(e) != 0; }();
+        if (lpr8 && max_len > 112 && max_len <= 160)
+            return windowed ? (generic ? launch_trim_t<20, 8, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<20, 8, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS))
+                            : (generic ? launch_trim_t<20, 8, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<20, 8, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS));
+    }
     if (max_len <= 64) FAQCS_TRIM_CASE(4, FAQCS_TRIM_NW);
     if (max_len <= 112) FAQCS_TRIM_CASE(7, FAQCS_TRIM_NW);
     if (max_len <= 160) FAQCS_TRIM_CASE(10, FAQCS_TRIM_NW);
