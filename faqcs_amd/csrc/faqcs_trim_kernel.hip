@@ -926,9 +926,13 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
                     : (generic ? launch_trim_t<C, 16, NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 16, NW, false, false>(FAQCS_TRIM_ARGS))
     {   // 8 lanes per read: the headline shape (reads <= 160 bases, default option set); FAQCS_TRIM_LPR8=0 switches it off
         static const bool lpr8 = [] { const char *e = getenv("FAQCS_TRIM_LPR8"); return !e || atoi(e) != 0; }();
-        if (lpr8 && max_len > 112 && max_len <= 160)
-            return windowed ? (generic ? launch_trim_t<20, 8, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<20, 8, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS))
-                            : (generic ? launch_trim_t<20, 8, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<20, 8, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS));
+#define FAQCS_TRIM_CASE8(C)                                                                                 \
+    return windowed ? (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS)) \
+                    : (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS))
+        if (lpr8 && max_len <= 64) FAQCS_TRIM_CASE8(8);
+        if (lpr8 && max_len <= 112) FAQCS_TRIM_CASE8(14);
+        if (lpr8 && max_len <= 160) FAQCS_TRIM_CASE8(20);
+#undef FAQCS_TRIM_CASE8
     }
     if (max_len <= 64) FAQCS_TRIM_CASE(4, FAQCS_TRIM_NW);
     if (max_len <= 112) FAQCS_TRIM_CASE(7, FAQCS_TRIM_NW);
