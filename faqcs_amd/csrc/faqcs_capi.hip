@@ -121,7 +121,12 @@ struct faqcs_ctx {
     DevBuf<uint32_t> s_seg, s_sl;
     DevBuf<uint16_t> s_hit;
     DevBuf<faqcs_read_result> s_res;
-    DevBuf<unsigned long long> s_rec_pre, s_rec_post; // per-read composition records (trim kernel -> composition_histogram)
+    // per-read composition records (trim kernel -> composition_histogram).  Two sets: the histogram kernels of
+    // submission k run on the aux stream next to the trim kernel of submission k+1 (LDS-bound next to VALU-bound).
+    struct RecSet { DevBuf<unsigned long long> pre, post; hipEvent_t trimmed = nullptr, folded = nullptr; bool used = false; };
+    RecSet rec[2];
+    uint64_t n_enqueued = 0;
+    hipStream_t aux = nullptr;
     // rarefaction state (trim.cpp:157-185): host-deterministic from read counts, values filled from the device
     uint64_t total_number = 0;
     int kmer_active = 0;
@@ -308,6 +313,8 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    for (auto &rs : c->rec) { HIPCHK(hipEventCreateWithFlags(&rs.trimmed, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&rs.folded, hipEventDisableTiming)); }
     HIPCHK(hipEventCreateWithFlags(&c->copied, hipEventDisableTiming));
     for (auto &sl : c->slot) HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     for (auto &e : c->ticket_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -386,6 +393,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->compute) (void)hipStreamSynchronize(c->compute);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
     for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
                     c->kt.slots, c->kt.stats, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
@@ -393,7 +401,9 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     for (auto &sl : c->slot) { sl.seq.release(); sl.qual.release(); sl.off.release(); if (sl.done) (void)hipEventDestroy(sl.done); }
     for (auto &e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
     c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
-    c->s_rec_pre.release(); c->s_rec_post.release(); c->ob_items.release();
+    for (auto &rs : c->rec) { rs.pre.release(); rs.post.release(); if (rs.trimmed) (void)hipEventDestroy(rs.trimmed); if (rs.folded) (void)hipEventDestroy(rs.folded); }
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    c->ob_items.release();
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -433,13 +443,21 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         Timing &t = c->timings[c->timing_used++];
         HIPCHK(hipEventRecord(t.a, c->compute));
         const bool wide = max_len > 256; // the long-read kernels write two-word composition records
-        HIPCHK(c->s_rec_pre.reserve((size_t)n * (wide ? 2 : 1))); HIPCHK(c->s_rec_post.reserve((size_t)n * (wide ? 2 : 1)));
-        HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, c->s_rec_pre.p, c->s_rec_post.p,
+        faqcs_ctx::RecSet &rs = c->rec[c->n_enqueued++ & 1];
+        if (rs.used) HIPCHK(hipStreamWaitEvent(c->compute, rs.folded, 0)); // the set's previous records have been folded
+        const size_t need = (size_t)n * (wide ? 2 : 1);
+        if (need > rs.pre.cap) HIPCHK(hipStreamSynchronize(c->aux));
+        HIPCHK(rs.pre.reserve(need)); HIPCHK(rs.post.reserve(need));
+        HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, rs.pre.p, rs.post.p,
                                  c->d_counters, c->d_err, c->n_cu, c->compute));
         HIPCHK(hipEventRecord(t.b, c->compute));
         if (!(c->dp.dbg & 1u)) {
-            HIPCHK(faqcs_launch_composition(c->s_rec_pre.p, n, wide, c->d_norm, c->d_counters + c->lay.pre_comp, c->n_cu, c->compute));
-            HIPCHK(faqcs_launch_composition(c->s_rec_post.p, n, wide, c->d_norm, c->d_counters + c->lay.post_comp, c->n_cu, c->compute));
+            HIPCHK(hipEventRecord(rs.trimmed, c->compute));
+            HIPCHK(hipStreamWaitEvent(c->aux, rs.trimmed, 0));
+            HIPCHK(faqcs_launch_composition(rs.pre.p, n, wide, c->d_norm, c->d_counters + c->lay.pre_comp, c->n_cu, c->aux));
+            HIPCHK(faqcs_launch_composition(rs.post.p, n, wide, c->d_norm, c->d_counters + c->lay.post_comp, c->n_cu, c->aux));
+            HIPCHK(hipEventRecord(rs.folded, c->aux));
+            rs.used = true;
         }
     }
     // ---- owner-partitioned k-mer mode: bucket this shard's (key, epoch) pairs by owner rank; the caller exchanges them
@@ -622,6 +640,7 @@ extern "C" int faqcs_sync(faqcs_ctx *c)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->copy));
     HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipStreamSynchronize(c->aux));
     for (size_t i = 0; i < c->timing_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->timings[i].a, c->timings[i].b) == hipSuccess) { c->kernel_ms += ms; ++c->kernel_launches; }
@@ -660,6 +679,7 @@ extern "C" int faqcs_reset_counters(faqcs_ctx *c)
 {
     if (!c) return fail(FAQCS_E_INVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->aux));
     HIPCHK(hipMemsetAsync(c->d_counters, 0, c->lay.total * sizeof(uint64_t), c->compute));
     return 0;
 }
