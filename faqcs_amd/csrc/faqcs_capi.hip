@@ -651,6 +651,7 @@ extern "C" int faqcs_sync(faqcs_ctx *c)
     HIPCHK(hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
     if (e & 1u) return fail(FAQCS_E_QUALITY, "fastq.h:quality_score: Found a quality score value that is greater than the maximum allowed quality score");
     if (e & 2u) return fail(FAQCS_E_BASE, "seq_overlap.cpp:na_to_bits: Unknown base!");
+    if (e & 4u) return fail(FAQCS_E_INVAL, "faqcs: internal error, the trim kernel's LDS block does not start at address 0");
     if (c->kt.stats) {
         unsigned long long st[3];
         HIPCHK(hipMemcpy(st, c->kt.stats, 24, hipMemcpyDeviceToHost));

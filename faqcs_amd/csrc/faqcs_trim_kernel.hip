@@ -94,15 +94,18 @@ template <int K> __device__ __forceinline__ uint32_t byte_times4(uint32_t w, uin
     else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
     return r;
 }
+// t_base_lds = LDS byte address of the table (the kernel's dynamic LDS starts at address 0, checked at kernel start): the
+// lookup is then ds_read_b32 v, <4 * byte> offset:<table> with no address add at all.
+typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
 template <int C, int J> struct BaseLookup {
-    static __device__ __forceinline__ void run(const uint32_t *t_base, const uint32_t *ws, uint32_t two, uint32_t *inc)
+    static __device__ __forceinline__ void run(const uint32_t t_base_lds, const uint32_t *ws, uint32_t two, uint32_t *inc)
     {
-        inc[J] = *(const uint32_t *)((const char *)t_base + byte_times4<J & 3>(ws[J >> 2], two));
-        BaseLookup<C, J + 1>::run(t_base, ws, two, inc);
+        inc[J] = *(lds_u32_ptr)(size_t)(byte_times4<J & 3>(ws[J >> 2], two) + t_base_lds);
+        BaseLookup<C, J + 1>::run(t_base_lds, ws, two, inc);
     }
 };
 template <int C> struct BaseLookup<C, C> {
-    static __device__ __forceinline__ void run(const uint32_t *, const uint32_t *, uint32_t, uint32_t *) {}
+    static __device__ __forceinline__ void run(const uint32_t, const uint32_t *, uint32_t, uint32_t *) {}
 };
 __device__ __forceinline__ uint32_t umax3_(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -271,6 +274,8 @@ __global__ __launch_bounds__(NW * 64, LPR == 8 ? 2 : FAQCS_TRIM_MINWAVES) void t
     }
     uint32_t two = 2u;
     asm volatile("" : "+v"(two)); // a VGPR operand for the SDWA shifts
+    // the base-table lookups address LDS by offset: the kernel's only LDS object must start at LDS address 0
+    if (tid == 0 && blockIdx.x == 0 && (uint32_t)(size_t)((lds_u32_ptr)smem) != 0u) atomicOr(err, 4u);
     __syncthreads();
 
     const uint32_t total_chunks = (n_reads + 63) >> 6;
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(NW * 64, LPR == 8 ? 2 : FAQCS_TRIM_MINWAVES) void t
 #pragma unroll 1
                 for (int attempt = 0; attempt < 2; ++attempt) {
                     uint32_t inc[C];
-                    BaseLookup<C, 0>::run(t_base, ws, two, inc);
+                    BaseLookup<C, 0>::run((uint32_t)(Cfg::O_TBASE * 4), ws, two, inc);
                     run = 0; sumv = 0; cntpack = 0; nubits = 0; gubits = 0; maxq = 0;
 #pragma unroll
                     for (int j = C - 1; j >= 0; --j) nubits = __builtin_amdgcn_alignbit(nubits, inc[j], 31); // bit j = BT_IS_NU of j
