@@ -3,13 +3,17 @@
 // Replaces trim_read() and its helpers (trim.cpp:225-551, :553-597, :629-885, :1191-1216) for every read
 // of a batch.
 //
-// Mapping.  A wavefront is FOUR DPP rows of 16 lanes; each row owns one read at a time (4 reads per wave in
-// flight) and lane l of a row owns the C consecutive positions [l*C, l*C+C), C = ceil(max_len/16) (10 for
-// 150 bp, 16 for 250 bp), fetched with ONE unaligned global_load_dwordx{D} per arena.  Every per-read
-// scalar (length, window, cut points, filter decision) is a row-uniform VGPR value: there are no ballots
-// and no scalar-ALU bit logic in the loop (round-1 profiling showed the ballot formulation was SALU-bound
-// at ~900 scalar instructions per read).  Cross-lane work is DPP only: row_shr prefix scans and
-// quad_perm/row_mirror butterflies, 4 instructions each and shared by the 4 reads of the wave.
+// Mapping.  LPR lanes share one read and lane l of the group owns the C consecutive positions [l*C, l*C+C), fetched
+// with ONE unaligned global_load_dwordx{D} per arena; a wave takes chunks of 64 reads.
+//   LPR =  8  reads <= 160 bases (C = 8 / 14 / 20): eight reads per wave, two per 16-lane DPP row
+//   LPR = 16  reads <= 256 bases (C = 4 ... 16):    four reads per wave, one per DPP row
+//   LPR = 64  reads <= 1024 bases (C = 5 / 8 / 16): the whole wave on one read
+// Every per-read scalar (length, window, cut points, filter decision) is a group-uniform VGPR value: there are no
+// ballots and no scalar-ALU bit logic in the loop (round-1 profiling showed the ballot formulation was SALU-bound at
+// ~900 scalar instructions per read).  Cross-lane work is DPP only (RowOps<LPR> in faqcs_dev.h): prefix scans and
+// butterflies of 3-4 instructions, shared by all reads of the wave.  What depends on a read's scalars alone (FilterStat,
+// small histograms, composition records, the result word) is parked in the read's owner lane and done once per
+// chunk, 64 reads wide.
 //
 // BWA_plus (trim.cpp:714-793) in closed form from ONE prefix sum P of (Q - q[i]) over the window
 // (SURVEY.md section 8 a-5):
@@ -22,7 +26,7 @@
 // the high 16 bits so a base costs ONE ds_add for both (the post-trim quality of a kept base equals its
 // pre-trim quality, trim.cpp:516-533).  position x base: a lane always owns the same positions, so the
 // matrix is privatised in REGISTERS (6-bit fields A,T,C,G,N per position, one v_add per base) and spilled
-// to LDS every 48 reads.  Length / average-quality histograms are small dense LDS arrays.  Composition
+// to LDS every <= 56 reads.  Length / average-quality histograms are small dense LDS arrays.  Composition
 // bins (10 001 x 6, sparse and data dependent) are NOT accumulated here: the kernel emits one 8-byte record
 // per read (length + 5 base counts, pre and post) and composition_histogram folds the records with the
 // whole LDS as a 16-bit table.  A block flushes LDS to the global u64 block with atomics before a 16-bit
