@@ -129,6 +129,8 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
     int short_tlen_max = 0; // longest adapter the register-blocked prefilter handles (<= 128 bases)
     for (uint32_t i = 0; i < A.n_adapters; ++i) { const int tl = (int)s_meta[i].x; if (tl <= 128 && tl > short_tlen_max) short_tlen_max = tl; }
     short_tlen_max = uni(short_tlen_max);
+    bool has_long = false; // some adapter takes the sliding long-target prefilter
+    for (uint32_t i = 0; i < A.n_adapters; ++i) has_long = has_long || (int)s_meta[i].x > 128;
 
     // A wave takes chunks of 64 consecutive reads: offsets load and results store as one coalesced vector per chunk,
     // per-read scalars come out of the lanes with v_readlane, and the bases of read t+1 are fetched while read t is
@@ -281,6 +283,35 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
                     const int need = 2 * thr - mcap;                          // (mcap + bound) / 2 >= thr  <=>  bound >= need
                     any_match = __any(maxcnt > 0u);
                     may_pass = __any((int)maxcnt >= need);
+                } else if (!(dbg & 8u) && MAXLEN == 256 && NBR == 6 && tpl_cached) {
+                    // long target (PhiX, artifact sequences): the same register windows, sliding over the target two words
+                    // per step.  Words 2u and 2u+1 face exactly the seven blocks u-1 .. u+5 (window index 12-2i / 13-2i for
+                    // block u-1+i); block u-1 has seen all of its words after step u and leaves the 7-deep accumulator.
+                    const uint32_t *tpl = s_tpl + 4 * uniu(meta.y);
+                    const int nw = (tlen + 31) >> 5;
+                    const int nb = (qlen + tlen - 1 + 63) >> 6;
+                    uint32_t cnt[7], maxcnt = 0;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) cnt[i] = 0;
+#pragma unroll 1
+                    for (int u = 0; u <= nb; ++u) {
+                        uint4 t0 = make_uint4(0u, 0u, 0u, 0u), t1 = make_uint4(0u, 0u, 0u, 0u);
+                        if (2 * u < nw) t0 = *reinterpret_cast<const uint4 *>(tpl + 8 * u);
+                        if (2 * u + 1 < nw) t1 = *reinterpret_cast<const uint4 *>(tpl + 8 * u + 4);
+#pragma unroll
+                        for (int i = 0; i < 7; ++i) {
+                            const int e0 = 12 - 2 * i, e1 = 13 - 2 * i;
+                            cnt[i] += __popc((R[0][e0] & t0.x) | (R[1][e0] & t0.y) | (R[2][e0] & t0.z) | (R[3][e0] & t0.w));
+                            cnt[i] += __popc((R[0][e1] & t1.x) | (R[1][e1] & t1.y) | (R[2][e1] & t1.z) | (R[3][e1] & t1.w));
+                        }
+                        maxcnt = umax_(maxcnt, cnt[0]);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) cnt[i] = cnt[i + 1];
+                        cnt[6] = 0;
+                    }
+                    const int need = 2 * thr - mcap;
+                    any_match = __any(maxcnt > 0u);
+                    may_pass = __any((int)maxcnt >= need);
                 } else if (!(dbg & 8u)) {
                     const uint32_t w0 = s_wstart[j];
                     const int nw = (int)(s_wstart[j + 1] - w0);
@@ -316,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
             }
         };
         if (!read_bad && qlen > 0) {
-            if (qlen + short_tlen_max - 1 <= 256) stage1(std::integral_constant<int, 4>{});
+            if (!has_long && qlen + short_tlen_max - 1 <= 256) stage1(std::integral_constant<int, 4>{});
             else stage1(std::integral_constant<int, 6>{});
         }
         // ---- stage 2 + the reference's sequential state (stale range, mask, credit), trim.cpp:1003-1071.  With every

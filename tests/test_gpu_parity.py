@@ -117,6 +117,37 @@ def test_long_reads_match_oracle(args, kind, maxlen):
     compare_engines(opt, reads, R=1024, seg_size=117)
 
 
+@pytest.mark.parametrize("args", [["--phiX"], ["--adapter", "--polyA", "--phiX", "--min_L", "20"]], ids=["phix", "adapter+phix"])
+def test_phix_reads_match_oracle(args):
+    """Long targets (2 x 5 386-base PhiX): the sliding-window prefilter and the exact stage on true PhiX reads (both strands,
+    with substitutions, partial overlaps at the genome ends) mixed with random reads."""
+    import make_fixtures
+
+    from faqcs_amd import options
+
+    rng = np.random.Generator(np.random.PCG64([11, len(args)]))
+    opt = parse_args(["-u", "x", "-d", "y"] + args)
+    phix = np.frombuffer(options.phix_sequence().encode(), np.uint8) if hasattr(options, "phix_sequence") else None
+    if phix is None:
+        phix = np.frombuffer([a for a in parse_args(["-u", "x", "-d", "y", "--phiX"]).adapter if "phi" in a[0].lower()][0][1].encode(), np.uint8)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for i in range(600):
+        if i % 3 == 0:
+            s, q = make_fixtures._adv_read(rng, 150)
+        else:
+            L = int(rng.integers(30, 151))
+            p0 = int(rng.integers(-40, len(phix) - L + 40))
+            lo, hi = max(p0, 0), min(p0 + L, len(phix))
+            s = np.concatenate([make_fixtures.ACGT[rng.integers(0, 4, lo - p0)], phix[lo:hi], make_fixtures.ACGT[rng.integers(0, 4, p0 + L - hi)]])
+            if i % 2:
+                s = np.frombuffer(s.tobytes().translate(comp)[::-1], np.uint8)
+            s = make_fixtures._mutate(rng, s, float(rng.choice([0.0, 0.03, 0.15, 0.3])))
+            q = (rng.integers(20, 41, L) + 33).astype(np.uint8)
+        reads.append((b"@p", bytes(s.tobytes()), bytes(q.tobytes())))
+    compare_engines(opt, reads, seg_size=211)
+
+
 def test_long_read_limits():
     """Exactly FAQCS_MAX_READ_LENGTH bases is accepted, one more is refused loudly (no silent truncation)."""
     from faqcs_amd.engine import FaqcsError
