@@ -99,6 +99,7 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
     __shared__ uint8_t s_mask[NW][MAXLEN];     // vector<bool> mask of trim.cpp:991 (1 = unmasked)
     __shared__ uint32_t s_pl[NW][4][PW];       // the read's four base bit-planes, position ordered (stage 1)
     __shared__ __attribute__((aligned(16))) uint32_t s_tpl[TPL_CAP]; // the adapters' bit-planes (4 dwords per 32 bases)
+    __shared__ uint32_t s_bb[NW][136];         // stage 2 on long targets: per 64-diagonal block, an upper bound of its best score
     __shared__ uint8_t s_iupac[32];
     __shared__ uint8_t s_na[256];              // na_to_bits() of every byte value (0 = the reference throws)
     __shared__ uint32_t s_start[FAQCS_MAX_ADAPTERS + 1], s_wstart[FAQCS_MAX_ADAPTERS + 1]; // adapter table of contents
@@ -212,8 +213,62 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
             gM = -1; gI = 0; gS = 0;
             int gJ = 0;
             const int ndiag = qlen + tlen - 1;
+            // Long targets (PhiX): a local alignment scores at most the number of matches on its diagonal, so the largest
+            // per-diagonal match count of a 64-diagonal block bounds every cell of the block.  The block with the largest
+            // bound is aligned first; a block whose bound is below the best score so far cannot win (ties are decided by
+            // the explicit (M, i, j) comparison below, so the visiting order is free).
+            const bool pruned = MAXLEN == 256 && tpl_cached && tlen > 128;
+            uint32_t *bb = s_bb[wave];
+            int first_block = 0;
+            if (pruned) {
+                uint32_t Rw[4][14];
+                {
+                    const int i00 = (qlen - 1) - lane;
+                    const uint32_t sh = (uint32_t)i00 & 31u;
+                    const uint32_t *pp = pl + (i00 >> 5) + PADL - 10;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int e = 0; e < 14; ++e) Rw[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
+                }
+                const uint32_t *tpl = s_tpl + 4 * s_wstart[j];
+                const int nw = (tlen + 31) >> 5, nb = (ndiag + 63) >> 6;
+                uint32_t cnt[7], best = 0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) cnt[i] = 0;
 #pragma unroll 1
-            for (int dd0 = 0; dd0 < ndiag; dd0 += 64) {
+                for (int u = 0; u <= nb; ++u) {
+                    uint4 t0 = make_uint4(0u, 0u, 0u, 0u), t1 = make_uint4(0u, 0u, 0u, 0u);
+                    if (2 * u < nw) t0 = *reinterpret_cast<const uint4 *>(tpl + 8 * u);
+                    if (2 * u + 1 < nw) t1 = *reinterpret_cast<const uint4 *>(tpl + 8 * u + 4);
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        const int e0 = 12 - 2 * i, e1 = 13 - 2 * i;
+                        cnt[i] += __popc((Rw[0][e0] & t0.x) | (Rw[1][e0] & t0.y) | (Rw[2][e0] & t0.z) | (Rw[3][e0] & t0.w));
+                        cnt[i] += __popc((Rw[0][e1] & t1.x) | (Rw[1][e1] & t1.y) | (Rw[2][e1] & t1.z) | (Rw[3][e1] & t1.w));
+                    }
+                    if (u >= 1) { // block u-1 is complete
+                        const uint32_t bnd = wave_max_u32(cnt[0]);
+                        if (lane == 0) bb[u - 1] = bnd;
+                        if (bnd > best) { best = bnd; first_block = u - 1; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) cnt[i] = cnt[i + 1];
+                    cnt[6] = 0;
+                }
+                lds_sync_wave();
+            }
+            const int n_blocks = (ndiag + 63) >> 6;
+#pragma unroll 1
+            for (int k = 0; k < n_blocks + (pruned ? 1 : 0); ++k) {
+                int blk = k;
+                if (pruned) {
+                    if (k == 0) blk = first_block;
+                    else { blk = k - 1; if (blk == first_block) continue; }
+                    const int bnd = (int)bb[blk];
+                    if (bnd < 1 || bnd < gM) continue;
+                }
+                const int dd0 = blk << 6;
                 const int d = dd0 + lane - (qlen - 1);                   // j_t - i on this lane's diagonal
                 const int dlo = dd0 - (qlen - 1), dhi = dlo + 63;
                 const int jt_lo = dlo > 0 ? dlo : 0;
