@@ -213,11 +213,11 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
             gM = -1; gI = 0; gS = 0;
             int gJ = 0;
             const int ndiag = qlen + tlen - 1;
-            // Long targets (PhiX): a local alignment scores at most the number of matches on its diagonal, so the largest
-            // per-diagonal match count of a 64-diagonal block bounds every cell of the block.  The block with the largest
+            // A local alignment scores at most the number of matches on its diagonal, so the largest per-diagonal match
+            // count of a 64-diagonal block bounds every cell of the block (87 blocks for PhiX, 3-4 for the built-in adapters).  The block with the largest
             // bound is aligned first; a block whose bound is below the best score so far cannot win (ties are decided by
             // the explicit (M, i, j) comparison below, so the visiting order is free).
-            const bool pruned = MAXLEN == 256 && tpl_cached && tlen > 128;
+            const bool pruned = MAXLEN == 256 && tpl_cached;
             uint32_t *bb = s_bb[wave];
             int first_block = 0;
             if (pruned) {
