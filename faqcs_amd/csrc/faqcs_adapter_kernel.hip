@@ -441,17 +441,33 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
         uint32_t first = 0, second = (uint32_t)qlen;
         if (best_score > 0) {
             lds_sync_wave();
-            // find_mask_range, trim.cpp:1144-1189, literal
+            // find_mask_range, trim.cpp:1144-1189, literal -- but walked run by run instead of base by base.  The loop's state
+            // only changes where the mask changes: an unmasked run [s, e) adds e - s to run_length (setting run_start when it
+            // was 0), and the masked bases after it all perform the same test, so one test per gap is the whole gap.  The
+            // transitions come from ballots of the mask bytes (a few scalar steps instead of |read| dependent LDS reads).
             uint32_t longest_run_start = 0, longest_run_length = 0, run_start = 0, run_length = 0;
-#pragma unroll 1
-            for (int p = 0; p < qlen; ++p) {
-                if (!mk[p]) {
-                    if (run_length > longest_run_length) { longest_run_length = run_length; longest_run_start = run_start; run_length = 0; }
-                } else {
-                    if (run_length == 0) run_start = (uint32_t)p;
-                    ++run_length;
+            uint32_t pending = 0;      // start of the open unmasked run
+            bool open = false;
+            uint64_t carry = 0;        // mask bit of the previous position (position -1 counts as masked)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c * 64 < qlen) {
+                    const int p = c * 64 + lane;
+                    const uint64_t m = __ballot(p < qlen && mk[p] != 0);
+                    uint64_t t = m ^ ((m << 1) | carry);   // bit b set: the mask changes between position 64c+b-1 and 64c+b
+                    carry = m >> 63;
+                    while (t) {
+                        const uint32_t pos = (uint32_t)(c * 64) + (uint32_t)__builtin_ctzll(t);
+                        t &= t - 1;
+                        if (!open) { if (run_length == 0) run_start = pos; pending = pos; open = true; }
+                        else {
+                            run_length += pos - pending; open = false;
+                            if (run_length > longest_run_length) { longest_run_length = run_length; longest_run_start = run_start; run_length = 0; }
+                        }
+                    }
                 }
             }
+            if (open) run_length += (uint32_t)qlen - pending; // the read ends inside an unmasked run
             if (run_length > longest_run_length) { longest_run_length = run_length; longest_run_start = run_start; }
             first = longest_run_length ? longest_run_start : 0u;
             second = longest_run_length;
