@@ -939,7 +939,9 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
     return windowed ? (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS)) \
                     : (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS))
         if (lpr8 && max_len <= 64) FAQCS_TRIM_CASE8(8);
-        if (lpr8 && max_len <= 112) FAQCS_TRIM_CASE8(14);
+        if (lpr8 && max_len <= 104) FAQCS_TRIM_CASE8(13);   // 2x100
+        if (lpr8 && max_len <= 128) FAQCS_TRIM_CASE8(16);
+        if (lpr8 && max_len <= 152) FAQCS_TRIM_CASE8(19);   // 2x150: 152 position slots instead of 160
         if (lpr8 && max_len <= 160) FAQCS_TRIM_CASE8(20);
 #undef FAQCS_TRIM_CASE8
     }
