@@ -155,6 +155,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
+        _check(lib, lib.faqcs_reset_counters(eng.ctx))  # one step = one job: its counter block starts at zero
         for (_s, _q, _o, res, _seg, bt, _m) in batches:
             _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(bt), res.data_ptr()))
         if world > 1:
@@ -182,6 +183,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     _check(lib, lib.faqcs_kernel_time_ms(eng.ctx, C.byref(avg_ms), C.byref(nl)))
+    # outside the timed region: the (all-reduced) counter block of the last step must account for every read of the job
+    blk = eng.counters()
+    lay = capi.python_layout(eng.holder.max_read_length, eng.holder.n_adapters)
+    fs = blk[lay["filter_stats"][0]:lay["filter_stats"][0] + 32]
+    if int(fs[capi.TOTAL_NUMBER]) != n_reads * world or int(fs[capi.TOTAL_LENGTH]) != n_reads * world * L:
+        raise SystemExit("bench: counter block does not add up: %d reads counted, %d expected" % (int(fs[capi.TOTAL_NUMBER]), n_reads * world))
 
     if rank == 0:
         total_reads = n_reads * world * a.steps
