@@ -476,7 +476,8 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
                 atomicAdd((unsigned long long *)&adapter_stats[2 * best_j + 1], (unsigned long long)((uint32_t)qlen - second));
             }
         }
-        if (lane == t) { res_sl = first | (second << 16); res_hit = (uint32_t)(best_score > 0 ? best_j + 1 : 0); }
+        // 0xffff = the read holds a base na_to_bits() rejects (seq_overlap.cpp:409): the trim kernel turns it into FAQCS_F_ERR_BASE
+        if (lane == t) { res_sl = first | (second << 16); res_hit = read_bad ? 0xffffu : (uint32_t)(best_score > 0 ? best_j + 1 : 0); }
         if (read_bad && lane == 0) atomicOr(err, 2u);
         lds_sync_wave();
       }

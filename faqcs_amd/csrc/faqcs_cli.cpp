@@ -490,6 +490,15 @@ struct Run {
         if (rc == FAQCS_E_BASE) throw Fatal("seq_overlap.cpp:na_to_bits: Unknown base!");
         if (rc) throw Fatal(faqcs_last_error());
     }
+    // the per-read error flags of a finished buffer (the library raises the same errors at faqcs_sync, but only for the
+    // whole run; the reference throws out of the trim() call of THIS buffer, so nothing of it may be written)
+    static void check_read_errors(const RecBuf *b)
+    {
+        for (uint32_t i = 0; i < b->n; ++i) {
+            if (b->res[i].flags & FAQCS_F_ERR_QUALITY) check(FAQCS_E_QUALITY);
+            if (b->res[i].flags & FAQCS_F_ERR_BASE) check(FAQCS_E_BASE);
+        }
+    }
     void ensure_ctx()
     {
         if (ctx) return;
@@ -571,6 +580,7 @@ void process_paired(Run &r)
                 if (!w.b1) break;
                 Run::check(faqcs_wait(r.ctx, w.b1->ticket));
                 Run::check(faqcs_wait(r.ctx, w.b2->ticket));
+                Run::check_read_errors(w.b1); Run::check_read_errors(w.b2); // trim() throws before anything of the buffer is written
                 for (uint32_t i = 0; i < w.b1->n; ++i) {
                     const bool v1 = w.b1->res[i].flags & FAQCS_F_VALID, v2 = w.b2->res[i].flags & FAQCS_F_VALID;
                     if (v1 && v2) { r.paired_read_number += 2; r.paired_base_length += w.b1->res[i].len + w.b2->res[i].len; }
@@ -650,6 +660,7 @@ void process_unpaired(Run &r)
                 Work w = wq.pop();
                 if (!w.b1) break;
                 Run::check(faqcs_wait(r.ctx, w.b1->ticket));
+                Run::check_read_errors(w.b1);
                 if (!opt.qc_only)
                     for (uint32_t i = 0; i < w.b1->n; ++i) {
                         if (w.b1->res[i].flags & FAQCS_F_VALID) r.write_read(fo, w.b1, i, sq, qq);

@@ -779,7 +779,8 @@ __global__ __launch_bounds__(NW * 64, LPR == 8 ? 2 : FAQCS_TRIM_MINWAVES) void t
                     }
                 }
                 if (mine) {
-                    out[my] = make_uint2(e_ret ? st_an : 0u, (st_fl & 0x3ffu) | (v_hit << 16));
+                    const bool bad_base = v_hit == 0xffffu; // set by adapter_overlap
+                    out[my] = make_uint2(e_ret ? st_an : 0u, (st_fl & 0x3ffu) | (bad_base ? (uint32_t)FAQCS_F_ERR_BASE : (v_hit << 16)));
                     const bool pre_on = !e_err, post_on = e_ret && !e_err;
                     const unsigned long long pA = st_pAT & 0xffffu, pT = st_pAT >> 16, pC = st_pCG & 0xffffu, pG = st_pCG >> 16, pn = st_N & 0xffffu;
                     const unsigned long long cA = st_cAT & 0xffffu, cT = st_cAT >> 16, cC = st_cCG & 0xffffu, cG = st_cCG >> 16, cn = st_N >> 16;

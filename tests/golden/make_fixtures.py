@@ -176,6 +176,20 @@ def materialise(name, outdir):
         r1, r2 = headline(3000, 150, adapter_frac=0.05)
     elif name == "head250":
         r1, r2 = headline(1200, 250)
+    elif name == "errq":  # a quality byte above Q41: the reference throws from quality_score() (fastq.h:31-33)
+        r1, r2 = adversarial(200, seed=31)
+        d, sq, q = r1[57]
+        r1[57] = (d, sq, q[:3] + b"~" + q[4:])
+    elif name == "errbase":  # a base the adapter aligner's na_to_bits() rejects (seq_overlap.cpp:372-411)
+        r1, r2 = adversarial(200, seed=37)
+        d, sq, q = r2[91]
+        r2[91] = (d, sq[:5] + b"*" + sq[6:], q)
+    elif name == "errid":  # mate ids disagree at record 20 (FaQCs.cpp:370-389)
+        r1, r2 = adversarial(200, seed=33)
+        r2[20] = (b"@OTHER20/2 extra", r2[20][1], r2[20][2])
+    elif name == "errcount":  # read 2 file is shorter
+        r1, r2 = adversarial(200, seed=35)
+        r2 = r2[:150]
     elif name == "long300":  # MiSeq 2x300: past the 256-base row kernels
         r1, r2 = adversarial(700, seed=21, maxlen=300, id_prefix="M")
     elif name == "long1000":  # ragged 20..1000-base reads (Ion Torrent / 454 lengths)

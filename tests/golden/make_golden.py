@@ -69,6 +69,11 @@ CASES = [
     ("long1000_bwa_avgq", "long1000", P + ["--mode", "BWA", "--avg_q", "20", "-n", "3"]),
     ("long1000_hard_lc", "long1000", P + ["--mode", "HARD", "-q", "12", "--lc", "0.6", "--5end", "7", "--3end", "9"]),
     ("long1000_adapter_polyA", "long1000", P + ["--adapter", "--polyA", "--discard"]),
+    ("err_quality_above_41", "errq", P),
+    ("err_unknown_base_adapter", "errbase", P + ["--adapter"]),
+    ("err_unknown_base_no_adapter", "errbase", P),
+    ("err_mate_id_mismatch", "errid", P),
+    ("err_unequal_record_counts", "errcount", P),
     ("example_fixed_point", "example", P),
     ("advbig_default", "advbig", P),
     ("advbig_adapter_polyA", "advbig", P + ["--adapter", "--polyA"]),

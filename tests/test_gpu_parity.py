@@ -215,9 +215,10 @@ def test_golden_cases_on_gpu(name, fixture_cache, tmp_path):
     """The reference's own outputs (QC.stats.txt, trimmed FASTQ, --debug tables) reproduced by the HIP path."""
     from golden_util import load_case, run_case
 
-    bad = run_case(load_case(name), fixture_cache, tmp_path, hip_factory, max_read_length=1024)
+    case = load_case(name)
+    bad = run_case(case, fixture_cache, tmp_path, hip_factory, max_read_length=1024)
     assert not bad, "\n".join(bad)
-    assert _native_loaded()
+    assert case["exit_code"] != 0 or _native_loaded()  # (an input error can stop the run before any read reaches the engine)
 
 
 def test_kmer_matches_oracle():
