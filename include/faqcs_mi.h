@@ -130,8 +130,11 @@ enum { FAQCS_FILT_NONE = 0, FAQCS_FILT_LENGTH_PRE = 1, FAQCS_FILT_LENGTH_POST = 
 #define FAQCS_F_QUAL_TRIMMED 0x0010u /* READ_QUAL_TRIM counted for this read */
 #define FAQCS_F_ADAPTER      0x0020u /* start_length changed by the adapter pre-pass */
 #define FAQCS_F_POLY_N_SEEN  0x0040u /* READ_NN counted (qc_only keeps the read valid, trim.cpp:368-370) */
-#define FAQCS_F_ERR_QUALITY  0x0100u
-#define FAQCS_F_ERR_BASE     0x0200u
+/* The read is where the reference's trim() call throws; the submission as a whole also fails at faqcs_sync()/
+ * faqcs_finish().  A driver that writes output per trim() call (the reference: per 32 768-read buffer) checks these to
+ * stop before the buffer that holds such a read, as the reference does (FaQCs.cpp:287-361). */
+#define FAQCS_F_ERR_QUALITY  0x0100u /* a quality above MAX_QUALITY_SCORE (fastq.h:31-33) */
+#define FAQCS_F_ERR_BASE     0x0200u /* adapters active and a base na_to_bits() rejects (seq_overlap.cpp:409) */
 
 /* Layout (in uint64 units) of the additive counter block.  Everything the reference accumulates in
  * filter_stats / PlotInfo / adapter_stats is a sum of per-read integers, so one block == one
