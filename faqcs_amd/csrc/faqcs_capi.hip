@@ -44,6 +44,7 @@ hipError_t faqcs_launch_kmer_extract(const DevParams &P, uint32_t k, const KmerO
 hipError_t faqcs_launch_kmer_outbox_offsets(const KmerOutbox &O, hipStream_t st);
 hipError_t faqcs_launch_kmer_insert_items(const KmerTable &T, const void *items, unsigned long long n,
                                           unsigned long long *tot_by_epoch, uint32_t n_epochs, int n_cu, hipStream_t st);
+hipError_t faqcs_launch_kmer_table_init(const KmerTable &T, int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_first_epoch_histogram(const KmerTable &T, unsigned long long *hist, uint32_t n_epochs, int n_cu,
                                                    hipStream_t st);
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
@@ -378,7 +379,7 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
         c->kt.mask = pow2 - 1;
         HIPCHK(hipMalloc((void **)&c->kt.slots, pow2 * sizeof(KmerSlot)));
         HIPCHK(hipMalloc((void **)&c->kt.stats, 64));
-        HIPCHK(hipMemset(c->kt.slots, 0xff, pow2 * sizeof(KmerSlot))); // empty key, count - 1, no epoch
+        HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute)); // empty key, count - 1 = 0, no epoch
         HIPCHK(hipMemset(c->kt.stats, 0, 64));
         c->snap_cap = 4096;
         HIPCHK(hipMalloc((void **)&c->d_snaps, c->snap_cap * 16));
@@ -744,7 +745,7 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
         faqcs_rarefaction pt{c->total_number, st[0], st[1]};
         c->points.push_back(pt);
     }
-    HIPCHK(hipMemsetAsync(c->kt.slots, 0xff, (c->kt.mask + 1) * sizeof(KmerSlot), c->compute));
+    HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute));
     HIPCHK(hipMemsetAsync(c->kt.stats, 0, 64, c->compute));
     return 0;
 }

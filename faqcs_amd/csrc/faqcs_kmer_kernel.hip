@@ -13,12 +13,16 @@
 // (codes A=0,T=1,C=2,G=3: complement flips bit0, trim.cpp:904-917), key = min(enc, enc_rc).
 #include "faqcs_dev.h"
 
-// One 16-byte slot per key so that a probe touches ONE 64-byte sector (key CAS, count add and epoch min all land in it;
-// separate key / count arrays cost two random sectors per insert).  The table is initialised with 0xff bytes: key = ~0 is
-// "empty", the count is stored minus one (0xffffffff + 1 wraps to 0) and the epoch starts at "none".
+// One 16-byte slot per key so that a probe touches ONE 64-byte sector (separate key / count arrays cost two random sectors
+// per insert).  An empty slot is {key = ~0, count_m1 = 0, first_epoch = ~0} (kmer_table_init): the count is stored MINUS ONE,
+// so the compare-and-swap that claims a slot already leaves the right count for a key seen once.
+// The path is bound by the chip's L2 atomic rate (~14 G atomics/s measured, independent of table size and key reuse), so
+// an insert costs ONE atomic wherever possible: a plain 16-byte load classifies the slot first (keys never change once
+// written, so a stale view can only say "empty" and fall through to the CAS); a new key costs the CAS only, a known key
+// the count add only, and the epoch min is issued only when it would lower the stored epoch.
 struct __attribute__((aligned(16))) KmerSlot {
     unsigned long long key;
-    uint32_t count_m1;     // occurrences - 1 (mod 2^32)
+    uint32_t count_m1;     // occurrences - 1
     uint32_t first_epoch;  // owner-partitioned (multi-GPU) mode: smallest epoch that inserted the key
 };
 struct KmerTable {
@@ -110,11 +114,26 @@ __device__ __forceinline__ bool kmer_insert(const KmerTable &T, const uint64_t k
     is_new = false;
 #pragma unroll 1
     for (uint32_t probe = 0; probe < 4096; ++probe) {
-        const unsigned long long old = atomicCAS(&T.slots[h].key, ~0ull, (unsigned long long)key);
-        if (old == ~0ull) is_new = true;
-        if (old == ~0ull || old == key) {
-            atomicAdd(&T.slots[h].count_m1, 1u);
-            if (T.partitioned) atomicMin(&T.slots[h].first_epoch, epoch);
+        KmerSlot *sl = &T.slots[h];
+        // device-scope relaxed loads (bypass the per-CU L1): one 16-byte read of the slot
+        typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
+        const ull2_t cur = __builtin_nontemporal_load(reinterpret_cast<const ull2_t *>(sl));
+        unsigned long long seen = cur.x;
+        if (seen == ~0ull) {
+            seen = atomicCAS(&sl->key, ~0ull, (unsigned long long)key);
+            if (seen == ~0ull) { // claimed: count_m1 = 0 already says "seen once"
+                is_new = true;
+                if (T.partitioned) atomicMin(&sl->first_epoch, epoch);
+                return true;
+            }
+            if (seen == key) { // lost the race against the same key
+                atomicAdd(&sl->count_m1, 1u);
+                if (T.partitioned) atomicMin(&sl->first_epoch, epoch);
+                return true;
+            }
+        } else if (seen == key) {
+            atomicAdd(&sl->count_m1, 1u);
+            if (T.partitioned && epoch < (uint32_t)(cur.y >> 32)) atomicMin(&sl->first_epoch, epoch);
             return true;
         }
         h = (h + 1) & T.mask;
@@ -208,6 +227,10 @@ __global__ __launch_bounds__(256) void kmer_insert_items(const KmerTable T, cons
     const int lane = threadIdx.x & 63;
     unsigned long long my_new = 0;
     bool full = false;
+    // occurrences per epoch: a wave keeps the running count of the epoch it is seeing in (uniform) registers and only
+    // touches the global counter when the epoch changes -- one same-address atomic per item batch would serialise in L2
+    uint32_t acc_e = 0xffffffffu;
+    unsigned long long acc_n = 0;
     for (unsigned long long i0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n;
          i0 += (unsigned long long)gridDim.x * blockDim.x) {
         const unsigned long long i = i0 + lane;
@@ -225,10 +248,15 @@ __global__ __launch_bounds__(256) void kmer_insert_items(const KmerTable T, cons
             const int leader = __ffsll((long long)todo) - 1;
             const uint32_t e0 = (uint32_t)__shfl((int)e, leader);
             const uint64_t m = __ballot(on && e == e0);
-            if (lane == leader && e0 < n_epochs) atomicAdd(&tot_by_epoch[e0], (unsigned long long)__popcll(m));
+            if (e0 != acc_e) {
+                if (lane == 0 && acc_n && acc_e < n_epochs) atomicAdd(&tot_by_epoch[acc_e], acc_n);
+                acc_e = e0; acc_n = 0;
+            }
+            acc_n += (unsigned long long)__popcll(m);
             todo &= ~m;
         }
     }
+    if (lane == 0 && acc_n && acc_e < n_epochs) atomicAdd(&tot_by_epoch[acc_e], acc_n);
     const unsigned long long nw = (unsigned long long)wave_sum_i32((int)my_new);
     if (lane == 0 && nw) atomicAdd(&T.stats[0], nw);
     if (__any(full) && lane == 0) atomicOr(&T.stats[2], 1ull);
@@ -327,5 +355,18 @@ hipError_t faqcs_launch_kmer_first_epoch_histogram(const KmerTable &T, unsigned 
                                                    hipStream_t st)
 {
     hipLaunchKernelGGL(kmer_first_epoch_histogram, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, hist, n_epochs);
+    return hipGetLastError();
+}
+
+__global__ void kmer_table_init(KmerSlot *slots, const uint64_t n)
+{
+    const ulonglong2 empty = make_ulonglong2(~0ull, 0xffffffff00000000ull); // key, {count_m1 = 0, first_epoch = ~0}
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<ulonglong2 *>(slots)[i] = empty;
+}
+
+hipError_t faqcs_launch_kmer_table_init(const KmerTable &T, int n_cu, hipStream_t st)
+{
+    hipLaunchKernelGGL(kmer_table_init, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T.slots, T.mask + 1);
     return hipGetLastError();
 }
