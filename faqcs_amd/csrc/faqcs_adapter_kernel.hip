@@ -100,6 +100,7 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
     __shared__ uint32_t s_pl[NW][4][PW];       // the read's four base bit-planes, position ordered (stage 1)
     __shared__ __attribute__((aligned(16))) uint32_t s_tpl[TPL_CAP]; // the adapters' bit-planes (4 dwords per 32 bases)
     __shared__ uint32_t s_bb[NW][136];         // stage 2 on long targets: per 64-diagonal block, an upper bound of its best score
+    __shared__ uint32_t s_ast[2 * FAQCS_MAX_ADAPTERS]; // (reads, bases) credited per adapter by this block
     __shared__ uint8_t s_iupac[32];
     __shared__ uint8_t s_na[256];              // na_to_bits() of every byte value (0 = the reference throws)
     __shared__ uint32_t s_start[FAQCS_MAX_ADAPTERS + 1], s_wstart[FAQCS_MAX_ADAPTERS + 1]; // adapter table of contents
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
     const bool tpl_cached = tpl_dwords <= (uint32_t)TPL_CAP;
     if (tpl_cached) for (uint32_t i = threadIdx.x; i < tpl_dwords; i += NW * 64) s_tpl[i] = A.planes[i];
     if (threadIdx.x < 32) s_iupac[threadIdx.x] = threadIdx.x < 26 ? k_iupac[threadIdx.x] : (uint8_t)0;
+    for (uint32_t i = threadIdx.x; i < 2 * FAQCS_MAX_ADAPTERS; i += NW * 64) s_ast[i] = 0u;
     for (uint32_t i = threadIdx.x; i < A.n_adapters; i += NW * 64) {
         const uint32_t tl = A.start[i + 1] - A.start[i];
         s_meta[i] = make_uint4(tl, A.wstart[i], (uint32_t)(int)__fmul_rn(A.match_rate, (float)(int)tl), 0u);
@@ -471,9 +473,9 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
             if (run_length > longest_run_length) { longest_run_length = run_length; longest_run_start = run_start; }
             first = longest_run_length ? longest_run_start : 0u;
             second = longest_run_length;
-            if (lane == 0) {
-                atomicAdd((unsigned long long *)&adapter_stats[2 * best_j], 1ull);                          // trim.cpp:1061-1064
-                atomicAdd((unsigned long long *)&adapter_stats[2 * best_j + 1], (unsigned long long)((uint32_t)qlen - second));
+            if (lane == 0) { // trim.cpp:1061-1064; block-local, one global atomic pair per adapter at the end of the block
+                atomicAdd(&s_ast[2 * best_j], 1u);
+                atomicAdd(&s_ast[2 * best_j + 1], (uint32_t)qlen - second);
             }
         }
         // 0xffff = the read holds a base na_to_bits() rejects (seq_overlap.cpp:409): the trim kernel turns it into FAQCS_F_ERR_BASE
@@ -483,6 +485,9 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
       }
       if (mine) { ad_sl[my] = res_sl; ad_hit[my] = (uint16_t)res_hit; }
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 2 * A.n_adapters; i += NW * 64)
+        if (s_ast[i]) atomicAdd((unsigned long long *)&adapter_stats[i], (unsigned long long)s_ast[i]);
 }
 
 hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,

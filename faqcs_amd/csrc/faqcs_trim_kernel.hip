@@ -824,7 +824,7 @@ __global__ __launch_bounds__(NW * 64, LPR == 8 ? 2 : FAQCS_TRIM_MINWAVES) void t
         if (((it + 1) % REG_FLUSH_EVERY) == 0 || block_flush) spill_base_regs();
 
         // ---- flush LDS -> global before a 16-bit field can overflow, and at the end ----------------------
-        if (block_flush) flush_block<C, LPR, NW>(smem, counters, P.R, tid);
+        if (block_flush && !(o_dbg & 64u)) flush_block<C, LPR, NW>(smem, counters, P.R, tid);
     }
     if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
 }
