@@ -487,15 +487,24 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         return 0;
     }
     // ---- rarefaction bookkeeping per reference trim() call (trim.cpp:157-185) -------------------------------
+    // The k-mers of consecutive segments go to the device in ONE launch per run of segments that ends at a sampling point
+    // (or at the end of the batch / of the curve): only there does the order of insertion become observable.
+    uint32_t run_begin = seg[0];
+    auto flush_run = [&](uint32_t run_end) -> int {
+        if (run_end > run_begin) HIPCHK(faqcs_launch_kmer(c->dp, p.kmer, c->kt, d_seq, d_qual, d_off, run_begin, run_end, d_res, c->n_cu, c->compute));
+        run_begin = run_end;
+        return 0;
+    };
     for (uint32_t s = 0; s < n_seg; ++s) {
         const uint32_t r0 = seg[s], r1 = seg[s + 1];
-        if (c->kmer_active) {
-            HIPCHK(faqcs_launch_kmer(c->dp, p.kmer, c->kt, d_seq, d_qual, d_off, r0, r1, d_res, c->n_cu, c->compute));
-        }
+        if (!c->kmer_active) run_begin = r1; // (segments after the curve completed are not counted, trim.cpp:180-184)
         c->total_number += (r1 - r0);
         if (c->kmer_active) {
             const uint64_t index = c->total_number / p.split_size;
             const size_t num_rarefaction = c->points.size();
+            if (s + 1 == n_seg || num_rarefaction >= p.num_subsample ||
+                (index > num_rarefaction && num_rarefaction < p.num_subsample))
+                if (int rc = flush_run(r1)) return rc;
             if (index > num_rarefaction && num_rarefaction < p.num_subsample) {
                 if (c->n_snaps == c->snap_cap) { // drain the snapshots taken so far
                     HIPCHK(hipStreamSynchronize(c->compute));
