@@ -321,9 +321,11 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
 #pragma unroll
                     for (int e = 0; e < 2 * NBR + 2; ++e) R[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
             }
+            uint4 meta_next = s_meta[0];
 #pragma unroll 1
             for (uint32_t j = 0; j < A.n_adapters; ++j) {
-                const uint4 meta = s_meta[j];
+                const uint4 meta = meta_next;
+                meta_next = s_meta[j + 1 < A.n_adapters ? j + 1 : j]; // the next adapter's header is in flight during this one
                 const int tlen = uni((int)meta.x);
                 const int m = tail ? tlen : (len8 < tlen ? len8 : tlen);
                 const int thr = m == tlen ? uni((int)meta.z) : (int)__fmul_rn(A.match_rate, (float)m); // trim.cpp:1007-1008 / :1082
