@@ -24,6 +24,8 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <atomic>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -559,7 +561,11 @@ struct Run {
     }
 };
 
-struct Work { RecBuf *b1 = nullptr, *b2 = nullptr; bool last = false; };
+struct Work {
+    RecBuf *b1 = nullptr, *b2 = nullptr;
+    bool last = false;
+    std::shared_ptr<std::atomic<int>> left; // writers that still read the pair's buffers
+};
 
 // FaQCs.cpp:153-538
 void process_paired(Run &r)
@@ -570,8 +576,28 @@ void process_paired(Run &r)
     try { s2.start(opt.in2, 12, r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read two sequences\n", opt.in2.c_str()); throw; }
     OutFile f1, f2, fu, fd;
     if (!opt.qc_only) { f1.open(opt.out1); f2.open(opt.out2); fu.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); }
-    Queue<Work> wq;
+    // Output side: a gate thread waits for the device, applies the reference's "trim() threw, nothing of this buffer is
+    // written" rule, counts the pairs and writes the singleton / discard files; the two mate files -- where nearly all the
+    // bytes go -- are each formatted and written by their own thread.  Every file still receives its records in read order.
+    Queue<Work> wq, q1, q2;
     std::string werr;
+    auto release = [&](Work &w) { if (w.left->fetch_sub(1) == 1) { s1.free_q.push(w.b1); s2.free_q.push(w.b2); } };
+    auto mate_writer = [&](Queue<Work> &q, OutFile &f, bool second) {
+        std::string s, t;
+        for (;;) {
+            Work w = q.pop();
+            if (!w.b1) break;
+            const RecBuf *mine = second ? w.b2 : w.b1;
+            if (!opt.qc_only)
+                for (uint32_t i = 0; i < mine->n; ++i)
+                    if ((w.b1->res[i].flags & FAQCS_F_VALID) && (w.b2->res[i].flags & FAQCS_F_VALID)) r.write_read(f, mine, i, s, t);
+            const bool last = w.last;
+            release(w);
+            if (last) break;
+        }
+    };
+    std::thread writer1([&] { mate_writer(q1, f1, false); });
+    std::thread writer2([&] { mate_writer(q2, f2, true); });
     std::thread writer([&] {
         std::string s, q;
         try {
@@ -581,21 +607,22 @@ void process_paired(Run &r)
                 Run::check(faqcs_wait(r.ctx, w.b1->ticket));
                 Run::check(faqcs_wait(r.ctx, w.b2->ticket));
                 Run::check_read_errors(w.b1); Run::check_read_errors(w.b2); // trim() throws before anything of the buffer is written
+                w.left = std::make_shared<std::atomic<int>>(3);
+                q1.push(w); q2.push(w);
                 for (uint32_t i = 0; i < w.b1->n; ++i) {
                     const bool v1 = w.b1->res[i].flags & FAQCS_F_VALID, v2 = w.b2->res[i].flags & FAQCS_F_VALID;
                     if (v1 && v2) { r.paired_read_number += 2; r.paired_base_length += w.b1->res[i].len + w.b2->res[i].len; }
-                    if (opt.qc_only) continue;
-                    if (v1 && v2) { r.write_read(f1, w.b1, i, s, q); r.write_read(f2, w.b2, i, s, q); }
-                    else {
-                        if (v1) r.write_read(fu, w.b1, i, s, q);
-                        else if (v2) r.write_read(fu, w.b2, i, s, q);
-                        if (fd.f) { if (!v1) Run::write_raw(fd, w.b1, i); if (!v2) Run::write_raw(fd, w.b2, i); }
-                    }
+                    if (opt.qc_only || (v1 && v2)) continue;
+                    if (v1) r.write_read(fu, w.b1, i, s, q);
+                    else if (v2) r.write_read(fu, w.b2, i, s, q);
+                    if (fd.f) { if (!v1) Run::write_raw(fd, w.b1, i); if (!v2) Run::write_raw(fd, w.b2, i); }
                 }
-                s1.free_q.push(w.b1); s2.free_q.push(w.b2);
-                if (w.last) break;
+                const bool last = w.last;
+                release(w);
+                if (last) break;
             }
         } catch (std::exception &e) { werr = e.what(); }
+        q1.push(Work()); q2.push(Work()); // (a mate writer that already saw its last buffer has left; the sentinel is then unused)
     });
     bool check_for_next_seq = true;
     std::string merr;
@@ -632,7 +659,7 @@ void process_paired(Run &r)
             if (last) break;
         }
     } catch (std::exception &e) { merr = e.what(); wq.push(Work()); }
-    writer.join();
+    writer.join(); writer1.join(); writer2.join();
     if (!merr.empty() || !werr.empty()) { // unblock the readers, then report like the reference's catch in main()
         f1.close(); f2.close(); fu.close(); fd.close();
         fprintf(stderr, "Caught the error %s\n", (!merr.empty() ? merr : werr).c_str());
