@@ -164,6 +164,39 @@ template <> struct RowOps<8> {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false) & (uint32_t)ge_(1);
     }
 };
+// 32 lanes per read (two reads per wave, reads of 257..512 bases): row butterflies / scans plus ONE cross-row step --
+// ds_swizzle (xor 16 inside each group of 32 lanes, no LDS memory touched) for reductions, row_bcast:15 into the odd rows
+// for scans.
+template <> struct RowOps<32> {
+    static __device__ __forceinline__ int swap_rows(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x401f); } // and 0x1f, or 0, xor 0x10
+    static __device__ __forceinline__ int all_sum(int v) { v = row_all_sum(v); return v + swap_rows(v); }
+    static __device__ __forceinline__ uint32_t all_or(uint32_t x) { const int v = (int)row_all_or(x); return (uint32_t)(v | swap_rows(v)); }
+    static __device__ __forceinline__ uint32_t all_umax(uint32_t x) { const int v = (int)row_all_umax(x); return (uint32_t)op_umax_(v, swap_rows(v)); }
+    static __device__ __forceinline__ int incl_scan_add(int v)
+    {
+        v = row_incl_scan_add(v);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+        return v;
+    }
+    static __device__ __forceinline__ uint32_t incl_scan_umax(uint32_t x)
+    {
+        int v = (int)row_incl_scan_umax(x);
+        v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+        return (uint32_t)v;
+    }
+    static __device__ __forceinline__ uint32_t next(uint32_t v)
+    {
+        const int l = (int)(threadIdx.x & 63u);
+        const uint32_t x = (uint32_t)__shfl((int)v, (l + 1) & 63);
+        return (l & 31) == 31 ? 0u : x;
+    }
+    static __device__ __forceinline__ uint32_t prev(uint32_t v)
+    {
+        const int l = (int)(threadIdx.x & 63u);
+        const uint32_t x = (uint32_t)__shfl((int)v, (l + 63) & 63);
+        return (l & 31) == 0 ? 0u : x;
+    }
+};
 template <> struct RowOps<64> {
     static __device__ __forceinline__ int all_sum(int v) { return wave_sum_i32(v); }
     static __device__ __forceinline__ uint32_t all_umax(uint32_t v) { return wave_max_u32(v); }

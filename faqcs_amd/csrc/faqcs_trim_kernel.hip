@@ -7,7 +7,8 @@
 // with ONE unaligned global_load_dwordx{D} per arena; a wave takes chunks of 64 reads.
 //   LPR =  8  reads <= 160 bases (C = 8 / 14 / 20): eight reads per wave, two per 16-lane DPP row
 //   LPR = 16  reads <= 256 bases (C = 4 ... 16):    four reads per wave, one per DPP row
-//   LPR = 64  reads <= 1024 bases (C = 5 / 8 / 16): the whole wave on one read
+//   LPR = 32  reads <= 512 bases (C = 10 / 16):     two reads per wave
+//   LPR = 64  reads <= 1024 bases (C = 16; 5 / 8 as the A/B fallback of LPR = 32): the whole wave on one read
 // Every per-read scalar (length, window, cut points, filter decision) is a group-uniform VGPR value: there are no
 // ballots and no scalar-ALU bit logic in the loop (round-1 profiling showed the ballot formulation was SALU-bound at
 // ~900 scalar instructions per read).  Cross-lane work is DPP only (RowOps<LPR> in faqcs_dev.h): prefix scans and
@@ -237,7 +238,7 @@ __device__ __noinline__ void flush_hq8(uint32_t *smem, uint64_t *counters, const
 // GENERIC: false = the headline option set (BWA_plus, 5' trimming on, not --qc_only, no --replace_to_N_q, no
 // --avg_q, -n 2) is compiled in, so those tests and their live scalars disappear from the loop.
 template <int C, int LPR, int NW, bool WINDOWED, bool GENERIC>
-__global__ __launch_bounds__(NW * 64, LPR == 8 ? 2 : FAQCS_TRIM_MINWAVES) void trim_filter_accumulate(
+__global__ __launch_bounds__(NW * 64, (LPR == 8 || (LPR == 32 && C > 10)) ? 2 : FAQCS_TRIM_MINWAVES) void trim_filter_accumulate(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, LPR == 8 ? 2 : FAQCS_TRIM_MINWAVES) void t
     const uint32_t n_iter = (total_chunks + chunks_per_iter - 1) / chunks_per_iter;
     constexpr uint32_t FLUSH_EVERY = 65535u / (NW * 64) > 0 ? 65535u / (NW * 64) : 1;
     // 6-bit fields: 3 chunks x 16 reads per row = 48 <= 63; a 64-lane row sees 64 reads per chunk and spills mid-chunk too
-    constexpr uint32_t REG_FLUSH_EVERY = LPR == 16 ? 3 : (LPR == 8 ? 7 : 1);
+    constexpr uint32_t REG_FLUSH_EVERY = LPR == 16 ? 3 : (LPR == 8 ? 7 : 1); // 32 lanes: 32 reads per chunk; 64: spills mid-chunk too
 
     const int in_off = P.in_off, Q = P.Q;
     const int o_mode = GENERIC ? P.mode : (int)FAQCS_MODE_BWA_PLUS;
@@ -909,7 +910,7 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
     }
     const uint32_t chunks = (n_reads + 63) / 64;
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    constexpr int minwaves = LPR == 8 ? 2 : (FAQCS_TRIM_MINWAVES > 2 ? FAQCS_TRIM_MINWAVES : 2);
+    constexpr int minwaves = (LPR == 8 || (LPR == 32 && C > 10)) ? 2 : (FAQCS_TRIM_MINWAVES > 2 ? FAQCS_TRIM_MINWAVES : 2);
     const int by_waves = (4 * minwaves + NW - 1) / NW; // resident waves per CU the registers allow
     if (blocks_per_cu > by_waves) blocks_per_cu = by_waves;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -952,6 +953,11 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
     if (max_len <= 208) FAQCS_TRIM_CASE(13, FAQCS_TRIM_NW);
     if (max_len <= 256) FAQCS_TRIM_CASE(16, FAQCS_TRIM_NW);
     // long reads: the whole wave on one read, one superset variant per width (MiSeq 2x300 -> C = 5)
+    {   // two reads per wave (32 lanes each) up to 512 bases; FAQCS_TRIM_LPR32=0 falls back to the whole wave per read
+        static const bool lpr32 = [] { const char *e = getenv("FAQCS_TRIM_LPR32"); return !e || atoi(e) != 0; }();
+        if (lpr32 && max_len <= 320) return launch_trim_t<10, 32, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
+        if (lpr32 && max_len <= 512) return launch_trim_t<16, 32, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
+    }
     if (max_len <= 320) return launch_trim_t<5, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
     if (max_len <= 512) return launch_trim_t<8, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
     if (max_len <= 1024) return launch_trim_t<16, 64, 8, true, true>(FAQCS_TRIM_ARGS); // 8 x 16 reads <= 255 per 8-bit cell
