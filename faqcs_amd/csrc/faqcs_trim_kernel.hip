@@ -947,9 +947,7 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
         if (lpr8 && max_len <= 160) FAQCS_TRIM_CASE8(20);
 #undef FAQCS_TRIM_CASE8
     }
-    if (max_len <= 64) FAQCS_TRIM_CASE(4, FAQCS_TRIM_NW);
-    if (max_len <= 112) FAQCS_TRIM_CASE(7, FAQCS_TRIM_NW);
-    if (max_len <= 160) FAQCS_TRIM_CASE(10, FAQCS_TRIM_NW);
+    // 16 lanes per read: 161..256 bases (and the A/B fallback of the 8-lane variants)
     if (max_len <= 208) FAQCS_TRIM_CASE(13, FAQCS_TRIM_NW);
     if (max_len <= 256) FAQCS_TRIM_CASE(16, FAQCS_TRIM_NW);
     // long reads: the whole wave on one read, one superset variant per width (MiSeq 2x300 -> C = 5)
