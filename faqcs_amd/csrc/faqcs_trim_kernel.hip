@@ -158,12 +158,22 @@ __device__ __noinline__ void flush_block(uint32_t *smem, uint64_t *counters, con
         if (v) {
             hq[i] = 0;
             const uint32_t q = i / W, p = i % W;
+            uint32_t pre = v & 0xffffu;
+            if (q == 0) {
+                // The read loop adds the "pre" 1 for EVERY position slot of a counted read, also past its end (where the
+                // masked quality byte is 0): column 0 of position p is over-counted once per read with len <= p, and the
+                // interval's length histogram says how many those are.
+                uint32_t shorter = 0;
+                for (uint32_t l = 0; l <= p; ++l) shorter += hlen[l] & 0xffffu;
+                pre -= shorter;
+            }
             if (p < R) {
-                if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)(v & 0xffffu));
+                if (pre) atomicAdd((unsigned long long *)(counters + L.pre_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)pre);
                 if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)(v >> 16));
             }
         }
     }
+    __syncthreads(); // (the correction above reads hlen, which the loop below clears)
     for (int i = tid; i < Cfg::HB; i += NW * 64) {
         const uint32_t v = hb[i];
         if (v) {
@@ -719,8 +729,11 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || (LPR == 32 && C > 10)) ? 2 : 
 #pragma unroll
                         for (int j = 0; j < C; ++j) { q[j] = read_err ? 0 : q[j]; incf[j] = read_err ? 0u : incf[j]; }
                     }
-                    const uint32_t inr = (act && !read_err) ? range_mask<C>(0, len, pbase) : 0u;
-                    const uint32_t postm = ret ? (win2 & inr) : 0u;
+                    // 1024-wide rows keep exact per-position "pre" bits; the others add 1 for every slot of a counted read and
+                    // let flush_block subtract the slots past the read's end
+                    const uint32_t inr = Cfg::HQ8 ? ((act && !read_err) ? range_mask<C>(0, len, pbase) : 0u) : 0u;
+                    const uint32_t counted = (act && !read_err) ? 1u : 0u;
+                    const uint32_t postm = ret ? (Cfg::HQ8 ? (win2 & inr) : win2) : 0u;
                     if (Cfg::HQ8) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
@@ -733,7 +746,7 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || (LPR == 32 && C > 10)) ? 2 : 
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = q[j];
-                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], ((inr >> j) & 1u) | ((uint32_t)bit_m1(postm, j) & 0x10000u));
+                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], counted | ((uint32_t)bit_m1(postm, j) & 0x10000u));
                             bpre[j] += incf[j];
                             const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
                             bpost[j] += w & (uint32_t)bit_m1(postm, j);
@@ -742,7 +755,7 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || (LPR == 32 && C > 10)) ? 2 : 
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = q[j];
-                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], ((inr >> j) & 1u) | ((uint32_t)bit_m1(postm, j) & 0x10000u));
+                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], counted | ((uint32_t)bit_m1(postm, j) & 0x10000u));
                             bpre[j] += incf[j];
                             bpost[j] += incf[j] & (uint32_t)bit_m1(postm, j);
                         }
