@@ -102,6 +102,13 @@ template <int K> __device__ __forceinline__ uint32_t byte_times4(uint32_t w, uin
 // t_base_lds = LDS byte address of the table (the kernel's dynamic LDS starts at address 0, checked at kernel start): the
 // lookup is then ds_read_b32 v, <4 * byte> offset:<table> with no address add at all.
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32_mut;
+// ds_add_u32 at an LDS BYTE offset computed in 32 bits (a generic pointer makes the compiler form the address with
+// v_mad_u64_u32, a multi-pass instruction, once per base)
+__device__ __forceinline__ void lds_add_u32(uint32_t byte_offset, uint32_t v)
+{
+    __hip_atomic_fetch_add((lds_u32_mut)(size_t)byte_offset, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 template <int C, int J> struct BaseLookup {
     static __device__ __forceinline__ void run(const uint32_t t_base_lds, const uint32_t *ws, uint32_t two, uint32_t *inc)
     {
@@ -733,20 +740,23 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || (LPR == 32 && C > 10)) ? 2 : 
                     // let flush_block subtract the slots past the read's end
                     const uint32_t inr = Cfg::HQ8 ? ((act && !read_err) ? range_mask<C>(0, len, pbase) : 0u) : 0u;
                     const uint32_t counted = (act && !read_err) ? 1u : 0u;
+                    const uint32_t pb4 = 4u * (uint32_t)pbase;
                     const uint32_t postm = ret ? (Cfg::HQ8 ? (win2 & inr) : win2) : 0u;
                     if (Cfg::HQ8) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = q[j];
                             const uint32_t x = ((inr >> j) & 1u) | ((uint32_t)bit_m1(postm, j) & 0x100u); // pre -> byte 0, post -> byte 1
-                            atomicAdd(&hq[qq * (W / 2) + ((pbase + j) >> 1)], x << (16 * ((pbase + j) & 1)));
+                            lds_add_u32(__umul24((uint32_t)qq, (uint32_t)(W / 2 * 4)) + (uint32_t)(Cfg::O_HQ * 4) + 4u * (uint32_t)((pbase + j) >> 1),
+                                        x << (16 * ((pbase + j) & 1)));
                         }
                     }
                     if (o_replace_q > 0) {
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = q[j];
-                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], counted | ((uint32_t)bit_m1(postm, j) & 0x10000u));
+                            if (!Cfg::HQ8) lds_add_u32(__umul24((uint32_t)qq, (uint32_t)(W * 4)) + pb4 + (uint32_t)(Cfg::O_HQ * 4 + 4 * j),
+                                                       counted | ((uint32_t)bit_m1(postm, j) & 0x10000u));
                             bpre[j] += incf[j];
                             const uint32_t w = ((repbits >> j) & 1u) ? (1u << BT_SHIFT(4)) : incf[j];
                             bpost[j] += w & (uint32_t)bit_m1(postm, j);
@@ -755,7 +765,8 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || (LPR == 32 && C > 10)) ? 2 : 
 #pragma unroll
                         for (int j = 0; j < C; ++j) {
                             const int qq = q[j];
-                            if (!Cfg::HQ8) atomicAdd(&hq[qq * W + pbase + j], counted | ((uint32_t)bit_m1(postm, j) & 0x10000u));
+                            if (!Cfg::HQ8) lds_add_u32(__umul24((uint32_t)qq, (uint32_t)(W * 4)) + pb4 + (uint32_t)(Cfg::O_HQ * 4 + 4 * j),
+                                                       counted | ((uint32_t)bit_m1(postm, j) & 0x10000u));
                             bpre[j] += incf[j];
                             bpost[j] += incf[j] & (uint32_t)bit_m1(postm, j);
                         }
