@@ -9,6 +9,9 @@ from faqcs_amd.options import parse_args
 
 pytestmark = pytest.mark.gpu
 
+# FAQCS_TEST_SEED=<n> shifts every seeded random batch (fuzzing runs; the default 0 is what the suite is pinned to)
+SEED = int(__import__("os").environ.get("FAQCS_TEST_SEED", "0"))
+
 
 def hip_factory(opt, max_read_length, in_off):
     from faqcs_amd.engine import HipEngine
@@ -99,7 +102,7 @@ OPTION_SETS = [
 @pytest.mark.parametrize("args", OPTION_SETS, ids=lambda a: " ".join(a) or "default")
 @pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 64), ("ragged", 250), ("adv", 100)])
 def test_random_batches_match_oracle(args, kind, maxlen):
-    rng = np.random.Generator(np.random.PCG64([len(kind), maxlen, OPTION_SETS.index(args)]))
+    rng = np.random.Generator(np.random.PCG64([len(kind), maxlen, OPTION_SETS.index(args), SEED]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     n = 700 if "--adapter" in args else 3000
     reads = random_batch(rng, n, maxlen, kind)
@@ -110,7 +113,7 @@ def test_random_batches_match_oracle(args, kind, maxlen):
 @pytest.mark.parametrize("kind,maxlen", [("adv", 300), ("ragged", 500), ("adv", 1024)])
 def test_long_reads_match_oracle(args, kind, maxlen):
     """Reads past the 256-base row kernels: the 64-lanes-per-read variants (widths 320 / 512 / 1024)."""
-    rng = np.random.Generator(np.random.PCG64([7, len(kind), maxlen, OPTION_SETS.index(args)]))
+    rng = np.random.Generator(np.random.PCG64([7, len(kind), maxlen, OPTION_SETS.index(args), SEED]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     n = 150 if "--adapter" in args else 500
     reads = random_batch(rng, n, maxlen, kind)
@@ -125,7 +128,7 @@ def test_phix_reads_match_oracle(args):
 
     from faqcs_amd import options
 
-    rng = np.random.Generator(np.random.PCG64([11, len(args)]))
+    rng = np.random.Generator(np.random.PCG64([11, len(args), SEED]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     phix = np.frombuffer(options.phix_sequence().encode(), np.uint8) if hasattr(options, "phix_sequence") else None
     if phix is None:
@@ -138,8 +141,10 @@ def test_phix_reads_match_oracle(args):
         else:
             L = int(rng.integers(30, 151))
             p0 = int(rng.integers(-40, len(phix) - L + 40))
-            lo, hi = max(p0, 0), min(p0 + L, len(phix))
-            s = np.concatenate([make_fixtures.ACGT[rng.integers(0, 4, lo - p0)], phix[lo:hi], make_fixtures.ACGT[rng.integers(0, 4, p0 + L - hi)]])
+            lo = min(max(p0, 0), len(phix))
+            hi = max(lo, min(p0 + L, len(phix)))
+            s = np.concatenate([make_fixtures.ACGT[rng.integers(0, 4, max(0, min(L, lo - p0)))], phix[lo:hi]])
+            s = np.concatenate([s, make_fixtures.ACGT[rng.integers(0, 4, L - len(s))]])
             if i % 2:
                 s = np.frombuffer(s.tobytes().translate(comp)[::-1], np.uint8)
             s = make_fixtures._mutate(rng, s, float(rng.choice([0.0, 0.03, 0.15, 0.3])))
@@ -168,7 +173,7 @@ def test_long_read_limits():
 @pytest.mark.parametrize("kind,maxlen", [("adv", 157), ("adv", 120), ("ragged", 104), ("adv", 200), ("ragged", 112)])
 def test_every_kernel_width_matches_oracle(args, kind, maxlen):
     """One batch per position-slot width the dispatcher can pick (8 lanes per read: C = 8/13/16/19/20; 16 lanes: C = 13/16)."""
-    rng = np.random.Generator(np.random.PCG64([3, len(kind), maxlen, OPTION_SETS.index(args)]))
+    rng = np.random.Generator(np.random.PCG64([3, len(kind), maxlen, OPTION_SETS.index(args), SEED]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     reads = random_batch(rng, 500 if "--adapter" in args else 1500, maxlen, kind)
     compare_engines(opt, reads, seg_size=389)
