@@ -4,7 +4,9 @@
 // regenerates exactly its slice.  Recipe: bases iid ACGT, each N w.p. 0.002; Phred+33 qualities: first 3
 // bases U[2,37], plateau U[30,40] up to a breakpoint b ~ U[L/2, L+40], tail Q2 w.p. 0.7 (per read) else
 // U[3,15]; with probability adapter_frac one of the 9 built-in adapters or poly-A (options.cpp:583-625) is
-// read through from a position U[40, L-10] with 5 % substitutions.
+// read through from a position U[40, L-10] with 5 % substitutions.  With genome_len > 0 (the k-mer configuration) a read
+// is a window of a fixed synthetic genome (base at position g = hash(seed, g)), on either strand, with 0.5 % substitutions,
+// so that distinct k-mers grow like they do on real data.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,7 +37,7 @@ __device__ __forceinline__ uint32_t below(uint32_t r, uint32_t n) { return (uint
 } // namespace
 
 __global__ void synth_fill(uint8_t *seq, uint8_t *qual, uint32_t *offset, uint32_t n_reads, uint32_t L, uint64_t seed,
-                           uint64_t first_read, float adapter_frac)
+                           uint64_t first_read, float adapter_frac, uint64_t genome_len)
 {
     const uint64_t total = (uint64_t)n_reads * L;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total + n_reads + 1; g += (uint64_t)gridDim.x * blockDim.x) {
@@ -49,6 +51,13 @@ __global__ void synth_fill(uint8_t *seq, uint8_t *qual, uint32_t *offset, uint32
         // base
         uint32_t x = rnd(seed, R, 1, p);
         uint8_t b = "ACGT"[x & 3u];
+        if (genome_len > L) {
+            const uint64_t start = mix(mix(seed ^ 0x67656e6f6d65ull) + R) % (genome_len - L);
+            const bool rc = (rnd(seed, R, 0, 6) & 1u) != 0;
+            const uint64_t gp = rc ? start + (L - 1 - p) : start + p;
+            const uint32_t gb = (uint32_t)(mix(seed * 0x2545f4914f6cdd1dull + gp) >> 62); // the genome's base at gp
+            if (rnd(seed, R, 5, p) >= (uint32_t)(0.005 * 4294967296.0)) b = rc ? "TGCA"[gb] : "ACGT"[gb];
+        }
         if (has_ad) {
             const uint32_t ai = below(rnd(seed, R, 0, 4), 10);
             const uint32_t ap = 40 + below(rnd(seed, R, 0, 5), L - 10 - 40 + 1);
@@ -71,8 +80,8 @@ __global__ void synth_fill(uint8_t *seq, uint8_t *qual, uint32_t *offset, uint32
 }
 
 hipError_t faqcs_launch_synth(uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads, uint32_t L,
-                              uint64_t seed, uint64_t first_read, float adapter_frac, hipStream_t st)
+                              uint64_t seed, uint64_t first_read, float adapter_frac, uint64_t genome_len, hipStream_t st)
 {
-    hipLaunchKernelGGL(synth_fill, dim3(256 * 16), dim3(256), 0, st, d_seq, d_qual, d_offset, n_reads, L, seed, first_read, adapter_frac);
+    hipLaunchKernelGGL(synth_fill, dim3(256 * 16), dim3(256), 0, st, d_seq, d_qual, d_offset, n_reads, L, seed, first_read, adapter_frac, genome_len);
     return hipGetLastError();
 }

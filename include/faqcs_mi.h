@@ -249,6 +249,10 @@ int  faqcs_kmer_epoch_counts(faqcs_ctx *ctx, uint64_t *distinct_by_first_epoch, 
  * (seed, first_read + i)); stride == L (packed).  d_offset gets n_reads+1 entries. */
 int  faqcs_synth_fill(int device_id, uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads,
                       uint32_t L, uint64_t seed, uint64_t first_read, float adapter_frac);
+/* The k-mer configuration of SURVEY section 8(d): reads are windows of a fixed synthetic genome of genome_len bases
+ * (either strand, 0.5 % substitutions, the same quality recipe), so distinct k-mers grow as on real data. */
+int  faqcs_synth_fill_genome(int device_id, uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads,
+                             uint32_t L, uint64_t seed, uint64_t first_read, uint64_t genome_len);
 /* average duration (ms) of the dominant kernel over the launches since the last call, measured with
  * HIP events recorded on the compute stream around each launch */
 int  faqcs_kernel_time_ms(faqcs_ctx *ctx, double *avg_ms, uint64_t *n_launches);

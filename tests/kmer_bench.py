@@ -1,4 +1,4 @@
-"""Diagnostic: throughput of the k-mer path (trim + kmer_count per 32 768-read segment).  Usage: python tests/kmer_bench.py [reads] [L]"""
+"""Diagnostic: throughput of the k-mer path (trim + kmer_count).  Usage: python tests/kmer_bench.py [reads] [L] [log2 slots] [genome length]"""
 import ctypes as C
 import os
 import sys
@@ -25,7 +25,11 @@ seq = torch.empty(n * L + 64, dtype=torch.uint8, device=dev)
 qual = torch.empty(n * L + 64, dtype=torch.uint8, device=dev)
 off = torch.empty(n + 1, dtype=torch.int32, device=dev)
 res = torch.empty((n, 4), dtype=torch.int16, device=dev)
-_check(lib, lib.faqcs_synth_fill(0, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), n, L, 20260101, 0, 0.0))
+genome = int(float(sys.argv[4])) if len(sys.argv) > 4 else 0  # 0 = all-random reads (worst case), else genome length
+if genome:
+    _check(lib, lib.faqcs_synth_fill_genome(0, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), n, L, 20260101, 0, genome))
+else:
+    _check(lib, lib.faqcs_synth_fill(0, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), n, L, 20260101, 0, 0.0))
 seg = np.arange(0, n + 32768, 32768, dtype=np.uint32)
 seg[-1] = n
 b = capi.Batch(seq.data_ptr(), qual.data_ptr(), off.data_ptr(), n, len(seg) - 1, seg.ctypes.data, L)
