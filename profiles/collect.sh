@@ -14,6 +14,7 @@ python3 bench.py > $out/bench_plain_100Mpairs.json 2> $out/bench_plain.err
 python3 bench.py --config adapter --pairs 20e6 --no-cpu-baseline > $out/bench_adapter_20Mpairs.json 2> $out/bench_adapter.err
 python3 bench.py --read-len 250 --pairs 40e6 --no-cpu-baseline > $out/bench_plain_250bp_40Mpairs.json 2>> $out/bench_plain.err
 python3 bench.py --read-len 300 --pairs 20e6 --no-cpu-baseline > $out/bench_plain_300bp_20Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 100 --pairs 60e6 --no-cpu-baseline > $out/bench_plain_100bp_60Mpairs.json 2>> $out/bench_plain.err
 fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_plain -o plain -- python3 bench.py --pairs 25165824 --steps 3 --no-cpu-baseline > $out/prof_plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_adapter -o adapter -- python3 bench.py --config adapter --pairs 4e6 --steps 3 --no-cpu-baseline > $out/prof_adapter.log 2>&1
