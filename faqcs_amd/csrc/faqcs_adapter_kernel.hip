@@ -321,32 +321,40 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
 #pragma unroll
                     for (int e = 0; e < 2 * NBR + 2; ++e) R[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
             }
-            uint4 meta_next = s_meta[0];
+            // per-adapter scalars of this read, computed once with lane = adapter (n_adapters <= 64) and read back with
+            // v_readlane inside the loop: |adapter|, first plane word, threshold, and "need" = 2 thr - min(|read|, |adapter|)
+            uint32_t va = 0, vb = 0;
+            if ((uint32_t)lane < A.n_adapters) {
+                const uint4 me = s_meta[lane];
+                const int tl = (int)me.x;
+                const int mm = tail ? tl : (len8 < tl ? len8 : tl);
+                const int th = mm == tl ? (int)me.z : (int)__fmul_rn(A.match_rate, (float)mm); // trim.cpp:1007-1008 / :1082
+                va = (uint32_t)tl | (me.y << 16);
+                vb = (uint32_t)th | ((uint32_t)(2 * th - (qlen < tl ? qlen : tl) + 32768) << 16);
+            }
 #pragma unroll 1
             for (uint32_t j = 0; j < A.n_adapters; ++j) {
-                const uint4 meta = meta_next;
-                meta_next = s_meta[j + 1 < A.n_adapters ? j + 1 : j]; // the next adapter's header is in flight during this one
-                const int tlen = uni((int)meta.x);
-                const int m = tail ? tlen : (len8 < tlen ? len8 : tlen);
-                const int thr = m == tlen ? uni((int)meta.z) : (int)__fmul_rn(A.match_rate, (float)m); // trim.cpp:1007-1008 / :1082
+                const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)va, (int)j), sb = (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)j);
+                const int tlen = (int)(sa & 0xffffu);
+                const int thr = (int)(sb & 0xffffu);
+                const int need_j = (int)(sb >> 16) - 32768;                  // (mcap + bound) / 2 >= thr  <=>  bound >= need
                 bool any_match = true, may_pass = true;
                 const int mcap = qlen < tlen ? qlen : tlen;
                 if (!(dbg & 8u) && MAXLEN == 256 && tlen <= 128 && tpl_cached) {
-                    const uint32_t *tpl = s_tpl + 4 * uniu(meta.y);
+                    const uint32_t *tpl = s_tpl + 4 * (sa >> 16);
                     const int nw = (tlen + 31) >> 5;
                     const int nb = (qlen + tlen - 1 + 63) >> 6;              // blocks past the last diagonal would only add zeros
                     uint32_t maxcnt;
                     if (NBR == 4) maxcnt = nb <= 3 ? prefilter_max<3, NBR>(R, tpl, nw) : prefilter_max<4, NBR>(R, tpl, nw);
                     else maxcnt = nb <= 4 ? prefilter_max<4, NBR>(R, tpl, nw) : prefilter_max<(NBR > 4 ? 6 : 4), NBR>(R, tpl, nw);
                     // bound = max over diagonals; only two threshold tests of it are needed
-                    const int need = 2 * thr - mcap;                          // (mcap + bound) / 2 >= thr  <=>  bound >= need
                     any_match = __any(maxcnt > 0u);
-                    may_pass = __any((int)maxcnt >= need);
+                    may_pass = __any((int)maxcnt >= need_j);
                 } else if (!(dbg & 8u) && MAXLEN == 256 && NBR == 6 && tpl_cached) {
                     // long target (PhiX, artifact sequences): the same register windows, sliding over the target two words
                     // per step.  Words 2u and 2u+1 face exactly the seven blocks u-1 .. u+5 (window index 12-2i / 13-2i for
                     // block u-1+i); block u-1 has seen all of its words after step u and leaves the 7-deep accumulator.
-                    const uint32_t *tpl = s_tpl + 4 * uniu(meta.y);
+                    const uint32_t *tpl = s_tpl + 4 * (sa >> 16);
                     const int nw = (tlen + 31) >> 5;
                     const int nb = (qlen + tlen - 1 + 63) >> 6;
                     uint32_t cnt[7], maxcnt = 0;
@@ -368,9 +376,8 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
                         for (int i = 0; i < 6; ++i) cnt[i] = cnt[i + 1];
                         cnt[6] = 0;
                     }
-                    const int need = 2 * thr - mcap;
                     any_match = __any(maxcnt > 0u);
-                    may_pass = __any((int)maxcnt >= need);
+                    may_pass = __any((int)maxcnt >= need_j);
                 } else if (!(dbg & 8u)) {
                     const uint32_t w0 = s_wstart[j];
                     const int nw = (int)(s_wstart[j + 1] - w0);
