@@ -505,9 +505,9 @@ hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const u
 {
     if (n_reads == 0) return hipSuccess;
     if (max_len <= 256) {
-        constexpr int NW = 8; // (A/B on MI355X: 4-wave blocks at 5 waves/SIMD were 9 % slower)
+        constexpr int NW = 4; // 4 waves/SIMD either way (123 VGPRs); A/B on MI355X: 4-wave blocks +2 % over 8-wave blocks
         uint32_t grid = (n_reads + NW - 1) / NW;
-        const uint32_t cap = (uint32_t)n_cu * 4u;
+        const uint32_t cap = (uint32_t)n_cu * 8u;
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((adapter_overlap<NW, 256>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
                            n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
