@@ -85,13 +85,13 @@ __device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][2 * NBR
 }
 
 template <int NW, int MAXLEN>
-__global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
+__global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overlap(
     const AdapterDev A, const uint8_t *__restrict__ seq, const uint32_t *__restrict__ off, const uint32_t n_reads,
     const uint32_t *__restrict__ seg_start, const uint32_t n_segments, uint32_t *__restrict__ ad_sl,
     uint16_t *__restrict__ ad_hit, uint64_t *__restrict__ adapter_stats, uint32_t *__restrict__ err, const uint32_t dbg)
 {
     constexpr int QW = MAXLEN / 32;            // data dwords per plane
-    constexpr int PADL = 12;                   // zero dwords on each side: the register-blocked stage 1 reads up to 12 dwords
+    constexpr int PADL = MAXLEN == 320 ? 14 : 12; // zero dwords on each side: the register-blocked stage 1 reads up to PADL dwords
     constexpr int PW = QW + 2 * PADL;          // before / after the data without clamping its index
     constexpr int TPL_CAP = 4096;              // adapter plane dwords cached in LDS (16 KB: every built-in set incl. PhiX)
     constexpr int NBLK = 6;                    // 64-diagonal blocks kept in registers: |read| <= 256, |adapter| <= 128
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
         auto stage1 = [&](auto nbr_tag) {
             constexpr int NBR = decltype(nbr_tag)::value;
             uint32_t R[4][2 * NBR + 2];
-            if (MAXLEN == 256 && tpl_cached) {
+            if (MAXLEN <= 320 && tpl_cached) {
                 const int i00 = (qlen - 1) - lane;                       // read bit facing adapter base 0 on block 0's diagonal
                 const uint32_t sh = (uint32_t)i00 & 31u;
                 const uint32_t *pp = pl + (i00 >> 5) + PADL - 2 * (NBR - 1); // e = 0
@@ -340,13 +340,14 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
                 const int need_j = (int)(sb >> 16) - 32768;                  // (mcap + bound) / 2 >= thr  <=>  bound >= need
                 bool any_match = true, may_pass = true;
                 const int mcap = qlen < tlen ? qlen : tlen;
-                if (!(dbg & 8u) && MAXLEN == 256 && tlen <= 128 && tpl_cached) {
+                if (!(dbg & 8u) && MAXLEN <= 320 && tlen <= 128 && tpl_cached) {
                     const uint32_t *tpl = s_tpl + 4 * (sa >> 16);
                     const int nw = (tlen + 31) >> 5;
                     const int nb = (qlen + tlen - 1 + 63) >> 6;              // blocks past the last diagonal would only add zeros
                     uint32_t maxcnt;
                     if (NBR == 4) maxcnt = nb <= 3 ? prefilter_max<3, NBR>(R, tpl, nw) : prefilter_max<4, NBR>(R, tpl, nw);
-                    else maxcnt = nb <= 4 ? prefilter_max<4, NBR>(R, tpl, nw) : prefilter_max<(NBR > 4 ? 6 : 4), NBR>(R, tpl, nw);
+                    else if (NBR == 6) maxcnt = nb <= 4 ? prefilter_max<4, NBR>(R, tpl, nw) : prefilter_max<(NBR >= 6 ? 6 : NBR), NBR>(R, tpl, nw);
+                    else maxcnt = nb <= 5 ? prefilter_max<(NBR >= 5 ? 5 : NBR), NBR>(R, tpl, nw) : prefilter_max<NBR, NBR>(R, tpl, nw); // 257..320-base reads
                     // bound = max over diagonals; only two threshold tests of it are needed
                     any_match = __any(maxcnt > 0u);
                     may_pass = __any((int)maxcnt >= need_j);
@@ -413,7 +414,8 @@ __global__ __launch_bounds__(NW * 64, 4) void adapter_overlap(
             }
         };
         if (!read_bad && qlen > 0) {
-            if (!has_long && qlen + short_tlen_max - 1 <= 256) stage1(std::integral_constant<int, 4>{});
+            if (MAXLEN == 320) stage1(std::integral_constant<int, 7>{});   // up to (320 + 128) / 64 = 7 blocks
+            else if (!has_long && qlen + short_tlen_max - 1 <= 256) stage1(std::integral_constant<int, 4>{});
             else stage1(std::integral_constant<int, 6>{});
         }
         // ---- stage 2 + the reference's sequential state (stale range, mask, credit), trim.cpp:1003-1071.  With every
@@ -510,6 +512,13 @@ hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const u
         const uint32_t cap = (uint32_t)n_cu * 8u;
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((adapter_overlap<NW, 256>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
+                           n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
+    } else if (max_len <= 320) { // MiSeq 2x300: the register-blocked prefilter with a 16-entry window per plane
+        constexpr int NW = 4;
+        uint32_t grid = (n_reads + NW - 1) / NW;
+        const uint32_t cap = (uint32_t)n_cu * 6u;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL((adapter_overlap<NW, 320>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
                            n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
     } else if (max_len <= 1024) {
         constexpr int NW = 8;
