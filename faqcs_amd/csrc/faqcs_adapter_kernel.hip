@@ -219,33 +219,34 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
             // count of a 64-diagonal block bounds every cell of the block (87 blocks for PhiX, 3-4 for the built-in adapters).  The block with the largest
             // bound is aligned first; a block whose bound is below the best score so far cannot win (ties are decided by
             // the explicit (M, i, j) comparison below, so the visiting order is free).
-            const bool pruned = MAXLEN == 256 && tpl_cached;
+            const bool pruned = MAXLEN <= 320 && tpl_cached;
+            constexpr int NBX = MAXLEN == 320 ? 7 : 6, NAX = NBX + 1; // window blocks / accumulators of the sliding bound pass
             uint32_t *bb = s_bb[wave];
             int first_block = 0;
             if (pruned) {
-                uint32_t Rw[4][14];
+                uint32_t Rw[4][2 * NBX + 2];
                 {
                     const int i00 = (qlen - 1) - lane;
                     const uint32_t sh = (uint32_t)i00 & 31u;
-                    const uint32_t *pp = pl + (i00 >> 5) + PADL - 10;
+                    const uint32_t *pp = pl + (i00 >> 5) + PADL - 2 * (NBX - 1);
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
 #pragma unroll
-                        for (int e = 0; e < 14; ++e) Rw[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
+                        for (int e = 0; e < 2 * NBX + 2; ++e) Rw[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
                 }
                 const uint32_t *tpl = s_tpl + 4 * s_wstart[j];
                 const int nw = (tlen + 31) >> 5, nb = (ndiag + 63) >> 6;
-                uint32_t cnt[7], best = 0;
+                uint32_t cnt[NAX], best = 0;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) cnt[i] = 0;
+                for (int i = 0; i < NAX; ++i) cnt[i] = 0;
 #pragma unroll 1
                 for (int u = 0; u <= nb; ++u) {
                     uint4 t0 = make_uint4(0u, 0u, 0u, 0u), t1 = make_uint4(0u, 0u, 0u, 0u);
                     if (2 * u < nw) t0 = *reinterpret_cast<const uint4 *>(tpl + 8 * u);
                     if (2 * u + 1 < nw) t1 = *reinterpret_cast<const uint4 *>(tpl + 8 * u + 4);
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) {
-                        const int e0 = 12 - 2 * i, e1 = 13 - 2 * i;
+                    for (int i = 0; i < NAX; ++i) {
+                        const int e0 = 2 * NBX - 2 * i, e1 = 2 * NBX + 1 - 2 * i;
                         cnt[i] += __popc((Rw[0][e0] & t0.x) | (Rw[1][e0] & t0.y) | (Rw[2][e0] & t0.z) | (Rw[3][e0] & t0.w));
                         cnt[i] += __popc((Rw[0][e1] & t1.x) | (Rw[1][e1] & t1.y) | (Rw[2][e1] & t1.z) | (Rw[3][e1] & t1.w));
                     }
@@ -255,8 +256,8 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
                         if (bnd > best) { best = bnd; first_block = u - 1; }
                     }
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) cnt[i] = cnt[i + 1];
-                    cnt[6] = 0;
+                    for (int i = 0; i + 1 < NAX; ++i) cnt[i] = cnt[i + 1];
+                    cnt[NAX - 1] = 0;
                 }
                 lds_sync_wave();
             }
@@ -351,31 +352,32 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
                     // bound = max over diagonals; only two threshold tests of it are needed
                     any_match = __any(maxcnt > 0u);
                     may_pass = __any((int)maxcnt >= need_j);
-                } else if (!(dbg & 8u) && MAXLEN == 256 && NBR == 6 && tpl_cached) {
+                } else if (!(dbg & 8u) && MAXLEN <= 320 && NBR >= 6 && tpl_cached) {
                     // long target (PhiX, artifact sequences): the same register windows, sliding over the target two words
-                    // per step.  Words 2u and 2u+1 face exactly the seven blocks u-1 .. u+5 (window index 12-2i / 13-2i for
-                    // block u-1+i); block u-1 has seen all of its words after step u and leaves the 7-deep accumulator.
+                    // per step.  Words 2u and 2u+1 face exactly the NBR+1 blocks u-1 .. u+NBR-1 (window index 2 NBR - 2i and
+                    // 2 NBR + 1 - 2i for block u-1+i); block u-1 has seen all of its words after step u and leaves the accumulator.
+                    constexpr int NACC = NBR + 1;
                     const uint32_t *tpl = s_tpl + 4 * (sa >> 16);
                     const int nw = (tlen + 31) >> 5;
                     const int nb = (qlen + tlen - 1 + 63) >> 6;
-                    uint32_t cnt[7], maxcnt = 0;
+                    uint32_t cnt[NACC], maxcnt = 0;
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) cnt[i] = 0;
+                    for (int i = 0; i < NACC; ++i) cnt[i] = 0;
 #pragma unroll 1
                     for (int u = 0; u <= nb; ++u) {
                         uint4 t0 = make_uint4(0u, 0u, 0u, 0u), t1 = make_uint4(0u, 0u, 0u, 0u);
                         if (2 * u < nw) t0 = *reinterpret_cast<const uint4 *>(tpl + 8 * u);
                         if (2 * u + 1 < nw) t1 = *reinterpret_cast<const uint4 *>(tpl + 8 * u + 4);
 #pragma unroll
-                        for (int i = 0; i < 7; ++i) {
-                            const int e0 = 12 - 2 * i, e1 = 13 - 2 * i;
+                        for (int i = 0; i < NACC; ++i) {
+                            const int e0 = 2 * NBR - 2 * i, e1 = 2 * NBR + 1 - 2 * i;
                             cnt[i] += __popc((R[0][e0] & t0.x) | (R[1][e0] & t0.y) | (R[2][e0] & t0.z) | (R[3][e0] & t0.w));
                             cnt[i] += __popc((R[0][e1] & t1.x) | (R[1][e1] & t1.y) | (R[2][e1] & t1.z) | (R[3][e1] & t1.w));
                         }
                         maxcnt = umax_(maxcnt, cnt[0]);
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) cnt[i] = cnt[i + 1];
-                        cnt[6] = 0;
+                        for (int i = 0; i + 1 < NACC; ++i) cnt[i] = cnt[i + 1];
+                        cnt[NACC - 1] = 0;
                     }
                     any_match = __any(maxcnt > 0u);
                     may_pass = __any((int)maxcnt >= need_j);

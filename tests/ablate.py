@@ -19,9 +19,9 @@ dbg = sys.argv[1]
 os.environ["FAQCS_DBG"] = dbg
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 8_000_000
 extra = sys.argv[3:]
-L = 150
+L = int(__import__("os").environ.get("FAQCS_ABLATE_L", "150"))
 opt = parse_args(["-u", "x", "-d", "y", "--ascii", "33"] + extra)
-eng = HipEngine(opt, 256, 33, device=0)
+eng = HipEngine(opt, 256 if L <= 256 else 1024, 33, device=0)
 lib = eng.lib
 dev = torch.device("cuda:0")
 seq = torch.empty(n * L + 64, dtype=torch.uint8, device=dev)

@@ -120,15 +120,16 @@ def test_long_reads_match_oracle(args, kind, maxlen):
     compare_engines(opt, reads, R=1024, seg_size=117)
 
 
+@pytest.mark.parametrize("maxlen", [150, 300])
 @pytest.mark.parametrize("args", [["--phiX"], ["--adapter", "--polyA", "--phiX", "--min_L", "20"]], ids=["phix", "adapter+phix"])
-def test_phix_reads_match_oracle(args):
+def test_phix_reads_match_oracle(args, maxlen):
     """Long targets (2 x 5 386-base PhiX): the sliding-window prefilter and the exact stage on true PhiX reads (both strands,
     with substitutions, partial overlaps at the genome ends) mixed with random reads."""
     import make_fixtures
 
     from faqcs_amd import options
 
-    rng = np.random.Generator(np.random.PCG64([11, len(args), SEED]))
+    rng = np.random.Generator(np.random.PCG64([11, len(args), SEED, maxlen]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     phix = np.frombuffer(options.phix_sequence().encode(), np.uint8) if hasattr(options, "phix_sequence") else None
     if phix is None:
@@ -137,9 +138,9 @@ def test_phix_reads_match_oracle(args):
     reads = []
     for i in range(600):
         if i % 3 == 0:
-            s, q = make_fixtures._adv_read(rng, 150)
+            s, q = make_fixtures._adv_read(rng, maxlen)
         else:
-            L = int(rng.integers(30, 151))
+            L = int(rng.integers(30, maxlen + 1))
             p0 = int(rng.integers(-40, len(phix) - L + 40))
             lo = min(max(p0, 0), len(phix))
             hi = max(lo, min(p0 + L, len(phix)))
@@ -150,7 +151,7 @@ def test_phix_reads_match_oracle(args):
             s = make_fixtures._mutate(rng, s, float(rng.choice([0.0, 0.03, 0.15, 0.3])))
             q = (rng.integers(20, 41, L) + 33).astype(np.uint8)
         reads.append((b"@p", bytes(s.tobytes()), bytes(q.tobytes())))
-    compare_engines(opt, reads, seg_size=211)
+    compare_engines(opt, reads, R=256 if maxlen <= 256 else 1024, seg_size=211)
 
 
 def test_long_read_limits():
