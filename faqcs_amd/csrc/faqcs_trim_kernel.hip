@@ -977,8 +977,12 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
     // long reads: the whole wave on one read, one superset variant per width (MiSeq 2x300 -> C = 5)
     {   // two reads per wave (32 lanes each) up to 512 bases; FAQCS_TRIM_LPR32=0 falls back to the whole wave per read
         static const bool lpr32 = [] { const char *e = getenv("FAQCS_TRIM_LPR32"); return !e || atoi(e) != 0; }();
-        if (lpr32 && max_len <= 320) return launch_trim_t<10, 32, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
-        if (lpr32 && max_len <= 512) return launch_trim_t<16, 32, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
+        if (lpr32 && max_len <= 320) // MiSeq 2x300: all four option variants like the short-read kernels
+            return windowed ? (generic ? launch_trim_t<10, 32, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<10, 32, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS))
+                            : (generic ? launch_trim_t<10, 32, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<10, 32, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS));
+        if (lpr32 && max_len <= 512)
+            return (windowed || generic) ? launch_trim_t<16, 32, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS)
+                                         : launch_trim_t<16, 32, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS);
     }
     if (max_len <= 320) return launch_trim_t<5, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
     if (max_len <= 512) return launch_trim_t<8, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
