@@ -255,7 +255,7 @@ __device__ __noinline__ void flush_hq8(uint32_t *smem, uint64_t *counters, const
 // GENERIC: false = the headline option set (BWA_plus, 5' trimming on, not --qc_only, no --replace_to_N_q, no
 // --avg_q, -n 2) is compiled in, so those tests and their live scalars disappear from the loop.
 template <int C, int LPR, int NW, bool WINDOWED, bool GENERIC>
-__global__ __launch_bounds__(NW * 64, (LPR == 8 || (LPR == 16 && C > 10) || (LPR == 32 && C > 10)) ? 2 : FAQCS_TRIM_MINWAVES) void trim_filter_accumulate(
+__global__ __launch_bounds__(NW * 64, (LPR == 8 || C > 10) ? 2 : FAQCS_TRIM_MINWAVES) void trim_filter_accumulate(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
@@ -935,7 +935,7 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
     const uint32_t chunks = (n_reads + 63) / 64;
     int blocks_per_cu = (int)((160 * 1024) / lds);
     // (variants whose per-position arrays do not fit 168 VGPRs run at 2 waves/SIMD rather than spill: the kernel is issue-bound)
-    constexpr int minwaves = (LPR == 8 || (LPR == 16 && C > 10) || (LPR == 32 && C > 10)) ? 2 : (FAQCS_TRIM_MINWAVES > 2 ? FAQCS_TRIM_MINWAVES : 2);
+    constexpr int minwaves = (LPR == 8 || C > 10) ? 2 : (FAQCS_TRIM_MINWAVES > 2 ? FAQCS_TRIM_MINWAVES : 2);
     const int by_waves = (4 * minwaves + NW - 1) / NW; // resident waves per CU the registers allow
     if (blocks_per_cu > by_waves) blocks_per_cu = by_waves;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
