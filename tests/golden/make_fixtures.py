@@ -176,6 +176,11 @@ def materialise(name, outdir):
         r1, r2 = headline(3000, 150, adapter_frac=0.05)
     elif name == "head250":
         r1, r2 = headline(1200, 250)
+    elif name == "adv64":  # the adversarial set re-encoded as Phred+64 (pre-1.8 Illumina)
+        r1, r2 = adversarial(600, seed=41)
+        up = bytes((min(255, c + 31) if c >= 33 else c) for c in range(256))
+        r1 = [(d, sq, q.translate(up)) for d, sq, q in r1]
+        r2 = [(d, sq, q.translate(up)) for d, sq, q in r2]
     elif name == "errq":  # a quality byte above Q41: the reference throws from quality_score() (fastq.h:31-33)
         r1, r2 = adversarial(200, seed=31)
         d, sq, q = r1[57]

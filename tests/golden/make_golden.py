@@ -69,6 +69,11 @@ CASES = [
     ("long1000_bwa_avgq", "long1000", P + ["--mode", "BWA", "--avg_q", "20", "-n", "3"]),
     ("long1000_hard_lc", "long1000", P + ["--mode", "HARD", "-q", "12", "--lc", "0.6", "--5end", "7", "--3end", "9"]),
     ("long1000_adapter_polyA", "long1000", P + ["--adapter", "--polyA", "--discard"]),
+    ("adv_prefix_stats", "adv", P + ["--prefix", "SAMPLE7", "--stats", "ignored_by_the_reference.txt"]),
+    ("adv_single_dash_long_options", "adv", ["-1", "{1}", "-2", "{2}", "-d", "{D}", "-t", "1", "-debug", "-min_L", "40", "-q", "12", "-lc", "0.7", "-discard", "-substitute"]),
+    ("adv64_autodetect", "adv64", P),
+    ("adv64_ascii64_out33", "adv64", P + ["--ascii", "64", "--out_ascii", "33"]),
+    ("adv_t8_no_adapter", "adv", ["-1", "{1}", "-2", "{2}", "-d", "{D}", "-t", "8", "--debug", "-n", "3"]),
     ("err_quality_above_41", "errq", P),
     ("err_unknown_base_adapter", "errbase", P + ["--adapter"]),
     ("err_unknown_base_no_adapter", "errbase", P),
