@@ -45,9 +45,9 @@ template <int C, int LPR> struct RowCfg {
     static constexpr int D = (C + 3) / 4;          // dwords per lane per arena
     static constexpr int W = LPR * C;              // positions covered by a row == columns of the LDS matrices
     // position x quality in LDS: one dword per cell (pre count lo16 / post count hi16) while that fits next to the
-    // other tables (W <= 512); wider rows pack two cells per dword as 8-bit pre/post counters and the block flushes
+    // other tables (W <= 768); wider rows pack two cells per dword as 8-bit pre/post counters and the block flushes
     // them every 16 reads per wave (HQ8_EVERY x NW <= 255 increments per cell between flushes)
-    static constexpr bool HQ8 = W > 512;
+    static constexpr bool HQ8 = W > 768;           // (768 wide: 158 KB of the CU's 160 KB LDS, one block per CU)
     static constexpr int HQ8_EVERY = 16;
     static constexpr int HQ = HQ8 ? FAQCS_NQ * W / 2 : FAQCS_NQ * W;
     // |sum of (Q - q)| <= W * 168: key bias and the bit width of a position field inside the argmax keys
@@ -987,6 +987,7 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
     }
     if (max_len <= 320) return launch_trim_t<5, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
     if (max_len <= 512) return launch_trim_t<8, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
+    if (max_len <= 768) return launch_trim_t<12, 64, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS);
     if (max_len <= 1024) return launch_trim_t<16, 64, 8, true, true>(FAQCS_TRIM_ARGS); // 8 x 16 reads <= 255 per 8-bit cell
 #undef FAQCS_TRIM_CASE
 #undef FAQCS_TRIM_ARGS

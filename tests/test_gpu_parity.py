@@ -110,9 +110,9 @@ def test_random_batches_match_oracle(args, kind, maxlen):
 
 
 @pytest.mark.parametrize("args", OPTION_SETS, ids=lambda a: " ".join(a) or "default")
-@pytest.mark.parametrize("kind,maxlen", [("adv", 300), ("ragged", 500), ("adv", 1024)])
+@pytest.mark.parametrize("kind,maxlen", [("adv", 300), ("ragged", 500), ("ragged", 700), ("adv", 1024)])
 def test_long_reads_match_oracle(args, kind, maxlen):
-    """Reads past the 256-base row kernels: the 64-lanes-per-read variants (widths 320 / 512 / 1024)."""
+    """Reads past 256 bases: 32 lanes per read (widths 320 / 512) and the whole wave per read (768 / 1024)."""
     rng = np.random.Generator(np.random.PCG64([7, len(kind), maxlen, OPTION_SETS.index(args), SEED]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     n = 150 if "--adapter" in args else 500
