@@ -167,6 +167,38 @@ template <> struct RowOps<8> {
 // 32 lanes per read (two reads per wave, reads of 257..512 bases): row butterflies / scans plus ONE cross-row step --
 // ds_swizzle (xor 16 inside each group of 32 lanes, no LDS memory touched) for reductions, row_bcast:15 into the odd rows
 // for scans.
+// 4 lanes per read (16 reads per wave, reads <= 76 bases): everything stays inside a DPP quad.
+template <> struct RowOps<4> {
+#define FAQCS_QUAD_ALL(OP)                                                             \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));                \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+    static __device__ __forceinline__ int all_sum(int v) { FAQCS_QUAD_ALL(op_add_) return v; }
+    static __device__ __forceinline__ uint32_t all_or(uint32_t x) { int v = (int)x; FAQCS_QUAD_ALL(op_or_) return (uint32_t)v; }
+    static __device__ __forceinline__ uint32_t all_umax(uint32_t x) { int v = (int)x; FAQCS_QUAD_ALL(op_umax_) return (uint32_t)v; }
+#undef FAQCS_QUAD_ALL
+    static __device__ __forceinline__ int ge_(int k) { return ((int)(threadIdx.x & 3u) >= k) ? -1 : 0; }
+    static __device__ __forceinline__ int incl_scan_add(int v)
+    {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x90, 0xf, 0xf, false) & ge_(1); // quad_perm [0,0,1,2]: lane i <- i-1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x44, 0xf, 0xf, false) & ge_(2); // quad_perm [0,1,0,1]: lane i <- i-2
+        return v;
+    }
+    static __device__ __forceinline__ uint32_t incl_scan_umax(uint32_t x)
+    {
+        int v = (int)x;
+        v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x90, 0xf, 0xf, false) & ge_(1));
+        v = op_umax_(v, __builtin_amdgcn_update_dpp(0, v, 0x44, 0xf, 0xf, false) & ge_(2));
+        return (uint32_t)v;
+    }
+    static __device__ __forceinline__ uint32_t next(uint32_t v)
+    {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF9, 0xf, 0xf, false) & (((threadIdx.x & 3u) == 3u) ? 0u : 0xffffffffu); // [1,2,3,3]
+    }
+    static __device__ __forceinline__ uint32_t prev(uint32_t v)
+    {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x90, 0xf, 0xf, false) & (uint32_t)ge_(1);
+    }
+};
 template <> struct RowOps<32> {
     static __device__ __forceinline__ int swap_rows(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x401f); } // and 0x1f, or 0, xor 0x10
     static __device__ __forceinline__ int all_sum(int v) { v = row_all_sum(v); return v + swap_rows(v); }

@@ -5,7 +5,8 @@
 //
 // Mapping.  LPR lanes share one read and lane l of the group owns the C consecutive positions [l*C, l*C+C), fetched
 // with ONE unaligned global_load_dwordx{D} per arena; a wave takes chunks of 64 reads.
-//   LPR =  8  reads <= 160 bases (C = 8 / 14 / 20): eight reads per wave, two per 16-lane DPP row
+//   LPR =  4  reads <= 76 bases (C = 16 / 19):      sixteen reads per wave, one per DPP quad
+//   LPR =  8  reads <= 160 bases (C = 8 ... 20):    eight reads per wave, two per 16-lane DPP row
 //   LPR = 16  reads <= 256 bases (C = 4 ... 16):    four reads per wave, one per DPP row
 //   LPR = 32  reads <= 512 bases (C = 10 / 16):     two reads per wave
 //   LPR = 64  reads <= 1024 bases (C = 16; 5 / 8 as the A/B fallback of LPR = 32): the whole wave on one read
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || C > 10) ? 2 : FAQCS_TRIM_MINW
     const uint32_t n_iter = (total_chunks + chunks_per_iter - 1) / chunks_per_iter;
     constexpr uint32_t FLUSH_EVERY = 65535u / (NW * 64) > 0 ? 65535u / (NW * 64) : 1;
     // 6-bit fields: 3 chunks x 16 reads per row = 48 <= 63; a 64-lane row sees 64 reads per chunk and spills mid-chunk too
-    constexpr uint32_t REG_FLUSH_EVERY = LPR == 16 ? 3 : (LPR == 8 ? 7 : 1); // 32 lanes: 32 reads per chunk; 64: spills mid-chunk too
+    constexpr uint32_t REG_FLUSH_EVERY = LPR == 16 ? 3 : (LPR == 8 ? 7 : (LPR == 4 ? 15 : 1)); // 32 lanes: 32 reads per chunk; 64: spills mid-chunk too
 
     const int in_off = P.in_off, Q = P.Q;
     const int o_mode = GENERIC ? P.mode : (int)FAQCS_MODE_BWA_PLUS;
@@ -965,6 +966,15 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
 #define FAQCS_TRIM_CASE8(C)                                                                                 \
     return windowed ? (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS)) \
                     : (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS))
+        {   // 4 lanes per read (16 reads per wave): reads <= 76 bases (2x75, 2x50); FAQCS_TRIM_LPR4=0 switches it off
+            static const bool lpr4 = [] { const char *e = getenv("FAQCS_TRIM_LPR4"); return !e || atoi(e) != 0; }();
+#define FAQCS_TRIM_CASE4(C)                                                                                 \
+    return windowed ? (generic ? launch_trim_t<C, 4, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 4, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS)) \
+                    : (generic ? launch_trim_t<C, 4, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 4, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS))
+            if (lpr4 && max_len <= 64) FAQCS_TRIM_CASE4(16);
+            if (lpr4 && max_len <= 76) FAQCS_TRIM_CASE4(19);
+#undef FAQCS_TRIM_CASE4
+        }
         if (lpr8 && max_len <= 64) FAQCS_TRIM_CASE8(8);
         if (lpr8 && max_len <= 104) FAQCS_TRIM_CASE8(13);   // 2x100
         if (lpr8 && max_len <= 128) FAQCS_TRIM_CASE8(16);
