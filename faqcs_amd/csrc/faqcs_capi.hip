@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -305,7 +306,9 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
         return fail(FAQCS_E_NODEVICE, "faqcs_create: no HIP device (the FaQCs MI355X hot path has no CPU fallback)");
     if (device_id < 0) HIPCHK(hipGetDevice(&device_id));
     HIPCHK(hipSetDevice(device_id));
-    faqcs_ctx *c = new faqcs_ctx();
+    // owned by a guard until every allocation below has succeeded: an early HIPCHK return must not leak the context
+    std::unique_ptr<faqcs_ctx, void (*)(faqcs_ctx *)> guard(new faqcs_ctx(), faqcs_destroy);
+    faqcs_ctx *c = guard.get();
     c->prm = *p;
     c->prm.adapter_seq = nullptr;
     c->device = device_id;
@@ -335,11 +338,11 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
         for (uint32_t j = 0; j < p->n_adapters; ++j) {
             const char *s = p->adapter_seq[j];
             const size_t L = strlen(s);
-            if (L == 0 || L > FAQCS_MAX_ADAPTER_LENGTH) { delete c; return fail(FAQCS_E_INVAL, "faqcs_create: adapter length out of range"); }
+            if (L == 0 || L > FAQCS_MAX_ADAPTER_LENGTH) return fail(FAQCS_E_INVAL, "faqcs_create: adapter length out of range");
             c->adapters.emplace_back(s);
             for (size_t k = 0; k < L; ++k) {
                 const uint8_t b = na_to_bits_host(s[k]);
-                if (!b) { delete c; return fail(FAQCS_E_BASE, "seq_overlap.cpp:na_to_bits: Unknown base!"); }
+                if (!b) return fail(FAQCS_E_BASE, "seq_overlap.cpp:na_to_bits: Unknown base!");
                 bits.push_back(b);
             }
             start.push_back((uint32_t)bits.size());
@@ -384,7 +387,7 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
         c->snap_cap = 4096;
         HIPCHK(hipMalloc((void **)&c->d_snaps, c->snap_cap * 16));
     }
-    *out = c;
+    *out = guard.release();
     return 0;
 }
 
