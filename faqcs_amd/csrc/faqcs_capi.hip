@@ -300,6 +300,8 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     if (p->max_read_length == 0 || p->max_read_length > FAQCS_MAX_READ_LENGTH) return fail(FAQCS_E_INVAL, "faqcs_create: max_read_length out of range");
     if (p->n_adapters > FAQCS_MAX_ADAPTERS) return fail(FAQCS_E_INVAL, "faqcs_create: too many adapters");
     if (p->mode < 0 || p->mode > 2) return fail(FAQCS_E_INVAL, "trim.cpp:trim_read: Undefined trimming mode!");
+    // the argmax keys of the trim kernel hold |sum of (Q - q)| <= 1024 * (|Q| + 41) in 18 bits (16 for reads <= 256 bases)
+    if (p->quality < -93 || p->quality > 93) return fail(FAQCS_E_INVAL, "faqcs_create: quality threshold outside [-93, 93]");
     if (p->kmer_rarefaction && (p->kmer < 2 || p->kmer > 31 || p->split_size == 0)) return fail(FAQCS_E_INVAL, "faqcs_create: kmer / split_size out of range");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -417,6 +419,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
 extern "C" int faqcs_set_quality(faqcs_ctx *c, int quality)
 {
     if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    if (quality < -93 || quality > 93) return fail(FAQCS_E_INVAL, "faqcs_set_quality: quality threshold outside [-93, 93]");
     c->prm.quality = quality;
     c->dp.Q = quality;
     return 0;
