@@ -369,7 +369,9 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     DevParams &d = c->dp;
     memset(&d, 0, sizeof(d));
     d.mode = p->mode; d.Q = p->quality; d.in_off = p->input_quality_offset; d.out_off = p->output_quality_offset;
-    d.min_len = p->min_read_length; d.max_poly_n = p->max_num_poly_N; d.trim5 = p->trim_5; d.trim3 = p->trim_3;
+    // (anything above the longest read behaves like the longest read + 1; the kernels compare these as ints)
+    auto cap16 = [](uint32_t v) { return v > 65535u ? 65535u : v; };
+    d.min_len = cap16(p->min_read_length); d.max_poly_n = cap16(p->max_num_poly_N); d.trim5 = cap16(p->trim_5); d.trim3 = cap16(p->trim_3);
     d.replace_q = p->replace_to_N_q; d.protect5 = p->protect_5; d.qc_only = p->qc_only;
     d.has_adapters = p->n_adapters ? 1 : 0; d.avgq_on = p->average_quality > 0.0f ? 1 : 0;
     d.R = p->max_read_length; d.n_adapters = p->n_adapters;
