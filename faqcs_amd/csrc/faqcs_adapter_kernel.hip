@@ -61,6 +61,18 @@ __device__ __forceinline__ void lds_sync_wave()
 // built ONCE per read (40 or 56 v_alignbit) and every (block, word) step is 4 and/or + 1 popcount on registers -- no LDS read,
 // no shift.  Returns the largest per-diagonal match count of this lane.
 // NBR = blocks the window array covers (4 when |read| + |longest short adapter| - 1 <= 256, else 6): e = w - 2 b + 2 (NBR - 1)
+// (x & y) | z in ONE instruction; the compiler otherwise pairs the four plane ANDs as and + and + or3
+__device__ __forceinline__ uint32_t and_or_(uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ uint32_t plane_match(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, const uint4 &t)
+{
+    return and_or_(r3, t.w, and_or_(r2, t.z, and_or_(r1, t.y, r0 & t.x)));
+}
+
 template <int NB, int NBR>
 __device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][2 * NBR + 2], const uint32_t *tpl, const int nw)
 {
@@ -74,7 +86,7 @@ __device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][2 * NBR
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int e = w - 2 * b + 2 * (NBR - 1);
-                cnt[b] += __popc((R[0][e] & t.x) | (R[1][e] & t.y) | (R[2][e] & t.z) | (R[3][e] & t.w));
+                cnt[b] += __popc(plane_match(R[0][e], R[1][e], R[2][e], R[3][e], t));
             }
         }
     }
@@ -247,8 +259,8 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
 #pragma unroll
                     for (int i = 0; i < NAX; ++i) {
                         const int e0 = 2 * NBX - 2 * i, e1 = 2 * NBX + 1 - 2 * i;
-                        cnt[i] += __popc((Rw[0][e0] & t0.x) | (Rw[1][e0] & t0.y) | (Rw[2][e0] & t0.z) | (Rw[3][e0] & t0.w));
-                        cnt[i] += __popc((Rw[0][e1] & t1.x) | (Rw[1][e1] & t1.y) | (Rw[2][e1] & t1.z) | (Rw[3][e1] & t1.w));
+                        cnt[i] += __popc(plane_match(Rw[0][e0], Rw[1][e0], Rw[2][e0], Rw[3][e0], t0));
+                        cnt[i] += __popc(plane_match(Rw[0][e1], Rw[1][e1], Rw[2][e1], Rw[3][e1], t1));
                     }
                     if (u >= 1) { // block u-1 is complete
                         const uint32_t bnd = wave_max_u32(cnt[0]);
@@ -371,8 +383,8 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
 #pragma unroll
                         for (int i = 0; i < NACC; ++i) {
                             const int e0 = 2 * NBR - 2 * i, e1 = 2 * NBR + 1 - 2 * i;
-                            cnt[i] += __popc((R[0][e0] & t0.x) | (R[1][e0] & t0.y) | (R[2][e0] & t0.z) | (R[3][e0] & t0.w));
-                            cnt[i] += __popc((R[0][e1] & t1.x) | (R[1][e1] & t1.y) | (R[2][e1] & t1.z) | (R[3][e1] & t1.w));
+                            cnt[i] += __popc(plane_match(R[0][e0], R[1][e0], R[2][e0], R[3][e0], t0));
+                            cnt[i] += __popc(plane_match(R[0][e1], R[1][e1], R[2][e1], R[3][e1], t1));
                         }
                         maxcnt = umax_(maxcnt, cnt[0]);
 #pragma unroll
