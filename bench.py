@@ -37,8 +37,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_PAIRS", 100e6)),
                     help="pairs per GPU resident in HBM (default: the 100 M pairs of BASELINE configs[1])")
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--config", choices=["plain", "adapter"], default="plain")
+    ap.add_argument("--read-len", type=int, default=None, help="default 150 (250 for --config kmer)")
+    ap.add_argument("--config", choices=["plain", "adapter", "kmer"], default="plain",
+                    help="plain = BASELINE configs[1] (the headline), adapter = configs[2], kmer = configs[4]'s shape on one GPU")
     ap.add_argument("--batch-reads", type=int, default=1 << 24, help="reads per submission (u32 offsets: < 4 GiB arena)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -120,10 +121,15 @@ def main():
     from faqcs_amd.engine import HipEngine, _check
     from faqcs_amd.options import parse_args
 
-    L = a.read_len
-    opt_args = ["--adapter", "--polyA"] if a.config == "adapter" else []
+    if a.config == "kmer" and world > 1:
+        raise SystemExit("bench: --config kmer measures one GPU (the multi-GPU k-mer exchange is faqcs_amd/parallel.py:KmerExchange)")
+    L = a.read_len or (250 if a.config == "kmer" else 150)
+    if a.config == "kmer" and a.pairs == 100e6:
+        a.pairs = 10e6  # 20 M reads of 250 bases from a 50 Mbp synthetic genome: 4.4 G k-mer occurrences per step
+    opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "1000000"]}.get(a.config, [])
     opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
-    eng = HipEngine(opt, 256 if L <= 256 else capi.MAX_READ_LENGTH, 33, device=local)
+    eng = HipEngine(opt, 256 if L <= 256 else capi.MAX_READ_LENGTH, 33, device=local,
+                    kmer_table_slots=(1 << 31) if a.config == "kmer" else 0)
     lib = eng.lib
 
     # ---- resident synthetic data set ---------------------------------------------------------------------
@@ -143,7 +149,10 @@ def main():
         qual = torch.empty(m * L + 64, dtype=torch.uint8, device=dev)
         off = torch.empty(m + 1, dtype=torch.int32, device=dev)
         res = torch.empty((m, 4), dtype=torch.int16, device=dev)
-        _check(lib, lib.faqcs_synth_fill(local, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, L, 20260101, first + done, adapter_frac))
+        if a.config == "kmer":  # windows of a fixed 50 Mbp genome, either strand, 0.5 % substitutions
+            _check(lib, lib.faqcs_synth_fill_genome(local, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, L, 20260101, first + done, 50_000_000))
+        else:
+            _check(lib, lib.faqcs_synth_fill(local, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, L, 20260101, first + done, adapter_frac))
         # the reference's 32 768-read trim() granularity only matters to the adapter pre-pass (groups of 8)
         seg = np.arange(0, m + capi.SEGMENT_READS, capi.SEGMENT_READS, dtype=np.uint32)
         seg[-1] = m
@@ -154,8 +163,13 @@ def main():
         done += m
     torch.cuda.synchronize()
 
+    kmer_seen = [0, 0]
+
     def step():
         _check(lib, lib.faqcs_reset_counters(eng.ctx))  # one step = one job: its counter block starts at zero
+        if a.config == "kmer":  # ... and so does its k-mer table (the totals of the finished pass are kept for the report)
+            kmer_seen[0], kmer_seen[1] = eng.kmer_totals()
+            eng.kmer_end_table()
         for (_s, _q, _o, res, _seg, bt, _m) in batches:
             _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(bt), res.data_ptr()))
         if world > 1:
@@ -211,15 +225,21 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synthetic %.0fM-pair 2x%dbp Q33 reads resident in HBM per GPU, BWA_plus -q 5 --min_L 50%s, "
                                    "1 step = 1 pass (trim_filter_accumulate%s + counter all-reduce)"
-                                   % (n_reads / 2e6, L, " --adapter --polyA (5 percent read-through)" if a.config == "adapter" else "",
-                                      " after adapter_overlap" if a.config == "adapter" else ""),
+                                   % (n_reads / 2e6, L, {"adapter": " --adapter --polyA (5 percent read-through)", "kmer": " --kmer_rarefaction, genome-sampled reads"}.get(a.config, ""),
+                                      {"adapter": " after adapter_overlap", "kmer": " + kmer_count"}.get(a.config, "")),
                        "pairs_per_gpu": n_reads // 2, "read_len": L, "launches_per_step": len(batches) * (2 if a.config == "adapter" else 1),
                        "M_pairs_per_s": round(value / 2, 3)},
+        }
+        if a.config == "kmer":
+            d_, t_ = eng.kmer_totals()
+            out["kmer"] = {"G_inserts_per_s": round(t_ / (dt / a.steps) / 1e9, 3), "distinct_per_step": int(d_), "occurrences_per_step": int(t_),
+                           "note": "canonical 31-mers of the kept reads into the device hash table (reset every step); bound by the L2 atomic rate"}
+        out.update({
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "trim_filter_accumulate",
                          "kernel_ms": round(avg_ms.value, 4), "launches": int(nl.value),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
-        }
+        })
         if world == 1 and not a.no_cpu_baseline:
             ns = min(400000, batches[0][6])
             hs = batches[0][0][: ns * L].cpu().numpy()

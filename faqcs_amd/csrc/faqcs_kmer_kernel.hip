@@ -263,34 +263,56 @@ __global__ __launch_bounds__(256) void kmer_insert_items(const KmerTable T, cons
 }
 
 // owner side: distinct_by_first_epoch[e] = number of keys whose smallest epoch is e
-__global__ void kmer_first_epoch_histogram(const KmerTable T, unsigned long long *hist, const uint32_t n_epochs)
+__global__ __launch_bounds__(256) void kmer_first_epoch_histogram(const KmerTable T, unsigned long long *hist, const uint32_t n_epochs)
 {
+    constexpr uint32_t LOCAL = 4096; // (block-local first: a handful of epochs from 10^8+ slots would serialise in L2)
+    __shared__ uint32_t h[LOCAL];
+    for (uint32_t i = threadIdx.x; i < LOCAL; i += blockDim.x) h[i] = 0;
+    __syncthreads();
     const uint64_t slots = T.mask + 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t per_block = (slots + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = lo + per_block < slots ? lo + per_block : slots;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const KmerSlot sl = T.slots[i];
         if (sl.key != ~0ull) {
             const uint32_t e = sl.first_epoch;
-            if (e < n_epochs) atomicAdd(&hist[e], 1ull);
+            if (e < LOCAL && e < n_epochs) atomicAdd(&h[e], 1u);
+            else if (e < n_epochs) atomicAdd(&hist[e], 1ull);
         }
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < LOCAL && i < n_epochs; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
-// histogram of counts over the table (FaQCs.cpp:518-521): dense[c] for c < dense_n, (count) list otherwise
-__global__ void kmer_count_histogram(const KmerTable T, unsigned long long *dense, uint32_t dense_n,
-                                     unsigned long long *big, unsigned long long *n_big, uint32_t big_cap)
+// histogram of counts over the table (FaQCs.cpp:518-521): dense[c] for c < dense_n, (count) list otherwise.
+// Nearly every key of a real run has one of a few hundred small counts: the block counts those in LDS first (global
+// atomics on a few hundred addresses from 10^8..10^9 slots serialise in L2 -- seconds on a 34 GB table).
+__global__ __launch_bounds__(256) void kmer_count_histogram(const KmerTable T, unsigned long long *dense, uint32_t dense_n,
+                                                            unsigned long long *big, unsigned long long *n_big, uint32_t big_cap)
 {
+    constexpr uint32_t LOCAL = 4096;
+    __shared__ uint32_t h[LOCAL];
+    for (uint32_t i = threadIdx.x; i < LOCAL; i += blockDim.x) h[i] = 0;
+    __syncthreads();
     const uint64_t slots = T.mask + 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t per_block = (slots + gridDim.x - 1) / gridDim.x; // contiguous slice per block: < 2^32 slots each
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = lo + per_block < slots ? lo + per_block : slots;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const KmerSlot sl = T.slots[i];
         if (sl.key != ~0ull) {
             const uint32_t c = sl.count_m1 + 1u;
-            if (c < dense_n) atomicAdd(&dense[c], 1ull);
+            if (c < LOCAL && c < dense_n) atomicAdd(&h[c], 1u);
+            else if (c < dense_n) atomicAdd(&dense[c], 1ull);
             else {
                 const unsigned long long s = atomicAdd(n_big, 1ull);
                 if (s < big_cap) big[s] = c;
             }
         }
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < LOCAL; i += blockDim.x)
+        if (h[i]) atomicAdd(&dense[i], (unsigned long long)h[i]);
 }
 
 hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T, const uint8_t *seq, const uint8_t *qual,

@@ -18,6 +18,7 @@ python3 bench.py --read-len 100 --pairs 60e6 --no-cpu-baseline > $out/bench_plai
 python3 bench.py --read-len 75 --pairs 60e6 --no-cpu-baseline > $out/bench_plain_75bp_60Mpairs.json 2>> $out/bench_plain.err
 python3 bench.py --read-len 600 --pairs 8e6 --no-cpu-baseline > $out/bench_plain_600bp_8Mpairs.json 2>> $out/bench_plain.err
 python3 bench.py --config adapter --read-len 300 --pairs 4e6 --no-cpu-baseline > $out/bench_adapter_300bp_4Mpairs.json 2>> $out/bench_adapter.err
+python3 bench.py --config kmer --no-cpu-baseline --steps 3 > $out/bench_kmer_250bp_10Mpairs.json 2>> $out/bench_plain.err
 fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_plain -o plain -- python3 bench.py --pairs 25165824 --steps 3 --no-cpu-baseline > $out/prof_plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_adapter -o adapter -- python3 bench.py --config adapter --pairs 4e6 --steps 3 --no-cpu-baseline > $out/prof_adapter.log 2>&1
