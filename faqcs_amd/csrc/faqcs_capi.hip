@@ -38,10 +38,14 @@ struct KmerOutbox {
     ulonglong2 *items;
     unsigned long long *dest_count, *dest_offset, *dest_cursor;
     uint32_t world;
+    uint32_t *wave_count;
+    unsigned long long *wave_offset;
+    uint32_t total_waves;
 };
+uint32_t faqcs_kmer_extract_waves(uint32_t n_reads, int n_cu);
 hipError_t faqcs_launch_kmer_extract(const DevParams &P, uint32_t k, const KmerOutbox &O, bool fill, const uint8_t *seq,
                                      const uint8_t *qual, const uint32_t *off, uint32_t r_begin, uint32_t r_end,
-                                     const faqcs_read_result *results, uint32_t epoch, int n_cu, hipStream_t st);
+                                     const faqcs_read_result *results, uint32_t epoch, uint32_t wave_base, int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_outbox_offsets(const KmerOutbox &O, hipStream_t st);
 hipError_t faqcs_launch_kmer_insert_items(const KmerTable &T, const void *items, unsigned long long n,
                                           unsigned long long *tot_by_epoch, uint32_t n_epochs, int n_cu, hipStream_t st);
@@ -141,6 +145,8 @@ struct faqcs_ctx {
     uint32_t part_rank = 0, part_world = 1, n_epochs = 0;
     std::vector<uint32_t> seg_epoch;             // epochs of the NEXT submission's segments
     DevBuf<ulonglong2> ob_items;
+    DevBuf<uint32_t> ob_wave_count;
+    DevBuf<unsigned long long> ob_wave_offset;
     unsigned long long *d_ob = nullptr;          // [3 * world]: dest_count, dest_offset, dest_cursor
     unsigned long long *d_tot_by_epoch = nullptr, *d_first_hist = nullptr; // [n_epochs] each
     unsigned long long *d_snaps = nullptr; // [snap_cap][2]
@@ -411,7 +417,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
     for (auto &rs : c->rec) { rs.pre.release(); rs.post.release(); if (rs.trimmed) (void)hipEventDestroy(rs.trimmed); if (rs.folded) (void)hipEventDestroy(rs.folded); }
     if (c->aux) (void)hipStreamDestroy(c->aux);
-    c->ob_items.release();
+    c->ob_items.release(); c->ob_wave_count.release(); c->ob_wave_offset.release();
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -477,18 +483,29 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         // is not available for device-resident batches: use the per-read bound n * max_len)
         const size_t cap = (size_t)n * (size_t)(max_len > p.kmer ? max_len - p.kmer + 1 : 0) + 1;
         HIPCHK(c->ob_items.reserve(cap));
-        KmerOutbox O{c->ob_items.p, c->d_ob, c->d_ob + c->part_world, c->d_ob + 2 * c->part_world, c->part_world};
+        // one launch per run of segments with the same epoch; the waves of all launches get consecutive rows of the
+        // per-wave count / offset tables
+        struct RunSpan { uint32_t s, e, wave_base; };
+        std::vector<RunSpan> runs;
+        uint32_t total_waves = 0;
+        for (uint32_t s = 0; s < n_seg;) {
+            uint32_t e = s + 1;
+            while (e < n_seg && c->seg_epoch[e] == c->seg_epoch[s]) ++e;
+            if (c->seg_epoch[s] != 0xffffffffu && seg[e] > seg[s]) {
+                runs.push_back({s, e, total_waves});
+                total_waves += faqcs_kmer_extract_waves(seg[e] - seg[s], c->n_cu);
+            }
+            s = e;
+        }
+        HIPCHK(c->ob_wave_count.reserve((size_t)total_waves * c->part_world + 1));
+        HIPCHK(c->ob_wave_offset.reserve((size_t)total_waves * c->part_world + 1));
+        KmerOutbox O{c->ob_items.p, c->d_ob, c->d_ob + c->part_world, c->d_ob + 2 * c->part_world, c->part_world,
+                     c->ob_wave_count.p, c->ob_wave_offset.p, total_waves};
         HIPCHK(hipMemsetAsync(c->d_ob, 0, 3 * c->part_world * 8, c->compute));
         for (int fill = 0; fill < 2; ++fill) {
-            uint32_t s = 0;
-            while (s < n_seg) { // one launch per run of segments with the same epoch
-                uint32_t e = s + 1;
-                while (e < n_seg && c->seg_epoch[e] == c->seg_epoch[s]) ++e;
-                if (c->seg_epoch[s] != 0xffffffffu)
-                    HIPCHK(faqcs_launch_kmer_extract(c->dp, p.kmer, O, fill != 0, d_seq, d_qual, d_off, seg[s], seg[e], d_res,
-                                                     c->seg_epoch[s], c->n_cu, c->compute));
-                s = e;
-            }
+            for (const RunSpan &r : runs)
+                HIPCHK(faqcs_launch_kmer_extract(c->dp, p.kmer, O, fill != 0, d_seq, d_qual, d_off, seg[r.s], seg[r.e], d_res,
+                                                 c->seg_epoch[r.s], r.wave_base, c->n_cu, c->compute));
             if (!fill) HIPCHK(faqcs_launch_kmer_outbox_offsets(O, c->compute));
         }
         c->seg_epoch.clear();

@@ -37,8 +37,14 @@ struct KmerOutbox {
     ulonglong2 *items;              // (key, epoch) pairs, grouped by destination rank
     unsigned long long *dest_count; // [world]  occurrences per destination (pass 1)
     unsigned long long *dest_offset;// [world]  exclusive prefix of dest_count
-    unsigned long long *dest_cursor;// [world]  fill cursors (pass 2)
+    unsigned long long *dest_cursor;// [world]  (unused by the kernels; kept zero)
     uint32_t world;
+    // The fill pass takes NO atomics: the count pass leaves every wave's per-destination count in wave_count, a scan turns
+    // them into wave_offset (start of the wave's slice inside the destination's bucket), and a wave then advances private
+    // cursors.  Both passes use the same grid per launch, so a wave sees the same reads in both.
+    uint32_t *wave_count;            // [total waves of the submission][world]
+    unsigned long long *wave_offset; // same shape
+    uint32_t total_waves;
 };
 
 __device__ __forceinline__ uint64_t kmer_mix(uint64_t x)
@@ -181,13 +187,16 @@ template <int NW, bool FILL>
 __global__ __launch_bounds__(NW * 64) void kmer_extract(
     const DevParams P, const uint32_t k, const KmerOutbox O, const uint8_t *__restrict__ seq,
     const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off, const uint32_t r_begin, const uint32_t r_end,
-    const uint2 *__restrict__ results, const uint32_t epoch)
+    const uint2 *__restrict__ results, const uint32_t epoch, const uint32_t wave_base)
 {
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * NW;
+    const uint32_t gw = wave_base + blockIdx.x * NW + (uint32_t)wave; // this wave's row in wave_count / wave_offset
     const uint64_t lt = (1ull << lane) - 1ull;
     unsigned long long my_count = 0; // pass 1: lane d accumulates the count for destination d
+    unsigned long long cursor = 0;   // pass 2: lane d holds the next free item index of destination d for this wave
+    if (FILL && (uint32_t)lane < O.world) cursor = O.wave_offset[(size_t)gw * O.world + lane];
 #pragma unroll 1
     for (uint32_t r = r_begin + blockIdx.x * NW + wave; r < r_end; r += n_waves) {
         kmer_enumerate(P, k, seq, qual, off, r, results, lane, [&](bool ok, uint64_t key) {
@@ -200,15 +209,37 @@ __global__ __launch_bounds__(NW * 64) void kmer_extract(
                 if (!FILL) {
                     if ((uint32_t)lane == d) my_count += cnt;
                 } else {
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(&O.dest_cursor[d], (unsigned long long)cnt);
-                    base = (unsigned long long)__shfl((long long)base, 0);
-                    if (dest == d) O.items[O.dest_offset[d] + base + (unsigned long long)__popcll(m & lt)] = make_ulonglong2(key, (unsigned long long)epoch);
+                    const unsigned long long base = (unsigned long long)__shfl((long long)cursor, (int)d);
+                    if (dest == d) O.items[base + (unsigned long long)__popcll(m & lt)] = make_ulonglong2(key, (unsigned long long)epoch);
+                    if ((uint32_t)lane == d) cursor += cnt;
                 }
             }
         });
     }
-    if (!FILL && (uint32_t)lane < O.world && my_count) atomicAdd(&O.dest_count[lane], my_count);
+    if (!FILL && (uint32_t)lane < O.world) {
+        O.wave_count[(size_t)gw * O.world + lane] = (uint32_t)my_count;
+        if (my_count) atomicAdd(&O.dest_count[lane], my_count);
+    }
+}
+
+// wave_offset[gw][d] = dest_offset[d] + sum of wave_count[gw'][d] over gw' < gw.  One block per destination.
+__global__ __launch_bounds__(1024) void kmer_outbox_wave_offsets(const KmerOutbox O)
+{
+    __shared__ unsigned long long part[1024];
+    const uint32_t d = blockIdx.x, tid = threadIdx.x;
+    const uint32_t per = (O.total_waves + 1023u) / 1024u;
+    const uint32_t lo = tid * per, hi = lo + per < O.total_waves ? lo + per : O.total_waves;
+    unsigned long long sum = 0;
+    for (uint32_t g = lo; g < hi; ++g) sum += O.wave_count[(size_t)g * O.world + d];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { // 1024 partial sums: a serial exclusive scan is plenty
+        unsigned long long run = O.dest_offset[d];
+        for (uint32_t i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+    unsigned long long run = part[tid];
+    for (uint32_t g = lo; g < hi; ++g) { O.wave_offset[(size_t)g * O.world + d] = run; run += O.wave_count[(size_t)g * O.world + d]; }
 }
 
 __global__ void kmer_outbox_offsets(const KmerOutbox O)
@@ -337,27 +368,36 @@ hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *d
     return hipGetLastError();
 }
 
+// waves a launch over n_reads reads uses (identical for the count and the fill pass)
+uint32_t faqcs_kmer_extract_waves(uint32_t n_reads, int n_cu)
+{
+    constexpr uint32_t NW = 4;
+    uint32_t grid = (n_reads + NW - 1) / NW;
+    const uint32_t cap = (uint32_t)n_cu * 8u;
+    if (grid > cap) grid = cap;
+    return grid * NW;
+}
+
 hipError_t faqcs_launch_kmer_extract(const DevParams &P, uint32_t k, const KmerOutbox &O, bool fill, const uint8_t *seq,
                                      const uint8_t *qual, const uint32_t *off, uint32_t r_begin, uint32_t r_end,
-                                     const faqcs_read_result *results, uint32_t epoch, int n_cu, hipStream_t st)
+                                     const faqcs_read_result *results, uint32_t epoch, uint32_t wave_base, int n_cu, hipStream_t st)
 {
     if (r_end <= r_begin) return hipSuccess;
     constexpr int NW = 4;
-    uint32_t grid = (r_end - r_begin + NW - 1) / NW;
-    const uint32_t cap = (uint32_t)n_cu * 8u;
-    if (grid > cap) grid = cap;
+    const uint32_t grid = faqcs_kmer_extract_waves(r_end - r_begin, n_cu) / NW;
     if (fill)
         hipLaunchKernelGGL((kmer_extract<NW, true>), dim3(grid), dim3(NW * 64), 0, st, P, k, O, seq, qual, off, r_begin, r_end,
-                           reinterpret_cast<const uint2 *>(results), epoch);
+                           reinterpret_cast<const uint2 *>(results), epoch, wave_base);
     else
         hipLaunchKernelGGL((kmer_extract<NW, false>), dim3(grid), dim3(NW * 64), 0, st, P, k, O, seq, qual, off, r_begin, r_end,
-                           reinterpret_cast<const uint2 *>(results), epoch);
+                           reinterpret_cast<const uint2 *>(results), epoch, wave_base);
     return hipGetLastError();
 }
 
 hipError_t faqcs_launch_kmer_outbox_offsets(const KmerOutbox &O, hipStream_t st)
 {
     hipLaunchKernelGGL(kmer_outbox_offsets, dim3(1), dim3(64), 0, st, O);
+    if (O.total_waves) hipLaunchKernelGGL(kmer_outbox_wave_offsets, dim3(O.world), dim3(1024), 0, st, O);
     return hipGetLastError();
 }
 
