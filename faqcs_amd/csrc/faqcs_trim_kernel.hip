@@ -244,6 +244,77 @@ __device__ __noinline__ void flush_hq8(uint32_t *smem, uint64_t *counters, const
     __syncthreads();
 }
 
+// What depends on a read's scalars alone, done once per 64-read chunk with one read per lane: result word, composition
+// records, length / average-quality histograms, FilterStat sums.
+struct ReadOutcome {
+    uint32_t an, fl, pAT, pCG, cAT, cCG, N; // start | kept << 16 ; flags ; base counts before / after (A|T<<16, C|G<<16, N pre | post << 16)
+    int Vpre, Vpost;                       // sum(raw - offset) over the read / over the kept window
+};
+template <int LPR>
+__device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool mine, const uint32_t my, const uint32_t v_len,
+                                               const uint32_t v_hit, const int lane, uint32_t *hlen, uint32_t *hrq, uint32_t *hbqpre,
+                                               uint32_t *hbqpost, uint32_t *lfs, const uint32_t *t_magic, uint2 *__restrict__ out,
+                                               unsigned long long *__restrict__ rec_pre, unsigned long long *__restrict__ rec_post,
+                                               const bool o_avgq_on, const uint32_t o_dbg)
+{
+        const bool e_ret = (o.fl & FAQCS_F_VALID) != 0, e_err = (o.fl & FAQCS_F_ERR_QUALITY) != 0;
+        const uint32_t e_len = v_len, e_n = o.an >> 16, e_filt = (o.fl & FAQCS_F_FILTER_MASK) >> FAQCS_F_FILTER_SHIFT;
+        // int(ave_Q) == max(0, floor(V / len)), V = sum(raw - offset); floor via mulhi with a host magic
+        int qb_pre = 0, qb_post = 0;
+        if (mine && e_len > 0 && o.Vpre > 0) qb_pre = e_len == 1 ? o.Vpre : (int)__umulhi((uint32_t)o.Vpre, t_magic[e_len]);
+        if (e_ret && o.Vpost > 0) qb_post = e_n == 1 ? o.Vpost : (int)__umulhi((uint32_t)o.Vpost, t_magic[e_n]);
+        qb_pre = qb_pre > 41 ? 41 : qb_pre;
+        qb_post = qb_post > 41 ? 41 : qb_post;
+        if (!(o_dbg & 2u) && mine && !e_err) { // length and int(average quality) histograms (trim.cpp:254-258,539-543,877-885)
+            atomicAdd(hlen + e_len, 1u);
+            atomicAdd(hrq + qb_pre, 1u);
+            if (e_len) atomicAdd(hbqpre + qb_pre, e_len);
+            if (e_ret) {
+                atomicAdd(hlen + e_n, 0x10000u);
+                atomicAdd(hrq + qb_post, 0x10000u);
+                atomicAdd(hbqpost + qb_post, e_n);
+            }
+        }
+        if (mine) {
+            const bool bad_base = v_hit == 0xffffu; // set by adapter_overlap
+            out[my] = make_uint2(e_ret ? o.an : 0u, (o.fl & 0x3ffu) | (bad_base ? (uint32_t)FAQCS_F_ERR_BASE : (v_hit << 16)));
+            const bool pre_on = !e_err, post_on = e_ret && !e_err;
+            const unsigned long long pA = o.pAT & 0xffffu, pT = o.pAT >> 16, pC = o.pCG & 0xffffu, pG = o.pCG >> 16, pn = o.N & 0xffffu;
+            const unsigned long long cA = o.cAT & 0xffffu, cT = o.cAT >> 16, cC = o.cCG & 0xffffu, cG = o.cCG >> 16, cn = o.N >> 16;
+            if (LPR <= 16) {
+                rec_pre[my] = pre_on ? (CR_VALID | e_len | (pA << 9) | (pT << 18) | (pC << 27) | (pG << 36) | (pn << 45)) : 0ull;
+                rec_post[my] = post_on ? (CR_VALID | e_n | (cA << 9) | (cT << 18) | (cC << 27) | (cG << 36) | (cn << 45)) : 0ull;
+            } else { // reads past 511 bases do not fit 9-bit fields: 11-bit fields over two words
+                reinterpret_cast<ulonglong2 *>(rec_pre)[my] =
+                    pre_on ? make_ulonglong2(CR_VALID | e_len | (pA << 11) | (pT << 22) | (pC << 33), pG | (pn << 11)) : make_ulonglong2(0ull, 0ull);
+                reinterpret_cast<ulonglong2 *>(rec_post)[my] =
+                    post_on ? make_ulonglong2(CR_VALID | e_n | (cA << 11) | (cT << 22) | (cC << 33), cG | (cn << 11)) : make_ulonglong2(0ull, 0ull);
+            }
+        }
+        // FilterStat (trim.cpp:238-240,317-323,325-387,505-513,527-531): a read count in the high and a base
+        // count in the low 20 bits, summed over the 64 reads of the chunk (64 x 1024 bases < 2^20)
+        const bool e_rlen = e_filt == FAQCS_FILT_LENGTH_PRE || e_filt == FAQCS_FILT_LENGTH_POST;
+        const uint32_t one = 1u << 20;
+        const uint32_t s_tot = (uint32_t)wave_sum_i32((int)(mine ? one | e_len : 0u));
+        const uint32_t s_trim = (uint32_t)wave_sum_i32((int)(e_ret ? one | e_n : 0u));
+        const uint32_t s_len = (uint32_t)wave_sum_i32((int)(e_rlen ? one | e_n : 0u));
+        const uint32_t s_nn = (uint32_t)wave_sum_i32((int)((o.fl & FAQCS_F_POLY_N_SEEN) ? one | e_n : 0u));
+        const uint32_t s_qt = (uint32_t)wave_sum_i32((int)((o.fl & FAQCS_F_QUAL_TRIMMED) ? one | (o.fl >> 20) : 0u));
+        const uint32_t s_lc = (uint32_t)wave_sum_i32((int)(e_filt == FAQCS_FILT_LOW_COMPLEXITY ? one | e_n : 0u));
+        uint32_t s_avg = 0;
+        if (o_avgq_on) s_avg = (uint32_t)wave_sum_i32((int)(e_filt == FAQCS_FILT_AVG_Q ? one | e_n : 0u));
+        if (lane == 0) {
+            const uint32_t m = one - 1u;
+            if (s_tot) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], s_tot & m); }
+            if (s_trim) { atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_NUMBER], s_trim >> 20); atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_LENGTH], s_trim & m); }
+            if (s_len) { atomicAdd(&lfs[FAQCS_READ_LENGTH], s_len >> 20); atomicAdd(&lfs[FAQCS_BASE_LENGTH], s_len & m); }
+            if (s_nn) { atomicAdd(&lfs[FAQCS_READ_NN], s_nn >> 20); atomicAdd(&lfs[FAQCS_BASE_NN], s_nn & m); }
+            if (s_avg) { atomicAdd(&lfs[FAQCS_READ_AVG_Q], s_avg >> 20); atomicAdd(&lfs[FAQCS_BASE_AVG_Q], s_avg & m); }
+            if (s_qt) { atomicAdd(&lfs[FAQCS_READ_QUAL_TRIM], s_qt >> 20); atomicAdd(&lfs[FAQCS_BASE_QUAL_TRIM], s_qt & m); }
+            if (s_lc) { atomicAdd(&lfs[FAQCS_READ_LOW_COMPLEXITY], s_lc >> 20); atomicAdd(&lfs[FAQCS_BASE_LOW_COMPLEXITY], s_lc & m); }
+        }
+}
+
 #ifndef FAQCS_TRIM_NW
 #define FAQCS_TRIM_NW 4        /* waves per block (A/B on MI355X: 4 waves x 3 blocks/CU beat 8 x 1 by 9 %) */
 #endif
@@ -786,62 +857,9 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || C > 10) ? 2 : FAQCS_TRIM_MINW
 
             // ---- chunk epilogue: one read per lane ----------------------------------------------------------
             if (!(o_dbg & 32u)) {
-                const bool e_ret = (st_fl & FAQCS_F_VALID) != 0, e_err = (st_fl & FAQCS_F_ERR_QUALITY) != 0;
-                const uint32_t e_len = v_len, e_n = st_an >> 16, e_filt = (st_fl & FAQCS_F_FILTER_MASK) >> FAQCS_F_FILTER_SHIFT;
-                // int(ave_Q) == max(0, floor(V / len)), V = sum(raw - offset); floor via mulhi with a host magic
-                int qb_pre = 0, qb_post = 0;
-                if (mine && e_len > 0 && st_Vpre > 0) qb_pre = e_len == 1 ? st_Vpre : (int)__umulhi((uint32_t)st_Vpre, t_magic[e_len]);
-                if (e_ret && st_Vpost > 0) qb_post = e_n == 1 ? st_Vpost : (int)__umulhi((uint32_t)st_Vpost, t_magic[e_n]);
-                qb_pre = qb_pre > 41 ? 41 : qb_pre;
-                qb_post = qb_post > 41 ? 41 : qb_post;
-                if (!(o_dbg & 2u) && mine && !e_err) { // length and int(average quality) histograms (trim.cpp:254-258,539-543,877-885)
-                    atomicAdd(hlen + e_len, 1u);
-                    atomicAdd(hrq + qb_pre, 1u);
-                    if (e_len) atomicAdd(hbqpre + qb_pre, e_len);
-                    if (e_ret) {
-                        atomicAdd(hlen + e_n, 0x10000u);
-                        atomicAdd(hrq + qb_post, 0x10000u);
-                        atomicAdd(hbqpost + qb_post, e_n);
-                    }
-                }
-                if (mine) {
-                    const bool bad_base = v_hit == 0xffffu; // set by adapter_overlap
-                    out[my] = make_uint2(e_ret ? st_an : 0u, (st_fl & 0x3ffu) | (bad_base ? (uint32_t)FAQCS_F_ERR_BASE : (v_hit << 16)));
-                    const bool pre_on = !e_err, post_on = e_ret && !e_err;
-                    const unsigned long long pA = st_pAT & 0xffffu, pT = st_pAT >> 16, pC = st_pCG & 0xffffu, pG = st_pCG >> 16, pn = st_N & 0xffffu;
-                    const unsigned long long cA = st_cAT & 0xffffu, cT = st_cAT >> 16, cC = st_cCG & 0xffffu, cG = st_cCG >> 16, cn = st_N >> 16;
-                    if (LPR <= 16) {
-                        rec_pre[my] = pre_on ? (CR_VALID | e_len | (pA << 9) | (pT << 18) | (pC << 27) | (pG << 36) | (pn << 45)) : 0ull;
-                        rec_post[my] = post_on ? (CR_VALID | e_n | (cA << 9) | (cT << 18) | (cC << 27) | (cG << 36) | (cn << 45)) : 0ull;
-                    } else { // reads past 511 bases do not fit 9-bit fields: 11-bit fields over two words
-                        reinterpret_cast<ulonglong2 *>(rec_pre)[my] =
-                            pre_on ? make_ulonglong2(CR_VALID | e_len | (pA << 11) | (pT << 22) | (pC << 33), pG | (pn << 11)) : make_ulonglong2(0ull, 0ull);
-                        reinterpret_cast<ulonglong2 *>(rec_post)[my] =
-                            post_on ? make_ulonglong2(CR_VALID | e_n | (cA << 11) | (cT << 22) | (cC << 33), cG | (cn << 11)) : make_ulonglong2(0ull, 0ull);
-                    }
-                }
-                // FilterStat (trim.cpp:238-240,317-323,325-387,505-513,527-531): a read count in the high and a base
-                // count in the low 20 bits, summed over the 64 reads of the chunk (64 x 1024 bases < 2^20)
-                const bool e_rlen = e_filt == FAQCS_FILT_LENGTH_PRE || e_filt == FAQCS_FILT_LENGTH_POST;
-                const uint32_t one = 1u << 20;
-                const uint32_t s_tot = (uint32_t)wave_sum_i32((int)(mine ? one | e_len : 0u));
-                const uint32_t s_trim = (uint32_t)wave_sum_i32((int)(e_ret ? one | e_n : 0u));
-                const uint32_t s_len = (uint32_t)wave_sum_i32((int)(e_rlen ? one | e_n : 0u));
-                const uint32_t s_nn = (uint32_t)wave_sum_i32((int)((st_fl & FAQCS_F_POLY_N_SEEN) ? one | e_n : 0u));
-                const uint32_t s_qt = (uint32_t)wave_sum_i32((int)((st_fl & FAQCS_F_QUAL_TRIMMED) ? one | (st_fl >> 20) : 0u));
-                const uint32_t s_lc = (uint32_t)wave_sum_i32((int)(e_filt == FAQCS_FILT_LOW_COMPLEXITY ? one | e_n : 0u));
-                uint32_t s_avg = 0;
-                if (o_avgq_on) s_avg = (uint32_t)wave_sum_i32((int)(e_filt == FAQCS_FILT_AVG_Q ? one | e_n : 0u));
-                if (lane == 0) {
-                    const uint32_t m = one - 1u;
-                    if (s_tot) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], s_tot & m); }
-                    if (s_trim) { atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_NUMBER], s_trim >> 20); atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_LENGTH], s_trim & m); }
-                    if (s_len) { atomicAdd(&lfs[FAQCS_READ_LENGTH], s_len >> 20); atomicAdd(&lfs[FAQCS_BASE_LENGTH], s_len & m); }
-                    if (s_nn) { atomicAdd(&lfs[FAQCS_READ_NN], s_nn >> 20); atomicAdd(&lfs[FAQCS_BASE_NN], s_nn & m); }
-                    if (s_avg) { atomicAdd(&lfs[FAQCS_READ_AVG_Q], s_avg >> 20); atomicAdd(&lfs[FAQCS_BASE_AVG_Q], s_avg & m); }
-                    if (s_qt) { atomicAdd(&lfs[FAQCS_READ_QUAL_TRIM], s_qt >> 20); atomicAdd(&lfs[FAQCS_BASE_QUAL_TRIM], s_qt & m); }
-                    if (s_lc) { atomicAdd(&lfs[FAQCS_READ_LOW_COMPLEXITY], s_lc >> 20); atomicAdd(&lfs[FAQCS_BASE_LOW_COMPLEXITY], s_lc & m); }
-                }
+                const ReadOutcome oc{st_an, st_fl, st_pAT, st_pCG, st_cAT, st_cCG, st_N, st_Vpre, st_Vpost};
+                chunk_epilogue<LPR>(oc, mine, my, v_len, v_hit, lane, smem + Cfg::O_LEN, smem + Cfg::O_RQ, smem + Cfg::O_BQPRE,
+                                    smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, o_avgq_on, o_dbg);
             }
         }
 
@@ -851,6 +869,613 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || C > 10) ? 2 : FAQCS_TRIM_MINW
 
         // ---- flush LDS -> global before a 16-bit field can overflow, and at the end ----------------------
         if (block_flush && !(o_dbg & 64u)) flush_block<C, LPR, NW>(smem, counters, P.R, tid);
+    }
+    if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// trim_tpr: the headline option set (BWA_plus, 5' trimming on, -n 2, no --qc_only / --replace_to_N_q / --avg_q)
+// for reads of at most 160 bases, in two phases per 64-read chunk.
+//
+//   phase A, "thread per read": the lane that OWNS a read holds its bytes in registers (ten 16-byte loads per
+//     arena) and takes every per-read decision alone: class counts (an LDS table with 8-bit A,T,C,G fields, a prefix
+//     snapshot per dword parked in LDS), upper-case N bits, quality sum and range check on four bytes per
+//     instruction, the two BWA_plus walks exactly as trim.cpp:714-793 states them (serially, position by position,
+//     all 64 reads in lockstep; a dword no lane still needs is skipped), length / poly-N / low-complexity filters.
+//     No cross-lane reduction and no row-uniform control flow is left: what used to be ~300 instructions per 8 reads
+//     is now spent once per 64.
+//   phase B, position-parallel (8 lanes per read, as trim_filter_accumulate): only applies the window -- position x
+//     quality and position x base accumulation.
+//   Rare inputs (a raw quality outside [offset, offset + 41], letters other than ACGTN, dinucleotide candidates)
+//     take exact per-position passes over the registers, entered only by chunks that contain such a read.
+// ---------------------------------------------------------------------------------------------------------
+template <int C> struct TprCfg {
+    using Row = RowCfg<C, 8>;
+    static constexpr int NP = (Row::W + 15) / 16;  // 16-byte pieces per read and arena
+    static constexpr int ND = NP * 4;              // dwords per read and arena held by the owner lane
+    static constexpr int NWORD = (ND * 4 + 31) / 32;
+    static constexpr int O_T2 = (Row::LDS_DWORDS + 3) & ~3;   // [256][2]: A,T,C,G one-hot in 8-bit fields ; isN(upper) | isN(any) << 1
+    static constexpr int O_SNAP = O_T2 + 512;                 // [NW][ND + 1][64] class counts before dword k (the last row: whole read)
+    static constexpr int SNAP_WAVE = (ND + 1) * 64;
+    static constexpr int lds_dwords(int nw) { return O_SNAP + nw * SNAP_WAVE; }
+};
+
+namespace {
+typedef uint32_t LdsPair __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) LdsPair *lds_u2_ptr;
+__device__ __forceinline__ void lds_store_u32(uint32_t byte_offset, uint32_t v) { *(lds_u32_mut)(size_t)byte_offset = v; }
+__device__ __forceinline__ uint32_t lds_load_u32(uint32_t byte_offset) { return *(lds_u32_ptr)(size_t)byte_offset; }
+template <int K> __device__ __forceinline__ uint32_t byte_times8(uint32_t w, uint32_t three)
+{
+    uint32_t r;
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(w));
+    else if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(w));
+    else if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(w));
+    return r;
+}
+// mask of the bytes [0, nb) of a dword, nb in 0..4
+__device__ __forceinline__ uint32_t low_bytes(int nb) { return nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u); }
+// bits [s, e) of a 32-bit word, 0 <= s, e <= 32
+__device__ __forceinline__ uint32_t bit_range(int s, int e)
+{
+    const uint32_t hi = e >= 32 ? 0xffffffffu : ((1u << e) - 1u), lo = s >= 32 ? 0xffffffffu : ((1u << s) - 1u);
+    return hi & ~lo;
+}
+} // namespace
+
+// ---- exact per-position passes of phase A, entered only by a chunk that holds such a read.  Out of line on purpose: their
+// register needs must not weigh on the main path (a call saves what it clobbers only when it is taken).
+struct ExactQuality { int sv, svp, mq; };   // sum(raw - offset) over the read / over the kept window, max(raw - offset)
+// patch = lead | trail << 8: terminal-N positions (< lead or >= trail) read as the offset (mask_quality_terminal_N)
+template <int NP>
+__device__ __noinline__ ExactQuality exact_quality_pass(const uint8_t *__restrict__ qual, const uint32_t v_off, const int len, const uint32_t patch,
+                                                        const int a, const int n, const int in_off)
+{
+    const int lead = (int)(patch & 0xffu), trail = (int)(patch >> 8);
+    ExactQuality r{0, 0, 0};
+#pragma unroll 1
+    for (int k = 0; k < NP; ++k) {
+        if (!__any(16 * k < len)) break;
+        PackedBytes<4> tq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tq.w[i] = 0u;
+        if (16 * k < len) tq = *(const PackedBytes<4> *)(qual + (size_t)v_off + 16 * k);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int p = 16 * k + i;
+            int v = (int)(int8_t)((tq.w[i >> 2] >> (8 * (i & 3))) & 0xffu) - in_off;
+            if (p < lead || p >= trail) v = 0;
+            if (p < len) {
+                r.sv += v;
+                r.mq = r.mq > v ? r.mq : v;
+                if ((unsigned)(p - a) < (unsigned)n) r.svp += v;
+            }
+        }
+    }
+    return r;
+}
+struct ExactBases { uint32_t npre, npost; bool trip; }; // N (any case) in the read / in the kept window; dinucleotide filter
+template <int NP>
+__device__ __noinline__ ExactBases exact_base_pass(const uint8_t *__restrict__ seq, const uint32_t v_off, const int len, const int a, const int n,
+                                                   const bool dinuc, const uint32_t dthr, const uint32_t cpk, const uint32_t snap_base,
+                                                   const uint32_t t2_lds)
+{
+    ExactBases r{0u, 0u, false};
+    uint32_t prev = 8u; // class 0..3 of the previous position if it is ACGT inside the window
+    // (the lane's snapshot column is free by now and holds the 16 transition counters)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds_store_u32(snap_base + (uint32_t)i * 256u, 0u);
+#pragma unroll 1
+    for (int k = 0; k < NP; ++k) {
+        if (!__any(16 * k < len)) break;
+        PackedBytes<4> ts;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ts.w[i] = 0u;
+        if (16 * k < len) ts = *(const PackedBytes<4> *)(seq + (size_t)v_off + 16 * k);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int p = 16 * k + i;
+            const uint32_t byte = p < len ? (ts.w[i >> 2] >> (8 * (i & 3))) & 0xffu : 0u;
+            const LdsPair e = *(lds_u2_ptr)(size_t)(byte * 8u + t2_lds);
+            const bool inw = (unsigned)(p - a) < (unsigned)n;
+            const uint32_t isn = (e.y >> 1) & 1u;
+            r.npre += isn;
+            r.npost += inw ? isn : 0u;
+            const uint32_t cur = (e.x != 0u && inw) ? (uint32_t)__builtin_ctz(e.x) >> 3 : 8u;
+            if (dinuc && cur < 4u && prev < 4u && cur != prev)
+                __hip_atomic_fetch_add((lds_u32_mut)(size_t)(snap_base + (prev * 4u + cur) * 256u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prev = cur;
+        }
+    }
+    if (dinuc) { // dc[X->Y] <= min(count X, count Y): only pairs whose two counts both reach dthr can trip
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                if (x != y) {
+                    const uint32_t dc = lds_load_u32(snap_base + (uint32_t)(x * 4 + y) * 256u);
+                    r.trip = r.trip || (((cpk >> (8 * x)) & 0xffu) >= dthr && ((cpk >> (8 * y)) & 0xffu) >= dthr && dc >= dthr);
+                }
+    }
+    return r;
+}
+
+// The two BWA_plus walks of phase A, one 4-position step per template instance so that the recursion ends as soon as no
+// lane needs another step.  K = area * 256 + <position byte> is carried along (no per-position constants in registers);
+// the bounds are kept relative to the current step (r* = bound - 4 * g) and re-based once per step.
+template <int G, int ND, bool WINDOWED> struct Walk3 {
+    // rlow: the walk's last position (at_least_scan == 0 after it); rend: end of the window; rthr: window start + n2
+    static __device__ __forceinline__ void run(const uint32_t (&qd)[ND], const int qoff_v, const int q_v, int &K, int &best, int rlow, int rend, int rthr)
+    {
+        if (!__any(rlow <= 3)) return; // every lane is done (a lane whose window still ends below keeps rlow <= 3)
+        if (__any(rend < 4)) {         // some lane's window ends inside or below this step
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                K -= 1;
+                if (j >= rlow && j < rend) {
+                    const bool can = WINDOWED ? j > rthr : (G == 0 ? j > rthr : true);
+                    if (can && K >= 0) rlow = j - 2;
+                    const int t = qoff_v - (int)(int8_t)((qd[G] >> (8 * j)) & 0xffu);
+                    K += (t < q_v ? t : q_v) * 256;
+                    best = best > K ? best : K;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                K -= 1;
+                if (j >= rlow) {
+                    const bool can = WINDOWED ? j > rthr : (G == 0 ? j > rthr : true);
+                    if (can && K >= 0) rlow = j - 2;
+                    const int t = qoff_v - (int)(int8_t)((qd[G] >> (8 * j)) & 0xffu);
+                    K += (t < q_v ? t : q_v) * 256;
+                    best = best > K ? best : K;
+                }
+            }
+        }
+        Walk3<G - 1, ND, WINDOWED>::run(qd, qoff_v, q_v, K, best, rlow + 4, rend + 4, rthr + 4);
+    }
+};
+template <int ND, bool WINDOWED> struct Walk3<-1, ND, WINDOWED> {
+    static __device__ __forceinline__ void run(const uint32_t (&)[ND], int, int, int &, int &, int, int, int) {}
+};
+template <int G, int ND, bool WINDOWED> struct Walk5 {
+    // rhigh: the walk's last position; rthr: final_pos_3 - n2 (resets need a position below it); rwa: window start
+    static __device__ __forceinline__ void run(const uint32_t (&qd)[ND], const int qoff_v, const int q_v, int &K, int &best, int rhigh, int rthr, int rwa)
+    {
+        if (!__any(rhigh >= 0)) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            K -= 1;
+            if (j <= rhigh && (!WINDOWED || j >= rwa)) {
+                if (j < rthr && K >= 0) rhigh = j + 2;
+                const int t = qoff_v - (int)(int8_t)((qd[G] >> (8 * j)) & 0xffu);
+                K += (t < q_v ? t : q_v) * 256;
+                best = best > K ? best : K;
+            }
+        }
+        Walk5<G + 1, ND, WINDOWED>::run(qd, qoff_v, q_v, K, best, rhigh - 4, rthr - 4, rwa - 4);
+    }
+};
+template <int ND, bool WINDOWED> struct Walk5<ND, ND, WINDOWED> {
+    static __device__ __forceinline__ void run(const uint32_t (&)[ND], int, int, int &, int &, int, int, int) {}
+};
+
+template <int C, int NW, bool WINDOWED>
+__global__ __launch_bounds__(NW * 64, 2) void trim_tpr(
+    const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
+    const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
+    const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
+    unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err)
+{
+    constexpr int LPR = 8;
+    using Cfg = RowCfg<C, LPR>;
+    using T = TprCfg<C>;
+    constexpr int D = Cfg::D, W = Cfg::W, NP = T::NP, ND = T::ND, NWORD = T::NWORD, NPOS = ND * 4;
+    static_assert(!Cfg::HQ8 && NPOS <= 255, "positions must fit the low byte of the argmax keys");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *hb = smem + Cfg::O_HB;
+    const uint32_t *t_lc = smem + Cfg::O_TLC;
+    const uint32_t *t_bm = smem + Cfg::O_TBM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int rl = lane & (LPR - 1);
+    const int rowb = lane & (64 - LPR);
+    const int wave = uni(tid >> 6);
+    const int pbase = rl * C;
+
+    for (int i = tid; i < Cfg::N_ZERO; i += NW * 64) smem[i] = 0u;
+    for (int i = tid; i < 256; i += NW * 64) {
+        const uint32_t w = P.base_tab[i];
+        smem[Cfg::O_TBASE + i] = w;
+        smem[T::O_T2 + 2 * i] = ((w >> BT_SHIFT(0)) & 1u) | (((w >> BT_SHIFT(1)) & 1u) << 8) | (((w >> BT_SHIFT(2)) & 1u) << 16) | (((w >> BT_SHIFT(3)) & 1u) << 24);
+        smem[T::O_T2 + 2 * i + 1] = (w >> 31) | (((w >> BT_SHIFT(4)) & 1u) << 1);
+    }
+    for (int i = tid; i <= W; i += NW * 64) {
+        smem[Cfg::O_TLC + i] = P.lc_thr[i];
+        smem[Cfg::O_TAVGQ + i] = (uint32_t)P.avgq_min_v[i];
+        smem[Cfg::O_TMAGIC + i] = P.div_magic[i];
+    }
+    for (int i = tid; i < Cfg::BMW * (C + 1); i += NW * 64) {
+        const int nb = med3i((i / Cfg::BMW) - 4 * (i % Cfg::BMW), 0, 4);
+        smem[Cfg::O_TBM + i] = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+    }
+    uint32_t two = 2u, three = 3u;
+    asm volatile("" : "+v"(two), "+v"(three)); // VGPR operands for the SDWA shifts
+    if (tid == 0 && blockIdx.x == 0 && (uint32_t)(size_t)((lds_u32_ptr)smem) != 0u) atomicOr(err, 4u);
+    __syncthreads();
+
+    const uint32_t total_chunks = (n_reads + 63) >> 6;
+    const uint32_t chunks_per_iter = gridDim.x * NW;
+    const uint32_t n_iter = (total_chunks + chunks_per_iter - 1) / chunks_per_iter;
+    constexpr uint32_t FLUSH_EVERY = 65535u / (NW * 64) > 0 ? 65535u / (NW * 64) : 1;
+    constexpr uint32_t REG_FLUSH_EVERY = 7; // 6-bit fields: 7 chunks x 8 reads per row = 56 <= 63
+
+    const int in_off = P.in_off, Q = P.Q;
+    const uint32_t snap_base = (uint32_t)(T::O_SNAP + wave * T::SNAP_WAVE + lane) * 4u; // LDS byte address of this lane's column
+    const uint32_t offb = ((uint32_t)in_off & 0xffu) * 0x01010101u;
+    const bool swar_ok = in_off >= 0 && in_off <= 86; // else every read takes the exact quality pass
+    uint32_t bpre[C], bpost[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { bpre[j] = 0; bpost[j] = 0; }
+    uint32_t any_err = 0;
+    auto spill_base_regs = [&]() {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t x = bpre[j], y = bpost[j];
+            if (x) {
+#pragma unroll
+                for (int c = 0; c < FAQCS_NBASE; ++c) {
+                    const uint32_t v = ((x >> BT_SHIFT(c)) & 63u) | (((y >> BT_SHIFT(c)) & 63u) << 16);
+                    if (v) atomicAdd(&hb[c * W + pbase + j], v);
+                }
+            }
+            bpre[j] = 0; bpost[j] = 0;
+        }
+    };
+
+#pragma unroll 1
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        const uint32_t chunk = (it * gridDim.x + blockIdx.x) * NW + wave;
+        if (chunk < total_chunks) {
+            const uint32_t base = chunk << 6;
+            const uint32_t my = base + lane;
+            const bool mine = my < n_reads;
+            const uint32_t v_off = mine ? off[my] : 0u;
+            const uint32_t v_len = mine ? off[my + 1] - v_off : 0u;
+            const uint32_t v_sl = (WINDOWED && ad_sl && mine) ? ad_sl[my] : (v_len << 16);
+            const uint32_t v_hit = (ad_hit && mine) ? ad_hit[my] : 0u;
+
+            // ---- software prefetch of the row's read 0 for phase B ----------------------------------------
+            PackedBytes<D> nseq, nqual;
+            int n_len = __shfl((int)v_len, rowb);
+            {
+                const uint32_t o = (uint32_t)__shfl((int)v_off, rowb);
+#pragma unroll
+                for (int k = 0; k < D; ++k) { nseq.w[k] = 0; nqual.w[k] = 0; }
+                if (pbase < n_len) {
+                    nseq = *(const PackedBytes<D> *)(seq + (size_t)o + pbase);
+                    nqual = *(const PackedBytes<D> *)(qual + (size_t)o + pbase);
+                }
+            }
+
+            // ================= phase A: one read per lane =====================================================
+            ReadOutcome oc;
+            uint32_t v_info, v_patch = 0; // what phase B needs: start | kept << 8 | valid << 16 | error << 17 | patch << 18 ; lead | trail << 8
+            {
+                const int len = (int)v_len;
+                uint32_t sd[ND], qd[ND];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    PackedBytes<4> ts, tq;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { ts.w[i] = 0u; tq.w[i] = offb; }
+                    if (16 * k < len) {
+                        ts = *(const PackedBytes<4> *)(seq + (size_t)v_off + 16 * k);
+                        tq = *(const PackedBytes<4> *)(qual + (size_t)v_off + 16 * k);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { sd[4 * k + i] = ts.w[i]; qd[4 * k + i] = tq.w[i]; }
+                }
+                uint32_t blast = 0; // last base (a lane without a read must not touch the arena: its offset is not one)
+                if (len) blast = (uint32_t)seq[(size_t)v_off + len - 1];
+                // bytes past the read inside its last 16-byte piece: base 0 (class "none"), quality == offset (q = 0, adds 0 to the sums)
+#pragma unroll
+                for (int k = 0; k < ND; ++k) {
+                    if (__any(len < 4 * k + 4 && 16 * (k >> 2) < len)) {
+                        const uint32_t m = low_bytes(med3i(len - 4 * k, 0, 4));
+                        sd[k] &= m;
+                        qd[k] = (qd[k] & m) | (offb & ~m);
+                    }
+                }
+
+                // ---- classes: A,T,C,G counts (8-bit fields) with a prefix snapshot per dword, upper-case N bits ----
+                uint32_t cnt4 = 0, nub[NWORD];
+#pragma unroll
+                for (int w = 0; w < NWORD; ++w) nub[w] = 0;
+#pragma unroll
+                for (int k = 0; k < ND; ++k) {
+                    lds_store_u32(snap_base + (uint32_t)k * 256u, cnt4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t ad = (j == 0 ? byte_times8<0>(sd[k], three) : j == 1 ? byte_times8<1>(sd[k], three)
+                                             : j == 2 ? byte_times8<2>(sd[k], three) : byte_times8<3>(sd[k], three)) + (uint32_t)(T::O_T2 * 4);
+                        const LdsPair e = *(lds_u2_ptr)(size_t)ad;
+                        cnt4 += e.x;
+                        nub[(4 * k + j) >> 5] = __builtin_amdgcn_alignbit(e.y, nub[(4 * k + j) >> 5], 1); // bit (p & 31) = upper-case N at p
+                    }
+                }
+                lds_store_u32(snap_base + (uint32_t)ND * 256u, cnt4);
+                if ((NPOS & 31) != 0) nub[NWORD - 1] >>= (32 - (NPOS & 31));
+                const int nACGT = (int)__builtin_amdgcn_sad_u8(cnt4, 0u, 0u);
+                int nup = 0;
+#pragma unroll
+                for (int w = 0; w < NWORD; ++w) nup += __builtin_popcount(nub[w]);
+                const bool abn_seq = nACGT + nup != len; // a letter that is neither ACGT (any case) nor 'N'
+
+                // ---- mask_quality_terminal_N (trim.cpp:1191-1216): upper-case 'N' runs at either end get Q0 -----
+                const bool tn = len > 0 && ((nub[0] & 1u) != 0u || blast == 'N');
+                if (__any(tn)) {
+                    int lead = NPOS, trail = 0;
+#pragma unroll
+                    for (int w = NWORD - 1; w >= 0; --w) { // first position that is not N
+                        const uint32_t x = ~nub[w];
+                        lead = x ? 32 * w + __builtin_ctz(x) : lead;
+                    }
+                    lead = lead < len ? lead : len;
+#pragma unroll
+                    for (int w = 0; w < NWORD; ++w) { // 1 + last position that is not N
+                        const uint32_t x = ~nub[w] & bit_range(0, med3i(len - 32 * w, 0, 32));
+                        trail = x ? 32 * w + 32 - __builtin_clz(x) : trail;
+                    }
+                    if (!tn) { lead = 0; trail = len; }
+                    v_patch = (uint32_t)lead | ((uint32_t)trail << 8);
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) {
+                        if (!__any(lead > 4 * k || (trail < 4 * k + 4 && 4 * k < len))) continue;
+                        const uint32_t m1 = low_bytes(med3i(lead - 4 * k, 0, 4));   // positions < lead
+                        const uint32_t m2 = ~low_bytes(med3i(trail - 4 * k, 0, 4)); // positions >= trail (past the read: already == offset)
+                        const uint32_t m = m1 | m2;
+                        qd[k] = (qd[k] & ~m) | (offb & m);
+                    }
+                }
+
+                // ---- quality: sum and range check, four bytes per instruction --------------------------------
+                // V = sum(raw - offset); a byte outside [offset, offset + 41] (or >= 128) sends the read to the exact pass
+                uint32_t qsum = 0, qbad = 0, qor = 0;
+#pragma unroll
+                for (int k = 0; k < ND; ++k) {
+                    qsum = __builtin_amdgcn_sad_u8(qd[k], 0u, qsum);
+                    const uint32_t t = (qd[k] | 0x80808080u) - offb;                      // byte: 128 + raw - offset (raw < 128)
+                    const uint32_t s = (t & 0x7f7f7f7fu) + 0x56565656u;                   // bit 7: raw - offset > 41
+                    qbad |= ~t | s;                                                       // bit 7 clear in t: raw < offset
+                    qor |= qd[k];
+                }
+                const bool badq = !swar_ok || (((qbad | qor) & 0x80808080u) != 0u);
+                int V_pre = (int)qsum - NPOS * in_off;
+                bool read_err = false;
+
+                // ---- the window the reference trims: after the adapter pre-pass and --5end/--3end (trim.cpp:270-314) ----
+                int wa = 0, wn = len;
+                uint32_t flags = 0, filt = 0;
+                if (WINDOWED && P.has_adapters) {
+                    const int first = (int)(v_sl & 0xffffu), second = (int)(v_sl >> 16);
+                    const bool mod = len != second;
+                    wa = mod ? first : 0; wn = mod ? second : len;
+                    flags = mod ? FAQCS_F_ADAPTER : 0u;
+                }
+                if (WINDOWED && P.trim5) {
+                    const bool over = (int)P.trim5 > wn;
+                    wa = over ? wa : wa + (int)P.trim5;
+                    wn = over ? 0 : wn - (int)P.trim5;
+                }
+                if (WINDOWED && P.trim3) wn = (int)P.trim3 > wn ? 0 : wn - (int)P.trim3;
+
+                // ---- BWA_plus (trim.cpp:714-793), walked as the reference walks it -----------------------------
+                const int a5 = wn < 5 ? wn : 5, nn2 = wn < 2 ? wn : 2, wend = wa + wn;
+                int qoff_v = Q + in_off, q_v = Q;
+                asm volatile("" : "+v"(qoff_v), "+v"(q_v));
+                // Q - quality_score(p) = min(Q, Q + offset - (signed char)raw)
+                // 3' walk.  at_least_scan == 0 after position p  <=>  p == lowp: the walk covers min(5, n) positions, and a
+                // reset at p (p > n2 and area >= 0 before p) moves its end to p - 2 (n2 == 2 whenever a reset can fire).
+                // best = maxArea << 8 | position of the first maximum.
+                int best = 255, K3 = NPOS;
+                Walk3<ND - 1, ND, WINDOWED>::run(qd, qoff_v, q_v, K3, best, (wn > 0 ? wend - a5 : NPOS) - 4 * (ND - 1), wend - 4 * (ND - 1),
+                                                 wa + nn2 - 4 * (ND - 1));
+                const int S3 = best >> 8;
+                const int fp3 = S3 > 0 ? (best & 255) - 1 - wa : wn - 1;
+                // 5' walk (trim.cpp:752-779): resets need pos_5 < final_pos_3 - n2; the FIRST maximum wins (low byte = 255 - p)
+                int best5 = 255, K5 = 256;
+                Walk5<0, ND, WINDOWED>::run(qd, qoff_v, q_v, K5, best5, wn > 0 ? wa + a5 - 1 : -1, wa + fp3 - nn2, wa);
+                const int S5 = best5 >> 8;
+                const int fp5 = S5 > 0 ? (255 - (best5 & 255)) + 1 - wa : 0;
+
+                // ---- length filters and the kept window (trim.cpp:317-360) -------------------------------------
+                int a = wa, n = wn;
+                bool ret = mine;
+                uint32_t qt_removed = 0;
+                if (ret && (n < (int)P.min_len || n == 0)) { ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
+                if (ret) {
+                    const int kept = fp3 <= fp5 ? 0 : fp3 - fp5 + 1;
+                    if (kept != n) { qt_removed = (uint32_t)(n - kept); flags |= FAQCS_F_QUAL_TRIMMED; }
+                    a += fp5;
+                    n = kept;
+                    if (n < (int)P.min_len || n == 0) { ret = false; filt = FAQCS_FILT_LENGTH_POST; }
+                }
+
+                // ---- poly-N (-n 2; trim.cpp:363-371, :578-597): two adjacent upper-case N inside the kept window ----
+                {
+                    uint32_t pr[NWORD], anyp = 0; // bit e: N at e - 1 and at e
+#pragma unroll
+                    for (int w = 0; w < NWORD; ++w) {
+                        pr[w] = nub[w] & ((nub[w] << 1) | (w ? nub[w - 1] >> 31 : 0u));
+                        anyp |= pr[w];
+                    }
+                    if (__any(ret && anyp != 0u)) {
+                        uint32_t hit = 0;
+#pragma unroll
+                        for (int w = 0; w < NWORD; ++w) hit |= pr[w] & bit_range(med3i(a + 1 - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
+                        if (ret && hit != 0u) { flags |= FAQCS_F_POLY_N_SEEN; ret = false; filt = FAQCS_FILT_POLY_N; }
+                    }
+                }
+
+                // ---- base counts before / inside the kept window (trim.cpp:390-403, :810-875) ---------------------
+                // prefix(x) = snapshot of dword x >> 2 plus the x & 3 bytes in front of x (one 4-byte load from the arena)
+                auto prefix4 = [&](int x) -> uint32_t {
+                    uint32_t c = lds_load_u32(snap_base + (uint32_t)(x >> 2) * 256u);
+                    if (__any((x & 3) != 0)) {
+                        uint32_t w = 0;
+                        if (x & 3) w = ((const PackedBytes<1> *)(seq + (size_t)v_off + (x & ~3)))->w[0] & low_bytes(x & 3);
+                        c += ((lds_u2_ptr)(size_t)(byte_times8<0>(w, three) + (uint32_t)(T::O_T2 * 4)))->x;
+                        c += ((lds_u2_ptr)(size_t)(byte_times8<1>(w, three) + (uint32_t)(T::O_T2 * 4)))->x;
+                        c += ((lds_u2_ptr)(size_t)(byte_times8<2>(w, three) + (uint32_t)(T::O_T2 * 4)))->x;
+                    }
+                    return c;
+                };
+                uint32_t c4post = cnt4;
+                if (__any(ret && (a != 0 || n != len))) {
+                    c4post = prefix4(a + n);
+                    if (__any(a != 0)) c4post -= prefix4(a);
+                }
+                const uint32_t pA = cnt4 & 0xffu, pT = (cnt4 >> 8) & 0xffu, pC = (cnt4 >> 16) & 0xffu, pG = cnt4 >> 24;
+                const uint32_t cA = c4post & 0xffu, cT = (c4post >> 8) & 0xffu, cC = (c4post >> 16) & 0xffu, cG = c4post >> 24;
+                uint32_t pN = (uint32_t)(len - nACGT), cN = (uint32_t)n - (cA + cT + cC + cG); // (exact pass below when abn_seq)
+
+                // ---- sum(raw - offset) over the kept window (trim.cpp:374, :553-576) ---------------------------
+                int V_post;
+                if (!WINDOWED) {
+                    // all v == q here (no byte below the offset): sum q over the kept window from the two walks' areas
+                    const int Tsum = len * Q - V_pre; // sum of (Q - q) over the read
+                    V_post = n * Q - (Tsum - (S3 > 0 ? S3 : 0) - (S5 > 0 ? S5 : 0));
+                } else {
+                    uint32_t s = 0;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) {
+                        const uint32_t m = low_bytes(med3i(a + n - 4 * k, 0, 4)) & ~low_bytes(med3i(a - 4 * k, 0, 4));
+                        s = __builtin_amdgcn_sad_u8(qd[k] & m, 0u, s);
+                    }
+                    V_post = (int)s - n * in_off;
+                }
+                // exact pass for a read with a raw quality outside [offset, offset + 41] (fastq.h:17-36: negative scores clamp
+                // to 0 in the trimmers but not in the averages; > 41 aborts the run)
+                if (__any(badq)) {
+                    const ExactQuality xq = exact_quality_pass<NP>(qual, v_off, len, tn ? v_patch : ((uint32_t)len << 8), a, n, in_off);
+                    if (badq) { V_pre = xq.sv; V_post = xq.svp; read_err = xq.mq > 41; }
+                }
+
+                // ---- low-complexity filter (trim.cpp:405-513) ---------------------------------------------------
+                bool lc_trip = false, dinuc = false;
+                uint32_t dthr = 0;
+                if (ret) {
+                    const uint32_t thr = t_lc[n];
+                    const uint32_t mthr = thr & 0xffffu;
+                    dthr = thr >> 16;
+                    lc_trip = cA >= mthr || cT >= mthr || cG >= mthr || cC >= mthr;
+                    // dc[X->Y] <= min(count X, count Y): only pairs whose two counts both reach dthr can trip
+                    dinuc = !lc_trip && ((cA >= dthr) + (cT >= dthr) + (cC >= dthr) + (cG >= dthr)) >= 2;
+                }
+                // exact per-position pass over the bases: N counts for reads with other letters, transition counts for
+                // dinucleotide candidates (both rare; the lane's snapshot column is free by now and holds the 16 counters)
+                if (__any(abn_seq || dinuc)) {
+                    const uint32_t cpk = cA | (cT << 8) | (cC << 16) | (cG << 24);
+                    const ExactBases xb = exact_base_pass<NP>(seq, v_off, len, a, n, dinuc, dthr, cpk, snap_base, (uint32_t)(T::O_T2 * 4));
+                    if (abn_seq) { pN = xb.npre; cN = xb.npost; }
+                    if (dinuc) lc_trip = lc_trip || xb.trip;
+                }
+                if (ret && lc_trip) { ret = false; filt = FAQCS_FILT_LOW_COMPLEXITY; }
+
+                if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
+                oc.an = (uint32_t)a | ((uint32_t)n << 16);
+                oc.fl = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT) | (qt_removed << 20);
+                oc.pAT = pA | (pT << 16); oc.pCG = pC | (pG << 16);
+                oc.cAT = cA | (cT << 16); oc.cCG = cC | (cG << 16);
+                oc.N = pN | (cN << 16);
+                oc.Vpre = V_pre; oc.Vpost = V_post;
+                v_info = (uint32_t)a | ((uint32_t)n << 8) | (ret ? 1u << 16 : 0u) | (read_err ? 1u << 17 : 0u) | (tn ? 1u << 18 : 0u);
+            }
+
+            // ================= phase B: 8 lanes per read, accumulate only ====================================
+#pragma unroll 1
+            for (int t = 0; t < LPR; ++t) {
+                if (base + (uint32_t)t >= n_reads) break; // wave-uniform: no row has a read left
+                const int len = n_len;
+                const bool act = base + (uint32_t)(rowb + t) < n_reads;
+                uint32_t ws[D], wq[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { ws[k] = nseq.w[k]; wq[k] = nqual.w[k]; }
+                const uint32_t info = (uint32_t)__shfl((int)v_info, rowb + t);
+                if (t + 1 < LPR) {
+                    n_len = __shfl((int)v_len, rowb + t + 1);
+                    const uint32_t o = (uint32_t)__shfl((int)v_off, rowb + t + 1);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { nseq.w[k] = 0; nqual.w[k] = 0; }
+                    if (pbase < n_len) {
+                        nseq = *(const PackedBytes<D> *)(seq + (size_t)o + pbase);
+                        nqual = *(const PackedBytes<D> *)(qual + (size_t)o + pbase);
+                    }
+                }
+                { // zero the bytes past the end of the read (the last dword of a lane may over-read 1..3 bytes)
+                    const int vb = med3i(len - pbase, 0, C);
+                    const uint4 bm = *reinterpret_cast<const uint4 *>(t_bm + Cfg::BMW * vb);
+                    uint32_t m[8] = {bm.x, bm.y, bm.z, bm.w, 0u, 0u, 0u, 0u};
+                    if (D > 4) {
+                        const uint4 bm2 = *reinterpret_cast<const uint4 *>(t_bm + Cfg::BMW * vb + 4);
+                        m[4] = bm2.x; m[5] = bm2.y; m[6] = bm2.z; m[7] = bm2.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { ws[k] &= m[k]; wq[k] &= m[k]; }
+                }
+                if (__any((info >> 18) & 1u)) { // terminal-N runs: their quality bytes become the offset (rare)
+                    const uint32_t pt = (uint32_t)__shfl((int)v_patch, rowb + t);
+                    const int lead = ((info >> 18) & 1u) ? (int)(pt & 0xffu) : 0, trail = ((info >> 18) & 1u) ? (int)(pt >> 8) : len;
+                    int pb = pbase;
+                    asm volatile("" : "+v"(pb)); // (keeps the 19 position values out of the loop-invariant registers)
+#pragma unroll
+                    for (int j = 0; j < C; ++j) {
+                        const int p = pb + j;
+                        if (p < len && (p < lead || p >= trail)) {
+                            const uint32_t sh = 8 * (j & 3);
+                            wq[j >> 2] = (wq[j >> 2] & ~(0xffu << sh)) | (((uint32_t)in_off & 0xffu) << sh);
+                        }
+                    }
+                }
+                const int a = (int)(info & 0xffu), n = (int)((info >> 8) & 0xffu);
+                const bool ret = ((info >> 16) & 1u) != 0u, read_err = ((info >> 17) & 1u) != 0u;
+                uint32_t incf[C];
+                BaseLookup<C, 0>::run((uint32_t)(Cfg::O_TBASE * 4), ws, two, incf);
+                int q[C];
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    const int v = (int)(int8_t)((wq[j >> 2] >> (8 * (j & 3))) & 0xffu) - in_off;
+                    q[j] = v < 0 ? 0 : v;
+                }
+                if (__any(read_err)) { // rare: keep the row's table indices in range, count nothing (fastq.h:31-33 aborts the run)
+#pragma unroll
+                    for (int j = 0; j < C; ++j) { q[j] = read_err ? 0 : q[j]; incf[j] = read_err ? 0u : incf[j]; }
+                }
+                // a position outside the read adds to quality column 0 (flush_block subtracts those) and class "none"
+                const uint32_t counted = (act && !read_err) ? 1u : 0u;
+                const uint32_t pb4 = 4u * (uint32_t)pbase;
+                const uint32_t postm = ret ? range_mask<C>(a, a + n, pbase) : 0u;
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    lds_add_u32(__umul24((uint32_t)q[j], (uint32_t)(W * 4)) + pb4 + (uint32_t)(Cfg::O_HQ * 4 + 4 * j),
+                                counted | ((uint32_t)bit_m1(postm, j) & 0x10000u));
+                    bpre[j] += incf[j];
+                    bpost[j] += incf[j] & (uint32_t)bit_m1(postm, j);
+                }
+            }
+
+            // ---- chunk epilogue: one read per lane ----------------------------------------------------------
+            chunk_epilogue<LPR>(oc, mine, my, v_len, v_hit, lane, smem + Cfg::O_LEN, smem + Cfg::O_RQ, smem + Cfg::O_BQPRE,
+                                smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, false, 0u);
+        }
+
+        const bool block_flush = ((it + 1) % FLUSH_EVERY) == 0 || it + 1 == n_iter;
+        if (((it + 1) % REG_FLUSH_EVERY) == 0 || block_flush) spill_base_regs();
+        if (block_flush) flush_block<C, LPR, NW>(smem, counters, P.R, tid);
     }
     if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
 }
@@ -949,6 +1574,34 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
     return hipGetLastError();
 }
 
+template <int C, int NW, bool WINDOWED>
+static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
+                                  uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
+                                  unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
+                                  int n_cu, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)TprCfg<C>::lds_dwords(NW) * 4;
+    static bool attr_set = false;
+    auto kern = trim_tpr<C, NW, WINDOWED>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint32_t chunks = (n_reads + 63) / 64;
+    int blocks_per_cu = (int)((160 * 1024) / lds);
+    const int by_waves = (4 * 2 + NW - 1) / NW; // 2 waves per SIMD
+    if (blocks_per_cu > by_waves) blocks_per_cu = by_waves;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    uint32_t grid = (chunks + NW - 1) / NW;
+    const uint32_t cap = (uint32_t)(n_cu * blocks_per_cu);
+    if (grid > cap) grid = cap;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
+                       reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err);
+    return hipGetLastError();
+}
+
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
@@ -974,6 +1627,14 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
             if (lpr4 && max_len <= 64) FAQCS_TRIM_CASE4(16);
             if (lpr4 && max_len <= 76) FAQCS_TRIM_CASE4(19);
 #undef FAQCS_TRIM_CASE4
+        }
+        {   // the two-phase kernel for the headline option set; FAQCS_TRIM_TPR=0 switches it off
+            static const bool tpr = [] { const char *e = getenv("FAQCS_TRIM_TPR"); return !e || atoi(e) != 0; }();
+#define FAQCS_TRIM_CASE_TPR(C) \
+    return windowed ? launch_trim_tpr<C, FAQCS_TRIM_NW, true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, FAQCS_TRIM_NW, false>(FAQCS_TRIM_ARGS)
+            if (lpr8 && tpr && !generic && max_len > 76 && max_len <= 152) FAQCS_TRIM_CASE_TPR(19);
+            if (lpr8 && tpr && !generic && max_len > 152 && max_len <= 160) FAQCS_TRIM_CASE_TPR(20);
+#undef FAQCS_TRIM_CASE_TPR
         }
         if (lpr8 && max_len <= 64) FAQCS_TRIM_CASE8(8);
         if (lpr8 && max_len <= 104) FAQCS_TRIM_CASE8(13);   // 2x100
