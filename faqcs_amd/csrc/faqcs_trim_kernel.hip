@@ -318,6 +318,10 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
 #ifndef FAQCS_TRIM_NW
 #define FAQCS_TRIM_NW 4        /* waves per block (A/B on MI355X: 4 waves x 3 blocks/CU beat 8 x 1 by 9 %) */
 #endif
+// trim_tpr: ONE block per CU (its LDS holds 10 KB of prefix snapshots per wave): 12 waves = 3 per SIMD while the registers
+// allow it (C <= 19: 168 VGPRs without a spill), 8 waves otherwise
+constexpr int tpr_waves_per_simd(int C) { return C <= 19 ? 3 : 2; }
+constexpr int tpr_nw(int C) { return 4 * tpr_waves_per_simd(C); }
 #ifndef FAQCS_TRIM_MINWAVES
 #define FAQCS_TRIM_MINWAVES 3  /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
 #endif
@@ -895,8 +899,8 @@ template <int C> struct TprCfg {
     static constexpr int ND = NP * 4;              // dwords per read and arena held by the owner lane
     static constexpr int NWORD = (ND * 4 + 31) / 32;
     static constexpr int O_T2 = (Row::LDS_DWORDS + 3) & ~3;   // [256][2]: A,T,C,G one-hot in 8-bit fields ; isN(upper) | isN(any) << 1
-    static constexpr int O_SNAP = O_T2 + 512;                 // [NW][ND + 1][64] class counts before dword k (the last row: whole read)
-    static constexpr int SNAP_WAVE = (ND + 1) * 64;
+    static constexpr int O_SNAP = O_T2 + 512;                 // [NW][ND][64] class counts before dword k
+    static constexpr int SNAP_WAVE = ND * 64;
     static constexpr int lds_dwords(int nw) { return O_SNAP + nw * SNAP_WAVE; }
 };
 
@@ -1003,37 +1007,33 @@ __device__ __noinline__ ExactBases exact_base_pass(const uint8_t *__restrict__ s
 
 // The two BWA_plus walks of phase A, one 4-position step per template instance so that the recursion ends as soon as no
 // lane needs another step.  K = area * 256 + <position byte> is carried along (no per-position constants in registers);
-// the bounds are kept relative to the current step (r* = bound - 4 * g) and re-based once per step.
+// the bounds are kept relative to the current step (r* = bound - 4 * g) and re-based once per step.  A step is
+// branch-free: "this lane visits position j" is the sign bit of a difference and gates the updates arithmetically, so
+// the four positions form one basic block with no exec-mask round trips through the scalar unit.
 template <int G, int ND, bool WINDOWED> struct Walk3 {
     // rlow: the walk's last position (at_least_scan == 0 after it); rend: end of the window; rthr: window start + n2
+    template <bool ENDS>
+    static __device__ __forceinline__ void step(const uint32_t w, const int qoff_v, const int q_v, int &K, int &best, int &rlow, const int rend, const int rthr)
+    {
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            K -= 1;
+            int live = rlow - (j + 1);                       // < 0: j >= rlow
+            if (ENDS) live &= j - rend;                      // < 0: j < rend
+            int rs = live & ~K;                              // < 0: visited and area >= 0 before this position
+            if (WINDOWED || G == 0) rs &= rthr - j;          // < 0: j > rthr (always true above position 2 of an unwindowed read)
+            rlow = rs < 0 ? j - 2 : rlow;
+            const int t = qoff_v - (int)(int8_t)((w >> (8 * j)) & 0xffu);
+            const int dq = t < q_v ? t : q_v;                // Q - quality_score() = min(Q, Q + offset - (signed char)raw)
+            K += (dq & (live >> 31)) * 256;
+            best = best > K ? best : K;                      // (a lane that is not visiting only counts K down: never a new maximum)
+        }
+    }
     static __device__ __forceinline__ void run(const uint32_t (&qd)[ND], const int qoff_v, const int q_v, int &K, int &best, int rlow, int rend, int rthr)
     {
         if (!__any(rlow <= 3)) return; // every lane is done (a lane whose window still ends below keeps rlow <= 3)
-        if (__any(rend < 4)) {         // some lane's window ends inside or below this step
-#pragma unroll
-            for (int j = 3; j >= 0; --j) {
-                K -= 1;
-                if (j >= rlow && j < rend) {
-                    const bool can = WINDOWED ? j > rthr : (G == 0 ? j > rthr : true);
-                    if (can && K >= 0) rlow = j - 2;
-                    const int t = qoff_v - (int)(int8_t)((qd[G] >> (8 * j)) & 0xffu);
-                    K += (t < q_v ? t : q_v) * 256;
-                    best = best > K ? best : K;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 3; j >= 0; --j) {
-                K -= 1;
-                if (j >= rlow) {
-                    const bool can = WINDOWED ? j > rthr : (G == 0 ? j > rthr : true);
-                    if (can && K >= 0) rlow = j - 2;
-                    const int t = qoff_v - (int)(int8_t)((qd[G] >> (8 * j)) & 0xffu);
-                    K += (t < q_v ? t : q_v) * 256;
-                    best = best > K ? best : K;
-                }
-            }
-        }
+        if (__any(rend < 4)) step<true>(qd[G], qoff_v, q_v, K, best, rlow, rend, rthr); // some window ends inside or below this step
+        else step<false>(qd[G], qoff_v, q_v, K, best, rlow, rend, rthr);
         Walk3<G - 1, ND, WINDOWED>::run(qd, qoff_v, q_v, K, best, rlow + 4, rend + 4, rthr + 4);
     }
 };
@@ -1048,12 +1048,14 @@ template <int G, int ND, bool WINDOWED> struct Walk5 {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             K -= 1;
-            if (j <= rhigh && (!WINDOWED || j >= rwa)) {
-                if (j < rthr && K >= 0) rhigh = j + 2;
-                const int t = qoff_v - (int)(int8_t)((qd[G] >> (8 * j)) & 0xffu);
-                K += (t < q_v ? t : q_v) * 256;
-                best = best > K ? best : K;
-            }
+            int live = (j - 1) - rhigh;                      // < 0: j <= rhigh
+            if (WINDOWED) live &= rwa - (j + 1);             // < 0: j >= rwa
+            const int rs = live & ~K & (j - rthr);           // < 0: visited, area >= 0 before, j < rthr
+            rhigh = rs < 0 ? j + 2 : rhigh;
+            const int t = qoff_v - (int)(int8_t)((qd[G] >> (8 * j)) & 0xffu);
+            const int dq = t < q_v ? t : q_v;
+            K += (dq & (live >> 31)) * 256;
+            best = best > K ? best : K;
         }
         Walk5<G + 1, ND, WINDOWED>::run(qd, qoff_v, q_v, K, best, rhigh - 4, rthr - 4, rwa - 4);
     }
@@ -1063,7 +1065,7 @@ template <int ND, bool WINDOWED> struct Walk5<ND, ND, WINDOWED> {
 };
 
 template <int C, int NW, bool WINDOWED>
-__global__ __launch_bounds__(NW * 64, 2) void trim_tpr(
+__global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
@@ -1074,6 +1076,8 @@ __global__ __launch_bounds__(NW * 64, 2) void trim_tpr(
     using T = TprCfg<C>;
     constexpr int D = Cfg::D, W = Cfg::W, NP = T::NP, ND = T::ND, NWORD = T::NWORD, NPOS = ND * 4;
     static_assert(!Cfg::HQ8 && NPOS <= 255, "positions must fit the low byte of the argmax keys");
+    static_assert(ND >= 16, "the snapshot column doubles as the 16 transition counters of exact_base_pass");
+    static_assert(T::lds_dwords(NW) * 4 <= 160 * 1024, "LDS");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *hb = smem + Cfg::O_HB;
     const uint32_t *t_lc = smem + Cfg::O_TLC;
@@ -1207,7 +1211,6 @@ __global__ __launch_bounds__(NW * 64, 2) void trim_tpr(
                         nub[(4 * k + j) >> 5] = __builtin_amdgcn_alignbit(e.y, nub[(4 * k + j) >> 5], 1); // bit (p & 31) = upper-case N at p
                     }
                 }
-                lds_store_u32(snap_base + (uint32_t)ND * 256u, cnt4);
                 if ((NPOS & 31) != 0) nub[NWORD - 1] >>= (32 - (NPOS & 31));
                 const int nACGT = (int)__builtin_amdgcn_sad_u8(cnt4, 0u, 0u);
                 int nup = 0;
@@ -1324,7 +1327,8 @@ __global__ __launch_bounds__(NW * 64, 2) void trim_tpr(
                 // ---- base counts before / inside the kept window (trim.cpp:390-403, :810-875) ---------------------
                 // prefix(x) = snapshot of dword x >> 2 plus the x & 3 bytes in front of x (one 4-byte load from the arena)
                 auto prefix4 = [&](int x) -> uint32_t {
-                    uint32_t c = lds_load_u32(snap_base + (uint32_t)(x >> 2) * 256u);
+                    uint32_t c = lds_load_u32(snap_base + (uint32_t)(x < NPOS ? x >> 2 : 0) * 256u);
+                    c = x < NPOS ? c : cnt4; // (the whole read)
                     if (__any((x & 3) != 0)) {
                         uint32_t w = 0;
                         if (x & 3) w = ((const PackedBytes<1> *)(seq + (size_t)v_off + (x & ~3)))->w[0] & low_bytes(x & 3);
@@ -1590,7 +1594,7 @@ static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const 
     }
     const uint32_t chunks = (n_reads + 63) / 64;
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    const int by_waves = (4 * 2 + NW - 1) / NW; // 2 waves per SIMD
+    const int by_waves = (4 * tpr_waves_per_simd(C) + NW - 1) / NW;
     if (blocks_per_cu > by_waves) blocks_per_cu = by_waves;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint32_t grid = (chunks + NW - 1) / NW;
@@ -1631,7 +1635,7 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
         {   // the two-phase kernel for the headline option set; FAQCS_TRIM_TPR=0 switches it off
             static const bool tpr = [] { const char *e = getenv("FAQCS_TRIM_TPR"); return !e || atoi(e) != 0; }();
 #define FAQCS_TRIM_CASE_TPR(C) \
-    return windowed ? launch_trim_tpr<C, FAQCS_TRIM_NW, true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, FAQCS_TRIM_NW, false>(FAQCS_TRIM_ARGS)
+    return windowed ? launch_trim_tpr<C, tpr_nw(C), true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C), false>(FAQCS_TRIM_ARGS)
             if (lpr8 && tpr && !generic && max_len > 76 && max_len <= 152) FAQCS_TRIM_CASE_TPR(19);
             if (lpr8 && tpr && !generic && max_len > 152 && max_len <= 160) FAQCS_TRIM_CASE_TPR(20);
 #undef FAQCS_TRIM_CASE_TPR
