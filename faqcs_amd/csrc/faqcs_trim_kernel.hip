@@ -319,8 +319,8 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
 #define FAQCS_TRIM_NW 4        /* waves per block (A/B on MI355X: 4 waves x 3 blocks/CU beat 8 x 1 by 9 %) */
 #endif
 // trim_tpr: ONE block per CU (its LDS holds 10 KB of prefix snapshots per wave): 12 waves = 3 per SIMD while the registers
-// allow it (C <= 19: 168 VGPRs without a spill), 8 waves otherwise
-constexpr int tpr_waves_per_simd(int C) { return C <= 19 ? 3 : 2; }
+// allow it (C = 19, the 2x150 shape: 168 VGPRs without a spill), 8 waves otherwise
+constexpr int tpr_waves_per_simd(int C) { return C == 19 ? 3 : 2; }
 constexpr int tpr_nw(int C) { return 4 * tpr_waves_per_simd(C); }
 #ifndef FAQCS_TRIM_MINWAVES
 #define FAQCS_TRIM_MINWAVES 3  /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
@@ -1636,7 +1636,8 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
             static const bool tpr = [] { const char *e = getenv("FAQCS_TRIM_TPR"); return !e || atoi(e) != 0; }();
 #define FAQCS_TRIM_CASE_TPR(C) \
     return windowed ? launch_trim_tpr<C, tpr_nw(C), true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C), false>(FAQCS_TRIM_ARGS)
-            if (lpr8 && tpr && !generic && max_len > 76 && max_len <= 152) FAQCS_TRIM_CASE_TPR(19);
+            if (lpr8 && tpr && !generic && max_len > 76 && max_len <= 104) FAQCS_TRIM_CASE_TPR(13);   // 2x100
+            if (lpr8 && tpr && !generic && max_len > 104 && max_len <= 152) FAQCS_TRIM_CASE_TPR(19);  // 2x150
             if (lpr8 && tpr && !generic && max_len > 152 && max_len <= 160) FAQCS_TRIM_CASE_TPR(20);
 #undef FAQCS_TRIM_CASE_TPR
         }
