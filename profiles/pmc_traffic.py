@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of profiles/collect.sh into the per-launch HBM
-traffic of trim_filter_accumulate, with the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE
+traffic of the trim kernel (trim_tpr / trim_filter_accumulate), with the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE
 is in KB and tallies 128-byte requests as 64 bytes -> x2; WRITE_SIZE in KB as is).
 Usage: pmc_traffic.py <dir with pmc_FETCH_SIZE/ pmc_WRITE_SIZE/> <reads per launch>"""
 import csv
@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
     for f in glob.glob(os.path.join(d, "pmc_" + c, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if row["Kernel_Name"].startswith("void trim_filter_accumulate") or "trim_filter_accumulate" in row["Kernel_Name"]:
+            if "trim_filter_accumulate" in row["Kernel_Name"] or "trim_tpr" in row["Kernel_Name"]:
                 if row["Counter_Name"] == c:
                     vals.append(float(row["Counter_Value"]))
                     name = row["Kernel_Name"]
