@@ -1,6 +1,8 @@
 """GPU parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
 libfaqcs_mi.so, against (1) the committed golden vectors produced by the real reference and (2) the CPU
 oracle on seeded random batches, bit-exact; plus size-independent properties at larger sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -178,6 +180,18 @@ def test_every_kernel_width_matches_oracle(args, kind, maxlen):
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     reads = random_batch(rng, 500 if "--adapter" in args else 1500, maxlen, kind)
     compare_engines(opt, reads, seg_size=389)
+
+
+def test_single_pass_kernel_variants_still_match_oracle():
+    """The default option set on reads of 77..160 bases runs trim_tpr; FAQCS_TRIM_TPR=0 (read once per process) sends the same
+    batches through the single-pass variants it replaced, which other option sets and A/B runs still use."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FAQCS_TRIM_TPR="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_every_kernel_width_matches_oracle or test_edge_reads or test_quality_error_is_reported"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
 
 
 def test_edge_reads():
