@@ -895,16 +895,19 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || C > 10) ? 2 : FAQCS_TRIM_MINW
 // ---------------------------------------------------------------------------------------------------------
 template <int C> struct TprCfg {
     using Row = RowCfg<C, 8>;
-    static constexpr int NP = (Row::W + 15) / 16;  // 16-byte pieces per read and arena
-    static constexpr int ND = NP * 4;              // dwords per read and arena held by the owner lane
+    static constexpr int NP = (Row::W + 15) / 16;  // 16-byte pieces per read and arena (the out-of-line exact passes)
+    static constexpr int ND = (Row::W + 3) / 4;    // dwords per read and arena held by the owner lane
+    static constexpr int NF = ND / 4, NR = ND % 4; // ... fetched as NF 16-byte pieces and one of NR dwords
+    static constexpr int SROW = 65;                // dwords per snapshot row: 64 lanes + 1, so that a column walk changes bank
     static constexpr int NWORD = (ND * 4 + 31) / 32;
     static constexpr int O_T2 = (Row::LDS_DWORDS + 3) & ~3;   // [256][2]: A,T,C,G one-hot in 8-bit fields ; isN(upper) | isN(any) << 1
-    static constexpr int O_SNAP = O_T2 + 512;                 // [NW][ND][64] class counts before dword k
-    static constexpr int SNAP_WAVE = ND * 64;
+    static constexpr int O_SNAP = O_T2 + 512;                 // [NW][ND][SROW] class counts before dword k; after phase A: the qualities
+    static constexpr int SNAP_WAVE = ND * SROW;
     static constexpr int lds_dwords(int nw) { return O_SNAP + nw * SNAP_WAVE; }
 };
 
 namespace {
+constexpr int TPR_SROW_BYTES = 65 * 4; // == TprCfg::SROW * 4
 typedef uint32_t LdsPair __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) LdsPair *lds_u2_ptr;
 __device__ __forceinline__ void lds_store_u32(uint32_t byte_offset, uint32_t v) { *(lds_u32_mut)(size_t)byte_offset = v; }
@@ -969,7 +972,7 @@ __device__ __noinline__ ExactBases exact_base_pass(const uint8_t *__restrict__ s
     uint32_t prev = 8u; // class 0..3 of the previous position if it is ACGT inside the window
     // (the lane's snapshot column is free by now and holds the 16 transition counters)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) lds_store_u32(snap_base + (uint32_t)i * 256u, 0u);
+    for (int i = 0; i < 16; ++i) lds_store_u32(snap_base + (uint32_t)i * (uint32_t)(TPR_SROW_BYTES), 0u);
 #pragma unroll 1
     for (int k = 0; k < NP; ++k) {
         if (!__any(16 * k < len)) break;
@@ -988,7 +991,7 @@ __device__ __noinline__ ExactBases exact_base_pass(const uint8_t *__restrict__ s
             r.npost += inw ? isn : 0u;
             const uint32_t cur = (e.x != 0u && inw) ? (uint32_t)__builtin_ctz(e.x) >> 3 : 8u;
             if (dinuc && cur < 4u && prev < 4u && cur != prev)
-                __hip_atomic_fetch_add((lds_u32_mut)(size_t)(snap_base + (prev * 4u + cur) * 256u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add((lds_u32_mut)(size_t)(snap_base + (prev * 4u + cur) * (uint32_t)(TPR_SROW_BYTES)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             prev = cur;
         }
     }
@@ -998,7 +1001,7 @@ __device__ __noinline__ ExactBases exact_base_pass(const uint8_t *__restrict__ s
 #pragma unroll
             for (int y = 0; y < 4; ++y)
                 if (x != y) {
-                    const uint32_t dc = lds_load_u32(snap_base + (uint32_t)(x * 4 + y) * 256u);
+                    const uint32_t dc = lds_load_u32(snap_base + (uint32_t)(x * 4 + y) * (uint32_t)(TPR_SROW_BYTES));
                     r.trip = r.trip || (((cpk >> (8 * x)) & 0xffu) >= dthr && ((cpk >> (8 * y)) & 0xffu) >= dthr && dc >= dthr);
                 }
     }
@@ -1074,9 +1077,10 @@ __global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
     constexpr int LPR = 8;
     using Cfg = RowCfg<C, LPR>;
     using T = TprCfg<C>;
-    constexpr int D = Cfg::D, W = Cfg::W, NP = T::NP, ND = T::ND, NWORD = T::NWORD, NPOS = ND * 4;
+    constexpr int D = Cfg::D, W = Cfg::W, NP = T::NP, ND = T::ND, NF = T::NF, NR = T::NR, NRX = NR ? NR : 1, NWORD = T::NWORD, NPOS = ND * 4;
     static_assert(!Cfg::HQ8 && NPOS <= 255, "positions must fit the low byte of the argmax keys");
     static_assert(ND >= 16, "the snapshot column doubles as the 16 transition counters of exact_base_pass");
+    static_assert(T::SROW * 4 == TPR_SROW_BYTES, "row stride");
     static_assert(T::lds_dwords(NW) * 4 <= 160 * 1024, "LDS");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *hb = smem + Cfg::O_HB;
@@ -1153,16 +1157,13 @@ __global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
             const uint32_t v_hit = (ad_hit && mine) ? ad_hit[my] : 0u;
 
             // ---- software prefetch of the row's read 0 for phase B ----------------------------------------
-            PackedBytes<D> nseq, nqual;
+            PackedBytes<D> nseq; // (bases only: the qualities reach phase B through LDS)
             int n_len = __shfl((int)v_len, rowb);
             {
                 const uint32_t o = (uint32_t)__shfl((int)v_off, rowb);
 #pragma unroll
-                for (int k = 0; k < D; ++k) { nseq.w[k] = 0; nqual.w[k] = 0; }
-                if (pbase < n_len) {
-                    nseq = *(const PackedBytes<D> *)(seq + (size_t)o + pbase);
-                    nqual = *(const PackedBytes<D> *)(qual + (size_t)o + pbase);
-                }
+                for (int k = 0; k < D; ++k) nseq.w[k] = 0;
+                if (pbase < n_len) nseq = *(const PackedBytes<D> *)(seq + (size_t)o + pbase);
             }
 
             // ================= phase A: one read per lane =====================================================
@@ -1172,7 +1173,7 @@ __global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
                 const int len = (int)v_len;
                 uint32_t sd[ND], qd[ND];
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
+                for (int k = 0; k < NF; ++k) {
                     PackedBytes<4> ts, tq;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { ts.w[i] = 0u; tq.w[i] = offb; }
@@ -1182,6 +1183,17 @@ __global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { sd[4 * k + i] = ts.w[i]; qd[4 * k + i] = tq.w[i]; }
+                }
+                if (NR) {
+                    PackedBytes<NRX> ts, tq;
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) { ts.w[i] = 0u; tq.w[i] = offb; }
+                    if (16 * NF < len) {
+                        ts = *(const PackedBytes<NRX> *)(seq + (size_t)v_off + 16 * NF);
+                        tq = *(const PackedBytes<NRX> *)(qual + (size_t)v_off + 16 * NF);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) { sd[4 * NF + i] = ts.w[i]; qd[4 * NF + i] = tq.w[i]; }
                 }
                 uint32_t blast = 0; // last base (a lane without a read must not touch the arena: its offset is not one)
                 if (len) blast = (uint32_t)seq[(size_t)v_off + len - 1];
@@ -1201,7 +1213,7 @@ __global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
                 for (int w = 0; w < NWORD; ++w) nub[w] = 0;
 #pragma unroll
                 for (int k = 0; k < ND; ++k) {
-                    lds_store_u32(snap_base + (uint32_t)k * 256u, cnt4);
+                    lds_store_u32(snap_base + (uint32_t)k * (uint32_t)(TPR_SROW_BYTES), cnt4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t ad = (j == 0 ? byte_times8<0>(sd[k], three) : j == 1 ? byte_times8<1>(sd[k], three)
@@ -1327,7 +1339,7 @@ __global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
                 // ---- base counts before / inside the kept window (trim.cpp:390-403, :810-875) ---------------------
                 // prefix(x) = snapshot of dword x >> 2 plus the x & 3 bytes in front of x (one 4-byte load from the arena)
                 auto prefix4 = [&](int x) -> uint32_t {
-                    uint32_t c = lds_load_u32(snap_base + (uint32_t)(x < NPOS ? x >> 2 : 0) * 256u);
+                    uint32_t c = lds_load_u32(snap_base + (uint32_t)(x < NPOS ? x >> 2 : 0) * (uint32_t)(TPR_SROW_BYTES));
                     c = x < NPOS ? c : cnt4; // (the whole read)
                     if (__any((x & 3) != 0)) {
                         uint32_t w = 0;
@@ -1397,10 +1409,15 @@ __global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
                 oc.cAT = cA | (cT << 16); oc.cCG = cC | (cG << 16);
                 oc.N = pN | (cN << 16);
                 oc.Vpre = V_pre; oc.Vpost = V_post;
-                v_info = (uint32_t)a | ((uint32_t)n << 8) | (ret ? 1u << 16 : 0u) | (read_err ? 1u << 17 : 0u) | (tn ? 1u << 18 : 0u);
+                v_info = (uint32_t)a | ((uint32_t)n << 8) | (ret ? 1u << 16 : 0u) | (read_err ? 1u << 17 : 0u);
+                // the snapshots are spent: the column now carries this read's quality bytes (terminal-N runs already at the
+                // offset, bytes past the read too) to the 8 lanes that accumulate it in phase B
+#pragma unroll
+                for (int k = 0; k < ND; ++k) lds_store_u32(snap_base + (uint32_t)k * (uint32_t)(TPR_SROW_BYTES), qd[k]);
             }
 
             // ================= phase B: 8 lanes per read, accumulate only ====================================
+            const uint32_t qcol = (uint32_t)(T::O_SNAP + wave * T::SNAP_WAVE) * 4u; // LDS byte address of the wave's column block
 #pragma unroll 1
             for (int t = 0; t < LPR; ++t) {
                 if (base + (uint32_t)t >= n_reads) break; // wave-uniform: no row has a read left
@@ -1408,19 +1425,16 @@ __global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
                 const bool act = base + (uint32_t)(rowb + t) < n_reads;
                 uint32_t ws[D], wq[D];
 #pragma unroll
-                for (int k = 0; k < D; ++k) { ws[k] = nseq.w[k]; wq[k] = nqual.w[k]; }
+                for (int k = 0; k < D; ++k) ws[k] = nseq.w[k];
                 const uint32_t info = (uint32_t)__shfl((int)v_info, rowb + t);
                 if (t + 1 < LPR) {
                     n_len = __shfl((int)v_len, rowb + t + 1);
                     const uint32_t o = (uint32_t)__shfl((int)v_off, rowb + t + 1);
 #pragma unroll
-                    for (int k = 0; k < D; ++k) { nseq.w[k] = 0; nqual.w[k] = 0; }
-                    if (pbase < n_len) {
-                        nseq = *(const PackedBytes<D> *)(seq + (size_t)o + pbase);
-                        nqual = *(const PackedBytes<D> *)(qual + (size_t)o + pbase);
-                    }
+                    for (int k = 0; k < D; ++k) nseq.w[k] = 0;
+                    if (pbase < n_len) nseq = *(const PackedBytes<D> *)(seq + (size_t)o + pbase);
                 }
-                { // zero the bytes past the end of the read (the last dword of a lane may over-read 1..3 bytes)
+                { // zero the base bytes past the end of the read (the last dword of a lane may over-read 1..3 bytes)
                     const int vb = med3i(len - pbase, 0, C);
                     const uint4 bm = *reinterpret_cast<const uint4 *>(t_bm + Cfg::BMW * vb);
                     uint32_t m[8] = {bm.x, bm.y, bm.z, bm.w, 0u, 0u, 0u, 0u};
@@ -1429,21 +1443,18 @@ __global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
                         m[4] = bm2.x; m[5] = bm2.y; m[6] = bm2.z; m[7] = bm2.w;
                     }
 #pragma unroll
-                    for (int k = 0; k < D; ++k) { ws[k] &= m[k]; wq[k] &= m[k]; }
+                    for (int k = 0; k < D; ++k) ws[k] &= m[k];
                 }
-                if (__any((info >> 18) & 1u)) { // terminal-N runs: their quality bytes become the offset (rare)
-                    const uint32_t pt = (uint32_t)__shfl((int)v_patch, rowb + t);
-                    const int lead = ((info >> 18) & 1u) ? (int)(pt & 0xffu) : 0, trail = ((info >> 18) & 1u) ? (int)(pt >> 8) : len;
-                    int pb = pbase;
-                    asm volatile("" : "+v"(pb)); // (keeps the 19 position values out of the loop-invariant registers)
+                { // the lane's C quality bytes out of the owner's column: dwords pbase / 4 ..., shifted into place
+                    const uint32_t col = qcol + (uint32_t)(rowb + t) * 4u;
+                    uint32_t rq[D + 1];
 #pragma unroll
-                    for (int j = 0; j < C; ++j) {
-                        const int p = pb + j;
-                        if (p < len && (p < lead || p >= trail)) {
-                            const uint32_t sh = 8 * (j & 3);
-                            wq[j >> 2] = (wq[j >> 2] & ~(0xffu << sh)) | (((uint32_t)in_off & 0xffu) << sh);
-                        }
+                    for (int i = 0; i <= D; ++i) {
+                        const int row = (pbase >> 2) + i;
+                        rq[i] = lds_load_u32(col + (uint32_t)(row < ND ? row : ND - 1) * (uint32_t)(TPR_SROW_BYTES));
                     }
+#pragma unroll
+                    for (int i = 0; i < D; ++i) wq[i] = __builtin_amdgcn_alignbyte(rq[i + 1], rq[i], (uint32_t)(pbase & 3));
                 }
                 const int a = (int)(info & 0xffu), n = (int)((info >> 8) & 0xffu);
                 const bool ret = ((info >> 16) & 1u) != 0u, read_err = ((info >> 17) & 1u) != 0u;
