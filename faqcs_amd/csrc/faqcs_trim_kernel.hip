@@ -320,8 +320,12 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
 #endif
 // trim_tpr: ONE block per CU (its LDS holds 10 KB of prefix snapshots per wave): 12 waves = 3 per SIMD while the registers
 // allow it (C = 19, the 2x150 shape: 168 VGPRs without a spill), 8 waves otherwise
-constexpr int tpr_waves_per_simd(int C) { return C == 19 ? 3 : 2; }
-constexpr int tpr_nw(int C) { return 4 * tpr_waves_per_simd(C); }
+constexpr int tpr_waves_per_simd(int C) { return (C == 19 || C == 13) ? 3 : 2; }   // what the hardware gets to run
+// C = 19: one block of 12 waves, compiled for 3 waves per SIMD (168 VGPRs, no spill).  C = 13 needs 152 registers when the
+// compiler is asked for 2 waves per SIMD but spills under a 168 cap, so it is compiled for 2 and launched as three
+// blocks of 4 waves (the hardware co-schedules them: 152 <= 168).  C = 20: one block of 8.
+constexpr int tpr_nw(int C) { return C == 19 ? 12 : (C == 13 ? 4 : 8); }
+constexpr int tpr_bounds_waves(int C) { return C == 19 ? 3 : 2; }
 #ifndef FAQCS_TRIM_MINWAVES
 #define FAQCS_TRIM_MINWAVES 3  /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
 #endif
@@ -1068,7 +1072,7 @@ template <int ND, bool WINDOWED> struct Walk5<ND, ND, WINDOWED> {
 };
 
 template <int C, int NW, bool WINDOWED>
-__global__ __launch_bounds__(NW * 64, tpr_waves_per_simd(C)) void trim_tpr(
+__global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C)) void trim_tpr(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
