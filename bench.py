@@ -214,7 +214,7 @@ def main():
         trim_kernel = "trim_tpr" if 76 < L <= 152 and os.environ.get("FAQCS_TRIM_TPR", "1") != "0" else "trim_filter_accumulate"
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config)
-        if os.path.exists(tf):
+        if os.path.exists(tf) and L == 150:  # (measured on the 2x150 shape only)
             try:
                 # measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied);
                 # stored per read, scaled to this run's launch size
