@@ -210,8 +210,8 @@ def main():
         reads_per_launch = n_reads / max(1, len(batches))
         alg_bytes = reads_per_launch * (2 * L + 4 + 8)
         achieved = alg_bytes / (avg_ms.value * 1e-3) / 1e9 if avg_ms.value > 0 else 0.0
-        # the default option set on reads of 77..152 bases runs the two-phase kernel (faqcs_trim_kernel.hip: faqcs_launch_trim)
-        trim_kernel = "trim_tpr" if 76 < L <= 152 and os.environ.get("FAQCS_TRIM_TPR", "1") != "0" else "trim_filter_accumulate"
+        # the default option set on reads of up to 160 bases runs the two-phase kernel (faqcs_trim_kernel.hip: faqcs_launch_trim)
+        trim_kernel = "trim_tpr" if L <= 160 and os.environ.get("FAQCS_TRIM_TPR", "1") != "0" else "trim_filter_accumulate"
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config)
         if os.path.exists(tf) and L == 150:  # (measured on the 2x150 shape only)

@@ -320,12 +320,13 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
 #endif
 // trim_tpr: ONE block per CU (its LDS holds 10 KB of prefix snapshots per wave): 12 waves = 3 per SIMD while the registers
 // allow it (C = 19, the 2x150 shape: 168 VGPRs without a spill), 8 waves otherwise
-constexpr int tpr_waves_per_simd(int C) { return (C == 19 || C == 13) ? 3 : 2; }   // what the hardware gets to run
+constexpr int tpr_waves_per_simd(int C, int LPR = 8) { return (LPR == 4 || C == 19 || C == 13) ? 3 : 2; } // what the hardware gets to run
 // C = 19: one block of 12 waves, compiled for 3 waves per SIMD (168 VGPRs, no spill).  C = 13 needs 152 registers when the
 // compiler is asked for 2 waves per SIMD but spills under a 168 cap, so it is compiled for 2 and launched as three
 // blocks of 4 waves (the hardware co-schedules them: 152 <= 168).  C = 20: one block of 8.
-constexpr int tpr_nw(int C) { return C == 19 ? 12 : (C == 13 ? 4 : 8); }
-constexpr int tpr_bounds_waves(int C) { return C == 19 ? 3 : 2; }
+// 4 lanes per read in phase B (reads <= 76 bases): like C = 13.
+constexpr int tpr_nw(int C, int LPR = 8) { return LPR == 4 ? 4 : (C == 19 ? 12 : (C == 13 ? 4 : 8)); }
+constexpr int tpr_bounds_waves(int C, int LPR = 8) { return (LPR == 8 && C == 19) ? 3 : 2; }
 #ifndef FAQCS_TRIM_MINWAVES
 #define FAQCS_TRIM_MINWAVES 3  /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
 #endif
@@ -897,8 +898,8 @@ __global__ __launch_bounds__(NW * 64, (LPR == 8 || C > 10) ? 2 : FAQCS_TRIM_MINW
 //   Rare inputs (a raw quality outside [offset, offset + 41], letters other than ACGTN, dinucleotide candidates)
 //     take exact per-position passes over the registers, entered only by chunks that contain such a read.
 // ---------------------------------------------------------------------------------------------------------
-template <int C> struct TprCfg {
-    using Row = RowCfg<C, 8>;
+template <int C, int LPR = 8> struct TprCfg {
+    using Row = RowCfg<C, LPR>;
     static constexpr int NP = (Row::W + 15) / 16;  // 16-byte pieces per read and arena (the out-of-line exact passes)
     static constexpr int ND = (Row::W + 3) / 4;    // dwords per read and arena held by the owner lane
     static constexpr int NF = ND / 4, NR = ND % 4; // ... fetched as NF 16-byte pieces and one of NR dwords
@@ -1071,16 +1072,16 @@ template <int ND, bool WINDOWED> struct Walk5<ND, ND, WINDOWED> {
     static __device__ __forceinline__ void run(const uint32_t (&)[ND], int, int, int &, int &, int, int, int) {}
 };
 
-template <int C, int NW, bool WINDOWED>
-__global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C)) void trim_tpr(
+template <int C, int NW, bool WINDOWED, int LPR = 8>
+__global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C, LPR)) void trim_tpr(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
     unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err)
 {
-    constexpr int LPR = 8;
+    static_assert(LPR == 8 || LPR == 4, "phase B runs 8 or 4 lanes per read");
     using Cfg = RowCfg<C, LPR>;
-    using T = TprCfg<C>;
+    using T = TprCfg<C, LPR>;
     constexpr int D = Cfg::D, W = Cfg::W, NP = T::NP, ND = T::ND, NF = T::NF, NR = T::NR, NRX = NR ? NR : 1, NWORD = T::NWORD, NPOS = ND * 4;
     static_assert(!Cfg::HQ8 && NPOS <= 255, "positions must fit the low byte of the argmax keys");
     static_assert(ND >= 16, "the snapshot column doubles as the 16 transition counters of exact_base_pass");
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C)) void trim_tpr(
     const uint32_t chunks_per_iter = gridDim.x * NW;
     const uint32_t n_iter = (total_chunks + chunks_per_iter - 1) / chunks_per_iter;
     constexpr uint32_t FLUSH_EVERY = 65535u / (NW * 64) > 0 ? 65535u / (NW * 64) : 1;
-    constexpr uint32_t REG_FLUSH_EVERY = 7; // 6-bit fields: 7 chunks x 8 reads per row = 56 <= 63
+    constexpr uint32_t REG_FLUSH_EVERY = LPR == 8 ? 7 : 15; // 6-bit fields: 7 chunks x 8 (15 x 4) reads per row <= 63
 
     const int in_off = P.in_off, Q = P.Q;
     const uint32_t snap_base = (uint32_t)(T::O_SNAP + wave * T::SNAP_WAVE + lane) * 4u; // LDS byte address of this lane's column
@@ -1593,15 +1594,15 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
     return hipGetLastError();
 }
 
-template <int C, int NW, bool WINDOWED>
+template <int C, int NW, bool WINDOWED, int LPR = 8>
 static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                   uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
                                   unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
                                   int n_cu, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)TprCfg<C>::lds_dwords(NW) * 4;
+    constexpr size_t lds = (size_t)TprCfg<C, LPR>::lds_dwords(NW) * 4;
     static bool attr_set = false;
-    auto kern = trim_tpr<C, NW, WINDOWED>;
+    auto kern = trim_tpr<C, NW, WINDOWED, LPR>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1609,7 +1610,7 @@ static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const 
     }
     const uint32_t chunks = (n_reads + 63) / 64;
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    const int by_waves = (4 * tpr_waves_per_simd(C) + NW - 1) / NW;
+    const int by_waves = (4 * tpr_waves_per_simd(C, LPR) + NW - 1) / NW;
     if (blocks_per_cu > by_waves) blocks_per_cu = by_waves;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint32_t grid = (chunks + NW - 1) / NW;
@@ -1638,15 +1639,6 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
 #define FAQCS_TRIM_CASE8(C)                                                                                 \
     return windowed ? (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS)) \
                     : (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS))
-        {   // 4 lanes per read (16 reads per wave): reads <= 76 bases (2x75, 2x50); FAQCS_TRIM_LPR4=0 switches it off
-            static const bool lpr4 = [] { const char *e = getenv("FAQCS_TRIM_LPR4"); return !e || atoi(e) != 0; }();
-#define FAQCS_TRIM_CASE4(C)                                                                                 \
-    return windowed ? (generic ? launch_trim_t<C, 4, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 4, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS)) \
-                    : (generic ? launch_trim_t<C, 4, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 4, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS))
-            if (lpr4 && max_len <= 64) FAQCS_TRIM_CASE4(16);
-            if (lpr4 && max_len <= 76) FAQCS_TRIM_CASE4(19);
-#undef FAQCS_TRIM_CASE4
-        }
         {   // the two-phase kernel for the headline option set; FAQCS_TRIM_TPR=0 switches it off
             static const bool tpr = [] { const char *e = getenv("FAQCS_TRIM_TPR"); return !e || atoi(e) != 0; }();
 #define FAQCS_TRIM_CASE_TPR(C) \
@@ -1655,6 +1647,23 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
             if (lpr8 && tpr && !generic && max_len > 104 && max_len <= 152) FAQCS_TRIM_CASE_TPR(19);  // 2x150
             if (lpr8 && tpr && !generic && max_len > 152 && max_len <= 160) FAQCS_TRIM_CASE_TPR(20);
 #undef FAQCS_TRIM_CASE_TPR
+#define FAQCS_TRIM_CASE_TPR4(C) \
+    return windowed ? launch_trim_tpr<C, tpr_nw(C, 4), true, 4>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C, 4), false, 4>(FAQCS_TRIM_ARGS)
+            {   // reads <= 76 bases: 4 lanes per read in phase B (2x75, 2x50)
+                static const bool lpr4t = [] { const char *e = getenv("FAQCS_TRIM_LPR4"); return !e || atoi(e) != 0; }();
+                if (lpr4t && tpr && !generic && max_len > 0 && max_len <= 64) FAQCS_TRIM_CASE_TPR4(16);
+                if (lpr4t && tpr && !generic && max_len > 64 && max_len <= 76) FAQCS_TRIM_CASE_TPR4(19);
+            }
+#undef FAQCS_TRIM_CASE_TPR4
+        }
+        {   // 4 lanes per read (16 reads per wave): reads <= 76 bases (2x75, 2x50); FAQCS_TRIM_LPR4=0 switches it off
+            static const bool lpr4 = [] { const char *e = getenv("FAQCS_TRIM_LPR4"); return !e || atoi(e) != 0; }();
+#define FAQCS_TRIM_CASE4(C)                                                                                 \
+    return windowed ? (generic ? launch_trim_t<C, 4, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 4, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS)) \
+                    : (generic ? launch_trim_t<C, 4, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 4, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS))
+            if (lpr4 && max_len <= 64) FAQCS_TRIM_CASE4(16);
+            if (lpr4 && max_len <= 76) FAQCS_TRIM_CASE4(19);
+#undef FAQCS_TRIM_CASE4
         }
         if (lpr8 && max_len <= 64) FAQCS_TRIM_CASE8(8);
         if (lpr8 && max_len <= 104) FAQCS_TRIM_CASE8(13);   // 2x100

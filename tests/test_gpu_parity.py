@@ -183,7 +183,7 @@ def test_every_kernel_width_matches_oracle(args, kind, maxlen):
 
 
 def test_single_pass_kernel_variants_still_match_oracle():
-    """The default option set on reads of 77..160 bases runs trim_tpr; FAQCS_TRIM_TPR=0 (read once per process) sends the same
+    """The default option set on reads of up to 160 bases runs trim_tpr; FAQCS_TRIM_TPR=0 (read once per process) sends the same
     batches through the single-pass variants it replaced, which other option sets and A/B runs still use."""
     import subprocess
     import sys
