@@ -16,6 +16,8 @@ python3 bench.py --read-len 250 --pairs 40e6 --no-cpu-baseline > $out/bench_plai
 python3 bench.py --read-len 300 --pairs 20e6 --no-cpu-baseline > $out/bench_plain_300bp_20Mpairs.json 2>> $out/bench_plain.err
 python3 bench.py --read-len 100 --pairs 60e6 --no-cpu-baseline > $out/bench_plain_100bp_60Mpairs.json 2>> $out/bench_plain.err
 python3 bench.py --read-len 75 --pairs 60e6 --no-cpu-baseline > $out/bench_plain_75bp_60Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 50 --pairs 60e6 --no-cpu-baseline > $out/bench_plain_50bp_60Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 125 --pairs 40e6 --no-cpu-baseline > $out/bench_plain_125bp_40Mpairs.json 2>> $out/bench_plain.err
 python3 bench.py --read-len 600 --pairs 8e6 --no-cpu-baseline > $out/bench_plain_600bp_8Mpairs.json 2>> $out/bench_plain.err
 python3 bench.py --config adapter --read-len 300 --pairs 4e6 --no-cpu-baseline > $out/bench_adapter_300bp_4Mpairs.json 2>> $out/bench_adapter.err
 python3 bench.py --config kmer --no-cpu-baseline --steps 3 > $out/bench_kmer_250bp_10Mpairs.json 2>> $out/bench_plain.err
