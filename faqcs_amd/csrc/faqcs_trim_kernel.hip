@@ -1,9 +1,12 @@
-// faqcs_trim_kernel.hip -- trim_filter_accumulate + composition_histogram (gfx950, wave64).
+// faqcs_trim_kernel.hip -- trim_tpr, trim_filter_accumulate + composition_histogram (gfx950, wave64).
 //
 // Replaces trim_read() and its helpers (trim.cpp:225-551, :553-597, :629-885, :1191-1216) for every read
-// of a batch.
+// of a batch.  Two kernels share the accumulators, the flush and the per-chunk epilogue:
+//   trim_tpr                 the default option set on reads of up to 160 bases (the headline shapes): two phases per
+//                            64-read chunk, described at its definition further down
+//   trim_filter_accumulate   every other option set and read length: one pass, described here
 //
-// Mapping.  LPR lanes share one read and lane l of the group owns the C consecutive positions [l*C, l*C+C), fetched
+// Mapping (trim_filter_accumulate).  LPR lanes share one read and lane l of the group owns the C consecutive positions [l*C, l*C+C), fetched
 // with ONE unaligned global_load_dwordx{D} per arena; a wave takes chunks of 64 reads.
 //   LPR =  4  reads <= 76 bases (C = 16 / 19):      sixteen reads per wave, one per DPP quad
 //   LPR =  8  reads <= 160 bases (C = 8 ... 20):    eight reads per wave, two per 16-lane DPP row
