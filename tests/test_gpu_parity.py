@@ -182,6 +182,17 @@ def test_every_kernel_width_matches_oracle(args, kind, maxlen):
     compare_engines(opt, reads, seg_size=389)
 
 
+@pytest.mark.parametrize("in_off", [40, 64, 90, 100])
+@pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 100), ("adv", 70)])
+def test_quality_offsets_that_leave_scores_outside_the_valid_range(in_off, kind, maxlen):
+    """Raw quality bytes are generated for Phred+33; decoding them with a larger offset makes most scores negative (clamped to
+    0 by the trimmers, not by the averages) -- the per-position exact pass of the two-phase kernel instead of its four-bytes-per-
+    instruction sums.  Offsets above 86 switch the packed range check off altogether."""
+    rng = np.random.Generator(np.random.PCG64([11, in_off, maxlen, SEED]))
+    opt = parse_args(["-u", "x", "-d", "y", "--ascii", str(in_off), "--min_L", "20"])
+    compare_engines(opt, random_batch(rng, 1200, maxlen, kind), in_off=in_off, seg_size=500)
+
+
 def test_single_pass_kernel_variants_still_match_oracle():
     """The default option set on reads of up to 160 bases runs trim_tpr; FAQCS_TRIM_TPR=0 (read once per process) sends the same
     batches through the single-pass variants it replaced, which other option sets and A/B runs still use."""
