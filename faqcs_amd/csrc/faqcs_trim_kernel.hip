@@ -323,13 +323,14 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
 #endif
 // trim_tpr: ONE block per CU (its LDS holds 10 KB of prefix snapshots per wave): 12 waves = 3 per SIMD while the registers
 // allow it (C = 19, the 2x150 shape: 168 VGPRs without a spill), 8 waves otherwise
-constexpr int tpr_waves_per_simd(int C, int LPR = 8) { return (LPR == 4 || C == 19 || C == 13) ? 3 : 2; } // what the hardware gets to run
+constexpr int tpr_waves_per_simd(int C, int LPR = 8, bool ext = false) { return (LPR == 4 || (C == 19 && !ext) || C == 13) ? 3 : 2; } // what the hardware gets to run
 // C = 19: one block of 12 waves, compiled for 3 waves per SIMD (168 VGPRs, no spill).  C = 13 needs 152 registers when the
 // compiler is asked for 2 waves per SIMD but spills under a 168 cap, so it is compiled for 2 and launched as three
 // blocks of 4 waves (the hardware co-schedules them: 152 <= 168).  C = 20: one block of 8.
 // 4 lanes per read in phase B (reads <= 76 bases): like C = 13.
-constexpr int tpr_nw(int C, int LPR = 8) { return LPR == 4 ? 4 : (C == 19 ? 12 : (C == 13 ? 4 : 8)); }
-constexpr int tpr_bounds_waves(int C, int LPR = 8) { return (LPR == 8 && C == 19) ? 3 : 2; }
+// EXT (--5trim_off, --avg_q, -n 0/1 on top of the default set): C = 19 then runs one block of 8 like C = 20.
+constexpr int tpr_nw(int C, int LPR = 8, bool ext = false) { return LPR == 4 ? 4 : (C == 19 ? (ext ? 8 : 12) : (C == 13 ? 4 : 8)); }
+constexpr int tpr_bounds_waves(int C, int LPR = 8, bool ext = false) { return (LPR == 8 && C == 19 && !ext) ? 3 : 2; }
 #ifndef FAQCS_TRIM_MINWAVES
 #define FAQCS_TRIM_MINWAVES 3  /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
 #endif
@@ -1075,8 +1076,8 @@ template <int ND, bool WINDOWED> struct Walk5<ND, ND, WINDOWED> {
     static __device__ __forceinline__ void run(const uint32_t (&)[ND], int, int, int &, int &, int, int, int) {}
 };
 
-template <int C, int NW, bool WINDOWED, int LPR = 8>
-__global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C, LPR)) void trim_tpr(
+template <int C, int NW, bool WINDOWED, int LPR = 8, bool EXT = false>
+__global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C, LPR, EXT)) void trim_tpr(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
@@ -1311,7 +1312,8 @@ __global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C, LPR)) void trim_tpr(
                 const int fp3 = S3 > 0 ? (best & 255) - 1 - wa : wn - 1;
                 // 5' walk (trim.cpp:752-779): resets need pos_5 < final_pos_3 - n2; the FIRST maximum wins (low byte = 255 - p)
                 int best5 = 255, K5 = 256;
-                Walk5<0, ND, WINDOWED>::run(qd, qoff_v, q_v, K5, best5, wn > 0 ? wa + a5 - 1 : -1, wa + fp3 - nn2, wa);
+                if (!(EXT && P.protect5)) // --5trim_off (trim.cpp:752)
+                    Walk5<0, ND, WINDOWED>::run(qd, qoff_v, q_v, K5, best5, wn > 0 ? wa + a5 - 1 : -1, wa + fp3 - nn2, wa);
                 const int S5 = best5 >> 8;
                 const int fp5 = S5 > 0 ? (255 - (best5 & 255)) + 1 - wa : 0;
 
@@ -1328,8 +1330,13 @@ __global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C, LPR)) void trim_tpr(
                     if (n < (int)P.min_len || n == 0) { ret = false; filt = FAQCS_FILT_LENGTH_POST; }
                 }
 
-                // ---- poly-N (-n 2; trim.cpp:363-371, :578-597): two adjacent upper-case N inside the kept window ----
-                {
+                // ---- poly-N (trim.cpp:363-371, :578-597): -n 2 = two adjacent upper-case N inside the kept window ----
+                if (EXT && P.max_poly_n != 2u) { // -n 0: every read trips; -n 1: any upper-case N inside the kept window
+                    uint32_t hit = 0;
+#pragma unroll
+                    for (int w = 0; w < NWORD; ++w) hit |= nub[w] & bit_range(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
+                    if (ret && (P.max_poly_n == 0u || hit != 0u)) { flags |= FAQCS_F_POLY_N_SEEN; ret = false; filt = FAQCS_FILT_POLY_N; }
+                } else {
                     uint32_t pr[NWORD], anyp = 0; // bit e: N at e - 1 and at e
 #pragma unroll
                     for (int w = 0; w < NWORD; ++w) {
@@ -1388,6 +1395,9 @@ __global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C, LPR)) void trim_tpr(
                     const ExactQuality xq = exact_quality_pass<NP>(qual, v_off, len, tn ? v_patch : ((uint32_t)len << 8), a, n, in_off);
                     if (badq) { V_pre = xq.sv; V_post = xq.svp; read_err = xq.mq > 41; }
                 }
+
+                // ---- average quality (trim.cpp:374-382) -------------------------------------------------------------
+                if (EXT && P.avgq_on && ret && V_post < ((const int32_t *)(smem + Cfg::O_TAVGQ))[n]) { ret = false; filt = FAQCS_FILT_AVG_Q; }
 
                 // ---- low-complexity filter (trim.cpp:405-513) ---------------------------------------------------
                 bool lc_trip = false, dinuc = false;
@@ -1493,7 +1503,7 @@ __global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C, LPR)) void trim_tpr(
 
             // ---- chunk epilogue: one read per lane ----------------------------------------------------------
             chunk_epilogue<LPR>(oc, mine, my, v_len, v_hit, lane, smem + Cfg::O_LEN, smem + Cfg::O_RQ, smem + Cfg::O_BQPRE,
-                                smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, false, 0u);
+                                smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, EXT && P.avgq_on != 0, 0u);
         }
 
         const bool block_flush = ((it + 1) % FLUSH_EVERY) == 0 || it + 1 == n_iter;
@@ -1597,7 +1607,7 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
     return hipGetLastError();
 }
 
-template <int C, int NW, bool WINDOWED, int LPR = 8>
+template <int C, int NW, bool WINDOWED, int LPR = 8, bool EXT = false>
 static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                   uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
                                   unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
@@ -1605,7 +1615,7 @@ static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const 
 {
     constexpr size_t lds = (size_t)TprCfg<C, LPR>::lds_dwords(NW) * 4;
     static bool attr_set = false;
-    auto kern = trim_tpr<C, NW, WINDOWED, LPR>;
+    auto kern = trim_tpr<C, NW, WINDOWED, LPR, EXT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1613,7 +1623,7 @@ static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const 
     }
     const uint32_t chunks = (n_reads + 63) / 64;
     int blocks_per_cu = (int)((160 * 1024) / lds);
-    const int by_waves = (4 * tpr_waves_per_simd(C, LPR) + NW - 1) / NW;
+    const int by_waves = (4 * tpr_waves_per_simd(C, LPR, EXT) + NW - 1) / NW;
     if (blocks_per_cu > by_waves) blocks_per_cu = by_waves;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint32_t grid = (chunks + NW - 1) / NW;
@@ -1644,18 +1654,22 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
                     : (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS))
         {   // the two-phase kernel for the headline option set; FAQCS_TRIM_TPR=0 switches it off
             static const bool tpr = [] { const char *e = getenv("FAQCS_TRIM_TPR"); return !e || atoi(e) != 0; }();
+            // EXT: the default set plus --5trim_off / --avg_q / -n 0 or 1 (compiled apart so that the default variants stay as they are)
+            const bool ext = generic && P.mode == FAQCS_MODE_BWA_PLUS && !P.qc_only && P.replace_q == 0 && P.max_poly_n <= 2 && P.dbg == 0;
 #define FAQCS_TRIM_CASE_TPR(C) \
-    return windowed ? launch_trim_tpr<C, tpr_nw(C), true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C), false>(FAQCS_TRIM_ARGS)
-            if (lpr8 && tpr && !generic && max_len > 76 && max_len <= 104) FAQCS_TRIM_CASE_TPR(13);   // 2x100
-            if (lpr8 && tpr && !generic && max_len > 104 && max_len <= 152) FAQCS_TRIM_CASE_TPR(19);  // 2x150
+    return ext ? (windowed ? launch_trim_tpr<C, tpr_nw(C, 8, true), true, 8, true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C, 8, true), false, 8, true>(FAQCS_TRIM_ARGS)) \
+               : (windowed ? launch_trim_tpr<C, tpr_nw(C), true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C), false>(FAQCS_TRIM_ARGS))
+            if (lpr8 && tpr && (!generic || ext) && max_len > 76 && max_len <= 104) FAQCS_TRIM_CASE_TPR(13);   // 2x100
+            if (lpr8 && tpr && (!generic || ext) && max_len > 104 && max_len <= 152) FAQCS_TRIM_CASE_TPR(19);  // 2x150
             if (lpr8 && tpr && !generic && max_len > 152 && max_len <= 160) FAQCS_TRIM_CASE_TPR(20);
 #undef FAQCS_TRIM_CASE_TPR
 #define FAQCS_TRIM_CASE_TPR4(C) \
-    return windowed ? launch_trim_tpr<C, tpr_nw(C, 4), true, 4>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C, 4), false, 4>(FAQCS_TRIM_ARGS)
+    return ext ? (windowed ? launch_trim_tpr<C, tpr_nw(C, 4), true, 4, true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C, 4), false, 4, true>(FAQCS_TRIM_ARGS)) \
+               : (windowed ? launch_trim_tpr<C, tpr_nw(C, 4), true, 4>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C, 4), false, 4>(FAQCS_TRIM_ARGS))
             {   // reads <= 76 bases: 4 lanes per read in phase B (2x75, 2x50)
                 static const bool lpr4t = [] { const char *e = getenv("FAQCS_TRIM_LPR4"); return !e || atoi(e) != 0; }();
-                if (lpr4t && tpr && !generic && max_len > 0 && max_len <= 64) FAQCS_TRIM_CASE_TPR4(16);
-                if (lpr4t && tpr && !generic && max_len > 64 && max_len <= 76) FAQCS_TRIM_CASE_TPR4(19);
+                if (lpr4t && tpr && (!generic || ext) && max_len > 0 && max_len <= 64) FAQCS_TRIM_CASE_TPR4(16);
+                if (lpr4t && tpr && (!generic || ext) && max_len > 64 && max_len <= 76) FAQCS_TRIM_CASE_TPR4(19);
             }
 #undef FAQCS_TRIM_CASE_TPR4
         }
