@@ -94,18 +94,68 @@ def cpu_baseline(opt_args, hs, hq, L, n_sample):
     return None
 
 
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a):
+    """`bench.py --gpus N` without a launcher: start N rank processes (one per GPU) BEFORE this process touches the GPU
+    (torch.cuda.device_count() does not initialise it) and relay rank 0's JSON line.  FAQCS_BENCH_SHARE_GPU=1 lets the
+    ranks share device 0 over gloo (a 1-GPU box can then exercise the N-rank path; never a measurement)."""
+    import torch
+
+    share = os.environ.get("FAQCS_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if not share and have < a.gpus:
+        raise SystemExit("bench: --gpus %d but only %d GPU(s) are visible" % (a.gpus, have))
+    port = free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if share:
+            env["FAQCS_BENCH_BACKEND"] = "gloo"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a)  # (does not return)
     import torch
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        raise SystemExit("bench: --gpus %d disagrees with WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (a.gpus, world))
+    backend = os.environ.get("FAQCS_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            if torch.cuda.device_count() <= local:
+                raise SystemExit("bench: rank %d wants GPU %d but %d are visible" % (rank, local, torch.cuda.device_count()))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -182,6 +232,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ranks_seen = [[rank, local]]
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, [rank, local, torch.cuda.get_device_properties(local).name])
+        ranks_seen = got
+
     for _ in range(a.warmup):
         step()
     avg_ms, nl = C.c_double(), C.c_uint64()
@@ -193,7 +249,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     _check(lib, lib.faqcs_kernel_time_ms(eng.ctx, C.byref(avg_ms), C.byref(nl)))
@@ -222,7 +278,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "M reads/sec (paired 2x%dbp)" % L, "value": round(value, 3), "unit": "M reads/s", "n_gpus": world,
+            "metric": "M reads/sec (paired 2x%dbp)" % L, "value": round(value, 3), "unit": "M reads/s", "n_gpus": world if world == 1 else dist.get_world_size(),
+            "ranks_seen": ranks_seen,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synthetic %.0fM-pair 2x%dbp Q33 reads resident in HBM per GPU, BWA_plus -q 5 --min_L 50%s, "

@@ -143,6 +143,8 @@ def load_library():
         "faqcs_host_alloc": (vp, [C.c_size_t]),
         "faqcs_host_free": (None, [vp]),
         "faqcs_counters_device": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
+        "faqcs_counters_export": (i32, [vp, vp, u64]),
+        "faqcs_counters_import": (i32, [vp, vp, u64]),
         "faqcs_finish": (i32, [vp, vp, u64]),
         "faqcs_reset_counters": (i32, [vp]),
         "faqcs_set_quality": (i32, [vp, i32]),

@@ -590,10 +590,10 @@ extern "C" int faqcs_submit_async(faqcs_ctx *c, const faqcs_batch *b, faqcs_read
     // the slot may still feed the kernels of submission k-2: growing it (hipFree) needs them finished, reusing it
     // only needs the copy stream to wait for them
     if (sl.used) {
-        if (bytes + 64 > sl.seq.cap || (size_t)n + 1 > sl.off.cap) HIPCHK(hipEventSynchronize(sl.done));
+        if (bytes + FAQCS_ARENA_PAD_BEFORE + FAQCS_ARENA_PAD_AFTER > sl.seq.cap || (size_t)n + 1 > sl.off.cap) HIPCHK(hipEventSynchronize(sl.done));
         else HIPCHK(hipStreamWaitEvent(c->copy, sl.done, 0));
     }
-    HIPCHK(sl.seq.reserve(bytes + 64)); HIPCHK(sl.qual.reserve(bytes + 64)); HIPCHK(sl.off.reserve((size_t)n + 1));
+    HIPCHK(sl.seq.reserve(bytes + FAQCS_ARENA_PAD_BEFORE + FAQCS_ARENA_PAD_AFTER)); HIPCHK(sl.qual.reserve(bytes + FAQCS_ARENA_PAD_BEFORE + FAQCS_ARENA_PAD_AFTER)); HIPCHK(sl.off.reserve((size_t)n + 1));
     if ((size_t)n + 1 > c->s_res.cap) HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(c->s_res.reserve((size_t)n + 1));
     // arena bytes land 16 bytes into the staging buffer; the kernels index with the ORIGINAL offsets
@@ -700,6 +700,28 @@ extern "C" int faqcs_counters_device(faqcs_ctx *c, void **d_ptr, uint64_t *n_u64
     if (!c || !d_ptr || !n_u64) return fail(FAQCS_E_INVAL, "null argument");
     *d_ptr = c->d_counters;
     *n_u64 = c->lay.total;
+    return 0;
+}
+
+// The collective runs on a buffer the CALLER owns (e.g. a torch tensor that RCCL registers for IPC): export the block into it,
+// all-reduce it, import the sum.  Both copies wait for the work submitted so far and return when the bytes have moved.
+extern "C" int faqcs_counters_export(faqcs_ctx *c, void *d_dst, uint64_t n_u64)
+{
+    if (!c || !d_dst || n_u64 < c->lay.total) return fail(FAQCS_E_INVAL, "faqcs_counters_export: buffer too small");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->aux));
+    HIPCHK(hipMemcpyAsync(d_dst, c->d_counters, c->lay.total * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    return 0;
+}
+
+extern "C" int faqcs_counters_import(faqcs_ctx *c, const void *d_src, uint64_t n_u64)
+{
+    if (!c || !d_src || n_u64 < c->lay.total) return fail(FAQCS_E_INVAL, "faqcs_counters_import: buffer too small");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->aux));
+    HIPCHK(hipMemcpyAsync(c->d_counters, d_src, c->lay.total * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
     return 0;
 }
 

@@ -39,284 +39,7 @@
 //
 // Float semantics of the reference are folded into integer lookup tables built on the host
 // (DevParams); the only float op left is the composition-bin multiply, an exact IEEE v_mul_f32.
-#include "faqcs_dev.h"
-
-#include <stdlib.h>
-
-namespace {
-
-template <int C, int LPR> struct RowCfg {
-    static constexpr int D = (C + 3) / 4;          // dwords per lane per arena
-    static constexpr int W = LPR * C;              // positions covered by a row == columns of the LDS matrices
-    // position x quality in LDS: one dword per cell (pre count lo16 / post count hi16) while that fits next to the
-    // other tables (W <= 768); wider rows pack two cells per dword as 8-bit pre/post counters and the block flushes
-    // them every 16 reads per wave (HQ8_EVERY x NW <= 255 increments per cell between flushes)
-    static constexpr bool HQ8 = W > 768;           // (768 wide: 158 KB of the CU's 160 KB LDS, one block per CU)
-    static constexpr int HQ8_EVERY = 16;
-    static constexpr int HQ = HQ8 ? FAQCS_NQ * W / 2 : FAQCS_NQ * W;
-    // |sum of (Q - q)| <= W * 168: key bias and the bit width of a position field inside the argmax keys
-    static constexpr int KEY_BIAS = LPR <= 16 ? (1 << 16) : (1 << 18);
-    static constexpr int PB = LPR <= 16 ? 9 : 11;
-    static constexpr int FK = 2 * W;               // "first position" keys are FK - p (0 == none)
-    static constexpr int HB = FAQCS_NBASE * W;
-    static constexpr int O_HQ = 0;
-    static constexpr int O_HB = O_HQ + HQ;
-    static constexpr int O_LEN = O_HB + HB;        // [W+1] lo16 pre / hi16 post
-    static constexpr int O_RQ = O_LEN + W + 2;     // [42]  lo16 pre / hi16 post
-    static constexpr int O_BQPRE = O_RQ + 42;      // [42]
-    static constexpr int O_BQPOST = O_BQPRE + 42;  // [42]
-    static constexpr int O_FS = O_BQPOST + 42;     // [32]
-    static constexpr int N_ZERO = O_FS + FS_SLOTS; // everything above is zero-initialised and flushed
-    static constexpr int O_TBASE = N_ZERO;         // [256] base table
-    static constexpr int O_TLC = O_TBASE + 256;    // [W+1]
-    static constexpr int O_TAVGQ = O_TLC + W + 1;  // [W+1]
-    static constexpr int O_TMAGIC = O_TAVGQ + W + 1;
-    static constexpr int BMW = D <= 4 ? 4 : 8;     // dwords per byte-mask row (one or two ds_read_b128)
-    static constexpr int O_TBM = (O_TMAGIC + W + 1 + 3) & ~3; // [C+1][BMW] byte masks "first vb bytes of the lane's dwords"
-    static constexpr int LDS_DWORDS = O_TBM + BMW * (C + 1);
-    static constexpr int JB = C > 16 ? 5 : 4;      // bits of a position index inside the lane-local argmax keys
-};
-
-template <int D> struct __attribute__((packed, aligned(1))) PackedBytes { uint32_t w[D]; };
-
-__device__ __forceinline__ int med3i(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
-
-// bits j in [0, C) with lo <= pbase + j < hi
-template <int C> __device__ __forceinline__ uint32_t range_mask(int lo, int hi, int pbase)
-{
-    const int s = med3i(lo - pbase, 0, C);
-    int e = med3i(hi - pbase, 0, C);
-    e = e > s ? e : s;
-    uint32_t m; // ((1 << (e - s)) - 1) << s in one instruction
-    asm("v_bfm_b32 %0, %1, %2" : "=v"(m) : "v"(e - s), "v"(s));
-    return m;
-}
-// 0 / -1 from bit j of mask.  Pinned to ONE v_bfe_i32: left to itself the compiler rewrites `x & -(bit)` into
-// and + compare + select (3 instructions per use, ~40 uses per read in a VALU-bound kernel).
-// 4 * byte K of w in ONE instruction (SDWA source select): the LDS byte offset of a base-table lookup
-template <int K> __device__ __forceinline__ uint32_t byte_times4(uint32_t w, uint32_t two)
-{
-    uint32_t r;
-    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
-    else if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w));
-    else if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w));
-    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
-    return r;
-}
-// t_base_lds = LDS byte address of the table (the kernel's dynamic LDS starts at address 0, checked at kernel start): the
-// lookup is then ds_read_b32 v, <4 * byte> offset:<table> with no address add at all.
-typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
-typedef __attribute__((address_space(3))) uint32_t *lds_u32_mut;
-// ds_add_u32 at an LDS BYTE offset computed in 32 bits (a generic pointer makes the compiler form the address with
-// v_mad_u64_u32, a multi-pass instruction, once per base)
-__device__ __forceinline__ void lds_add_u32(uint32_t byte_offset, uint32_t v)
-{
-    __hip_atomic_fetch_add((lds_u32_mut)(size_t)byte_offset, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-template <int C, int J> struct BaseLookup {
-    static __device__ __forceinline__ void run(const uint32_t t_base_lds, const uint32_t *ws, uint32_t two, uint32_t *inc)
-    {
-        inc[J] = *(lds_u32_ptr)(size_t)(byte_times4<J & 3>(ws[J >> 2], two) + t_base_lds);
-        BaseLookup<C, J + 1>::run(t_base_lds, ws, two, inc);
-    }
-};
-template <int C> struct BaseLookup<C, C> {
-    static __device__ __forceinline__ void run(const uint32_t, const uint32_t *, uint32_t, uint32_t *) {}
-};
-__device__ __forceinline__ uint32_t umax3_(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ int bit_m1(uint32_t mask, int j)
-{
-    int r;
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(mask), "n"(j));
-    return r;
-}
-
-} // namespace
-
-// LDS -> global u64 block.  Deliberately NOT inlined: the counter-block layout (a dozen 64-bit offsets) would
-// otherwise stay live in SGPRs across the whole read loop and push the kernel into scalar-register spills.
-template <int C, int LPR, int NW>
-__device__ __noinline__ void flush_block(uint32_t *smem, uint64_t *counters, const uint32_t R, const int tid)
-{
-    using Cfg = RowCfg<C, LPR>;
-    constexpr int W = Cfg::W;
-    uint32_t *hq = smem + Cfg::O_HQ, *hb = smem + Cfg::O_HB, *hlen = smem + Cfg::O_LEN, *hrq = smem + Cfg::O_RQ;
-    uint32_t *hbqpre = smem + Cfg::O_BQPRE, *hbqpost = smem + Cfg::O_BQPOST, *lfs = smem + Cfg::O_FS;
-    // faqcs_counters_layout() restated (include/faqcs_mi.h): only R is needed for the offsets used here
-    faqcs_layout L;
-    {
-        uint64_t o = 0;
-        L.filter_stats = o;    o += 32;
-        L.pre_read_qhist = o;  o += FAQCS_NQ;
-        L.pre_base_qhist = o;  o += FAQCS_NQ;
-        L.post_read_qhist = o; o += FAQCS_NQ;
-        L.post_base_qhist = o; o += FAQCS_NQ;
-        L.pre_len_hist = o;    o += (uint64_t)R + 1;
-        L.post_len_hist = o;   o += (uint64_t)R + 1;
-        L.pre_qual = o;        o += (uint64_t)R * FAQCS_NQ;
-        L.post_qual = o;       o += (uint64_t)R * FAQCS_NQ;
-        L.pre_base = o;        o += (uint64_t)R * FAQCS_NBASE;
-        L.post_base = o;
-    }
-    __syncthreads();
-    for (int i = tid; i < (Cfg::HQ8 ? 0 : Cfg::HQ); i += NW * 64) {
-        const uint32_t v = hq[i];
-        if (v) {
-            hq[i] = 0;
-            const uint32_t q = i / W, p = i % W;
-            uint32_t pre = v & 0xffffu;
-            if (q == 0) {
-                // The read loop adds the "pre" 1 for EVERY position slot of a counted read, also past its end (where the
-                // masked quality byte is 0): column 0 of position p is over-counted once per read with len <= p, and the
-                // interval's length histogram says how many those are.
-                uint32_t shorter = 0;
-                for (uint32_t l = 0; l <= p; ++l) shorter += hlen[l] & 0xffffu;
-                pre -= shorter;
-            }
-            if (p < R) {
-                if (pre) atomicAdd((unsigned long long *)(counters + L.pre_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)pre);
-                if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_qual + (uint64_t)p * FAQCS_NQ + q), (unsigned long long)(v >> 16));
-            }
-        }
-    }
-    __syncthreads(); // (the correction above reads hlen, which the loop below clears)
-    for (int i = tid; i < Cfg::HB; i += NW * 64) {
-        const uint32_t v = hb[i];
-        if (v) {
-            hb[i] = 0;
-            const uint32_t c = i / W, p = i % W;
-            if (p < R) {
-                if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_base + (uint64_t)p * FAQCS_NBASE + c), (unsigned long long)(v & 0xffffu));
-                if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_base + (uint64_t)p * FAQCS_NBASE + c), (unsigned long long)(v >> 16));
-            }
-        }
-    }
-    for (int i = tid; i <= W; i += NW * 64) {
-        const uint32_t v = hlen[i];
-        if (v && (uint32_t)i <= R) {
-            hlen[i] = 0;
-            if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_len_hist + i), (unsigned long long)(v & 0xffffu));
-            if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_len_hist + i), (unsigned long long)(v >> 16));
-        }
-    }
-    if (tid < FAQCS_NQ) {
-        const uint32_t v = hrq[tid], x = hbqpre[tid], y = hbqpost[tid];
-        hrq[tid] = 0; hbqpre[tid] = 0; hbqpost[tid] = 0;
-        if (v & 0xffffu) atomicAdd((unsigned long long *)(counters + L.pre_read_qhist + tid), (unsigned long long)(v & 0xffffu));
-        if (v >> 16) atomicAdd((unsigned long long *)(counters + L.post_read_qhist + tid), (unsigned long long)(v >> 16));
-        if (x) atomicAdd((unsigned long long *)(counters + L.pre_base_qhist + tid), (unsigned long long)x);
-        if (y) atomicAdd((unsigned long long *)(counters + L.post_base_qhist + tid), (unsigned long long)y);
-    }
-    if (tid >= 64 && tid < 64 + FAQCS_NUM_STAT) {
-        const int k = tid - 64;
-        const uint32_t v = lfs[k];
-        if (v) { atomicAdd((unsigned long long *)(counters + L.filter_stats + k), (unsigned long long)v); lfs[k] = 0; }
-    }
-    __syncthreads();
-}
-
-// 8-bit packed position x quality cells (rows wider than 512) -> global u64 block; called by the whole block
-template <int C, int LPR, int NW>
-__device__ __noinline__ void flush_hq8(uint32_t *smem, uint64_t *counters, const uint32_t R, const int tid)
-{
-    using Cfg = RowCfg<C, LPR>;
-    constexpr int HW = Cfg::W / 2;
-    uint32_t *hq = smem + Cfg::O_HQ;
-    const uint64_t pre_qual = 32 + 4 * FAQCS_NQ + 2 * ((uint64_t)R + 1), post_qual = pre_qual + (uint64_t)R * FAQCS_NQ;
-    __syncthreads();
-    for (int i = tid; i < Cfg::HQ; i += NW * 64) {
-        const uint32_t v = hq[i];
-        if (v) {
-            hq[i] = 0;
-            const uint32_t q = i / HW, p = 2u * (uint32_t)(i % HW);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t a = (v >> (16 * h)) & 0xffu, b = (v >> (16 * h + 8)) & 0xffu;
-                if (p + h < R) {
-                    if (a) atomicAdd((unsigned long long *)(counters + pre_qual + (uint64_t)(p + h) * FAQCS_NQ + q), (unsigned long long)a);
-                    if (b) atomicAdd((unsigned long long *)(counters + post_qual + (uint64_t)(p + h) * FAQCS_NQ + q), (unsigned long long)b);
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// What depends on a read's scalars alone, done once per 64-read chunk with one read per lane: result word, composition
-// records, length / average-quality histograms, FilterStat sums.
-struct ReadOutcome {
-    uint32_t an, fl, pAT, pCG, cAT, cCG, N; // start | kept << 16 ; flags ; base counts before / after (A|T<<16, C|G<<16, N pre | post << 16)
-    int Vpre, Vpost;                       // sum(raw - offset) over the read / over the kept window
-};
-template <int LPR>
-__device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool mine, const uint32_t my, const uint32_t v_len,
-                                               const uint32_t v_hit, const int lane, uint32_t *hlen, uint32_t *hrq, uint32_t *hbqpre,
-                                               uint32_t *hbqpost, uint32_t *lfs, const uint32_t *t_magic, uint2 *__restrict__ out,
-                                               unsigned long long *__restrict__ rec_pre, unsigned long long *__restrict__ rec_post,
-                                               const bool o_avgq_on, const uint32_t o_dbg)
-{
-        const bool e_ret = (o.fl & FAQCS_F_VALID) != 0, e_err = (o.fl & FAQCS_F_ERR_QUALITY) != 0;
-        const uint32_t e_len = v_len, e_n = o.an >> 16, e_filt = (o.fl & FAQCS_F_FILTER_MASK) >> FAQCS_F_FILTER_SHIFT;
-        // int(ave_Q) == max(0, floor(V / len)), V = sum(raw - offset); floor via mulhi with a host magic
-        int qb_pre = 0, qb_post = 0;
-        if (mine && e_len > 0 && o.Vpre > 0) qb_pre = e_len == 1 ? o.Vpre : (int)__umulhi((uint32_t)o.Vpre, t_magic[e_len]);
-        if (e_ret && o.Vpost > 0) qb_post = e_n == 1 ? o.Vpost : (int)__umulhi((uint32_t)o.Vpost, t_magic[e_n]);
-        qb_pre = qb_pre > 41 ? 41 : qb_pre;
-        qb_post = qb_post > 41 ? 41 : qb_post;
-        if (!(o_dbg & 2u) && mine && !e_err) { // length and int(average quality) histograms (trim.cpp:254-258,539-543,877-885)
-            atomicAdd(hlen + e_len, 1u);
-            atomicAdd(hrq + qb_pre, 1u);
-            if (e_len) atomicAdd(hbqpre + qb_pre, e_len);
-            if (e_ret) {
-                atomicAdd(hlen + e_n, 0x10000u);
-                atomicAdd(hrq + qb_post, 0x10000u);
-                atomicAdd(hbqpost + qb_post, e_n);
-            }
-        }
-        if (mine) {
-            const bool bad_base = v_hit == 0xffffu; // set by adapter_overlap
-            out[my] = make_uint2(e_ret ? o.an : 0u, (o.fl & 0x3ffu) | (bad_base ? (uint32_t)FAQCS_F_ERR_BASE : (v_hit << 16)));
-            const bool pre_on = !e_err, post_on = e_ret && !e_err;
-            const unsigned long long pA = o.pAT & 0xffffu, pT = o.pAT >> 16, pC = o.pCG & 0xffffu, pG = o.pCG >> 16, pn = o.N & 0xffffu;
-            const unsigned long long cA = o.cAT & 0xffffu, cT = o.cAT >> 16, cC = o.cCG & 0xffffu, cG = o.cCG >> 16, cn = o.N >> 16;
-            if (LPR <= 16) {
-                rec_pre[my] = pre_on ? (CR_VALID | e_len | (pA << 9) | (pT << 18) | (pC << 27) | (pG << 36) | (pn << 45)) : 0ull;
-                rec_post[my] = post_on ? (CR_VALID | e_n | (cA << 9) | (cT << 18) | (cC << 27) | (cG << 36) | (cn << 45)) : 0ull;
-            } else { // reads past 511 bases do not fit 9-bit fields: 11-bit fields over two words
-                reinterpret_cast<ulonglong2 *>(rec_pre)[my] =
-                    pre_on ? make_ulonglong2(CR_VALID | e_len | (pA << 11) | (pT << 22) | (pC << 33), pG | (pn << 11)) : make_ulonglong2(0ull, 0ull);
-                reinterpret_cast<ulonglong2 *>(rec_post)[my] =
-                    post_on ? make_ulonglong2(CR_VALID | e_n | (cA << 11) | (cT << 22) | (cC << 33), cG | (cn << 11)) : make_ulonglong2(0ull, 0ull);
-            }
-        }
-        // FilterStat (trim.cpp:238-240,317-323,325-387,505-513,527-531): a read count in the high and a base
-        // count in the low 20 bits, summed over the 64 reads of the chunk (64 x 1024 bases < 2^20)
-        const bool e_rlen = e_filt == FAQCS_FILT_LENGTH_PRE || e_filt == FAQCS_FILT_LENGTH_POST;
-        const uint32_t one = 1u << 20;
-        const uint32_t s_tot = (uint32_t)wave_sum_i32((int)(mine ? one | e_len : 0u));
-        const uint32_t s_trim = (uint32_t)wave_sum_i32((int)(e_ret ? one | e_n : 0u));
-        const uint32_t s_len = (uint32_t)wave_sum_i32((int)(e_rlen ? one | e_n : 0u));
-        const uint32_t s_nn = (uint32_t)wave_sum_i32((int)((o.fl & FAQCS_F_POLY_N_SEEN) ? one | e_n : 0u));
-        const uint32_t s_qt = (uint32_t)wave_sum_i32((int)((o.fl & FAQCS_F_QUAL_TRIMMED) ? one | (o.fl >> 20) : 0u));
-        const uint32_t s_lc = (uint32_t)wave_sum_i32((int)(e_filt == FAQCS_FILT_LOW_COMPLEXITY ? one | e_n : 0u));
-        uint32_t s_avg = 0;
-        if (o_avgq_on) s_avg = (uint32_t)wave_sum_i32((int)(e_filt == FAQCS_FILT_AVG_Q ? one | e_n : 0u));
-        if (lane == 0) {
-            const uint32_t m = one - 1u;
-            if (s_tot) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], s_tot & m); }
-            if (s_trim) { atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_NUMBER], s_trim >> 20); atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_LENGTH], s_trim & m); }
-            if (s_len) { atomicAdd(&lfs[FAQCS_READ_LENGTH], s_len >> 20); atomicAdd(&lfs[FAQCS_BASE_LENGTH], s_len & m); }
-            if (s_nn) { atomicAdd(&lfs[FAQCS_READ_NN], s_nn >> 20); atomicAdd(&lfs[FAQCS_BASE_NN], s_nn & m); }
-            if (s_avg) { atomicAdd(&lfs[FAQCS_READ_AVG_Q], s_avg >> 20); atomicAdd(&lfs[FAQCS_BASE_AVG_Q], s_avg & m); }
-            if (s_qt) { atomicAdd(&lfs[FAQCS_READ_QUAL_TRIM], s_qt >> 20); atomicAdd(&lfs[FAQCS_BASE_QUAL_TRIM], s_qt & m); }
-            if (s_lc) { atomicAdd(&lfs[FAQCS_READ_LOW_COMPLEXITY], s_lc >> 20); atomicAdd(&lfs[FAQCS_BASE_LOW_COMPLEXITY], s_lc & m); }
-        }
-}
+#include "faqcs_trim_common.h"
 
 #ifndef FAQCS_TRIM_NW
 #define FAQCS_TRIM_NW 4        /* waves per block (A/B on MI355X: 4 waves x 3 blocks/CU beat 8 x 1 by 9 %) */
@@ -1635,11 +1358,23 @@ static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const 
     return hipGetLastError();
 }
 
+hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
+                                 uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
+                                 faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
+                                 uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st);
+
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
                              uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
 {
+    {   // trim_lds (faqcs_trim_lds_kernel.hip): every byte from HBM once, through LDS; FAQCS_TRIM_LDS=0 switches it off
+        static const bool lds_on = [] { const char *e = getenv("FAQCS_TRIM_LDS"); return e && atoi(e) != 0; }();
+        if (lds_on) {
+            const hipError_t e = faqcs_launch_trim_lds(P, seq, qual, off, n_reads, max_len, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st);
+            if (e != hipErrorNotSupported) return e;
+        }
+    }
     const bool windowed = P.has_adapters || ((P.trim5 || P.trim3) && !P.qc_only);
     const bool generic = !(P.mode == FAQCS_MODE_BWA_PLUS && !P.protect5 && !P.qc_only && P.replace_q == 0 && !P.avgq_on &&
                            P.max_poly_n == 2 && P.dbg == 0);

@@ -1,0 +1,751 @@
+// faqcs_trim_lds_kernel.hip -- trim_lds: the trim / filter / accumulate pass with every byte read from HBM ONCE, as
+// coalesced 16-byte LDS-DMA loads (global_load_lds_dwordx4), for reads of up to 160 bases (gfx950, wave64).
+//
+// Replaces trim_read() and its helpers (trim.cpp:225-551, :553-597, :629-885, :1191-1216) like the other trim kernels;
+// the accumulators, the block flush and the chunk epilogue are shared with them (faqcs_trim_common.h).
+//
+// A wave owns a chunk of 64 consecutive reads.  Reads are packed back to back in the arenas, so the chunk is ONE
+// contiguous span of <= 64 x W bytes per arena: the wave copies the span of the QUALITY arena into its 9.8 KB slot of LDS
+// with <= 10 wave-wide DMA instructions (1 KB each, no VGPR round trip), works on it, then copies the span of the BASE
+// arena into the same slot and works on that.  Inside a slot read i still starts at (offset[i] - span start): a lane reads
+// "its" read with per-lane LDS addresses (dynamic indexing that a register-resident copy cannot give), and LDS takes
+// unaligned dword reads, so no byte shuffling is left.
+//
+//   Q-A  one read per lane      terminal-N patch (in place, rare), sum + range check of the qualities four bytes per
+//                               instruction, the two BWA_plus walks exactly as trim.cpp:714-793 states them -- every lane
+//                               starts at ITS window end and reads the dword under its own cursor --, length filters
+//   Q-B  8 lanes per read       position x quality accumulation: one ds_add per base, address = raw byte x row stride
+//                               (v_mul_u32_u24 with an SDWA byte select) + lane base, data = one v_perm_b32 of two byte masks
+//                               (position inside the read -> pre count, inside the kept window -> post count)
+//   S-A  one read per lane      base classes (LDS table, 8-bit one-hot A,T,C,G fields + upper-case-N bit), counts before /
+//                               inside the kept window, poly-N, low complexity -> the read's verdict
+//   S-B  8 lanes per read       position x base accumulation in registers (6-bit fields); bases outside the kept window are
+//                               flagged in bit 7 so that ONE 8-byte table entry yields the pre and the post increment
+//   epilogue, one read per lane result word, composition records, small histograms, FilterStat (chunk_epilogue)
+//
+// The post-trim quality cells are added in Q-B, before S-A can veto the read (poly-N / low complexity / average quality):
+// a vetoed read is rare, and its post cells are taken back by a small corrective pass over the chunk (Q-B with a negative
+// increment) after the bases have been judged.
+#include "faqcs_trim_common.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+template <int C, int NW> struct LdsCfg {
+    using Row = RowCfg<C, 8>;
+    static constexpr int W = Row::W;
+    static constexpr int ND = (W + 3) / 4;                     // dwords of the longest read
+    static constexpr int NP = (W + 15) / 16;                   // 16-byte pieces (the out-of-line exact passes)
+    static constexpr int NWORD = (ND * 4 + 31) / 32;
+    static constexpr int O_T2 = (Row::LDS_DWORDS + 3) & ~3;    // [256][2] S-A: A,T,C,G one-hot in 8-bit fields ; isN(upper) | isN(any) << 1
+    static constexpr int O_T3 = O_T2 + 512;                    // [256][2] S-B: 6-bit count fields, pre ; post (bytes >= 128: outside the kept window)
+    static constexpr int O_STG = O_T3 + 512;
+    static constexpr int STG_BYTES = 64 * W + 32;              // one arena's span of a chunk + 16-byte alignment slack
+    static constexpr int STG_DW = (STG_BYTES + 15) / 16 * 4;
+    static constexpr int TAIL_PAD = 64;                        // dwords: a lane may read W bytes from the start of the span's last read
+    static constexpr int lds_dwords() { return O_STG + NW * STG_DW + TAIL_PAD; }
+};
+
+typedef uint32_t LdsPair2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) LdsPair2 *lds_u2c_ptr;
+typedef __attribute__((address_space(3))) uint8_t *lds_u8_mut;
+typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
+struct __attribute__((packed, aligned(1))) U32u { uint32_t w; };
+typedef const __attribute__((address_space(3))) U32u *lds_u32u_ptr;
+
+__device__ __forceinline__ uint32_t lds_ld(uint32_t byte_offset) { return *(lds_u32_ptr)(size_t)byte_offset; }
+// four bytes at ANY byte address: two aligned dwords and a funnel shift (a misaligned ds_read_b32 is legal on gfx950 but
+// serialises the wave: measured 64 LDS clocks per instruction)
+__device__ __forceinline__ uint32_t lds_ld_any(uint32_t byte_offset)
+{
+    const uint32_t a4 = byte_offset & ~3u;
+    return __builtin_amdgcn_alignbyte(lds_ld(a4 + 4u), lds_ld(a4), byte_offset & 3u);
+}
+__device__ __forceinline__ uint32_t lds_ld_u8(uint32_t byte_offset) { return (uint32_t) * (lds_u8_ptr)(size_t)byte_offset; }
+__device__ __forceinline__ void lds_st_u8(uint32_t byte_offset, uint32_t v) { *(lds_u8_mut)(size_t)byte_offset = (uint8_t)v; }
+
+template <int K> __device__ __forceinline__ uint32_t byte_x8(uint32_t w, uint32_t three)
+{
+    uint32_t r;
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(w));
+    else if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(w));
+    else if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(w));
+    return r;
+}
+// byte K of w times m (m < 2^24), one instruction
+template <int K> __device__ __forceinline__ uint32_t byte_mul(uint32_t w, uint32_t m)
+{
+    uint32_t r;
+    if (K == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(m), "v"(w));
+    else if (K == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(m), "v"(w));
+    else if (K == 2) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(m), "v"(w));
+    else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(m), "v"(w));
+    return r;
+}
+__device__ __forceinline__ uint32_t low_bytes_(int nb) { return nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u); }
+__device__ __forceinline__ uint32_t bit_range_(int s, int e)
+{
+    const uint32_t hi = e >= 32 ? 0xffffffffu : ((1u << e) - 1u), lo = s >= 32 ? 0xffffffffu : ((1u << s) - 1u);
+    return hi & ~lo;
+}
+
+// One arena's span of the chunk -> the wave's LDS slot: <= NI wave-wide 1 KB DMA loads from 16-byte aligned addresses.
+// g = arena + (span start rounded down to 16 bytes), nbytes = bytes from there to the span's end.
+template <int NI>
+__device__ __forceinline__ void dma_span(const uint8_t *g, const uint32_t nbytes, uint32_t *slot, const int lane)
+{
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if ((uint32_t)(i * 1024) >= nbytes) break; // wave-uniform
+        if ((uint32_t)(i * 1024 + lane * 16) < nbytes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(slot + i * 256), 16, 0, 0);
+    }
+}
+
+// ---- rare exact passes over the GLOBAL arenas (entered only by a chunk that holds such a read; out of line) -----------
+struct ExactQ { int sv, svp, mq; };   // sum(raw - offset) over the read / over the kept window, max(raw - offset)
+// patch = lead | trail << 8: terminal-N positions (< lead or >= trail) read as the offset (mask_quality_terminal_N)
+__device__ __noinline__ ExactQ exact_quality(const uint8_t *__restrict__ qual, const uint32_t v_off, const int len, const uint32_t patch,
+                                             const int a, const int n, const int in_off, const bool need)
+{
+    const int lead = (int)(patch & 0xffu), trail = (int)(patch >> 8);
+    ExactQ r{0, 0, 0};
+#pragma unroll 1
+    for (int p = 0; __any(need && p < len); ++p) {
+        if (need && p < len) {
+            int v = (int)(int8_t)qual[(size_t)v_off + p] - in_off;
+            if (p < lead || p >= trail) v = 0;
+            r.sv += v;
+            r.mq = r.mq > v ? r.mq : v;
+            if ((unsigned)(p - a) < (unsigned)n) r.svp += v;
+        }
+    }
+    return r;
+}
+struct ExactB { uint32_t npre, npost; bool trip; }; // N (any case) in the read / in the kept window; dinucleotide filter
+__device__ __noinline__ ExactB exact_bases(const uint8_t *__restrict__ seq, const uint32_t v_off, const int len, const int a, const int n,
+                                           const bool need, const bool dinuc, const uint32_t dthr)
+{
+    ExactB r{0u, 0u, false};
+    uint32_t prev = 4u, dmax = 0; // class 0..3 of the previous window position if it is ACGT
+    uint32_t dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0; // 16 transition counters, 8 bits each (a window holds <= 160 transitions... saturating is enough: see below)
+#pragma unroll 1
+    for (int p = 0; __any(need && p < len); ++p) {
+        if (need && p < len) {
+            const uint32_t b = (uint32_t)seq[(size_t)v_off + p];
+            const bool inw = (unsigned)(p - a) < (unsigned)n;
+            const uint32_t u = b & 0xdfu;
+            const uint32_t isn = u == 'N' ? 1u : 0u;
+            r.npre += isn;
+            r.npost += inw ? isn : 0u;
+            uint32_t cur = u == 'A' ? 0u : u == 'T' ? 1u : u == 'C' ? 2u : u == 'G' ? 3u : 4u;
+            if (!inw) cur = 4u;
+            if (dinuc && cur < 4u && prev < 4u && cur != prev) {
+                const uint32_t k = prev * 4u + cur, sh = 8u * (k & 3u);
+                uint32_t &d = (k >> 2) == 0 ? dc0 : (k >> 2) == 1 ? dc1 : (k >> 2) == 2 ? dc2 : dc3;
+                uint32_t c = (d >> sh) & 0xffu;
+                c = c < 255u ? c + 1u : c; // (a count of 255 already exceeds every threshold: dthr <= 161)
+                d = (d & ~(0xffu << sh)) | (c << sh);
+                dmax = dmax > c ? dmax : c;
+            }
+            prev = cur;
+        }
+    }
+    r.trip = dinuc && dmax >= dthr;
+    return r;
+}
+
+} // namespace
+
+constexpr int lds_waves(int C) { return C <= 19 ? 12 : 8; }
+
+template <int C, int NW, bool WINDOWED, bool EXT>
+__global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
+    const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
+    const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
+    const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
+    unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err)
+{
+    constexpr int LPR = 8;
+    using Cfg = RowCfg<C, LPR>;
+    using T = LdsCfg<C, NW>;
+    constexpr int D = Cfg::D, W = Cfg::W, ND = T::ND, NWORD = T::NWORD, NPOS = ND * 4, BMW = Cfg::BMW;
+    constexpr int NI = (T::STG_BYTES + 1023) / 1024;
+    static_assert(!Cfg::HQ8 && NPOS <= 255, "step indices must fit the low byte of the argmax keys");
+    static_assert(T::lds_dwords() * 4 <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *hb = smem + Cfg::O_HB;
+    const uint32_t *t_lc = smem + Cfg::O_TLC;
+    const uint32_t *t_bm = smem + Cfg::O_TBM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int rl = lane & (LPR - 1);
+    const int rowb = lane & (64 - LPR);
+    const int wave = uni(tid >> 6);
+    const int pbase = rl * C;
+
+    for (int i = tid; i < Cfg::N_ZERO; i += NW * 64) smem[i] = 0u;
+    for (int i = tid; i < 256; i += NW * 64) {
+        const uint32_t w = P.base_tab[i];
+        smem[T::O_T2 + 2 * i] = ((w >> BT_SHIFT(0)) & 1u) | (((w >> BT_SHIFT(1)) & 1u) << 8) | (((w >> BT_SHIFT(2)) & 1u) << 16) | (((w >> BT_SHIFT(3)) & 1u) << 24);
+        smem[T::O_T2 + 2 * i + 1] = (w >> 31) | (((w >> BT_SHIFT(4)) & 1u) << 1);
+        const uint32_t f = P.base_tab[i & 127] & BT_FIELDS; // S-B: byte | 0x80 = the same base outside the kept window
+        smem[T::O_T3 + 2 * i] = f;
+        smem[T::O_T3 + 2 * i + 1] = i < 128 ? f : 0u;
+    }
+    for (int i = tid; i <= W; i += NW * 64) {
+        smem[Cfg::O_TLC + i] = P.lc_thr[i];
+        smem[Cfg::O_TAVGQ + i] = (uint32_t)P.avgq_min_v[i];
+        smem[Cfg::O_TMAGIC + i] = P.div_magic[i];
+    }
+    for (int i = tid; i < BMW * (C + 1); i += NW * 64) {
+        const int nb = med3i((i / BMW) - 4 * (i % BMW), 0, 4);
+        smem[Cfg::O_TBM + i] = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+    }
+    uint32_t three = 3u, wx4 = (uint32_t)(W * 4);
+    asm volatile("" : "+v"(three), "+v"(wx4)); // VGPR operands for the SDWA instructions
+    if (tid == 0 && blockIdx.x == 0 && (uint32_t)(size_t)((lds_u32_ptr)smem) != 0u) atomicOr(err, 4u);
+    __syncthreads();
+
+    const uint32_t total_chunks = (n_reads + 63) >> 6;
+    const uint32_t chunks_per_iter = gridDim.x * NW;
+    const uint32_t n_iter = (total_chunks + chunks_per_iter - 1) / chunks_per_iter;
+    constexpr uint32_t FLUSH_EVERY = 65535u / (NW * 64) > 0 ? 65535u / (NW * 64) : 1;
+    constexpr uint32_t REG_FLUSH_EVERY = 7; // 6-bit fields: 7 chunks x 8 reads per row <= 63
+
+    const int in_off = P.in_off, Q = P.Q;
+    uint32_t *slot = smem + T::O_STG + wave * T::STG_DW;
+    const uint32_t slot_b = (uint32_t)(T::O_STG + wave * T::STG_DW) * 4u; // LDS byte address of the wave's slot
+    const uint32_t offb = ((uint32_t)in_off & 0xffu) * 0x01010101u;
+    const bool swar_ok = in_off >= 0 && in_off <= 86; // else every read takes the exact quality pass
+    const uint32_t hq_lane = (uint32_t)(Cfg::O_HQ * 4 + pbase * 4) - (uint32_t)in_off * (uint32_t)(W * 4); // + raw byte * W * 4 = the cell
+    uint32_t bpre[C], bpost[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { bpre[j] = 0; bpost[j] = 0; }
+    uint32_t any_err = 0;
+    auto spill_base_regs = [&]() {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t x = bpre[j], y = bpost[j];
+            if (x) {
+#pragma unroll
+                for (int c = 0; c < FAQCS_NBASE; ++c) {
+                    const uint32_t v = ((x >> BT_SHIFT(c)) & 63u) | (((y >> BT_SHIFT(c)) & 63u) << 16);
+                    if (v) atomicAdd(&hb[c * W + pbase + j], v);
+                }
+            }
+            bpre[j] = 0; bpost[j] = 0;
+        }
+    };
+
+    // position x quality cells of the 8 reads in flight: DATA = +1 pre / +1 post (sign = -1: take the post cells back)
+    // i0 = slot offset of the read | len << 16 ; i1 = a | n << 8 | post << 16 | counted << 17
+    auto quality_cells = [&](const uint32_t i0, const uint32_t i1, auto undo_t) {
+        constexpr bool undo = decltype(undo_t)::value;
+        const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
+        const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
+        const int vb = med3i(len - pbase, 0, C);
+        const int lo = post ? med3i(a - pbase, 0, C) : 0, hi = post ? med3i(a + n - pbase, 0, C) : 0;
+        uint32_t cm[D], im[D], wq[D], rq[D + 1];
+        const uint32_t qa = slot_b + (i0 & 0xffffu) + (uint32_t)pbase;
+#pragma unroll
+        for (int k = 0; k <= D; ++k) rq[k] = lds_ld((qa & ~3u) + 4u * (uint32_t)k);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const uint32_t inside = t_bm[BMW * vb + k]; // 0xff: a position of the read
+            cm[k] = (counted && !undo) ? inside & 0x01010101u : 0u;
+            im[k] = (t_bm[BMW * hi + k] ^ t_bm[BMW * lo + k]) & (undo ? 0xffffffffu : 0x01010101u);
+            // a byte past the read is whatever the slot holds there: make it the offset so that its (zero) increment stays
+            // inside the table -- a stray read-modify-write could undo another wave's DMA or patch
+            const uint32_t w = __builtin_amdgcn_alignbyte(rq[k + 1], rq[k], qa & 3u);
+            wq[k] = (w & inside) | (offb & ~inside);
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t b = (uint32_t)(j & 3);
+            // byte 0 = cm.byte[b] (pre, lo16), bytes 2 (and 3 when undoing: 0xffff = -1 in the hi16) = im.byte[b] (post)
+            const uint32_t sel = undo ? (((b) << 24) | ((b) << 16) | 0x0c0cu) : ((0x0cu << 24) | (b << 16) | (0x0cu << 8) | (4u + b));
+            const uint32_t data = __builtin_amdgcn_perm(cm[j >> 2], im[j >> 2], sel);
+            const uint32_t ad = ((j & 3) == 0 ? byte_mul<0>(wq[j >> 2], wx4) : (j & 3) == 1 ? byte_mul<1>(wq[j >> 2], wx4)
+                                 : (j & 3) == 2 ? byte_mul<2>(wq[j >> 2], wx4) : byte_mul<3>(wq[j >> 2], wx4)) + hq_lane;
+            lds_add_u32(ad + 4u * (uint32_t)j, data);
+        }
+    };
+
+#pragma unroll 1
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        const uint32_t chunk = (it * gridDim.x + blockIdx.x) * NW + wave;
+        if (chunk < total_chunks) {
+            const uint32_t base = chunk << 6;
+            const uint32_t my = base + lane;
+            const bool mine = my < n_reads;
+            // a lane without a read sits at the end of the last read (length 0): the span ends where lane 63 ends
+            const uint32_t v_off = off[mine ? my : n_reads];
+            const uint32_t v_end = off[mine ? my + 1 : n_reads];
+            const uint32_t v_len = v_end - v_off;
+            const uint32_t v_sl = (WINDOWED && ad_sl && mine) ? ad_sl[my] : (v_len << 16);
+            const uint32_t v_hit = (ad_hit && mine) ? ad_hit[my] : 0u;
+            const uint32_t cs = uniu(v_off), ce = (uint32_t)__builtin_amdgcn_readlane((int)v_end, 63);
+            const int len = (int)v_len;
+
+            // ---- the span of the QUALITY arena -> LDS -------------------------------------------------------------
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the previous chunk's reads of the slot have returned)
+            const uint32_t shq = (uint32_t)((size_t)(qual + cs) & 15u);
+            dma_span<NI>(qual + cs - shq, ce - cs + shq, slot, lane);
+            const uint32_t rowq = v_off - cs + shq; // this lane's read inside the slot
+            // first / last base (mask_quality_terminal_N needs them before the qualities are looked at)
+            uint32_t bfirst = 0, blast = 0;
+            if (len) { bfirst = (uint32_t)seq[(size_t)v_off]; blast = (uint32_t)seq[(size_t)v_off + len - 1]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+            // ================= Q-A: one read per lane ===============================================================
+            ReadOutcome oc;
+            uint32_t v_patch = (uint32_t)len << 8; // lead | trail << 8
+            // ---- mask_quality_terminal_N (trim.cpp:1191-1216): upper-case 'N' runs at either end get Q0, in place ----
+            const bool tn = len > 0 && (bfirst == 'N' || blast == 'N');
+            if (__any(tn)) {
+                int lead = 0, trail = len;
+                bool go = tn && bfirst == 'N';
+#pragma unroll 1
+                while (__any(go)) {
+                    if (go) { ++lead; go = lead < len && seq[(size_t)v_off + lead] == 'N'; }
+                }
+                go = tn && blast == 'N' && lead < len;
+                if (tn && lead >= len) trail = 0;
+#pragma unroll 1
+                while (__any(go)) {
+                    if (go) { --trail; go = trail > 0 && seq[(size_t)v_off + trail - 1] == 'N'; }
+                }
+                if (tn) v_patch = (uint32_t)lead | ((uint32_t)trail << 8);
+                const int ntail = tn ? len - trail : 0;
+#pragma unroll 1
+                for (int i = 0; __any(tn && (i < lead || i < ntail)); ++i) {
+                    if (tn && i < lead) lds_st_u8(slot_b + rowq + (uint32_t)i, (uint32_t)in_off);
+                    if (tn && i < ntail) lds_st_u8(slot_b + rowq + (uint32_t)(trail + i), (uint32_t)in_off);
+                }
+            }
+
+            // ---- quality: sum and range check, four bytes per instruction --------------------------------
+            // V = sum(raw - offset); a byte outside [offset, offset + 41] (or >= 128) sends the read to the exact pass
+            uint32_t qsum = 0, qacc = 0;
+            int n_dw = 0; // dwords every lane has summed (wave-uniform): a dword past a lane's read counts as four offset bytes
+            const uint32_t c_hi = 0x56565656u; // x = raw - offset ; x + 0x56: bit 7 <=> x > 41
+            {
+                const int nfull = len >> 2, rem = len & 3;
+                const int kmax = uni((int)wave_max_u32((uint32_t)nfull));
+                const uint32_t qa = slot_b + rowq, qa4 = qa & ~3u, qsh = qa & 3u;
+                uint32_t prev = lds_ld(qa4);
+#pragma unroll 4
+                for (int k = 0; k < kmax; ++k) {
+                    const uint32_t nxt = lds_ld(qa4 + 4u * (uint32_t)k + 4u);
+                    uint32_t w = __builtin_amdgcn_alignbyte(nxt, prev, qsh);
+                    prev = nxt;
+                    w = k < nfull ? w : offb;
+                    qsum = __builtin_amdgcn_sad_u8(w, 0u, qsum);
+                    const uint32_t x = w - offb; // a byte below the offset borrows: bit 7 of that byte (or of a lower one) is set
+                    qacc |= x | (x + c_hi) | w;  // bit 7: raw < offset, raw > offset + 41 or raw >= 128, in some byte
+                }
+                n_dw = kmax;
+                if (__any(rem != 0)) { // the bytes of the last, partial dword (past the read: quality == offset, adds 0)
+                    const uint32_t m = low_bytes_(rem); // (rem == 0: no byte)
+                    const uint32_t w = (lds_ld_any(qa + 4u * (uint32_t)nfull) & m) | (offb & ~m);
+                    qsum = __builtin_amdgcn_sad_u8(w, 0u, qsum);
+                    const uint32_t x = w - offb;
+                    qacc |= x | (x + c_hi) | w;
+                    n_dw = kmax + 1;
+                }
+            }
+            const bool badq = !swar_ok || ((qacc & 0x80808080u) != 0u);
+            int V_pre = (int)qsum - 4 * n_dw * in_off;
+            bool read_err = false;
+            if (__any(badq)) {
+                // the trimmers clamp a negative score to 0 (fastq.h:17-36): clamp the staged bytes in place; the sums and the
+                // > 41 verdict of such a read come from the exact pass over the arena further down
+#pragma unroll 1
+                for (int p = 0; __any(badq && p < len); ++p) {
+                    if (badq && p < len) {
+                        const uint32_t r = lds_ld_u8(slot_b + rowq + (uint32_t)p);
+                        int v = (int)(int8_t)r - in_off;
+                        v = v < 0 ? 0 : (v > 41 ? 41 : v);
+                        lds_st_u8(slot_b + rowq + (uint32_t)p, (uint32_t)(v + in_off));
+                    }
+                }
+            }
+
+            // ---- the window the reference trims: after the adapter pre-pass and --5end/--3end (trim.cpp:270-314) ----
+            int wa = 0, wn = len;
+            uint32_t flags = 0, filt = 0;
+            if (WINDOWED && P.has_adapters) {
+                const int first = (int)(v_sl & 0xffffu), second = (int)(v_sl >> 16);
+                const bool mod = len != second;
+                wa = mod ? first : 0; wn = mod ? second : len;
+                flags = mod ? FAQCS_F_ADAPTER : 0u;
+            }
+            if (WINDOWED && P.trim5) {
+                const bool over = (int)P.trim5 > wn;
+                wa = over ? wa : wa + (int)P.trim5;
+                wn = over ? 0 : wn - (int)P.trim5;
+            }
+            if (WINDOWED && P.trim3) wn = (int)P.trim3 > wn ? 0 : wn - (int)P.trim3;
+
+            // ---- BWA_plus (trim.cpp:714-793), walked as the reference walks it ---------------------------------
+            // Step s of a walk visits window position wn - 1 - s (3') or s (5').  at_least_scan == 0 after step `bud`: the walk
+            // covers min(5, n) positions and a reset at step s (area >= 0 before it, position still > n2 away from the far end)
+            // moves its end to s + 2 (n2 == 2 whenever a reset can fire).  key = area << 8 | 255 - s: the FIRST maximum wins.
+            const int a5 = wn < 5 ? wn : 5, nn2 = wn < 2 ? wn : 2, qoff = Q + in_off;
+            int S3, fp3, S5 = 0, fp5 = 0;
+            {
+                int bud = a5 - 1, area = 0, best = 255;
+                const int rlim = wn - 1 - nn2; // reset at step s <=> wn - 1 - s > n2
+                const uint32_t endq = slot_b + rowq + (uint32_t)(wa + wn);
+                const uint32_t e4 = endq & ~3u, esh = endq & 3u;
+                uint32_t hi = lds_ld(e4);
+#pragma unroll 1
+                for (int s0 = 0; __any(s0 <= bud); s0 += 4) {
+                    const uint32_t lo = lds_ld(e4 - 4u - (uint32_t)s0);
+                    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, esh); // positions wend-4-s0 .. wend-1-s0
+                    hi = lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int s = s0 + j;
+                        if (s <= bud) {
+                            if (area >= 0 && s < rlim) bud = s + 2;
+                            area += qoff - (int)((w >> (8 * (3 - j))) & 0xffu);
+                            const int K = area * 256 + (255 - s);
+                            best = best > K ? best : K;
+                        }
+                    }
+                }
+                S3 = best >> 8;
+                fp3 = S3 > 0 ? (wn - 1 - (255 - (best & 255))) - 1 : wn - 1;
+            }
+            if (!(EXT && P.protect5)) { // --5trim_off (trim.cpp:752)
+                int bud = a5 - 1, area = 0, best = 255;
+                const int rlim = fp3 - nn2; // reset at step s <=> s < final_pos_3 - n2
+                const uint32_t begq = slot_b + rowq + (uint32_t)wa;
+                const uint32_t b4 = begq & ~3u, bsh = begq & 3u;
+                uint32_t lo = lds_ld(b4);
+#pragma unroll 1
+                for (int s0 = 0; __any(s0 <= bud); s0 += 4) {
+                    const uint32_t hi = lds_ld(b4 + 4u + (uint32_t)s0);
+                    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, bsh);
+                    lo = hi;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int s = s0 + j;
+                        if (s <= bud) {
+                            if (area >= 0 && s < rlim) bud = s + 2;
+                            area += qoff - (int)((w >> (8 * j)) & 0xffu);
+                            const int K = area * 256 + (255 - s);
+                            best = best > K ? best : K;
+                        }
+                    }
+                }
+                S5 = best >> 8;
+                fp5 = S5 > 0 ? (255 - (best & 255)) + 1 : 0;
+            }
+
+            // ---- length filters and the kept window (trim.cpp:317-360) -------------------------------------
+            int a = wa, n = wn;
+            bool ret = mine;
+            uint32_t qt_removed = 0;
+            if (ret && (n < (int)P.min_len || n == 0)) { ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
+            if (ret) {
+                const int kept = fp3 <= fp5 ? 0 : fp3 - fp5 + 1;
+                if (kept != n) { qt_removed = (uint32_t)(n - kept); flags |= FAQCS_F_QUAL_TRIMMED; }
+                a += fp5;
+                n = kept;
+                if (n < (int)P.min_len || n == 0) { ret = false; filt = FAQCS_FILT_LENGTH_POST; }
+            }
+
+            // ---- sum(raw - offset) over the kept window (trim.cpp:374, :553-576) ---------------------------
+            int V_win = V_pre;
+            if (WINDOWED) { // the window's own sum first
+                uint32_t sm = 0;
+                const int k0 = wa >> 2, k1 = (wa + wn + 3) >> 2; // dwords that hold a window byte
+                const int kmax = uni((int)wave_max_u32((uint32_t)(k1 - k0)));
+#pragma unroll 2
+                for (int i = 0; i < kmax; ++i) {
+                    const int k = k0 + i;
+                    const uint32_t w = lds_ld_any(slot_b + rowq + 4u * (uint32_t)k); // (k >= k1: masked to nothing)
+                    const uint32_t m = low_bytes_(med3i(wa + wn - 4 * k, 0, 4)) & ~low_bytes_(med3i(wa - 4 * k, 0, 4));
+                    sm = __builtin_amdgcn_sad_u8(w & m, 0u, sm);
+                }
+                V_win = (int)sm - wn * in_off;
+            }
+            // all v == q here (no byte below the offset): what the two walks cut off is their maximal areas
+            int V_post = n * Q - ((wn * Q - V_win) - (S3 > 0 ? S3 : 0) - (S5 > 0 ? S5 : 0));
+            // exact pass for a read with a raw quality outside [offset, offset + 41] (negative scores clamp to 0 in the
+            // trimmers but not in the averages; > 41 aborts the run)
+            if (__any(badq)) {
+                const ExactQ xq = exact_quality(qual, v_off, len, v_patch, a, n, in_off, badq);
+                if (badq) { V_pre = xq.sv; V_post = xq.svp; read_err = xq.mq > 41; }
+            }
+            // ---- average quality (trim.cpp:374-382): after poly-N in the reference; poly-N is judged in S-A, and a read it
+            // rejects never reaches this test, so the order is restored there (avgq_fail is only applied to a read that passes) ----
+            const bool avgq_fail = EXT && P.avgq_on && V_post < ((const int32_t *)(smem + Cfg::O_TAVGQ))[n];
+
+            // ================= Q-B: 8 lanes per read, position x quality ===========================================
+            // (post cells are added for every read that is still valid; S-A's vetoes are taken back below)
+            const uint32_t qi0 = rowq | ((uint32_t)len << 16);
+            const uint32_t qi1 = (uint32_t)a | ((uint32_t)n << 8) | (ret ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u);
+#pragma unroll 1
+            for (int t = 0; t < LPR; ++t) {
+                if (base + (uint32_t)t >= n_reads) break; // wave-uniform: no row has a read left
+                quality_cells((uint32_t)__shfl((int)qi0, rowb + t), (uint32_t)__shfl((int)qi1, rowb + t), std::false_type{});
+            }
+
+            // ---- the span of the BASE arena -> the same slot ---------------------------------------------------------
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every LDS read of the slot has returned
+            const uint32_t shs = (uint32_t)((size_t)(seq + cs) & 15u);
+            dma_span<NI>(seq + cs - shs, ce - cs + shs, slot, lane);
+            const uint32_t rows = v_off - cs + shs;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+            // ================= S-A: one read per lane, the bases =====================================================
+            const bool ret_q = ret;
+            uint32_t pA, pT, pC, pG, pN, cA, cT, cC, cG, cN;
+            {
+                // ---- classes: A,T,C,G counts (8-bit fields), the counts in front of the kept window's two ends, upper-case N bits ----
+                uint32_t cnt4 = 0, nub[NWORD], sA = 0, sE = 0;
+                const int ka = a >> 2, ke = (a + n) >> 2;
+                const int nfull = len >> 2, rem = len & 3;
+                const int kmax = uni((int)wave_max_u32((uint32_t)((len + 3) >> 2)));
+                const uint32_t sa = slot_b + rows, sa4 = sa & ~3u, ssh = sa & 3u;
+                uint32_t prev = lds_ld(sa4);
+#pragma unroll
+                for (int wd = 0; wd < NWORD; ++wd) {
+                    uint32_t nw = 0;
+                    const int kend = (8 * wd + 8 < ND) ? 8 * wd + 8 : ND;
+                    if (8 * wd < kmax) { // (wave-uniform)
+#pragma unroll 2
+                        for (int k = 8 * wd; k < kend; ++k) {
+                            const uint32_t nxt = lds_ld(sa4 + 4u * (uint32_t)k + 4u);
+                            uint32_t w = __builtin_amdgcn_alignbyte(nxt, prev, ssh);
+                            prev = nxt;
+                            if (__any(k >= nfull)) w &= low_bytes_(med3i(len - 4 * k, 0, 4)); // bytes past the read: class "none"
+                            sA = k == ka ? cnt4 : sA;
+                            sE = k == ke ? cnt4 : sE;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t ad = (j == 0 ? byte_x8<0>(w, three) : j == 1 ? byte_x8<1>(w, three)
+                                                     : j == 2 ? byte_x8<2>(w, three) : byte_x8<3>(w, three)) + (uint32_t)(T::O_T2 * 4);
+                                const LdsPair2 e = *(lds_u2c_ptr)(size_t)ad;
+                                cnt4 += e.x;
+                                nw = __builtin_amdgcn_alignbit(e.y, nw, 1); // bit (p & 31) = upper-case N at p
+                            }
+                        }
+                    }
+                    nub[wd] = nw;
+                }
+                if ((NPOS & 31) != 0) nub[NWORD - 1] >>= (32 - (NPOS & 31));
+                if (ka >= ND) sA = cnt4;
+                if (ke >= ND) sE = cnt4;
+                const int nACGT = (int)__builtin_amdgcn_sad_u8(cnt4, 0u, 0u);
+                int nup = 0;
+#pragma unroll
+                for (int w = 0; w < NWORD; ++w) nup += __builtin_popcount(nub[w]);
+                const bool abn_seq = nACGT + nup != len; // a letter that is neither ACGT (any case) nor 'N'
+
+                // ---- poly-N (trim.cpp:363-371, :578-597): -n 2 = two adjacent upper-case N inside the kept window ----
+                if (EXT && P.max_poly_n != 2u) { // -n 0: every read trips; -n 1: any upper-case N inside the kept window
+                    uint32_t hit = 0;
+#pragma unroll
+                    for (int w = 0; w < NWORD; ++w) hit |= nub[w] & bit_range_(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
+                    if (ret && (P.max_poly_n == 0u || hit != 0u)) { flags |= FAQCS_F_POLY_N_SEEN; ret = false; filt = FAQCS_FILT_POLY_N; }
+                } else {
+                    uint32_t pr[NWORD], anyp = 0; // bit e: N at e - 1 and at e
+#pragma unroll
+                    for (int w = 0; w < NWORD; ++w) {
+                        pr[w] = nub[w] & ((nub[w] << 1) | (w ? nub[w - 1] >> 31 : 0u));
+                        anyp |= pr[w];
+                    }
+                    if (__any(ret && anyp != 0u)) {
+                        uint32_t hit = 0;
+#pragma unroll
+                        for (int w = 0; w < NWORD; ++w) hit |= pr[w] & bit_range_(med3i(a + 1 - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
+                        if (ret && hit != 0u) { flags |= FAQCS_F_POLY_N_SEEN; ret = false; filt = FAQCS_FILT_POLY_N; }
+                    }
+                }
+                // ---- average quality (judged in Q-A, applied here: after poly-N, trim.cpp:374-382) ----
+                if (EXT && ret && avgq_fail) { ret = false; filt = FAQCS_FILT_AVG_Q; }
+
+                // ---- base counts before / inside the kept window (trim.cpp:390-403, :810-875) ---------------------
+                // prefix(x) = count in front of dword x >> 2 plus the x & 3 bytes in front of x
+                auto partial = [&](int x) -> uint32_t {
+                    uint32_t c = 0;
+                    if (__any((x & 3) != 0)) {
+                        uint32_t w = 0;
+                        w = lds_ld_any(slot_b + rows + (uint32_t)(x & ~3)) & (low_bytes_(x & 3) & ((x & 3) ? 0xffffffffu : 0u));
+                        c += ((lds_u2c_ptr)(size_t)(byte_x8<0>(w, three) + (uint32_t)(T::O_T2 * 4)))->x;
+                        c += ((lds_u2c_ptr)(size_t)(byte_x8<1>(w, three) + (uint32_t)(T::O_T2 * 4)))->x;
+                        c += ((lds_u2c_ptr)(size_t)(byte_x8<2>(w, three) + (uint32_t)(T::O_T2 * 4)))->x;
+                    }
+                    return c;
+                };
+                uint32_t c4post = cnt4;
+                if (__any(ret && (a != 0 || n != len))) {
+                    c4post = sE + partial(a + n);
+                    if (__any(a != 0)) c4post -= sA + partial(a);
+                }
+                pA = cnt4 & 0xffu; pT = (cnt4 >> 8) & 0xffu; pC = (cnt4 >> 16) & 0xffu; pG = cnt4 >> 24;
+                cA = c4post & 0xffu; cT = (c4post >> 8) & 0xffu; cC = (c4post >> 16) & 0xffu; cG = c4post >> 24;
+                pN = (uint32_t)(len - nACGT); cN = (uint32_t)n - (cA + cT + cC + cG); // (exact pass below when abn_seq)
+
+                // ---- low-complexity filter (trim.cpp:405-513) ---------------------------------------------------
+                bool lc_trip = false, dinuc = false;
+                uint32_t dthr = 0;
+                if (ret) {
+                    const uint32_t thr = t_lc[n];
+                    const uint32_t mthr = thr & 0xffffu;
+                    dthr = thr >> 16;
+                    lc_trip = cA >= mthr || cT >= mthr || cG >= mthr || cC >= mthr;
+                    // dc[X->Y] <= min(count X, count Y): only pairs whose two counts both reach dthr can trip
+                    dinuc = !lc_trip && ((cA >= dthr) + (cT >= dthr) + (cC >= dthr) + (cG >= dthr)) >= 2;
+                }
+                // exact per-position pass over the bases: N counts for reads with other letters, transition counts for
+                // dinucleotide candidates (both rare)
+                if (__any(abn_seq || dinuc)) {
+                    const ExactB xb = exact_bases(seq, v_off, len, a, n, abn_seq || dinuc, dinuc, dthr);
+                    if (abn_seq) { pN = xb.npre; cN = xb.npost; }
+                    if (dinuc) lc_trip = lc_trip || xb.trip;
+                    // bytes >= 128 are no letters: they must not look like "outside the window" to S-B
+                    if (__any(abn_seq)) {
+#pragma unroll 1
+                        for (int p = 0; __any(abn_seq && p < len); ++p)
+                            if (abn_seq && p < len && lds_ld_u8(slot_b + rows + (uint32_t)p) >= 128u) lds_st_u8(slot_b + rows + (uint32_t)p, 0u);
+                    }
+                }
+                if (ret && lc_trip) { ret = false; filt = FAQCS_FILT_LOW_COMPLEXITY; }
+            }
+
+            // ================= S-B: 8 lanes per read, position x base ==============================================
+            const uint32_t si0 = rows | ((uint32_t)len << 16);
+            const uint32_t si1 = (uint32_t)a | ((uint32_t)n << 8) | (ret ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u);
+#pragma unroll 1
+            for (int t = 0; t < LPR; ++t) {
+                if (base + (uint32_t)t >= n_reads) break;
+                const uint32_t i0 = (uint32_t)__shfl((int)si0, rowb + t), i1 = (uint32_t)__shfl((int)si1, rowb + t);
+                const int rlen = (int)(i0 >> 16), ra = (int)(i1 & 0xffu), rn = (int)((i1 >> 8) & 0xffu);
+                const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
+                const int vb = counted ? med3i(rlen - pbase, 0, C) : 0;
+                const int lo = post ? med3i(ra - pbase, 0, C) : 0, hi = post ? med3i(ra + rn - pbase, 0, C) : 0;
+                uint32_t ws[D], rs[D + 1];
+                const uint32_t ba = slot_b + (i0 & 0xffffu) + (uint32_t)pbase;
+#pragma unroll
+                for (int k = 0; k <= D; ++k) rs[k] = lds_ld((ba & ~3u) + 4u * (uint32_t)k);
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const uint32_t w = __builtin_amdgcn_alignbyte(rs[k + 1], rs[k], ba & 3u) & t_bm[BMW * vb + k];
+                    const uint32_t outm = ~(t_bm[BMW * hi + k] ^ t_bm[BMW * lo + k]);
+                    ws[k] = (w & 0x7f7f7f7fu) | (outm & 0x80808080u); // bit 7 = outside the kept window
+                }
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    const uint32_t ad = ((j & 3) == 0 ? byte_x8<0>(ws[j >> 2], three) : (j & 3) == 1 ? byte_x8<1>(ws[j >> 2], three)
+                                         : (j & 3) == 2 ? byte_x8<2>(ws[j >> 2], three) : byte_x8<3>(ws[j >> 2], three)) + (uint32_t)(T::O_T3 * 4);
+                    const LdsPair2 e = *(lds_u2c_ptr)(size_t)ad;
+                    bpre[j] += e.x;
+                    bpost[j] += e.y;
+                }
+            }
+
+            // ---- a read S-A rejected after Q-B counted its post cells: take them back (needs the qualities again) ----
+            const bool veto = ret_q && !ret;
+            if (__any(veto)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dma_span<NI>(qual + cs - shq, ce - cs + shq, slot, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the in-place edits of Q-A again: terminal-N runs and clamped bytes
+                if (__any(veto && (tn || badq))) {
+#pragma unroll 1
+                    for (int p = 0; __any(veto && (tn || badq) && p < len); ++p) {
+                        if (veto && (tn || badq) && p < len) {
+                            const uint32_t r = lds_ld_u8(slot_b + rowq + (uint32_t)p);
+                            int v = (int)(int8_t)r - in_off;
+                            v = v < 0 ? 0 : (v > 41 ? 41 : v);
+                            if (p < (int)(v_patch & 0xffu) || p >= (int)(v_patch >> 8)) v = 0;
+                            lds_st_u8(slot_b + rowq + (uint32_t)p, (uint32_t)(v + in_off));
+                        }
+                    }
+                }
+                const uint32_t ui1 = (uint32_t)a | ((uint32_t)n << 8) | (veto ? 1u << 16 : 0u);
+#pragma unroll 1
+                for (int t = 0; t < LPR; ++t) {
+                    const uint32_t i1 = (uint32_t)__shfl((int)ui1, rowb + t);
+                    if (!__any(((i1 >> 16) & 1u) != 0u)) continue;
+                    quality_cells((uint32_t)__shfl((int)qi0, rowb + t), i1, std::true_type{});
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+
+            if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
+            oc.an = (uint32_t)a | ((uint32_t)n << 16);
+            oc.fl = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT) | (qt_removed << 20);
+            oc.pAT = pA | (pT << 16); oc.pCG = pC | (pG << 16);
+            oc.cAT = cA | (cT << 16); oc.cCG = cC | (cG << 16);
+            oc.N = pN | (cN << 16);
+            oc.Vpre = V_pre; oc.Vpost = V_post;
+
+            // ---- chunk epilogue: one read per lane ----------------------------------------------------------
+            chunk_epilogue<LPR>(oc, mine, my, v_len, v_hit, lane, smem + Cfg::O_LEN, smem + Cfg::O_RQ, smem + Cfg::O_BQPRE,
+                                smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, EXT && P.avgq_on != 0, 0u);
+        }
+
+        const bool block_flush = ((it + 1) % FLUSH_EVERY) == 0 || it + 1 == n_iter;
+        if (((it + 1) % REG_FLUSH_EVERY) == 0 || block_flush) spill_base_regs();
+        if (block_flush) flush_block<C, LPR, NW, false>(smem, counters, P.R, tid);
+    }
+    if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
+}
+
+template <int C, bool WINDOWED, bool EXT>
+static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
+                                  uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
+                                  unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
+                                  int n_cu, hipStream_t st)
+{
+    constexpr int NW = lds_waves(C);
+    constexpr size_t lds = (size_t)LdsCfg<C, NW>::lds_dwords() * 4;
+    static bool attr_set = false;
+    auto kern = trim_lds<C, NW, WINDOWED, EXT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint32_t chunks = (n_reads + 63) / 64;
+    uint32_t grid = (chunks + NW - 1) / NW;
+    if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu; // one block per CU: its LDS holds a slot per wave
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
+                       reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err);
+    return hipGetLastError();
+}
+
+// Returns hipErrorNotSupported when the configuration is not one trim_lds is compiled for (the caller then takes the
+// other trim kernels).
+hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
+                                 uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
+                                 faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
+                                 uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
+{
+    const bool windowed = P.has_adapters || ((P.trim5 || P.trim3) && !P.qc_only);
+    const bool plain = P.mode == FAQCS_MODE_BWA_PLUS && !P.protect5 && !P.qc_only && P.replace_q == 0 && !P.avgq_on &&
+                       P.max_poly_n == 2 && P.dbg == 0;
+    const bool ext = !plain && P.mode == FAQCS_MODE_BWA_PLUS && !P.qc_only && P.replace_q == 0 && P.max_poly_n <= 2 && P.dbg == 0;
+    if (!plain && !ext) return hipErrorNotSupported;
+#define FAQCS_LDS_ARGS P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st
+#define FAQCS_LDS_CASE(C)                                                                                                 \
+    return ext ? (windowed ? launch_trim_lds<C, true, true>(FAQCS_LDS_ARGS) : launch_trim_lds<C, false, true>(FAQCS_LDS_ARGS)) \
+               : (windowed ? launch_trim_lds<C, true, false>(FAQCS_LDS_ARGS) : launch_trim_lds<C, false, false>(FAQCS_LDS_ARGS))
+    if (max_len > 104 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x150
+#undef FAQCS_LDS_CASE
+#undef FAQCS_LDS_ARGS
+    return hipErrorNotSupported;
+}

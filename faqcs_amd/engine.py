@@ -41,7 +41,7 @@ class HipEngine:
 
     # -- the trim() seam ---------------------------------------------------------------------------
     def process(self, seq, qual, offset, segment_start):
-        """seq/qual: uint8 arenas (padded by >= 16 readable bytes), offset: uint32[n+1],
+        """seq/qual: uint8 arenas (host memory: the library copies them into padded device buffers), offset: uint32[n+1],
         segment_start: uint32[n_segments+1].  Returns the per-read result array."""
         offset = np.ascontiguousarray(offset, dtype=np.uint32)
         segment_start = np.ascontiguousarray(segment_start, dtype=np.uint32)
@@ -64,6 +64,13 @@ class HipEngine:
         ptr, n = C.c_void_p(), C.c_uint64()
         _check(self.lib, self.lib.faqcs_counters_device(self.ctx, C.byref(ptr), C.byref(n)))
         return ptr.value, int(n.value)
+
+    def counters_export(self, d_dst, n_u64):
+        """Device-to-device copy of the block into a caller-owned buffer (the buffer the collective runs on)."""
+        _check(self.lib, self.lib.faqcs_counters_export(self.ctx, d_dst, int(n_u64)))
+
+    def counters_import(self, d_src, n_u64):
+        _check(self.lib, self.lib.faqcs_counters_import(self.ctx, d_src, int(n_u64)))
 
     def counters(self):
         out = np.zeros(self.n_counters, dtype=np.uint64)

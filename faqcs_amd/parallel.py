@@ -25,17 +25,35 @@ def shard_bounds(n_items, rank, world_size):
 
 
 def allreduce_counters_device(engine, group=None):
-    """In-place all-reduce(sum) of the engine's device-resident counter block.  uint64 sums are done on the
-    int64 view (two's-complement addition is the same operation)."""
+    """All-reduce(sum) of the engine's device-resident counter block, in place.
+
+    The collective runs on a TORCH-allocated staging tensor: RCCL registers torch's own allocations for peer access
+    (IPC handles), which it cannot do for memory the library allocated.  The block is copied device-to-device into
+    the tensor (faqcs_counters_export), all-reduced, and copied back (faqcs_counters_import).  Under a `gloo` group
+    (CPU tests, ranks sharing one GPU) the staging tensor lives on the host.  uint64 sums are done on the int64 view
+    (two's-complement addition is the same operation).  Returns the reduced block as a host numpy array only when
+    asked through engine.counters() afterwards; this function returns the staging tensor."""
     import torch
     import torch.distributed as dist
 
-    ptr, n = engine.counters_device()
-    engine.sync()
-    t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    torch.cuda.synchronize()
-    return t
+    n = engine.n_counters
+    if dist.get_backend(group) == "nccl":
+        t = getattr(engine, "_allreduce_buf", None)
+        if t is None or t.numel() != n:
+            t = torch.empty(n, dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+            engine._allreduce_buf = t
+        torch.cuda.current_stream().synchronize()  # (nothing of ours is pending on torch's stream; cheap)
+        engine.counters_export(t.data_ptr(), n)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        torch.cuda.current_stream().synchronize()
+        engine.counters_import(t.data_ptr(), n)
+        return t
+    total = allreduce_counters_host(engine.counters(), group)
+    h = torch.from_numpy(total.view(np.int64).copy())
+    d = h.to(torch.device("cuda", torch.cuda.current_device()))
+    torch.cuda.current_stream().synchronize()
+    engine.counters_import(d.data_ptr(), n)
+    return h
 
 
 def allreduce_counters_host(block, group=None):
@@ -95,7 +113,10 @@ class KmerExchange:
         else:
             dist.all_to_all_single(recv, send, group=self.group)
         n_send, n_recv = int(send.sum()), int(recv.sum())
-        items = torch.as_tensor(_DevArray(ptr, max(1, 2 * n_send)), device="cuda")[: 2 * n_send] if n_send else torch.empty(0, dtype=torch.int64, device="cuda")
+        # the outbox is library memory: RCCL sends from a torch-owned copy (it registers torch's allocations for peer access)
+        items = torch.empty(2 * n_send, dtype=torch.int64, device="cuda")
+        if n_send:
+            items.copy_(torch.as_tensor(_DevArray(ptr, 2 * n_send), device="cuda"))
         in_splits = [2 * int(x) for x in send]
         out_splits = [2 * int(x) for x in recv]
         if on_device:

@@ -45,6 +45,8 @@ enum {
 #define FAQCS_NCOMP_KIND 6     /* NucleotideCount fields A,T,C,G,N,GC, FaQCs.h:167-174 */
 #define FAQCS_SEGMENT_READS 32768 /* buffer_size, FaQCs.cpp:232,585 */
 #define FAQCS_MAX_READ_LENGTH 1024 /* longest read the HIP kernels take (the reference: int16 aligner, < 32 768) */
+#define FAQCS_ARENA_PAD_BEFORE 16 /* readable bytes required in front of / behind a batch's arenas (faqcs_batch) */
+#define FAQCS_ARENA_PAD_AFTER 64
 #define FAQCS_MAX_ADAPTERS 64
 #define FAQCS_MAX_ADAPTER_LENGTH 8192
 
@@ -94,8 +96,12 @@ typedef struct faqcs_params {
 /* One submission: reads packed back to back in two byte arenas (structure of arrays).
  * Read i occupies seq[offset[i] .. offset[i+1]) and qual[offset[i] .. offset[i+1]) -- the reference
  * rejects |seq| != |qual| at parse time (fastq.cpp:117-121) so one offset array serves both.
- * Both arenas must be readable for 16 bytes before offset[0]&~15 .. past offset[n] rounded up to 16
- * (the kernels use aligned 16-byte loads).  segment_start[] partitions the reads into reference
+ * PADDING CONTRACT: both arenas must be readable from 16 bytes before seq/qual + offset[0] up to 64 bytes past
+ * seq/qual + offset[n] (FAQCS_ARENA_PAD_BEFORE / FAQCS_ARENA_PAD_AFTER): the kernels fetch a read with unaligned
+ * multi-dword loads predicated on the read's length only (up to 19 bytes past its end) and whole 16-byte aligned
+ * pieces of a 64-read span (up to 15 bytes either side); the padding bytes are never interpreted.  faqcs_submit()
+ * and faqcs_submit_async() copy into padded device buffers themselves, so the contract binds faqcs_submit_device()
+ * callers.  segment_start[] partitions the reads into reference
  * trim() calls (adapter groups of 8 restart at a segment start, trim.cpp:977-1071; k-mer rarefaction
  * points are taken at segment ends, trim.cpp:157-185). */
 typedef struct faqcs_batch {
@@ -202,6 +208,12 @@ int  faqcs_set_quality(faqcs_ctx *ctx, int quality);
 /* Device address + length (uint64 units) of the additive counter block, so the host can run the one
  * collective this path needs -- all-reduce(sum, uint64) over RCCL -- in place before faqcs_finish(). */
 int  faqcs_counters_device(faqcs_ctx *ctx, void **d_ptr, uint64_t *n_u64);
+
+/* The same collective on a buffer the CALLER owns (what bench.py / faqcs_amd/parallel.py do: RCCL registers its own
+ * allocations for peer access, so the all-reduce runs on a torch tensor): export copies the block (device to device,
+ * d_dst/d_src are device pointers of >= n_u64 words) after the work submitted so far, import stores the reduced block. */
+int  faqcs_counters_export(faqcs_ctx *ctx, void *d_dst, uint64_t n_u64);
+int  faqcs_counters_import(faqcs_ctx *ctx, const void *d_src, uint64_t n_u64);
 
 /* Copies the counter block to the host (layout: faqcs_counters_layout); syncs first.
  * Raises FAQCS_E_QUALITY / FAQCS_E_BASE if any read tripped the reference's throw sites. */

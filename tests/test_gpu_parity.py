@@ -336,6 +336,88 @@ def test_two_rank_kmer_exchange(args, n_reads, tmp_path):
     assert open(out).read() == "ok", open(out).read()
 
 
+def _counter_rank(rank, world, port, args, n_reads, out):
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for d in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        sys.path.insert(0, d)
+    import torch
+
+    torch.cuda.init()  # before libfaqcs_mi.so: the library then binds to torch's HIP runtime (one runtime per process)
+    import torch.distributed as dist
+    from oracle_engine import OracleEngine
+
+    from faqcs_amd import driver, parallel
+    from faqcs_amd.engine import HipEngine
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    opt = parse_args(["-u", "x", "-d", "y"] + args)
+    rng = np.random.Generator(np.random.PCG64(777))
+    reads = random_batch(rng, n_reads, 150, "adv")
+    # shards are cut on reference trim() call boundaries (segments): the adapter groups of 8 restart there (trim.cpp:977-1071)
+    seg_size = 517
+    segs = [reads[i:i + seg_size] for i in range(0, n_reads, seg_size)]
+    lo, hi = parallel.shard_bounds(len(segs), rank, world)
+    eng = HipEngine(opt, 256, 33, device=0)
+    seq, qual, offset, seg = driver.pack_segments(segs[lo:hi])
+    res = eng.process(seq, qual, offset, seg)
+    parallel.allreduce_counters_device(eng)  # export -> all-reduce -> import: the block on the device is the job's total
+    total = eng.counters()
+    n_before = sum(len(x) for x in segs[:lo])
+    ora = OracleEngine(opt, 256, 33)
+    s2, q2, o2, g2 = driver.pack_segments(segs)
+    res_all = ora.process(s2, q2, o2, g2)
+    ok = bool((total == ora.counters()).all()) and bool((res == res_all[n_before:n_before + len(res)]).all())
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    if rank == 0:
+        with open(out, "w") as f:
+            f.write("ok" if all(flags) else "mismatch %r" % (flags,))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("args", [[], ["--adapter", "--polyA"], ["-q", "20", "--min_L", "30", "--5end", "3"]], ids=["plain", "adapter", "windowed"])
+def test_two_rank_hip_counters_allreduce(args, tmp_path):
+    """BASELINE configs[3] in miniature: two ranks (sharing the box's one GPU, gloo) each run the HIP engine on their shard of
+    reference trim() calls; after parallel.allreduce_counters_device() EVERY rank's device block equals the single-process
+    oracle's, and the per-read results equal the oracle's rows of that shard (merge semantics: trim.cpp:120-154)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_counter_rank, args=(2, port, args, 4000, out), nprocs=2, join=True)
+    assert open(out).read() == "ok", open(out).read()
+
+
+def test_bench_gpus_2_runs_two_ranks(tmp_path):
+    """`bench.py --gpus 2` with no launcher must START two ranks (here sharing the one GPU over gloo, FAQCS_BENCH_SHARE_GPU=1)
+    and say so in its line; a disagreement between --gpus and WORLD_SIZE is an error, not a silent 1-GPU run."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FAQCS_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--pairs", "2e6", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and sorted(x[0] for x in line["ranks_seen"]) == [0, 1]
+    env2 = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--pairs", "1e6"], env=env2,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r2.returncode != 0 and b"disagrees" in r2.stderr
+
+
 def test_full_size_properties():
     """BASELINE configs[1] shape at a size the oracle cannot follow: size-independent invariants of the
     counter block, device-resident submission == host submission, and idempotence of trimming."""
