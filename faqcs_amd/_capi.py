@@ -161,6 +161,7 @@ def load_library():
         "faqcs_synth_fill": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, C.c_float]),
         "faqcs_synth_fill_genome": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, u64]),
         "faqcs_kernel_time_ms": (i32, [vp, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "faqcs_debug_words": (i32, [vp, vp, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError == a symbol the header declares is missing

@@ -338,8 +338,8 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     HIPCHK(upload(&c->d_magic, magic)); HIPCHK(upload(&c->d_basetab, basetab));
     HIPCHK(hipMalloc((void **)&c->d_counters, c->lay.total * sizeof(uint64_t)));
     HIPCHK(hipMemset(c->d_counters, 0, c->lay.total * sizeof(uint64_t)));
-    HIPCHK(hipMalloc((void **)&c->d_err, 64));
-    HIPCHK(hipMemset(c->d_err, 0, 64));
+    HIPCHK(hipMalloc((void **)&c->d_err, 256)); // [0] error bits ; bytes 64.. : 16 diagnostic u64 words (FAQCS_LDS_STAMPS builds)
+    HIPCHK(hipMemset(c->d_err, 0, 256));
 
     if (p->n_adapters) {
         std::vector<uint8_t> bits; std::vector<uint32_t> start(1, 0);
@@ -907,6 +907,17 @@ extern "C" int faqcs_synth_fill_genome(int device_id, uint8_t *d_seq, uint8_t *d
 {
     if (genome_len <= L) return fail(FAQCS_E_INVAL, "faqcs_synth_fill_genome: the genome must be longer than a read");
     return synth_fill_impl(device_id, d_seq, d_qual, d_offset, n_reads, L, seed, first_read, 0.f, genome_len);
+}
+
+// Diagnostic builds only (-DFAQCS_LDS_STAMPS): the 16 u64 words the trim kernel accumulates its section clocks in; reads and clears them.
+extern "C" int faqcs_debug_words(faqcs_ctx *c, uint64_t *out, uint32_t n)
+{
+    if (!c || !out || n > 16) return fail(FAQCS_E_INVAL, "faqcs_debug_words: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemcpy(out, reinterpret_cast<const uint8_t *>(c->d_err) + 64, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(reinterpret_cast<uint8_t *>(c->d_err) + 64, 0, 128));
+    return 0;
 }
 
 extern "C" int faqcs_kernel_time_ms(faqcs_ctx *c, double *avg_ms, uint64_t *n_launches)

@@ -1369,7 +1369,7 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
                              uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
 {
     {   // trim_lds (faqcs_trim_lds_kernel.hip): every byte from HBM once, through LDS; FAQCS_TRIM_LDS=0 switches it off
-        static const bool lds_on = [] { const char *e = getenv("FAQCS_TRIM_LDS"); return e && atoi(e) != 0; }();
+        static const bool lds_on = [] { const char *e = getenv("FAQCS_TRIM_LDS"); return !e || atoi(e) != 0; }();
         if (lds_on) {
             const hipError_t e = faqcs_launch_trim_lds(P, seq, qual, off, n_reads, max_len, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st);
             if (e != hipErrorNotSupported) return e;

@@ -92,6 +92,48 @@ __device__ __forceinline__ uint32_t bit_range_(int s, int e)
     return hi & ~lo;
 }
 
+// One dword (four positions) of a BWA_plus walk, for the lanes that are still walking; the others are switched off in EXEC
+// and never come back.
+//   it     step index of the dword's first position (wave-uniform)
+//   c0     (it + 1) * (Q + offset) * 256 + 254 - it ; dc = (Q + offset) * 256 - 1: key = (area << 8) + code with
+//          area = a + (steps so far) * (Q + offset) (a = minus the sum of the raw bytes), code = 254 - step index
+//   rb     (last step index of the walk) - it: position j of the dword is visited while rb >= j; a reset at j (area >= 0
+//          before the step, step index < rlim) makes it j + 2; the caller's view moves on by 4 per dword
+//   DESC   the walk visits the dword's bytes 3, 2, 1, 0 (3' walk) or 0, 1, 2, 3 (5' walk)
+// Per position: v_cmpx (alive), 2 x v_cmp + s_or (no reset), v_cndmask (rb), v_sub_sdwa (area), v_lshl_add (key), v_max.
+template <bool DESC>
+__device__ __forceinline__ void walk_step(const uint32_t w, const int it, const int c0, const int dc, int &rb, const int rlim, int &a, int &K, int &best)
+{
+    unsigned long long sv, t;
+    int s = uni(it), c = uni(c0);
+#define FAQCS_WALK_POS(J, J2, B)                                                                                   \
+    "v_cmpx_le_i32 vcc, " #J ", %[rb]\n\t"                                                                         \
+    "v_cmp_gt_i32 vcc, 0, %[K]\n\t"                                                                                \
+    "v_cmp_le_i32 %[t], %[rlim], %[s]\n\t"                                                                         \
+    "s_or_b64 vcc, vcc, %[t]\n\t"                                                                                  \
+    "v_cndmask_b32 %[rb], " #J2 ", %[rb], vcc\n\t"                                                                 \
+    "v_sub_u32_sdwa %[a], %[a], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B "\n\t"  \
+    "v_lshl_add_u32 %[K], %[a], 8, %[c]\n\t"                                                                       \
+    "v_max_i32 %[best], %[best], %[K]\n\t"                                                                         \
+    "s_add_i32 %[s], %[s], 1\n\t"                                                                                  \
+    "s_add_i32 %[c], %[c], %[dc]\n\t"
+    if (DESC)
+        asm volatile("s_mov_b64 %[sv], exec\n\t" FAQCS_WALK_POS(0, 2, 3) FAQCS_WALK_POS(1, 3, 2) FAQCS_WALK_POS(2, 4, 1) FAQCS_WALK_POS(3, 5, 0)
+                     "s_mov_b64 exec, %[sv]\n\t"
+                     "v_add_u32 %[rb], -4, %[rb]"
+                     : [rb] "+v"(rb), [a] "+v"(a), [K] "+v"(K), [best] "+v"(best), [s] "+s"(s), [c] "+s"(c), [sv] "=&s"(sv), [t] "=&s"(t)
+                     : [w] "v"(w), [rlim] "v"(rlim), [dc] "s"(dc)
+                     : "vcc");
+    else
+        asm volatile("s_mov_b64 %[sv], exec\n\t" FAQCS_WALK_POS(0, 2, 0) FAQCS_WALK_POS(1, 3, 1) FAQCS_WALK_POS(2, 4, 2) FAQCS_WALK_POS(3, 5, 3)
+                     "s_mov_b64 exec, %[sv]\n\t"
+                     "v_add_u32 %[rb], -4, %[rb]"
+                     : [rb] "+v"(rb), [a] "+v"(a), [K] "+v"(K), [best] "+v"(best), [s] "+s"(s), [c] "+s"(c), [sv] "=&s"(sv), [t] "=&s"(t)
+                     : [w] "v"(w), [rlim] "v"(rlim), [dc] "s"(dc)
+                     : "vcc");
+#undef FAQCS_WALK_POS
+}
+
 // One arena's span of the chunk -> the wave's LDS slot: <= NI wave-wide 1 KB DMA loads from 16-byte aligned addresses.
 // g = arena + (span start rounded down to 16 bytes), nbytes = bytes from there to the span's end.
 template <int NI>
@@ -194,9 +236,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         const uint32_t w = P.base_tab[i];
         smem[T::O_T2 + 2 * i] = ((w >> BT_SHIFT(0)) & 1u) | (((w >> BT_SHIFT(1)) & 1u) << 8) | (((w >> BT_SHIFT(2)) & 1u) << 16) | (((w >> BT_SHIFT(3)) & 1u) << 24);
         smem[T::O_T2 + 2 * i + 1] = (w >> 31) | (((w >> BT_SHIFT(4)) & 1u) << 1);
-        const uint32_t f = P.base_tab[i & 127] & BT_FIELDS; // S-B: byte | 0x80 = the same base outside the kept window
-        smem[T::O_T3 + 2 * i] = f;
-        smem[T::O_T3 + 2 * i + 1] = i < 128 ? f : 0u;
+    }
+    for (int i = tid; i < 256; i += NW * 64) { // S-B: entry[b] = (pre, post) increments of base b; entry[b ^ 1] = (pre, 0): outside the kept window
+        const uint32_t f = P.base_tab[i] & BT_FIELDS, g = P.base_tab[i ^ 1] & BT_FIELDS; // (b and b ^ 1 are never both bases)
+        smem[T::O_T3 + 2 * i] = f | g;
+        smem[T::O_T3 + 2 * i + 1] = f;
     }
     for (int i = tid; i <= W; i += NW * 64) {
         smem[Cfg::O_TLC + i] = P.lc_thr[i];
@@ -243,27 +287,35 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         }
     };
 
-    // position x quality cells of the 8 reads in flight: DATA = +1 pre / +1 post (sign = -1: take the post cells back)
+    // ---- the position-parallel passes (8 lanes per read).  What a lane fetches from LDS for one read: six aligned dwords
+    // that hold its C bytes and three rows of the byte-mask table (positions inside the read / in front of the kept
+    // window's end / in front of its start).  Fetched one read AHEAD of its use so that the LDS latency is covered.
     // i0 = slot offset of the read | len << 16 ; i1 = a | n << 8 | post << 16 | counted << 17
-    auto quality_cells = [&](const uint32_t i0, const uint32_t i1, auto undo_t) {
-        constexpr bool undo = decltype(undo_t)::value;
+    struct RawB { uint32_t r[D + 1], mv[D], mh[D], ml[D]; };
+    auto load_b = [&](const uint32_t i0, const uint32_t i1, RawB &x) {
         const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
-        const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
+        const bool post = ((i1 >> 16) & 1u) != 0u;
         const int vb = med3i(len - pbase, 0, C);
         const int lo = post ? med3i(a - pbase, 0, C) : 0, hi = post ? med3i(a + n - pbase, 0, C) : 0;
-        uint32_t cm[D], im[D], wq[D], rq[D + 1];
-        const uint32_t qa = slot_b + (i0 & 0xffffu) + (uint32_t)pbase;
+        const uint32_t qa = (slot_b + (i0 & 0xffffu) + (uint32_t)pbase) & ~3u;
 #pragma unroll
-        for (int k = 0; k <= D; ++k) rq[k] = lds_ld((qa & ~3u) + 4u * (uint32_t)k);
+        for (int k = 0; k <= D; ++k) x.r[k] = lds_ld(qa + 4u * (uint32_t)k);
+#pragma unroll
+        for (int k = 0; k < D; ++k) { x.mv[k] = t_bm[BMW * vb + k]; x.mh[k] = t_bm[BMW * hi + k]; x.ml[k] = t_bm[BMW * lo + k]; }
+    };
+    // position x quality cells: DATA = +1 pre / +1 post per base (undo: -1 post, for a read S-A vetoed afterwards).
+    // A byte past the read belongs to the next read of the span or to the pad behind it (valid quality bytes both: its
+    // zero increment stays inside the table).
+    auto quality_cells = [&](const RawB &x, const uint32_t i0, const uint32_t i1, auto undo_t) {
+        constexpr bool undo = decltype(undo_t)::value;
+        const bool counted = ((i1 >> 17) & 1u) != 0u;
+        const uint32_t sh = ((i0 & 0xffffu) + (uint32_t)pbase + slot_b) & 3u;
+        uint32_t cm[D], im[D], wq[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            const uint32_t inside = t_bm[BMW * vb + k]; // 0xff: a position of the read
-            cm[k] = (counted && !undo) ? inside & 0x01010101u : 0u;
-            im[k] = (t_bm[BMW * hi + k] ^ t_bm[BMW * lo + k]) & (undo ? 0xffffffffu : 0x01010101u);
-            // a byte past the read is whatever the slot holds there: make it the offset so that its (zero) increment stays
-            // inside the table -- a stray read-modify-write could undo another wave's DMA or patch
-            const uint32_t w = __builtin_amdgcn_alignbyte(rq[k + 1], rq[k], qa & 3u);
-            wq[k] = (w & inside) | (offb & ~inside);
+            cm[k] = (counted && !undo) ? x.mv[k] & 0x01010101u : 0u;
+            im[k] = (x.mh[k] ^ x.ml[k]) & (undo ? 0xffffffffu : 0x01010101u);
+            wq[k] = __builtin_amdgcn_alignbyte(x.r[k + 1], x.r[k], sh);
         }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -276,17 +328,69 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             lds_add_u32(ad + 4u * (uint32_t)j, data);
         }
     };
+    // position x base: 6-bit count fields in registers.  A base outside the kept window is looked up at (byte ^ 1) -- '@',
+    // 'B', 'F', 'U', 'O' and their lower-case forms, none of them a base -- whose entry carries the pre increment only; the
+    // neighbouring 8-byte entry sits in another pair of banks, so the two flavours of a base never collide.
+    auto base_cells = [&](const RawB &x, const uint32_t i0, const uint32_t i1) {
+        const bool counted = ((i1 >> 17) & 1u) != 0u;
+        const uint32_t sh = ((i0 & 0xffffu) + (uint32_t)pbase + slot_b) & 3u;
+        uint32_t ws[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const uint32_t w = __builtin_amdgcn_alignbyte(x.r[k + 1], x.r[k], sh) & (counted ? x.mv[k] : 0u);
+            ws[k] = w ^ (~(x.mh[k] ^ x.ml[k]) & 0x01010101u);
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t ad = ((j & 3) == 0 ? byte_x8<0>(ws[j >> 2], three) : (j & 3) == 1 ? byte_x8<1>(ws[j >> 2], three)
+                                 : (j & 3) == 2 ? byte_x8<2>(ws[j >> 2], three) : byte_x8<3>(ws[j >> 2], three)) + (uint32_t)(T::O_T3 * 4);
+            const LdsPair2 e = *(lds_u2c_ptr)(size_t)ad;
+            bpre[j] += e.x;
+            bpost[j] += e.y;
+        }
+    };
+    // the loop over the 8 reads of a lane's row (a deeper software pipeline -- info two reads ahead, LDS bytes one read ahead --
+    // was measured: +5 VALU per read for the register copies and no shorter waits; the LDS pipeline itself is the limit)
+#define FAQCS_B_LOOP(I0, I1, CELLS)                                                                                   \
+    {                                                                                                                 \
+        _Pragma("unroll 1") for (int t = 0; t < LPR; ++t) {                                                          \
+            if (base + (uint32_t)t >= n_reads) break; /* wave-uniform: no row has a read left */                      \
+            const uint32_t a0_ = (uint32_t)__shfl((int)(I0), rowb + t), a1_ = (uint32_t)__shfl((int)(I1), rowb + t);   \
+            RawB cur_;                                                                                                \
+            load_b(a0_, a1_, cur_);                                                                                   \
+            CELLS(cur_, a0_, a1_);                                                                                    \
+        }                                                                                                             \
+    }
 
+#ifdef FAQCS_LDS_STAMPS
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+#define FAQCS_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_prev; st_prev = now_; }
+#else
+#define FAQCS_STAMP(i)
+#endif
+    uint32_t p_off = 0, p_end = 0;
+    auto fetch_offsets = [&](const uint32_t it_) {
+        const uint32_t chunk_ = (it_ * gridDim.x + blockIdx.x) * NW + wave;
+        if (it_ < n_iter && chunk_ < total_chunks) {
+            const uint32_t my_ = (chunk_ << 6) + (uint32_t)lane;
+            p_off = off[my_ < n_reads ? my_ : n_reads];
+            p_end = off[my_ < n_reads ? my_ + 1 : n_reads];
+        }
+    };
+    fetch_offsets(0);
 #pragma unroll 1
     for (uint32_t it = 0; it < n_iter; ++it) {
         const uint32_t chunk = (it * gridDim.x + blockIdx.x) * NW + wave;
+#ifdef FAQCS_LDS_STAMPS
+        st_prev = __builtin_amdgcn_s_memtime();
+#endif
         if (chunk < total_chunks) {
             const uint32_t base = chunk << 6;
             const uint32_t my = base + lane;
             const bool mine = my < n_reads;
             // a lane without a read sits at the end of the last read (length 0): the span ends where lane 63 ends
-            const uint32_t v_off = off[mine ? my : n_reads];
-            const uint32_t v_end = off[mine ? my + 1 : n_reads];
+            // (the two offsets were fetched during the previous chunk)
+            const uint32_t v_off = p_off, v_end = p_end;
             const uint32_t v_len = v_end - v_off;
             const uint32_t v_sl = (WINDOWED && ad_sl && mine) ? ad_sl[my] : (v_len << 16);
             const uint32_t v_hit = (ad_hit && mine) ? ad_hit[my] : 0u;
@@ -301,7 +405,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // first / last base (mask_quality_terminal_N needs them before the qualities are looked at)
             uint32_t bfirst = 0, blast = 0;
             if (len) { bfirst = (uint32_t)seq[(size_t)v_off]; blast = (uint32_t)seq[(size_t)v_off + len - 1]; }
+            fetch_offsets(it + 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // pad behind the span: the position-parallel passes read up to W + 5 bytes past a short last read, and what they
+            // find there must be a valid quality byte (see quality_cells)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const uint32_t o = ce - cs + shq + (uint32_t)(64 * i + lane);
+                if (64 * i + lane < W + 12 && o < (uint32_t)T::STG_BYTES) lds_st_u8(slot_b + o, (uint32_t)in_off);
+            }
+            FAQCS_STAMP(0)
 
             // ================= Q-A: one read per lane ===============================================================
             ReadOutcome oc;
@@ -377,6 +490,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 }
             }
 
+            FAQCS_STAMP(1)
             // ---- the window the reference trims: after the adapter pre-pass and --5end/--3end (trim.cpp:270-314) ----
             int wa = 0, wn = len;
             uint32_t flags = 0, filt = 0;
@@ -395,59 +509,77 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 
             // ---- BWA_plus (trim.cpp:714-793), walked as the reference walks it ---------------------------------
             // Step s of a walk visits window position wn - 1 - s (3') or s (5').  at_least_scan == 0 after step `bud`: the walk
-            // covers min(5, n) positions and a reset at step s (area >= 0 before it, position still > n2 away from the far end)
-            // moves its end to s + 2 (n2 == 2 whenever a reset can fire).  key = area << 8 | 255 - s: the FIRST maximum wins.
+            // covers min(5, n) positions and a reset at step s (area >= 0 before it, s < rlim: the position is still more than
+            // n2 away from the far end) moves its end to s + 2 (n2 == 2 whenever a reset can fire).
+            // key = area << 8 | code, code falling with time: the FIRST maximum wins (walk_step above).
             const int a5 = wn < 5 ? wn : 5, nn2 = wn < 2 ? wn : 2, qoff = Q + in_off;
+            const int dc = uni(qoff * 256 - 1);
             int S3, fp3, S5 = 0, fp5 = 0;
             {
-                int bud = a5 - 1, area = 0, best = 255;
-                const int rlim = wn - 1 - nn2; // reset at step s <=> wn - 1 - s > n2
+                int rlim = wn - 1 - nn2; // a reset at step s needs wn - 1 - s > n2
                 const uint32_t endq = slot_b + rowq + (uint32_t)(wa + wn);
-                const uint32_t e4 = endq & ~3u, esh = endq & 3u;
-                uint32_t hi = lds_ld(e4);
+                const uint32_t esh = endq & 3u;
+                uint32_t e4 = endq & ~3u;
+                uint32_t hi = lds_ld(e4), cur = lds_ld(e4 - 4u);
+                // Fast forward over a run of identical dwords b,b,b,b with Q - q(b) > 0 at the 3' end (the '#' tail of an Illumina
+                // read): every position of such a run is visited, resets the scan and sets a new maximum, so m dwords of it leave
+                // area = 4 m (Q - q), the maximum at the run's last position and two more positions to visit.
+                int m = 0;
+                const uint32_t w0 = __builtin_amdgcn_alignbyte(hi, cur, esh);
+                const uint32_t pat = __builtin_amdgcn_perm(w0, w0, 0u);
+                const int dq0 = qoff - (int)(w0 & 0xffu);
+                {
+                    const int mcap = rlim >> 2; // steps 4 i .. 4 i + 3 all reset: 4 i + 3 < rlim
+                    bool run = dq0 > 0;
+                    uint32_t h = hi, c = cur;
 #pragma unroll 1
-                for (int s0 = 0; __any(s0 <= bud); s0 += 4) {
-                    const uint32_t lo = lds_ld(e4 - 4u - (uint32_t)s0);
-                    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, esh); // positions wend-4-s0 .. wend-1-s0
-                    hi = lo;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int s = s0 + j;
-                        if (s <= bud) {
-                            if (area >= 0 && s < rlim) bud = s + 2;
-                            area += qoff - (int)((w >> (8 * (3 - j))) & 0xffu);
-                            const int K = area * 256 + (255 - s);
-                            best = best > K ? best : K;
-                        }
+                    for (int i = 0; ; ++i) {
+                        const uint32_t nx = lds_ld(e4 - 8u - 4u * (uint32_t)i);
+                        const uint32_t w = __builtin_amdgcn_alignbyte(h, c, esh);
+                        run = run && w == pat && i < mcap;
+                        m += run ? 1 : 0;
+                        h = c; c = nx;
+                        if (!__any(run)) break;
                     }
+                }
+                int rb = a5 - 1, area = 0, best = 255, K = 255; // rb: steps still to go after the current one
+                if (__any(m > 0)) {
+                    const int A0 = 4 * m * dq0;
+                    area = A0;
+                    best = K = (A0 << 8) + 255; // (m == 0: 255)
+                    rb = m > 0 ? 1 : rb;
+                    rlim -= 4 * m;
+                    e4 -= 4u * (uint32_t)m;
+                    hi = lds_ld(e4); cur = lds_ld(e4 - 4u);
+                }
+#pragma unroll 1
+                for (int it = 0; __any(rb >= 0); it += 4) {
+                    const uint32_t nx = lds_ld(e4 - 8u - (uint32_t)it);
+                    const uint32_t w = __builtin_amdgcn_alignbyte(hi, cur, esh); // positions wend-4-it .. wend-1-it
+                    hi = cur; cur = nx;
+                    walk_step<true>(w, it, (it + 1) * qoff * 256 + 254 - it, dc, rb, rlim, area, K, best);
                 }
                 S3 = best >> 8;
-                fp3 = S3 > 0 ? (wn - 1 - (255 - (best & 255))) - 1 : wn - 1;
+                const int code = best & 255;
+                const int sb = code == 255 ? 4 * m - 1 : 4 * m + 254 - code;
+                fp3 = S3 > 0 ? (wn - 1 - sb) - 1 : wn - 1;
             }
+            FAQCS_STAMP(2)
             if (!(EXT && P.protect5)) { // --5trim_off (trim.cpp:752)
-                int bud = a5 - 1, area = 0, best = 255;
-                const int rlim = fp3 - nn2; // reset at step s <=> s < final_pos_3 - n2
+                int rb = a5 - 1, area = 0, best = 255, K = 255;
+                const int rlim = fp3 - nn2; // a reset at step s needs s < final_pos_3 - n2
                 const uint32_t begq = slot_b + rowq + (uint32_t)wa;
                 const uint32_t b4 = begq & ~3u, bsh = begq & 3u;
-                uint32_t lo = lds_ld(b4);
+                uint32_t lo = lds_ld(b4), cur = lds_ld(b4 + 4u);
 #pragma unroll 1
-                for (int s0 = 0; __any(s0 <= bud); s0 += 4) {
-                    const uint32_t hi = lds_ld(b4 + 4u + (uint32_t)s0);
-                    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, bsh);
-                    lo = hi;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int s = s0 + j;
-                        if (s <= bud) {
-                            if (area >= 0 && s < rlim) bud = s + 2;
-                            area += qoff - (int)((w >> (8 * j)) & 0xffu);
-                            const int K = area * 256 + (255 - s);
-                            best = best > K ? best : K;
-                        }
-                    }
+                for (int it = 0; __any(rb >= 0); it += 4) {
+                    const uint32_t nx = lds_ld(b4 + 8u + (uint32_t)it);
+                    const uint32_t w = __builtin_amdgcn_alignbyte(cur, lo, bsh);
+                    lo = cur; cur = nx;
+                    walk_step<false>(w, it, (it + 1) * qoff * 256 + 254 - it, dc, rb, rlim, area, K, best);
                 }
                 S5 = best >> 8;
-                fp5 = S5 > 0 ? (255 - (best & 255)) + 1 : 0;
+                fp5 = S5 > 0 ? (254 - (best & 255)) + 1 : 0;
             }
 
             // ---- length filters and the kept window (trim.cpp:317-360) -------------------------------------
@@ -490,22 +622,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // rejects never reaches this test, so the order is restored there (avgq_fail is only applied to a read that passes) ----
             const bool avgq_fail = EXT && P.avgq_on && V_post < ((const int32_t *)(smem + Cfg::O_TAVGQ))[n];
 
+            FAQCS_STAMP(3)
             // ================= Q-B: 8 lanes per read, position x quality ===========================================
             // (post cells are added for every read that is still valid; S-A's vetoes are taken back below)
             const uint32_t qi0 = rowq | ((uint32_t)len << 16);
             const uint32_t qi1 = (uint32_t)a | ((uint32_t)n << 8) | (ret ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u);
-#pragma unroll 1
-            for (int t = 0; t < LPR; ++t) {
-                if (base + (uint32_t)t >= n_reads) break; // wave-uniform: no row has a read left
-                quality_cells((uint32_t)__shfl((int)qi0, rowb + t), (uint32_t)__shfl((int)qi1, rowb + t), std::false_type{});
-            }
+#define FAQCS_QCELLS(X, A, B) quality_cells(X, A, B, std::false_type{})
+            FAQCS_B_LOOP(qi0, qi1, FAQCS_QCELLS)
+#undef FAQCS_QCELLS
 
+            FAQCS_STAMP(4)
             // ---- the span of the BASE arena -> the same slot ---------------------------------------------------------
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every LDS read of the slot has returned
             const uint32_t shs = (uint32_t)((size_t)(seq + cs) & 15u);
             dma_span<NI>(seq + cs - shs, ce - cs + shs, slot, lane);
             const uint32_t rows = v_off - cs + shs;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FAQCS_STAMP(5)
 
             // ================= S-A: one read per lane, the bases =====================================================
             const bool ret_q = ret;
@@ -514,7 +647,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 // ---- classes: A,T,C,G counts (8-bit fields), the counts in front of the kept window's two ends, upper-case N bits ----
                 uint32_t cnt4 = 0, nub[NWORD], sA = 0, sE = 0;
                 const int ka = a >> 2, ke = (a + n) >> 2;
-                const int nfull = len >> 2, rem = len & 3;
+                const int nfull = len >> 2;
                 const int kmax = uni((int)wave_max_u32((uint32_t)((len + 3) >> 2)));
                 const uint32_t sa = slot_b + rows, sa4 = sa & ~3u, ssh = sa & 3u;
                 uint32_t prev = lds_ld(sa4);
@@ -614,47 +747,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     const ExactB xb = exact_bases(seq, v_off, len, a, n, abn_seq || dinuc, dinuc, dthr);
                     if (abn_seq) { pN = xb.npre; cN = xb.npost; }
                     if (dinuc) lc_trip = lc_trip || xb.trip;
-                    // bytes >= 128 are no letters: they must not look like "outside the window" to S-B
+                    // S-B looks a base outside the kept window up at (byte ^ 1): a letter that is no base must not pass for one
                     if (__any(abn_seq)) {
 #pragma unroll 1
-                        for (int p = 0; __any(abn_seq && p < len); ++p)
-                            if (abn_seq && p < len && lds_ld_u8(slot_b + rows + (uint32_t)p) >= 128u) lds_st_u8(slot_b + rows + (uint32_t)p, 0u);
+                        for (int p = 0; __any(abn_seq && p < len); ++p) {
+                            if (abn_seq && p < len) {
+                                const uint32_t b = lds_ld_u8(slot_b + rows + (uint32_t)p);
+                                const LdsPair2 e = *(lds_u2c_ptr)(size_t)(b * 8u + (uint32_t)(T::O_T2 * 4));
+                                if ((e.x | e.y) == 0u) lds_st_u8(slot_b + rows + (uint32_t)p, 0u);
+                            }
+                        }
                     }
                 }
                 if (ret && lc_trip) { ret = false; filt = FAQCS_FILT_LOW_COMPLEXITY; }
             }
 
+            FAQCS_STAMP(6)
             // ================= S-B: 8 lanes per read, position x base ==============================================
             const uint32_t si0 = rows | ((uint32_t)len << 16);
             const uint32_t si1 = (uint32_t)a | ((uint32_t)n << 8) | (ret ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u);
-#pragma unroll 1
-            for (int t = 0; t < LPR; ++t) {
-                if (base + (uint32_t)t >= n_reads) break;
-                const uint32_t i0 = (uint32_t)__shfl((int)si0, rowb + t), i1 = (uint32_t)__shfl((int)si1, rowb + t);
-                const int rlen = (int)(i0 >> 16), ra = (int)(i1 & 0xffu), rn = (int)((i1 >> 8) & 0xffu);
-                const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
-                const int vb = counted ? med3i(rlen - pbase, 0, C) : 0;
-                const int lo = post ? med3i(ra - pbase, 0, C) : 0, hi = post ? med3i(ra + rn - pbase, 0, C) : 0;
-                uint32_t ws[D], rs[D + 1];
-                const uint32_t ba = slot_b + (i0 & 0xffffu) + (uint32_t)pbase;
-#pragma unroll
-                for (int k = 0; k <= D; ++k) rs[k] = lds_ld((ba & ~3u) + 4u * (uint32_t)k);
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const uint32_t w = __builtin_amdgcn_alignbyte(rs[k + 1], rs[k], ba & 3u) & t_bm[BMW * vb + k];
-                    const uint32_t outm = ~(t_bm[BMW * hi + k] ^ t_bm[BMW * lo + k]);
-                    ws[k] = (w & 0x7f7f7f7fu) | (outm & 0x80808080u); // bit 7 = outside the kept window
-                }
-#pragma unroll
-                for (int j = 0; j < C; ++j) {
-                    const uint32_t ad = ((j & 3) == 0 ? byte_x8<0>(ws[j >> 2], three) : (j & 3) == 1 ? byte_x8<1>(ws[j >> 2], three)
-                                         : (j & 3) == 2 ? byte_x8<2>(ws[j >> 2], three) : byte_x8<3>(ws[j >> 2], three)) + (uint32_t)(T::O_T3 * 4);
-                    const LdsPair2 e = *(lds_u2c_ptr)(size_t)ad;
-                    bpre[j] += e.x;
-                    bpost[j] += e.y;
-                }
-            }
+            FAQCS_B_LOOP(si0, si1, base_cells)
 
+            FAQCS_STAMP(7)
             // ---- a read S-A rejected after Q-B counted its post cells: take them back (needs the qualities again) ----
             const bool veto = ret_q && !ret;
             if (__any(veto)) {
@@ -679,7 +793,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 for (int t = 0; t < LPR; ++t) {
                     const uint32_t i1 = (uint32_t)__shfl((int)ui1, rowb + t);
                     if (!__any(((i1 >> 16) & 1u) != 0u)) continue;
-                    quality_cells((uint32_t)__shfl((int)qi0, rowb + t), i1, std::true_type{});
+                    const uint32_t i0 = (uint32_t)__shfl((int)qi0, rowb + t);
+                    RawB x;
+                    load_b(i0, i1, x);
+                    quality_cells(x, i0, i1, std::true_type{});
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -697,11 +814,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                                 smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, EXT && P.avgq_on != 0, 0u);
         }
 
+        FAQCS_STAMP(8)
         const bool block_flush = ((it + 1) % FLUSH_EVERY) == 0 || it + 1 == n_iter;
         if (((it + 1) % REG_FLUSH_EVERY) == 0 || block_flush) spill_base_regs();
         if (block_flush) flush_block<C, LPR, NW, false>(smem, counters, P.R, tid);
     }
     if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
+#ifdef FAQCS_LDS_STAMPS
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + i, st_acc[i]);
+    }
+#endif
+#undef FAQCS_STAMP
 }
 
 template <int C, bool WINDOWED, bool EXT>
@@ -744,7 +869,10 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
 #define FAQCS_LDS_CASE(C)                                                                                                 \
     return ext ? (windowed ? launch_trim_lds<C, true, true>(FAQCS_LDS_ARGS) : launch_trim_lds<C, false, true>(FAQCS_LDS_ARGS)) \
                : (windowed ? launch_trim_lds<C, true, false>(FAQCS_LDS_ARGS) : launch_trim_lds<C, false, false>(FAQCS_LDS_ARGS))
-    if (max_len > 104 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x150
+    if (max_len > 76 && max_len <= 104) FAQCS_LDS_CASE(13);  // 2x100
+    if (max_len > 104 && max_len <= 128) FAQCS_LDS_CASE(16); // 2x125
+    if (max_len > 128 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x150
+    if (max_len > 152 && max_len <= 160) FAQCS_LDS_CASE(20);
 #undef FAQCS_LDS_CASE
 #undef FAQCS_LDS_ARGS
     return hipErrorNotSupported;

@@ -265,6 +265,8 @@ int  faqcs_synth_fill(int device_id, uint8_t *d_seq, uint8_t *d_qual, uint32_t *
  * (either strand, 0.5 % substitutions, the same quality recipe), so distinct k-mers grow as on real data. */
 int  faqcs_synth_fill_genome(int device_id, uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads,
                              uint32_t L, uint64_t seed, uint64_t first_read, uint64_t genome_len);
+/* diagnostic builds only: section clocks accumulated by the trim kernel (16 words; read and cleared) */
+int  faqcs_debug_words(faqcs_ctx *ctx, uint64_t *out, uint32_t n);
 /* average duration (ms) of the dominant kernel over the launches since the last call, measured with
  * HIP events recorded on the compute stream around each launch */
 int  faqcs_kernel_time_ms(faqcs_ctx *ctx, double *avg_ms, uint64_t *n_launches);
