@@ -240,8 +240,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    avg_ms, nl = C.c_double(), C.c_uint64()
-    lib.faqcs_kernel_time_ms(eng.ctx, C.byref(avg_ms), C.byref(nl))  # reset the kernel timer
+    kt = capi.KernelTimes()
+    lib.faqcs_kernel_report(eng.ctx, C.byref(kt))  # reset the kernel timers
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -252,7 +252,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    _check(lib, lib.faqcs_kernel_time_ms(eng.ctx, C.byref(avg_ms), C.byref(nl)))
+    _check(lib, lib.faqcs_kernel_report(eng.ctx, C.byref(kt)))
     # outside the timed region: the (all-reduced) counter block of the last step must account for every read of the job
     blk = eng.counters()
     lay = capi.python_layout(eng.holder.max_read_length, eng.holder.n_adapters)
@@ -265,16 +265,24 @@ def main():
         value = total_reads / dt / 1e6
         reads_per_launch = n_reads / max(1, len(batches))
         alg_bytes = reads_per_launch * (2 * L + 4 + 8)
-        achieved = alg_bytes / (avg_ms.value * 1e-3) / 1e9 if avg_ms.value > 0 else 0.0
-        # the default option set on reads of up to 160 bases runs the two-phase kernel (faqcs_trim_kernel.hip: faqcs_launch_trim)
-        trim_kernel = "trim_tpr" if L <= 160 and os.environ.get("FAQCS_TRIM_TPR", "1") != "0" else "trim_filter_accumulate"
-        traffic = None
+        trim_kernel = (kt.trim_kernel or b"").decode() or "trim"
+        # the roofline entry describes the DOMINANT kernel of the configuration: adapter_overlap for --config adapter
+        # (its algorithmic bytes: the bases once + 6 bytes of result per read), the trim kernel otherwise
+        dominant, dom_ms = trim_kernel, kt.trim_ms
+        if a.config == "adapter" and kt.adapter_ms > kt.trim_ms:
+            dominant, dom_ms = "adapter_overlap", kt.adapter_ms
+            alg_bytes = reads_per_launch * (L + 4 + 6)
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config)
-        if os.path.exists(tf) and L == 150:  # (measured on the 2x150 shape only)
+        if os.path.exists(tf) and L == 150 and dominant != "adapter_overlap":  # (measured on the 2x150 shape only)
             try:
-                # measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied);
-                # stored per read, scaled to this run's launch size
-                traffic = int(json.load(open(tf))["hbm_bytes_per_read"] * reads_per_launch)
+                # NOT measured in this run: rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE separately, gfx950 correction applied)
+                # of the same kernel, stored per read by profiles/pmc_traffic.py and scaled to this run's launch size
+                tj = json.load(open(tf))
+                if tj.get("kernel", trim_kernel) == trim_kernel:
+                    traffic = int(tj["hbm_bytes_per_read"] * reads_per_launch)
+                    traffic_src = "profiles/traffic_%s.json (rocprofv3 --pmc, %s)" % (a.config, tj.get("tag", "stored per read"))
             except Exception:
                 traffic = None
         out = {
@@ -283,9 +291,9 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synthetic %.0fM-pair 2x%dbp Q33 reads resident in HBM per GPU, BWA_plus -q 5 --min_L 50%s, "
-                                   "1 step = 1 pass (%s%s + counter all-reduce)"
-                                   % (n_reads / 2e6, L, trim_kernel, {"adapter": " --adapter --polyA (5 percent read-through)", "kmer": " --kmer_rarefaction, genome-sampled reads"}.get(a.config, ""),
-                                      {"adapter": " after adapter_overlap", "kmer": " + kmer_count"}.get(a.config, "")),
+                                   "1 step = 1 pass (%s%s%s + counter all-reduce)"
+                                   % (n_reads / 2e6, L, {"adapter": " --adapter --polyA (5 percent read-through)", "kmer": " --kmer_rarefaction, genome-sampled reads"}.get(a.config, ""),
+                                      {"adapter": "adapter_overlap, then ", "kmer": ""}.get(a.config, ""), trim_kernel, {"kmer": " + kmer_count"}.get(a.config, "")),
                        "pairs_per_gpu": n_reads // 2, "read_len": L, "launches_per_step": len(batches) * (2 if a.config == "adapter" else 1),
                        "M_pairs_per_s": round(value / 2, 3)},
         }
@@ -295,10 +303,18 @@ def main():
                            "note": "canonical 31-mers of the kept reads into the device hash table (reset every step); bound by the L2 atomic rate"}
         out.update({
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": trim_kernel,
-                         "kernel_ms": round(avg_ms.value, 4), "launches": int(nl.value),
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "kernel": dominant,
+                         "kernel_ms": round(dom_ms, 4), "launches": int(kt.n_launches),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "kernels_ms": {trim_kernel: round(kt.trim_ms, 4), "adapter_overlap": round(kt.adapter_ms, 4)}},
         })
+        if dominant == "adapter_overlap":
+            # adapter_overlap is bound by integer VALU issue, not by HBM: the work is L x sum|adapter| cell updates per
+            # read (62 850 for the 9 built-ins + polyA at L = 150); the instruction count per read comes from the PMC profile
+            cells = 62850.0 * L / 150.0
+            out["roofline"]["valu"] = {"cell_updates_per_s": round(reads_per_launch * cells / (dom_ms * 1e-3) / 1e12, 3), "unit": "T cell updates/s",
+                                       "valu_peak_G_wave_instr_per_s": 614.0,
+                                       "note": "bound by VALU issue: see profiles/ for SQ_INSTS_VALU per read of adapter_overlap"}
         if world == 1 and not a.no_cpu_baseline:
             ns = min(400000, batches[0][6])
             hs = batches[0][0][: ns * L].cpu().numpy()

@@ -62,6 +62,10 @@ class Layout(C.Structure):
     ]
 
 
+class KernelTimes(C.Structure):
+    _fields_ = [("trim_ms", C.c_double), ("adapter_ms", C.c_double), ("n_launches", C.c_uint64), ("trim_kernel", C.c_char_p)]
+
+
 RESULT_DTYPE = np.dtype([("start", "<u2"), ("len", "<u2"), ("flags", "<u2"), ("adapter", "<u2")])
 RAREFACTION_DTYPE = np.dtype([("num_seq", "<u8"), ("distinct_kmer", "<u8"), ("total_kmer", "<u8")])
 
@@ -156,12 +160,14 @@ def load_library():
         "faqcs_kmer_partition": (i32, [vp, u32, u32, u32]),
         "faqcs_kmer_set_epochs": (i32, [vp, vp, u32]),
         "faqcs_kmer_outbox": (i32, [vp, C.POINTER(vp), vp]),
+        "faqcs_kmer_outbox_host": (i32, [vp, vp, u64, C.POINTER(u64)]),
         "faqcs_kmer_insert_device": (i32, [vp, vp, u64]),
         "faqcs_kmer_epoch_counts": (i32, [vp, vp, vp, u32]),
         "faqcs_synth_fill": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, C.c_float]),
         "faqcs_synth_fill_genome": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, u64]),
         "faqcs_kernel_time_ms": (i32, [vp, C.POINTER(C.c_double), C.POINTER(u64)]),
         "faqcs_debug_words": (i32, [vp, vp, u32]),
+        "faqcs_kernel_report": (i32, [vp, C.POINTER(KernelTimes)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError == a symbol the header declares is missing

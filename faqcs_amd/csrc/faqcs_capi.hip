@@ -52,6 +52,7 @@ hipError_t faqcs_launch_kmer_insert_items(const KmerTable &T, const void *items,
 hipError_t faqcs_launch_kmer_table_init(const KmerTable &T, int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_first_epoch_histogram(const KmerTable &T, unsigned long long *hist, uint32_t n_epochs, int n_cu,
                                                    hipStream_t st);
+const char *faqcs_last_trim_kernel();
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
@@ -97,7 +98,7 @@ template <class T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct Timing { hipEvent_t a, b; };
+struct Timing { hipEvent_t a, b, p; bool adapter; }; // p .. a: the adapter pre-pass (when there is one), a .. b: the trim kernel
 
 } // namespace
 
@@ -155,8 +156,9 @@ struct faqcs_ctx {
     // kernel timing
     std::vector<Timing> timings;
     size_t timing_used = 0;
-    double kernel_ms = 0.0;
+    double kernel_ms = 0.0, adapter_ms = 0.0;
     uint64_t kernel_launches = 0;
+    const char *trim_kernel = "";
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -408,7 +410,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->compute) (void)hipStreamSynchronize(c->compute);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
-    for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.p); }
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
                     c->kt.slots, c->kt.stats, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
     for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -443,7 +445,16 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
 {
     const faqcs_params &p = c->prm;
     uint32_t *d_sl = nullptr; uint16_t *d_hit = nullptr;
+    Timing *tm = nullptr;
+    if (n) {
+        if (c->timing_used == c->timings.size()) {
+            Timing t; HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b)); HIPCHK(hipEventCreate(&t.p)); t.adapter = false; c->timings.push_back(t);
+        }
+        tm = &c->timings[c->timing_used++];
+        tm->adapter = p.n_adapters != 0;
+    }
     if (n && p.n_adapters) {
+        HIPCHK(hipEventRecord(tm->p, c->compute));
         HIPCHK(c->s_sl.reserve(n)); HIPCHK(c->s_hit.reserve(n)); HIPCHK(c->s_seg.reserve(n_seg + 1));
         d_sl = c->s_sl.p; d_hit = c->s_hit.p;
         HIPCHK(hipMemcpyAsync(c->s_seg.p, seg, (n_seg + 1) * 4, hipMemcpyHostToDevice, c->compute));
@@ -452,10 +463,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
                                     c->d_counters + c->lay.adapter_stats, c->d_err, c->dp.dbg, c->n_cu, c->compute));
     }
     if (n) {
-        if (c->timing_used == c->timings.size()) {
-            Timing t; HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b)); c->timings.push_back(t);
-        }
-        Timing &t = c->timings[c->timing_used++];
+        Timing &t = *tm;
         HIPCHK(hipEventRecord(t.a, c->compute));
         const bool wide = max_len > 256; // the long-read kernels write two-word composition records
         faqcs_ctx::RecSet &rs = c->rec[c->n_enqueued++ & 1];
@@ -466,6 +474,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, rs.pre.p, rs.post.p,
                                  c->d_counters, c->d_err, c->n_cu, c->compute));
         HIPCHK(hipEventRecord(t.b, c->compute));
+        c->trim_kernel = faqcs_last_trim_kernel();
         if (!(c->dp.dbg & 1u)) {
             HIPCHK(hipEventRecord(rs.trimmed, c->compute));
             HIPCHK(hipStreamWaitEvent(c->aux, rs.trimmed, 0));
@@ -679,6 +688,7 @@ extern "C" int faqcs_sync(faqcs_ctx *c)
     for (size_t i = 0; i < c->timing_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->timings[i].a, c->timings[i].b) == hipSuccess) { c->kernel_ms += ms; ++c->kernel_launches; }
+        if (c->timings[i].adapter && hipEventElapsedTime(&ms, c->timings[i].p, c->timings[i].a) == hipSuccess) c->adapter_ms += ms;
     }
     c->timing_used = 0;
     if (int rc = resolve_points(c)) return rc;
@@ -848,6 +858,26 @@ extern "C" int faqcs_kmer_outbox(faqcs_ctx *c, void **d_items, uint64_t *counts)
     return 0;
 }
 
+// Host copy of the keys of the last submission's outbox (all destinations, in bucket order): what a single-process caller
+// that keeps its own MAP<Word, size_t> (the reference's trim() seam, integration/trim_shim.cpp) merges per call.
+extern "C" int faqcs_kmer_outbox_host(faqcs_ctx *c, uint64_t *keys, uint64_t cap, uint64_t *n_keys)
+{
+    if (!c || !n_keys) return fail(FAQCS_E_INVAL, "null argument");
+    if (!c->partitioned) return fail(FAQCS_E_INVAL, "faqcs_kmer_outbox_host: call faqcs_kmer_partition first");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    std::vector<unsigned long long> h(c->part_world);
+    HIPCHK(hipMemcpy(h.data(), c->d_ob, (size_t)c->part_world * 8, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint32_t d = 0; d < c->part_world; ++d) total += h[d];
+    *n_keys = total;
+    if (!keys || cap < total || total == 0) return 0;
+    std::vector<unsigned long long> items((size_t)total * 2);
+    HIPCHK(hipMemcpy(items.data(), c->ob_items.p, (size_t)total * 16, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < total; ++i) keys[i] = items[2 * i];
+    return 0;
+}
+
 extern "C" int faqcs_kmer_insert_device(faqcs_ctx *c, const void *d_items, uint64_t n_items)
 {
     if (!c || (!d_items && n_items)) return fail(FAQCS_E_INVAL, "null argument");
@@ -926,6 +956,20 @@ extern "C" int faqcs_kernel_time_ms(faqcs_ctx *c, double *avg_ms, uint64_t *n_la
     if (int rc = faqcs_sync(c)) return rc;
     *n_launches = c->kernel_launches;
     *avg_ms = c->kernel_launches ? c->kernel_ms / (double)c->kernel_launches : 0.0;
-    c->kernel_ms = 0.0; c->kernel_launches = 0;
+    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kernel_launches = 0;
+    return 0;
+}
+
+// Per-kernel averages since the last call of this or of faqcs_kernel_time_ms(): the trim kernel (with the name of the variant
+// the last submission ran) and the adapter pre-pass (0 without adapters).  Resets the sums like faqcs_kernel_time_ms().
+extern "C" int faqcs_kernel_report(faqcs_ctx *c, faqcs_kernel_times *out)
+{
+    if (!c || !out) return fail(FAQCS_E_INVAL, "null argument");
+    if (int rc = faqcs_sync(c)) return rc;
+    out->n_launches = c->kernel_launches;
+    out->trim_ms = c->kernel_launches ? c->kernel_ms / (double)c->kernel_launches : 0.0;
+    out->adapter_ms = c->kernel_launches ? c->adapter_ms / (double)c->kernel_launches : 0.0;
+    out->trim_kernel = c->trim_kernel;
+    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kernel_launches = 0;
     return 0;
 }

@@ -43,6 +43,7 @@ struct Fatal : std::runtime_error { using std::runtime_error::runtime_error; };
 // options (options.cpp:72-774)
 // ---------------------------------------------------------------------------------------------------------
 struct Opt {
+    std::vector<int> devices; // --gpus / --gpu_ids (empty: the current device)
     bool print_usage = false, protect_5 = false, replace_N = false, kmer_rarefaction = false, discard_output = false;
     bool qc_only = false, trim_only = false, filter_adapter = false, filter_phiX = false, debug = false, version = false;
     int mode = FAQCS_MODE_BWA_PLUS;
@@ -134,7 +135,9 @@ const LongOpt LONG_OPTS[] = {
     {"min_L", true}, {"avg_q", true}, {"lc", true}, {"phiX", false}, {"ascii", true}, {"out_ascii", true}, {"prefix", true},
     {"stats", true}, {"split_size", true}, {"qc_only", false}, {"kmer_rarefaction", false}, {"subset", true}, {"discard", false},
     {"substitute", false}, {"trim_only", false}, {"5trim_off", false}, {"debug", false}, {"version", false}, {"R1", true},
-    {"R2", true}, {"Ru", false}, {"Rd", false}, {"QRpdf", false}, {"replace_to_N_q", true}};
+    {"R2", true}, {"Ru", false}, {"Rd", false}, {"QRpdf", false}, {"replace_to_N_q", true},
+    // extensions of this command line (not in the reference): --gpus N = the first N devices, --gpu_ids a,b,... = these devices
+    {"gpus", true}, {"gpu_ids", true}};
 
 Opt parse_args(int argc, char **argv)
 {
@@ -198,6 +201,8 @@ Opt parse_args(int argc, char **argv)
         else if (name == "R1" || name == "1") o.in1 = val;
         else if (name == "R2" || name == "2") o.in2 = val;
         else if (name == "replace_to_N_q") o.replace_to_N_q = strtou(val);
+        else if (name == "gpus") { o.devices.clear(); for (unsigned k = 0; k < strtou(val); ++k) o.devices.push_back((int)k); }
+        else if (name == "gpu_ids") { o.devices.clear(); size_t b = 0; while (b <= val.size()) { const size_t e = val.find(',', b); o.devices.push_back(atoi(val.substr(b, e == std::string::npos ? e : e - b).c_str())); if (e == std::string::npos) break; b = e + 1; } }
         else if (name == "u") o.inu = val;
         else if (name == "d") o.output_dir = val;
         else if (name == "m") o.kmer = strtou(val);
@@ -260,6 +265,7 @@ struct RecBuf {
     std::string defs;
     std::vector<uint32_t> def_off; // n + 1
     uint64_t ticket = 0;
+    int dev = 0;                 // index of the context (device) the buffer was submitted to
 
     void init(size_t bytes)
     {
@@ -471,7 +477,8 @@ struct OutFile {
 
 struct Run {
     Opt &opt;
-    faqcs_ctx *ctx = nullptr;
+    faqcs_ctx *ctx = nullptr;            // == ctxs[0]: owns the k-mer table
+    std::vector<faqcs_ctx *> ctxs;       // one per device: 32 768-read buffers are dealt to them round robin
     faqcs_params prm;
     std::vector<const char *> adapter_ptr;
     uint32_t R = FAQCS_MAX_READ_LENGTH;
@@ -514,14 +521,21 @@ struct Run {
             for (auto &a : opt.adapter) adapter_ptr.push_back(a.second.c_str());
             prm.n_adapters = (uint32_t)opt.adapter.size(); prm.adapter_seq = adapter_ptr.data();
         }
-        check(faqcs_create(&prm, -1, &ctx));
+        std::vector<int> devs = opt.devices;
+        if (devs.empty()) devs.push_back(-1);
+        if (devs.size() > 1 && opt.kmer_rarefaction) { // the rarefaction curve depends on the order of the trim() calls: one table, one device
+            fprintf(stderr, "faqcs_mi: --kmer_rarefaction runs on one device (the first of the list)\n");
+            devs.resize(1);
+        }
+        for (int d : devs) { faqcs_ctx *c = nullptr; check(faqcs_create(&prm, d, &c)); ctxs.push_back(c); }
+        ctx = ctxs[0];
     }
     void nextseq_check(const RecBuf *b) // trim.cpp:619-626, FaQCs.cpp:272-277,404-414
     {
         if (quality < 20 && b->n > 0 && b->defs.compare(0, 3, "@NS") == 0) {
             fprintf(stderr, "The input looks like NextSeq data and the quality level (-q) is adjusted to 20 for trimming.\n");
             quality = 20;
-            if (ctx) check(faqcs_set_quality(ctx, quality)); else prm.quality = quality;
+            if (ctx) { for (faqcs_ctx *c : ctxs) check(faqcs_set_quality(c, quality)); } else prm.quality = quality;
         }
     }
     int detect(const RecBuf *b)
@@ -530,12 +544,13 @@ struct Run {
         if (!r) throw Fatal("trim.cpp:auto_detect_quality_offset: Unknown quality format!");
         return r;
     }
-    void submit(RecBuf *b)
+    void submit(RecBuf *b, uint64_t buffer_no)
     {
+        b->dev = (int)(buffer_no % ctxs.size());
         const uint32_t seg[2] = {0, b->n};
         faqcs_batch bt; memset(&bt, 0, sizeof(bt));
         bt.seq = b->seq; bt.qual = b->qual; bt.offset = b->off; bt.n_reads = b->n; bt.n_segments = 1; bt.segment_start = seg;
-        check(faqcs_submit_async(ctx, &bt, b->res, &b->ticket));
+        check(faqcs_submit_async(ctxs[b->dev], &bt, b->res, &b->ticket));
     }
     // writes one surviving record with the reference's byte edits (trim.cpp:390-403,516-525,1191-1216; fastq.cpp:127-138)
     void write_read(OutFile &f, const RecBuf *b, uint32_t i, std::string &s, std::string &q)
@@ -581,6 +596,7 @@ void process_paired(Run &r)
     // bytes go -- are each formatted and written by their own thread.  Every file still receives its records in read order.
     Queue<Work> wq, q1, q2;
     std::string werr;
+    std::atomic<bool> failed{false};
     auto release = [&](Work &w) { if (w.left->fetch_sub(1) == 1) { s1.free_q.push(w.b1); s2.free_q.push(w.b2); } };
     auto mate_writer = [&](Queue<Work> &q, OutFile &f, bool second) {
         std::string s, t;
@@ -604,8 +620,8 @@ void process_paired(Run &r)
             for (;;) {
                 Work w = wq.pop();
                 if (!w.b1) break;
-                Run::check(faqcs_wait(r.ctx, w.b1->ticket));
-                Run::check(faqcs_wait(r.ctx, w.b2->ticket));
+                Run::check(faqcs_wait(r.ctxs[w.b1->dev], w.b1->ticket));
+                Run::check(faqcs_wait(r.ctxs[w.b2->dev], w.b2->ticket));
                 Run::check_read_errors(w.b1); Run::check_read_errors(w.b2); // trim() throws before anything of the buffer is written
                 w.left = std::make_shared<std::atomic<int>>(3);
                 q1.push(w); q2.push(w);
@@ -621,13 +637,26 @@ void process_paired(Run &r)
                 release(w);
                 if (last) break;
             }
-        } catch (std::exception &e) { werr = e.what(); }
+        } catch (std::exception &e) {
+            // The producer must learn of it (it stops submitting) and must not starve meanwhile: keep handing the buffers
+            // of the pairs already queued back to the readers until its sentinel arrives.
+            werr = e.what();
+            failed = true;
+            for (;;) {
+                Work w = wq.pop();
+                if (!w.b1) break;
+                s1.free_q.push(w.b1); s2.free_q.push(w.b2);
+                if (w.last) break;
+            }
+        }
         q1.push(Work()); q2.push(Work()); // (a mate writer that already saw its last buffer has left; the sentinel is then unused)
     });
     bool check_for_next_seq = true;
     std::string merr;
+    uint64_t pair_no = 0;
     try {
         for (;;) {
+            if (failed) { wq.push(Work()); break; } // the gate thread met an error of the device (reported below)
             RecBuf *b1 = s1.pop(), *b2 = s2.pop();
             const uint32_t n = std::min(b1->n, b2->n);
             for (uint32_t i = 0; i < n; ++i) { // FaQCs.cpp:383-389
@@ -653,7 +682,8 @@ void process_paired(Run &r)
             }
             if (last || check_for_next_seq) { r.nextseq_check(b1); check_for_next_seq = false; } // Q16: also on the last buffer
             r.ensure_ctx();
-            r.submit(b1); r.submit(b2);
+            r.submit(b1, pair_no); r.submit(b2, pair_no);
+            ++pair_no;
             Work w; w.b1 = b1; w.b2 = b2; w.last = last;
             wq.push(w);
             if (last) break;
@@ -662,7 +692,7 @@ void process_paired(Run &r)
     writer.join(); writer1.join(); writer2.join();
     if (!merr.empty() || !werr.empty()) { // unblock the readers, then report like the reference's catch in main()
         f1.close(); f2.close(); fu.close(); fd.close();
-        fprintf(stderr, "Caught the error %s\n", (!merr.empty() ? merr : werr).c_str());
+        fprintf(stderr, "Caught the error %s\n", (!werr.empty() ? werr : merr).c_str());
         _exit(EXIT_FAILURE); // reader / parser threads may be blocked on their queues: leave like the reference's catch in main()
     }
     s1.stop(); s2.stop();
@@ -680,13 +710,14 @@ void process_unpaired(Run &r)
     if (!opt.qc_only) { fo.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); } // "wT": truncates process_paired's singletons (Q17)
     Queue<Work> wq;
     std::string werr;
+    std::atomic<bool> failed{false};
     std::thread writer([&] {
         std::string sq, qq;
         try {
             for (;;) {
                 Work w = wq.pop();
                 if (!w.b1) break;
-                Run::check(faqcs_wait(r.ctx, w.b1->ticket));
+                Run::check(faqcs_wait(r.ctxs[w.b1->dev], w.b1->ticket));
                 Run::check_read_errors(w.b1);
                 if (!opt.qc_only)
                     for (uint32_t i = 0; i < w.b1->n; ++i) {
@@ -696,19 +727,30 @@ void process_unpaired(Run &r)
                 s.free_q.push(w.b1);
                 if (w.last) break;
             }
-        } catch (std::exception &e) { werr = e.what(); }
+        } catch (std::exception &e) {
+            werr = e.what();
+            failed = true;
+            for (;;) { // keep the reader supplied with buffers until the producer has seen the failure
+                Work w = wq.pop();
+                if (!w.b1) break;
+                s.free_q.push(w.b1);
+                if (w.last) break;
+            }
+        }
     });
     bool check_for_next_seq = true;
     std::string merr;
+    uint64_t buf_no = 0;
     try {
         for (;;) {
+            if (failed) { wq.push(Work()); break; }
             RecBuf *b = s.pop();
             if (!b->error.empty()) throw Fatal(b->error);
             const bool last = b->eof;
             if (r.in_off == AUTO_OFFSET) r.in_off = r.detect(b);
             if (last || check_for_next_seq) { r.nextseq_check(b); check_for_next_seq = false; }
             r.ensure_ctx();
-            r.submit(b);
+            r.submit(b, buf_no++);
             Work w; w.b1 = b; w.last = last;
             wq.push(w);
             if (last) break;
@@ -717,7 +759,7 @@ void process_unpaired(Run &r)
     writer.join();
     if (!merr.empty() || !werr.empty()) {
         fo.close(); fd.close();
-        fprintf(stderr, "Caught the error %s\n", (!merr.empty() ? merr : werr).c_str());
+        fprintf(stderr, "Caught the error %s\n", (!werr.empty() ? werr : merr).c_str());
         _exit(EXIT_FAILURE);
     }
     s.stop();
@@ -904,8 +946,12 @@ int main(int argc, char **argv)
         r.ensure_ctx();
         faqcs_layout L;
         faqcs_counters_layout(r.R, r.prm.n_adapters, &L);
-        std::vector<uint64_t> c(L.total);
+        std::vector<uint64_t> c(L.total), part(L.total);
         Run::check(faqcs_finish(r.ctx, c.data(), c.size()));
+        for (size_t k = 1; k < r.ctxs.size(); ++k) { // every accumulator is a sum of per-read integers (trim.cpp:120-154): add the devices' blocks
+            Run::check(faqcs_finish(r.ctxs[k], part.data(), part.size()));
+            for (size_t i = 0; i < c.size(); ++i) c[i] += part[i];
+        }
         uint64_t fs[FAQCS_NUM_STAT];
         for (int k = 0; k < FAQCS_NUM_STAT; ++k) fs[k] = c[L.filter_stats + k];
         fs[FAQCS_PAIRED_READ_NUMBER] += r.paired_read_number;
@@ -927,7 +973,7 @@ int main(int argc, char **argv)
             else { const std::string t = stats_text(opt, fs, ast, r.quality); fwrite(t.data(), 1, t.size(), f); fclose(f); }
         }
         if (!opt.trim_only && opt.debug) write_tables(opt, L, c.data(), r.R, r.ctx);
-        faqcs_destroy(r.ctx);
+        for (faqcs_ctx *k : r.ctxs) faqcs_destroy(k);
     } catch (std::exception &e) {
         fprintf(stderr, "Caught the error %s\n", e.what());
         return EXIT_FAILURE;

@@ -1363,6 +1363,9 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
                                  faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
                                  uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st);
 
+static thread_local const char *g_last_trim_kernel = "";
+const char *faqcs_last_trim_kernel() { return g_last_trim_kernel; }
+
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
@@ -1372,9 +1375,10 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
         static const bool lds_on = [] { const char *e = getenv("FAQCS_TRIM_LDS"); return !e || atoi(e) != 0; }();
         if (lds_on) {
             const hipError_t e = faqcs_launch_trim_lds(P, seq, qual, off, n_reads, max_len, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st);
-            if (e != hipErrorNotSupported) return e;
+            if (e != hipErrorNotSupported) { g_last_trim_kernel = "trim_lds"; return e; }
         }
     }
+    g_last_trim_kernel = "trim_filter_accumulate";
     const bool windowed = P.has_adapters || ((P.trim5 || P.trim3) && !P.qc_only);
     const bool generic = !(P.mode == FAQCS_MODE_BWA_PLUS && !P.protect5 && !P.qc_only && P.replace_q == 0 && !P.avgq_on &&
                            P.max_poly_n == 2 && P.dbg == 0);
@@ -1392,15 +1396,17 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
             // EXT: the default set plus --5trim_off / --avg_q / -n 0 or 1 (compiled apart so that the default variants stay as they are)
             const bool ext = generic && P.mode == FAQCS_MODE_BWA_PLUS && !P.qc_only && P.replace_q == 0 && P.max_poly_n <= 2 && P.dbg == 0;
 #define FAQCS_TRIM_CASE_TPR(C) \
+    { g_last_trim_kernel = "trim_tpr"; \
     return ext ? (windowed ? launch_trim_tpr<C, tpr_nw(C, 8, true), true, 8, true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C, 8, true), false, 8, true>(FAQCS_TRIM_ARGS)) \
-               : (windowed ? launch_trim_tpr<C, tpr_nw(C), true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C), false>(FAQCS_TRIM_ARGS))
+               : (windowed ? launch_trim_tpr<C, tpr_nw(C), true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C), false>(FAQCS_TRIM_ARGS)); }
             if (lpr8 && tpr && (!generic || ext) && max_len > 76 && max_len <= 104) FAQCS_TRIM_CASE_TPR(13);   // 2x100
             if (lpr8 && tpr && (!generic || ext) && max_len > 104 && max_len <= 152) FAQCS_TRIM_CASE_TPR(19);  // 2x150
             if (lpr8 && tpr && !generic && max_len > 152 && max_len <= 160) FAQCS_TRIM_CASE_TPR(20);
 #undef FAQCS_TRIM_CASE_TPR
 #define FAQCS_TRIM_CASE_TPR4(C) \
+    { g_last_trim_kernel = "trim_tpr"; \
     return ext ? (windowed ? launch_trim_tpr<C, tpr_nw(C, 4), true, 4, true>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C, 4), false, 4, true>(FAQCS_TRIM_ARGS)) \
-               : (windowed ? launch_trim_tpr<C, tpr_nw(C, 4), true, 4>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C, 4), false, 4>(FAQCS_TRIM_ARGS))
+               : (windowed ? launch_trim_tpr<C, tpr_nw(C, 4), true, 4>(FAQCS_TRIM_ARGS) : launch_trim_tpr<C, tpr_nw(C, 4), false, 4>(FAQCS_TRIM_ARGS)); }
             {   // reads <= 76 bases: 4 lanes per read in phase B (2x75, 2x50)
                 static const bool lpr4t = [] { const char *e = getenv("FAQCS_TRIM_LPR4"); return !e || atoi(e) != 0; }();
                 if (lpr4t && tpr && (!generic || ext) && max_len > 0 && max_len <= 64) FAQCS_TRIM_CASE_TPR4(16);

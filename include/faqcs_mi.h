@@ -251,6 +251,11 @@ int  faqcs_kmer_set_epochs(faqcs_ctx *ctx, const uint32_t *segment_epoch, uint32
 /* After a submission: device array of (u64 key, u64 epoch) pairs grouped by destination rank 0..world-1 and the
  * number of pairs per destination (counts[world]).  Valid until the next submission. */
 int  faqcs_kmer_outbox(faqcs_ctx *ctx, void **d_items, uint64_t *counts);
+/* The keys of the last submission's outbox copied to the host (all destinations; keys == NULL or cap too small: only the
+ * count is returned).  For a caller that owns the table itself, like the reference's trim() seam (MAP<Word,size_t>,
+ * trim.cpp:133-135): the key values are an injective re-encoding of the canonical k-mers, so counts and distinct counts
+ * are the reference's, the key values are not. */
+int  faqcs_kmer_outbox_host(faqcs_ctx *ctx, uint64_t *keys, uint64_t cap, uint64_t *n_keys);
 /* Owner side: inserts n_items received pairs (device pointer; returns when the buffer may be reused). */
 int  faqcs_kmer_insert_device(faqcs_ctx *ctx, const void *d_items, uint64_t n_items);
 /* Owner side: keys by first epoch and occurrences by epoch of THIS rank's table ([n_epochs] each, cap >= n_epochs). */
@@ -270,6 +275,10 @@ int  faqcs_debug_words(faqcs_ctx *ctx, uint64_t *out, uint32_t n);
 /* average duration (ms) of the dominant kernel over the launches since the last call, measured with
  * HIP events recorded on the compute stream around each launch */
 int  faqcs_kernel_time_ms(faqcs_ctx *ctx, double *avg_ms, uint64_t *n_launches);
+/* the same per kernel: the trim kernel (and which variant ran: "trim_lds", "trim_tpr", "trim_filter_accumulate") and the
+ * adapter pre-pass adapter_overlap (0 without adapters); both measured with HIP events on the compute stream */
+typedef struct faqcs_kernel_times { double trim_ms, adapter_ms; uint64_t n_launches; const char *trim_kernel; } faqcs_kernel_times;
+int  faqcs_kernel_report(faqcs_ctx *ctx, faqcs_kernel_times *out);
 
 #ifdef __cplusplus
 }

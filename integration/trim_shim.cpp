@@ -47,6 +47,8 @@ struct Shim {
     vector<faqcs_read_result> res;
     faqcs_params prm;
     vector<const char *> adapter_ptr;
+    bool kmers = false;          // the context extracts the k-mers of every call for the caller's MAP<Word, size_t>
+    vector<uint64_t> keys;
 
     ~Shim() { if (ctx) faqcs_destroy(ctx); }
 };
@@ -70,7 +72,6 @@ void ensure_ctx(const Options &o)
         }
         return;
     }
-    if (o.kmer_rarefaction) throw "trim_shim: --kmer_rarefaction is not available through the trim() shim (see INTEGRATION.md)";
     faqcs_params &p = g.prm;
     memset(&p, 0, sizeof(p));
     p.abi_version = FAQCS_ABI_VERSION;
@@ -89,6 +90,10 @@ void ensure_ctx(const Options &o)
     p.protect_5 = o.protect_5;
     p.qc_only = o.qc_only;
     p.kmer = o.kmer;
+    // k-mers: the caller owns the table (MAP<Word, size_t>&): the device only EXTRACTS the canonical k-mers of every call
+    // (owner-partitioned mode with one owner) and the shim merges them into the caller's map (trim.cpp:133-135)
+    p.kmer_rarefaction = o.kmer_rarefaction ? 1u : 0u;
+    p.kmer_table_slots = 1u << 16;
     p.split_size = o.split_size;
     p.num_subsample = o.num_subsample;
     p.max_read_length = g.R;
@@ -102,6 +107,7 @@ void ensure_ctx(const Options &o)
     }
     int rc = faqcs_create(&p, -1, &g.ctx);
     if (rc) fail(rc);
+    if (p.kmer_rarefaction) { rc = faqcs_kmer_partition(g.ctx, 0, 1, 1); if (rc) fail(rc); g.kmers = true; }
     faqcs_counters_layout(g.R, p.n_adapters, &g.lay);
     g.prev.assign(g.lay.total, 0);
     g.cur.assign(g.lay.total, 0);
@@ -137,7 +143,7 @@ void add_comp(vector<NucleotideCount> &dst, const uint64_t *cur, const uint64_t 
 
 // FaQCs.h:245-248
 void trim(vector<Read> &m_buffer, vector<size_t> &m_filter_stats,
-          MAP<string, pair<size_t, size_t> > &m_adapter_stats, MAP<Word, size_t> & /*m_kmer_table*/, PlotInfo &m_info,
+          MAP<string, pair<size_t, size_t> > &m_adapter_stats, MAP<Word, size_t> &m_kmer_table, PlotInfo &m_info,
           Options &m_opt)
 {
     ensure_ctx(m_opt);
@@ -163,7 +169,13 @@ void trim(vector<Read> &m_buffer, vector<size_t> &m_filter_stats,
     faqcs_batch b;
     memset(&b, 0, sizeof(b));
     b.seq = &g.seq[0]; b.qual = &g.qual[0]; b.offset = &g.off[0]; b.n_reads = n; b.n_segments = 1; b.segment_start = seg;
-    int rc = faqcs_submit(g.ctx, &b, &g.res[0]);
+    int rc = 0;
+    if (g.kmers) { // this call's k-mers are wanted while the curve is open (trim.cpp:82, :180-184)
+        const uint32_t epoch = m_opt.kmer_rarefaction ? 0u : FAQCS_EPOCH_NONE;
+        rc = faqcs_kmer_set_epochs(g.ctx, &epoch, 1);
+        if (rc) fail(rc);
+    }
+    rc = faqcs_submit(g.ctx, &b, &g.res[0]);
     if (rc) fail(rc);
     rc = faqcs_finish(g.ctx, &g.cur[0], g.cur.size()); // syncs; raises the reference's throw sites
     if (rc) fail(rc);
@@ -204,6 +216,28 @@ void trim(vector<Read> &m_buffer, vector<size_t> &m_filter_stats,
     add_comp(m_info.pre_nuc_composition, c + L.pre_comp, p + L.pre_comp);
     add_comp(m_info.post_nuc_composition, c + L.post_comp, p + L.post_comp);
     g.prev.swap(g.cur);
+
+    // ---- k-mers of this call into the caller's table, then the sampling rule of trim.cpp:157-185 ---------------------
+    if (g.kmers && m_opt.kmer_rarefaction) {
+        uint64_t nk = 0;
+        rc = faqcs_kmer_outbox_host(g.ctx, NULL, 0, &nk);
+        if (rc) fail(rc);
+        g.keys.resize(nk + 1);
+        rc = faqcs_kmer_outbox_host(g.ctx, &g.keys[0], nk, &nk);
+        if (rc) fail(rc);
+        for (uint64_t i = 0; i < nk; ++i) ++m_kmer_table[(Word)g.keys[i]];
+        const size_t reads_so_far = m_filter_stats[FilterStat::TOTAL_NUMBER];
+        const size_t index = reads_so_far / m_opt.split_size, have = m_info.kmer_rarefaction.size();
+        if (index > have && have < m_opt.num_subsample) {
+            Rarefaction point;
+            point.num_seq = reads_so_far;
+            point.distinct_kmer = m_kmer_table.size();
+            point.total_kmer = 0;
+            for (MAP<Word, size_t>::const_iterator it = m_kmer_table.begin(); it != m_kmer_table.end(); ++it) point.total_kmer += it->second;
+            m_info.kmer_rarefaction.push_back(point);
+        }
+        if (have >= m_opt.num_subsample) m_opt.kmer_rarefaction = false; // the curve is complete
+    }
 }
 
 // trim.cpp:619-626

@@ -62,6 +62,8 @@ CASES = [
     ("head150_default", "head150", P + ["--min_L", "50", "-q", "5"]),
     ("head150_adapter_polyA", "head150", P + ["--adapter", "--polyA"]),
     ("head250_default", "head250", P),
+    # BASELINE configs[4]'s shape: 2x250, k-mer rarefaction with --subset 200 (no -m: the reference's getopt string lacks it)
+    ("head250_kmer", "head250", P + ["--kmer_rarefaction", "--subset", "200", "--split_size", "300"]),
     ("long300_default", "long300", P),
     ("long300_adapter_polyA", "long300", P + ["--adapter", "--polyA"]),
     ("long300_kmer_q20", "long300", P + ["--kmer_rarefaction", "--split_size", "300", "-q", "20", "--replace_to_N_q", "12"]),
@@ -69,7 +71,8 @@ CASES = [
     ("long1000_bwa_avgq", "long1000", P + ["--mode", "BWA", "--avg_q", "20", "-n", "3"]),
     ("long1000_hard_lc", "long1000", P + ["--mode", "HARD", "-q", "12", "--lc", "0.6", "--5end", "7", "--3end", "9"]),
     ("long1000_adapter_polyA", "long1000", P + ["--adapter", "--polyA", "--discard"]),
-    ("adv_prefix_stats", "adv", P + ["--prefix", "SAMPLE7", "--stats", "ignored_by_the_reference.txt"]),
+    # --stats is honoured (options.cpp:291-293,739-740): the statistics go to the named file instead of <prefix>.stats.txt
+    ("adv_prefix_stats", "adv", P + ["--prefix", "SAMPLE7", "--stats", "{D}/custom.stats.txt"]),
     ("adv_single_dash_long_options", "adv", ["-1", "{1}", "-2", "{2}", "-d", "{D}", "-t", "1", "-debug", "-min_L", "40", "-q", "12", "-lc", "0.7", "-discard", "-substitute"]),
     ("adv64_autodetect", "adv64", P),
     ("adv64_ascii64_out33", "adv64", P + ["--ascii", "64", "--out_ascii", "33"]),
@@ -104,7 +107,7 @@ def fixture_paths(name):
 
 def substitute(args, p1, p2, outdir):
     m = {"{1}": p1, "{2}": p2, "{U}": p1, "{D}": outdir, "{ART}": ARTIFACT_FASTA}
-    return [m.get(a, a) for a in args]
+    return [m.get(a, a.replace("{D}", outdir)) for a in args]
 
 
 def collect_outputs(outdir):

@@ -40,7 +40,7 @@ def run_case(case, cache, tmp_path, engine_factory, **kw):
     assert [md5_file(p1), md5_file(p2)] == case["fixture_md5"], "fixture generator drifted: " + case["fixture"]
     outdir = os.path.join(str(tmp_path), "out")
     m = {"{1}": p1, "{2}": p2, "{U}": p1, "{D}": outdir, "{ART}": ARTIFACT_FASTA}
-    argv = [m.get(a, a) for a in case["args"]]
+    argv = [m.get(a, a.replace("{D}", outdir)) for a in case["args"]]
     err = io.StringIO()
     rc = driver.run(argv, engine_factory=engine_factory, err=err, **kw)
     bad = []
@@ -98,7 +98,7 @@ def compare_outputs(case, outdir, rc, err_text):
     return bad
 
 
-def run_case_binary(case, cache, tmp_path, binary):
+def run_case_binary(case, cache, tmp_path, binary, extra_args=()):
     """Runs a FaQCs-compatible executable (the reference driver linked against integration/trim_shim.cpp) on the
     case's command line and compares every output file with the reference's own outputs."""
     import subprocess
@@ -106,7 +106,7 @@ def run_case_binary(case, cache, tmp_path, binary):
     p1, p2 = fixture_paths(case["fixture"], cache)
     outdir = os.path.join(str(tmp_path), "out")
     m = {"{1}": p1, "{2}": p2, "{U}": p1, "{D}": outdir, "{ART}": ARTIFACT_FASTA}
-    argv = [m.get(a, a) for a in case["args"]]
+    argv = [m.get(a, a.replace("{D}", outdir)) for a in case["args"]] + list(extra_args)
     for _ in range(6):  # the reference driver can die of SIGPIPE feeding the absent R (see make_golden.py)
         import shutil
 

@@ -488,7 +488,7 @@ _SHIM_BIN = __import__("os").path.join(__import__("os").path.dirname(__import__(
                                        "oracle", "_ref", "FaQCs_hip")
 
 
-@pytest.mark.parametrize("name", [n for n in __import__("golden_util").case_names() if "kmer" not in n])
+@pytest.mark.parametrize("name", __import__("golden_util").case_names())
 def test_reference_driver_with_hip_trim(name, fixture_cache, tmp_path):
     """the reference's OWN driver (FaQCs.cpp, options.cpp, fastq.cpp, plot.cpp compiled from where
     they lie) linked against integration/trim_shim.cpp -> libfaqcs_mi.so must reproduce the reference's outputs."""
@@ -514,3 +514,46 @@ def test_native_cli_reproduces_reference(name, fixture_cache, tmp_path):
 
     bad = run_case_binary(load_case(name), fixture_cache, tmp_path, _CLI_BIN)
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name", ["advbig_default", "advbig_adapter_polyA", "adv_default", "adv_discard", "adv_unpaired_only"])
+def test_native_cli_on_two_devices(name, fixture_cache, tmp_path):
+    """faqcs_mi --gpu_ids 0,0: the 32 768-read buffers are dealt round robin to TWO device contexts (both on this box's one GPU),
+    the ordered writers re-serialise by buffer number and the two counter blocks are summed -- one QC.stats.txt, the same
+    bytes as the reference (the advbig cases cross the buffer boundary, so both contexts see work; FaQCs.cpp:240-501)."""
+    from golden_util import case_names, load_case, run_case_binary
+
+    if name not in case_names():
+        pytest.skip("no such golden case")
+    bad = run_case_binary(load_case(name), fixture_cache, tmp_path, _CLI_BIN, extra_args=["--gpu_ids", "0,0"])
+    assert not bad, "\n".join(bad)
+
+
+def test_native_cli_reports_a_device_error_in_a_large_input(tmp_path):
+    """A read whose quality exceeds Q41 in the FIRST buffer of an input of 20 buffers: the gate thread meets the error while
+    the producer still has many buffers to submit.  The run must end with the reference's message and a failure status, not
+    hang with every buffer in flight (fastq.h:31-33; FaQCs.cpp:136-147)."""
+    import subprocess
+
+    n = 20 * 32768 + 7
+    rec = b"@r%d\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 40 + b"\n"
+    path = str(tmp_path / "big.fastq")
+    with open(path, "wb") as f:
+        chunks = []
+        for i in range(n):
+            if i == 5:
+                chunks.append(b"@r5\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 39 + bytes([33 + 42]) + b"\n")
+            else:
+                chunks.append(rec % i)
+            if len(chunks) == 65536:
+                f.write(b"".join(chunks))
+                chunks = []
+        f.write(b"".join(chunks))
+    for extra in ([], ["--gpu_ids", "0,0"]):
+        r = subprocess.run([_CLI_BIN, "-u", path, "-d", str(tmp_path / "out"), "--ascii", "33"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 1, (r.returncode, r.stderr.decode()[-500:])
+        assert b"Caught the error fastq.h:quality_score" in r.stderr
+    p2 = str(tmp_path / "big2.fastq")
+    os.link(path, p2)
+    r = subprocess.run([_CLI_BIN, "-1", path, "-2", p2, "-d", str(tmp_path / "out2"), "--ascii", "33"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 1 and b"Caught the error fastq.h:quality_score" in r.stderr
