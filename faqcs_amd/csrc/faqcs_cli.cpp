@@ -616,10 +616,12 @@ void process_paired(Run &r)
     std::thread writer2([&] { mate_writer(q2, f2, true); });
     std::thread writer([&] {
         std::string s, q;
+        bool cur_last = false; // the pair in hand is the input's last one: nothing follows it in the queue
         try {
             for (;;) {
                 Work w = wq.pop();
                 if (!w.b1) break;
+                cur_last = w.last;
                 Run::check(faqcs_wait(r.ctxs[w.b1->dev], w.b1->ticket));
                 Run::check(faqcs_wait(r.ctxs[w.b2->dev], w.b2->ticket));
                 Run::check_read_errors(w.b1); Run::check_read_errors(w.b2); // trim() throws before anything of the buffer is written
@@ -642,11 +644,11 @@ void process_paired(Run &r)
             // of the pairs already queued back to the readers until its sentinel arrives.
             werr = e.what();
             failed = true;
-            for (;;) {
+            while (!cur_last) {
                 Work w = wq.pop();
                 if (!w.b1) break;
                 s1.free_q.push(w.b1); s2.free_q.push(w.b2);
-                if (w.last) break;
+                cur_last = w.last;
             }
         }
         q1.push(Work()); q2.push(Work()); // (a mate writer that already saw its last buffer has left; the sentinel is then unused)
@@ -713,10 +715,12 @@ void process_unpaired(Run &r)
     std::atomic<bool> failed{false};
     std::thread writer([&] {
         std::string sq, qq;
+        bool cur_last = false;
         try {
             for (;;) {
                 Work w = wq.pop();
                 if (!w.b1) break;
+                cur_last = w.last;
                 Run::check(faqcs_wait(r.ctxs[w.b1->dev], w.b1->ticket));
                 Run::check_read_errors(w.b1);
                 if (!opt.qc_only)
@@ -730,11 +734,11 @@ void process_unpaired(Run &r)
         } catch (std::exception &e) {
             werr = e.what();
             failed = true;
-            for (;;) { // keep the reader supplied with buffers until the producer has seen the failure
+            while (!cur_last) { // keep the reader supplied with buffers until the producer has seen the failure
                 Work w = wq.pop();
                 if (!w.b1) break;
                 s.free_q.push(w.b1);
-                if (w.last) break;
+                cur_last = w.last;
             }
         }
     });

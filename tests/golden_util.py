@@ -111,7 +111,7 @@ def run_case_binary(case, cache, tmp_path, binary, extra_args=()):
         import shutil
 
         shutil.rmtree(outdir, ignore_errors=True)
-        proc = subprocess.run([binary] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        proc = subprocess.run([binary] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         if proc.returncode != -13:
             break
     return compare_outputs(case, outdir, proc.returncode, proc.stderr.decode(errors="replace"))
