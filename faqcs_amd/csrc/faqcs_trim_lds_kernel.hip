@@ -500,12 +500,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 wa = mod ? first : 0; wn = mod ? second : len;
                 flags = mod ? FAQCS_F_ADAPTER : 0u;
             }
-            if (WINDOWED && P.trim5) {
+            const bool do_trim = !(EXT && P.qc_only); // --qc_only: adapters are still cut, nothing else is (trim.cpp:279,299,325)
+            if (WINDOWED && P.trim5 && do_trim) {
                 const bool over = (int)P.trim5 > wn;
                 wa = over ? wa : wa + (int)P.trim5;
                 wn = over ? 0 : wn - (int)P.trim5;
             }
-            if (WINDOWED && P.trim3) wn = (int)P.trim3 > wn ? 0 : wn - (int)P.trim3;
+            if (WINDOWED && P.trim3 && do_trim) wn = (int)P.trim3 > wn ? 0 : wn - (int)P.trim3;
 
             // ---- BWA_plus (trim.cpp:714-793), walked as the reference walks it ---------------------------------
             // Step s of a walk visits window position wn - 1 - s (3') or s (5').  at_least_scan == 0 after step `bud`: the walk
@@ -514,8 +515,47 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // key = area << 8 | code, code falling with time: the FIRST maximum wins (walk_step above).
             const int a5 = wn < 5 ? wn : 5, nn2 = wn < 2 ? wn : 2, qoff = Q + in_off;
             const int dc = uni(qoff * 256 - 1);
-            int S3, fp3, S5 = 0, fp5 = 0;
-            {
+            int S3 = 0, fp3 = wn - 1, S5 = 0, fp5 = 0;
+            const int mode = EXT ? P.mode : FAQCS_MODE_BWA_PLUS;
+            bool sum_kept = false; // the kept window's quality sum needs its own pass (no walk areas to derive it from)
+            if (EXT && do_trim && mode == FAQCS_MODE_BWA) {
+                // trim.cpp:675-709: from the 3' end while position > 0 and area >= 0; the first maximum of the area cuts
+                int area = 0, best = 0, p = wn - 1;
+                const uint32_t q0 = slot_b + rowq + (uint32_t)wa;
+#pragma unroll 1
+                while (__any(p > 0 && area >= 0)) {
+                    if (p > 0 && area >= 0) {
+                        area += qoff - (int)lds_ld_u8(q0 + (uint32_t)p);
+                        if (area > best) { best = area; fp3 = p - 1; }
+                        --p;
+                    }
+                }
+                S3 = best;
+            } else if (EXT && do_trim && mode == FAQCS_MODE_HARD) {
+                // trim.cpp:629-672: 3' = first position from the end (above 0) with q > Q, 5' = first position below it with q > Q
+                const uint32_t q0 = slot_b + rowq + (uint32_t)wa;
+                int p3 = wn - 1;
+                bool go = p3 > 0;
+#pragma unroll 1
+                while (__any(go)) {
+                    if (go) {
+                        if (qoff < (int)lds_ld_u8(q0 + (uint32_t)p3)) { fp3 = p3; go = false; }
+                        else { --p3; go = p3 > 0; }
+                    }
+                }
+                if (!P.protect5) {
+                    int p5 = 0;
+                    go = p5 < p3;
+#pragma unroll 1
+                    while (__any(go)) {
+                        if (go) {
+                            if (qoff < (int)lds_ld_u8(q0 + (uint32_t)p5)) { fp5 = p5; go = false; }
+                            else { ++p5; go = p5 < p3; }
+                        }
+                    }
+                }
+                sum_kept = true;
+            } else if (do_trim) {
                 int rlim = wn - 1 - nn2; // a reset at step s needs wn - 1 - s > n2
                 const uint32_t endq = slot_b + rowq + (uint32_t)(wa + wn);
                 const uint32_t esh = endq & 3u;
@@ -565,7 +605,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 fp3 = S3 > 0 ? (wn - 1 - sb) - 1 : wn - 1;
             }
             FAQCS_STAMP(2)
-            if (!(EXT && P.protect5)) { // --5trim_off (trim.cpp:752)
+            if (do_trim && mode == FAQCS_MODE_BWA_PLUS && !(EXT && P.protect5)) { // --5trim_off (trim.cpp:752)
                 int rb = a5 - 1, area = 0, best = 255, K = 255;
                 const int rlim = fp3 - nn2; // a reset at step s needs s < final_pos_3 - n2
                 const uint32_t begq = slot_b + rowq + (uint32_t)wa;
@@ -587,8 +627,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             bool ret = mine;
             uint32_t qt_removed = 0;
             if (ret && (n < (int)P.min_len || n == 0)) { ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
-            if (ret) {
-                const int kept = fp3 <= fp5 ? 0 : fp3 - fp5 + 1;
+            if (ret && do_trim) {
+                // BWA_plus: final_pos_3 <= final_pos_5 empties the read (trim.cpp:781-790); BWA keeps [0, final_pos_3]; HARD [5', 3']
+                const int kept = mode == FAQCS_MODE_BWA_PLUS ? (fp3 <= fp5 ? 0 : fp3 - fp5 + 1) : fp3 - fp5 + 1;
                 if (kept != n) { qt_removed = (uint32_t)(n - kept); flags |= FAQCS_F_QUAL_TRIMMED; }
                 a += fp5;
                 n = kept;
@@ -612,6 +653,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             }
             // all v == q here (no byte below the offset): what the two walks cut off is their maximal areas
             int V_post = n * Q - ((wn * Q - V_win) - (S3 > 0 ? S3 : 0) - (S5 > 0 ? S5 : 0));
+            if (EXT && sum_kept) { // (wave-uniform: the trim mode)
+                uint32_t sm = 0;
+                const int k0 = a >> 2, k1 = (a + n + 3) >> 2;
+                const int kmax = uni((int)wave_max_u32((uint32_t)(k1 > k0 ? k1 - k0 : 0)));
+#pragma unroll 2
+                for (int i = 0; i < kmax; ++i) {
+                    const int k = k0 + i;
+                    const uint32_t w = lds_ld_any(slot_b + rowq + 4u * (uint32_t)k);
+                    const uint32_t m = low_bytes_(med3i(a + n - 4 * k, 0, 4)) & ~low_bytes_(med3i(a - 4 * k, 0, 4));
+                    sm = __builtin_amdgcn_sad_u8(w & m, 0u, sm);
+                }
+                V_post = (int)sm - n * in_off;
+            }
             // exact pass for a read with a raw quality outside [offset, offset + 41] (negative scores clamp to 0 in the
             // trimmers but not in the averages; > 41 aborts the run)
             if (__any(badq)) {
@@ -686,11 +740,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 const bool abn_seq = nACGT + nup != len; // a letter that is neither ACGT (any case) nor 'N'
 
                 // ---- poly-N (trim.cpp:363-371, :578-597): -n 2 = two adjacent upper-case N inside the kept window ----
-                if (EXT && P.max_poly_n != 2u) { // -n 0: every read trips; -n 1: any upper-case N inside the kept window
-                    uint32_t hit = 0;
+                if (EXT && P.max_poly_n != 2u) { // -n 0: every read trips; -n k: a run of k upper-case N inside the kept window
+                    uint32_t run[NWORD], hit = 0;
 #pragma unroll
-                    for (int w = 0; w < NWORD; ++w) hit |= nub[w] & bit_range_(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
-                    if (ret && (P.max_poly_n == 0u || hit != 0u)) { flags |= FAQCS_F_POLY_N_SEEN; ret = false; filt = FAQCS_FILT_POLY_N; }
+                    for (int w = 0; w < NWORD; ++w) run[w] = nub[w] & bit_range_(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
+                    // bit e of `run` after i rounds: N at e - i .. e, all inside the window
+#pragma unroll 1
+                    for (uint32_t i = 1; i < P.max_poly_n && i <= (uint32_t)NPOS; ++i) {
+                        uint32_t carry = 0;
+#pragma unroll
+                        for (int w = 0; w < NWORD; ++w) {
+                            const uint32_t shifted = (run[w] << 1) | carry;
+                            carry = run[w] >> 31;
+                            run[w] = shifted & nub[w] & bit_range_(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
+                        }
+                    }
+#pragma unroll
+                    for (int w = 0; w < NWORD; ++w) hit |= run[w];
+                    if (ret && (P.max_poly_n == 0u || (hit != 0u && P.max_poly_n <= (uint32_t)NPOS))) {
+                        flags |= FAQCS_F_POLY_N_SEEN;
+                        if (do_trim) { ret = false; filt = FAQCS_FILT_POLY_N; } // --qc_only counts it and keeps the read (trim.cpp:368-370)
+                    }
                 } else {
                     uint32_t pr[NWORD], anyp = 0; // bit e: N at e - 1 and at e
 #pragma unroll
@@ -702,7 +772,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                         uint32_t hit = 0;
 #pragma unroll
                         for (int w = 0; w < NWORD; ++w) hit |= pr[w] & bit_range_(med3i(a + 1 - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
-                        if (ret && hit != 0u) { flags |= FAQCS_F_POLY_N_SEEN; ret = false; filt = FAQCS_FILT_POLY_N; }
+                        if (ret && hit != 0u) {
+                            flags |= FAQCS_F_POLY_N_SEEN;
+                            if (do_trim) { ret = false; filt = FAQCS_FILT_POLY_N; }
+                        }
                     }
                 }
                 // ---- average quality (judged in Q-A, applied here: after poly-N, trim.cpp:374-382) ----
@@ -863,7 +936,8 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
     const bool windowed = P.has_adapters || ((P.trim5 || P.trim3) && !P.qc_only);
     const bool plain = P.mode == FAQCS_MODE_BWA_PLUS && !P.protect5 && !P.qc_only && P.replace_q == 0 && !P.avgq_on &&
                        P.max_poly_n == 2 && P.dbg == 0;
-    const bool ext = !plain && P.mode == FAQCS_MODE_BWA_PLUS && !P.qc_only && P.replace_q == 0 && P.max_poly_n <= 2 && P.dbg == 0;
+    // every option set except --replace_to_N_q (its G -> N edit needs base and quality of a position together) and the ablation bits
+    const bool ext = !plain && P.replace_q == 0 && P.dbg == 0;
     if (!plain && !ext) return hipErrorNotSupported;
 #define FAQCS_LDS_ARGS P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st
 #define FAQCS_LDS_CASE(C)                                                                                                 \
