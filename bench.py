@@ -42,6 +42,8 @@ def parse():
                     help="plain = BASELINE configs[1] (the headline), adapter = configs[2], kmer = configs[4]'s shape on one GPU")
     ap.add_argument("--batch-reads", type=int, default=1 << 24, help="reads per submission (u32 offsets: < 4 GiB arena)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_E2E_PAIRS", 2e6)),
+                    help="pairs of the same workload written as FASTQ to /dev/shm for the end-to-end (files in, files out) run of faqcs_mi; 0 = skip")
     return ap.parse_args()
 
 
@@ -92,6 +94,56 @@ def cpu_baseline(opt_args, hs, hq, L, n_sample):
         return {"value": round(port, 4), "unit": "M reads/s", "cores": 1, "kind": "port",
                 "sample": "%d reads of the same workload through oracle/faqcs_oracle.c (single thread, compute only)" % min(n_sample, 200000)}
     return None
+
+
+def e2e_run(opt_args, hs, hq, L, n_pairs):
+    """End to end through files: the first n_pairs pairs of the workload as two uncompressed FASTQ files in /dev/shm ->
+    faqcs_amd/faqcs_mi (FaQCs command line on the HIP library) -> trimmed FASTQ + QC.stats.txt in /dev/shm.  Whole-process wall
+    clock, HIP start-up included.  hs / hq: host copies of 2 * n_pairs reads (mate 1 = the first half)."""
+    cli = os.path.join(ROOT, "faqcs_amd", "faqcs_mi")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    tmp = tempfile.mkdtemp(prefix="faqcs_e2e_", dir=base)
+    try:
+        n = int(n_pairs)
+        paths = []
+        for mate in (1, 2):
+            lo = (mate - 1) * n
+            idw = 9
+            head = np.frombuffer(b"@SYN:", np.uint8)
+            tail = np.frombuffer(b"/%d\n" % mate, np.uint8)
+            rec = len(head) + idw + len(tail) + L + 3 + L + 1
+            a = np.empty((n, rec), np.uint8)
+            c = 0
+            a[:, c:c + len(head)] = head; c += len(head)
+            ids = np.arange(n, dtype=np.int64)
+            for k in range(idw):
+                a[:, c + idw - 1 - k] = 48 + (ids // 10 ** k) % 10
+            c += idw
+            a[:, c:c + len(tail)] = tail; c += len(tail)
+            a[:, c:c + L] = hs[lo * L:(lo + n) * L].reshape(n, L); c += L
+            a[:, c:c + 3] = np.frombuffer(b"\n+\n", np.uint8); c += 3
+            a[:, c:c + L] = hq[lo * L:(lo + n) * L].reshape(n, L); c += L
+            a[:, c] = 10
+            pth = os.path.join(tmp, "r%d.fq" % mate)
+            a.tofile(pth)
+            paths.append(pth)
+            del a
+        cmd = [cli, "-1", paths[0], "-2", paths[1], "-d", os.path.join(tmp, "out"), "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr.decode(errors="replace")[-300:]}
+        out_bytes = sum(os.path.getsize(os.path.join(tmp, "out", f)) for f in os.listdir(os.path.join(tmp, "out")))
+        in_bytes = sum(os.path.getsize(p) for p in paths)
+        return {"value": round(2 * n / dt / 1e6, 3), "unit": "M reads/s", "seconds": round(dt, 3), "pairs": n,
+                "input_GB": round(in_bytes / 1e9, 3), "output_GB": round(out_bytes / 1e9, 3),
+                "what": "faqcs_mi: uncompressed FASTQ in /dev/shm -> parse -> pinned SoA -> HIP trim -> trimmed FASTQ + QC.stats.txt in /dev/shm; "
+                        "whole-process wall clock including HIP start-up"}
+    except Exception as e:
+        return {"error": str(e)}
+    finally:
+        subprocess.run(["rm", "-rf", tmp])
 
 
 def free_port():
@@ -321,6 +373,11 @@ def main():
             hq = batches[0][1][: ns * L].cpu().numpy()
             pad = np.zeros(64, np.uint8)
             out["cpu_baseline"] = cpu_baseline(opt_args, np.concatenate([hs, pad]), np.concatenate([hq, pad]), L, ns)
+        if world == 1 and a.e2e_pairs > 0 and a.config != "kmer" and os.path.exists(os.path.join(ROOT, "faqcs_amd", "faqcs_mi")):
+            ne = int(min(a.e2e_pairs, batches[0][6] // 2))
+            es = batches[0][0][: 2 * ne * L].cpu().numpy()
+            eq = batches[0][1][: 2 * ne * L].cpu().numpy()
+            out["e2e"] = e2e_run(opt_args, es, eq, L, ne)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -325,7 +325,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t data = __builtin_amdgcn_perm(cm[j >> 2], im[j >> 2], sel);
             const uint32_t ad = ((j & 3) == 0 ? byte_mul<0>(wq[j >> 2], wx4) : (j & 3) == 1 ? byte_mul<1>(wq[j >> 2], wx4)
                                  : (j & 3) == 2 ? byte_mul<2>(wq[j >> 2], wx4) : byte_mul<3>(wq[j >> 2], wx4)) + hq_lane;
+#ifndef FAQCS_LDS_NO_QB_ATOMICS
             lds_add_u32(ad + 4u * (uint32_t)j, data);
+#else
+            asm volatile("" :: "v"(ad), "v"(data));
+#endif
         }
     };
     // position x base: 6-bit count fields in registers.  A base outside the kept window is looked up at (byte ^ 1) -- '@',
@@ -344,7 +348,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         for (int j = 0; j < C; ++j) {
             const uint32_t ad = ((j & 3) == 0 ? byte_x8<0>(ws[j >> 2], three) : (j & 3) == 1 ? byte_x8<1>(ws[j >> 2], three)
                                  : (j & 3) == 2 ? byte_x8<2>(ws[j >> 2], three) : byte_x8<3>(ws[j >> 2], three)) + (uint32_t)(T::O_T3 * 4);
+#ifndef FAQCS_LDS_NO_SB_LOOKUP
             const LdsPair2 e = *(lds_u2c_ptr)(size_t)ad;
+#else
+            LdsPair2 e; e.x = ad; e.y = ad >> 3; // (diagnostic build: no table lookup)
+#endif
             bpre[j] += e.x;
             bpost[j] += e.y;
         }
@@ -722,7 +730,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                             for (int j = 0; j < 4; ++j) {
                                 const uint32_t ad = (j == 0 ? byte_x8<0>(w, three) : j == 1 ? byte_x8<1>(w, three)
                                                      : j == 2 ? byte_x8<2>(w, three) : byte_x8<3>(w, three)) + (uint32_t)(T::O_T2 * 4);
+#ifndef FAQCS_LDS_NO_SA_LOOKUP
                                 const LdsPair2 e = *(lds_u2c_ptr)(size_t)ad;
+#else
+                                LdsPair2 e; e.x = ad & 0x01010101u; e.y = ad >> 9; // (diagnostic build: no table lookup)
+#endif
                                 cnt4 += e.x;
                                 nw = __builtin_amdgcn_alignbit(e.y, nw, 1); // bit (p & 31) = upper-case N at p
                             }

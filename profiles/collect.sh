@@ -11,22 +11,23 @@ mkdir -p $out
 export TMPDIR=/tmp
 if [ "${SKIP_BENCH:-0}" != 1 ]; then
 python3 bench.py > $out/bench_plain_100Mpairs.json 2> $out/bench_plain.err
-python3 bench.py --config adapter --pairs 20e6 --no-cpu-baseline > $out/bench_adapter_20Mpairs.json 2> $out/bench_adapter.err
-python3 bench.py --read-len 250 --pairs 40e6 --no-cpu-baseline > $out/bench_plain_250bp_40Mpairs.json 2>> $out/bench_plain.err
-python3 bench.py --read-len 300 --pairs 20e6 --no-cpu-baseline > $out/bench_plain_300bp_20Mpairs.json 2>> $out/bench_plain.err
-python3 bench.py --read-len 100 --pairs 60e6 --no-cpu-baseline > $out/bench_plain_100bp_60Mpairs.json 2>> $out/bench_plain.err
-python3 bench.py --read-len 75 --pairs 60e6 --no-cpu-baseline > $out/bench_plain_75bp_60Mpairs.json 2>> $out/bench_plain.err
-python3 bench.py --read-len 50 --pairs 60e6 --no-cpu-baseline > $out/bench_plain_50bp_60Mpairs.json 2>> $out/bench_plain.err
-python3 bench.py --read-len 125 --pairs 40e6 --no-cpu-baseline > $out/bench_plain_125bp_40Mpairs.json 2>> $out/bench_plain.err
-python3 bench.py --read-len 600 --pairs 8e6 --no-cpu-baseline > $out/bench_plain_600bp_8Mpairs.json 2>> $out/bench_plain.err
-python3 bench.py --config adapter --read-len 300 --pairs 4e6 --no-cpu-baseline > $out/bench_adapter_300bp_4Mpairs.json 2>> $out/bench_adapter.err
+FAQCS_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --pairs 10e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_2ranks_shared_gpu.json 2>> $out/bench_plain.err  # (FAQCS_BENCH_SHARE_GPU=1 in the environment: the launch path, not a measurement)
+python3 bench.py --config adapter --pairs 20e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_adapter_20Mpairs.json 2> $out/bench_adapter.err
+python3 bench.py --read-len 250 --pairs 40e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_250bp_40Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 300 --pairs 20e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_300bp_20Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 100 --pairs 60e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_100bp_60Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 75 --pairs 60e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_75bp_60Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 50 --pairs 60e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_50bp_60Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 125 --pairs 40e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_125bp_40Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --read-len 600 --pairs 8e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_600bp_8Mpairs.json 2>> $out/bench_plain.err
+python3 bench.py --config adapter --read-len 300 --pairs 4e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_adapter_300bp_4Mpairs.json 2>> $out/bench_adapter.err
 python3 bench.py --config kmer --no-cpu-baseline --steps 3 > $out/bench_kmer_250bp_10Mpairs.json 2>> $out/bench_plain.err
 fi
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_plain -o plain -- python3 bench.py --pairs 25165824 --steps 3 --no-cpu-baseline > $out/prof_plain.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_adapter -o adapter -- python3 bench.py --config adapter --pairs 4e6 --steps 3 --no-cpu-baseline > $out/prof_adapter.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_plain -o plain -- python3 bench.py --pairs 25165824 --steps 3 --no-cpu-baseline --e2e-pairs 0 > $out/prof_plain.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_adapter -o adapter -- python3 bench.py --config adapter --pairs 4e6 --steps 3 --no-cpu-baseline --e2e-pairs 0 > $out/prof_adapter.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python3 tests/ablate.py 0 16e6 > $out/pmc_$c.log 2>&1
 done
-python3 profiles/pmc_traffic.py $out 16000000 > $out/traffic_plain.json 2> $out/traffic.err
+python3 profiles/pmc_traffic.py $out 16000000 $tag > $out/traffic_plain.json 2> $out/traffic.err
 find $out -name "*kernel_stats.csv" -exec sh -c 'cp "$1" '$out'/$(basename $(dirname $(dirname "$1")))_kernel_stats.csv' _ {} \;
 ls -la $out
