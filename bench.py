@@ -42,7 +42,7 @@ def parse():
                     help="plain = BASELINE configs[1] (the headline), adapter = configs[2], kmer = configs[4]'s shape on one GPU")
     ap.add_argument("--batch-reads", type=int, default=1 << 24, help="reads per submission (u32 offsets: < 4 GiB arena)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_E2E_PAIRS", 2e6)),
+    ap.add_argument("--e2e-pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_E2E_PAIRS", 8e6)),
                     help="pairs of the same workload written as FASTQ to /dev/shm for the end-to-end (files in, files out) run of faqcs_mi; 0 = skip")
     return ap.parse_args()
 
@@ -130,16 +130,28 @@ def e2e_run(opt_args, hs, hq, L, n_pairs):
             del a
         cmd = [cli, "-1", paths[0], "-2", paths[1], "-d", os.path.join(tmp, "out"), "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, FAQCS_MI_TIMING="1"))
         dt = time.perf_counter() - t0
+        marks = {}
+        for line in r.stderr.decode(errors="replace").splitlines():  # "[faqcs_mi    0.385 s] device context(s) ready"
+            if line.startswith("[faqcs_mi") and " s] " in line:
+                try:
+                    marks[line.split(" s] ", 1)[1].strip()] = float(line[9:].split(" s]")[0])
+                except ValueError:
+                    pass
         if r.returncode != 0:
             return {"error": r.stderr.decode(errors="replace")[-300:]}
         out_bytes = sum(os.path.getsize(os.path.join(tmp, "out", f)) for f in os.listdir(os.path.join(tmp, "out")))
         in_bytes = sum(os.path.getsize(p) for p in paths)
+        pipe = None
+        if "first pair parsed" in marks and "outputs written" in marks and marks["outputs written"] > marks["first pair parsed"]:
+            pipe = round(2 * n / (marks["outputs written"] - marks["first pair parsed"]) / 1e6, 3)
         return {"value": round(2 * n / dt / 1e6, 3), "unit": "M reads/s", "seconds": round(dt, 3), "pairs": n,
+                "pipeline_value": pipe, "stage_marks_s": marks,
                 "input_GB": round(in_bytes / 1e9, 3), "output_GB": round(out_bytes / 1e9, 3),
                 "what": "faqcs_mi: uncompressed FASTQ in /dev/shm -> parse -> pinned SoA -> HIP trim -> trimmed FASTQ + QC.stats.txt in /dev/shm; "
-                        "whole-process wall clock including HIP start-up"}
+                        "whole-process wall clock including HIP start-up and process teardown; pipeline_value = the same reads over the interval from the first "
+                        "parsed pair to the last output byte (faqcs_mi's own stage marks)"}
     except Exception as e:
         return {"error": str(e)}
     finally:
@@ -156,7 +168,7 @@ def free_port():
     return p
 
 
-def launch_ranks(a):
+def launch_ranks(a, real_stdout):
     """`bench.py --gpus N` without a launcher: start N rank processes (one per GPU) BEFORE this process touches the GPU
     (torch.cuda.device_count() does not initialise it) and relay rank 0's JSON line.  FAQCS_BENCH_SHARE_GPU=1 lets the
     ranks share device 0 over gloo (a 1-GPU box can then exercise the N-rank path; never a measurement)."""
@@ -179,17 +191,20 @@ def launch_ranks(a):
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = p.wait() or rc
-    sys.stdout.write(out)
-    sys.stdout.flush()
+    real_stdout.write(out)
+    real_stdout.flush()
     raise SystemExit(rc)
 
 
 def main():
     a = parse()
+    # stdout carries exactly ONE JSON line: whatever a library prints there (gloo, the HIP runtime) goes to stderr instead
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if a.gpus < 1:
         raise SystemExit("bench: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        launch_ranks(a)  # (does not return)
+        launch_ranks(a, real_stdout)  # (does not return)
     import torch
 
     rank = int(os.environ.get("RANK", 0))
@@ -378,7 +393,8 @@ def main():
             es = batches[0][0][: 2 * ne * L].cpu().numpy()
             eq = batches[0][1][: 2 * ne * L].cpu().numpy()
             out["e2e"] = e2e_run(opt_args, es, eq, L, ne)
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

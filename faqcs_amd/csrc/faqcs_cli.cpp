@@ -9,8 +9,11 @@
 // order while later buffers are parsed and trimmed.  The per-read hot path runs ONLY on the GPU library.
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <cmath>
@@ -38,6 +41,11 @@ constexpr uint32_t BUF_READS = FAQCS_SEGMENT_READS;
 const int AUTO_OFFSET = -128;
 
 struct Fatal : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// FAQCS_MI_TIMING=1: wall-clock marks of the run's stages on stderr (diagnostics)
+double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+const double T0 = now_s();
+void tmark(const char *what) { static const bool on = getenv("FAQCS_MI_TIMING") != nullptr; if (on) fprintf(stderr, "[faqcs_mi %8.3f s] %s\n", now_s() - T0, what); }
 
 // ---------------------------------------------------------------------------------------------------------
 // options (options.cpp:72-774)
@@ -263,7 +271,12 @@ struct RecBuf {
     uint32_t *off = nullptr;     // BUF_READS + 1 (pinned)
     faqcs_read_result *res = nullptr; // BUF_READS (pinned)
     std::string defs;
-    std::vector<uint32_t> def_off; // n + 1
+    std::vector<uint32_t> def_off; // n + 1 (deflines copied into `defs`: the streaming path)
+    const char *map_base = nullptr; // deflines left in the memory-mapped input (the mapped path): dpos / dlen
+    std::vector<uint64_t> dpos;
+    std::vector<uint32_t> dlen;
+    const char *def(uint32_t i) const { return map_base ? map_base + dpos[i] : defs.data() + def_off[i]; }
+    uint32_t deflen(uint32_t i) const { return map_base ? dlen[i] : def_off[i + 1] - def_off[i]; }
     uint64_t ticket = 0;
     int dev = 0;                 // index of the context (device) the buffer was submitted to
 
@@ -532,7 +545,7 @@ struct Run {
     }
     void nextseq_check(const RecBuf *b) // trim.cpp:619-626, FaQCs.cpp:272-277,404-414
     {
-        if (quality < 20 && b->n > 0 && b->defs.compare(0, 3, "@NS") == 0) {
+        if (quality < 20 && b->n > 0 && b->deflen(0) >= 3 && memcmp(b->def(0), "@NS", 3) == 0) {
             fprintf(stderr, "The input looks like NextSeq data and the quality level (-q) is adjusted to 20 for trimming.\n");
             quality = 20;
             if (ctx) { for (faqcs_ctx *c : ctxs) check(faqcs_set_quality(c, quality)); } else prm.quality = quality;
@@ -557,7 +570,7 @@ struct Run {
     {
         const faqcs_read_result &x = b->res[i];
         const uint32_t o = b->off[i], len = b->off[i + 1] - o;
-        f.put(b->defs.data() + b->def_off[i], b->def_off[i + 1] - b->def_off[i]); f.put("\n", 1);
+        f.put(b->def(i), b->deflen(i)); f.put("\n", 1);
         const uint8_t *sp = b->seq + o, *qp = b->qual + o;
         if (prm.replace_to_N_q == 0 && prm.input_quality_offset == prm.output_quality_offset && len && sp[0] != 'N' && sp[len - 1] != 'N') {
             // no byte of this record is edited (trim.cpp:390-403,516-525,1191-1216): copy the kept window
@@ -571,7 +584,7 @@ struct Run {
     static void write_raw(OutFile &f, const RecBuf *b, uint32_t i)
     {
         const uint32_t o = b->off[i], len = b->off[i + 1] - o;
-        f.put(b->defs.data() + b->def_off[i], b->def_off[i + 1] - b->def_off[i]); f.put("\n", 1);
+        f.put(b->def(i), b->deflen(i)); f.put("\n", 1);
         f.put((const char *)b->seq + o, len); f.put("\n+\n", 3); f.put((const char *)b->qual + o, len); f.put("\n", 1);
     }
 };
@@ -581,6 +594,474 @@ struct Work {
     bool last = false;
     std::shared_ptr<std::atomic<int>> left; // writers that still read the pair's buffers
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// The mapped path: uncompressed regular files (what a drop-in run on a fast scratch file system or /dev/shm sees).
+// The streaming path above moves every byte through one I/O thread per file (gzread -> line count -> block -> parser), which
+// tops out near 1.3 GB/s per file; here the input is memory-mapped, an index of the 32 768-record buffers is built by
+// counting newlines in parallel, a pool of parser threads fills pinned structure-of-arrays buffers straight from the mapping
+// (deflines stay there), and a pool of formatter threads renders the survivors of finished buffers and pwrite()s them at
+// offsets the gate thread hands out in input order.  Same reference semantics, same C ABI underneath.
+// ---------------------------------------------------------------------------------------------------------
+struct MapFile {
+    const char *p = nullptr; size_t n = 0; int fd = -1;
+    bool open(const std::string &path)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); fd = -1; return false; }
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); fd = -1; return false; }
+            p = (const char *)m;
+            madvise(m, n, MADV_WILLNEED);
+        }
+        return true;
+    }
+    void close() { if (p) munmap((void *)p, n); if (fd >= 0) ::close(fd); p = nullptr; fd = -1; }
+};
+
+// plain text?  (a gzip member starts 1f 8b; anything unreadable takes the streaming path, which reports the error)
+bool is_plain_regular_file(const std::string &path)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    unsigned char m[2] = {0, 0};
+    const size_t got = fread(m, 1, 2, f);
+    fclose(f);
+    return !(got == 2 && m[0] == 0x1f && m[1] == 0x8b);
+}
+
+__attribute__((target("avx2"))) size_t count_newlines_avx2(const char *p, size_t n)
+{
+    size_t c = 0, i = 0;
+    const __m256i nl = _mm256_set1_epi8('\n');
+    for (; i + 32 <= n; i += 32) c += (size_t)__builtin_popcount((unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i)), nl)));
+    for (; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+size_t count_newlines(const char *p, size_t n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return count_newlines_avx2(p, n);
+    size_t c = 0;
+    for (const char *q = p, *e = p + n; q < e;) { const char *x = (const char *)memchr(q, '\n', (size_t)(e - q)); if (!x) break; ++c; q = x + 1; }
+    return c;
+}
+
+// start[k] = byte offset of record k * BUF_READS, start[n_buf] = file size.  The last buffer holds the remainder (possibly
+// nothing: the streaming reader also ends with an empty buffer when the record count is a multiple of BUF_READS).
+std::vector<size_t> index_buffers(const MapFile &f, unsigned threads)
+{
+    const size_t lines_per_buf = 4ull * BUF_READS;
+    const size_t slice = std::max<size_t>(8u << 20, (f.n + threads - 1) / std::max(1u, threads));
+    const size_t n_slices = f.n ? (f.n + slice - 1) / slice : 0;
+    std::vector<size_t> cnt(n_slices, 0);
+    std::atomic<size_t> next{0};
+    auto worker1 = [&] { for (size_t i; (i = next++) < n_slices;) cnt[i] = count_newlines(f.p + i * slice, std::min(slice, f.n - i * slice)); };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < threads && t < n_slices; ++t) th.emplace_back(worker1);
+    worker1();
+    for (auto &t : th) t.join();
+    th.clear();
+    std::vector<size_t> line0(n_slices + 1, 0);
+    for (size_t i = 0; i < n_slices; ++i) line0[i + 1] = line0[i] + cnt[i];
+    const size_t total_nl = line0[n_slices];
+    const size_t n_full = total_nl / lines_per_buf;      // boundaries after newline number lines_per_buf * k, k = 1 .. n_full
+    std::vector<size_t> start(n_full + 2, 0);
+    start[n_full + 1] = f.n;
+    next = 0;
+    auto worker2 = [&] {
+        for (size_t i; (i = next++) < n_slices;) {
+            // boundaries whose newline (1-based index lines_per_buf * k) falls in this slice
+            size_t k = line0[i] / lines_per_buf + 1;
+            if (k * lines_per_buf > line0[i + 1] || k > n_full) continue;
+            const char *q = f.p + i * slice, *e = q + std::min(slice, f.n - i * slice);
+            size_t seen = line0[i];
+            while (q < e && k <= n_full && k * lines_per_buf <= line0[i + 1]) {
+                const char *x = (const char *)memchr(q, '\n', (size_t)(e - q));
+                if (!x) break;
+                ++seen; q = x + 1;
+                if (seen == k * lines_per_buf) { start[k] = (size_t)(q - f.p); ++k; }
+            }
+        }
+    };
+    for (unsigned t = 1; t < threads && t < n_slices; ++t) th.emplace_back(worker2);
+    worker2();
+    for (auto &t : th) t.join();
+    if (n_full && start[n_full] == f.n) { /* the file ends exactly on a buffer boundary: the last buffer is empty */ }
+    return start;
+}
+
+// first '\n' or '\r' in [p, end) (end if none), 32 bytes per step where the CPU has AVX2
+__attribute__((target("avx2"))) const char *find_break_avx2(const char *p, const char *end)
+{
+    const __m256i nl = _mm256_set1_epi8('\n'), cr = _mm256_set1_epi8('\r');
+    for (; p + 32 <= end; p += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)p);
+        const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_or_si256(_mm256_cmpeq_epi8(v, nl), _mm256_cmpeq_epi8(v, cr)));
+        if (m) return p + __builtin_ctz(m);
+    }
+    for (; p < end; ++p) if (*p == '\n' || *p == '\r') return p;
+    return end;
+}
+const char *find_break(const char *p, const char *end)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return find_break_avx2(p, end);
+    for (; p < end; ++p) if (*p == '\n' || *p == '\r') return p;
+    return end;
+}
+// Source::line_end() with one pass over the line: the content ends at the first '\r' or '\n', the line at the next '\n'
+inline const char *line_end_fast(const char *p, const char *end, const char *&next, bool &terminated)
+{
+    const char *x = find_break(p, end);
+    if (x == end) { terminated = false; next = end; return end; }
+    if (*x == '\n') { terminated = true; next = x + 1; return x; }
+    const char *nlp = (const char *)memchr(x, '\n', (size_t)(end - x));
+    terminated = nlp != nullptr;
+    next = nlp ? nlp + 1 : end;
+    return x;
+}
+
+// fastq.cpp:8-125 on the byte range [b0, b1) of a mapped file (same rules and messages as Source::parse_block)
+void parse_range(const char *base, size_t b0, size_t b1, bool eof, RecBuf *b)
+{
+    b->n = 0; b->eof = eof; b->error.clear(); b->map_base = base; b->dpos.clear(); b->dlen.clear();
+    b->dpos.reserve(BUF_READS); b->dlen.reserve(BUF_READS);
+    size_t o = 32;
+    b->off[0] = (uint32_t)o;
+    if ((b1 - b0) + 128 > b->cap) b->grow((b1 - b0) + 128);
+    const char *p = base + b0, *end = base + b1;
+    while (p < end) {
+        const char *nx; bool term;
+        const char *e = line_end_fast(p, end, nx, term);
+        const char *d = p; const size_t dl = (size_t)(e - p);
+        p = nx;
+        if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read sequence"; break; }
+        e = line_end_fast(p, end, nx, term);
+        const size_t slen = (size_t)(e - p);
+        memcpy(b->seq + o, p, slen);
+        p = nx;
+        if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read '+'"; break; }
+        (void)line_end_fast(p, end, nx, term);
+        if (!term) { b->error = "fastq.cpp:next_read: Error reading '+' delimiter"; break; }
+        p = nx;
+        if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read quality"; break; }
+        e = line_end_fast(p, end, nx, term);
+        const size_t qlen = (size_t)(e - p);
+        if (slen != qlen) { b->error = "fastq.cpp:next_read: |Sequence| != |Quality|"; break; }
+        memcpy(b->qual + o, p, qlen);
+        p = nx;
+        o += slen;
+        b->dpos.push_back((uint64_t)(d - base)); b->dlen.push_back((uint32_t)dl);
+        ++b->n;
+        b->off[b->n] = (uint32_t)o;
+    }
+}
+
+struct FastTask { const RecBuf *mine = nullptr, *b1 = nullptr, *b2 = nullptr; char *dst = nullptr; size_t size = 0; int pair_slot = -1; };
+
+// one survivor rendered into memory: the bytes Run::write_read() would put
+char *render_read(const faqcs_params &prm, const RecBuf *b, uint32_t i, char *o)
+{
+    const faqcs_read_result &x = b->res[i];
+    const uint32_t ro = b->off[i], len = b->off[i + 1] - ro;
+    const uint32_t dl = b->deflen(i);
+    memcpy(o, b->def(i), dl); o += dl; *o++ = '\n';
+    const uint8_t *sp = b->seq + ro, *qp = b->qual + ro;
+    if (prm.replace_to_N_q == 0 && prm.input_quality_offset == prm.output_quality_offset && len && sp[0] != 'N' && sp[len - 1] != 'N') {
+        memcpy(o, sp + x.start, x.len); o += x.len; memcpy(o, "\n+\n", 3); o += 3;
+        memcpy(o, qp + x.start, x.len); o += x.len; *o++ = '\n';
+        return o;
+    }
+    uint8_t *so = (uint8_t *)o, *qo = (uint8_t *)o + x.len + 3;
+    faqcs_apply_edits(&prm, sp, qp, len, &x, so, qo);
+    memcpy(o + x.len, "\n+\n", 3);
+    o += 2 * (size_t)x.len + 3; *o++ = '\n';
+    return o;
+}
+
+// FaQCs.cpp:153-538 (paired == true) and :540-757 (paired == false) on mapped inputs
+void process_mapped(Run &r, bool paired)
+{
+    Opt &opt = r.opt;
+    const int nsrc = paired ? 2 : 1;
+    MapFile mf[2];
+    const std::string *paths[2] = {paired ? &opt.in1 : &opt.inu, &opt.in2};
+    for (int s = 0; s < nsrc; ++s)
+        if (!mf[s].open(*paths[s])) {
+            fprintf(stderr, paired ? (s == 0 ? "Unable to open %s for loading read one sequences\n" : "Unable to open %s for loading read two sequences\n")
+                                   : "Unable to open %s for loading unpaired read sequences\n", paths[s]->c_str());
+            throw Fatal("I/O error");
+        }
+    std::thread warm([&] { // the HIP runtime and the library's code object load once per process: start that now
+        if (r.ctx) return;
+        faqcs_params wp; memset(&wp, 0, sizeof(wp));
+        wp.abi_version = FAQCS_ABI_VERSION; wp.mode = FAQCS_MODE_BWA_PLUS; wp.quality = 5; wp.input_quality_offset = 33; wp.output_quality_offset = 33;
+        wp.min_read_length = 50; wp.max_num_poly_N = 2; wp.low_complexity_cutoff_ratio = 0.85f; wp.filterAdapterMismatchRate = 0.2f; wp.kmer = 31;
+        wp.split_size = 1000000; wp.num_subsample = 20; wp.max_read_length = 256;
+        faqcs_ctx *wc = nullptr;
+        if (faqcs_create(&wp, opt.devices.empty() ? -1 : opt.devices[0], &wc) == 0) faqcs_destroy(wc);
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } warm_joiner{warm};
+    const unsigned hw = std::max(2u, opt.num_thread ? opt.num_thread : std::thread::hardware_concurrency());
+    const unsigned n_parse = std::min(16u, std::max(2u, hw / 6)), n_format = std::min(16u, std::max(2u, hw / 6));
+    std::vector<size_t> start[2];
+    for (int s = 0; s < nsrc; ++s) start[s] = index_buffers(mf[s], std::min(32u, hw));
+    tmark("inputs mapped and indexed");
+    const size_t nbuf[2] = {start[0].size() - 1, nsrc == 2 ? start[1].size() - 1 : 0};
+    const size_t n_pairs = nbuf[0]; // the run ends with read one's last buffer (FaQCs.cpp:240-252); a shorter read two fails the pair test first
+
+    // ---- output files --------------------------------------------------------------------------------------
+    int fd_out[2] = {-1, -1};
+    char *out_map[2] = {nullptr, nullptr};
+    size_t out_cap[2] = {0, 0}, out_len[2] = {0, 0};
+    OutFile fu, fdisc;
+    if (!opt.qc_only) {
+        const std::string *outs[2] = {paired ? &opt.out1 : &opt.outu, &opt.out2};
+        // A survivor is never longer than its input record, so the input's size bounds the output's: the file is sized to that,
+        // mapped, written by many threads at once (page faults scale where write() on one inode does not) and cut to its
+        // real length at the end.
+        for (int s = 0; s < nsrc; ++s) {
+            fd_out[s] = ::open(outs[s]->c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+            if (fd_out[s] < 0) throw Fatal("I/O error");
+            out_cap[s] = mf[s].n + 4096;
+            if (ftruncate(fd_out[s], (off_t)out_cap[s]) != 0) throw Fatal("I/O error");
+            void *m = mmap(nullptr, out_cap[s], PROT_READ | PROT_WRITE, MAP_SHARED, fd_out[s], 0);
+            if (m == MAP_FAILED) throw Fatal("I/O error");
+            out_map[s] = (char *)m;
+        }
+        if (paired) fu.open(opt.outu);
+        if (!opt.outd.empty()) fdisc.open(opt.outd);
+    }
+
+    // ---- buffers, parser pool, ordered delivery ----------------------------------------------------------------
+    const int NBUF = 6 + (int)n_parse;
+    std::vector<RecBuf> bufs[2];
+    std::mutex am; std::condition_variable acv;       // buffer assignment: free lists + next buffer number per source
+    std::vector<RecBuf *> free_l[2];
+    size_t next_k[2] = {0, 0};
+    for (int s = 0; s < nsrc; ++s) { bufs[s].resize(NBUF); for (auto &b : bufs[s]) { b.init((size_t)BUF_READS * 176); free_l[s].push_back(&b); } } // (grown on demand)
+    tmark("pinned buffers allocated");
+    struct Slot { RecBuf *b[2] = {nullptr, nullptr}; std::atomic<int> parsed{0}; std::string pair_error, pair_note; };
+    std::vector<Slot> slots(std::max<size_t>(1, std::max(nbuf[0], nbuf[1])));
+    std::mutex rm; std::condition_variable rcv;       // pair k complete
+    std::vector<char> pair_ready(slots.size(), 0);
+    std::atomic<bool> failed{false};
+    std::string werr;
+
+    auto pair_check = [&](Slot &sl) { // FaQCs.cpp:370-389: mate ids, then equal counts; the messages are printed by the main thread in order
+        const RecBuf *b1 = sl.b[0], *b2 = sl.b[1];
+        const uint32_t n = std::min(b1->n, b2->n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const char *d1 = b1->def(i), *d2 = b2->def(i);
+            const size_t l1 = id_len(d1, b1->deflen(i)), l2 = id_len(d2, b2->deflen(i));
+            if (l1 != l2 || memcmp(d1, d2, l1) != 0) {
+                char msg[1024];
+                snprintf(msg, sizeof(msg), "Read one id (%.*s)\ndoes not match\nread two id (%.*s)\n", (int)l1, d1, (int)l2, d2);
+                sl.pair_note = msg; sl.pair_error = "FaQCs.cpp:trim: I/O error";
+                return;
+            }
+        }
+        if (b1->n != b2->n) {
+            const RecBuf *lng = b1->n > b2->n ? b1 : b2;
+            char msg[1024];
+            snprintf(msg, sizeof(msg), "Did not find a match to read %s: %.*s\n", b1->n > b2->n ? "one" : "two", (int)lng->deflen(n), lng->def(n));
+            sl.pair_note = msg; sl.pair_error = "FaQCs.cppI/O error";
+        }
+    };
+    std::mutex tm_m; double t_parse_wait = 0, t_parse_work = 0, t_fmt_render = 0, t_fmt_write = 0, t_fmt_idle = 0;
+    auto parser = [&] {
+        double w_wait = 0, w_work = 0;
+        struct Acc { std::mutex &m; double &a, &b, &x, &y; ~Acc() { std::lock_guard<std::mutex> l(m); a += x; b += y; } } acc{tm_m, t_parse_wait, t_parse_work, w_wait, w_work};
+        for (;;) {
+            int s = -1; size_t k = 0; RecBuf *b = nullptr;
+            const double tp0 = now_s();
+            {
+                std::unique_lock<std::mutex> l(am);
+                for (;;) {
+                    if (failed) return;
+                    // the source that is behind goes first (both files advance together)
+                    s = -1;
+                    for (int c = 0; c < nsrc; ++c) if (next_k[c] < nbuf[c] && (s < 0 || next_k[c] < next_k[s])) s = c;
+                    if (s < 0) return;
+                    if (!free_l[s].empty()) break;
+                    acv.wait(l);
+                }
+                b = free_l[s].back(); free_l[s].pop_back();
+                k = next_k[s]++;
+            }
+            const double tp1 = now_s();
+            parse_range(mf[s].p, start[s][k], start[s][k + 1], k + 1 == nbuf[s], b);
+            w_wait += tp1 - tp0; w_work += now_s() - tp1;
+            Slot &sl = slots[k];
+            sl.b[s] = b;
+            bool complete = nsrc == 1;
+            if (nsrc == 2) {
+                if (k >= nbuf[1 - s]) complete = false;                     // no partner buffer: the pair test of an earlier pair fails first
+                else if (sl.parsed.fetch_add(1) == 1) { pair_check(sl); complete = true; }
+            }
+            if (complete) { { std::lock_guard<std::mutex> l(rm); pair_ready[k] = 1; } rcv.notify_all(); }
+        }
+    };
+    std::vector<std::thread> parsers;
+    for (unsigned t = 0; t < n_parse; ++t) parsers.emplace_back(parser);
+    auto give_back = [&](int s, RecBuf *b) { { std::lock_guard<std::mutex> l(am); free_l[s].push_back(b); } acv.notify_all(); };
+
+    // ---- formatter pool --------------------------------------------------------------------------------------
+    struct PairRef { std::atomic<int> left{0}; RecBuf *b[2] = {nullptr, nullptr}; };
+    std::vector<PairRef> refs(slots.size());
+    Queue<FastTask> fq;
+    std::atomic<size_t> tasks_out{0};
+    auto release_pair = [&](size_t k) { if (refs[k].left.fetch_sub(1) == 1) for (int s = 0; s < nsrc; ++s) if (refs[k].b[s]) give_back(s, refs[k].b[s]); };
+    auto formatter = [&] {
+        double w_r = 0, w_w = 0, w_i = 0;
+        struct Acc3 { std::mutex &m; double &a, &b, &c, &x, &y, &z; ~Acc3() { std::lock_guard<std::mutex> l(m); a += x; b += y; c += z; } } acc{tm_m, t_fmt_render, t_fmt_write, t_fmt_idle, w_r, w_w, w_i};
+        for (;;) {
+            const double tf0 = now_s();
+            FastTask t = fq.pop();
+            const double tf1 = now_s();
+            w_i += tf1 - tf0;
+            if (!t.mine) return;
+            if (t.size) {
+                char *o = t.dst;
+                for (uint32_t i = 0; i < t.mine->n; ++i)
+                    if ((t.b1->res[i].flags & FAQCS_F_VALID) && (!t.b2 || (t.b2->res[i].flags & FAQCS_F_VALID))) o = render_read(r.prm, t.mine, i, o);
+                w_r += now_s() - tf1;
+                if ((size_t)(o - t.dst) != t.size) { werr = "faqcs_mi: internal error, a rendered buffer has the wrong size"; failed = true; acv.notify_all(); rcv.notify_all(); }
+            }
+            release_pair((size_t)t.pair_slot);
+            --tasks_out;
+        }
+    };
+    std::vector<std::thread> formatters;
+    for (unsigned t = 0; t < n_format; ++t) formatters.emplace_back(formatter);
+
+    // ---- gate: device results -> counts, output offsets, singleton / discard files, format tasks (input order) -----------
+    struct GateWork { size_t k = 0; bool last = false, stop = false; };
+    Queue<GateWork> wq;
+    std::atomic<double> t_gate_wait{0.0}, t_gate_loop{0.0};
+    std::thread gate([&] {
+        std::string s, q;
+        off_t off_out[2] = {0, 0};
+        bool cur_last = false;
+        try {
+            for (;;) {
+                GateWork w = wq.pop();
+                if (w.stop) break;
+                cur_last = w.last;
+                RecBuf *b1 = slots[w.k].b[0], *b2 = nsrc == 2 ? slots[w.k].b[1] : nullptr;
+                const double tg0 = now_s();
+                Run::check(faqcs_wait(r.ctxs[b1->dev], b1->ticket));
+                if (b2) Run::check(faqcs_wait(r.ctxs[b2->dev], b2->ticket));
+                const double tg1 = now_s();
+                t_gate_wait = t_gate_wait.load() + (tg1 - tg0);
+                Run::check_read_errors(b1); if (b2) Run::check_read_errors(b2); // trim() throws before anything of the buffer is written
+                size_t sz[2] = {0, 0};
+                for (uint32_t i = 0; i < b1->n; ++i) {
+                    const bool v1 = b1->res[i].flags & FAQCS_F_VALID, v2 = b2 ? (b2->res[i].flags & FAQCS_F_VALID) != 0 : true;
+                    if (v1 && v2) {
+                        if (b2) { r.paired_read_number += 2; r.paired_base_length += b1->res[i].len + b2->res[i].len; }
+                        sz[0] += b1->deflen(i) + 2 * (size_t)b1->res[i].len + 5;
+                        if (b2) sz[1] += b2->deflen(i) + 2 * (size_t)b2->res[i].len + 5;
+                        continue;
+                    }
+                    if (opt.qc_only) continue;
+                    if (b2) {
+                        if (v1) r.write_read(fu, b1, i, s, q);
+                        else if (v2) r.write_read(fu, b2, i, s, q);
+                        if (fdisc.f) { if (!v1) Run::write_raw(fdisc, b1, i); if (!v2) Run::write_raw(fdisc, b2, i); }
+                    } else if (fdisc.f) Run::write_raw(fdisc, b1, i);
+                }
+                refs[w.k].b[0] = b1; refs[w.k].b[1] = b2;
+                refs[w.k].left = opt.qc_only ? 1 : nsrc + 1;
+                if (!opt.qc_only)
+                    for (int m = 0; m < nsrc; ++m) {
+                        FastTask t; t.mine = m ? b2 : b1; t.b1 = b1; t.b2 = b2; t.dst = out_map[m] + off_out[m]; t.size = sz[m]; t.pair_slot = (int)w.k;
+                        off_out[m] += (off_t)sz[m]; out_len[m] = (size_t)off_out[m];
+                        ++tasks_out;
+                        fq.push(t);
+                    }
+                release_pair(w.k);
+                t_gate_loop = t_gate_loop.load() + (now_s() - tg1);
+                if (w.last) break;
+            }
+        } catch (std::exception &e) {
+            werr = e.what();
+            failed = true;
+            acv.notify_all(); rcv.notify_all();
+            while (!cur_last) { GateWork w = wq.pop(); if (w.stop) break; cur_last = w.last; for (int c = 0; c < nsrc; ++c) if (slots[w.k].b[c]) give_back(c, slots[w.k].b[c]); }
+        }
+    });
+
+    // ---- main: pairs in input order -> host preconditions -> device ---------------------------------------------
+    bool check_for_next_seq = true;
+    std::string merr;
+    double t_wait_parse = 0, t_submit = 0;
+    try {
+        for (size_t k = 0; k < n_pairs; ++k) {
+            if (failed) { GateWork w; w.stop = true; wq.push(w); break; }
+            const double tw0 = now_s();
+            { std::unique_lock<std::mutex> l(rm); rcv.wait(l, [&] { return pair_ready[k] != 0 || failed.load(); }); }
+            t_wait_parse += now_s() - tw0;
+            if (failed) { GateWork w; w.stop = true; wq.push(w); break; }
+            Slot &sl = slots[k];
+            RecBuf *b1 = sl.b[0], *b2 = nsrc == 2 ? sl.b[1] : nullptr;
+            if (!sl.pair_note.empty()) fputs(sl.pair_note.c_str(), stderr);
+            if (!sl.pair_error.empty()) throw Fatal(sl.pair_error);
+            if (!b1->error.empty()) throw Fatal(b1->error);
+            if (b2 && !b2->error.empty()) throw Fatal(b2->error);
+            const bool last = b1->eof;
+            if (r.in_off == AUTO_OFFSET) { // FaQCs.cpp:261-270,393-402
+                r.in_off = r.detect(b1);
+                if (b2 && r.in_off != r.detect(b2)) { fprintf(stderr, "Inconsistent quality offset detection between reads one and two\n"); throw Fatal("FaQCs.cpp:process_paired: I/O Error"); }
+            }
+            if (last || check_for_next_seq) { r.nextseq_check(b1); check_for_next_seq = false; } // Q16: also on the last buffer
+            if (k == 0) tmark("first pair parsed");
+            if (warm.joinable()) warm.join();
+            r.ensure_ctx();
+            if (k == 0) tmark("device context(s) ready");
+            const double ts0 = now_s();
+            r.submit(b1, k); if (b2) r.submit(b2, k);
+            t_submit += now_s() - ts0;
+            GateWork w; w.k = k; w.last = last;
+            wq.push(w);
+            if (last) break;
+        }
+    } catch (std::exception &e) { merr = e.what(); failed = true; acv.notify_all(); GateWork w; w.stop = true; wq.push(w); }
+    if (warm.joinable()) warm.join();
+    tmark("last pair submitted");
+    if (getenv("FAQCS_MI_TIMING")) fprintf(stderr, "[faqcs_mi] main thread: %.3f s waiting for parsed pairs, %.3f s in faqcs_submit_async; gate: %.3f s waiting for the device, %.3f s in its own loop\n", t_wait_parse, t_submit, t_gate_wait.load(), t_gate_loop.load());
+    gate.join();
+    tmark("gate done");
+    if (!merr.empty() || !werr.empty() || failed) { // report like the reference's catch in main(); pool threads may be blocked on their queues
+        while (tasks_out.load() != 0) std::this_thread::yield(); // the buffers in front of the failing one are complete files content
+        for (int s = 0; s < nsrc; ++s) if (fd_out[s] >= 0) { if (ftruncate(fd_out[s], (off_t)out_len[s]) != 0) {} ::close(fd_out[s]); }
+        fu.close(); fdisc.close();
+        fprintf(stderr, "Caught the error %s\n", (!werr.empty() ? werr : merr).c_str());
+        _exit(EXIT_FAILURE);
+    }
+    while (tasks_out.load() != 0) std::this_thread::yield();
+    for (size_t t = 0; t < formatters.size(); ++t) fq.push(FastTask());
+    for (auto &t : formatters) t.join();
+    tmark("outputs written");
+    { std::lock_guard<std::mutex> l(am); next_k[0] = nbuf[0]; next_k[1] = nbuf[1]; } // (a longer read two file: its surplus buffers were never wanted)
+    acv.notify_all();
+    for (auto &t : parsers) t.join();
+    if (getenv("FAQCS_MI_TIMING")) fprintf(stderr, "[faqcs_mi] %u parsers: %.3f s parsing, %.3f s waiting for a buffer; %u formatters: %.3f s rendering, %.3f s in pwrite, %.3f s idle (thread-seconds)\n",
+                                           n_parse, t_parse_work, t_parse_wait, n_format, t_fmt_render, t_fmt_write, t_fmt_idle);
+    for (int s = 0; s < nsrc; ++s)
+        if (fd_out[s] >= 0) { munmap(out_map[s], out_cap[s]); if (ftruncate(fd_out[s], (off_t)out_len[s]) != 0) throw Fatal("I/O error"); ::close(fd_out[s]); }
+    // (pinned buffers and mappings are left to process exit: unpinning a gigabyte takes longer than the rest of the epilogue)
+    static std::vector<std::vector<RecBuf>> keep; keep.emplace_back(std::move(bufs[0])); keep.emplace_back(std::move(bufs[1]));
+    fu.close(); fdisc.close();
+    if (r.ctx) Run::check(faqcs_kmer_end_table(r.ctx)); // FaQCs.cpp:518-537
+}
 
 // FaQCs.cpp:153-538
 void process_paired(Run &r)
@@ -662,8 +1143,8 @@ void process_paired(Run &r)
             RecBuf *b1 = s1.pop(), *b2 = s2.pop();
             const uint32_t n = std::min(b1->n, b2->n);
             for (uint32_t i = 0; i < n; ++i) { // FaQCs.cpp:383-389
-                const char *d1 = b1->defs.data() + b1->def_off[i], *d2 = b2->defs.data() + b2->def_off[i];
-                const size_t l1 = id_len(d1, b1->def_off[i + 1] - b1->def_off[i]), l2 = id_len(d2, b2->def_off[i + 1] - b2->def_off[i]);
+                const char *d1 = b1->def(i), *d2 = b2->def(i);
+                const size_t l1 = id_len(d1, b1->deflen(i)), l2 = id_len(d2, b2->deflen(i));
                 if (l1 != l2 || memcmp(d1, d2, l1) != 0) {
                     fprintf(stderr, "Read one id (%.*s)\ndoes not match\nread two id (%.*s)\n", (int)l1, d1, (int)l2, d2);
                     throw Fatal("FaQCs.cpp:trim: I/O error");
@@ -672,7 +1153,7 @@ void process_paired(Run &r)
             if (b1->n != b2->n) { // FaQCs.cpp:370-380
                 const RecBuf *lng = b1->n > b2->n ? b1 : b2;
                 fprintf(stderr, "Did not find a match to read %s: %.*s\n", b1->n > b2->n ? "one" : "two",
-                        (int)(lng->def_off[n + 1] - lng->def_off[n]), lng->defs.data() + lng->def_off[n]);
+                        (int)lng->deflen(n), lng->def(n));
                 throw Fatal("FaQCs.cppI/O error");
             }
             if (!b1->error.empty()) throw Fatal(b1->error);
@@ -944,9 +1425,12 @@ int main(int argc, char **argv)
             return EXIT_FAILURE;
         }
         remove_file(opt.plots_file); remove_file(opt.stats_file); remove_file(opt.out1); remove_file(opt.out2); remove_file(opt.outu); remove_file(opt.outd);
+        tmark("options parsed");
         Run r(opt);
-        if (!opt.in1.empty()) process_paired(r);
-        if (!opt.inu.empty()) process_unpaired(r);
+        // uncompressed regular files take the mapped path; gzip members, pipes and FAQCS_MI_STREAMING=1 the streaming one
+        const bool streaming = getenv("FAQCS_MI_STREAMING") && atoi(getenv("FAQCS_MI_STREAMING")) != 0;
+        if (!opt.in1.empty()) { if (!streaming && is_plain_regular_file(opt.in1) && is_plain_regular_file(opt.in2)) process_mapped(r, true); else process_paired(r); }
+        if (!opt.inu.empty()) { if (!streaming && is_plain_regular_file(opt.inu)) process_mapped(r, false); else process_unpaired(r); }
         r.ensure_ctx();
         faqcs_layout L;
         faqcs_counters_layout(r.R, r.prm.n_adapters, &L);
@@ -977,7 +1461,9 @@ int main(int argc, char **argv)
             else { const std::string t = stats_text(opt, fs, ast, r.quality); fwrite(t.data(), 1, t.size(), f); fclose(f); }
         }
         if (!opt.trim_only && opt.debug) write_tables(opt, L, c.data(), r.R, r.ctx);
-        for (faqcs_ctx *k : r.ctxs) faqcs_destroy(k);
+        tmark("statistics written");
+        fflush(nullptr);
+        _exit(EXIT_SUCCESS); // (device memory, pinned buffers and mappings go with the process)
     } catch (std::exception &e) {
         fprintf(stderr, "Caught the error %s\n", e.what());
         return EXIT_FAILURE;

@@ -1,46 +1,58 @@
-"""Diagnostic: steady-state end-to-end throughput of faqcs_amd/faqcs_mi on a larger uncompressed FASTQ pair.
-Usage: python tests/e2e_big.py [pairs] [extra faqcs flags...]"""
+"""Diagnostic (not a test): end-to-end timing of faqcs_mi on synthetic 2x150 FASTQ files in /dev/shm with stage marks.
+python tests/e2e_big.py [pairs] [extra faqcs_mi args...]"""
 import os
-import resource
 import subprocess
 import sys
-import tempfile
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import make_fixtures  # noqa: E402
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 4_000_000
-extra = sys.argv[2:]
-tmp = tempfile.mkdtemp(prefix="faqcs_big_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 L = 150
-t0 = time.perf_counter()
+base = "/dev/shm/faqcs_e2e_big"
+os.makedirs(base, exist_ok=True)
+blk = 500_000
+seqs, quals = make_fixtures.headline_arrays(2 * blk, L)
+paths = []
 for mate in (1, 2):
-    s, q = make_fixtures.headline_arrays(n, L, mate=mate)
-    ids = np.char.add(np.char.add("@SYN:", np.char.zfill(np.arange(n).astype(str), 9)), "/%d" % mate).astype("S16")
-    rec = np.empty((n, 16 + 1 + L + 3 + L + 1), dtype=np.uint8)
-    rec[:, :16] = ids.view(np.uint8).reshape(n, 16)
-    rec[:, 16] = 10
-    rec[:, 17:17 + L] = s
-    rec[:, 17 + L:20 + L] = np.frombuffer(b"\n+\n", np.uint8)
-    rec[:, 20 + L:20 + 2 * L] = q
-    rec[:, 20 + 2 * L] = 10
-    rec.tofile(os.path.join(tmp, "r%d.fq" % mate))
-    del s, q, rec, ids
-print("generated %d pairs in %.1f s (%s)" % (n, time.perf_counter() - t0, tmp))
-cmd = [os.path.join(ROOT, "faqcs_amd", "faqcs_mi"), "-1", os.path.join(tmp, "r1.fq"), "-2", os.path.join(tmp, "r2.fq"), "-d",
-       os.path.join(tmp, "out"), "--ascii", "33", "--trim_only"] + extra
-for rep in range(2):
-    r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    p = os.path.join(base, "r%d.fq" % mate)
+    paths.append(p)
+    with open(p, "wb") as f:
+        done = 0
+        while done < n:
+            m = min(blk, n - done)
+            idw = 9
+            head = np.frombuffer(b"@SYN:", np.uint8)
+            tail = np.frombuffer(b"/%d\n" % mate, np.uint8)
+            rec = len(head) + idw + len(tail) + L + 3 + L + 1
+            a = np.empty((m, rec), np.uint8)
+            c = 0
+            a[:, c:c + len(head)] = head; c += len(head)
+            ids = np.arange(done, done + m, dtype=np.int64)
+            for k in range(idw):
+                a[:, c + idw - 1 - k] = 48 + (ids // 10 ** k) % 10
+            c += idw
+            a[:, c:c + len(tail)] = tail; c += len(tail)
+            lo = (mate - 1) * blk
+            a[:, c:c + L] = seqs[lo:lo + m]; c += L
+            a[:, c:c + 3] = np.frombuffer(b"\n+\n", np.uint8); c += 3
+            a[:, c:c + L] = quals[lo:lo + m]; c += L
+            a[:, c] = 10
+            a.tofile(f)
+            done += m
+cli = os.path.join(ROOT, "faqcs_amd", "faqcs_mi")
+for env in ({}, {"FAQCS_MI_STREAMING": "1"}):
+    out = os.path.join(base, "out")
+    subprocess.run(["rm", "-rf", out])
     t0 = time.perf_counter()
-    rc = subprocess.run(cmd, stderr=subprocess.DEVNULL).returncode
+    r = subprocess.run([cli, "-1", paths[0], "-2", paths[1], "-d", out, "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + sys.argv[2:],
+                       env=dict(os.environ, FAQCS_MI_TIMING="1", **env), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     dt = time.perf_counter() - t0
-    r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
-    print("faqcs_mi %s rc=%d wall %.2f s (user %.1f sys %.1f) -> %.2f M reads/s end to end, %.2f GB/s of FASTQ text" % (
-        " ".join(extra), rc, dt, r1.ru_utime - r0.ru_utime, r1.ru_stime - r0.ru_stime, 2 * n / dt / 1e6,
-        2 * n * (37 + 2 * L) / dt / 1e9))
-print(open(os.path.join(tmp, "out", "QC.stats.txt")).read()[:300])
-subprocess.run(["rm", "-rf", tmp])
+    print("%s: %d pairs in %.3f s = %.1f M reads/s (rc %d)" % ("streaming" if env else "mapped", n, dt, 2 * n / dt / 1e6, r.returncode))
+    print(r.stderr.decode(errors="replace"))
+subprocess.run(["rm", "-rf", base])
