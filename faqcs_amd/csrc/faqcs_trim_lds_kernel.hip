@@ -955,10 +955,11 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
 #define FAQCS_LDS_CASE(C)                                                                                                 \
     return ext ? (windowed ? launch_trim_lds<C, true, true>(FAQCS_LDS_ARGS) : launch_trim_lds<C, false, true>(FAQCS_LDS_ARGS)) \
                : (windowed ? launch_trim_lds<C, true, false>(FAQCS_LDS_ARGS) : launch_trim_lds<C, false, false>(FAQCS_LDS_ARGS))
+    // measured on MI355X (kernel-only, G reads/s, trim_lds vs trim_tpr): 2x100 7.46 vs 7.10 (C = 13), 2x125 5.64 vs 5.06 on the
+    // C = 19 grid (4.44 on C = 16, whose 128-dword rows put every read of a half wave on the same banks), 2x150 5.8 vs 5.2;
+    // 153..160 bases stay on trim_tpr (the 160-wide slots leave room for 8 waves only: 4.38 vs 4.69)
     if (max_len > 76 && max_len <= 104) FAQCS_LDS_CASE(13);  // 2x100
-    if (max_len > 104 && max_len <= 128) FAQCS_LDS_CASE(16); // 2x125
-    if (max_len > 128 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x150
-    if (max_len > 152 && max_len <= 160) FAQCS_LDS_CASE(20);
+    if (max_len > 104 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x125, 2x150
 #undef FAQCS_LDS_CASE
 #undef FAQCS_LDS_ARGS
     return hipErrorNotSupported;
