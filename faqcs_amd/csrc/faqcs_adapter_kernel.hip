@@ -73,8 +73,8 @@ __device__ __forceinline__ uint32_t plane_match(uint32_t r0, uint32_t r1, uint32
     return and_or_(r3, t.w, and_or_(r2, t.z, and_or_(r1, t.y, r0 & t.x)));
 }
 
-template <int NB, int NBR>
-__device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][2 * NBR + 2], const uint32_t *tpl, const int nw)
+template <int NB, int NBR, bool WANT_CNT = false>
+__device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][2 * NBR + 2], const uint32_t *tpl, const int nw, uint32_t (&cnt_out)[8])
 {
     uint32_t cnt[NB];
 #pragma unroll
@@ -91,6 +91,10 @@ __device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][2 * NBR
         }
     }
     uint32_t m = 0;
+    if (WANT_CNT) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) cnt_out[b] = b < NB ? cnt[b] : 0u;
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) m = umax_(m, cnt[b]);
     return m;
@@ -111,6 +115,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
     __shared__ uint8_t s_mask[NW][MAXLEN];     // vector<bool> mask of trim.cpp:991 (1 = unmasked)
     __shared__ uint32_t s_pl[NW][4][PW];       // the read's four base bit-planes, position ordered (stage 1)
     __shared__ __attribute__((aligned(16))) uint32_t s_tpl[TPL_CAP]; // the adapters' bit-planes (4 dwords per 32 bases)
+    __shared__ uint8_t s_sb[NW][FAQCS_MAX_ADAPTERS][8]; // stage 1 -> stage 2: per 64-diagonal block, an upper bound of its best score (short adapters that may pass)
     __shared__ uint32_t s_bb[NW][136];         // stage 2 on long targets: per 64-diagonal block, an upper bound of its best score
     __shared__ uint32_t s_ast[2 * FAQCS_MAX_ADAPTERS]; // (reads, bases) credited per adapter by this block
     __shared__ uint8_t s_iupac[32];
@@ -316,12 +321,81 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
             }
         };
 
+        // The same alignment for a short adapter whose per-block bounds stage 1 left in s_sb: no bound pass, and the cells come
+        // from MATCH BITS -- the lane's diagonal against the adapter, 32 cells per plane word (8 LDS reads + 4 v_alignbit +
+        // 4 logic ops), instead of one scalar load and one LDS read per cell -- so the Kadane loop waits for nothing.
+        auto align_bits = [&](uint32_t j, int &gM, int &gS, int &gI) {
+            const uint4 me = s_meta[j];
+            const int tlen = (int)me.x;
+            const uint32_t *tpl = s_tpl + 4 * me.y;
+            const int nw = (tlen + 31) >> 5;                              // <= 4
+            const int ndiag = qlen + tlen - 1, n_blocks = (ndiag + 63) >> 6; // <= 8
+            gM = -1; gI = 0; gS = 0;
+            int gJ = 0;
+            int first_block = 0, fb = -1;
+            for (int b = 0; b < n_blocks; ++b) { const int v = (int)s_sb[wave][j][b]; if (v > fb) { fb = v; first_block = b; } }
+#pragma unroll 1
+            for (int k = 0; k <= n_blocks; ++k) {
+                int blk = k - 1;
+                if (k == 0) blk = first_block; else if (blk == first_block) continue;
+                const int bnd = (int)s_sb[wave][j][blk];
+                if (bnd < 1 || bnd < gM) continue;                         // (a local alignment scores at most the matches on its diagonal)
+                const int dd0 = blk << 6;
+                const int d = dd0 + lane - (qlen - 1);                     // j_t - i on this lane's diagonal
+                uint32_t mb[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    mb[w] = 0u;
+                    if (w < nw) {
+                        const int i0 = 32 * w - d;                         // read position facing adapter base 32 w
+                        int idx = i0 >> 5;
+                        idx = idx < -(PADL - 1) ? -(PADL - 1) : (idx > QW + PADL - 2 ? QW + PADL - 2 : idx);
+                        const uint32_t sh = (uint32_t)i0 & 31u;
+                        const uint32_t *pp = pl + idx + PADL;
+                        const uint4 t = *reinterpret_cast<const uint4 *>(tpl + 4 * w);
+                        mb[w] = plane_match(__builtin_amdgcn_alignbit(pp[1], pp[0], sh), __builtin_amdgcn_alignbit(pp[PW + 1], pp[PW], sh),
+                                            __builtin_amdgcn_alignbit(pp[2 * PW + 1], pp[2 * PW], sh), __builtin_amdgcn_alignbit(pp[3 * PW + 1], pp[3 * PW], sh), t);
+                    }
+                }
+                int M = -1, st = 0, bM = -1, bS = 0, bI = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (32 * w < tlen) {
+                        const int kend = tlen - 32 * w < 32 ? tlen - 32 * w : 32;
+                        const uint32_t bits = mb[w];
+#pragma unroll 2
+                        for (int kb = 0; kb < kend; ++kb) {
+                            const int i = 32 * w + kb - d;
+                            const bool valid = (unsigned)i < (unsigned)qlen;
+                            const int sc = ((bits >> kb) & 1u) ? 1 : -1;   // seq_overlap.cpp:157-161
+                            const int nS = (M < 0) ? i : st;               // seq_overlap.cpp:255,272-275
+                            const int nM = (M > 0 ? M : 0) + sc;           // seq_overlap.cpp:185-188
+                            M = valid ? nM : -1;
+                            st = nS;
+                            const bool up = valid && nM >= 0 && nM >= bM;  // seq_overlap.cpp:338-354 (>=: later cell wins)
+                            bM = up ? nM : bM; bS = up ? nS : bS; bI = up ? i : bI;
+                        }
+                    }
+                }
+                const int Mx = (int)wave_max_u32((uint32_t)(bM + 1)) - 1;
+                if (Mx >= 0) {
+                    const uint32_t key = (bM == Mx) ? ((((uint32_t)bI << 13) | (uint32_t)(bI + d)) + 1u) : 0u;
+                    const uint32_t K = wave_max_u32(key) - 1u;
+                    const int wi = (int)(K >> 13), wj = (int)(K & 8191u);
+                    const int wl = wj - wi + (qlen - 1) - dd0;             // lane that owns the winning diagonal
+                    const int ws = __builtin_amdgcn_readlane(bS, wl);
+                    const bool better = Mx > gM || (Mx == gM && (wi > gI || (wi == gI && wj > gJ)));
+                    if (better) { gM = Mx; gI = wi; gJ = wj; gS = ws; }
+                }
+            }
+        };
+
         int best_score = 0, best_j = -1;
         bool have = false, known = false;
         uint32_t last_j = 0;
         int rs = 0, re = 0;
         // ---- stage 1 for every adapter: two bits per adapter (any cell matches / the threshold is reachable) ---------
-        uint64_t m_any = 0, m_pass = 0;
+        uint64_t m_any = 0, m_pass = 0, m_bnd = 0; // m_bnd: stage 1 left the adapter's per-block bounds in s_sb
         auto stage1 = [&](auto nbr_tag) {
             constexpr int NBR = decltype(nbr_tag)::value;
             uint32_t R[4][2 * NBR + 2];
@@ -355,15 +429,30 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
                 const int mcap = qlen < tlen ? qlen : tlen;
                 if (!(dbg & 8u) && MAXLEN <= 320 && tlen <= 128 && tpl_cached) {
                     const uint32_t *tpl = s_tpl + 4 * (sa >> 16);
+                    // (Measured and rejected: leaving a last plane word of <= 3 bases uncompared and counting those bases as matches.
+                    // The weaker bound lets enough random reads through to stage 2 to cost more than the word saves: -8 %.)
                     const int nw = (tlen + 31) >> 5;
+                    constexpr int slack = 0;
                     const int nb = (qlen + tlen - 1 + 63) >> 6;              // blocks past the last diagonal would only add zeros
-                    uint32_t maxcnt;
-                    if (NBR == 4) maxcnt = nb <= 3 ? prefilter_max<3, NBR>(R, tpl, nw) : prefilter_max<4, NBR>(R, tpl, nw);
-                    else if (NBR == 6) maxcnt = nb <= 4 ? prefilter_max<4, NBR>(R, tpl, nw) : prefilter_max<(NBR >= 6 ? 6 : NBR), NBR>(R, tpl, nw);
-                    else maxcnt = nb <= 5 ? prefilter_max<(NBR >= 5 ? 5 : NBR), NBR>(R, tpl, nw) : prefilter_max<NBR, NBR>(R, tpl, nw); // 257..320-base reads
+                    uint32_t maxcnt, cb[8];
+                    if (NBR == 4) maxcnt = nb <= 3 ? prefilter_max<3, NBR>(R, tpl, nw, cb) : prefilter_max<4, NBR>(R, tpl, nw, cb);
+                    else if (NBR == 6) maxcnt = nb <= 4 ? prefilter_max<4, NBR>(R, tpl, nw, cb) : prefilter_max<(NBR >= 6 ? 6 : NBR), NBR>(R, tpl, nw, cb);
+                    else maxcnt = nb <= 5 ? prefilter_max<(NBR >= 5 ? 5 : NBR), NBR>(R, tpl, nw, cb) : prefilter_max<NBR, NBR>(R, tpl, nw, cb); // 257..320-base reads
                     // bound = max over diagonals; only two threshold tests of it are needed
                     any_match = __any(maxcnt > 0u);
-                    may_pass = __any((int)maxcnt >= need_j);
+                    may_pass = __any((int)maxcnt + slack >= need_j);
+                    if (may_pass) { // rare: the per-block bounds for stage 2 (it aligns the most promising block first and prunes the rest)
+                        uint32_t cw[8];
+                        (void)prefilter_max<NBR, NBR, true>(R, tpl, nw, cw);
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            if (b < NBR && b < nb) {
+                                const uint32_t bnd = wave_max_u32(cw[b]) + (uint32_t)slack;
+                                if (lane == 0) s_sb[wave][j][b] = (uint8_t)(bnd > 255u ? 255u : bnd);
+                            }
+                        }
+                        m_bnd |= 1ull << j;
+                    }
                 } else if (!(dbg & 8u) && MAXLEN <= 320 && NBR >= 6 && tpl_cached) {
                     // long target (PhiX, artifact sequences): the same register windows, sliding over the target two words
                     // per step.  Words 2u and 2u+1 face exactly the NBR+1 blocks u-1 .. u+NBR-1 (window index 2 NBR - 2i and
@@ -449,7 +538,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
                 if (any_match) {
                     if (!may_pass) { have = true; known = false; last_j = j; continue; } // cannot mask, cannot be credited
                     int gM, gS, gI;
-                    align_exact(j, gM, gS, gI);
+                    if ((m_bnd >> j) & 1ull) align_bits(j, gM, gS, gI); else align_exact(j, gM, gS, gI);
                     if (gM >= 0) { have = true; known = true; last_j = j; rs = gS; re = gI; score = gM; }
                     else if (!have) continue;                                // (only reachable with the prefilter disabled)
                 } else {

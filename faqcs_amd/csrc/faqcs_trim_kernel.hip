@@ -1257,6 +1257,7 @@ __global__ __launch_bounds__(NT) void composition_histogram(const unsigned long 
     constexpr uint32_t FLUSH_EVERY = 65535u / NT;
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t i = (r * gridDim.x + blockIdx.x) * NT + tid;
+        uint32_t nbin = 0xffffffffu; // this thread's N bin (none)
         if (i < n) {
             unsigned long long x, y = 0;
             if (WIDE) { const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(rec)[i]; x = v.x; y = v.y; }
@@ -1279,9 +1280,23 @@ __global__ __launch_bounds__(NT) void composition_histogram(const unsigned long 
                 idx[5] = idx[3] + idx[2];                                                                                  // :874 (G + C)
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
+                    if (k == 4) continue; // N: below
                     const uint32_t e = idx[k] * FAQCS_NCOMP_KIND + k;
                     atomicAdd(&tab[e >> 1], 1u << (16 * (e & 1u)));
                 }
+                nbin = idx[4] * FAQCS_NCOMP_KIND + 4;
+            }
+        }
+        // The N bin is the same for nearly every read (no N at all: bin 0): 64 lanes adding to ONE LDS address serialise, and
+        // that one kind cost more than the other five together.  The lanes of a wave that share a bin add their count once.
+        {
+            unsigned long long todo = __ballot(nbin != 0xffffffffu);
+            while (todo) {
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)nbin, leader);
+                const unsigned long long same = __ballot(nbin == v);
+                if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&tab[v >> 1], (uint32_t)__popcll(same) << (16 * (v & 1u)));
+                todo &= ~same;
             }
         }
         if (((r + 1) % FLUSH_EVERY) == 0 || r + 1 == rounds) {
