@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--config", choices=["plain", "adapter", "kmer"], default="plain",
                     help="plain = BASELINE configs[1] (the headline), adapter = configs[2], kmer = configs[4]'s shape on one GPU")
     ap.add_argument("--batch-reads", type=int, default=1 << 24, help="reads per submission (u32 offsets: < 4 GiB arena)")
+    ap.add_argument("--at-frac", type=float, default=None, help="A+T fraction of the synthetic bases (default: uniform ACGT); 0.9 makes most "
+                    "reads dinucleotide candidates of the low-complexity filter (an AT-rich genome)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_E2E_PAIRS", 8e6)),
                     help="pairs of the same workload written as FASTQ to /dev/shm for the end-to-end (files in, files out) run of faqcs_mi; 0 = skip")
@@ -198,6 +200,8 @@ def launch_ranks(a, real_stdout):
 
 def main():
     a = parse()
+    if a.at_frac is not None:
+        os.environ["FAQCS_SYNTH_AT"] = repr(a.at_frac)
     # stdout carries exactly ONE JSON line: whatever a library prints there (gloo, the HIP runtime) goes to stderr instead
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
@@ -357,8 +361,8 @@ def main():
             "ranks_seen": ranks_seen,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "synthetic %.0fM-pair 2x%dbp Q33 reads resident in HBM per GPU, BWA_plus -q 5 --min_L 50%s, "
-                                   "1 step = 1 pass (%s%s%s + counter all-reduce)"
+            "config": {"workload": ("synthetic %.0fM-pair 2x%dbp Q33 reads" + ("" if a.at_frac is None else " (A+T = %g of the bases)" % a.at_frac) + " resident in HBM per GPU, BWA_plus -q 5 --min_L 50%s, "
+                                    "1 step = 1 pass (%s%s%s + counter all-reduce)")
                                    % (n_reads / 2e6, L, {"adapter": " --adapter --polyA (5 percent read-through)", "kmer": " --kmer_rarefaction, genome-sampled reads"}.get(a.config, ""),
                                       {"adapter": "adapter_overlap, then ", "kmer": ""}.get(a.config, ""), trim_kernel, {"kmer": " + kmer_count"}.get(a.config, "")),
                        "pairs_per_gpu": n_reads // 2, "read_len": L, "launches_per_step": len(batches) * (2 if a.config == "adapter" else 1),

@@ -69,7 +69,7 @@ hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *d
                                        unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
                                        hipStream_t st);
 hipError_t faqcs_launch_synth(uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads, uint32_t L,
-                              uint64_t seed, uint64_t first_read, float adapter_frac, uint64_t genome_len, hipStream_t st);
+                              uint64_t seed, uint64_t first_read, float adapter_frac, uint64_t genome_len, float at_frac, hipStream_t st);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -921,7 +921,8 @@ static int synth_fill_impl(int device_id, uint8_t *d_seq, uint8_t *d_qual, uint3
 {
     if (device_id >= 0) HIPCHK(hipSetDevice(device_id));
     if ((uint64_t)n_reads * L + L > 0xffffffffull) return fail(FAQCS_E_INVAL, "faqcs_synth_fill: arena exceeds 32-bit offsets");
-    HIPCHK(faqcs_launch_synth(d_seq, d_qual, d_offset, n_reads, L, seed, first_read, adapter_frac, genome_len, nullptr));
+    const char *at = getenv("FAQCS_SYNTH_AT"); // (A+T fraction of the synthetic bases; unset: uniform ACGT)
+    HIPCHK(faqcs_launch_synth(d_seq, d_qual, d_offset, n_reads, L, seed, first_read, adapter_frac, genome_len, at ? (float)atof(at) : -1.0f, nullptr));
     HIPCHK(hipDeviceSynchronize());
     return 0;
 }

@@ -36,8 +36,10 @@ __device__ __forceinline__ uint32_t rnd(uint64_t seed, uint64_t read, uint32_t a
 __device__ __forceinline__ uint32_t below(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
 } // namespace
 
+// at_frac < 0: bases uniform over ACGT (the SURVEY recipe); otherwise A+T make up at_frac of the bases (AT-rich genomes: the
+// dinucleotide-candidate path of the low-complexity filter becomes visible)
 __global__ void synth_fill(uint8_t *seq, uint8_t *qual, uint32_t *offset, uint32_t n_reads, uint32_t L, uint64_t seed,
-                           uint64_t first_read, float adapter_frac, uint64_t genome_len)
+                           uint64_t first_read, float adapter_frac, uint64_t genome_len, float at_frac)
 {
     const uint64_t total = (uint64_t)n_reads * L;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total + n_reads + 1; g += (uint64_t)gridDim.x * blockDim.x) {
@@ -51,6 +53,7 @@ __global__ void synth_fill(uint8_t *seq, uint8_t *qual, uint32_t *offset, uint32
         // base
         uint32_t x = rnd(seed, R, 1, p);
         uint8_t b = "ACGT"[x & 3u];
+        if (at_frac >= 0.f) b = ((x >> 8) < (uint32_t)((double)at_frac * 16777216.0)) ? "AT"[x & 1u] : "CG"[x & 1u];
         if (genome_len > L) {
             const uint64_t start = mix(mix(seed ^ 0x67656e6f6d65ull) + R) % (genome_len - L);
             const bool rc = (rnd(seed, R, 0, 6) & 1u) != 0;
@@ -80,8 +83,8 @@ __global__ void synth_fill(uint8_t *seq, uint8_t *qual, uint32_t *offset, uint32
 }
 
 hipError_t faqcs_launch_synth(uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads, uint32_t L,
-                              uint64_t seed, uint64_t first_read, float adapter_frac, uint64_t genome_len, hipStream_t st)
+                              uint64_t seed, uint64_t first_read, float adapter_frac, uint64_t genome_len, float at_frac, hipStream_t st)
 {
-    hipLaunchKernelGGL(synth_fill, dim3(256 * 16), dim3(256), 0, st, d_seq, d_qual, d_offset, n_reads, L, seed, first_read, adapter_frac, genome_len);
+    hipLaunchKernelGGL(synth_fill, dim3(256 * 16), dim3(256), 0, st, d_seq, d_qual, d_offset, n_reads, L, seed, first_read, adapter_frac, genome_len, at_frac);
     return hipGetLastError();
 }

@@ -826,12 +826,49 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     // dc[X->Y] <= min(count X, count Y): only pairs whose two counts both reach dthr can trip
                     dinuc = !lc_trip && ((cA >= dthr) + (cT >= dthr) + (cC >= dthr) + (cG >= dthr)) >= 2;
                 }
-                // exact per-position pass over the bases: N counts for reads with other letters, transition counts for
-                // dinucleotide candidates (both rare)
-                if (__any(abn_seq || dinuc)) {
-                    const ExactB xb = exact_bases(seq, v_off, len, a, n, abn_seq || dinuc, dinuc, dthr);
+                // Dinucleotide candidates (two bases that each fill >= dthr of the kept window: AT- or GC-rich genomes).  At most two
+                // classes can reach dthr when it exceeds a third of the window (the default --lc 0.85: 42.5 %), and then only the two
+                // transitions between them can trip: count those two over the window, from the staged bases.  More candidate
+                // classes (a small --lc) take the general pass below.
+                bool dinuc_general = false;
+                if (__any(dinuc)) {
+                    const int ncand = (int)(cA >= dthr) + (int)(cT >= dthr) + (int)(cC >= dthr) + (int)(cG >= dthr);
+                    dinuc_general = dinuc && ncand > 2;
+                    const bool two = dinuc && ncand == 2;
+                    // one-hot byte masks (the table's A, T, C, G fields) of the lane's two candidate classes
+                    const uint32_t mA = cA >= dthr ? 0x000000ffu : 0u, mT = cT >= dthr ? 0x0000ff00u : 0u, mC = cC >= dthr ? 0x00ff0000u : 0u,
+                                   mG = cG >= dthr ? 0xff000000u : 0u;
+                    const uint32_t both = mA | mT | mC | mG;
+                    const uint32_t mx = (both & 0xffu) ? 0xffu : (both & 0xff00u) ? 0xff00u : (both & 0xff0000u) ? 0xff0000u : (both ? 0xff000000u : 0u);
+                    const uint32_t my_ = both & ~mx; // X = the lower field, Y = the other one
+                    uint32_t dxy = 0, dyx = 0, prevx = 0, prevy = 0; // prev*: the previous window position held X / Y
+                    const int k0 = a >> 2, k1 = (a + n + 3) >> 2;
+                    const int kmax2 = uni((int)wave_max_u32((uint32_t)(two && k1 > k0 ? k1 - k0 : 0)));
+#pragma unroll 1
+                    for (int i = 0; i < kmax2; ++i) {
+                        const int k = k0 + i;
+                        const uint32_t w = lds_ld_any(slot_b + rows + 4u * (uint32_t)k);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int p = 4 * k + j;
+                            const uint32_t ad = (j == 0 ? byte_x8<0>(w, three) : j == 1 ? byte_x8<1>(w, three)
+                                                 : j == 2 ? byte_x8<2>(w, three) : byte_x8<3>(w, three)) + (uint32_t)(T::O_T2 * 4);
+                            uint32_t ex = ((lds_u2c_ptr)(size_t)ad)->x;
+                            ex = ((unsigned)(p - a) < (unsigned)n) ? ex : 0u; // outside the window: no class (resets `last`, trim.cpp:405-513)
+                            const uint32_t isx = (ex & mx) ? 1u : 0u, isy = (ex & my_) ? 1u : 0u;
+                            dxy += prevx & isy;
+                            dyx += prevy & isx;
+                            prevx = isx; prevy = isy;
+                        }
+                    }
+                    if (two) lc_trip = lc_trip || dxy >= dthr || dyx >= dthr;
+                }
+                // exact per-position pass over the arena: N counts for reads with other letters, every transition count for the
+                // general dinucleotide case (both rare)
+                if (__any(abn_seq || dinuc_general)) {
+                    const ExactB xb = exact_bases(seq, v_off, len, a, n, abn_seq || dinuc_general, dinuc_general, dthr);
                     if (abn_seq) { pN = xb.npre; cN = xb.npost; }
-                    if (dinuc) lc_trip = lc_trip || xb.trip;
+                    if (dinuc_general) lc_trip = lc_trip || xb.trip;
                     // S-B looks a base outside the kept window up at (byte ^ 1): a letter that is no base must not pass for one
                     if (__any(abn_seq)) {
 #pragma unroll 1

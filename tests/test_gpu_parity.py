@@ -595,3 +595,37 @@ def test_native_cli_mapped_path_equals_streaming_path(args, tmp_path):
     assert sorted(outs[0]) == sorted(outs[1])
     for fn in outs[0]:
         assert outs[0][fn] == outs[1][fn], "%s differs between the mapped and the streaming path" % fn
+
+
+@pytest.mark.parametrize("args", [[], ["--lc", "0.5"], ["--lc", "0.3", "--min_L", "20"], ["--adapter"]], ids=["default", "lc05", "lc03", "adapter"])
+def test_at_rich_reads_match_oracle(args):
+    """AT- and GC-rich reads: two bases each fill more than dthr of the kept window, so the dinucleotide part of the
+    low-complexity filter (trim.cpp:405-513) has to count transitions exactly -- the two-class counter of trim_lds at the
+    default --lc, the general pass at small --lc -- including reads that do trip it (alternating ATAT.. stretches)."""
+    rng = np.random.Generator(np.random.PCG64([77, SEED]))
+    opt = parse_args(["-u", "x", "-d", "y", "--ascii", "33"] + args)
+    reads = []
+    for i in range(2500):
+        L = int(rng.integers(60, 151))
+        kind = i % 5
+        if kind == 0:
+            p = [0.46, 0.46, 0.04, 0.04]      # AT-rich, random order
+        elif kind == 1:
+            p = [0.05, 0.05, 0.45, 0.45]      # GC-rich
+        elif kind == 2:
+            p = [0.5, 0.5, 0.0, 0.0]          # only A and T
+        else:
+            p = [0.3, 0.3, 0.2, 0.2]
+        s = np.frombuffer(b"ATCG", np.uint8)[rng.choice(4, L, p=p)].copy()
+        if kind == 3:                          # mostly alternating: trips
+            s[: L - 10] = np.frombuffer(b"AT" * 80, np.uint8)[: L - 10]
+            flips = rng.integers(0, L - 10, 6)
+            s[flips] = ord("A")
+        if kind == 4 and L > 40:               # a lower-case stretch and an N inside the run
+            s[10:30] = np.frombuffer(bytes(s[10:30]).lower(), np.uint8)
+            s[35] = ord("N")
+        q = (rng.integers(25, 41, L) + 33).astype(np.uint8)
+        if rng.random() < 0.4:
+            q[int(rng.integers(L // 2, L)):] = 35
+        reads.append((b"@x", s.tobytes(), q.tobytes()))
+    compare_engines(opt, reads, seg_size=700)
