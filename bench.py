@@ -242,8 +242,6 @@ def main():
     from faqcs_amd.engine import HipEngine, _check
     from faqcs_amd.options import parse_args
 
-    if a.config == "kmer" and world > 1:
-        raise SystemExit("bench: --config kmer measures one GPU (the multi-GPU k-mer exchange is faqcs_amd/parallel.py:KmerExchange)")
     L = a.read_len or (250 if a.config == "kmer" else 150)
     if a.config == "kmer" and a.pairs == 100e6:
         a.pairs = 10e6  # 20 M reads of 250 bases from a 50 Mbp synthetic genome: 4.4 G k-mer occurrences per step
@@ -286,13 +284,38 @@ def main():
 
     kmer_seen = [0, 0]
 
+    # k-mers across ranks: every canonical k-mer has one owner rank; a rank buckets the (key, epoch) pairs of its
+    # shard by owner, RCCL all-to-all moves them, the owner inserts.  The epoch of a 32 768-read segment comes from the GLOBAL
+    # sampling schedule (rank-major order of the shards): parallel.rarefaction_schedule.
+    kx, kmer_epochs, kmer_points_seq = None, None, None
+    if a.config == "kmer" and world > 1:
+        sizes = []
+        for _r in range(world):
+            for (_s, _q, _o, _res, seg, _bt, _m) in batches:  # (every rank holds batches of the same shape)
+                sizes.extend(int(seg[i + 1] - seg[i]) for i in range(len(seg) - 1))
+        ep, kmer_points_seq = parallel.rarefaction_schedule(sizes, opt.split_size, opt.num_subsample)
+        per_rank = len(sizes) // world
+        kmer_epochs = ep[rank * per_rank:(rank + 1) * per_rank]
+        kx = parallel.KmerExchange(eng, rank, world, opt.num_subsample)
+    kmer_last = {}
+
     def step():
         _check(lib, lib.faqcs_reset_counters(eng.ctx))  # one step = one job: its counter block starts at zero
-        if a.config == "kmer":  # ... and so does its k-mer table (the totals of the finished pass are kept for the report)
+        if a.config == "kmer" and kx is None:  # ... and so does its k-mer table (the totals of the finished pass are kept for the report)
             kmer_seen[0], kmer_seen[1] = eng.kmer_totals()
             eng.kmer_end_table()
-        for (_s, _q, _o, res, _seg, bt, _m) in batches:
+        e0 = 0
+        for (_s, _q, _o, res, seg, bt, _m) in batches:
+            if kx is not None:
+                eng.kmer_set_epochs(kmer_epochs[e0:e0 + len(seg) - 1])
+                e0 += len(seg) - 1
             _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(bt), res.data_ptr()))
+            if kx is not None:
+                kx.exchange()
+        if kx is not None:  # the additive epoch histograms -> the job's rarefaction points (one small all-reduce); fresh tables
+            pts, _hist = kx.finish(kmer_points_seq, n_reads * world)
+            kmer_last["points"] = len(pts)
+            kmer_last["distinct"], kmer_last["total"] = (pts[-1][1], pts[-1][2]) if pts else (0, 0)
         if world > 1:
             parallel.allreduce_counters_device(eng)
         else:
@@ -368,7 +391,12 @@ def main():
                        "pairs_per_gpu": n_reads // 2, "read_len": L, "launches_per_step": len(batches) * (2 if a.config == "adapter" else 1),
                        "M_pairs_per_s": round(value / 2, 3)},
         }
-        if a.config == "kmer":
+        if a.config == "kmer" and kx is not None:
+            out["kmer"] = {"G_inserts_per_s": round(kmer_last.get("total", 0) / (dt / a.steps) / 1e9, 3), "distinct_at_last_point": int(kmer_last.get("distinct", 0)),
+                           "occurrences_at_last_point": int(kmer_last.get("total", 0)), "points": int(kmer_last.get("points", 0)),
+                           "note": "owner-partitioned tables: (key, epoch) pairs bucketed by owner on the device, all-to-all over the process group, "
+                                   "owner-side insert; distinct / total from the all-reduced epoch histograms"}
+        elif a.config == "kmer":
             d_, t_ = eng.kmer_totals()
             out["kmer"] = {"G_inserts_per_s": round(t_ / (dt / a.steps) / 1e9, 3), "distinct_per_step": int(d_), "occurrences_per_step": int(t_),
                            "note": "canonical 31-mers of the kept reads into the device hash table (reset every step); bound by the L2 atomic rate"}

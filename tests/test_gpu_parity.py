@@ -268,7 +268,7 @@ def test_kmer_matches_oracle():
         assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
 
 
-def _kmer_rank(rank, world, port, args, n_reads, seg_size, out):
+def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150):
     import os
     import sys
 
@@ -287,7 +287,7 @@ def _kmer_rank(rank, world, port, args, n_reads, seg_size, out):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     rng = np.random.Generator(np.random.PCG64(4242))
-    reads = random_batch(rng, n_reads, 150, "adv")
+    reads = random_batch(rng, n_reads, maxlen, "adv")
     segs = [reads[i:i + seg_size] for i in range(0, n_reads, seg_size)]
     epochs, points = parallel.rarefaction_schedule([len(s) for s in segs], opt.split_size, opt.num_subsample)
     lo, hi = parallel.shard_bounds(len(segs), rank, world)
@@ -315,12 +315,13 @@ def _kmer_rank(rank, world, port, args, n_reads, seg_size, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("args,n_reads", [
-    (["--kmer_rarefaction", "--split_size", "300", "--subset", "4"], 3000),   # curve completes mid-run
-    (["--kmer_rarefaction", "--split_size", "700"], 2600),                       # curve still open at the end
-    (["--kmer_rarefaction", "--split_size", "5000", "--qc_only"], 1500),         # no scheduled point: the fallback one
-], ids=["complete", "open", "fallback"])
-def test_two_rank_kmer_exchange(args, n_reads, tmp_path):
+@pytest.mark.parametrize("args,n_reads,maxlen", [
+    (["--kmer_rarefaction", "--split_size", "300", "--subset", "4"], 3000, 150),   # curve completes mid-run
+    (["--kmer_rarefaction", "--split_size", "700"], 2600, 150),                       # curve still open at the end
+    (["--kmer_rarefaction", "--split_size", "5000", "--qc_only"], 1500, 150),         # no scheduled point: the fallback one
+    (["--kmer_rarefaction", "--split_size", "400", "--subset", "200"], 2400, 250),    # BASELINE configs[4]'s shape: 2x250, --subset 200
+], ids=["complete", "open", "fallback", "len250_subset200"])
+def test_two_rank_kmer_exchange(args, n_reads, maxlen, tmp_path):
     """owner-partitioned k-mer tables, (key, epoch) all-to-all (gloo here, two ranks sharing the
     one GPU of the box), additive epoch histograms -> the same rarefaction points and count histogram as one process."""
     import socket
@@ -332,7 +333,7 @@ def test_two_rank_kmer_exchange(args, n_reads, tmp_path):
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "result.txt")
-    mp.spawn(_kmer_rank, args=(2, port, args, n_reads, 333, out), nprocs=2, join=True)
+    mp.spawn(_kmer_rank, args=(2, port, args, n_reads, 333, out, maxlen), nprocs=2, join=True)
     assert open(out).read() == "ok", open(out).read()
 
 
