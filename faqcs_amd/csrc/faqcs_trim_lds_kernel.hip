@@ -357,6 +357,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             bpost[j] += e.y;
         }
     };
+    // (Measured and not kept: a 160-wide table grid with the four rows of a half wave started 0..3 positions apart, which makes
+    // the ds_add of the position x quality pass conflict-free by construction -- SQ_LDS_BANK_CONFLICT 22.6 -> 13.7 and
+    // SQ_LDS_IDX_ACTIVE 51 -> 44 clocks per read, but +3 VALU per read for the 20th position and the wrapped steps, and the
+    // same 5.7 G reads/s: the waves wait on LDS round trips, not on LDS throughput.)
     // the loop over the 8 reads of a lane's row (a deeper software pipeline -- info two reads ahead, LDS bytes one read ahead --
     // was measured: +5 VALU per read for the register copies and no shorter waits; the LDS pipeline itself is the limit)
 #define FAQCS_B_LOOP(I0, I1, CELLS)                                                                                   \
