@@ -31,6 +31,14 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// dwords in flight per LDS wait of the two lane-per-read passes (tuned on MI355X)
+#ifndef FAQCS_LDS_SUM_UNROLL
+#define FAQCS_LDS_SUM_UNROLL 4
+#endif
+#ifndef FAQCS_LDS_SA_UNROLL
+#define FAQCS_LDS_SA_UNROLL 2
+#endif
+
 namespace {
 
 template <int C, int NW> struct LdsCfg {
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 const int kmax = uni((int)wave_max_u32((uint32_t)nfull));
                 const uint32_t qa = slot_b + rowq, qa4 = qa & ~3u, qsh = qa & 3u;
                 uint32_t prev = lds_ld(qa4);
-#pragma unroll 4
+#pragma unroll FAQCS_LDS_SUM_UNROLL
                 for (int k = 0; k < kmax; ++k) {
                     const uint32_t nxt = lds_ld(qa4 + 4u * (uint32_t)k + 4u);
                     uint32_t w = __builtin_amdgcn_alignbyte(nxt, prev, qsh);
@@ -722,7 +730,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     uint32_t nw = 0;
                     const int kend = (8 * wd + 8 < ND) ? 8 * wd + 8 : ND;
                     if (8 * wd < kmax) { // (wave-uniform)
-#pragma unroll 2
+#pragma unroll FAQCS_LDS_SA_UNROLL
                         for (int k = 8 * wd; k < kend; ++k) {
                             const uint32_t nxt = lds_ld(sa4 + 4u * (uint32_t)k + 4u);
                             uint32_t w = __builtin_amdgcn_alignbyte(nxt, prev, ssh);
