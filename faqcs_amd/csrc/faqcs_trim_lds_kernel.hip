@@ -755,8 +755,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     nub[wd] = nw;
                 }
                 if ((NPOS & 31) != 0) nub[NWORD - 1] >>= (32 - (NPOS & 31));
-                if (ka >= ND) sA = cnt4;
-                if (ke >= ND) sE = cnt4;
+                if (ka >= kmax) sA = cnt4; // (the loops stop at the wave's longest read: a window end on that read's last dword
+                if (ke >= kmax) sE = cnt4; //  boundary is never visited; nothing is counted past kmax, so the total is the prefix)
                 const int nACGT = (int)__builtin_amdgcn_sad_u8(cnt4, 0u, 0u);
                 int nup = 0;
 #pragma unroll

@@ -630,3 +630,24 @@ def test_at_rich_reads_match_oracle(args):
             q[int(rng.integers(L // 2, L)):] = 35
         reads.append((b"@x", s.tobytes(), q.tobytes()))
     compare_engines(opt, reads, seg_size=700)
+
+
+@pytest.mark.parametrize("args", [[], ["--lc", "0.5"], ["--mode", "BWA"], ["--avg_q", "20", "-n", "1"]], ids=["default", "lc05", "bwa", "avgq"])
+@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 148, 150, 152, 156, 160])
+def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, args):
+    """Every read of the batch has the same length (mostly a multiple of 4: the wave's dword loops stop exactly at the read's
+    end), a low-quality head that the 5' walk cuts and a high-quality tail, so the kept window is [a, L) with a > 0: its base
+    counts are (total) - (prefix in front of a).  Found by fuzzing: the prefix at a window end on the wave's last dword boundary
+    was never captured for widths where that boundary is not the slot's last dword."""
+    rng = np.random.Generator(np.random.PCG64([91, L, SEED]))
+    opt = parse_args(["-u", "x", "-d", "y", "--min_L", "1"] + args)
+    reads = []
+    for i in range(900):
+        s = np.frombuffer(b"ACGTNacgt", np.uint8)[rng.choice(9, L, p=[.235, .235, .235, .235, .02, .01, .01, .01, .01])].copy()
+        q = (rng.integers(28, 41, L) + 33).astype(np.uint8)
+        head = int(rng.integers(0, min(L, 12))) if i % 3 else 0
+        q[:head] = 33 + rng.integers(0, 4, head)
+        if i % 7 == 0 and L > 20:
+            q[L - int(rng.integers(1, 9)):] = 34      # some reads do lose their tail
+        reads.append((b"@x", s.tobytes(), q.tobytes()))
+    compare_engines(opt, reads, seg_size=300)
