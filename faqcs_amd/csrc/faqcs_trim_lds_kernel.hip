@@ -1007,6 +1007,10 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
     // measured on MI355X (kernel-only, G reads/s, trim_lds vs trim_tpr): 2x100 7.46 vs 7.10 (C = 13), 2x125 5.64 vs 5.06 on the
     // C = 19 grid (4.44 on C = 16, whose 128-dword rows put every read of a half wave on the same banks), 2x150 5.8 vs 5.2;
     // 153..160 bases stay on trim_tpr (the 160-wide slots leave room for 8 waves only: 4.38 vs 4.69)
+    // Lane-per-read passes read "their" read at a lane stride of one read length: equal-length reads of 4 x (a multiple of 8)
+    // bases put 8 (96 bases) or 32 (128 bases) lanes on each LDS bank -- 2x128 runs at 3.2 G reads/s here against 5.0 on
+    // trim_tpr, 2x96 6.2 against 6.7 (profiles/r2c/len_sweep.txt); 4-way strides (112, 144) are a toss-up and stay.
+    if (max_len % 32 == 0) return hipErrorNotSupported;
     if (max_len > 76 && max_len <= 104) FAQCS_LDS_CASE(13);  // 2x100
     if (max_len > 104 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x125, 2x150
 #undef FAQCS_LDS_CASE

@@ -633,7 +633,7 @@ def test_at_rich_reads_match_oracle(args):
 
 
 @pytest.mark.parametrize("args", [[], ["--lc", "0.5"], ["--mode", "BWA"], ["--avg_q", "20", "-n", "1"]], ids=["default", "lc05", "bwa", "avgq"])
-@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 148, 150, 152, 156, 160])
+@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 128, 144, 148, 150, 152, 156, 160])
 def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, args):
     """Every read of the batch has the same length (mostly a multiple of 4: the wave's dword loops stop exactly at the read's
     end), a low-quality head that the 5' walk cuts and a high-quality tail, so the kept window is [a, L) with a > 0: its base
@@ -651,3 +651,25 @@ def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, a
             q[L - int(rng.integers(1, 9)):] = 34      # some reads do lose their tail
         reads.append((b"@x", s.tobytes(), q.tobytes()))
     compare_engines(opt, reads, seg_size=300)
+
+
+@pytest.mark.parametrize("L,args,kernel", [
+    (150, [], "trim_lds"), (151, ["--adapter"], "trim_lds"), (100, ["--mode", "HARD", "-q", "10"], "trim_lds"), (125, ["--qc_only"], "trim_lds"),
+    (128, [], "trim_tpr"), (96, [], "trim_tpr"), (75, [], "trim_tpr"), (160, [], "trim_tpr"),
+    (150, ["--replace_to_N_q", "15"], "trim_filter_accumulate"), (250, [], "trim_filter_accumulate"), (128, ["--qc_only"], "trim_filter_accumulate"),
+])
+def test_dispatcher_picks_the_documented_trim_kernel(L, args, kernel):
+    """DESIGN.md section 4 names the trim kernel of every (read length, option set) class; faqcs_kernel_report() says which one ran."""
+    import ctypes as C
+
+    rng = np.random.Generator(np.random.PCG64([5, L, SEED]))
+    opt = parse_args(["-u", "x", "-d", "y"] + args)
+    reads = [(b"@x", make_uniform(rng, L), bytes((rng.integers(20, 41, L) + 33).astype(np.uint8))) for _ in range(300)]
+    hip, _ = compare_engines(opt, reads)
+    kt = capi.KernelTimes()
+    assert hip.lib.faqcs_kernel_report(hip.ctx, C.byref(kt)) == 0
+    assert (kt.trim_kernel or b"").decode() == kernel
+
+
+def make_uniform(rng, L):
+    return bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)])
