@@ -134,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
     for (int i = lane; i < 4 * PW; i += 64) pl[i] = 0u; // pads stay zero for the whole kernel
     for (uint32_t i = threadIdx.x; i <= A.n_adapters; i += NW * 64) { s_start[i] = A.start[i]; s_wstart[i] = A.wstart[i]; }
     const uint32_t tpl_dwords = 4u * A.wstart[A.n_adapters];
-    const bool tpl_cached = tpl_dwords <= (uint32_t)TPL_CAP;
+    const bool tpl_cached = uni((int)(tpl_dwords <= (uint32_t)TPL_CAP)) != 0; // (uni: the branches on it stay scalar branches)
     if (tpl_cached) for (uint32_t i = threadIdx.x; i < tpl_dwords; i += NW * 64) s_tpl[i] = A.planes[i];
     if (threadIdx.x < 32) s_iupac[threadIdx.x] = threadIdx.x < 26 ? k_iupac[threadIdx.x] : (uint8_t)0;
     for (uint32_t i = threadIdx.x; i < 2 * FAQCS_MAX_ADAPTERS; i += NW * 64) s_ast[i] = 0u;
@@ -151,6 +151,8 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
     short_tlen_max = uni(short_tlen_max);
     bool has_long = false; // some adapter takes the sliding long-target prefilter
     for (uint32_t i = 0; i < A.n_adapters; ++i) has_long = has_long || (int)s_meta[i].x > 128;
+    has_long = uni((int)has_long) != 0;
+    const bool prefilter_on = uni((int)((dbg & 8u) == 0u)) != 0;
 
     // A wave takes chunks of 64 consecutive reads: offsets load and results store as one coalesced vector per chunk,
     // per-read scalars come out of the lanes with v_readlane, and the bases of read t+1 are fetched while read t is
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
                 const int need_j = (int)(sb >> 16) - 32768;                  // (mcap + bound) / 2 >= thr  <=>  bound >= need
                 bool any_match = true, may_pass = true;
                 const int mcap = qlen < tlen ? qlen : tlen;
-                if (!(dbg & 8u) && MAXLEN <= 320 && tlen <= 128 && tpl_cached) {
+                if (prefilter_on && MAXLEN <= 320 && tlen <= 128 && tpl_cached) {
                     const uint32_t *tpl = s_tpl + 4 * (sa >> 16);
                     // (Measured and rejected: leaving a last plane word of <= 3 bases uncompared and counting those bases as matches.
                     // The weaker bound lets enough random reads through to stage 2 to cost more than the word saves: -8 %.)
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
                         }
                         m_bnd |= 1ull << j;
                     }
-                } else if (!(dbg & 8u) && MAXLEN <= 320 && NBR >= 6 && tpl_cached) {
+                } else if (prefilter_on && MAXLEN <= 320 && NBR >= 6 && tpl_cached) {
                     // long target (PhiX, artifact sequences): the same register windows, sliding over the target two words
                     // per step.  Words 2u and 2u+1 face exactly the NBR+1 blocks u-1 .. u+NBR-1 (window index 2 NBR - 2i and
                     // 2 NBR + 1 - 2i for block u-1+i); block u-1 has seen all of its words after step u and leaves the accumulator.
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
                     }
                     any_match = __any(maxcnt > 0u);
                     may_pass = __any((int)maxcnt >= need_j);
-                } else if (!(dbg & 8u)) {
+                } else if (prefilter_on) {
                     const uint32_t w0 = s_wstart[j];
                     const int nw = (int)(s_wstart[j + 1] - w0);
                     const int ndiag = qlen + tlen - 1;
@@ -512,8 +514,9 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
                     any_match = bound > 0;
                     may_pass = (mcap + bound) / 2 >= thr;
                 }
-                m_any |= (uint64_t)any_match << j;
-                m_pass |= (uint64_t)may_pass << j;
+                // (wave-uniform flags: kept in SGPRs -- as lane values each adapter paid two 64-bit VALU shifts and four ors)
+                m_any |= (uint64_t)(uint32_t)uni((int)any_match) << j;
+                m_pass |= (uint64_t)(uint32_t)uni((int)may_pass) << j;
             }
         };
         if (!read_bad && qlen > 0) {
