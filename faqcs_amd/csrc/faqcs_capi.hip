@@ -57,8 +57,8 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
                              uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st);
-hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, bool wide, const float *comp_norm, uint64_t *dst,
-                                    int n_cu, hipStream_t st);
+hipError_t faqcs_launch_composition(const unsigned long long *rec_pre, const unsigned long long *rec_post, uint32_t n, bool wide,
+                                    const float *comp_norm, uint64_t *dst_pre, uint64_t *dst_post, int n_cu, hipStream_t st);
 hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
                                 uint32_t max_len, const uint32_t *seg_start, uint32_t n_segments, uint32_t *ad_sl,
                                 uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, uint32_t dbg, int n_cu, hipStream_t st);
@@ -478,8 +478,8 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         if (!(c->dp.dbg & 1u)) {
             HIPCHK(hipEventRecord(rs.trimmed, c->compute));
             HIPCHK(hipStreamWaitEvent(c->aux, rs.trimmed, 0));
-            HIPCHK(faqcs_launch_composition(rs.pre.p, n, wide, c->d_norm, c->d_counters + c->lay.pre_comp, c->n_cu, c->aux));
-            HIPCHK(faqcs_launch_composition(rs.post.p, n, wide, c->d_norm, c->d_counters + c->lay.post_comp, c->n_cu, c->aux));
+            HIPCHK(faqcs_launch_composition(rs.pre.p, rs.post.p, n, wide, c->d_norm, c->d_counters + c->lay.pre_comp,
+                                            c->d_counters + c->lay.post_comp, c->n_cu, c->aux));
             HIPCHK(hipEventRecord(rs.folded, c->aux));
             rs.used = true;
         }

@@ -1241,39 +1241,62 @@ __global__ __launch_bounds__(NW * 64, tpr_bounds_waves(C, LPR, EXT)) void trim_t
 // records.  One thread per record; the block's LDS holds the whole 10 001 x 6 table as 16-bit counters
 // (two per dword), flushed to the global u64 block before any of them can overflow.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef FAQCS_COMP_U
+#define FAQCS_COMP_U 4 /* records per thread and round */
+#endif
 template <int NT, bool WIDE>
-__global__ __launch_bounds__(NT) void composition_histogram(const unsigned long long *__restrict__ rec, const uint32_t n,
-                                                            const float *__restrict__ comp_norm,
-                                                            uint64_t *__restrict__ dst /* counters + L.{pre,post}_comp */)
+__global__ __launch_bounds__(NT) void composition_histogram(const unsigned long long *__restrict__ rec_a, const unsigned long long *__restrict__ rec_b,
+                                                            const uint32_t n, const float *__restrict__ comp_norm,
+                                                            uint64_t *__restrict__ dst_a, uint64_t *__restrict__ dst_b /* counters + L.{pre,post}_comp */)
 {
     constexpr int NE = FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND; // 60 006 16-bit counters
     constexpr int ND = (NE + 1) / 2;
+    constexpr int U = FAQCS_COMP_U; // records per thread and round, fetched together: a round is one memory latency, not U
     extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
     const int tid = threadIdx.x;
+    // ONE launch folds both record arrays (pre- and post-trim): even blocks take the first, odd blocks the second (the table
+    // fills the LDS of a CU, so the two cannot share one)
+    const bool second = (blockIdx.x & 1u) != 0u;
+    const unsigned long long *__restrict__ rec = second ? rec_b : rec_a;
+    uint64_t *__restrict__ dst = second ? dst_b : dst_a;
+    const uint32_t bid = blockIdx.x >> 1, nblk = gridDim.x >> 1; // (the grid is even)
+    // the per-length factors behind the table, in LDS too: as a global load the factor sat between a record and its atomics,
+    // a second memory latency per round (measured: 5 % of the trim launch the fold shares the GPU with)
+    float *normt = reinterpret_cast<float *>(tab + ND);
+    constexpr int NNORM = WIDE ? FAQCS_TAB_LEN + 1 : 512;
     for (int i = tid; i < ND; i += NT) tab[i] = 0;
+    for (int i = tid; i < NNORM; i += NT) normt[i] = i <= FAQCS_TAB_LEN ? comp_norm[i] : 0.0f;
     __syncthreads();
-    const uint32_t per_round = gridDim.x * NT;
+    const uint32_t per_round = nblk * NT * U;
     const uint32_t rounds = (n + per_round - 1) / per_round;
-    constexpr uint32_t FLUSH_EVERY = 65535u / NT;
+    constexpr uint32_t FLUSH_EVERY = 65535u / (NT * U);
     for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t i = (r * gridDim.x + blockIdx.x) * NT + tid;
-        uint32_t nbin = 0xffffffffu; // this thread's N bin (none)
-        if (i < n) {
-            unsigned long long x, y = 0;
-            if (WIDE) { const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(rec)[i]; x = v.x; y = v.y; }
-            else x = rec[i];
-            if (x & CR_VALID) {
+        const uint32_t i0 = (r * nblk + bid) * (NT * U) + tid;
+        unsigned long long x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = i0 + u * NT;
+            x[u] = 0; y[u] = 0;
+            if (i < n) {
+                if (WIDE) { const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(rec)[i]; x[u] = v.x; y[u] = v.y; }
+                else x[u] = rec[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t nbin = 0xffffffffu; // this thread's N bin (none)
+            if (x[u] & CR_VALID) {
                 uint32_t len, cnt[5];
                 if (WIDE) {
-                    len = (uint32_t)(x & 2047u);
-                    cnt[0] = (uint32_t)(x >> 11) & 2047u; cnt[1] = (uint32_t)(x >> 22) & 2047u; cnt[2] = (uint32_t)(x >> 33) & 2047u;
-                    cnt[3] = (uint32_t)y & 2047u; cnt[4] = (uint32_t)(y >> 11) & 2047u;
+                    len = (uint32_t)(x[u] & 2047u);
+                    cnt[0] = (uint32_t)(x[u] >> 11) & 2047u; cnt[1] = (uint32_t)(x[u] >> 22) & 2047u; cnt[2] = (uint32_t)(x[u] >> 33) & 2047u;
+                    cnt[3] = (uint32_t)y[u] & 2047u; cnt[4] = (uint32_t)(y[u] >> 11) & 2047u;
                 } else {
-                    len = (uint32_t)(x & 511u);
+                    len = (uint32_t)(x[u] & 511u);
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) cnt[k] = (uint32_t)(x >> (9 + 9 * k)) & 511u;
+                    for (int k = 0; k < 5; ++k) cnt[k] = (uint32_t)(x[u] >> (9 + 9 * k)) & 511u;
                 }
-                const float norm = comp_norm[len];
+                const float norm = normt[len];
                 uint32_t idx[6];
 #pragma unroll
                 for (int k = 0; k < 5; ++k) idx[k] = (uint32_t)__fmul_rn(norm, (float)cnt[k]); // :862-872
@@ -1286,17 +1309,14 @@ __global__ __launch_bounds__(NT) void composition_histogram(const unsigned long 
                 }
                 nbin = idx[4] * FAQCS_NCOMP_KIND + 4;
             }
-        }
-        // The N bin is the same for nearly every read (no N at all: bin 0): 64 lanes adding to ONE LDS address serialise, and
-        // that one kind cost more than the other five together.  The lanes of a wave that share a bin add their count once.
-        {
-            unsigned long long todo = __ballot(nbin != 0xffffffffu);
-            while (todo) {
-                const int leader = __builtin_ctzll(todo);
-                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)nbin, leader);
-                const unsigned long long same = __ballot(nbin == v);
-                if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&tab[v >> 1], (uint32_t)__popcll(same) << (16 * (v & 1u)));
-                todo &= ~same;
+            // The N bin is the same for nearly every read (no N at all: bin 0): 64 lanes adding to ONE LDS address serialise, and
+            // that one kind cost more than the other five together.  The lanes of a wave that hit bin 0 add their count once; a read
+            // with N in it adds for itself (a loop over the distinct bins of the wave was measured: 3 % of the co-running trim launch).
+            {
+                constexpr uint32_t bin0 = 4u; // idx 0, kind 4
+                const unsigned long long zero = __ballot(nbin == bin0);
+                if (zero != 0ull && (int)(threadIdx.x & 63u) == __builtin_ctzll(zero)) atomicAdd(&tab[bin0 >> 1], (uint32_t)__popcll(zero) << (16 * (bin0 & 1u)));
+                if (nbin != 0xffffffffu && nbin != bin0) atomicAdd(&tab[nbin >> 1], 1u << (16 * (nbin & 1u)));
             }
         }
         if (((r + 1) % FLUSH_EVERY) == 0 || r + 1 == rounds) {
@@ -1467,13 +1487,13 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
     return hipErrorInvalidValue;
 }
 
-// wide: the two-word records of the long-read kernels (max_len > 256)
-hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, bool wide, const float *comp_norm, uint64_t *dst,
-                                    int n_cu, hipStream_t st)
+// wide: the two-word records of the long-read kernels (max_len > 256).  One launch for the pre- and the post-trim records.
+hipError_t faqcs_launch_composition(const unsigned long long *rec_pre, const unsigned long long *rec_post, uint32_t n, bool wide,
+                                    const float *comp_norm, uint64_t *dst_pre, uint64_t *dst_post, int n_cu, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     constexpr int NT = 1024;
-    constexpr size_t lds = (size_t)((FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND + 1) / 2) * 4;
+    constexpr size_t lds = (size_t)((FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND + 1) / 2) * 4 + (size_t)(FAQCS_TAB_LEN + 1) * 4; // table + per-length factors
     static bool attr_set = false;
     auto kern = wide ? composition_histogram<NT, true> : composition_histogram<NT, false>;
     if (!attr_set) {
@@ -1482,8 +1502,9 @@ hipError_t faqcs_launch_composition(const unsigned long long *rec, uint32_t n, b
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    uint32_t grid = (n + NT - 1) / NT;
-    if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, rec, n, comp_norm, dst);
+    uint32_t per_array = (n + NT * FAQCS_COMP_U - 1) / (NT * FAQCS_COMP_U); // blocks one array can use
+    if (per_array > (uint32_t)(n_cu / 2)) per_array = (uint32_t)(n_cu / 2); // (fewer, longer blocks are slower: 64 per array -6 %)
+    if (per_array < 1) per_array = 1;
+    hipLaunchKernelGGL(kern, dim3(2 * per_array), dim3(NT), lds, st, rec_pre, rec_post, n, comp_norm, dst_pre, dst_post);
     return hipGetLastError();
 }
