@@ -37,5 +37,5 @@ bash profiles/pmc_insts.sh $tag/insts1 > $out/pmc_instruction_mix.txt 2>&1
 PMC="SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH SQ_INSTS_SMEM" bash profiles/pmc_insts.sh $tag/insts2 >> $out/pmc_instruction_mix.txt 2>&1
 bash profiles/pmc_adapter.sh $tag/adapter 0.05 > $out/pmc_adapter.txt 2>&1
 if [ "${SKIP_KMER_PMC:-0}" != 1 ]; then bash profiles/pmc_kmer.sh $tag/kmer > $out/pmc_kmer_atomics.txt 2>&1; fi
-find $out -name "*kernel_stats.csv" -exec sh -c 'cp "$1" '$out'/$(basename $(dirname $(dirname "$1")))_kernel_stats.csv' _ {} \;
+cp $out/prof_plain/plain_kernel_stats.csv $out/rocprofv3_kernel_stats_bench_plain_25Mpairs.csv; cp $out/prof_adapter/adapter_kernel_stats.csv $out/rocprofv3_kernel_stats_bench_adapter_4Mpairs.csv
 ls -la $out
