@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the FaQCs per-read hot path on MI355X.
 
-A *step* is one pass of the trim kernel (trim_tpr for the headline shape; + adapter_overlap for --config adapter) over the whole
+A *step* is one pass of the trim kernel (trim_lds for the headline shape; + adapter_overlap for --config adapter) over the whole
 synthetic data set resident in HBM: BASELINE.json configs[1] (100 M pairs of 2x150 bp, BWA_plus -q 5
 --min_L 50) per GPU, generated on the device by faqcs_synth_fill.  Inputs are in HBM
 when the timed region starts; every step ends with the job's one collective, the all-reduce of the counter
@@ -12,6 +12,11 @@ Prints ONE JSON line on rank 0 (see the task contract), including
                events on the library's compute stream; peak = 8 TB/s HBM3E
   cpu_baseline the real reference binary (oracle/_ref/FaQCs_ref -t <cores>, kind "reference") or the plain-C
                port (kind "port") timed on a bounded sample of the same workload on this host.
+  e2e          (N = 1, plain / adapter) faqcs_mi from FASTQ files in /dev/shm to trimmed FASTQ + QC.stats.txt, reads/s.
+
+--gpus N without WORLD_SIZE in the environment: this process starts N rank processes (before it touches the GPU) and relays
+rank 0's line; under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  --config kmer --gpus N runs the
+owner-partitioned k-mer exchange of DESIGN.md section 6.
 """
 import argparse
 import ctypes as C

@@ -18,9 +18,10 @@
 // the DELTA of the device counter block since the previous call into the caller's filter_stats,
 // adapter_stats and PlotInfo, so write_stats() and plot() downstream see what they always saw.
 //
-// Not supported through this shim: --kmer_rarefaction (the reference folds MAP<Word,size_t> kmer_table into
-// its report AFTER the last trim() call, FaQCs.cpp:518-537, with no hook for a device-resident table).  The
-// C ABI itself supports it (faqcs_kmer_*); use the repo's own driver for that mode.
+// --kmer_rarefaction: the reference merges per-call thread-local tables into the caller's MAP<Word,size_t> (trim.cpp:133-135)
+// and samples the curve inside trim() (:157-185).  Here the context counts into a one-rank owner partition, the call's k-mer
+// occurrences are downloaded (faqcs_kmer_outbox_host) and added to that map, and the sampling rule is restated below, so
+// FaQCs.cpp:518-537 consumes the map as it always did.
 #include <algorithm>
 #include <cstring>
 #include <iostream>
