@@ -5,6 +5,20 @@
 
 #include <stdlib.h>
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting of a kernel: a process with contexts on several devices
+// (faqcs_mi --gpus N) has to make it on each of them once.  `done` = one bit per device ordinal, owned by the caller (one per kernel).
+static inline hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes, unsigned long long &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+    return e;
+}
+
 namespace {
 
 template <int C, int LPR> struct RowCfg {

@@ -1342,13 +1342,9 @@ static hipError_t launch_trim_t(const DevParams &P, const uint8_t *seq, const ui
                                 int n_cu, hipStream_t st)
 {
     constexpr size_t lds = (size_t)RowCfg<C, LPR>::LDS_DWORDS * 4;
-    static bool attr_set = false;
+    static unsigned long long attr_done = 0;
     auto kern = trim_filter_accumulate<C, LPR, NW, WINDOWED, GENERIC>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const uint32_t chunks = (n_reads + 63) / 64;
     int blocks_per_cu = (int)((160 * 1024) / lds);
     // (variants whose per-position arrays do not fit 168 VGPRs run at 2 waves/SIMD rather than spill: the kernel is issue-bound)
@@ -1372,13 +1368,9 @@ static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const 
                                   int n_cu, hipStream_t st)
 {
     constexpr size_t lds = (size_t)TprCfg<C, LPR>::lds_dwords(NW) * 4;
-    static bool attr_set = false;
+    static unsigned long long attr_done = 0;
     auto kern = trim_tpr<C, NW, WINDOWED, LPR, EXT>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const uint32_t chunks = (n_reads + 63) / 64;
     int blocks_per_cu = (int)((160 * 1024) / lds);
     const int by_waves = (4 * tpr_waves_per_simd(C, LPR, EXT) + NW - 1) / NW;
@@ -1494,14 +1486,9 @@ hipError_t faqcs_launch_composition(const unsigned long long *rec_pre, const uns
     if (n == 0) return hipSuccess;
     constexpr int NT = 1024;
     constexpr size_t lds = (size_t)((FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND + 1) / 2) * 4 + (size_t)(FAQCS_TAB_LEN + 1) * 4; // table + per-length factors
-    static bool attr_set = false;
+    static unsigned long long attr_done_w = 0, attr_done_n = 0;
     auto kern = wide ? composition_histogram<NT, true> : composition_histogram<NT, false>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(composition_histogram<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(composition_histogram<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, wide ? attr_done_w : attr_done_n); e != hipSuccess) return e;
     uint32_t per_array = (n + NT * FAQCS_COMP_U - 1) / (NT * FAQCS_COMP_U); // blocks one array can use
     if (per_array > (uint32_t)(n_cu / 2)) per_array = (uint32_t)(n_cu / 2); // (fewer, longer blocks are slower: 64 per array -6 %)
     if (per_array < 1) per_array = 1;

@@ -971,13 +971,9 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
 {
     constexpr int NW = lds_waves(C);
     constexpr size_t lds = (size_t)LdsCfg<C, NW>::lds_dwords() * 4;
-    static bool attr_set = false;
+    static unsigned long long attr_done = 0;
     auto kern = trim_lds<C, NW, WINDOWED, EXT>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const uint32_t chunks = (n_reads + 63) / 64;
     uint32_t grid = (chunks + NW - 1) / NW;
     if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu; // one block per CU: its LDS holds a slot per wave
