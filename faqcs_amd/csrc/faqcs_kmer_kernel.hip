@@ -113,6 +113,19 @@ __device__ __forceinline__ void kmer_enumerate(const DevParams &P, const uint32_
     }
 }
 
+// The table's atomics, device scope.  (Checked in round 2: workgroup scope compiles to the SAME instructions on gfx950 -- the
+// atomics carry no scope bit below "device" -- and the counters show every one of them leaving the XCD's L2 for the memory
+// side (TCC_EA0_ATOMIC == TCC_ATOMIC, profiles/r2c/pmc_kmer_atomics.txt): with eight L2s that is where device-wide atomicity
+// lives.  There is no cheaper L2-local atomic to route XCD-partitioned slots to.)
+#define FAQCS_KMER_SCOPE __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ unsigned long long slot_cas(unsigned long long *p, unsigned long long expect, unsigned long long v)
+{
+    __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FAQCS_KMER_SCOPE);
+    return expect;
+}
+__device__ __forceinline__ void slot_add(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, FAQCS_KMER_SCOPE); }
+__device__ __forceinline__ void slot_min(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, FAQCS_KMER_SCOPE); }
+
 // open-addressing insert; returns false when the probe budget is exhausted (table full)
 __device__ __forceinline__ bool kmer_insert(const KmerTable &T, const uint64_t key, const uint32_t epoch, bool &is_new)
 {
@@ -126,20 +139,20 @@ __device__ __forceinline__ bool kmer_insert(const KmerTable &T, const uint64_t k
         const ull2_t cur = __builtin_nontemporal_load(reinterpret_cast<const ull2_t *>(sl));
         unsigned long long seen = cur.x;
         if (seen == ~0ull) {
-            seen = atomicCAS(&sl->key, ~0ull, (unsigned long long)key);
+            seen = slot_cas(&sl->key, ~0ull, (unsigned long long)key);
             if (seen == ~0ull) { // claimed: count_m1 = 0 already says "seen once"
                 is_new = true;
-                if (T.partitioned) atomicMin(&sl->first_epoch, epoch);
+                if (T.partitioned) slot_min(&sl->first_epoch, epoch);
                 return true;
             }
             if (seen == key) { // lost the race against the same key
-                atomicAdd(&sl->count_m1, 1u);
-                if (T.partitioned) atomicMin(&sl->first_epoch, epoch);
+                slot_add(&sl->count_m1, 1u);
+                if (T.partitioned) slot_min(&sl->first_epoch, epoch);
                 return true;
             }
         } else if (seen == key) {
-            atomicAdd(&sl->count_m1, 1u);
-            if (T.partitioned && epoch < (uint32_t)(cur.y >> 32)) atomicMin(&sl->first_epoch, epoch);
+            slot_add(&sl->count_m1, 1u);
+            if (T.partitioned && epoch < (uint32_t)(cur.y >> 32)) slot_min(&sl->first_epoch, epoch);
             return true;
         }
         h = (h + 1) & T.mask;
