@@ -12,6 +12,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <immintrin.h>
 
@@ -1402,6 +1403,271 @@ void write_tables(const Opt &o, const faqcs_layout &L, const uint64_t *c, uint32
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The PDF report (plot.cpp:93-515: the reference pipes an R script into `R --vanilla --silent --slave`, then deletes the tables
+// unless --debug).  Same process contract here -- same command, same tables on disk while R runs, same PDF name -- with a script
+// written for this repository (the reference's script text is not reproduced): one page per plot of the reference's report.
+// ---------------------------------------------------------------------------------------------------------------------
+std::string r_quote(const std::string &s)
+{
+    std::string q = "\"";
+    for (char ch : s) { if (ch == '\\' || ch == '"') q += '\\'; q += ch; }
+    return q + "\"";
+}
+
+std::string report_script(const Opt &o)
+{
+    const std::string d = o.output_dir + "/", p = o.prefix;
+    std::string s;
+    s += "options(warn = -1)\n";
+    s += "pdf_file <- " + r_quote(o.plots_file) + "\n";
+    s += "stats_file <- " + r_quote(o.stats_file) + "\n";
+    s += "pre <- function(name) file.path(" + r_quote(o.output_dir) + ", paste0(\"qa.\", " + r_quote(p) + ", \".\", name))\n";
+    s += "post <- function(name) file.path(" + r_quote(o.output_dir) + ", paste0(" + r_quote(p) + ", \".\", name))\n";
+    s += std::string("qc_only <- ") + (o.qc_only ? "TRUE" : "FALSE") + "\n";
+    s += R"R(
+have <- function(f) file.exists(f) && file.info(f)$size > 0
+page <- function(expr) try(expr, silent = TRUE)
+both <- function(name) c(pre(name), post(name))[c(have(pre(name)), have(post(name)))]
+label <- function(f) if (grepl("/qa\\.[^/]*$", f)) "input reads" else if (qc_only) "reads (QC only)" else "trimmed reads"
+
+pdf(file = pdf_file, width = 12, height = 7)
+
+# 1. the statistics text
+page({
+  txt <- readLines(stats_file)
+  par(family = "mono", mar = c(1, 1, 3, 1))
+  plot(0:1, 0:1, type = "n", axes = FALSE, xlab = "", ylab = "")
+  step <- min(0.035, 0.95 / max(1, length(txt)))
+  for (i in seq_along(txt)) text(0.02, 1 - step * (i - 1), txt[i], adj = 0, cex = 0.8)
+  title("QC statistics")
+  par(family = "", mar = c(5, 4, 4, 2) + 0.1)
+})
+
+# 2. read length histograms
+page({
+  fs <- both("length_count.txt")
+  if (length(fs)) {
+    par(mfrow = c(1, length(fs)))
+    for (f in fs) {
+      t <- read.table(f, header = FALSE, col.names = c("len", "n"))
+      barplot(t$n / 1e6, names.arg = t$len, xlab = "length (bases)", ylab = "reads (millions)", main = label(f), border = NA, col = "steelblue")
+    }
+    par(mfrow = c(1, 1))
+    mtext("Read length histogram", outer = TRUE, line = -1.5, font = 2)
+  }
+})
+
+# 3. composition of the reads: GC, then A, T, C, G, N
+content <- function(f) read.table(f, header = FALSE, col.names = c("kind", "pct", "n"), stringsAsFactors = FALSE)
+page({
+  fs <- both("base_content.txt")
+  if (length(fs)) {
+    par(mfrow = c(1, length(fs)))
+    for (f in fs) {
+      t <- content(f); g <- t[t$kind == "GC", ]
+      if (nrow(g)) {
+        m <- sum(g$pct * g$n) / sum(g$n)
+        plot(g$pct, g$n / 1e3, type = "h", xlim = c(0, 100), xlab = "GC (%)", ylab = "reads (thousands)", main = label(f), col = "darkgreen")
+        legend("topright", legend = sprintf("mean %.2f %%", m), bty = "n")
+      }
+    }
+    par(mfrow = c(1, 1))
+    mtext("GC content of the reads", outer = TRUE, line = -1.5, font = 2)
+  }
+})
+page({
+  fs <- both("base_content.txt")
+  if (length(fs)) {
+    par(mfrow = c(1, length(fs)))
+    cols <- c(A = "green3", T = "red", C = "blue", G = "black", N = "grey50")
+    for (f in fs) {
+      t <- content(f); t <- t[t$kind != "GC", ]
+      plot(NA, xlim = c(0, 100), ylim = c(0, max(t$n) / 1e3), xlab = "share of the read (%)", ylab = "reads (thousands)", main = label(f))
+      for (k in names(cols)) { x <- t[t$kind == k, ]; if (nrow(x)) lines(x$pct, x$n / 1e3, col = cols[k]) }
+      legend("topright", legend = names(cols), col = cols, lty = 1, bty = "n")
+    }
+    par(mfrow = c(1, 1))
+    mtext("Nucleotide content of the reads", outer = TRUE, line = -1.5, font = 2)
+  }
+})
+
+# 4. composition per cycle (position x A, T, C, G, N), then N alone
+base_matrix <- function(f) { m <- as.matrix(read.table(f, header = FALSE)); colnames(m) <- c("A", "T", "C", "G", "N"); m }
+page({
+  fs <- both("base.matrix")
+  if (length(fs)) {
+    par(mfrow = c(1, length(fs)))
+    cols <- c(A = "green3", T = "red", C = "blue", G = "black")
+    for (f in fs) {
+      m <- base_matrix(f); pct <- 100 * m / pmax(1, rowSums(m))
+      plot(NA, xlim = c(1, nrow(m)), ylim = c(0, max(50, pct[, 1:4])), xlab = "cycle", ylab = "%", main = label(f))
+      for (k in names(cols)) lines(seq_len(nrow(m)), pct[, k], col = cols[k])
+      legend("topright", legend = names(cols), col = cols, lty = 1, bty = "n")
+    }
+    par(mfrow = c(1, 1))
+    mtext("Nucleotide content per cycle", outer = TRUE, line = -1.5, font = 2)
+  }
+})
+page({
+  fs <- both("base.matrix")
+  if (length(fs)) {
+    par(mfrow = c(1, length(fs)))
+    for (f in fs) {
+      m <- base_matrix(f)
+      plot(seq_len(nrow(m)), 100 * m[, "N"] / pmax(1, rowSums(m)), type = "h", xlab = "cycle", ylab = "N (%)", main = label(f), col = "grey30")
+    }
+    par(mfrow = c(1, 1))
+    mtext("N content per cycle", outer = TRUE, line = -1.5, font = 2)
+  }
+})
+
+# 5. k-mers: rarefaction curve and count histogram
+page({
+  f <- post("Kmercount.txt")
+  if (have(f)) {
+    t <- read.table(f, header = FALSE, col.names = c("reads", "distinct", "total"))
+    x <- cumsum(t$reads)
+    plot(x / 1e6, t$distinct / 1e6, type = "b", xlab = "reads sampled (millions)", ylab = "distinct k-mers (millions)", main = "K-mer rarefaction curve")
+    if (nrow(t) > 1) {
+      legend("bottomright", legend = sprintf("last slope %.3f distinct k-mers per read", diff(tail(t$distinct, 2)) / diff(tail(x, 2))), bty = "n")
+    }
+  }
+})
+page({
+  f <- post("kmerH.txt")
+  if (have(f)) {
+    t <- read.table(f, header = FALSE, col.names = c("count", "kmers"))
+    t <- t[order(t$count), ]
+    plot(t$count, t$kmers, log = "xy", type = "h", xlab = "occurrences of a k-mer", ylab = "k-mers", main = "K-mer frequency histogram")
+  }
+})
+
+# 6. average read quality
+page({
+  fs <- both("for_qual_histogram.txt")
+  if (length(fs)) {
+    par(mfrow = c(1, length(fs)))
+    for (f in fs) {
+      t <- read.table(f, header = TRUE)
+      t <- t[order(t$Score), ]
+      barplot(t$readsNum / 1e6, names.arg = t$Score, xlab = "average quality of a read", ylab = "reads (millions)", main = label(f), border = NA, col = "orange3")
+    }
+    par(mfrow = c(1, 1))
+    mtext("Average read quality histogram", outer = TRUE, line = -1.5, font = 2)
+  }
+})
+
+# 7. quality per cycle from the position x score matrix: box plot, surface, totals per score
+quality_matrix <- function(f) as.matrix(read.table(f, header = FALSE))
+quantile_row <- function(r, probs) { cs <- cumsum(r); tot <- cs[length(cs)]; if (tot == 0) return(rep(NA, length(probs))); sapply(probs, function(p) which(cs >= p * tot)[1] - 1) }
+page({
+  fs <- both("quality.matrix")
+  if (length(fs)) {
+    par(mfrow = c(1, length(fs)))
+    for (f in fs) {
+      m <- quality_matrix(f)
+      st <- apply(m, 1, quantile_row, probs = c(0.1, 0.25, 0.5, 0.75, 0.9))
+      z <- list(stats = st, n = rowSums(m), conf = matrix(NA_real_, 2, ncol(st)), out = numeric(0), group = numeric(0), names = seq_len(ncol(st)))
+      bxp(z, outline = FALSE, xlab = "cycle", ylab = "quality", main = label(f), ylim = c(0, ncol(m) - 1), boxfill = "khaki", whisklty = 1, xaxt = "n")
+      at <- pretty(seq_len(ncol(st))); at <- at[at >= 1 & at <= ncol(st)]
+      axis(1, at = at, labels = at)
+      lines(seq_len(ncol(st)), (m %*% (0:(ncol(m) - 1))) / pmax(1, rowSums(m)), col = "red")
+    }
+    par(mfrow = c(1, 1))
+    mtext("Quality per cycle (10 / 25 / 50 / 75 / 90 % and the mean)", outer = TRUE, line = -1.5, font = 2)
+  }
+})
+page({
+  fs <- both("quality.matrix")
+  if (length(fs)) {
+    par(mfrow = c(1, length(fs)))
+    for (f in fs) {
+      m <- quality_matrix(f)
+      persp(seq_len(nrow(m)), 0:(ncol(m) - 1), m / 1e3, theta = 40, phi = 25, xlab = "cycle", ylab = "quality", zlab = "bases (thousands)",
+            main = label(f), col = "lightblue", border = NA, shade = 0.5, ticktype = "detailed")
+    }
+    par(mfrow = c(1, 1))
+    mtext("Quality surface (cycle x score x bases)", outer = TRUE, line = -1.5, font = 2)
+  }
+})
+page({
+  fs <- both("quality.matrix")
+  if (length(fs)) {
+    par(mfrow = c(1, length(fs)))
+    for (f in fs) {
+      m <- quality_matrix(f); n <- colSums(m)
+      q20 <- 100 * sum(n[21:length(n)]) / max(1, sum(n)); q30 <- 100 * sum(n[31:length(n)]) / max(1, sum(n))
+      barplot(n / 1e6, names.arg = 0:(length(n) - 1), xlab = "quality", ylab = "bases (millions)", main = label(f), border = NA,
+              col = ifelse(0:(length(n) - 1) >= 30, "darkgreen", ifelse(0:(length(n) - 1) >= 20, "orange", "red3")))
+      legend("topleft", legend = c(sprintf(">= Q20: %.2f %%", q20), sprintf(">= Q30: %.2f %%", q30)), bty = "n")
+    }
+    par(mfrow = c(1, 1))
+    mtext("Bases per quality score", outer = TRUE, line = -1.5, font = 2)
+  }
+})
+
+invisible(dev.off())
+quit(save = "no")
+)R";
+    return s;
+}
+
+// A helper process forked BEFORE the first HIP call (a process that has initialised the GPU must not exec): it waits for the
+// script on a pipe and then runs R exactly as the reference does.  An empty script (--trim_only, or a run that failed) = no R.
+struct ReportHelper {
+    pid_t pid = -1;
+    int fd = -1;
+    void start()
+    {
+        int pf[2];
+        if (pipe(pf) != 0) return;
+        fflush(nullptr);
+        pid = fork();
+        if (pid < 0) { close(pf[0]); close(pf[1]); pid = -1; return; }
+        if (pid == 0) {
+            close(pf[1]);
+            std::string script;
+            char buf[65536];
+            ssize_t n;
+            while ((n = read(pf[0], buf, sizeof buf)) > 0) script.append(buf, (size_t)n);
+            close(pf[0]);
+            if (!script.empty()) {
+                FILE *r = popen("R --vanilla --silent --slave", "w"); // plot.cpp:507
+                if (!r) fprintf(stderr, "Warning: Unable to run R for plot generation\n");
+                else { fwrite(script.data(), 1, script.size(), r); pclose(r); }
+            }
+            _exit(0);
+        }
+        close(pf[0]);
+        fd = pf[1];
+    }
+    // hands the script over and waits until R is done with the tables
+    void run(const std::string &script)
+    {
+        if (pid < 0) return;
+        size_t off = 0;
+        while (off < script.size()) { const ssize_t n = write(fd, script.data() + off, script.size() - off); if (n <= 0) break; off += (size_t)n; }
+        close(fd); fd = -1;
+        int st = 0;
+        waitpid(pid, &st, 0);
+        pid = -1;
+    }
+};
+
+std::vector<std::string> table_files(const Opt &o)
+{
+    std::vector<std::string> v;
+    const std::string d = o.output_dir + "/", p = o.prefix;
+    for (const char *n : {"quality.matrix", "base.matrix", "for_qual_histogram.txt", "base_content.txt", "length_count.txt"}) {
+        v.push_back(d + "qa." + p + "." + n);
+        v.push_back(d + p + "." + n);
+    }
+    v.push_back(d + p + ".kmerH.txt");
+    v.push_back(d + p + ".Kmercount.txt");
+    return v;
+}
+
 void remove_file(const std::string &p)
 {
     struct stat st;
@@ -1426,6 +1692,8 @@ int main(int argc, char **argv)
         }
         remove_file(opt.plots_file); remove_file(opt.stats_file); remove_file(opt.out1); remove_file(opt.out2); remove_file(opt.outu); remove_file(opt.outd);
         tmark("options parsed");
+        ReportHelper report; // (forked here: nothing has touched the GPU yet, no thread is running)
+        if (!opt.trim_only) report.start();
         Run r(opt);
         // uncompressed regular files take the mapped path; gzip members, pipes and FAQCS_MI_STREAMING=1 the streaming one
         const bool streaming = getenv("FAQCS_MI_STREAMING") && atoi(getenv("FAQCS_MI_STREAMING")) != 0;
@@ -1460,7 +1728,11 @@ int main(int argc, char **argv)
             if (!f) fprintf(stderr, "Unable to open %s for writing filtering statistics\n", opt.stats_file.c_str());
             else { const std::string t = stats_text(opt, fs, ast, r.quality); fwrite(t.data(), 1, t.size(), f); fclose(f); }
         }
-        if (!opt.trim_only && opt.debug) write_tables(opt, L, c.data(), r.R, r.ctx);
+        if (!opt.trim_only) { // plot.cpp:20-515: tables, R, then the tables go unless --debug
+            write_tables(opt, L, c.data(), r.R, r.ctx);
+            report.run(report_script(opt));
+            if (!opt.debug) for (const std::string &f : table_files(opt)) unlink(f.c_str());
+        }
         tmark("statistics written");
         fflush(nullptr);
         _exit(EXIT_SUCCESS); // (device memory, pinned buffers and mappings go with the process)

@@ -673,3 +673,43 @@ def test_dispatcher_picks_the_documented_trim_kernel(L, args, kernel):
 
 def make_uniform(rng, L):
     return bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)])
+
+
+def test_native_cli_pipes_a_report_script_to_R(tmp_path):
+    """plot.cpp:93-515 process contract: without --trim_only the tables are written, an R script is piped into
+    `R --vanilla --silent --slave`, and the tables are deleted afterwards unless --debug.  A stub `R` on PATH records its
+    command line, its stdin and the files it could see."""
+    import stat
+    import subprocess
+
+    rng = np.random.Generator(np.random.PCG64([404, SEED]))
+    reads = random_batch(rng, 4000, 150, "adv")
+    fq = tmp_path / "in.fastq"
+    with open(fq, "wb") as f:
+        for i, (_, s, q) in enumerate(reads):
+            if s:
+                f.write(b"@r%d\n%s\n+\n%s\n" % (i, s, q))
+    stub_dir = tmp_path / "bin"
+    stub_dir.mkdir()
+    stub = stub_dir / "R"
+    stub.write_text('#!/bin/sh\necho "$@" > "$FAQCS_TEST_R_OUT/args"\ncat > "$FAQCS_TEST_R_OUT/script"\nls "$FAQCS_TEST_R_DIR" > "$FAQCS_TEST_R_OUT/ls"\n')
+    stub.chmod(stub.stat().st_mode | stat.S_IXUSR | stat.S_IXGRP | stat.S_IXOTH)
+    tables = ["qa.QC.quality.matrix", "QC.quality.matrix", "qa.QC.base.matrix", "QC.base.matrix", "qa.QC.for_qual_histogram.txt",
+              "QC.for_qual_histogram.txt", "qa.QC.base_content.txt", "QC.base_content.txt", "qa.QC.length_count.txt", "QC.length_count.txt"]
+    for mode, extra in (("plain", []), ("debug", ["--debug"]), ("trim_only", ["--trim_only"]), ("kmer", ["--kmer_rarefaction", "--split_size", "1000"])):
+        out, cap = tmp_path / ("out_" + mode), tmp_path / ("cap_" + mode)
+        cap.mkdir()
+        env = dict(os.environ, PATH=str(stub_dir) + os.pathsep + os.environ["PATH"], FAQCS_TEST_R_OUT=str(cap), FAQCS_TEST_R_DIR=str(out))
+        r = subprocess.run([_CLI_BIN, "-u", str(fq), "-d", str(out), "--ascii", "33"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        left = sorted(os.listdir(out))
+        if mode == "trim_only":
+            assert not (cap / "script").exists() and not any(t in left for t in tables)
+            continue
+        assert (cap / "args").read_text().split() == ["--vanilla", "--silent", "--slave"]
+        script = (cap / "script").read_text()
+        assert str(out / "QC_qc_report.pdf") in script and str(out / "QC.stats.txt") in script and "dev.off()" in script
+        seen = (cap / "ls").read_text().split()
+        want = tables + (["QC.kmerH.txt", "QC.Kmercount.txt"] if mode == "kmer" else [])
+        assert all(t in seen for t in want) and "QC.stats.txt" in seen, seen          # R ran while the tables were there
+        assert all((t in left) == (mode == "debug") for t in want), left                # and they are gone afterwards unless --debug
