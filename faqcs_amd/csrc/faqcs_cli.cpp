@@ -325,9 +325,155 @@ struct TextBlock {
 // counting newlines only; a small pool of parser threads turns blocks into pinned structure-of-arrays RecBufs
 // (fastq.cpp:8-125 semantics: four lines per record, a '\r' also ends a line, |seq| must equal |qual|); buffers are
 // handed to the consumer strictly in file order.
+// ---------------------------------------------------------------------------------------------------------
+// BGZF input (bgzip, htslib: gzip members of <= 64 KiB that carry their compressed size in a 'BC' extra field): the members
+// of a memory-mapped file are found by hopping from header to header and inflated by a pool of threads, in file order
+// (fastq.cpp:8-125 reads through gzread; a single-member .gz cannot be split and stays on gzread below).
+// ---------------------------------------------------------------------------------------------------------
+struct BgzfReader {
+    struct Task { size_t begin = 0, end = 0; std::vector<char> out; size_t n_out = 0; bool done = false; bool bad = false; };
+    const uint8_t *base = nullptr;
+    size_t size = 0, scan = 0;
+    int fd = -1;
+    std::vector<Task> ring;
+    uint64_t issued = 0, taken = 0; // task numbers handed to the workers / consumed by next()
+    uint64_t claimed = 0;
+    bool closing = false, failed = false;
+    std::mutex m; std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> workers;
+    static constexpr size_t TASK_BLOCKS = 64;
+
+    // BSIZE of the member that starts at `o` (its total size), 0 = not a BGZF member header
+    static size_t member_size(const uint8_t *p, size_t avail)
+    {
+        if (avail < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return 0;
+        const size_t xlen = p[10] | ((size_t)p[11] << 8);
+        if (avail < 12 + xlen) return 0;
+        for (size_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *f = p + 12 + x;
+            const size_t slen = f[2] | ((size_t)f[3] << 8);
+            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) return (size_t)(f[4] | ((size_t)f[5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        return 0;
+    }
+    static bool looks_like_bgzf(const std::string &path)
+    {
+        struct stat st;
+        if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28) return false;
+        uint8_t h[64];
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        const size_t n = fread(h, 1, sizeof h, f);
+        fclose(f);
+        return member_size(h, n) != 0;
+    }
+    bool open(const std::string &path, int n_threads)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); fd = -1; return false; }
+        size = (size_t)st.st_size;
+        void *mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (mp == MAP_FAILED) { ::close(fd); fd = -1; return false; }
+        madvise(mp, size, MADV_SEQUENTIAL);
+        base = (const uint8_t *)mp;
+        ring.resize((size_t)(2 * n_threads + 2));
+        for (int i = 0; i < n_threads; ++i) workers.emplace_back([this] { work(); });
+        return true;
+    }
+    // (under the lock) carve the next task out of the file: up to TASK_BLOCKS whole members
+    bool issue_locked()
+    {
+        if (scan >= size || failed) return false;
+        Task &t = ring[issued % ring.size()];
+        t.begin = scan; t.done = false; t.bad = false; t.n_out = 0;
+        size_t nb = 0;
+        while (nb < TASK_BLOCKS && scan < size) {
+            const size_t ms = member_size(base + scan, size - scan);
+            if (ms < 26 || scan + ms > size) { if (nb == 0) { failed = true; return false; } break; } // not BGZF from here on: stop (gzread would fail too)
+            scan += ms; ++nb;
+        }
+        t.end = scan;
+        ++issued;
+        return true;
+    }
+    void work()
+    {
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, -15) != Z_OK) return;
+        for (;;) {
+            Task *t;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv_work.wait(l, [&] { return closing || claimed < issued; });
+                if (claimed >= issued) break; // closing
+                t = &ring[claimed % ring.size()];
+                ++claimed;
+            }
+            if (t->out.size() < TASK_BLOCKS * 65536) t->out.resize(TASK_BLOCKS * 65536);
+            size_t o = t->begin, w = 0;
+            bool bad = false;
+            while (o < t->end && !bad) {
+                const uint8_t *p = base + o;
+                const size_t ms = member_size(p, t->end - o), xlen = p[10] | ((size_t)p[11] << 8);
+                const size_t hdr = 12 + xlen;
+                const uint32_t isize = (uint32_t)p[ms - 4] | ((uint32_t)p[ms - 3] << 8) | ((uint32_t)p[ms - 2] << 16) | ((uint32_t)p[ms - 1] << 24);
+                if (hdr + 8 > ms || isize > 65536 || w + isize > t->out.size()) { bad = true; break; }
+                if (isize) {
+                    inflateReset(&z);
+                    z.next_in = const_cast<Bytef *>(p + hdr); z.avail_in = (uInt)(ms - hdr - 8);
+                    z.next_out = (Bytef *)t->out.data() + w; z.avail_out = (uInt)isize;
+                    const int rc = inflate(&z, Z_FINISH);
+                    if (rc != Z_STREAM_END || z.avail_out != 0) { bad = true; break; }
+                    w += isize;
+                }
+                o += ms;
+            }
+            {
+                std::lock_guard<std::mutex> l(m);
+                t->n_out = w; t->bad = bad; t->done = true;
+            }
+            cv_done.notify_all();
+        }
+        inflateEnd(&z);
+    }
+    // the next run of decompressed bytes in file order (valid until the following call); 0 = end of data
+    size_t next(const char *&data)
+    {
+        std::unique_lock<std::mutex> l(m);
+        for (;;) {
+            while (issued - taken < ring.size() - 1 && issue_locked()) cv_work.notify_one();
+            if (taken == issued) return 0;
+            Task &t = ring[taken % ring.size()];
+            cv_done.wait(l, [&] { return t.done; });
+            ++taken;
+            if (t.bad) { failed = true; return 0; } // (a corrupt member ends the input, as a failing gzread does)
+            if (t.n_out == 0) continue; // empty members (the BGZF end-of-file marker)
+            data = t.out.data();
+            return t.n_out;
+        }
+    }
+    void close()
+    {
+        { std::lock_guard<std::mutex> l(m); closing = true; claimed = issued; }
+        cv_work.notify_all();
+        for (auto &w : workers) if (w.joinable()) w.join();
+        workers.clear();
+        if (base) munmap(const_cast<uint8_t *>(base), size);
+        base = nullptr;
+        if (fd >= 0) ::close(fd);
+        fd = -1;
+    }
+};
+
 struct Source {
     std::string path;
     gzFile gz = nullptr;
+    BgzfReader bgzf;
+    bool use_bgzf = false;
     Queue<RecBuf *> free_q;
     Queue<TextBlock *> block_free, block_full;
     std::thread io_th;
@@ -341,9 +487,12 @@ struct Source {
     void start(const std::string &p, int nbuf, int nparse)
     {
         path = p;
-        gz = gzopen(p.c_str(), "r");
-        if (!gz) throw Fatal("I/O error");
-        gzbuffer(gz, 1 << 20);
+        if (!getenv("FAQCS_MI_NO_BGZF") && BgzfReader::looks_like_bgzf(p)) use_bgzf = bgzf.open(p, std::max(2, nparse));
+        if (!use_bgzf) {
+            gz = gzopen(p.c_str(), "r");
+            if (!gz) throw Fatal("I/O error");
+            gzbuffer(gz, 1 << 20);
+        }
         bufs.resize(nbuf);
         for (auto &b : bufs) { b.init((size_t)BUF_READS * 320); free_q.push(&b); }
         blocks.resize(nparse + 2);
@@ -362,9 +511,12 @@ struct Source {
         cur->buf = free_q.pop();
         const uint32_t want = 4 * BUF_READS;
         for (;;) {
-            const int got = gzread(gz, io.data(), (unsigned)io.size());
-            if (got <= 0) break;
-            const char *p = io.data(), *end = p + got;
+            const char *chunk = io.data();
+            size_t got;
+            if (use_bgzf) got = bgzf.next(chunk);
+            else { const int g = gzread(gz, io.data(), (unsigned)io.size()); got = g > 0 ? (size_t)g : 0; }
+            if (got == 0) break;
+            const char *p = chunk, *end = p + got;
             while (p < end) {
                 // take whole lines until the block holds `want` of them
                 const char *q = p;
@@ -465,6 +617,7 @@ struct Source {
         if (io_th.joinable()) io_th.join();
         for (auto &t : parsers) if (t.joinable()) t.join();
         if (gz) gzclose(gz);
+        if (use_bgzf) bgzf.close();
         for (auto &b : bufs) b.release();
     }
 };

@@ -1,5 +1,5 @@
 """Diagnostic (not a test): end-to-end timing of faqcs_mi on synthetic 2x150 FASTQ files in /dev/shm with stage marks.
-python tests/e2e_big.py [pairs] [extra faqcs_mi args...]"""
+python tests/e2e_big.py [pairs] [extra faqcs_mi args...]      FAQCS_E2E_GZ=1: also as bgzip (BGZF) and as plain gzip input"""
 import os
 import subprocess
 import sys
@@ -55,4 +55,37 @@ for env in ({}, {"FAQCS_MI_STREAMING": "1"}):
     dt = time.perf_counter() - t0
     print("%s: %d pairs in %.3f s = %.1f M reads/s (rc %d)" % ("streaming" if env else "mapped", n, dt, 2 * n / dt / 1e6, r.returncode))
     print(r.stderr.decode(errors="replace"))
+if os.environ.get("FAQCS_E2E_GZ"):
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def member(raw):  # one BGZF member (zlib releases the GIL: the pool compresses in parallel)
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = c.compress(raw) + c.flush()
+        return struct.pack("<4BI2BH2BHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, 12 + 6 + len(body) + 8 - 1) + body + struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw))
+
+    gz_sets = {"bgzf": [], "gzip": []}
+    with ThreadPoolExecutor(32) as pool:
+        for p in paths:
+            data = open(p, "rb").read()
+            blocks = [data[o:o + 65280] for o in range(0, len(data), 65280)] + [b""]
+            with open(p + ".bgzf.gz", "wb") as f:
+                for m in pool.map(member, blocks, chunksize=64):
+                    f.write(m)
+            gz_sets["bgzf"].append(p + ".bgzf.gz")
+            c = zlib.compressobj(1, zlib.DEFLATED, 31)
+            with open(p + ".plain.gz", "wb") as f:
+                for o in range(0, len(data), 1 << 24):
+                    f.write(c.compress(data[o:o + (1 << 24)]))
+                f.write(c.flush())
+            gz_sets["gzip"].append(p + ".plain.gz")
+    for tag, gp in gz_sets.items():
+        out = os.path.join(base, "out")
+        subprocess.run(["rm", "-rf", out])
+        t0 = time.perf_counter()
+        r = subprocess.run([cli, "-1", gp[0], "-2", gp[1], "-d", out, "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + sys.argv[2:],
+                           env=dict(os.environ, FAQCS_MI_TIMING="1"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        dt = time.perf_counter() - t0
+        print("%s input (%.2f GB compressed per file): %d pairs in %.3f s = %.1f M reads/s (rc %d)" % (tag, os.path.getsize(gp[0]) / 1e9, n, dt, 2 * n / dt / 1e6, r.returncode))
 subprocess.run(["rm", "-rf", base])

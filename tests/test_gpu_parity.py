@@ -713,3 +713,65 @@ def test_native_cli_pipes_a_report_script_to_R(tmp_path):
         want = tables + (["QC.kmerH.txt", "QC.Kmercount.txt"] if mode == "kmer" else [])
         assert all(t in seen for t in want) and "QC.stats.txt" in seen, seen          # R ran while the tables were there
         assert all((t in left) == (mode == "debug") for t in want), left                # and they are gone afterwards unless --debug
+
+
+def _write_bgzf(path, data, block=60000, level=4):
+    """BGZF (bgzip / htslib): gzip members of <= 64 KiB with a 'BC' extra subfield that holds the member's size - 1."""
+    import struct
+    import zlib
+
+    with open(path, "wb") as f:
+        for o in list(range(0, len(data), block)) + [None]:
+            raw = b"" if o is None else data[o:o + block]   # (the last, empty member is BGZF's end-of-file marker)
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            body = c.compress(raw) + c.flush()
+            bsize = 12 + 6 + len(body) + 8
+            f.write(struct.pack("<4BI2BH2BHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize - 1))
+            f.write(body)
+            f.write(struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw) & 0xffffffff))
+
+
+def test_native_cli_reads_bgzf_in_parallel(tmp_path):
+    """bgzip-compressed inputs are inflated member by member by a thread pool (BgzfReader in faqcs_cli.cpp): same output bytes
+    as from the plain files, and as from the same .gz read through gzread (FAQCS_MI_NO_BGZF=1)."""
+    import hashlib
+    import subprocess
+
+    import make_fixtures
+
+    rng = np.random.Generator(np.random.PCG64([505, SEED]))
+    n = 3 * 32768 + 1234
+    texts = [[], []]
+    for i in range(n):
+        for m in (0, 1):
+            s, q = make_fixtures._adv_read(rng, 120)
+            if len(s) == 0:
+                s, q = np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"IIII", np.uint8)
+            texts[m].append(b"@p%d/%d\n%s\n+\n%s\n" % (i, m + 1, s.tobytes(), q.tobytes()))
+    plain, gz = [], []
+    for m in (0, 1):
+        data = b"".join(texts[m])
+        plain.append(str(tmp_path / ("r%d.fastq" % (m + 1))))
+        gz.append(str(tmp_path / ("r%d.fastq.gz" % (m + 1))))
+        with open(plain[-1], "wb") as f:
+            f.write(data)
+        _write_bgzf(gz[-1], data)
+
+    def run(tag, inputs, env_extra):
+        out = tmp_path / tag
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([_CLI_BIN, "-1", inputs[0], "-2", inputs[1], "-d", str(out), "--ascii", "33", "--adapter", "--trim_only"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        return {f: hashlib.md5(open(out / f, "rb").read()).hexdigest() for f in sorted(os.listdir(out))}
+
+    want = run("plain", plain, {})
+    assert run("bgzf", gz, {}) == want
+    assert run("gzread", gz, {"FAQCS_MI_NO_BGZF": "1"}) == want
+    # unpaired, and a file whose last member is cut off: the run ends like a failing gzread (no hang, no crash)
+    data = open(gz[0], "rb").read()
+    cut = str(tmp_path / "cut.fastq.gz")
+    with open(cut, "wb") as f:
+        f.write(data[: len(data) // 2])
+    r = subprocess.run([_CLI_BIN, "-u", cut, "-d", str(tmp_path / "cut_out"), "--ascii", "33", "--trim_only"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode in (0, 1)
