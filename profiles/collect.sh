@@ -26,7 +26,7 @@ FAQCS_BENCH_SHARE_GPU=1 python3 bench.py --config kmer --gpus 2 --pairs 4e6 --st
 python3 bench.py --at-frac 0.9 --pairs 40e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_at90_40Mpairs.json 2>> $out/bench_plain.err   # AT-rich genome: the dinucleotide counter on most reads
 python3 bench.py --read-len 128 --pairs 40e6 --no-cpu-baseline --e2e-pairs 0 > $out/bench_plain_128bp_40Mpairs.json 2>> $out/bench_plain.err  # (stays on trim_tpr: LDS bank stride)
 fi
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_plain -o plain -- python3 bench.py --pairs 25165824 --steps 3 --no-cpu-baseline --e2e-pairs 0 > $out/prof_plain.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_plain -o plain -- python3 bench.py --pairs 42949630 --steps 3 --no-cpu-baseline --e2e-pairs 0 > $out/prof_plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_adapter -o adapter -- python3 bench.py --config adapter --pairs 4e6 --steps 3 --no-cpu-baseline --e2e-pairs 0 > $out/prof_adapter.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python3 tests/ablate.py 0 16e6 > $out/pmc_$c.log 2>&1
@@ -37,5 +37,5 @@ bash profiles/pmc_insts.sh $tag/insts1 > $out/pmc_instruction_mix.txt 2>&1
 PMC="SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH SQ_INSTS_SMEM" bash profiles/pmc_insts.sh $tag/insts2 >> $out/pmc_instruction_mix.txt 2>&1
 bash profiles/pmc_adapter.sh $tag/adapter 0.05 > $out/pmc_adapter.txt 2>&1
 if [ "${SKIP_KMER_PMC:-0}" != 1 ]; then bash profiles/pmc_kmer.sh $tag/kmer > $out/pmc_kmer_atomics.txt 2>&1; fi
-cp $out/prof_plain/plain_kernel_stats.csv $out/rocprofv3_kernel_stats_bench_plain_25Mpairs.csv; cp $out/prof_adapter/adapter_kernel_stats.csv $out/rocprofv3_kernel_stats_bench_adapter_4Mpairs.csv
+cp $out/prof_plain/plain_kernel_stats.csv $out/rocprofv3_kernel_stats_bench_plain_43Mpairs.csv; cp $out/prof_adapter/adapter_kernel_stats.csv $out/rocprofv3_kernel_stats_bench_adapter_4Mpairs.csv
 ls -la $out
