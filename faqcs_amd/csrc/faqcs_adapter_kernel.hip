@@ -531,7 +531,13 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overla
         const uint64_t m_all = A.n_adapters >= 64 ? ~0ull : ((1ull << A.n_adapters) - 1ull);
         if (!read_bad && qlen > 0 && !(m_pass == 0 && m_any == m_all)) {
             // the per-base arrays of stage 2 are only needed here (a few percent of the reads)
-            for (int p = lane; p < qlen; p += 64) { q[p] = s_na[seq[(size_t)o + p]]; mk[p] = 1; }
+            // (from the bytes this lane fetched for pack_query: a second global load here stalled every such read -- a fifth of them
+            // with --polyA, whose weak threshold lets ~15 % of random reads through the prefilter -- for a memory latency)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int p = c * 64 + lane;
+                if (p < qlen) { q[p] = s_na[cbyte[c]]; mk[p] = 1; }
+            }
             lds_sync_wave();
 #pragma unroll 1
             for (uint32_t j = 0; j < A.n_adapters; ++j) {

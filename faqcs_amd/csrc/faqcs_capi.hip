@@ -641,7 +641,8 @@ extern "C" int faqcs_wait(faqcs_ctx *c, uint64_t ticket)
 extern "C" void *faqcs_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    // portable: a buffer is handed to whichever device context takes the next 32 768-read block (faqcs_mi --gpus N)
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
     return p;
 }
 
