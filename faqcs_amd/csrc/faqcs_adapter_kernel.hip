@@ -61,13 +61,10 @@ __device__ __forceinline__ void lds_sync_wave()
 // built ONCE per read (40 or 56 v_alignbit) and every (block, word) step is 4 and/or + 1 popcount on registers -- no LDS read,
 // no shift.  Returns the largest per-diagonal match count of this lane.
 // NBR = blocks the window array covers (4 when |read| + |longest short adapter| - 1 <= 256, else 6): e = w - 2 b + 2 (NBR - 1)
-// (x & y) | z in ONE instruction; the compiler otherwise pairs the four plane ANDs as and + and + or3
-__device__ __forceinline__ uint32_t and_or_(uint32_t x, uint32_t y, uint32_t z)
-{
-    uint32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-    return r;
-}
+// (x & y) | z in ONE instruction.  Written as the v_bitop3_b32 builtin (truth table 0xEA), not as inline assembly: the compiler
+// pairs a plain C expression as and + and + or3, and it fenced every inline v_and_or_b32 of a dependent chain with an s_nop
+// (nine per plane word in the three-block variant).
+__device__ __forceinline__ uint32_t and_or_(uint32_t x, uint32_t y, uint32_t z) { return __builtin_amdgcn_bitop3_b32(x, y, z, 0xEA); }
 __device__ __forceinline__ uint32_t plane_match(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, const uint4 &t)
 {
     return and_or_(r3, t.w, and_or_(r2, t.z, and_or_(r1, t.y, r0 & t.x)));
