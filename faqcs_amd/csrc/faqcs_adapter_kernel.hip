@@ -97,8 +97,11 @@ __device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][2 * NBR
     return m;
 }
 
+#ifndef FAQCS_ADAPTER_WAVES
+#define FAQCS_ADAPTER_WAVES 4 /* waves per SIMD the 256-base variant is compiled for (5 = 96 VGPRs with 12 spilled: measured, no faster) */
+#endif
 template <int NW, int MAXLEN>
-__global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : 4) void adapter_overlap(
+__global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS_ADAPTER_WAVES : 4)) void adapter_overlap(
     const AdapterDev A, const uint8_t *__restrict__ seq, const uint32_t *__restrict__ off, const uint32_t n_reads,
     const uint32_t *__restrict__ seg_start, const uint32_t n_segments, uint32_t *__restrict__ ad_sl,
     uint16_t *__restrict__ ad_hit, uint64_t *__restrict__ adapter_stats, uint32_t *__restrict__ err, const uint32_t dbg)
