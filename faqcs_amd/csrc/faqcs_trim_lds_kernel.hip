@@ -1,5 +1,5 @@
 // faqcs_trim_lds_kernel.hip -- trim_lds: the trim / filter / accumulate pass with every byte read from HBM ONCE, as
-// coalesced 16-byte LDS-DMA loads (global_load_lds_dwordx4), for reads of up to 160 bases (gfx950, wave64).
+// coalesced 16-byte LDS-DMA loads (global_load_lds_dwordx4), for reads of 77 ... 152 bases (gfx950, wave64).
 //
 // Replaces trim_read() and its helpers (trim.cpp:225-551, :553-597, :629-885, :1191-1216) like the other trim kernels;
 // the accumulators, the block flush and the chunk epilogue are shared with them (faqcs_trim_common.h).
@@ -8,8 +8,8 @@
 // contiguous span of <= 64 x W bytes per arena: the wave copies the span of the QUALITY arena into its 9.8 KB slot of LDS
 // with <= 10 wave-wide DMA instructions (1 KB each, no VGPR round trip), works on it, then copies the span of the BASE
 // arena into the same slot and works on that.  Inside a slot read i still starts at (offset[i] - span start): a lane reads
-// "its" read with per-lane LDS addresses (dynamic indexing that a register-resident copy cannot give), and LDS takes
-// unaligned dword reads, so no byte shuffling is left.
+// "its" read with per-lane LDS addresses (dynamic indexing that a register-resident copy cannot give) -- as two ALIGNED
+// dwords and one v_alignbyte per four bytes: a misaligned ds_read_b32 is legal on gfx950 but serialises the wave.
 //
 //   Q-A  one read per lane      terminal-N patch (in place, rare), sum + range check of the qualities four bytes per
 //                               instruction, the two BWA_plus walks exactly as trim.cpp:714-793 states them -- every lane
@@ -19,13 +19,17 @@
 //                               (position inside the read -> pre count, inside the kept window -> post count)
 //   S-A  one read per lane      base classes (LDS table, 8-bit one-hot A,T,C,G fields + upper-case-N bit), counts before /
 //                               inside the kept window, poly-N, low complexity -> the read's verdict
-//   S-B  8 lanes per read       position x base accumulation in registers (6-bit fields); bases outside the kept window are
-//                               flagged in bit 7 so that ONE 8-byte table entry yields the pre and the post increment
+//   S-B  8 lanes per read       position x base accumulation in registers (6-bit fields): ONE 8-byte table entry yields the pre
+//                               and the post increment; a base outside the kept window is looked up at (byte ^ 1), whose entry
+//                               carries that base's pre increment and no post increment (b and b ^ 1 are never both bases)
 //   epilogue, one read per lane result word, composition records, small histograms, FilterStat (chunk_epilogue)
 //
 // The post-trim quality cells are added in Q-B, before S-A can veto the read (poly-N / low complexity / average quality):
 // a vetoed read is rare, and its post cells are taken back by a small corrective pass over the chunk (Q-B with a negative
 // increment) after the bases have been judged.
+//
+// Dispatch (faqcs_launch_trim_lds at the end of the file): every option set except --replace_to_N_q; batches whose longest
+// read is a multiple of 32 bases stay on trim_tpr (LDS bank stride of the lane-per-read passes).
 #include "faqcs_trim_common.h"
 
 #include <stdlib.h>
@@ -48,7 +52,7 @@ template <int C, int NW> struct LdsCfg {
     static constexpr int NP = (W + 15) / 16;                   // 16-byte pieces (the out-of-line exact passes)
     static constexpr int NWORD = (ND * 4 + 31) / 32;
     static constexpr int O_T2 = (Row::LDS_DWORDS + 3) & ~3;    // [256][2] S-A: A,T,C,G one-hot in 8-bit fields ; isN(upper) | isN(any) << 1
-    static constexpr int O_T3 = O_T2 + 512;                    // [256][2] S-B: 6-bit count fields, pre ; post (bytes >= 128: outside the kept window)
+    static constexpr int O_T3 = O_T2 + 512;                    // [256][2] S-B: 6-bit count fields, pre ; post (entry[b ^ 1]: b outside the kept window)
     static constexpr int O_STG = O_T3 + 512;
     static constexpr int STG_BYTES = 64 * W + 32;              // one arena's span of a chunk + 16-byte alignment slack
     static constexpr int STG_DW = (STG_BYTES + 15) / 16 * 4;
