@@ -1,9 +1,11 @@
 // faqcs_trim_kernel.hip -- trim_tpr, trim_filter_accumulate + composition_histogram (gfx950, wave64).
 //
 // Replaces trim_read() and its helpers (trim.cpp:225-551, :553-597, :629-885, :1191-1216) for every read
-// of a batch.  Two kernels share the accumulators, the flush and the per-chunk epilogue:
-//   trim_tpr                 the default option set on reads of up to 160 bases (the headline shapes): two phases per
-//                            64-read chunk, described at its definition further down
+// of a batch.  Three kernels share the accumulators, the flush and the per-chunk epilogue (faqcs_trim_common.h);
+// faqcs_launch_trim at the end of this file picks one per submission:
+//   trim_lds (faqcs_trim_lds_kernel.hip)   reads of 77 ... 152 bases, every option set but --replace_to_N_q: the headline shapes
+//   trim_tpr                 the default-like option sets on reads of up to 160 bases that trim_lds does not take (<= 76,
+//                            153 ... 160 and multiple-of-32 lengths): two phases per 64-read chunk, described at its definition
 //   trim_filter_accumulate   every other option set and read length: one pass, described here
 //
 // Mapping (trim_filter_accumulate).  LPR lanes share one read and lane l of the group owns the C consecutive positions [l*C, l*C+C), fetched
