@@ -448,14 +448,43 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                     if (may_pass) { // rare: the per-block bounds for stage 2 (it aligns the most promising block first and prunes the rest)
                         uint32_t cw[8];
                         (void)prefilter_max<NBR, NBR, true>(R, tpl, nw, cw);
+                        // Second filter.  The match-count bound is weak for short adapters with a low threshold (polyA: 16 of 20 lets
+                        // ~15 % of random reads through).  For a block whose count bound reaches `need` the exact best score of every
+                        // diagonal is cheap to get from the SAME match bits: a score-only Kadane, 4 instructions per cell, no start
+                        // tracking (seq_overlap.cpp:185-188; a cell outside the read has match bit 0 and can only lower M, which is what
+                        // the exact pass's reset to -1 does too).  The wave maximum is the block's exact bound: num_match =
+                        // (match_length + score) / 2 <= (mcap + score) / 2, so a read passes only if some block's best score reaches `need`.
+                        bool pass2 = false;
 #pragma unroll
                         for (int b = 0; b < 8; ++b) {
                             if (b < NBR && b < nb) {
-                                const uint32_t bnd = wave_max_u32(cw[b]) + (uint32_t)slack;
+                                uint32_t bnd = wave_max_u32(cw[b]) + (uint32_t)slack;
+                                if ((int)bnd >= need_j && bnd > 0u) { // (wave-uniform)
+                                    int M = -1, best = -1;
+#pragma unroll
+                                    for (int w = 0; w < 4; ++w) {
+                                        if (w < nw) {
+                                            const uint4 t = *reinterpret_cast<const uint4 *>(tpl + 4 * w);
+                                            const int e = w - 2 * b + 2 * (NBR - 1);
+                                            const uint32_t bits = plane_match(R[0][e], R[1][e], R[2][e], R[3][e], t);
+                                            const int kend = tlen - 32 * w < 32 ? tlen - 32 * w : 32;
+#pragma unroll 4
+                                            for (int kb = 0; kb < kend; ++kb) {
+                                                const int sc = (int)((bits >> kb) & 1u) * 2 - 1;
+                                                M = (M > 0 ? M : 0) + sc;
+                                                best = best > M ? best : M;
+                                            }
+                                        }
+                                    }
+                                    const int bx = (int)wave_max_u32((uint32_t)(best + 1)) - 1; // exact best score of the block (-1: no match)
+                                    bnd = bx > 0 ? (uint32_t)bx : 0u;
+                                    pass2 = pass2 || bx >= need_j;
+                                }
                                 if (lane == 0) s_sb[wave][j][b] = (uint8_t)(bnd > 255u ? 255u : bnd);
                             }
                         }
-                        m_bnd |= 1ull << j;
+                        may_pass = pass2;
+                        if (may_pass) m_bnd |= 1ull << j;
                     }
                 } else if (prefilter_on && MAXLEN <= 320 && NBR >= 6 && tpl_cached) {
                     // long target (PhiX, artifact sequences): the same register windows, sliding over the target two words
