@@ -1829,9 +1829,37 @@ void remove_file(const std::string &p)
 
 } // namespace
 
+// Host-only self checks (no device is touched): `faqcs_mi --bgzf_cat <file>` writes the inflated bytes of a BGZF file to stdout
+// through BgzfReader, `faqcs_mi --report_script <FaQCs options...>` prints the R script the report step would pipe.
+int host_self_check(int argc, char **argv)
+{
+    if (argc >= 3 && !strcmp(argv[1], "--bgzf_cat")) {
+        if (!BgzfReader::looks_like_bgzf(argv[2])) { fprintf(stderr, "not a BGZF file\n"); return 2; }
+        BgzfReader r;
+        if (!r.open(argv[2], 4)) { fprintf(stderr, "I/O error\n"); return 1; }
+        const char *data;
+        size_t n;
+        while ((n = r.next(data)) != 0) fwrite(data, 1, n, stdout);
+        const bool bad = r.failed;
+        r.close();
+        fflush(stdout);
+        return bad ? 3 : 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "--report_script")) {
+        std::vector<char *> av{argv[0]};
+        for (int i = 2; i < argc; ++i) av.push_back(argv[i]);
+        Opt o = parse_args((int)av.size(), av.data());
+        const std::string t = report_script(o);
+        fwrite(t.data(), 1, t.size(), stdout);
+        return 0;
+    }
+    return -1;
+}
+
 int main(int argc, char **argv)
 {
     try {
+        { const int rc = host_self_check(argc, argv); if (rc >= 0) return rc; }
         Opt opt = parse_args(argc, argv);
         for (auto &m : opt.messages) fprintf(stderr, "%s\n", m.c_str());
         if (opt.print_usage) {
