@@ -731,6 +731,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 const int kmax = uni((int)wave_max_u32((uint32_t)((len + 3) >> 2)));
                 const uint32_t sa = slot_b + rows, sa4 = sa & ~3u, ssh = sa & 3u;
                 uint32_t prev = lds_ld(sa4);
+#ifdef FAQCS_LDS_FAKE_SA // (diagnostic build: no class pass at all -- balanced fake counts, no N; what S-A's per-base work costs)
+                const uint32_t fk = ((uint32_t)my * 2654435761u) >> 28; // (spread the fake counts over a few dozen values, like real reads)
+                const uint32_t fd = fk < (uint32_t)(len >> 2) ? fk : 0u, fd2 = (fk >> 1) < (uint32_t)(len >> 2) ? (fk >> 1) : 0u;
+                cnt4 = (uint32_t)(len >> 2) * 0x01010101u + (uint32_t)(len & 3) + fd - (fd << 8) + (fd2 << 16) - (fd2 << 24);
+                sA = (uint32_t)(a >> 2) * 0x01010101u + (uint32_t)(a & 3);
+                sE = (uint32_t)((a + n) >> 2) * 0x01010101u + (uint32_t)((a + n) & 3);
+#pragma unroll
+                for (int wd = 0; wd < NWORD; ++wd) nub[wd] = 0;
+                (void)prev; (void)ssh; (void)nfull; (void)ka; (void)ke;
+#else
 #pragma unroll
                 for (int wd = 0; wd < NWORD; ++wd) {
                     uint32_t nw = 0;
@@ -761,6 +771,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     nub[wd] = nw;
                 }
                 if ((NPOS & 31) != 0) nub[NWORD - 1] >>= (32 - (NPOS & 31));
+#endif
                 if (ka >= kmax) sA = cnt4; // (the loops stop at the wave's longest read: a window end on that read's last dword
                 if (ke >= kmax) sE = cnt4; //  boundary is never visited; nothing is counted past kmax, so the total is the prefix)
                 const int nACGT = (int)__builtin_amdgcn_sad_u8(cnt4, 0u, 0u);
@@ -825,10 +836,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     return c;
                 };
                 uint32_t c4post = cnt4;
+#ifdef FAQCS_LDS_FAKE_SA
+                {
+                    const uint32_t fk = ((uint32_t)my * 2654435761u) >> 28;
+                    const uint32_t fd = fk < (uint32_t)(n >> 2) ? fk : 0u, fd2 = (fk >> 1) < (uint32_t)(n >> 2) ? (fk >> 1) : 0u;
+                    c4post = (uint32_t)(n >> 2) * 0x01010101u + (uint32_t)(n & 3) + fd - (fd << 8) + (fd2 << 16) - (fd2 << 24);
+                }
+                (void)partial;
+#else
                 if (__any(ret && (a != 0 || n != len))) {
                     c4post = sE + partial(a + n);
                     if (__any(a != 0)) c4post -= sA + partial(a);
                 }
+#endif
                 pA = cnt4 & 0xffu; pT = (cnt4 >> 8) & 0xffu; pC = (cnt4 >> 16) & 0xffu; pG = cnt4 >> 24;
                 cA = c4post & 0xffu; cT = (c4post >> 8) & 0xffu; cC = (c4post >> 16) & 0xffu; cG = c4post >> 24;
                 pN = (uint32_t)(len - nACGT); cN = (uint32_t)n - (cA + cT + cC + cG); // (exact pass below when abn_seq)
