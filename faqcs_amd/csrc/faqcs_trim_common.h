@@ -48,8 +48,8 @@ template <int C, int LPR> struct RowCfg {
     static constexpr int O_TAVGQ = O_TLC + W + 1;  // [W+1]
     static constexpr int O_TMAGIC = O_TAVGQ + W + 1;
     static constexpr int BMW = D <= 4 ? 4 : 8;     // dwords per byte-mask row (one or two ds_read_b128)
-    static constexpr int O_TBM = (O_TMAGIC + W + 1 + 3) & ~3; // [C+1][BMW] byte masks "first vb bytes of the lane's dwords"
-    static constexpr int LDS_DWORDS = O_TBM + BMW * (C + 1);
+    static constexpr int O_TBM = (O_TMAGIC + W + 1 + 3) & ~3; // [C+2][BMW] byte masks "first vb bytes of the lane's dwords" (trim_lds: vb <= C + 1)
+    static constexpr int LDS_DWORDS = O_TBM + BMW * (C + 2);
     static constexpr int JB = C > 16 ? 5 : 4;      // bits of a position index inside the lane-local argmax keys
 };
 

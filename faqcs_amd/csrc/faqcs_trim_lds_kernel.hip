@@ -249,17 +249,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         smem[T::O_T2 + 2 * i] = ((w >> BT_SHIFT(0)) & 1u) | (((w >> BT_SHIFT(1)) & 1u) << 8) | (((w >> BT_SHIFT(2)) & 1u) << 16) | (((w >> BT_SHIFT(3)) & 1u) << 24);
         smem[T::O_T2 + 2 * i + 1] = (w >> 31) | (((w >> BT_SHIFT(4)) & 1u) << 1);
     }
-    for (int i = tid; i < 256; i += NW * 64) { // S-B: entry[b] = (pre, post) increments of base b; entry[b ^ 1] = (pre, 0): outside the kept window
-        const uint32_t f = P.base_tab[i] & BT_FIELDS, g = P.base_tab[i ^ 1] & BT_FIELDS; // (b and b ^ 1 are never both bases)
-        smem[T::O_T3 + 2 * i] = f | g;
-        smem[T::O_T3 + 2 * i + 1] = f;
+    for (int i = tid; i < 256; i += NW * 64) { // S: entry[b] = (pre, post) increments of the ASCII byte b; entry[b | 0x80] = (pre, 0): b outside the kept window
+        const uint32_t f = P.base_tab[i & 127] & BT_FIELDS; // (a byte >= 0x80 in the INPUT is no base: such a chunk is patched and redone, see the S pass)
+        smem[T::O_T3 + 2 * i] = f;
+        smem[T::O_T3 + 2 * i + 1] = i < 128 ? f : 0u;
     }
     for (int i = tid; i <= W; i += NW * 64) {
         smem[Cfg::O_TLC + i] = P.lc_thr[i];
         smem[Cfg::O_TAVGQ + i] = (uint32_t)P.avgq_min_v[i];
         smem[Cfg::O_TMAGIC + i] = P.div_magic[i];
     }
-    for (int i = tid; i < BMW * (C + 1); i += NW * 64) {
+    for (int i = tid; i < BMW * (C + 2); i += NW * 64) {
         const int nb = med3i((i / BMW) - 4 * (i % BMW), 0, 4);
         smem[Cfg::O_TBM + i] = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
     }
@@ -307,8 +307,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     auto load_b = [&](const uint32_t i0, const uint32_t i1, RawB &x) {
         const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
         const bool post = ((i1 >> 16) & 1u) != 0u;
-        const int vb = med3i(len - pbase, 0, C);
-        const int lo = post ? med3i(a - pbase, 0, C) : 0, hi = post ? med3i(a + n - pbase, 0, C) : 0;
+        const int vb = med3i(len - pbase, 0, C + 1);
+        const int lo = post ? med3i(a - pbase, 0, C + 1) : 0, hi = post ? med3i(a + n - pbase, 0, C + 1) : 0;
         const uint32_t qa = (slot_b + (i0 & 0xffffu) + (uint32_t)pbase) & ~3u;
 #pragma unroll
         for (int k = 0; k <= D; ++k) x.r[k] = lds_ld(qa + 4u * (uint32_t)k);
@@ -344,29 +344,110 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #endif
         }
     };
-    // position x base: 6-bit count fields in registers.  A base outside the kept window is looked up at (byte ^ 1) -- '@',
-    // 'B', 'F', 'U', 'O' and their lower-case forms, none of them a base -- whose entry carries the pre increment only; the
-    // neighbouring 8-byte entry sits in another pair of banks, so the two flavours of a base never collide.
-    auto base_cells = [&](const RawB &x, const uint32_t i0, const uint32_t i1) {
-        const bool counted = ((i1 >> 17) & 1u) != 0u;
+    // ---- S: position x base in registers (6-bit count fields), AND the read's own base counts, from ONE 8-byte table entry per base:
+    // .x = the pre-trim increment, .y = the post-trim increment.  A base outside the kept window is looked up at (byte | 0x80), whose
+    // entry carries the pre increment only (input bytes >= 0x80 are no bases: a chunk that holds one is undone, patched and redone).
+    // The lane's 19 increments are summed on the side (<= 19 per field), the 8 lanes of the read are added up by DPP (fields
+    // widened to 12 bits after the first step: a read has up to 152 bases) and the lane whose turn it is (rl == t) keeps the
+    // totals: what S-A used to compute with a second lookup per base in the lane-per-read layout.
+    // MODE 0: count ; 1: take back the post increments of the reads flagged in i1 (vetoed after counting) ; 2: take back everything
+    uint32_t tot_pe = 0, tot_po = 0, tot_ce = 0, tot_co = 0; // this lane's read: pre A | C << 12 | N << 24, pre T | G << 12, post ...
+    uint32_t seen7 = 0;                                       // OR of every counted base byte of the chunk (bit 7: abnormal input)
+    bool pairhit = false;                                     // this lane's read: two adjacent upper-case N inside the kept window
+    uint32_t nub[NWORD];                                      // (EXT, -n >= 3) this lane's read: upper-case N inside the kept window, one bit per position
+    auto base_step = [&](const int t, const uint32_t i0, const uint32_t i1, auto mode_t) {
+        constexpr int MODE = decltype(mode_t)::value;
+        const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
+        const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
+        const int vb = med3i(len - pbase, 0, C + 1);
+        const int lo = med3i(a - pbase, 0, C + 1), hi = med3i(a + n - pbase, 0, C + 1);
+        const uint32_t qa = (slot_b + (i0 & 0xffffu) + (uint32_t)pbase) & ~3u;
         const uint32_t sh = ((i0 & 0xffffu) + (uint32_t)pbase + slot_b) & 3u;
-        uint32_t ws[D];
+        uint32_t r[D + 1], w[D], inw[D];
+#pragma unroll
+        for (int k = 0; k <= D; ++k) r[k] = lds_ld(qa + 4u * (uint32_t)k);
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            const uint32_t w = __builtin_amdgcn_alignbyte(x.r[k + 1], x.r[k], sh) & (counted ? x.mv[k] : 0u);
-            ws[k] = w ^ (~(x.mh[k] ^ x.ml[k]) & 0x01010101u);
+            const uint32_t mv = t_bm[BMW * vb + k], mh = t_bm[BMW * hi + k], ml = t_bm[BMW * lo + k];
+            w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & (counted ? mv : 0u); // a byte past the read: 0, no class
+            inw[k] = mh ^ ml;                                                             // 0xff: inside the kept window
         }
+        uint32_t tp = 0, tq = 0;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            const uint32_t ad = ((j & 3) == 0 ? byte_x8<0>(ws[j >> 2], three) : (j & 3) == 1 ? byte_x8<1>(ws[j >> 2], three)
-                                 : (j & 3) == 2 ? byte_x8<2>(ws[j >> 2], three) : byte_x8<3>(ws[j >> 2], three)) + (uint32_t)(T::O_T3 * 4);
-#ifndef FAQCS_LDS_NO_SB_LOOKUP
+            const int k = j >> 2;
+            if ((j & 3) == 0) {
+                if (MODE == 0) seen7 |= w[k];
+                w[k] ^= ~(post ? inw[k] : 0u) & 0x80808080u; // (w[k] is the table index from here on; bit 7 is put back for the N tests)
+            }
+            const uint32_t ad = ((j & 3) == 0 ? byte_x8<0>(w[k], three) : (j & 3) == 1 ? byte_x8<1>(w[k], three)
+                                 : (j & 3) == 2 ? byte_x8<2>(w[k], three) : byte_x8<3>(w[k], three)) + (uint32_t)(T::O_T3 * 4);
             const LdsPair2 e = *(lds_u2c_ptr)(size_t)ad;
-#else
-            LdsPair2 e; e.x = ad; e.y = ad >> 3; // (diagnostic build: no table lookup)
-#endif
-            bpre[j] += e.x;
-            bpost[j] += e.y;
+            if (MODE == 0) { bpre[j] += e.x; bpost[j] += e.y; tp += e.x; tq += e.y; }
+            if (MODE == 1) bpost[j] -= e.y;
+            if (MODE == 2) { bpre[j] -= e.x; bpost[j] -= e.y; }
+        }
+        if (MODE == 0) {
+            // the read's totals: 8 lanes, <= 19 per 6-bit field each; one step in 6-bit fields (<= 38), the rest in 12-bit fields
+            tp += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tp, 0xB1, 0xf, 0xf, false);
+            tq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tq, 0xB1, 0xf, 0xf, false);
+            uint32_t pe = tp & 0x3f03f03fu, po = (tp >> 6) & 0x0003f03fu, ce = tq & 0x3f03f03fu, co = (tq >> 6) & 0x0003f03fu;
+            pe += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x4E, 0xf, 0xf, false);
+            po += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)po, 0x4E, 0xf, 0xf, false);
+            ce += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ce, 0x4E, 0xf, 0xf, false);
+            co += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)co, 0x4E, 0xf, 0xf, false);
+            pe += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x141, 0xf, 0xf, false);
+            po += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)po, 0x141, 0xf, 0xf, false);
+            ce += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ce, 0x141, 0xf, 0xf, false);
+            co += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)co, 0x141, 0xf, 0xf, false);
+            const bool turn = rl == t;
+            tot_pe = turn ? pe : tot_pe; tot_po = turn ? po : tot_po; tot_ce = turn ? ce : tot_ce; tot_co = turn ? co : tot_co;
+            // ---- upper-case N inside the kept window (count_poly_n, trim.cpp:578-597): looked at only when the read has enough N
+            // (any case) in its window to matter, or when it is judged without being counted (chk) ----
+            const uint32_t cN = ce >> 24;
+            const bool chk = ((i1 >> 18) & 1u) != 0u;
+            const uint32_t need_n = (EXT && P.max_poly_n != 2u) ? P.max_poly_n : 2u;
+            if ((!EXT || P.max_poly_n >= 2u) && __any(cN >= need_n || chk)) {
+                uint32_t nb[D]; // bit 7 of a byte: upper-case 'N' inside the kept window
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const uint32_t orig = w[k] ^ (~(post ? inw[k] : 0u) & 0x80808080u); // (the byte itself again)
+                    const uint32_t x = (orig & inw[k]) ^ 0x4e4e4e4eu;
+                    const uint32_t sx = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+                    nb[k] = ~(sx | x) & 0x80808080u;
+                }
+                if (!EXT || P.max_poly_n == 2u) { // two adjacent N: positions (j, j + 1), j one of the lane's C positions
+                    uint32_t hit = 0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        uint32_t here = nb[k];
+                        if (4 * k + 4 > C) here &= low_bytes_(C - 4 * k); // j < C
+                        const uint32_t next = k + 1 < D ? __builtin_amdgcn_alignbyte(nb[k + 1], nb[k], 1u) : (nb[k] >> 8);
+                        hit |= here & next;
+                    }
+                    const bool rowhit = RowOps<8>::all_or(hit) != 0u;
+                    pairhit = turn ? rowhit : pairhit;
+                } else { // -n >= 3: the read's N positions as a bit mask, for the run test after the loop
+                    uint32_t m = 0; // the lane's C positions
+#pragma unroll
+                    for (int k = 0; k < D; ++k) m |= ((((nb[k] >> 7) * 0x00204081u) >> 21) & 0xfu) << (4 * k);
+                    m &= (1u << C) - 1u;
+                    const uint32_t p0 = (uint32_t)pbase, wd0 = p0 >> 5, s0 = p0 & 31u;
+                    const uint32_t mlo = m << s0, mhi = s0 ? m >> (32u - s0) : 0u;
+#pragma unroll
+                    for (int wd = 0; wd < NWORD; ++wd) {
+                        const uint32_t c = ((uint32_t)wd == wd0 ? mlo : 0u) | ((uint32_t)wd == wd0 + 1u ? mhi : 0u);
+                        const uint32_t all = RowOps<8>::all_or(c);
+                        nub[wd] = turn ? all : nub[wd];
+                    }
+                }
+            } else if (MODE == 0) {
+                pairhit = turn ? false : pairhit;
+                if (EXT && P.max_poly_n >= 3u) {
+#pragma unroll
+                    for (int wd = 0; wd < NWORD; ++wd) nub[wd] = turn ? 0u : nub[wd];
+                }
+            }
         }
     };
     // (Measured and not kept: a 160-wide table grid with the four rows of a half wave started 0..3 positions apart, which makes
@@ -706,7 +787,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // ================= Q-B: 8 lanes per read, position x quality ===========================================
             // (post cells are added for every read that is still valid; S-A's vetoes are taken back below)
             const uint32_t qi0 = rowq | ((uint32_t)len << 16);
-            const uint32_t qi1 = (uint32_t)a | ((uint32_t)n << 8) | (ret ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u);
+            // retc: the read is still kept as far as the qualities can tell (an average-quality failure is final whatever poly-N says later)
+            const bool retc = ret && !avgq_fail;
+            const uint32_t qi1 = (uint32_t)a | ((uint32_t)n << 8) | (retc ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u);
 #define FAQCS_QCELLS(X, A, B) quality_cells(X, A, B, std::false_type{})
             FAQCS_B_LOOP(qi0, qi1, FAQCS_QCELLS)
 #undef FAQCS_QCELLS
@@ -720,138 +803,73 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FAQCS_STAMP(5)
 
-            // ================= S-A: one read per lane, the bases =====================================================
-            const bool ret_q = ret;
-            uint32_t pA, pT, pC, pG, pN, cA, cT, cC, cG, cN;
-            {
-                // ---- classes: A,T,C,G counts (8-bit fields), the counts in front of the kept window's two ends, upper-case N bits ----
-                uint32_t cnt4 = 0, nub[NWORD], sA = 0, sE = 0;
-                const int ka = a >> 2, ke = (a + n) >> 2;
-                const int nfull = len >> 2;
-                const int kmax = uni((int)wave_max_u32((uint32_t)((len + 3) >> 2)));
-                const uint32_t sa = slot_b + rows, sa4 = sa & ~3u, ssh = sa & 3u;
-                uint32_t prev = lds_ld(sa4);
-#ifdef FAQCS_LDS_FAKE_SA // (diagnostic build: no class pass at all -- balanced fake counts, no N; what S-A's per-base work costs)
-                const uint32_t fk = ((uint32_t)my * 2654435761u) >> 28; // (spread the fake counts over a few dozen values, like real reads)
-                const uint32_t fd = fk < (uint32_t)(len >> 2) ? fk : 0u, fd2 = (fk >> 1) < (uint32_t)(len >> 2) ? (fk >> 1) : 0u;
-                cnt4 = (uint32_t)(len >> 2) * 0x01010101u + (uint32_t)(len & 3) + fd - (fd << 8) + (fd2 << 16) - (fd2 << 24);
-                sA = (uint32_t)(a >> 2) * 0x01010101u + (uint32_t)(a & 3);
-                sE = (uint32_t)((a + n) >> 2) * 0x01010101u + (uint32_t)((a + n) & 3);
-#pragma unroll
-                for (int wd = 0; wd < NWORD; ++wd) nub[wd] = 0;
-                (void)prev; (void)ssh; (void)nfull; (void)ka; (void)ke;
-#else
-#pragma unroll
-                for (int wd = 0; wd < NWORD; ++wd) {
-                    uint32_t nw = 0;
-                    const int kend = (8 * wd + 8 < ND) ? 8 * wd + 8 : ND;
-                    if (8 * wd < kmax) { // (wave-uniform)
-#pragma unroll FAQCS_LDS_SA_UNROLL
-                        for (int k = 8 * wd; k < kend; ++k) {
-                            const uint32_t nxt = lds_ld(sa4 + 4u * (uint32_t)k + 4u);
-                            uint32_t w = __builtin_amdgcn_alignbyte(nxt, prev, ssh);
-                            prev = nxt;
-                            if (__any(k >= nfull)) w &= low_bytes_(med3i(len - 4 * k, 0, 4)); // bytes past the read: class "none"
-                            sA = k == ka ? cnt4 : sA;
-                            sE = k == ke ? cnt4 : sE;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const uint32_t ad = (j == 0 ? byte_x8<0>(w, three) : j == 1 ? byte_x8<1>(w, three)
-                                                     : j == 2 ? byte_x8<2>(w, three) : byte_x8<3>(w, three)) + (uint32_t)(T::O_T2 * 4);
-#ifndef FAQCS_LDS_NO_SA_LOOKUP
-                                const LdsPair2 e = *(lds_u2c_ptr)(size_t)ad;
-#else
-                                LdsPair2 e; e.x = ad & 0x01010101u; e.y = ad >> 9; // (diagnostic build: no table lookup)
-#endif
-                                cnt4 += e.x;
-                                nw = __builtin_amdgcn_alignbit(e.y, nw, 1); // bit (p & 31) = upper-case N at p
-                            }
-                        }
-                    }
-                    nub[wd] = nw;
+            // ================= S: 8 lanes per read, the bases (base_step) ==============================================
+            // i1: a | n << 8 | post << 16 | counted << 17 | chk << 18.  chk: the read fails the average quality but is still judged for
+            // poly-N, which the reference tests first (trim.cpp:363-382).
+            const uint32_t si0 = rows | ((uint32_t)len << 16);
+            const uint32_t si1 = (uint32_t)a | ((uint32_t)n << 8) | (retc ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u) |
+                                 ((ret && !retc) ? 1u << 18 : 0u);
+#define FAQCS_S_LOOP(I1, MODE)                                                                                        \
+    {                                                                                                                 \
+        _Pragma("unroll 1") for (int t = 0; t < LPR; ++t) {                                                          \
+            if (base + (uint32_t)t >= n_reads) break; /* wave-uniform: no row has a read left */                      \
+            const uint32_t a1_ = (uint32_t)__shfl((int)(I1), rowb + t);                                               \
+            if (MODE == 1 && !__any(((a1_ >> 16) & 1u) != 0u)) continue;                                              \
+            const uint32_t a0_ = (uint32_t)__shfl((int)si0, rowb + t);                                                \
+            base_step(t, a0_, a1_, std::integral_constant<int, MODE>{});                                              \
+        }                                                                                                             \
+    }
+            seen7 = 0;
+            FAQCS_S_LOOP(si1, 0)
+            if (__any((seen7 & 0x80808080u) != 0u)) {
+                // a byte >= 0x80 among the bases: it was looked up as "outside the kept window".  Take the chunk back, blank such bytes
+                // in the slot (no class: what the reference's switch does with them, trim.cpp:831-857) and count again.
+                FAQCS_S_LOOP(si1, 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+                for (int p = 0; __any(p < len); ++p) {
+                    if (p < len && (lds_ld_u8(slot_b + rows + (uint32_t)p) & 0x80u)) lds_st_u8(slot_b + rows + (uint32_t)p, 0u);
                 }
-                if ((NPOS & 31) != 0) nub[NWORD - 1] >>= (32 - (NPOS & 31));
-#endif
-                if (ka >= kmax) sA = cnt4; // (the loops stop at the wave's longest read: a window end on that read's last dword
-                if (ke >= kmax) sE = cnt4; //  boundary is never visited; nothing is counted past kmax, so the total is the prefix)
-                const int nACGT = (int)__builtin_amdgcn_sad_u8(cnt4, 0u, 0u);
-                int nup = 0;
-#pragma unroll
-                for (int w = 0; w < NWORD; ++w) nup += __builtin_popcount(nub[w]);
-                const bool abn_seq = nACGT + nup != len; // a letter that is neither ACGT (any case) nor 'N'
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                FAQCS_S_LOOP(si1, 0)
+            }
 
+            FAQCS_STAMP(6)
+            // ================= one read per lane again: the verdicts that depend on the bases ==========================
+            uint32_t pA = tot_pe & 0xfffu, pC = (tot_pe >> 12) & 0xfffu, pN = tot_pe >> 24, pT = tot_po & 0xfffu, pG = tot_po >> 12;
+            uint32_t cA = tot_ce & 0xfffu, cC = (tot_ce >> 12) & 0xfffu, cN = tot_ce >> 24, cT = tot_co & 0xfffu, cG = tot_co >> 12;
+            {
                 // ---- poly-N (trim.cpp:363-371, :578-597): -n 2 = two adjacent upper-case N inside the kept window ----
+                bool polyn;
                 if (EXT && P.max_poly_n != 2u) { // -n 0: every read trips; -n k: a run of k upper-case N inside the kept window
                     uint32_t run[NWORD], hit = 0;
+                    if (P.max_poly_n != 0u) {
 #pragma unroll
-                    for (int w = 0; w < NWORD; ++w) run[w] = nub[w] & bit_range_(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
-                    // bit e of `run` after i rounds: N at e - i .. e, all inside the window
+                        for (int w = 0; w < NWORD; ++w) run[w] = nub[w] & bit_range_(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
+                        // bit e of `run` after i rounds: N at e - i .. e, all inside the window
 #pragma unroll 1
-                    for (uint32_t i = 1; i < P.max_poly_n && i <= (uint32_t)NPOS; ++i) {
-                        uint32_t carry = 0;
+                        for (uint32_t i = 1; i < P.max_poly_n && i <= (uint32_t)NPOS; ++i) {
+                            uint32_t carry = 0;
 #pragma unroll
-                        for (int w = 0; w < NWORD; ++w) {
-                            const uint32_t shifted = (run[w] << 1) | carry;
-                            carry = run[w] >> 31;
-                            run[w] = shifted & nub[w] & bit_range_(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
+                            for (int w = 0; w < NWORD; ++w) {
+                                const uint32_t shifted = (run[w] << 1) | carry;
+                                carry = run[w] >> 31;
+                                run[w] = shifted & nub[w] & bit_range_(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
+                            }
                         }
-                    }
 #pragma unroll
-                    for (int w = 0; w < NWORD; ++w) hit |= run[w];
-                    if (ret && (P.max_poly_n == 0u || (hit != 0u && P.max_poly_n <= (uint32_t)NPOS))) {
-                        flags |= FAQCS_F_POLY_N_SEEN;
-                        if (do_trim) { ret = false; filt = FAQCS_FILT_POLY_N; } // --qc_only counts it and keeps the read (trim.cpp:368-370)
+                        for (int w = 0; w < NWORD; ++w) hit |= run[w];
                     }
+                    polyn = P.max_poly_n == 0u || (hit != 0u && P.max_poly_n <= (uint32_t)NPOS);
                 } else {
-                    uint32_t pr[NWORD], anyp = 0; // bit e: N at e - 1 and at e
-#pragma unroll
-                    for (int w = 0; w < NWORD; ++w) {
-                        pr[w] = nub[w] & ((nub[w] << 1) | (w ? nub[w - 1] >> 31 : 0u));
-                        anyp |= pr[w];
-                    }
-                    if (__any(ret && anyp != 0u)) {
-                        uint32_t hit = 0;
-#pragma unroll
-                        for (int w = 0; w < NWORD; ++w) hit |= pr[w] & bit_range_(med3i(a + 1 - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));
-                        if (ret && hit != 0u) {
-                            flags |= FAQCS_F_POLY_N_SEEN;
-                            if (do_trim) { ret = false; filt = FAQCS_FILT_POLY_N; }
-                        }
-                    }
+                    polyn = pairhit;
+                }
+                if (ret && polyn) {
+                    flags |= FAQCS_F_POLY_N_SEEN;
+                    if (do_trim) { ret = false; filt = FAQCS_FILT_POLY_N; } // --qc_only counts it and keeps the read (trim.cpp:368-370)
                 }
                 // ---- average quality (judged in Q-A, applied here: after poly-N, trim.cpp:374-382) ----
                 if (EXT && ret && avgq_fail) { ret = false; filt = FAQCS_FILT_AVG_Q; }
-
-                // ---- base counts before / inside the kept window (trim.cpp:390-403, :810-875) ---------------------
-                // prefix(x) = count in front of dword x >> 2 plus the x & 3 bytes in front of x
-                auto partial = [&](int x) -> uint32_t {
-                    uint32_t c = 0;
-                    if (__any((x & 3) != 0)) {
-                        uint32_t w = 0;
-                        w = lds_ld_any(slot_b + rows + (uint32_t)(x & ~3)) & (low_bytes_(x & 3) & ((x & 3) ? 0xffffffffu : 0u));
-                        c += ((lds_u2c_ptr)(size_t)(byte_x8<0>(w, three) + (uint32_t)(T::O_T2 * 4)))->x;
-                        c += ((lds_u2c_ptr)(size_t)(byte_x8<1>(w, three) + (uint32_t)(T::O_T2 * 4)))->x;
-                        c += ((lds_u2c_ptr)(size_t)(byte_x8<2>(w, three) + (uint32_t)(T::O_T2 * 4)))->x;
-                    }
-                    return c;
-                };
-                uint32_t c4post = cnt4;
-#ifdef FAQCS_LDS_FAKE_SA
-                {
-                    const uint32_t fk = ((uint32_t)my * 2654435761u) >> 28;
-                    const uint32_t fd = fk < (uint32_t)(n >> 2) ? fk : 0u, fd2 = (fk >> 1) < (uint32_t)(n >> 2) ? (fk >> 1) : 0u;
-                    c4post = (uint32_t)(n >> 2) * 0x01010101u + (uint32_t)(n & 3) + fd - (fd << 8) + (fd2 << 16) - (fd2 << 24);
-                }
-                (void)partial;
-#else
-                if (__any(ret && (a != 0 || n != len))) {
-                    c4post = sE + partial(a + n);
-                    if (__any(a != 0)) c4post -= sA + partial(a);
-                }
-#endif
-                pA = cnt4 & 0xffu; pT = (cnt4 >> 8) & 0xffu; pC = (cnt4 >> 16) & 0xffu; pG = cnt4 >> 24;
-                cA = c4post & 0xffu; cT = (c4post >> 8) & 0xffu; cC = (c4post >> 16) & 0xffu; cG = c4post >> 24;
-                pN = (uint32_t)(len - nACGT); cN = (uint32_t)n - (cA + cT + cC + cG); // (exact pass below when abn_seq)
 
                 // ---- low-complexity filter (trim.cpp:405-513) ---------------------------------------------------
                 bool lc_trip = false, dinuc = false;
@@ -901,37 +919,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     }
                     if (two) lc_trip = lc_trip || dxy >= dthr || dyx >= dthr;
                 }
-                // exact per-position pass over the arena: N counts for reads with other letters, every transition count for the
-                // general dinucleotide case (both rare)
-                if (__any(abn_seq || dinuc_general)) {
-                    const ExactB xb = exact_bases(seq, v_off, len, a, n, abn_seq || dinuc_general, dinuc_general, dthr);
-                    if (abn_seq) { pN = xb.npre; cN = xb.npost; }
+                // exact per-position pass over the arena: every transition count for the general dinucleotide case (rare)
+                if (__any(dinuc_general)) {
+                    const ExactB xb = exact_bases(seq, v_off, len, a, n, dinuc_general, dinuc_general, dthr);
                     if (dinuc_general) lc_trip = lc_trip || xb.trip;
-                    // S-B looks a base outside the kept window up at (byte ^ 1): a letter that is no base must not pass for one
-                    if (__any(abn_seq)) {
-#pragma unroll 1
-                        for (int p = 0; __any(abn_seq && p < len); ++p) {
-                            if (abn_seq && p < len) {
-                                const uint32_t b = lds_ld_u8(slot_b + rows + (uint32_t)p);
-                                const LdsPair2 e = *(lds_u2c_ptr)(size_t)(b * 8u + (uint32_t)(T::O_T2 * 4));
-                                if ((e.x | e.y) == 0u) lds_st_u8(slot_b + rows + (uint32_t)p, 0u);
-                            }
-                        }
-                    }
                 }
                 if (ret && lc_trip) { ret = false; filt = FAQCS_FILT_LOW_COMPLEXITY; }
             }
 
-            FAQCS_STAMP(6)
-            // ================= S-B: 8 lanes per read, position x base ==============================================
-            const uint32_t si0 = rows | ((uint32_t)len << 16);
-            const uint32_t si1 = (uint32_t)a | ((uint32_t)n << 8) | (ret ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u);
-            FAQCS_B_LOOP(si0, si1, base_cells)
-
             FAQCS_STAMP(7)
-            // ---- a read S-A rejected after Q-B counted its post cells: take them back (needs the qualities again) ----
-            const bool veto = ret_q && !ret;
+            // ---- a read rejected here after its post-trim cells were counted: take them back, the bases first (still staged), then
+            // the qualities (staged again) ----
+            const bool veto = retc && !ret;
             if (__any(veto)) {
+                const uint32_t vi1 = (uint32_t)a | ((uint32_t)n << 8) | (veto ? 1u << 16 : 0u) | (veto ? 1u << 17 : 0u);
+                FAQCS_S_LOOP(vi1, 1)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 dma_span<NI>(qual + cs - shq, ce - cs + shq, slot, lane);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -960,6 +962,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+#undef FAQCS_S_LOOP
 
             if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
             oc.an = (uint32_t)a | ((uint32_t)n << 16);
