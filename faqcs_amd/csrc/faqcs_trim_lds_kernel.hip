@@ -406,8 +406,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // (any case) in its window to matter, or when it is judged without being counted (chk) ----
             const uint32_t cN = ce >> 24;
             const bool chk = ((i1 >> 18) & 1u) != 0u;
+            // -n 2 (the default): a pair test; -n k, k != 0: the read's N positions as a bit mask (a run of k needs k N); -n 0: nothing to look at
             const uint32_t need_n = (EXT && P.max_poly_n != 2u) ? P.max_poly_n : 2u;
-            if ((!EXT || P.max_poly_n >= 2u) && __any(cN >= need_n || chk)) {
+            if ((!EXT || P.max_poly_n != 0u) && __any(cN >= need_n || chk)) {
                 uint32_t nb[D]; // bit 7 of a byte: upper-case 'N' inside the kept window
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     }
                     const bool rowhit = RowOps<8>::all_or(hit) != 0u;
                     pairhit = turn ? rowhit : pairhit;
-                } else { // -n >= 3: the read's N positions as a bit mask, for the run test after the loop
+                } else { // -n 1, -n >= 3: the read's N positions as a bit mask, for the run test after the loop
                     uint32_t m = 0; // the lane's C positions
 #pragma unroll
                     for (int k = 0; k < D; ++k) m |= ((((nb[k] >> 7) * 0x00204081u) >> 21) & 0xfu) << (4 * k);
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 }
             } else if (MODE == 0) {
                 pairhit = turn ? false : pairhit;
-                if (EXT && P.max_poly_n >= 3u) {
+                if (EXT && P.max_poly_n != 2u) {
 #pragma unroll
                     for (int wd = 0; wd < NWORD; ++wd) nub[wd] = turn ? 0u : nub[wd];
                 }

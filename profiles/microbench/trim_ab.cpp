@@ -31,6 +31,7 @@ struct Lib {
     decltype(&faqcs_synth_fill) synth;
     decltype(&faqcs_kernel_report) report;
     decltype(&faqcs_last_error) last_error;
+    decltype(&faqcs_debug_words) debug_words;
     faqcs_ctx *ctx = nullptr;
     double ms_sum = 0;
     int n = 0;
@@ -59,7 +60,7 @@ int main(int argc, char **argv)
 #define SYM(f, name) l.f = (decltype(l.f))dlsym(l.h, name); if (!l.f) { fprintf(stderr, "%s: no %s\n", argv[i], name); return 1; }
         SYM(create, "faqcs_create") SYM(destroy, "faqcs_destroy") SYM(submit_device, "faqcs_submit_device") SYM(sync, "faqcs_sync")
         SYM(finish, "faqcs_finish") SYM(reset, "faqcs_reset_counters") SYM(layout, "faqcs_counters_layout") SYM(synth, "faqcs_synth_fill")
-        SYM(report, "faqcs_kernel_report") SYM(last_error, "faqcs_last_error")
+        SYM(report, "faqcs_kernel_report") SYM(last_error, "faqcs_last_error") SYM(debug_words, "faqcs_debug_words")
         libs.push_back(l);
     }
     HC(hipSetDevice(0));
@@ -125,6 +126,20 @@ int main(int argc, char **argv)
             printf("round %d %-44s trim %.4f ms/launch -> %.1f M reads/s\n", r, l.path.c_str(), kt.trim_ms, n / kt.trim_ms / 1e3);
             l.ms_sum += kt.trim_ms; l.n++;
             l.reset(l.ctx);
+        }
+    }
+    if (getenv("TRIM_AB_STAMPS")) { // a -DFAQCS_LDS_STAMPS build: section clocks since the context was created (err words 16..)
+        static const char *names[9] = {"load Q (offsets + DMA)", "terminal-N + sum pass", "3' walk", "5' walk + filters", "Q-B", "load S (DMA)",
+                                       "S (fused pass)", "verdicts / dinucleotide", "undo / epilogue / flush"};
+        for (auto &l : libs) {
+            uint64_t w[16] = {0};
+            l.debug_words(l.ctx, w, 16);
+            double tot = 0;
+            for (int i = 0; i < 9; ++i) tot += (double)w[i];
+            if (tot <= 0) continue;
+            const double chunks = (double)(1 + rounds * reps) * n / 64.0;
+            printf("%s: section clocks per 64-read chunk per wave (total %.0f)\n", l.path.c_str(), tot / chunks);
+            for (int i = 0; i < 9; ++i) printf("  %-26s %8.1f = %5.1f %%\n", names[i], w[i] / chunks, 100.0 * w[i] / tot);
         }
     }
     for (auto &l : libs) printf("mean %-44s trim %.4f ms/launch -> %.1f M reads/s (frac of 8 TB/s at %u B/read: %.4f)\n", l.path.c_str(), l.ms_sum / l.n,

@@ -34,7 +34,7 @@ _check(lib, lib.faqcs_debug_words(eng.ctx, w.ctypes.data, 16))
 for _ in range(3):
     _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(b), res.data_ptr()))
 _check(lib, lib.faqcs_debug_words(eng.ctx, w.ctypes.data, 16))
-names = ["load Q (offsets + DMA)", "terminal-N + sum pass", "3' walk", "5' walk + filters", "Q-B", "load S (DMA)", "S-A", "S-B", "veto/epilogue/flush"]
+names = ["load Q (offsets + DMA)", "terminal-N + sum pass", "3' walk", "5' walk + filters", "Q-B", "load S (DMA)", "S (fused pass)", "verdicts / dinucleotide", "undo / epilogue / flush"]
 tot = float(w[:9].sum())
 for i, nm in enumerate(names):
     print("%-26s %7.1f clocks/read-chunk-wave = %5.1f %%" % (nm, w[i] / (3 * n / 64), 100.0 * w[i] / tot))
