@@ -115,6 +115,7 @@ struct faqcs_ctx {
     float *d_norm = nullptr;
     uint64_t *d_counters = nullptr;
     uint32_t *d_err = nullptr;
+    uint32_t *d_partials = nullptr;
     // adapters
     std::vector<std::string> adapters;
     uint8_t *d_abits = nullptr;
@@ -342,6 +343,8 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     HIPCHK(hipMemset(c->d_counters, 0, c->lay.total * sizeof(uint64_t)));
     HIPCHK(hipMalloc((void **)&c->d_err, 256)); // [0] error bits ; bytes 64.. : 16 diagnostic u64 words (FAQCS_LDS_STAMPS builds)
     HIPCHK(hipMemset(c->d_err, 0, 256));
+    HIPCHK(hipMalloc((void **)&c->d_partials, (size_t)c->n_cu * 2 * FAQCS_PARTIAL_ROW * sizeof(uint32_t)));
+    HIPCHK(hipMemset(c->d_partials, 0, (size_t)c->n_cu * 2 * FAQCS_PARTIAL_ROW * sizeof(uint32_t)));
 
     if (p->n_adapters) {
         std::vector<uint8_t> bits; std::vector<uint32_t> start(1, 0);
@@ -385,6 +388,7 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     d.R = p->max_read_length; d.n_adapters = p->n_adapters;
     if (const char *e = getenv("FAQCS_DBG")) d.dbg = (uint32_t)strtoul(e, nullptr, 0);
     d.lc_thr = c->d_lcthr; d.avgq_min_v = c->d_avgq; d.comp_norm = c->d_norm; d.div_magic = c->d_magic; d.base_tab = c->d_basetab;
+    d.partials = c->d_partials;
     d.lay = c->lay;
 
     c->kmer_active = p->kmer_rarefaction ? 1 : 0;
@@ -411,7 +415,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
     for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.p); }
-    void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
+    void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_partials, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
                     c->kt.slots, c->kt.stats, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (auto &sl : c->slot) { sl.seq.release(); sl.qual.release(); sl.off.release(); if (sl.done) (void)hipEventDestroy(sl.done); }

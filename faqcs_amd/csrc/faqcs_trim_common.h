@@ -231,12 +231,33 @@ struct ReadOutcome {
     uint32_t an, fl, pAT, pCG, cAT, cCG, N; // start | kept << 16 ; flags ; base counts before / after (A|T<<16, C|G<<16, N pre | post << 16)
     int Vpre, Vpost;                       // sum(raw - offset) over the read / over the kept window
 };
+// FilterStat sums kept per lane over several chunks (trim_lds: folded into the block's cells every few chunks, next to the register
+// spill, instead of seven wave reductions per chunk): read count << 20 | base count, at most 2^12 reads and 2^20 bases per wave
+struct FsAcc { uint32_t tot = 0, trim = 0, len = 0, nn = 0, qt = 0, lc = 0, avg = 0; };
+__device__ __forceinline__ void fs_acc_flush(FsAcc &f, const int lane, uint32_t *lfs)
+{
+    const uint32_t m = (1u << 20) - 1u;
+    const uint32_t s_tot = (uint32_t)wave_sum_i32((int)f.tot), s_trim = (uint32_t)wave_sum_i32((int)f.trim), s_len = (uint32_t)wave_sum_i32((int)f.len);
+    const uint32_t s_nn = (uint32_t)wave_sum_i32((int)f.nn), s_qt = (uint32_t)wave_sum_i32((int)f.qt), s_lc = (uint32_t)wave_sum_i32((int)f.lc);
+    const uint32_t s_avg = (uint32_t)wave_sum_i32((int)f.avg);
+    if (lane == 0) {
+        if (s_tot) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], s_tot & m); }
+        if (s_trim) { atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_NUMBER], s_trim >> 20); atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_LENGTH], s_trim & m); }
+        if (s_len) { atomicAdd(&lfs[FAQCS_READ_LENGTH], s_len >> 20); atomicAdd(&lfs[FAQCS_BASE_LENGTH], s_len & m); }
+        if (s_nn) { atomicAdd(&lfs[FAQCS_READ_NN], s_nn >> 20); atomicAdd(&lfs[FAQCS_BASE_NN], s_nn & m); }
+        if (s_avg) { atomicAdd(&lfs[FAQCS_READ_AVG_Q], s_avg >> 20); atomicAdd(&lfs[FAQCS_BASE_AVG_Q], s_avg & m); }
+        if (s_qt) { atomicAdd(&lfs[FAQCS_READ_QUAL_TRIM], s_qt >> 20); atomicAdd(&lfs[FAQCS_BASE_QUAL_TRIM], s_qt & m); }
+        if (s_lc) { atomicAdd(&lfs[FAQCS_READ_LOW_COMPLEXITY], s_lc >> 20); atomicAdd(&lfs[FAQCS_BASE_LOW_COMPLEXITY], s_lc & m); }
+    }
+    f = FsAcc();
+}
+
 template <int LPR>
 __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool mine, const uint32_t my, const uint32_t v_len,
                                                const uint32_t v_hit, const int lane, uint32_t *hlen, uint32_t *hrq, uint32_t *hbqpre,
                                                uint32_t *hbqpost, uint32_t *lfs, const uint32_t *t_magic, uint2 *__restrict__ out,
                                                unsigned long long *__restrict__ rec_pre, unsigned long long *__restrict__ rec_post,
-                                               const bool o_avgq_on, const uint32_t o_dbg)
+                                               const bool o_avgq_on, const uint32_t o_dbg, FsAcc *defer = nullptr)
 {
         const bool e_ret = (o.fl & FAQCS_F_VALID) != 0, e_err = (o.fl & FAQCS_F_ERR_QUALITY) != 0;
         const uint32_t e_len = v_len, e_n = o.an >> 16, e_filt = (o.fl & FAQCS_F_FILTER_MASK) >> FAQCS_F_FILTER_SHIFT;
@@ -276,6 +297,16 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
         // count in the low 20 bits, summed over the 64 reads of the chunk (64 x 1024 bases < 2^20)
         const bool e_rlen = e_filt == FAQCS_FILT_LENGTH_PRE || e_filt == FAQCS_FILT_LENGTH_POST;
         const uint32_t one = 1u << 20;
+        if (defer) { // (a compile-time choice: the pointer is a constant of the inlined call)
+            defer->tot += mine ? one | e_len : 0u;
+            defer->trim += e_ret ? one | e_n : 0u;
+            defer->len += e_rlen ? one | e_n : 0u;
+            defer->nn += (o.fl & FAQCS_F_POLY_N_SEEN) ? one | e_n : 0u;
+            defer->qt += (o.fl & FAQCS_F_QUAL_TRIMMED) ? one | (o.fl >> 20) : 0u;
+            defer->lc += e_filt == FAQCS_FILT_LOW_COMPLEXITY ? one | e_n : 0u;
+            if (o_avgq_on) defer->avg += e_filt == FAQCS_FILT_AVG_Q ? one | e_n : 0u;
+            return;
+        }
         const uint32_t s_tot = (uint32_t)wave_sum_i32((int)(mine ? one | e_len : 0u));
         const uint32_t s_trim = (uint32_t)wave_sum_i32((int)(e_ret ? one | e_n : 0u));
         const uint32_t s_len = (uint32_t)wave_sum_i32((int)(e_rlen ? one | e_n : 0u));

@@ -53,7 +53,8 @@ template <int C, int NW> struct LdsCfg {
     static constexpr int NWORD = (ND * 4 + 31) / 32;
     static constexpr int O_T2 = (Row::LDS_DWORDS + 3) & ~3;    // [256][2] S-A: A,T,C,G one-hot in 8-bit fields ; isN(upper) | isN(any) << 1
     static constexpr int O_T3 = O_T2 + 512;                    // [256][2] S-B: 6-bit count fields, pre ; post (entry[b ^ 1]: b outside the kept window)
-    static constexpr int O_STG = O_T3 + 512;
+    static constexpr int O_CTR = O_T3 + 512;                   // [4] the block's chunk queue: next unclaimed chunk number
+    static constexpr int O_STG = O_CTR + 4;
     static constexpr int STG_BYTES = 64 * W + 32;              // one arena's span of a chunk + 16-byte alignment slack
     static constexpr int STG_DW = (STG_BYTES + 15) / 16 * 4;
     static constexpr int TAIL_PAD = 64;                        // dwords: a lane may read W bytes from the start of the span's last read
@@ -217,6 +218,83 @@ __device__ __noinline__ ExactB exact_bases(const uint8_t *__restrict__ seq, cons
 
 constexpr int lds_waves(int C) { return C <= 19 ? 12 : 8; }
 
+// LDS accumulators -> this block's OWN row of partial sums in global memory (plain coalesced read-modify-write, no atomics: only
+// this block touches the row), low and high half-words apart; fold_partials, launched behind the trim kernel, adds the rows of all
+// blocks to the u64 counter block and zeroes them.  (The direct flush of faqcs_trim_common.h costs one 64-bit global atomic per
+// non-zero counter and block -- 256 blocks x ~14 000 counters, each on a sector of its own, all at the end of the launch: 15 % of
+// the kernel time, measured with the section stamps.)
+template <int C, int LPR, int NW>
+__device__ __noinline__ void flush_block_partial(uint32_t *smem, uint32_t *__restrict__ row, const int tid)
+{
+    using Cfg = RowCfg<C, LPR>;
+    static_assert(Cfg::N_ZERO <= FAQCS_PARTIAL_ROW, "partial-sum row");
+    __syncthreads();
+    for (int i = tid; i < Cfg::N_ZERO; i += NW * 64) {
+        const uint32_t v = smem[i];
+        if (v) {
+            smem[i] = 0;
+            if (v & 0xffffu) row[i] += v & 0xffffu;
+            if (v >> 16) row[FAQCS_PARTIAL_ROW + i] += v >> 16;
+        }
+    }
+    __syncthreads();
+}
+
+// One thread per LDS accumulator cell i and quarter of the rows: the sum over the blocks' partial rows -> the counter block (the index mapping of
+// flush_block in faqcs_trim_common.h); the rows are left zeroed for the next launch.  Only one thread adds to a given counter and
+// kernels on one stream do not overlap, but the add stays atomic: another context's kernels may share the block in a caller's design.
+template <int C, int LPR>
+__global__ __launch_bounds__(256) void fold_partials(uint32_t *__restrict__ partials, const uint32_t n_rows, uint64_t *__restrict__ counters, const uint32_t R)
+{
+    using Cfg = RowCfg<C, LPR>;
+    constexpr int W = Cfg::W;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63); // 64 cells x 4 interleaved sets of rows per block
+    if (i >= Cfg::N_ZERO) return;
+    unsigned long long lo = 0, hi = 0;
+#pragma unroll 8
+    for (uint32_t b = threadIdx.x >> 6; b < n_rows; b += 4) {
+        uint32_t *row = partials + (size_t)b * 2 * FAQCS_PARTIAL_ROW;
+        const uint32_t x = row[i], y = row[FAQCS_PARTIAL_ROW + i];
+        if (x) { row[i] = 0; lo += x; }
+        if (y) { row[FAQCS_PARTIAL_ROW + i] = 0; hi += y; }
+    }
+    if (!(lo | hi)) return;
+    // faqcs_counters_layout() restated (include/faqcs_mi.h)
+    uint64_t o = 0;
+    const uint64_t filter_stats = o;    o += 32;
+    const uint64_t pre_read_qhist = o;  o += FAQCS_NQ;
+    const uint64_t pre_base_qhist = o;  o += FAQCS_NQ;
+    const uint64_t post_read_qhist = o; o += FAQCS_NQ;
+    const uint64_t post_base_qhist = o; o += FAQCS_NQ;
+    const uint64_t pre_len_hist = o;    o += (uint64_t)R + 1;
+    const uint64_t post_len_hist = o;   o += (uint64_t)R + 1;
+    const uint64_t pre_qual = o;        o += (uint64_t)R * FAQCS_NQ;
+    const uint64_t post_qual = o;       o += (uint64_t)R * FAQCS_NQ;
+    const uint64_t pre_base = o;        o += (uint64_t)R * FAQCS_NBASE;
+    const uint64_t post_base = o;
+    auto add = [&](uint64_t idx, unsigned long long v) { if (v) atomicAdd((unsigned long long *)(counters + idx), v); };
+    if (i < Cfg::O_HB) { // position x quality: pre in the low, post in the high half-word
+        const uint32_t q = (uint32_t)(i - Cfg::O_HQ) / W, p = (uint32_t)(i - Cfg::O_HQ) % W;
+        if (p < R) { add(pre_qual + (uint64_t)p * FAQCS_NQ + q, lo); add(post_qual + (uint64_t)p * FAQCS_NQ + q, hi); }
+    } else if (i < Cfg::O_LEN) {
+        const uint32_t c = (uint32_t)(i - Cfg::O_HB) / W, p = (uint32_t)(i - Cfg::O_HB) % W;
+        if (p < R) { add(pre_base + (uint64_t)p * FAQCS_NBASE + c, lo); add(post_base + (uint64_t)p * FAQCS_NBASE + c, hi); }
+    } else if (i < Cfg::O_RQ) {
+        const uint32_t l = (uint32_t)(i - Cfg::O_LEN);
+        if (l <= R) { add(pre_len_hist + l, lo); add(post_len_hist + l, hi); }
+    } else if (i < Cfg::O_BQPRE) {
+        const uint32_t k = (uint32_t)(i - Cfg::O_RQ);
+        if (k < FAQCS_NQ) { add(pre_read_qhist + k, lo); add(post_read_qhist + k, hi); }
+    } else if (i < Cfg::O_BQPOST) { // 32-bit cells: the two halves of one number
+        add(pre_base_qhist + (uint32_t)(i - Cfg::O_BQPRE), lo + (hi << 16));
+    } else if (i < Cfg::O_FS) {
+        add(post_base_qhist + (uint32_t)(i - Cfg::O_BQPOST), lo + (hi << 16));
+    } else {
+        const uint32_t k = (uint32_t)(i - Cfg::O_FS);
+        if (k < FAQCS_NUM_STAT) add(filter_stats + k, lo + (hi << 16));
+    }
+}
+
 template <int C, int NW, bool WINDOWED, bool EXT>
 __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
@@ -236,6 +314,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const uint32_t *t_lc = smem + Cfg::O_TLC;
     const uint32_t *t_bm = smem + Cfg::O_TBM;
 
+#ifdef FAQCS_LDS_STAMPS
+    const unsigned long long clk_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int rl = lane & (LPR - 1);
@@ -266,13 +347,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     uint32_t three = 3u, wx4 = (uint32_t)(W * 4);
     asm volatile("" : "+v"(three), "+v"(wx4)); // VGPR operands for the SDWA instructions
     if (tid == 0 && blockIdx.x == 0 && (uint32_t)(size_t)((lds_u32_ptr)smem) != 0u) atomicOr(err, 4u);
+    if (tid == 0) smem[T::O_CTR] = (uint32_t)NW; // the first NW chunks of the block are taken by wave number
     __syncthreads();
 
+    // ---- which chunks: groups of NW consecutive 64-read chunks are dealt to the blocks round-robin; INSIDE a block the waves claim
+    // the block's chunks one at a time from a counter in LDS (chunk number c of the block = chunk c % NW of its group c / NW), so that
+    // the waves of a block -- the younger ones get fewer issue slots -- finish together and meet at a flush barrier within one chunk's
+    // time (with a fixed chunk -> wave map the early waves idled at the barriers for 16 % of the kernel time).
     const uint32_t total_chunks = (n_reads + 63) >> 6;
-    const uint32_t chunks_per_iter = gridDim.x * NW;
-    const uint32_t n_iter = (total_chunks + chunks_per_iter - 1) / chunks_per_iter;
-    constexpr uint32_t FLUSH_EVERY = 65535u / (NW * 64) > 0 ? 65535u / (NW * 64) : 1;
+    const uint32_t n_groups = (total_chunks + NW - 1) / NW;
+    const uint32_t my_groups = n_groups > blockIdx.x ? (n_groups - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const bool last_mine = n_groups > blockIdx.x && (n_groups - 1 - blockIdx.x) % gridDim.x == 0; // the (possibly partial) last group
+    const uint32_t n_local = my_groups * NW - (last_mine ? n_groups * NW - total_chunks : 0u);
+    // flush k (k = 1, 2, ...) comes before the block's chunk k * FLUSH_CHUNKS, the last one after its last chunk: the 16-bit halves of
+    // the LDS cells take FLUSH_CHUNKS x 64 <= 65535 increments in between (chunks are claimed in order, so a wave that holds a chunk
+    // >= k * FLUSH_CHUNKS waits at flush k while exactly the chunks below it are being finished)
+    constexpr uint32_t FLUSH_CHUNKS = 65535u / 64u / NW * NW;
+    const uint32_t n_flushes = (n_local + FLUSH_CHUNKS - 1) / FLUSH_CHUNKS;
     constexpr uint32_t REG_FLUSH_EVERY = 7; // 6-bit fields: 7 chunks x 8 reads per row <= 63
+    auto chunk_of = [&](const uint32_t c_) { return ((c_ / NW) * gridDim.x + blockIdx.x) * NW + c_ % NW; };
 
     const int in_off = P.in_off, Q = P.Q;
     uint32_t *slot = smem + T::O_STG + wave * T::STG_DW;
@@ -284,19 +377,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #pragma unroll
     for (int j = 0; j < C; ++j) { bpre[j] = 0; bpost[j] = 0; }
     uint32_t any_err = 0;
+    // the register fields -> the block's position x base cells.  Straight-line: one LDS add per field, no test per lane (the
+    // branchy form -- skip a zero field -- cost 23 000 clocks per call: 95 divergent regions with an LDS round trip each)
+    const uint32_t hb_lane = (uint32_t)(Cfg::O_HB * 4 + pbase * 4);
+    FsAcc fs_acc; // FilterStat sums of the chunks since the last spill (7 chunks x 64 reads x 152 bases per wave: inside the packed fields)
     auto spill_base_regs = [&]() {
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const uint32_t x = bpre[j], y = bpost[j];
-            if (x) {
 #pragma unroll
-                for (int c = 0; c < FAQCS_NBASE; ++c) {
-                    const uint32_t v = ((x >> BT_SHIFT(c)) & 63u) | (((y >> BT_SHIFT(c)) & 63u) << 16);
-                    if (v) atomicAdd(&hb[c * W + pbase + j], v);
-                }
+            for (int c = 0; c < FAQCS_NBASE; ++c) {
+                const uint32_t v = ((x >> BT_SHIFT(c)) & 63u) | (((y >> BT_SHIFT(c)) & 63u) << 16);
+                lds_add_u32(hb_lane + (uint32_t)((c * W + j) * 4), v);
             }
             bpre[j] = 0; bpost[j] = 0;
         }
+        fs_acc_flush(fs_acc, lane, smem + Cfg::O_FS);
     };
 
     // ---- the position-parallel passes (8 lanes per read).  What a lane fetches from LDS for one read: six aligned dwords
@@ -469,28 +565,48 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     }
 
 #ifdef FAQCS_LDS_STAMPS
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_flush = 0;
 #define FAQCS_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_prev; st_prev = now_; }
 #else
 #define FAQCS_STAMP(i)
 #endif
     uint32_t p_off = 0, p_end = 0;
-    auto fetch_offsets = [&](const uint32_t it_) {
-        const uint32_t chunk_ = (it_ * gridDim.x + blockIdx.x) * NW + wave;
-        if (it_ < n_iter && chunk_ < total_chunks) {
-            const uint32_t my_ = (chunk_ << 6) + (uint32_t)lane;
+    auto fetch_offsets = [&](const uint32_t c_) { // c_: the block's chunk number
+        if (c_ < n_local) {
+            const uint32_t my_ = (chunk_of(c_) << 6) + (uint32_t)lane;
             p_off = off[my_ < n_reads ? my_ : n_reads];
             p_end = off[my_ < n_reads ? my_ + 1 : n_reads];
         }
     };
-    fetch_offsets(0);
+    uint32_t c_cur = (uint32_t)wave, n_flushed = 0, since_spill = 0;
+    fetch_offsets(c_cur);
+#ifdef FAQCS_LDS_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime(); // shader clock = d(memtime) / d(memrealtime) x 100 MHz
+#endif
 #pragma unroll 1
-    for (uint32_t it = 0; it < n_iter; ++it) {
-        const uint32_t chunk = (it * gridDim.x + blockIdx.x) * NW + wave;
+    for (;;) {
 #ifdef FAQCS_LDS_STAMPS
         st_prev = __builtin_amdgcn_s_memtime();
 #endif
-        if (chunk < total_chunks) {
+        {   // the flushes that come before chunk c_cur (every wave of the block passes each of them exactly once)
+            const uint32_t due = c_cur < n_local ? c_cur / FLUSH_CHUNKS : n_flushes;
+#pragma unroll 1
+            while (n_flushed < due) {
+                spill_base_regs();
+                flush_block_partial<C, LPR, NW>(smem, P.partials + (size_t)blockIdx.x * 2 * FAQCS_PARTIAL_ROW, tid);
+                ++n_flushed; since_spill = 0;
+            }
+        }
+#ifdef FAQCS_LDS_STAMPS
+        st_flush += __builtin_amdgcn_s_memtime() - st_prev;
+        st_prev = __builtin_amdgcn_s_memtime();
+#endif
+        if (c_cur >= n_local) break;
+        uint32_t c_next = 0;
+        if (lane == 0) c_next = __hip_atomic_fetch_add((lds_u32_mut)(size_t)(uint32_t)(T::O_CTR * 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c_next = uniu(c_next);
+        {
+            const uint32_t chunk = chunk_of(c_cur);
             const uint32_t base = chunk << 6;
             const uint32_t my = base + lane;
             const bool mine = my < n_reads;
@@ -513,7 +629,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // first / last base (mask_quality_terminal_N needs them before the qualities are looked at)
             uint32_t bfirst = 0, blast = 0;
             if (len) { bfirst = (uint32_t)seq[(size_t)v_off]; blast = (uint32_t)seq[(size_t)v_off + len - 1]; }
-            fetch_offsets(it + 1);
+            fetch_offsets(c_next);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // pad behind the span: the position-parallel passes read up to W + 5 bytes past a short last read, and what they
             // find there must be a valid quality byte (see quality_cells)
@@ -975,19 +1091,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 
             // ---- chunk epilogue: one read per lane ----------------------------------------------------------
             chunk_epilogue<LPR>(oc, mine, my, v_len, v_hit, lane, smem + Cfg::O_LEN, smem + Cfg::O_RQ, smem + Cfg::O_BQPRE,
-                                smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, EXT && P.avgq_on != 0, 0u);
+                                smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, EXT && P.avgq_on != 0, 0u, &fs_acc);
         }
 
         FAQCS_STAMP(8)
-        const bool block_flush = ((it + 1) % FLUSH_EVERY) == 0 || it + 1 == n_iter;
-        if (((it + 1) % REG_FLUSH_EVERY) == 0 || block_flush) spill_base_regs();
-        if (block_flush) flush_block<C, LPR, NW, false>(smem, counters, P.R, tid);
+        if (++since_spill == REG_FLUSH_EVERY) { spill_base_regs(); since_spill = 0; }
+#ifdef FAQCS_LDS_STAMPS
+        st_flush += __builtin_amdgcn_s_memtime() - st_prev; // (register spill + block flush: outside the nine sections)
+#endif
+        c_cur = c_next;
     }
     if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
 #ifdef FAQCS_LDS_STAMPS
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + i, st_acc[i]);
+        atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 9, __builtin_amdgcn_s_memtime() - clk0);
+        atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 11, st_flush);
+        atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 12, clk0 - clk_entry);
+        atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 10, __builtin_amdgcn_s_memrealtime() - rt0);
     }
 #endif
 #undef FAQCS_STAMP
@@ -1010,6 +1132,8 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
                        reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8>::N_ZERO + 63) / 64), dim3(256), 0, st, P.partials, grid, counters, P.R);
     return hipGetLastError();
 }
 

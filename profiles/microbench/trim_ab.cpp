@@ -140,6 +140,9 @@ int main(int argc, char **argv)
             const double chunks = (double)(1 + rounds * reps) * n / 64.0;
             printf("%s: section clocks per 64-read chunk per wave (total %.0f)\n", l.path.c_str(), tot / chunks);
             for (int i = 0; i < 9; ++i) printf("  %-26s %8.1f = %5.1f %%\n", names[i], w[i] / chunks, 100.0 * w[i] / tot);
+            printf("  %-26s %8.1f   (outside the sections)\n  %-26s %8.1f   (per chunk; once per wave)\n  %-26s %8.1f\n", "register spill + flush", w[11] / chunks,
+                   "kernel entry -> loop", w[12] / chunks, "loop, entry to exit", w[9] / chunks);
+            if (w[10]) printf("  shader clock while the kernel runs: %.3f GHz (s_memtime / s_memrealtime x 100 MHz, summed over the waves)\n", (double)w[9] / (double)w[10] * 0.1);
         }
     }
     for (auto &l : libs) printf("mean %-44s trim %.4f ms/launch -> %.1f M reads/s (frac of 8 TB/s at %u B/read: %.4f)\n", l.path.c_str(), l.ms_sum / l.n,
