@@ -267,7 +267,44 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
         if (e_ret && o.Vpost > 0) qb_post = e_n == 1 ? o.Vpost : (int)__umulhi((uint32_t)o.Vpost, t_magic[e_n]);
         qb_pre = qb_pre > 41 ? 41 : qb_pre;
         qb_post = qb_post > 41 ? 41 : qb_post;
-        if (!(o_dbg & 2u) && mine && !e_err) { // length and int(average quality) histograms (trim.cpp:254-258,539-543,877-885)
+        if (defer) {
+            // (trim_lds) the same six histogram cells, with the lanes that share the first lane's (length, quality bin) pair folded
+            // into ONE add per cell by that lane: 64 reads of one length are 64 adds to one LDS address otherwise, which the LDS
+            // serialises (~110 clocks per instruction, measured; equal-length reads with a narrow quality spread are the common case)
+            const bool act = mine && !e_err;
+            if (act) {
+                const uint32_t key = e_len | ((uint32_t)qb_pre << 16);
+                const bool same = key == (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(same));
+                if (same) {
+                    if (lane == __ffsll((unsigned long long)__ballot(true)) - 1) {
+                        atomicAdd(hlen + e_len, cnt);
+                        atomicAdd(hrq + qb_pre, cnt);
+                        if (e_len) atomicAdd(hbqpre + qb_pre, cnt * e_len);
+                    }
+                } else {
+                    atomicAdd(hlen + e_len, 1u);
+                    atomicAdd(hrq + qb_pre, 1u);
+                    if (e_len) atomicAdd(hbqpre + qb_pre, e_len);
+                }
+            }
+            if (act && e_ret) {
+                const uint32_t key = e_n | ((uint32_t)qb_post << 16);
+                const bool same = key == (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(same));
+                if (same) {
+                    if (lane == __ffsll((unsigned long long)__ballot(true)) - 1) {
+                        atomicAdd(hlen + e_n, cnt << 16);
+                        atomicAdd(hrq + qb_post, cnt << 16);
+                        atomicAdd(hbqpost + qb_post, cnt * e_n);
+                    }
+                } else {
+                    atomicAdd(hlen + e_n, 0x10000u);
+                    atomicAdd(hrq + qb_post, 0x10000u);
+                    atomicAdd(hbqpost + qb_post, e_n);
+                }
+            }
+        } else if (!(o_dbg & 2u) && mine && !e_err) { // length and int(average quality) histograms (trim.cpp:254-258,539-543,877-885)
             atomicAdd(hlen + e_len, 1u);
             atomicAdd(hrq + qb_pre, 1u);
             if (e_len) atomicAdd(hbqpre + qb_pre, e_len);

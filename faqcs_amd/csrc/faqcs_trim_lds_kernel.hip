@@ -414,7 +414,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     // position x quality cells: DATA = +1 pre / +1 post per base (undo: -1 post, for a read S-A vetoed afterwards).
     // A byte past the read belongs to the next read of the span or to the pad behind it (valid quality bytes both: its
     // zero increment stays inside the table).
-    auto quality_cells = [&](const RawB &x, const uint32_t i0, const uint32_t i1, auto undo_t) {
+    uint32_t qb_sum = 0; // (Q-B, `sum` steps) this lane's read: the sum of its raw quality bytes
+    auto quality_cells = [&](const RawB &x, const uint32_t i0, const uint32_t i1, auto undo_t, const int t, const bool sum) {
         constexpr bool undo = decltype(undo_t)::value;
         const bool counted = ((i1 >> 17) & 1u) != 0u;
         const uint32_t sh = ((i0 & 0xffffu) + (uint32_t)pbase + slot_b) & 3u;
@@ -424,6 +425,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             cm[k] = (counted && !undo) ? x.mv[k] & 0x01010101u : 0u;
             im[k] = (x.mh[k] ^ x.ml[k]) & (undo ? 0xffffffffu : 0x01010101u);
             wq[k] = __builtin_amdgcn_alignbyte(x.r[k + 1], x.r[k], sh);
+        }
+        if (!undo && sum) { // (wave-uniform) the read's quality sum: the lane's bytes inside the read, then the 8 lanes of the read
+            uint32_t qs = 0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                uint32_t m = x.mv[k];
+                if (4 * k + 4 > C) m &= low_bytes_(C - 4 * k); // (the masks cover C + 1 positions)
+                qs = __builtin_amdgcn_sad_u8(wq[k] & m, 0u, qs);
+            }
+            qs = (uint32_t)RowOps<8>::all_sum((int)qs);
+            qb_sum = (rl == t) ? qs : qb_sum;
         }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -560,7 +572,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t a0_ = (uint32_t)__shfl((int)(I0), rowb + t), a1_ = (uint32_t)__shfl((int)(I1), rowb + t);   \
             RawB cur_;                                                                                                \
             load_b(a0_, a1_, cur_);                                                                                   \
-            CELLS(cur_, a0_, a1_);                                                                                    \
+            CELLS(cur_, a0_, a1_, t);                                                                                 \
         }                                                                                                             \
     }
 
@@ -577,6 +589,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             p_off = off[my_ < n_reads ? my_ : n_reads];
             p_end = off[my_ < n_reads ? my_ + 1 : n_reads];
         }
+    };
+    // What a chunk needs from global memory before its first pass: the quality span (DMA into the wave's slot), the adapter pre-pass's
+    // words, the first / last base of every read (mask_quality_terminal_N looks at them before the qualities are used).
+    struct ChunkLoads { uint32_t v_off, v_end, v_sl, v_hit, bfirst, blast; };
+    ChunkLoads ld = {0, 0, 0, 0, 0, 0};
+    bool pre_issued = false;
+    auto issue_loads = [&](const uint32_t c_, const uint32_t o_, const uint32_t e_, ChunkLoads &L) {
+        const uint32_t my_ = (chunk_of(c_) << 6) + (uint32_t)lane;
+        const bool mine_ = my_ < n_reads;
+        const uint32_t len_ = e_ - o_;
+        const uint32_t cs_ = uniu(o_), ce_ = (uint32_t)__builtin_amdgcn_readlane((int)e_, 63);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (every read of the slot's previous content has returned)
+        const uint32_t shq_ = (uint32_t)((size_t)(qual + cs_) & 15u);
+        dma_span<NI>(qual + cs_ - shq_, ce_ - cs_ + shq_, slot, lane);
+        L.v_off = o_; L.v_end = e_;
+        L.v_sl = (WINDOWED && ad_sl && mine_) ? ad_sl[my_] : (len_ << 16);
+        L.v_hit = (ad_hit && mine_) ? ad_hit[my_] : 0u;
+        L.bfirst = 0; L.blast = 0;
+        if (len_) { L.bfirst = (uint32_t)seq[(size_t)o_]; L.blast = (uint32_t)seq[(size_t)o_ + len_ - 1]; }
     };
     uint32_t c_cur = (uint32_t)wave, n_flushed = 0, since_spill = 0;
     fetch_offsets(c_cur);
@@ -610,25 +641,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t base = chunk << 6;
             const uint32_t my = base + lane;
             const bool mine = my < n_reads;
+            // ---- the span of the QUALITY arena -> LDS, and the per-read words that come from global memory.  Requested at the end
+            // of the previous chunk (issue_loads below, once the slot is no longer read); here for a wave's first chunk only.
+            if (!pre_issued) issue_loads(c_cur, p_off, p_end, ld);
             // a lane without a read sits at the end of the last read (length 0): the span ends where lane 63 ends
-            // (the two offsets were fetched during the previous chunk)
-            const uint32_t v_off = p_off, v_end = p_end;
+            const uint32_t v_off = ld.v_off, v_end = ld.v_end;
             const uint32_t v_len = v_end - v_off;
-            const uint32_t v_sl = (WINDOWED && ad_sl && mine) ? ad_sl[my] : (v_len << 16);
-            const uint32_t v_hit = (ad_hit && mine) ? ad_hit[my] : 0u;
+            const uint32_t v_sl = ld.v_sl, v_hit = ld.v_hit;
             const uint32_t cs = uniu(v_off), ce = (uint32_t)__builtin_amdgcn_readlane((int)v_end, 63);
             const int len = (int)v_len;
-
-            // ---- the span of the QUALITY arena -> LDS -------------------------------------------------------------
-            // (Measured and rejected: requesting this copy for the NEXT chunk in front of the current chunk's epilogue, when the slot
-            // is free -- the 6 % of the wave time spent here is covered by the other waves already: 5.85 -> 5.83 G reads/s.)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the previous chunk's reads of the slot have returned)
             const uint32_t shq = (uint32_t)((size_t)(qual + cs) & 15u);
-            dma_span<NI>(qual + cs - shq, ce - cs + shq, slot, lane);
             const uint32_t rowq = v_off - cs + shq; // this lane's read inside the slot
-            // first / last base (mask_quality_terminal_N needs them before the qualities are looked at)
-            uint32_t bfirst = 0, blast = 0;
-            if (len) { bfirst = (uint32_t)seq[(size_t)v_off]; blast = (uint32_t)seq[(size_t)v_off + len - 1]; }
+            const uint32_t bfirst = ld.bfirst, blast = ld.blast;
             fetch_offsets(c_next);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // pad behind the span: the position-parallel passes read up to W + 5 bytes past a short last read, and what they
@@ -672,7 +696,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             uint32_t qsum = 0, qacc = 0;
             int n_dw = 0; // dwords every lane has summed (wave-uniform): a dword past a lane's read counts as four offset bytes
             const uint32_t c_hi = 0x56565656u; // x = raw - offset ; x + 0x56: bit 7 <=> x > 41
-            {
+            // The range check first, over the span as it lies in the slot (16 aligned bytes per lane and instruction, no bank
+            // conflicts, whatever read a byte belongs to).  No byte out of range -- every chunk of valid data -- and no option that
+            // needs a read's sums before Q-B: the lane-per-read pass below is skipped and Q-B takes the sums (its lanes hold the bytes
+            // anyway).  The few bytes either side of the span inside its first / last 16-byte piece are other reads' qualities (or the
+            // arena's padding at its two ends: then the pass below runs, which is always right).
+            bool sum_pass = !swar_ok || WINDOWED || (EXT && P.avgq_on);
+            if (!sum_pass) {
+                typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+                uint32_t acc = 0;
+                const uint32_t n16 = (ce - cs + shq + 15u) >> 4;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    if ((uint32_t)(i * 64) >= n16) break; // wave-uniform
+                    if ((uint32_t)(i * 64 + lane) < n16) {
+                        const U4 v = *(const __attribute__((address_space(3))) U4 *)(size_t)(slot_b + (uint32_t)(i * 1024 + lane * 16));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const uint32_t x = v[e] - offb; acc |= x | (x + c_hi) | v[e]; }
+                    }
+                }
+                sum_pass = __any((acc & 0x80808080u) != 0u);
+            }
+            if (sum_pass) {
                 const int nfull = len >> 2, rem = len & 3;
                 const int kmax = uni((int)wave_max_u32((uint32_t)nfull));
                 const uint32_t qa = slot_b + rowq, qa4 = qa & ~3u, qsh = qa & 3u;
@@ -796,13 +841,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     const int mcap = rlim >> 2; // steps 4 i .. 4 i + 3 all reset: 4 i + 3 < rlim
                     bool run = dq0 > 0;
                     uint32_t h = hi, c = cur;
+                    // four dwords per LDS round trip (the loop is a chain of round trips: a Q2 tail of 75 bases is 19 dwords)
 #pragma unroll 1
-                    for (int i = 0; ; ++i) {
-                        const uint32_t nx = lds_ld(e4 - 8u - 4u * (uint32_t)i);
-                        const uint32_t w = __builtin_amdgcn_alignbyte(h, c, esh);
-                        run = run && w == pat && i < mcap;
+                    for (int i = 0; ; i += 4) {
+                        const uint32_t n0 = lds_ld(e4 - 8u - 4u * (uint32_t)i), n1 = lds_ld(e4 - 12u - 4u * (uint32_t)i);
+                        const uint32_t n2 = lds_ld(e4 - 16u - 4u * (uint32_t)i), n3 = lds_ld(e4 - 20u - 4u * (uint32_t)i);
+                        run = run && __builtin_amdgcn_alignbyte(h, c, esh) == pat && i < mcap;
                         m += run ? 1 : 0;
-                        h = c; c = nx;
+                        run = run && __builtin_amdgcn_alignbyte(c, n0, esh) == pat && i + 1 < mcap;
+                        m += run ? 1 : 0;
+                        run = run && __builtin_amdgcn_alignbyte(n0, n1, esh) == pat && i + 2 < mcap;
+                        m += run ? 1 : 0;
+                        run = run && __builtin_amdgcn_alignbyte(n1, n2, esh) == pat && i + 3 < mcap;
+                        m += run ? 1 : 0;
+                        h = n2; c = n3;
                         if (!__any(run)) break;
                     }
                 }
@@ -907,9 +959,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // retc: the read is still kept as far as the qualities can tell (an average-quality failure is final whatever poly-N says later)
             const bool retc = ret && !avgq_fail;
             const uint32_t qi1 = (uint32_t)a | ((uint32_t)n << 8) | (retc ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u);
-#define FAQCS_QCELLS(X, A, B) quality_cells(X, A, B, std::false_type{})
+#define FAQCS_QCELLS(X, A, B, T_) quality_cells(X, A, B, std::false_type{}, T_, !sum_pass)
             FAQCS_B_LOOP(qi0, qi1, FAQCS_QCELLS)
 #undef FAQCS_QCELLS
+            if (!sum_pass) { // the sums that the lane-per-read pass did not take (no byte out of range: all v == q)
+                V_pre = (int)qb_sum - len * in_off;
+                if (!(EXT && sum_kept)) V_post = n * Q - ((wn * Q - V_pre) - (S3 > 0 ? S3 : 0) - (S5 > 0 ? S5 : 0));
+            }
 
             FAQCS_STAMP(4)
             // ---- the span of the BASE arena -> the same slot ---------------------------------------------------------
@@ -1075,11 +1131,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     const uint32_t i0 = (uint32_t)__shfl((int)qi0, rowb + t);
                     RawB x;
                     load_b(i0, i1, x);
-                    quality_cells(x, i0, i1, std::true_type{});
+                    quality_cells(x, i0, i1, std::true_type{}, t, false);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
 #undef FAQCS_S_LOOP
+
+            // the slot is not read any more: request the next chunk's loads now, under the epilogue (p_off / p_end: its offsets,
+            // fetched at the top of this chunk)
+            ChunkLoads ld_next = ld;
+            pre_issued = c_next < n_local;
+            if (pre_issued) issue_loads(c_next, p_off, p_end, ld_next);
 
             if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
             oc.an = (uint32_t)a | ((uint32_t)n << 16);
@@ -1092,6 +1154,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // ---- chunk epilogue: one read per lane ----------------------------------------------------------
             chunk_epilogue<LPR>(oc, mine, my, v_len, v_hit, lane, smem + Cfg::O_LEN, smem + Cfg::O_RQ, smem + Cfg::O_BQPRE,
                                 smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, EXT && P.avgq_on != 0, 0u, &fs_acc);
+            ld = ld_next;
         }
 
         FAQCS_STAMP(8)

@@ -148,5 +148,7 @@ int main(int argc, char **argv)
     for (auto &l : libs) printf("mean %-44s trim %.4f ms/launch -> %.1f M reads/s (frac of 8 TB/s at %u B/read: %.4f)\n", l.path.c_str(), l.ms_sum / l.n,
                                 n / (l.ms_sum / l.n) / 1e3, 2 * L + 12, n * (2.0 * L + 12) / (l.ms_sum / l.n * 1e-3) / 8e12);
     fflush(stdout);
-    _Exit(0); // (skip the teardown of several HIP-linked libraries in one process)
+    if (libs.size() > 1) _Exit(0); // (skip the teardown of several HIP-linked libraries in one process)
+    for (auto &l : libs) l.destroy(l.ctx);
+    return 0;
 }
