@@ -53,8 +53,9 @@ template <int C, int NW> struct LdsCfg {
     static constexpr int NWORD = (ND * 4 + 31) / 32;
     static constexpr int O_T2 = (Row::LDS_DWORDS + 3) & ~3;    // [256][2] S-A: A,T,C,G one-hot in 8-bit fields ; isN(upper) | isN(any) << 1
     static constexpr int O_T3 = O_T2 + 512;                    // [256][2] S-B: 6-bit count fields, pre ; post (entry[b ^ 1]: b outside the kept window)
-    static constexpr int O_CTR = O_T3 + 512;                   // [4] the block's chunk queue: next unclaimed chunk number
-    static constexpr int O_STG = O_CTR + 4;
+    static constexpr int O_CTR = O_T3 + 512;                   // [8] the block's chunk queue: [0] next unclaimed chunk number, [1] the block's chunk
+                                                               // count once known, [4..7] ring: group number << 20 | group id
+    static constexpr int O_STG = O_CTR + 8;
     static constexpr int STG_BYTES = 64 * W + 32;              // one arena's span of a chunk + 16-byte alignment slack
     static constexpr int STG_DW = (STG_BYTES + 15) / 16 * 4;
     static constexpr int TAIL_PAD = 64;                        // dwords: a lane may read W bytes from the start of the span's last read
@@ -240,24 +241,35 @@ __device__ __noinline__ void flush_block_partial(uint32_t *smem, uint32_t *__res
     __syncthreads();
 }
 
-// One thread per LDS accumulator cell i and quarter of the rows: the sum over the blocks' partial rows -> the counter block (the index mapping of
+// One thread per LDS accumulator cell i and sixteenth of the rows: the sum over the blocks' partial rows -> the counter block (the index mapping of
 // flush_block in faqcs_trim_common.h); the rows are left zeroed for the next launch.  Only one thread adds to a given counter and
 // kernels on one stream do not overlap, but the add stays atomic: another context's kernels may share the block in a caller's design.
 template <int C, int LPR>
-__global__ __launch_bounds__(256) void fold_partials(uint32_t *__restrict__ partials, const uint32_t n_rows, uint64_t *__restrict__ counters, const uint32_t R)
+__global__ __launch_bounds__(1024) void fold_partials(uint32_t *__restrict__ partials, const uint32_t n_rows, uint64_t *__restrict__ counters, const uint32_t R,
+                                                      uint32_t *__restrict__ g_next)
 {
     using Cfg = RowCfg<C, LPR>;
     constexpr int W = Cfg::W;
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63); // 64 cells x 4 interleaved sets of rows per block
-    if (i >= Cfg::N_ZERO) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *g_next = 0u; // (the trim kernel's group counter: zero between launches)
+    __shared__ unsigned long long part[2][16][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63); // 64 cells x 16 interleaved sets of rows per block
     unsigned long long lo = 0, hi = 0;
+    if (i < Cfg::N_ZERO) {
 #pragma unroll 8
-    for (uint32_t b = threadIdx.x >> 6; b < n_rows; b += 4) {
-        uint32_t *row = partials + (size_t)b * 2 * FAQCS_PARTIAL_ROW;
-        const uint32_t x = row[i], y = row[FAQCS_PARTIAL_ROW + i];
-        if (x) { row[i] = 0; lo += x; }
-        if (y) { row[FAQCS_PARTIAL_ROW + i] = 0; hi += y; }
+        for (uint32_t b = threadIdx.x >> 6; b < n_rows; b += 16) {
+            uint32_t *row = partials + (size_t)b * 2 * FAQCS_PARTIAL_ROW;
+            const uint32_t x = row[i], y = row[FAQCS_PARTIAL_ROW + i];
+            if (x) { row[i] = 0; lo += x; }
+            if (y) { row[FAQCS_PARTIAL_ROW + i] = 0; hi += y; }
+        }
     }
+    part[0][threadIdx.x >> 6][threadIdx.x & 63] = lo;
+    part[1][threadIdx.x >> 6][threadIdx.x & 63] = hi;
+    __syncthreads();
+    if (threadIdx.x >= 64 || i >= Cfg::N_ZERO) return;
+    lo = 0; hi = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { lo += part[0][g][threadIdx.x]; hi += part[1][g][threadIdx.x]; }
     if (!(lo | hi)) return;
     // faqcs_counters_layout() restated (include/faqcs_mi.h)
     uint64_t o = 0;
@@ -347,25 +359,44 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     uint32_t three = 3u, wx4 = (uint32_t)(W * 4);
     asm volatile("" : "+v"(three), "+v"(wx4)); // VGPR operands for the SDWA instructions
     if (tid == 0 && blockIdx.x == 0 && (uint32_t)(size_t)((lds_u32_ptr)smem) != 0u) atomicOr(err, 4u);
-    if (tid == 0) smem[T::O_CTR] = (uint32_t)NW; // the first NW chunks of the block are taken by wave number
-    __syncthreads();
-
-    // ---- which chunks: groups of NW consecutive 64-read chunks are dealt to the blocks round-robin; INSIDE a block the waves claim
-    // the block's chunks one at a time from a counter in LDS (chunk number c of the block = chunk c % NW of its group c / NW), so that
-    // the waves of a block -- the younger ones get fewer issue slots -- finish together and meet at a flush barrier within one chunk's
-    // time (with a fixed chunk -> wave map the early waves idled at the barriers for 16 % of the kernel time).
     const uint32_t total_chunks = (n_reads + 63) >> 6;
     const uint32_t n_groups = (total_chunks + NW - 1) / NW;
-    const uint32_t my_groups = n_groups > blockIdx.x ? (n_groups - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-    const bool last_mine = n_groups > blockIdx.x && (n_groups - 1 - blockIdx.x) % gridDim.x == 0; // the (possibly partial) last group
-    const uint32_t n_local = my_groups * NW - (last_mine ? n_groups * NW - total_chunks : 0u);
+    uint32_t *g_next = err + 8; // groups handed out beyond the first gridDim.x (zero between launches: fold_partials resets it)
+    if (tid == 0) {
+        smem[T::O_CTR] = (uint32_t)NW; // the first NW chunks of the block are taken by wave number
+        smem[T::O_CTR + 1] = 0xffffffffu;
+        smem[T::O_CTR + 4] = blockIdx.x; // group number 0 of the block: group blockIdx.x
+        smem[T::O_CTR + 5] = 0xffffffffu; smem[T::O_CTR + 6] = 0xffffffffu; smem[T::O_CTR + 7] = 0xffffffffu;
+        const uint32_t g1 = gridDim.x + atomicAdd(g_next, 1u);
+        if (g1 < n_groups) smem[T::O_CTR + 5] = (1u << 20) | g1; else smem[T::O_CTR + 1] = (uint32_t)NW;
+    }
+    __syncthreads();
+
+    // ---- which chunks.  The reads are cut into groups of NW consecutive 64-read chunks.  A block starts with group blockIdx.x and
+    // takes further groups from a counter in global memory (one atomic per NW chunks): a block that starts late -- the previous
+    // launch's composition fold still holds its CU -- or runs on a slower CU simply takes fewer groups (with a fixed share per block
+    // the last block finished 16 % after the first, and the fold beside the next launch cost 8 % of it).  INSIDE a block the waves
+    // claim chunks one at a time from a counter in LDS: chunk number c of the block = chunk c % NW of the block's group number c / NW.
+    // The id of group number L + 1 is fetched by the wave that claims the first chunk of group number L, a whole group ahead of its
+    // first use, and published in a four-entry ring in LDS (tagged with the group number).  When the global counter runs out, the
+    // block's chunk count becomes known instead.
     // flush k (k = 1, 2, ...) comes before the block's chunk k * FLUSH_CHUNKS, the last one after its last chunk: the 16-bit halves of
     // the LDS cells take FLUSH_CHUNKS x 64 <= 65535 increments in between (chunks are claimed in order, so a wave that holds a chunk
     // >= k * FLUSH_CHUNKS waits at flush k while exactly the chunks below it are being finished)
     constexpr uint32_t FLUSH_CHUNKS = 65535u / 64u / NW * NW;
-    const uint32_t n_flushes = (n_local + FLUSH_CHUNKS - 1) / FLUSH_CHUNKS;
     constexpr uint32_t REG_FLUSH_EVERY = 7; // 6-bit fields: 7 chunks x 8 reads per row <= 63
-    auto chunk_of = [&](const uint32_t c_) { return ((c_ / NW) * gridDim.x + blockIdx.x) * NW + c_ % NW; };
+    constexpr uint32_t NO_CHUNK = 0xffffffffu;
+    auto lds_word = [&](const int i) { return uniu(*(volatile const __attribute__((address_space(3))) uint32_t *)(size_t)(uint32_t)((T::O_CTR + i) * 4)); };
+    // the global chunk of the block's chunk number c_ (NO_CHUNK: past the block's last chunk); waits for the group's id if need be
+    auto chunk_of = [&](const uint32_t c_) -> uint32_t {
+        const uint32_t L = c_ / NW;
+        for (;;) {
+            if (c_ >= lds_word(1)) return NO_CHUNK;
+            const uint32_t e = lds_word(4 + (int)(L & 3u));
+            if ((e >> 20) == (L & 0xfffu)) return (e & 0xfffffu) * NW + c_ % NW;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    };
 
     const int in_off = P.in_off, Q = P.Q;
     uint32_t *slot = smem + T::O_STG + wave * T::STG_DW;
@@ -382,13 +413,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const uint32_t hb_lane = (uint32_t)(Cfg::O_HB * 4 + pbase * 4);
     FsAcc fs_acc; // FilterStat sums of the chunks since the last spill (7 chunks x 64 reads x 152 bases per wave: inside the packed fields)
     auto spill_base_regs = [&]() {
+        // the 8 rows of the wave hold the same positions: each row starts with another class, so that an add meets at most one other
+        // row on its cell instead of seven
+        uint32_t sh_c[FAQCS_NBASE], ad_c[FAQCS_NBASE];
+#pragma unroll
+        for (int c = 0; c < FAQCS_NBASE; ++c) {
+            uint32_t cp = (uint32_t)c + (uint32_t)(lane >> 3) % FAQCS_NBASE;
+            cp = cp >= FAQCS_NBASE ? cp - FAQCS_NBASE : cp;
+            sh_c[c] = cp * 6u;
+            ad_c[c] = hb_lane + cp * (uint32_t)(W * 4);
+        }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const uint32_t x = bpre[j], y = bpost[j];
 #pragma unroll
             for (int c = 0; c < FAQCS_NBASE; ++c) {
-                const uint32_t v = ((x >> BT_SHIFT(c)) & 63u) | (((y >> BT_SHIFT(c)) & 63u) << 16);
-                lds_add_u32(hb_lane + (uint32_t)((c * W + j) * 4), v);
+                const uint32_t v = ((x >> sh_c[c]) & 63u) | (((y >> sh_c[c]) & 63u) << 16);
+                lds_add_u32(ad_c[c] + (uint32_t)(j * 4), v);
             }
             bpre[j] = 0; bpost[j] = 0;
         }
@@ -402,8 +443,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     struct RawB { uint32_t r[D + 1], mv[D], mh[D], ml[D]; };
     auto load_b = [&](const uint32_t i0, const uint32_t i1, RawB &x) {
         const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
-        const bool post = ((i1 >> 16) & 1u) != 0u;
-        const int vb = med3i(len - pbase, 0, C + 1);
+        const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
+        const int vb = counted ? med3i(len - pbase, 0, C + 1) : 0; // (a read that is not counted: no byte of it is)
         const int lo = post ? med3i(a - pbase, 0, C + 1) : 0, hi = post ? med3i(a + n - pbase, 0, C + 1) : 0;
         const uint32_t qa = (slot_b + (i0 & 0xffffu) + (uint32_t)pbase) & ~3u;
 #pragma unroll
@@ -417,12 +458,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     uint32_t qb_sum = 0; // (Q-B, `sum` steps) this lane's read: the sum of its raw quality bytes
     auto quality_cells = [&](const RawB &x, const uint32_t i0, const uint32_t i1, auto undo_t, const int t, const bool sum) {
         constexpr bool undo = decltype(undo_t)::value;
-        const bool counted = ((i1 >> 17) & 1u) != 0u;
         const uint32_t sh = ((i0 & 0xffffu) + (uint32_t)pbase + slot_b) & 3u;
         uint32_t cm[D], im[D], wq[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            cm[k] = (counted && !undo) ? x.mv[k] & 0x01010101u : 0u;
+            cm[k] = !undo ? x.mv[k] & 0x01010101u : 0u; // (load_b: no byte of a read that is not counted is inside it)
             im[k] = (x.mh[k] ^ x.ml[k]) & (undo ? 0xffffffffu : 0x01010101u);
             wq[k] = __builtin_amdgcn_alignbyte(x.r[k + 1], x.r[k], sh);
         }
@@ -466,9 +506,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     auto base_step = [&](const int t, const uint32_t i0, const uint32_t i1, auto mode_t) {
         constexpr int MODE = decltype(mode_t)::value;
         const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
-        const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
-        const int vb = med3i(len - pbase, 0, C + 1);
-        const int lo = med3i(a - pbase, 0, C + 1), hi = med3i(a + n - pbase, 0, C + 1);
+        const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u, chk = ((i1 >> 18) & 1u) != 0u;
+        const int vb = counted ? med3i(len - pbase, 0, C + 1) : 0; // (a read that is not counted: every byte reads as "past the read")
+        // the kept window as the table lookups see it: empty for a read that is not kept (every base outside: pre increments only)
+        const int lo = med3i(a - pbase, 0, C + 1), hi = (post || chk) ? med3i(a + n - pbase, 0, C + 1) : lo;
         const uint32_t qa = (slot_b + (i0 & 0xffffu) + (uint32_t)pbase) & ~3u;
         const uint32_t sh = ((i0 & 0xffffu) + (uint32_t)pbase + slot_b) & 3u;
         uint32_t r[D + 1], w[D], inw[D];
@@ -477,8 +518,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const uint32_t mv = t_bm[BMW * vb + k], mh = t_bm[BMW * hi + k], ml = t_bm[BMW * lo + k];
-            w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & (counted ? mv : 0u); // a byte past the read: 0, no class
-            inw[k] = mh ^ ml;                                                             // 0xff: inside the kept window
+            w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & mv; // a byte past the read: 0, no class
+            inw[k] = mh ^ ml;                                           // 0xff: inside the kept window
         }
         uint32_t tp = 0, tq = 0;
 #pragma unroll
@@ -486,7 +527,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const int k = j >> 2;
             if ((j & 3) == 0) {
                 if (MODE == 0) seen7 |= w[k];
-                w[k] ^= ~(post ? inw[k] : 0u) & 0x80808080u; // (w[k] is the table index from here on; bit 7 is put back for the N tests)
+                w[k] ^= ~((EXT && chk) ? 0u : inw[k]) & 0x80808080u; // (w[k] is the table index from here on; bit 7 is put back for the N tests)
             }
             const uint32_t ad = ((j & 3) == 0 ? byte_x8<0>(w[k], three) : (j & 3) == 1 ? byte_x8<1>(w[k], three)
                                  : (j & 3) == 2 ? byte_x8<2>(w[k], three) : byte_x8<3>(w[k], three)) + (uint32_t)(T::O_T3 * 4);
@@ -513,14 +554,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // ---- upper-case N inside the kept window (count_poly_n, trim.cpp:578-597): looked at only when the read has enough N
             // (any case) in its window to matter, or when it is judged without being counted (chk) ----
             const uint32_t cN = ce >> 24;
-            const bool chk = ((i1 >> 18) & 1u) != 0u;
             // -n 2 (the default): a pair test; -n k, k != 0: the read's N positions as a bit mask (a run of k needs k N); -n 0: nothing to look at
             const uint32_t need_n = (EXT && P.max_poly_n != 2u) ? P.max_poly_n : 2u;
             if ((!EXT || P.max_poly_n != 0u) && __any(cN >= need_n || chk)) {
                 uint32_t nb[D]; // bit 7 of a byte: upper-case 'N' inside the kept window
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    const uint32_t orig = w[k] ^ (~(post ? inw[k] : 0u) & 0x80808080u); // (the byte itself again)
+                    const uint32_t orig = w[k] ^ (~((EXT && chk) ? 0u : inw[k]) & 0x80808080u); // (the byte itself again)
                     const uint32_t x = (orig & inw[k]) ^ 0x4e4e4e4eu;
                     const uint32_t sx = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
                     nb[k] = ~(sx | x) & 0x80808080u;
@@ -583,9 +623,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #define FAQCS_STAMP(i)
 #endif
     uint32_t p_off = 0, p_end = 0;
-    auto fetch_offsets = [&](const uint32_t c_) { // c_: the block's chunk number
-        if (c_ < n_local) {
-            const uint32_t my_ = (chunk_of(c_) << 6) + (uint32_t)lane;
+    auto fetch_offsets = [&](const uint32_t chunk_) { // (a chunk past the last one of the launch: a chunk of no reads)
+        if (chunk_ != NO_CHUNK) {
+            const uint32_t my_ = (chunk_ << 6) + (uint32_t)lane;
             p_off = off[my_ < n_reads ? my_ : n_reads];
             p_end = off[my_ < n_reads ? my_ + 1 : n_reads];
         }
@@ -595,8 +635,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     struct ChunkLoads { uint32_t v_off, v_end, v_sl, v_hit, bfirst, blast; };
     ChunkLoads ld = {0, 0, 0, 0, 0, 0};
     bool pre_issued = false;
-    auto issue_loads = [&](const uint32_t c_, const uint32_t o_, const uint32_t e_, ChunkLoads &L) {
-        const uint32_t my_ = (chunk_of(c_) << 6) + (uint32_t)lane;
+    auto issue_loads = [&](const uint32_t chunk_, const uint32_t o_, const uint32_t e_, ChunkLoads &L) {
+        const uint32_t my_ = (chunk_ << 6) + (uint32_t)lane;
         const bool mine_ = my_ < n_reads;
         const uint32_t len_ = e_ - o_;
         const uint32_t cs_ = uniu(o_), ce_ = (uint32_t)__builtin_amdgcn_readlane((int)e_, 63);
@@ -610,7 +650,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         if (len_) { L.bfirst = (uint32_t)seq[(size_t)o_]; L.blast = (uint32_t)seq[(size_t)o_ + len_ - 1]; }
     };
     uint32_t c_cur = (uint32_t)wave, n_flushed = 0, since_spill = 0;
-    fetch_offsets(c_cur);
+    uint32_t chunk_cur = chunk_of(c_cur);
+    fetch_offsets(chunk_cur);
 #ifdef FAQCS_LDS_STAMPS
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime(); // shader clock = d(memtime) / d(memrealtime) x 100 MHz
 #endif
@@ -620,7 +661,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         st_prev = __builtin_amdgcn_s_memtime();
 #endif
         {   // the flushes that come before chunk c_cur (every wave of the block passes each of them exactly once)
-            const uint32_t due = c_cur < n_local ? c_cur / FLUSH_CHUNKS : n_flushes;
+            const uint32_t n_local = lds_word(1); // (known by the time a wave holds a chunk number past it)
+            const uint32_t due = chunk_cur != NO_CHUNK ? c_cur / FLUSH_CHUNKS : (n_local + FLUSH_CHUNKS - 1) / FLUSH_CHUNKS;
 #pragma unroll 1
             while (n_flushed < due) {
                 spill_base_regs();
@@ -632,18 +674,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         st_flush += __builtin_amdgcn_s_memtime() - st_prev;
         st_prev = __builtin_amdgcn_s_memtime();
 #endif
-        if (c_cur >= n_local) break;
+        if (chunk_cur == NO_CHUNK) break;
         uint32_t c_next = 0;
         if (lane == 0) c_next = __hip_atomic_fetch_add((lds_u32_mut)(size_t)(uint32_t)(T::O_CTR * 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         c_next = uniu(c_next);
+        // the first chunk of group number L: ask for the id of group number L + 1 (published below, behind this chunk's loads)
+        const bool fetch_group = c_next % NW == 0 && c_next < lds_word(1);
+        uint32_t g_new = 0;
+        if (fetch_group && lane == 0) g_new = atomicAdd(g_next, 1u);
+        const uint32_t chunk_next = chunk_of(c_next);
         {
-            const uint32_t chunk = chunk_of(c_cur);
+            const uint32_t chunk = chunk_cur;
             const uint32_t base = chunk << 6;
             const uint32_t my = base + lane;
             const bool mine = my < n_reads;
             // ---- the span of the QUALITY arena -> LDS, and the per-read words that come from global memory.  Requested at the end
             // of the previous chunk (issue_loads below, once the slot is no longer read); here for a wave's first chunk only.
-            if (!pre_issued) issue_loads(c_cur, p_off, p_end, ld);
+            if (!pre_issued) issue_loads(chunk_cur, p_off, p_end, ld);
             // a lane without a read sits at the end of the last read (length 0): the span ends where lane 63 ends
             const uint32_t v_off = ld.v_off, v_end = ld.v_end;
             const uint32_t v_len = v_end - v_off;
@@ -653,8 +700,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t shq = (uint32_t)((size_t)(qual + cs) & 15u);
             const uint32_t rowq = v_off - cs + shq; // this lane's read inside the slot
             const uint32_t bfirst = ld.bfirst, blast = ld.blast;
-            fetch_offsets(c_next);
+            fetch_offsets(chunk_next);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (fetch_group) { // publish group number L + 1 of the block, or the block's chunk count when the launch has no group left
+                const uint32_t L1 = c_next / NW + 1u, gid = gridDim.x + uniu(g_new);
+                if (lane == 0) {
+                    if (gid < n_groups) *(volatile __attribute__((address_space(3))) uint32_t *)(size_t)(uint32_t)((T::O_CTR + 4 + (int)(L1 & 3u)) * 4) = ((L1 & 0xfffu) << 20) | gid;
+                    else *(volatile __attribute__((address_space(3))) uint32_t *)(size_t)(uint32_t)((T::O_CTR + 1) * 4) = L1 * NW;
+                }
+            }
             // pad behind the span: the position-parallel passes read up to W + 5 bytes past a short last read, and what they
             // find there must be a valid quality byte (see quality_cells)
 #pragma unroll
@@ -1140,8 +1194,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // the slot is not read any more: request the next chunk's loads now, under the epilogue (p_off / p_end: its offsets,
             // fetched at the top of this chunk)
             ChunkLoads ld_next = ld;
-            pre_issued = c_next < n_local;
-            if (pre_issued) issue_loads(c_next, p_off, p_end, ld_next);
+            pre_issued = chunk_next != NO_CHUNK;
+            if (pre_issued) issue_loads(chunk_next, p_off, p_end, ld_next);
 
             if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
             oc.an = (uint32_t)a | ((uint32_t)n << 16);
@@ -1162,7 +1216,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #ifdef FAQCS_LDS_STAMPS
         st_flush += __builtin_amdgcn_s_memtime() - st_prev; // (register spill + block flush: outside the nine sections)
 #endif
-        c_cur = c_next;
+        c_cur = c_next; chunk_cur = chunk_next;
     }
     if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
 #ifdef FAQCS_LDS_STAMPS
@@ -1171,6 +1225,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         for (int i = 0; i < 9; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + i, st_acc[i]);
         atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 9, __builtin_amdgcn_s_memtime() - clk0);
         atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 11, st_flush);
+#ifdef FAQCS_LDS_BLOCKLOG
+        if (wave == 0) printf("block %u xcc %u chunks %u start %llu end %llu\n", blockIdx.x, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)), smem[T::O_CTR + 1],
+                              (unsigned long long)rt0, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+        if (wave == 0) { // when the blocks finish: latest and earliest s_memrealtime (10 ns ticks) of a block's wave 0
+            const unsigned long long te = __builtin_amdgcn_s_memrealtime();
+            atomicMax(reinterpret_cast<unsigned long long *>(err + 16) + 13, te);
+            atomicMax(reinterpret_cast<unsigned long long *>(err + 16) + 14, ~te);
+            atomicMax(reinterpret_cast<unsigned long long *>(err + 16) + 15, ~rt0); // (the earliest loop start)
+        }
         atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 12, clk0 - clk_entry);
         atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 10, __builtin_amdgcn_s_memrealtime() - rt0);
     }
@@ -1196,7 +1260,7 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
                        reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8>::N_ZERO + 63) / 64), dim3(256), 0, st, P.partials, grid, counters, P.R);
+    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, grid, counters, P.R, err + 8);
     return hipGetLastError();
 }
 

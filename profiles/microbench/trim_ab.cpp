@@ -119,8 +119,10 @@ int main(int argc, char **argv)
         for (auto &l : libs) {
             faqcs_kernel_times kt;
             l.report(l.ctx, &kt); // resets the timers
-            for (int k = 0; k < reps; ++k)
+            for (int k = 0; k < reps; ++k) {
                 if (l.submit_device(l.ctx, &b, d_res) != 0) { fprintf(stderr, "%s: submit: %s\n", l.path.c_str(), l.last_error()); return 1; }
+                if (getenv("TRIM_AB_SYNC_EACH")) l.sync(l.ctx); // (the composition fold of a launch then never runs beside the next launch)
+            }
             l.sync(l.ctx);
             l.report(l.ctx, &kt);
             printf("round %d %-44s trim %.4f ms/launch -> %.1f M reads/s\n", r, l.path.c_str(), kt.trim_ms, n / kt.trim_ms / 1e3);
@@ -142,6 +144,14 @@ int main(int argc, char **argv)
             for (int i = 0; i < 9; ++i) printf("  %-26s %8.1f = %5.1f %%\n", names[i], w[i] / chunks, 100.0 * w[i] / tot);
             printf("  %-26s %8.1f   (outside the sections)\n  %-26s %8.1f   (per chunk; once per wave)\n  %-26s %8.1f\n", "register spill + flush", w[11] / chunks,
                    "kernel entry -> loop", w[12] / chunks, "loop, entry to exit", w[9] / chunks);
+            {   // one more launch on its own: when do the blocks finish?
+                uint64_t z[16];
+                l.debug_words(l.ctx, z, 16);
+                l.submit_device(l.ctx, &b, d_res); l.sync(l.ctx);
+                l.debug_words(l.ctx, z, 16);
+                const double t_last = (double)z[13], t_first = (double)~z[14], t_start = (double)~z[15];
+                printf("  blocks finish between %.1f and %.1f us after the first wave entered its loop (wave 0 of each block)\n", (t_first - t_start) * 0.01, (t_last - t_start) * 0.01);
+            }
             if (w[10]) printf("  shader clock while the kernel runs: %.3f GHz (s_memtime / s_memrealtime x 100 MHz, summed over the waves)\n", (double)w[9] / (double)w[10] * 0.1);
         }
     }
