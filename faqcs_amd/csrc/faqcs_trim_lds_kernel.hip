@@ -219,7 +219,7 @@ __device__ __noinline__ ExactB exact_bases(const uint8_t *__restrict__ seq, cons
 
 constexpr int lds_waves(int C) { return C <= 19 ? 12 : 8; }
 
-// LDS accumulators -> this block's OWN row of partial sums in global memory (plain coalesced read-modify-write, no atomics: only
+// LDS accumulators -> this block's OWN row of partial sums in global memory (coalesced adds without a return value: only
 // this block touches the row), low and high half-words apart; fold_partials, launched behind the trim kernel, adds the rows of all
 // blocks to the u64 counter block and zeroes them.  (The direct flush of faqcs_trim_common.h costs one 64-bit global atomic per
 // non-zero counter and block -- 256 blocks x ~14 000 counters, each on a sector of its own, all at the end of the launch: 15 % of
@@ -234,8 +234,9 @@ __device__ __noinline__ void flush_block_partial(uint32_t *smem, uint32_t *__res
         const uint32_t v = smem[i];
         if (v) {
             smem[i] = 0;
-            if (v & 0xffffu) row[i] += v & 0xffffu;
-            if (v >> 16) row[FAQCS_PARTIAL_ROW + i] += v >> 16;
+            // (no-return atomics on the block's own row: nothing to wait for, unlike a load-add-store per cell)
+            if (v & 0xffffu) __hip_atomic_fetch_add(&row[i], v & 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v >> 16) __hip_atomic_fetch_add(&row[FAQCS_PARTIAL_ROW + i], v >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     }
 
 #ifdef FAQCS_LDS_STAMPS
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_flush = 0;
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_flush = 0, st_spill = 0;
 #define FAQCS_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_prev; st_prev = now_; }
 #else
 #define FAQCS_STAMP(i)
@@ -1214,7 +1215,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         FAQCS_STAMP(8)
         if (++since_spill == REG_FLUSH_EVERY) { spill_base_regs(); since_spill = 0; }
 #ifdef FAQCS_LDS_STAMPS
-        st_flush += __builtin_amdgcn_s_memtime() - st_prev; // (register spill + block flush: outside the nine sections)
+        st_spill += __builtin_amdgcn_s_memtime() - st_prev; // (the register spill: outside the nine sections, like the block flush)
 #endif
         c_cur = c_next; chunk_cur = chunk_next;
     }
@@ -1235,7 +1236,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             atomicMax(reinterpret_cast<unsigned long long *>(err + 16) + 14, ~te);
             atomicMax(reinterpret_cast<unsigned long long *>(err + 16) + 15, ~rt0); // (the earliest loop start)
         }
-        atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 12, clk0 - clk_entry);
+        atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 12, st_spill);
+        (void)clk_entry;
         atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 10, __builtin_amdgcn_s_memrealtime() - rt0);
     }
 #endif

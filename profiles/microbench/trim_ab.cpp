@@ -142,8 +142,8 @@ int main(int argc, char **argv)
             const double chunks = (double)(1 + rounds * reps) * n / 64.0;
             printf("%s: section clocks per 64-read chunk per wave (total %.0f)\n", l.path.c_str(), tot / chunks);
             for (int i = 0; i < 9; ++i) printf("  %-26s %8.1f = %5.1f %%\n", names[i], w[i] / chunks, 100.0 * w[i] / tot);
-            printf("  %-26s %8.1f   (outside the sections)\n  %-26s %8.1f   (per chunk; once per wave)\n  %-26s %8.1f\n", "register spill + flush", w[11] / chunks,
-                   "kernel entry -> loop", w[12] / chunks, "loop, entry to exit", w[9] / chunks);
+            printf("  %-26s %8.1f   (outside the sections)\n  %-26s %8.1f   (per chunk; once per wave)\n  %-26s %8.1f\n", "block flushes (+ barrier)", w[11] / chunks,
+                   "register spills", w[12] / chunks, "loop, entry to exit", w[9] / chunks);
             {   // one more launch on its own: when do the blocks finish?
                 uint64_t z[16];
                 l.debug_words(l.ctx, z, 16);
