@@ -486,7 +486,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t data = __builtin_amdgcn_perm(cm[j >> 2], im[j >> 2], sel);
             const uint32_t ad = ((j & 3) == 0 ? byte_mul<0>(wq[j >> 2], wx4) : (j & 3) == 1 ? byte_mul<1>(wq[j >> 2], wx4)
                                  : (j & 3) == 2 ? byte_mul<2>(wq[j >> 2], wx4) : byte_mul<3>(wq[j >> 2], wx4)) + hq_lane;
-#ifndef FAQCS_LDS_NO_QB_ATOMICS
+#ifdef FAQCS_LDS_QB_NOCONFLICT // (diagnostic build, wrong results: every lane on a bank of its own -- what the conflicts of these adds cost)
+            lds_add_u32((ad & 0x3u) + (uint32_t)(Cfg::O_HQ * 4) + (uint32_t)lane * 4u + 256u * (uint32_t)j, data);
+#elif !defined(FAQCS_LDS_NO_QB_ATOMICS)
             lds_add_u32(ad + 4u * (uint32_t)j, data);
 #else
             asm volatile("" :: "v"(ad), "v"(data));

@@ -485,6 +485,102 @@ def test_full_size_properties():
     assert bool((res2 == res).all())
 
 
+def _fill_arenas(lib, dev, total_bytes, L):
+    """Two synthetic arenas of total_bytes + padding (may exceed 4 GiB: filled in pieces of whole L-base reads)."""
+    import torch
+
+    from faqcs_amd.engine import _check
+
+    n_fill = (total_bytes + 64 + L - 1) // L
+    seq = torch.empty(n_fill * L + 128, dtype=torch.uint8, device=dev)
+    qual = torch.empty(n_fill * L + 128, dtype=torch.uint8, device=dev)
+    piece = (1 << 31) // L
+    done = 0
+    while done < n_fill:
+        m = min(piece, n_fill - done)
+        scratch = torch.empty(m + 1, dtype=torch.int32, device=dev)
+        _check(lib, lib.faqcs_synth_fill(0, seq.data_ptr() + 64 + done * L, qual.data_ptr() + 64 + done * L, scratch.data_ptr(), m, L, 20260101, done, 0.0))
+        done += m
+    torch.cuda.synchronize()
+    return seq, qual  # (the arenas proper start 64 bytes in: FAQCS_ARENA_PAD_BEFORE)
+
+
+def _check_slices(opt, R, seq, qual, off_host, res_dev, slices, L):
+    """Per-read results of the given read ranges against the oracle (arenas copied back slice by slice)."""
+    from oracle_engine import OracleEngine
+
+    for lo, hi in slices:
+        b0, b1 = int(off_host[lo]), int(off_host[hi])
+        hs = seq[64 + b0: 64 + b1 + 64].cpu().numpy()
+        hq = qual[64 + b0: 64 + b1 + 64].cpu().numpy()
+        ho = (off_host[lo:hi + 1].astype(np.int64) - b0).astype(np.uint32)
+        ora = OracleEngine(opt, R, 33)
+        want = ora.process(hs, hq, ho, np.array([0, hi - lo], dtype=np.uint32))
+        got = res_dev[lo:hi].cpu().numpy().view(np.uint16).view(capi.RESULT_DTYPE).ravel()
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, "reads %d..%d: first differing read %d: hip=%s oracle=%s" % (lo, hi, lo + bad[0], got[bad[0]], want[bad[0]])
+
+
+@pytest.mark.parametrize("L,kernel,ragged", [(150, "trim_lds", False), (150, "trim_lds", True), (128, "trim_tpr", False),
+                                             (250, "trim_filter_accumulate", False), (250, "trim_filter_accumulate", True)])
+def test_launch_at_the_4gib_arena_limit_matches_oracle(L, kernel, ragged):
+    """The launch size bench.py uses: an arena of (2^32 - 4096) // L reads (u32 offsets up to 4 GiB).  The kernels do 32-bit
+    arithmetic on offsets, so the END of such an arena -- the last chunk is partial -- and the reads either side of 2^31 are
+    compared with the oracle; the ragged variant (read lengths L - 40 .. L) ends 33 bytes short of 2^32."""
+    import ctypes as C
+
+    import torch
+
+    from faqcs_amd.engine import HipEngine, _check
+
+    R = 256
+    opt = parse_args(["-u", "x", "-d", "y", "--ascii", "33"])
+    eng = HipEngine(opt, R, 33, device=0)
+    lib = eng.lib
+    dev = torch.device("cuda:0")
+    if ragged:
+        rng = np.random.Generator(np.random.PCG64([L, SEED, 4]))
+        lens = rng.integers(L - 40, L + 1, size=(1 << 32) // (L - 40) + 8, dtype=np.int64)
+        cum = np.cumsum(lens)
+        limit = (1 << 32) - 33
+        n = int(np.searchsorted(cum, limit - (L - 40), side="right"))  # reads that end at least one short read before the limit
+        last = limit - int(cum[n - 1])                                 # one more read that ends exactly at the limit
+        assert L - 40 <= last <= 2 * L
+        if last > L:                                                   # (split it so that no read is longer than L)
+            ends = np.concatenate([cum[:n], [cum[n - 1] + last - (L - 20), limit]])
+        else:
+            ends = np.concatenate([cum[:n], [limit]])
+        off_host = np.concatenate([[0], ends]).astype(np.uint32)
+        total = limit
+    else:
+        n_reads = (0xFFFFFFFF - 4096) // L
+        off_host = (np.arange(n_reads + 1, dtype=np.uint64) * L).astype(np.uint32)
+        total = int(off_host[-1])
+    n = len(off_host) - 1
+    assert int(np.diff(off_host.astype(np.int64)).max()) <= L and (1 << 32) - total < (64 if ragged else 4096 + 2 * L)
+    seq, qual = _fill_arenas(lib, dev, total, L)
+    off = torch.from_numpy(off_host.view(np.int32)).to(dev)
+    res = torch.empty((n, 4), dtype=torch.int16, device=dev)
+    seg = np.array([0, n], dtype=np.uint32)
+    b = capi.Batch(seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, 1, seg.ctypes.data, L)
+    _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(b), res.data_ptr()))
+    eng.sync()
+    kt = capi.KernelTimes()
+    lib.faqcs_kernel_report(eng.ctx, C.byref(kt))
+    assert (kt.trim_kernel or b"").decode() == kernel
+    blk = eng.counters()
+    lay = capi.python_layout(R, 0)
+    fs = blk[lay["filter_stats"][0]:lay["filter_stats"][0] + 32]
+    assert int(fs[capi.TOTAL_NUMBER]) == n and int(fs[capi.TOTAL_LENGTH]) == total
+    mid = int(np.searchsorted(off_host, 1 << 31))
+    _check_slices(opt, R, seq, qual, off_host, res, [(n - 20000, n), (mid - 5000, mid + 5000), (0, 5000)], L)
+    # the sum of the per-read results is what the counter block says
+    r = res.cpu().numpy().view(np.uint16)
+    valid = (r[:, 2] & 1) != 0
+    assert int(fs[capi.TOTAL_TRIMMED_NUMBER]) == int(valid.sum())
+    assert int(fs[capi.TOTAL_TRIMMED_LENGTH]) == int(r[valid, 1].astype(np.int64).sum())
+
+
 _SHIM_BIN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),
                                        "oracle", "_ref", "FaQCs_hip")
 
