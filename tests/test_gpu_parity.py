@@ -581,6 +581,116 @@ def test_launch_at_the_4gib_arena_limit_matches_oracle(L, kernel, ragged):
     assert int(fs[capi.TOTAL_TRIMMED_LENGTH]) == int(r[valid, 1].astype(np.int64).sum())
 
 
+def test_full_size_adapter_polya():
+    """BASELINE configs[2]'s option set (--adapter --polyA, 5 % read-through) on 4 M reads: a size at which the adapter pre-pass runs
+    thousands of 32 768-read segments and the trim kernel's flush / register-spill paths with an adapter window trigger.  Invariants
+    of the adapter statistics against the per-read results, and the oracle on the first two and the last (partial) segment."""
+    import ctypes as C
+
+    import torch
+
+    from faqcs_amd.engine import HipEngine, _check
+
+    n, L, R = 4_000_000 + 12_345, 150, 256
+    opt = parse_args(["-u", "x", "-d", "y", "--ascii", "33", "--adapter", "--polyA"])
+    eng = HipEngine(opt, R, 33, device=0)
+    lib = eng.lib
+    dev = torch.device("cuda:0")
+    seq = torch.empty(n * L + 128, dtype=torch.uint8, device=dev)
+    qual = torch.empty(n * L + 128, dtype=torch.uint8, device=dev)
+    off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    res = torch.empty((n, 4), dtype=torch.int16, device=dev)
+    _check(lib, lib.faqcs_synth_fill(0, seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, L, 20260101, 0, 0.05))
+    seg = np.arange(0, n + capi.SEGMENT_READS, capi.SEGMENT_READS, dtype=np.uint32)
+    seg[-1] = n
+    b = capi.Batch(seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, len(seg) - 1, seg.ctypes.data, L)
+    _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(b), res.data_ptr()))
+    blk = eng.counters()
+    na = eng.holder.n_adapters
+    lay = capi.python_layout(R, na)
+    fs = blk[lay["filter_stats"][0]:lay["filter_stats"][0] + 32]
+    assert int(fs[capi.TOTAL_NUMBER]) == n and int(fs[capi.TOTAL_LENGTH]) == n * L
+    r = res.cpu().numpy().view(np.uint16)
+    ast = blk[lay["adapter_stats"][0]:lay["adapter_stats"][0] + 2 * na].reshape(na, 2)
+    credited = np.bincount(r[:, 3], minlength=na + 1)
+    assert (credited[1:] == ast[:, 0]).all(), "reads credited per adapter"
+    assert 0.03 * n < credited[1:].sum() < 0.12 * n  # (5 % read-through plus chance hits)
+    valid = (r[:, 2] & 1) != 0
+    assert int(fs[capi.TOTAL_TRIMMED_NUMBER]) == int(valid.sum())
+    assert int(fs[capi.TOTAL_TRIMMED_LENGTH]) == int(r[valid, 1].astype(np.int64).sum())
+    post_len = blk[lay["post_len_hist"][0]:lay["post_len_hist"][0] + lay["post_len_hist"][1]]
+    assert (np.bincount(r[valid, 1], minlength=R + 1)[:R + 1] == post_len).all()
+    off_host = off.cpu().numpy().view(np.uint32)
+    from oracle_engine import OracleEngine
+
+    for lo, hi in ((0, 2 * capi.SEGMENT_READS), (int(seg[-2]), n)):
+        b0, b1 = int(off_host[lo]), int(off_host[hi])
+        hs, hq = seq[64 + b0: 64 + b1 + 64].cpu().numpy(), qual[64 + b0: 64 + b1 + 64].cpu().numpy()
+        ho = (off_host[lo:hi + 1].astype(np.int64) - b0).astype(np.uint32)
+        sg = np.arange(0, hi - lo + capi.SEGMENT_READS, capi.SEGMENT_READS, dtype=np.uint32)
+        sg[-1] = hi - lo
+        want = OracleEngine(opt, R, 33).process(hs, hq, ho, sg)
+        got = r[lo:hi].view(capi.RESULT_DTYPE).ravel()
+        assert (got == want).all(), "reads %d..%d" % (lo, hi)
+
+
+def test_full_size_kmer_250():
+    """BASELINE configs[4]'s shape (2x250, --kmer_rarefaction, genome-sampled reads): the first 50 000 reads against the oracle
+    (sampling points, distinct / total k-mers, the count histogram), then 1 M reads for the invariants of the curve."""
+    import ctypes as C
+
+    import torch
+
+    from faqcs_amd.engine import HipEngine, _check
+    from oracle_engine import OracleEngine
+
+    n, m, L, R = 1_000_000, 50_000, 250, 256
+    args = ["-u", "x", "-d", "y", "--ascii", "33", "--kmer_rarefaction", "--split_size", "10000", "--subset", "40"]
+    opt = parse_args(args)
+    dev = torch.device("cuda:0")
+    eng = HipEngine(opt, R, 33, device=0, kmer_table_slots=1 << 28)
+    lib = eng.lib
+    seq = torch.empty(n * L + 128, dtype=torch.uint8, device=dev)
+    qual = torch.empty(n * L + 128, dtype=torch.uint8, device=dev)
+    off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    res = torch.empty((n, 4), dtype=torch.int16, device=dev)
+    _check(lib, lib.faqcs_synth_fill_genome(0, seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, L, 20260101, 0, 50_000_000))
+
+    def run(engine, count):
+        seg = np.arange(0, count + 4000, 4000, dtype=np.uint32)  # (segments = the reference's trim() calls: sampling points fall on their ends)
+        seg[-1] = count
+        b = capi.Batch(seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), count, len(seg) - 1, seg.ctypes.data, L)
+        _check(engine.lib, engine.lib.faqcs_submit_device(engine.ctx, C.byref(b), res.data_ptr()))
+        engine.sync()
+        return seg
+
+    seg = run(eng, m)
+    hs, hq = seq[64: 64 + m * L + 64].cpu().numpy(), qual[64: 64 + m * L + 64].cpu().numpy()
+    ho = off[: m + 1].cpu().numpy().view(np.uint32)
+    ora = OracleEngine(opt, R, 33)
+    want = ora.process(hs, hq, ho, seg)
+    assert (res[:m].cpu().numpy().view(np.uint16).view(capi.RESULT_DTYPE).ravel() == want).all()
+    assert (eng.counters() == ora.counters()).all()
+    eng.kmer_end_table()
+    ora.kmer_end_table()
+    p1, p2 = eng.kmer_points(), ora.kmer_points()
+    assert len(p1) >= 4 and (p1 == p2).all()
+    h1, h2 = eng.kmer_histogram(), ora.kmer_histogram()
+    assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
+    # the whole set on a fresh engine: the curve is monotone, ends at the table's totals, and its first points are the prefix's
+    eng2 = HipEngine(opt, R, 33, device=0, kmer_table_slots=1 << 28)
+    run(eng2, n)
+    eng2.kmer_end_table()
+    pts = eng2.kmer_points()
+    assert len(pts) > len(p1)
+    k = min(len(p1), len(pts)) - 1
+    assert (pts[:k] == p1[:k]).all()
+    assert (np.diff(pts["distinct_kmer"].astype(np.int64)) >= 0).all() and (np.diff(pts["total_kmer"].astype(np.int64)) > 0).all()
+    assert (pts["distinct_kmer"] <= pts["total_kmer"]).all()
+    cnt, nk = eng2.kmer_histogram()
+    assert int((cnt * nk).sum()) >= int(pts["total_kmer"][-1])
+
+
 _SHIM_BIN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),
                                        "oracle", "_ref", "FaQCs_hip")
 
