@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_PAIRS", 100e6)),
-                    help="pairs per GPU resident in HBM (default: the 100 M pairs of BASELINE configs[1])")
+    ap.add_argument("--pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_PAIRS", 0)),
+                    help="pairs per GPU resident in HBM (default: BASELINE's sizes -- 100 M for plain / adapter on one GPU (configs[1], [2]), "
+                         "125 M per GPU for plain on 8 GPUs (configs[3]: 1 B pairs), 25 M per GPU for kmer (configs[4]: 200 M pairs on 8 GPUs))")
     ap.add_argument("--read-len", type=int, default=None, help="default 150 (250 for --config kmer)")
     ap.add_argument("--config", choices=["plain", "adapter", "kmer"], default="plain",
                     help="plain = BASELINE configs[1] (the headline), adapter = configs[2], kmer = configs[4]'s shape on one GPU")
@@ -187,21 +188,62 @@ def launch_ranks(a, real_stdout):
     if not share and have < a.gpus:
         raise SystemExit("bench: --gpus %d but only %d GPU(s) are visible" % (a.gpus, have))
     port = free_port()
-    procs = []
+    procs, errs = [], []
+    err_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(err_dir, exist_ok=True)
+    except OSError:
+        err_dir = tempfile.gettempdir()
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if share:
             env["FAQCS_BENCH_BACKEND"] = "gloo"
+        errs.append(open(os.path.join(err_dir, "rank%d.err" % r), "wb"))  # every rank's stderr is kept
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
-    real_stdout.write(out)
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
+    # Poll every rank: the first one that exits non-zero takes the job down within seconds (the others would sit in the rendezvous
+    # or in a collective until a timeout otherwise).  Only child processes started here are signalled.
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for r, f in enumerate(errs):
+            f.close()
+            try:
+                tail = open(f.name, "rb").read()[-600:].decode(errors="replace")
+            except OSError:
+                tail = ""
+            if tail.strip():
+                sys.stderr.write("bench: rank %d stderr (%s), last lines:\n%s\n" % (r, f.name, tail))
+        raise SystemExit(rc if rc > 0 else 1)
+    reader.join(timeout=10)
+    for f in errs:
+        f.close()
+    real_stdout.write((chunks[0] if chunks else b"").decode())
     real_stdout.flush()
-    raise SystemExit(rc)
+    raise SystemExit(0)
 
 
 def main():
@@ -227,12 +269,17 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+
+        rdzv_timeout = datetime.timedelta(seconds=int(os.environ.get("FAQCS_BENCH_RDZV_TIMEOUT", "120")))  # a missing rank fails the job, it does not hang it
+        if os.environ.get("FAQCS_BENCH_DIE_RANK") == str(rank):  # (test hook: this rank dies before the rendezvous)
+            raise SystemExit(7)
         if backend == "nccl":
             if torch.cuda.device_count() <= local:
                 raise SystemExit("bench: rank %d wants GPU %d but %d are visible" % (rank, local, torch.cuda.device_count()))
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=rdzv_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=rdzv_timeout)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -249,8 +296,8 @@ def main():
     from faqcs_amd.options import parse_args
 
     L = a.read_len or (250 if a.config == "kmer" else 150)
-    if a.config == "kmer" and a.pairs == 100e6:
-        a.pairs = 10e6  # 20 M reads of 250 bases from a 50 Mbp synthetic genome: 4.4 G k-mer occurrences per step
+    if not a.pairs:
+        a.pairs = 25e6 if a.config == "kmer" else (125e6 if (a.config == "plain" and world == 8) else 100e6)
     opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "1000000"]}.get(a.config, [])
     opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
     eng = HipEngine(opt, 256 if L <= 256 else capi.MAX_READ_LENGTH, 33, device=local,
@@ -372,6 +419,11 @@ def main():
         if a.config == "adapter" and kt.adapter_ms > kt.trim_ms:
             dominant, dom_ms = "adapter_overlap", kt.adapter_ms
             alg_bytes = reads_per_launch * (L + 4 + 6)
+        kmer_k = 31
+        if a.config == "kmer" and (kt.kmer_ms + kt.kmer_insert_ms) > kt.trim_ms:
+            # + (L - k + 1) x 16 bytes per read (8-byte key + 8-byte slot read-modify-write): 3 520 B/read at L = 250, k = 31
+            dominant, dom_ms = ("kmer_count" if kx is None else "kmer_extract + kmer_insert_items"), kt.kmer_ms + kt.kmer_insert_ms
+            alg_bytes = reads_per_launch * (L - kmer_k + 1) * 16
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config)
@@ -411,15 +463,30 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "kernel": dominant,
                          "kernel_ms": round(dom_ms, 4), "launches": int(kt.n_launches),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "kernels_ms": {trim_kernel: round(kt.trim_ms, 4), "adapter_overlap": round(kt.adapter_ms, 4)}},
+                         "kernels_ms": {trim_kernel: round(kt.trim_ms, 4), "adapter_overlap": round(kt.adapter_ms, 4),
+                                        "kmer (count, or extract)": round(kt.kmer_ms, 4), "kmer_insert_items": round(kt.kmer_insert_ms, 4)}},
         })
+        if a.config == "kmer" and "kmer" in out and dom_ms > 0:
+            # the k-mer kernels are bound by the rate of device-scope atomics (one per occurrence), not by bytes: measured ceiling
+            # 13.5 G atomics/s (profiles/r2c/pmc_kmer_atomics.txt, TCC_EA0_ATOMIC = 1.00 per insert)
+            occ = out["kmer"].get("occurrences_per_step", out["kmer"].get("occurrences_at_last_point", 0)) / max(1, len(batches))
+            rate = occ / (dom_ms * 1e-3) / 1e9
+            out["roofline"]["atomics"] = {"G_atomics_per_s": round(rate, 3), "measured_peak_G_per_s": 13.5, "frac": round(rate / 13.5, 4),
+                                          "note": "occurrences inserted per launch / the k-mer kernels' time; one memory-side atomic per occurrence"}
         if dominant == "adapter_overlap":
             # adapter_overlap is bound by integer VALU issue, not by HBM: the work is L x sum|adapter| cell updates per
             # read (62 850 for the 9 built-ins + polyA at L = 150); the instruction count per read comes from the PMC profile
             cells = 62850.0 * L / 150.0
+            # VALU issue: SQ_INSTS_VALU per read of adapter_overlap from its PMC profile (profiles/r2c/pmc_adapter.txt: 683 at L = 150, 5 %
+            # read-through) x reads/s, against the MEASURED issue rate of the instruction class the kernel is made of (v_bitop3, v_bcnt,
+            # v_alignbit, DPP, compares: 4 cycles per wave instruction = 575 G/s chip-wide; only plain VOP1/VOP2 integer ops reach
+            # 1 000 G/s -- profiles/r3a/valu_lds_peak.txt)
+            valu_per_read = 683.0 * L / 150.0
+            g_instr = reads_per_launch * valu_per_read / (dom_ms * 1e-3) / 1e9
             out["roofline"]["valu"] = {"cell_updates_per_s": round(reads_per_launch * cells / (dom_ms * 1e-3) / 1e12, 3), "unit": "T cell updates/s",
-                                       "valu_peak_G_wave_instr_per_s": 614.0,
-                                       "note": "bound by VALU issue: see profiles/ for SQ_INSTS_VALU per read of adapter_overlap"}
+                                       "G_wave_instr_per_s": round(g_instr, 1), "measured_peak_G_wave_instr_per_s": 575.0, "frac": round(g_instr / 575.0, 4),
+                                       "valu_instr_per_read": valu_per_read,
+                                       "note": "bound by VALU issue: instruction count per read from profiles/r2c/pmc_adapter.txt, peak from profiles/r3a/valu_lds_peak.txt"}
         if world == 1 and not a.no_cpu_baseline:
             ns = min(400000, batches[0][6])
             hs = batches[0][0][: ns * L].cpu().numpy()

@@ -63,7 +63,8 @@ class Layout(C.Structure):
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("trim_ms", C.c_double), ("adapter_ms", C.c_double), ("n_launches", C.c_uint64), ("trim_kernel", C.c_char_p)]
+    _fields_ = [("trim_ms", C.c_double), ("adapter_ms", C.c_double), ("n_launches", C.c_uint64), ("trim_kernel", C.c_char_p),
+                ("kmer_ms", C.c_double), ("kmer_insert_ms", C.c_double)]
 
 
 RESULT_DTYPE = np.dtype([("start", "<u2"), ("len", "<u2"), ("flags", "<u2"), ("adapter", "<u2")])

@@ -98,7 +98,9 @@ template <class T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct Timing { hipEvent_t a, b, p; bool adapter; }; // p .. a: the adapter pre-pass (when there is one), a .. b: the trim kernel
+// p .. a: the adapter pre-pass (when there is one), a .. b: the trim kernel, k0 .. k1: the submission's k-mer kernels (kmer_count, or
+// kmer_extract in the owner-partitioned mode)
+struct Timing { hipEvent_t a, b, p, k0, k1; bool adapter, kmer; };
 
 } // namespace
 
@@ -157,8 +159,9 @@ struct faqcs_ctx {
     // kernel timing
     std::vector<Timing> timings;
     size_t timing_used = 0;
-    double kernel_ms = 0.0, adapter_ms = 0.0;
+    double kernel_ms = 0.0, adapter_ms = 0.0, kmer_ms = 0.0, kmer_insert_ms = 0.0;
     uint64_t kernel_launches = 0;
+    hipEvent_t ins_a = nullptr, ins_b = nullptr;
     const char *trim_kernel = "";
 };
 
@@ -414,7 +417,9 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->compute) (void)hipStreamSynchronize(c->compute);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
-    for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.p); }
+    for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.p); (void)hipEventDestroy(t.k0); (void)hipEventDestroy(t.k1); }
+    if (c->ins_a) (void)hipEventDestroy(c->ins_a);
+    if (c->ins_b) (void)hipEventDestroy(c->ins_b);
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_partials, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
                     c->kt.slots, c->kt.stats, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
     for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -452,10 +457,12 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
     Timing *tm = nullptr;
     if (n) {
         if (c->timing_used == c->timings.size()) {
-            Timing t; HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b)); HIPCHK(hipEventCreate(&t.p)); t.adapter = false; c->timings.push_back(t);
+            Timing t; HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b)); HIPCHK(hipEventCreate(&t.p)); HIPCHK(hipEventCreate(&t.k0)); HIPCHK(hipEventCreate(&t.k1));
+            t.adapter = false; t.kmer = false; c->timings.push_back(t);
         }
         tm = &c->timings[c->timing_used++];
         tm->adapter = p.n_adapters != 0;
+        tm->kmer = false;
     }
     if (n && p.n_adapters) {
         HIPCHK(hipEventRecord(tm->p, c->compute));
@@ -515,12 +522,14 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         KmerOutbox O{c->ob_items.p, c->d_ob, c->d_ob + c->part_world, c->d_ob + 2 * c->part_world, c->part_world,
                      c->ob_wave_count.p, c->ob_wave_offset.p, total_waves};
         HIPCHK(hipMemsetAsync(c->d_ob, 0, 3 * c->part_world * 8, c->compute));
+        if (tm) { HIPCHK(hipEventRecord(tm->k0, c->compute)); tm->kmer = true; }
         for (int fill = 0; fill < 2; ++fill) {
             for (const RunSpan &r : runs)
                 HIPCHK(faqcs_launch_kmer_extract(c->dp, p.kmer, O, fill != 0, d_seq, d_qual, d_off, seg[r.s], seg[r.e], d_res,
                                                  c->seg_epoch[r.s], r.wave_base, c->n_cu, c->compute));
             if (!fill) HIPCHK(faqcs_launch_kmer_outbox_offsets(O, c->compute));
         }
+        if (tm) HIPCHK(hipEventRecord(tm->k1, c->compute));
         c->seg_epoch.clear();
         return 0;
     }
@@ -528,6 +537,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
     // The k-mers of consecutive segments go to the device in ONE launch per run of segments that ends at a sampling point
     // (or at the end of the batch / of the curve): only there does the order of insertion become observable.
     uint32_t run_begin = seg[0];
+    if (tm && c->kmer_active) { HIPCHK(hipEventRecord(tm->k0, c->compute)); tm->kmer = true; }
     auto flush_run = [&](uint32_t run_end) -> int {
         if (run_end > run_begin) HIPCHK(faqcs_launch_kmer(c->dp, p.kmer, c->kt, d_seq, d_qual, d_off, run_begin, run_end, d_res, c->n_cu, c->compute));
         run_begin = run_end;
@@ -560,6 +570,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
             if (num_rarefaction >= p.num_subsample) c->kmer_active = 0; // trim.cpp:180-184
         }
     }
+    if (tm && tm->kmer) HIPCHK(hipEventRecord(tm->k1, c->compute));
     return 0;
 }
 
@@ -693,6 +704,7 @@ extern "C" int faqcs_sync(faqcs_ctx *c)
     for (size_t i = 0; i < c->timing_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->timings[i].a, c->timings[i].b) == hipSuccess) { c->kernel_ms += ms; ++c->kernel_launches; }
+        if (c->timings[i].kmer && hipEventElapsedTime(&ms, c->timings[i].k0, c->timings[i].k1) == hipSuccess) c->kmer_ms += ms;
         if (c->timings[i].adapter && hipEventElapsedTime(&ms, c->timings[i].p, c->timings[i].a) == hipSuccess) c->adapter_ms += ms;
     }
     c->timing_used = 0;
@@ -888,8 +900,12 @@ extern "C" int faqcs_kmer_insert_device(faqcs_ctx *c, const void *d_items, uint6
     if (!c || (!d_items && n_items)) return fail(FAQCS_E_INVAL, "null argument");
     if (!c->partitioned) return fail(FAQCS_E_INVAL, "faqcs_kmer_insert_device: call faqcs_kmer_partition first");
     HIPCHK(hipSetDevice(c->device));
+    if (!c->ins_a) { HIPCHK(hipEventCreate(&c->ins_a)); HIPCHK(hipEventCreate(&c->ins_b)); }
+    HIPCHK(hipEventRecord(c->ins_a, c->compute));
     HIPCHK(faqcs_launch_kmer_insert_items(c->kt, d_items, n_items, c->d_tot_by_epoch, c->n_epochs, c->n_cu, c->compute));
+    HIPCHK(hipEventRecord(c->ins_b, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute)); // the caller may recycle d_items as soon as this returns
+    { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ins_a, c->ins_b) == hipSuccess) c->kmer_insert_ms += ms; }
     return 0;
 }
 
@@ -962,7 +978,7 @@ extern "C" int faqcs_kernel_time_ms(faqcs_ctx *c, double *avg_ms, uint64_t *n_la
     if (int rc = faqcs_sync(c)) return rc;
     *n_launches = c->kernel_launches;
     *avg_ms = c->kernel_launches ? c->kernel_ms / (double)c->kernel_launches : 0.0;
-    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kernel_launches = 0;
+    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kmer_ms = 0.0; c->kmer_insert_ms = 0.0; c->kernel_launches = 0;
     return 0;
 }
 
@@ -976,6 +992,8 @@ extern "C" int faqcs_kernel_report(faqcs_ctx *c, faqcs_kernel_times *out)
     out->trim_ms = c->kernel_launches ? c->kernel_ms / (double)c->kernel_launches : 0.0;
     out->adapter_ms = c->kernel_launches ? c->adapter_ms / (double)c->kernel_launches : 0.0;
     out->trim_kernel = c->trim_kernel;
-    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kernel_launches = 0;
+    out->kmer_ms = c->kernel_launches ? c->kmer_ms / (double)c->kernel_launches : 0.0;
+    out->kmer_insert_ms = c->kernel_launches ? c->kmer_insert_ms / (double)c->kernel_launches : 0.0;
+    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kmer_ms = 0.0; c->kmer_insert_ms = 0.0; c->kernel_launches = 0;
     return 0;
 }

@@ -277,7 +277,11 @@ int  faqcs_debug_words(faqcs_ctx *ctx, uint64_t *out, uint32_t n);
 int  faqcs_kernel_time_ms(faqcs_ctx *ctx, double *avg_ms, uint64_t *n_launches);
 /* the same per kernel: the trim kernel (and which variant ran: "trim_lds", "trim_tpr", "trim_filter_accumulate") and the
  * adapter pre-pass adapter_overlap (0 without adapters); both measured with HIP events on the compute stream */
-typedef struct faqcs_kernel_times { double trim_ms, adapter_ms; uint64_t n_launches; const char *trim_kernel; } faqcs_kernel_times;
+typedef struct faqcs_kernel_times {
+    double trim_ms, adapter_ms; uint64_t n_launches; const char *trim_kernel;
+    double kmer_ms;        /* k-mer kernels of a submission (kmer_count; kmer_extract in the owner-partitioned mode), per submission */
+    double kmer_insert_ms; /* faqcs_kmer_insert_device (owner-partitioned mode), per submission */
+} faqcs_kernel_times;
 int  faqcs_kernel_report(faqcs_ctx *ctx, faqcs_kernel_times *out);
 
 #ifdef __cplusplus

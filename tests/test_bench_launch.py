@@ -43,3 +43,18 @@ def test_library_binds_to_torch_hip_runtime():
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert r.stdout.decode().startswith("1 "), r.stdout.decode()
+
+
+def test_a_rank_that_dies_before_the_rendezvous_fails_the_job_fast():
+    """bench.py --gpus 2 starts the ranks itself: rank 1 exits before init_process_group, rank 0 is left waiting in the rendezvous.
+    The launcher polls every rank, terminates the survivors and exits with the dead rank's code within seconds (it used to block
+    on rank 0 until the store timeout), keeping every rank's stderr under gpurun_out/."""
+    import time
+
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--pairs", "1e5", "--steps", "1", "--warmup", "0"],
+             {"FAQCS_BENCH_SHARE_GPU": "1", "FAQCS_BENCH_DIE_RANK": "1", "FAQCS_BENCH_RDZV_TIMEOUT": "600"})
+    dt = time.time() - t0
+    assert r.returncode == 7, (r.returncode, r.stderr.decode()[-1500:])
+    assert dt < 30, dt
+    assert os.path.exists(os.path.join(ROOT, "gpurun_out", "rank1.err"))
