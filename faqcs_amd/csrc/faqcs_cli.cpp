@@ -319,6 +319,7 @@ struct TextBlock {
     struct RecBuf *buf = nullptr; // destination, assigned by the I/O thread IN FILE ORDER (so the oldest block always owns one)
     bool eof = false;        // last block of the file
     bool unterminated = false; // the file ended without a final newline
+    bool io_error = false;     // the compressed stream failed behind this block's text (not an end of file)
 };
 
 // One input file: an I/O thread reads (gz or plain) and cuts the byte stream into blocks of 4 * BUF_READS lines by
@@ -339,6 +340,11 @@ struct BgzfReader {
     uint64_t issued = 0, taken = 0; // task numbers handed to the workers / consumed by next()
     uint64_t claimed = 0;
     bool closing = false, failed = false;
+    // what follows the last whole BGZF member (ordinary gzip members appended to a bgzip file, or garbage): inflated by the
+    // consumer itself through zlib's gzip decoder, as gzread would go on reading; a failure there fails the input
+    bool tail = false, tail_init = false, tail_done = false, tail_mid = false;
+    z_stream tz;
+    std::vector<char> tail_out;
     std::mutex m; std::condition_variable cv_work, cv_done;
     std::vector<std::thread> workers;
     static constexpr size_t TASK_BLOCKS = 64;
@@ -392,7 +398,7 @@ struct BgzfReader {
         size_t nb = 0;
         while (nb < TASK_BLOCKS && scan < size) {
             const size_t ms = member_size(base + scan, size - scan);
-            if (ms < 26 || scan + ms > size) { if (nb == 0) { failed = true; return false; } break; } // not BGZF from here on: stop (gzread would fail too)
+            if (ms < 26 || scan + ms > size) { if (nb == 0) { tail = true; return false; } break; } // not BGZF from here on: the rest goes through zlib (next_tail)
             scan += ms; ++nb;
         }
         t.end = scan;
@@ -428,6 +434,8 @@ struct BgzfReader {
                     z.next_out = (Bytef *)t->out.data() + w; z.avail_out = (uInt)isize;
                     const int rc = inflate(&z, Z_FINISH);
                     if (rc != Z_STREAM_END || z.avail_out != 0) { bad = true; break; }
+                    const uint32_t crc = (uint32_t)p[ms - 8] | ((uint32_t)p[ms - 7] << 8) | ((uint32_t)p[ms - 6] << 16) | ((uint32_t)p[ms - 5] << 24);
+                    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)t->out.data() + w, (uInt)isize) != crc) { bad = true; break; } // (gzread checks it too)
                     w += isize;
                 }
                 o += ms;
@@ -446,7 +454,7 @@ struct BgzfReader {
         std::unique_lock<std::mutex> l(m);
         for (;;) {
             while (issued - taken < ring.size() - 1 && issue_locked()) cv_work.notify_one();
-            if (taken == issued) return 0;
+            if (taken == issued) { if (tail && !failed) { l.unlock(); return next_tail(data); } return 0; }
             Task &t = ring[taken % ring.size()];
             cv_done.wait(l, [&] { return t.done; });
             ++taken;
@@ -456,8 +464,46 @@ struct BgzfReader {
             return t.n_out;
         }
     }
+    // the bytes behind the last BGZF member, through zlib (gzip members, concatenated or not); 0 = end of data or failure (`failed`)
+    size_t next_tail(const char *&data)
+    {
+        if (tail_done) return 0;
+        if (!tail_init) {
+            memset(&tz, 0, sizeof tz);
+            if (inflateInit2(&tz, 15 + 16) != Z_OK) { failed = true; tail_done = true; return 0; }
+            tz.next_in = const_cast<Bytef *>(base + scan); tz.avail_in = 0;
+            tail_out.resize(8u << 20);
+            tail_init = true;
+        }
+        for (;;) {
+            if (tz.avail_in == 0) {
+                const size_t left = size - scan;
+                if (left == 0) { tail_done = true; inflateEnd(&tz); if (tail_mid) failed = true; return 0; } // (the file ends inside a member)
+                const size_t take = left < (64u << 20) ? left : (64u << 20);
+                tz.next_in = const_cast<Bytef *>(base + scan); tz.avail_in = (uInt)take;
+                scan += take;
+            }
+            tz.next_out = (Bytef *)tail_out.data(); tz.avail_out = (uInt)tail_out.size();
+            const int rc = inflate(&tz, Z_NO_FLUSH);
+            const size_t got = tail_out.size() - tz.avail_out;
+            tail_mid = rc != Z_STREAM_END;
+            if (rc == Z_STREAM_END) { // one member done: another may follow (gzread reads concatenated members)
+                const Bytef *ni = tz.next_in; const uInt ai = tz.avail_in;
+                if (ai == 0 && scan >= size) { tail_done = true; inflateEnd(&tz); }
+                else { inflateReset(&tz); tz.next_in = const_cast<Bytef *>(ni); tz.avail_in = ai; }
+            } else if (rc != Z_OK && !(rc == Z_BUF_ERROR && got == 0 && tz.avail_in == 0 && scan < size)) {
+                // a data error, or the stream ends in the middle of a member (Z_BUF_ERROR with nothing left to feed)
+                failed = true; tail_done = true; inflateEnd(&tz);
+                if (got) { data = tail_out.data(); return got; }
+                return 0;
+            }
+            if (got) { data = tail_out.data(); return got; }
+            if (tail_done) return 0;
+        }
+    }
     void close()
     {
+        if (tail_init && !tail_done) { inflateEnd(&tz); tail_done = true; }
         { std::lock_guard<std::mutex> l(m); closing = true; claimed = issued; }
         cv_work.notify_all();
         for (auto &w : workers) if (w.joinable()) w.join();
@@ -507,14 +553,21 @@ struct Source {
         std::vector<char> io(16 << 20);
         uint64_t seq_no = 0;
         TextBlock *cur = block_free.pop();
-        cur->text.clear(); cur->n_lines = 0; cur->eof = false; cur->unterminated = false; cur->seq_no = seq_no;
+        cur->text.clear(); cur->n_lines = 0; cur->eof = false; cur->unterminated = false; cur->io_error = false; cur->seq_no = seq_no;
         cur->buf = free_q.pop();
         const uint32_t want = 4 * BUF_READS;
         for (;;) {
             const char *chunk = io.data();
             size_t got;
-            if (use_bgzf) got = bgzf.next(chunk);
-            else { const int g = gzread(gz, io.data(), (unsigned)io.size()); got = g > 0 ? (size_t)g : 0; }
+            if (use_bgzf) { got = bgzf.next(chunk); if (got == 0 && bgzf.failed) cur->io_error = true; }
+            else {
+                const int g = gzread(gz, io.data(), (unsigned)io.size());
+                got = g > 0 ? (size_t)g : 0;
+                // a read that fails without being at the end of the file: the reference's gzgets() returns NULL with !gzeof() there
+                // and next_read() throws (fastq.cpp:34-41)
+                if (g < 0 || (g == 0 && !gzeof(gz))) cur->io_error = true;
+                else if (g == 0) { int en = 0; (void)gzerror(gz, &en); if (en != Z_OK && en != Z_STREAM_END) cur->io_error = true; }
+            }
             if (got == 0) break;
             const char *p = chunk, *end = p + got;
             while (p < end) {
@@ -532,10 +585,13 @@ struct Source {
                 if (lines == want) {
                     block_full.push(cur);
                     cur = block_free.pop();
-                    cur->text.clear(); cur->n_lines = 0; cur->eof = false; cur->unterminated = false; cur->seq_no = ++seq_no;
+                    cur->text.clear(); cur->n_lines = 0; cur->eof = false; cur->unterminated = false; cur->io_error = false; cur->seq_no = ++seq_no;
                     cur->buf = free_q.pop();
                 }
             }
+        }
+        if (cur->io_error) { // gzgets() hands back nothing of the line it was reading when the stream failed (it returns NULL): drop the partial line
+            while (!cur->text.empty() && cur->text.back() != '\n') cur->text.pop_back();
         }
         if (!cur->text.empty() && cur->text.back() != '\n') { cur->unterminated = true; ++cur->n_lines; }
         cur->eof = true;
@@ -594,6 +650,9 @@ struct Source {
             if (!t) return;
             RecBuf *b = t->buf;
             parse_block(t, b);
+            // the stream failed behind this text: where the reference's next gzgets() returns NULL without being at the end of the
+            // file (fastq.cpp:34-41); a record cut short by the failure has set its own message already
+            if (t->io_error && b->error.empty()) b->error = "fastq.cpp:next_read: Unable to read header";
             const uint64_t sn = t->seq_no;
             const bool last = t->eof;
             block_free.push(t);

@@ -69,3 +69,48 @@ def test_report_script_names_the_files_of_the_run(tmp_path):
     assert 'stats_file <- "%s/S1.stats.txt"' % out.replace('"', '\\"') in s
     assert "qc_only <- TRUE" in s and s.rstrip().endswith('quit(save = "no")')
     assert s.count("page({") == 12 and s.count("{") == s.count("}") and s.count("(") == s.count(")")
+
+
+def test_bgzf_followed_by_ordinary_gzip_members_is_read_to_the_end(tmp_path):
+    """`cat a.bgz b.gz`: gzread (the reference's reader) decodes every member whatever its framing; the BGZF reader hands what
+    follows its last whole member to zlib instead of ending the input (100 001 of 150 002 bytes, exit code 0 downstream)."""
+    import gzip
+
+    rng = np.random.Generator(np.random.PCG64(17))
+    a = bytes(rng.integers(33, 75, 100_001, dtype=np.uint8))
+    b = bytes(rng.integers(33, 75, 50_001, dtype=np.uint8))
+    c = bytes(rng.integers(33, 75, 777, dtype=np.uint8))
+    p = str(tmp_path / "mixed.gz")
+    write_bgzf(p, a, 40000, eof_marker=False)
+    with open(p, "ab") as f:
+        f.write(gzip.compress(b))
+        f.write(gzip.compress(c))  # (two ordinary members)
+    assert gzip.open(p).read() == a + b + c
+    r = subprocess.run([CLI, "--bgzf_cat", p], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == a + b + c
+
+
+def test_bgzf_reader_reports_what_gzread_reports(tmp_path):
+    """A wrong CRC32 trailer, a truncated last member, garbage behind the last member: gzread fails on each (the reference then
+    throws `Unable to read header`, fastq.cpp:34-41); --bgzf_cat returns 3, never 0."""
+    data = bytes(np.random.Generator(np.random.PCG64(5)).integers(33, 75, 300_000, dtype=np.uint8))
+    good = str(tmp_path / "good.gz")
+    write_bgzf(good, data, 50000)
+    raw = open(good, "rb").read()
+    # the first member's CRC32 (8 bytes before the second member's header)
+    first = 12 + 6 + struct.unpack_from("<H", raw, 16)[0] + 1 - (12 + 6)  # BSIZE + 1 = the member's size
+    bad_crc = bytearray(raw)
+    bad_crc[first - 8] ^= 0x01
+    cases = {"crc": bytes(bad_crc), "truncated": raw[:len(raw) - 28 - 40], "garbage": raw + b"this is not gzip at all" * 3}
+    for name, blob in cases.items():
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(blob)
+        r = subprocess.run([CLI, "--bgzf_cat", p], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 3, (name, r.returncode)
+        assert data.startswith(r.stdout) or name == "garbage", name
+        if name == "garbage":
+            assert r.stdout == data  # (everything in front of the garbage is delivered, then the failure)
+        import gzip
+        with pytest.raises(Exception):
+            gzip.open(p).read()

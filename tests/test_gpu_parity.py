@@ -941,6 +941,7 @@ def test_native_cli_reads_bgzf_in_parallel(tmp_path):
     """bgzip-compressed inputs are inflated member by member by a thread pool (BgzfReader in faqcs_cli.cpp): same output bytes
     as from the plain files, and as from the same .gz read through gzread (FAQCS_MI_NO_BGZF=1)."""
     import hashlib
+    import struct
     import subprocess
 
     import make_fixtures
@@ -980,4 +981,39 @@ def test_native_cli_reads_bgzf_in_parallel(tmp_path):
     with open(cut, "wb") as f:
         f.write(data[: len(data) // 2])
     r = subprocess.run([_CLI_BIN, "-u", cut, "-d", str(tmp_path / "cut_out"), "--ascii", "33", "--trim_only"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    assert r.returncode in (0, 1)
+    assert r.returncode == 1 and b"Caught the error fastq.cpp:next_read:" in r.stderr, r.stderr.decode()[-400:]  # (never a silent short run)
+    # ... and so do the same bytes read through gzread, and the reference itself when it is here
+    r2 = subprocess.run([_CLI_BIN, "-u", cut, "-d", str(tmp_path / "cut_out2"), "--ascii", "33", "--trim_only"], env=dict(os.environ, FAQCS_MI_NO_BGZF="1"),
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r2.returncode == 1 and b"Caught the error fastq.cpp:next_read:" in r2.stderr
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "FaQCs_ref")
+    if os.path.exists(ref):
+        r3 = subprocess.run([ref, "-u", cut, "-d", str(tmp_path / "cut_ref"), "--ascii", "33", "--trim_only"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        msg = lambda e: e.decode().split("next_read:")[-1].strip()  # noqa: E731  (the reference's text carries its source path)
+        assert r3.returncode == 1 and b"fastq.cpp:next_read:" in r3.stderr and msg(r3.stderr) == msg(r.stderr) == msg(r2.stderr)
+    # a wrong CRC32 in a member (the deflate stream itself intact): gzread checks the trailer, so does the BGZF reader
+    raw = bytearray(data)
+    bsize = struct.unpack_from("<H", raw, 16)[0] + 1
+    raw[bsize - 8] ^= 0x01
+    crc = str(tmp_path / "crc.fastq.gz")
+    with open(crc, "wb") as f:
+        f.write(raw)
+    r = subprocess.run([_CLI_BIN, "-u", crc, "-d", str(tmp_path / "crc_out"), "--ascii", "33", "--trim_only"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 1 and b"Caught the error fastq.cpp:next_read:" in r.stderr
+    # bgzip members followed by ordinary gzip members (cat a.bgz b.gz): every read arrives
+    import gzip
+
+    half = len(texts[0]) // 2
+    mixed = str(tmp_path / "mixed.fastq.gz")
+    _write_bgzf(mixed, b"".join(texts[0][:half]))
+    blob = open(mixed, "rb").read()[:-28]  # (without the end-of-file marker: the gzip members follow directly)
+    with open(mixed, "wb") as f:
+        f.write(blob)
+        f.write(gzip.compress(b"".join(texts[0][half:half + 1000])))
+        f.write(gzip.compress(b"".join(texts[0][half + 1000:])))
+    def run_u(tag, path):
+        out = tmp_path / tag
+        r_ = subprocess.run([_CLI_BIN, "-u", path, "-d", str(out), "--ascii", "33", "--trim_only"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r_.returncode == 0, r_.stderr.decode()[-800:]
+        return {f: hashlib.md5(open(out / f, "rb").read()).hexdigest() for f in sorted(os.listdir(out))}
+    assert run_u("mixed_out", mixed) == run_u("plain_u_out", plain[0])
