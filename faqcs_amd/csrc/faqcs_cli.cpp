@@ -1125,6 +1125,15 @@ void process_mapped(Run &r, bool paired)
     std::vector<std::thread> parsers;
     for (unsigned t = 0; t < n_parse; ++t) parsers.emplace_back(parser);
     auto give_back = [&](int s, RecBuf *b) { { std::lock_guard<std::mutex> l(am); free_l[s].push_back(b); } acv.notify_all(); };
+    // first error wins; `failed` is set and the waiters are woken while BOTH their mutexes are held, so a waiter that has just
+    // evaluated its predicate cannot miss the wake-up
+    auto fail_run = [&](const std::string &what) {
+        std::lock_guard<std::mutex> l1(rm);
+        std::lock_guard<std::mutex> l2(am);
+        if (werr.empty()) werr = what;
+        failed = true;
+        acv.notify_all(); rcv.notify_all();
+    };
 
     // ---- formatter pool --------------------------------------------------------------------------------------
     struct PairRef { std::atomic<int> left{0}; RecBuf *b[2] = {nullptr, nullptr}; };
@@ -1146,7 +1155,7 @@ void process_mapped(Run &r, bool paired)
                 for (uint32_t i = 0; i < t.mine->n; ++i)
                     if ((t.b1->res[i].flags & FAQCS_F_VALID) && (!t.b2 || (t.b2->res[i].flags & FAQCS_F_VALID))) o = render_read(r.prm, t.mine, i, o);
                 w_r += now_s() - tf1;
-                if ((size_t)(o - t.dst) != t.size) { werr = "faqcs_mi: internal error, a rendered buffer has the wrong size"; failed = true; acv.notify_all(); rcv.notify_all(); }
+                if ((size_t)(o - t.dst) != t.size) fail_run("faqcs_mi: internal error, a rendered buffer has the wrong size");
             }
             release_pair((size_t)t.pair_slot);
             --tasks_out;
@@ -1205,9 +1214,7 @@ void process_mapped(Run &r, bool paired)
                 if (w.last) break;
             }
         } catch (std::exception &e) {
-            werr = e.what();
-            failed = true;
-            acv.notify_all(); rcv.notify_all();
+            fail_run(e.what());
             while (!cur_last) { GateWork w = wq.pop(); if (w.stop) break; cur_last = w.last; for (int c = 0; c < nsrc; ++c) if (slots[w.k].b[c]) give_back(c, slots[w.k].b[c]); }
         }
     });
@@ -1966,6 +1973,7 @@ int main(int argc, char **argv)
 
 static int run_command(int argc, char **argv)
 {
+    signal(SIGPIPE, SIG_IGN); // (a report helper that has died must not kill the run after its outputs are written: write() returns EPIPE)
     try {
         Opt opt = parse_args(argc, argv);
         for (auto &m : opt.messages) fprintf(stderr, "%s\n", m.c_str());

@@ -505,7 +505,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     uint32_t tot_pe = 0, tot_po = 0, tot_ce = 0, tot_co = 0; // this lane's read: pre A | C << 12 | N << 24, pre T | G << 12, post ...
     uint32_t seen7 = 0;                                       // OR of every counted base byte of the chunk (bit 7: abnormal input)
     bool pairhit = false;                                     // this lane's read: two adjacent upper-case N inside the kept window
-    uint32_t nub[NWORD];                                      // (EXT, -n >= 3) this lane's read: upper-case N inside the kept window, one bit per position
     auto base_step = [&](const int t, const uint32_t i0, const uint32_t i1, auto mode_t) {
         constexpr int MODE = decltype(mode_t)::value;
         const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
@@ -557,9 +556,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // ---- upper-case N inside the kept window (count_poly_n, trim.cpp:578-597): looked at only when the read has enough N
             // (any case) in its window to matter, or when it is judged without being counted (chk) ----
             const uint32_t cN = ce >> 24;
-            // -n 2 (the default): a pair test; -n k, k != 0: the read's N positions as a bit mask (a run of k needs k N); -n 0: nothing to look at
-            const uint32_t need_n = (EXT && P.max_poly_n != 2u) ? P.max_poly_n : 2u;
-            if ((!EXT || P.max_poly_n != 0u) && __any(cN >= need_n || chk)) {
+            // -n 2 (the default): two adjacent N, tested here; any other -n: judged after the loop, from the staged bases
+            if ((!EXT || P.max_poly_n == 2u) && __any(cN >= 2u || chk)) {
                 uint32_t nb[D]; // bit 7 of a byte: upper-case 'N' inside the kept window
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
@@ -568,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     const uint32_t sx = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
                     nb[k] = ~(sx | x) & 0x80808080u;
                 }
-                if (!EXT || P.max_poly_n == 2u) { // two adjacent N: positions (j, j + 1), j one of the lane's C positions
+                { // two adjacent N: positions (j, j + 1), j one of the lane's C positions
                     uint32_t hit = 0;
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
@@ -579,26 +577,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     }
                     const bool rowhit = RowOps<8>::all_or(hit) != 0u;
                     pairhit = turn ? rowhit : pairhit;
-                } else { // -n 1, -n >= 3: the read's N positions as a bit mask, for the run test after the loop
-                    uint32_t m = 0; // the lane's C positions
-#pragma unroll
-                    for (int k = 0; k < D; ++k) m |= ((((nb[k] >> 7) * 0x00204081u) >> 21) & 0xfu) << (4 * k);
-                    m &= (1u << C) - 1u;
-                    const uint32_t p0 = (uint32_t)pbase, wd0 = p0 >> 5, s0 = p0 & 31u;
-                    const uint32_t mlo = m << s0, mhi = s0 ? m >> (32u - s0) : 0u;
-#pragma unroll
-                    for (int wd = 0; wd < NWORD; ++wd) {
-                        const uint32_t c = ((uint32_t)wd == wd0 ? mlo : 0u) | ((uint32_t)wd == wd0 + 1u ? mhi : 0u);
-                        const uint32_t all = RowOps<8>::all_or(c);
-                        nub[wd] = turn ? all : nub[wd];
-                    }
                 }
             } else if (MODE == 0) {
                 pairhit = turn ? false : pairhit;
-                if (EXT && P.max_poly_n != 2u) {
-#pragma unroll
-                    for (int wd = 0; wd < NWORD; ++wd) nub[wd] = turn ? 0u : nub[wd];
-                }
             }
         }
     };
@@ -1072,7 +1053,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 // ---- poly-N (trim.cpp:363-371, :578-597): -n 2 = two adjacent upper-case N inside the kept window ----
                 bool polyn;
                 if (EXT && P.max_poly_n != 2u) { // -n 0: every read trips; -n k: a run of k upper-case N inside the kept window
-                    uint32_t run[NWORD], hit = 0;
+                    uint32_t run[NWORD], hit = 0, nub[NWORD]; // nub: upper-case 'N' of the read, one bit per position
+#pragma unroll
+                    for (int wd = 0; wd < NWORD; ++wd) nub[wd] = 0;
+                    // a run of k needs k N (any case) inside the window: only such reads (and the ones judged without having been
+                    // counted) are scanned, one read per lane, from the staged bases
+                    const bool scan = P.max_poly_n != 0u && ret && (cN >= P.max_poly_n || !retc);
+                    if (__any(scan)) {
+                        const int kmax = uni((int)wave_max_u32(scan ? (uint32_t)((len + 3) >> 2) : 0u));
+#pragma unroll
+                        for (int wd = 0; wd < NWORD; ++wd) {
+                            if (8 * wd < kmax) { // (wave-uniform)
+                                uint32_t nw = 0;
+#pragma unroll 2
+                                for (int k = 8 * wd; k < 8 * wd + 8 && k < ND; ++k) {
+                                    uint32_t w = lds_ld_any(slot_b + rows + 4u * (uint32_t)k) & low_bytes_(med3i(len - 4 * k, 0, 4));
+                                    w ^= 0x4e4e4e4eu;
+                                    const uint32_t nz = ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w; // bit 7 of a byte: the byte is not 'N'
+                                    nw |= ((((~nz & 0x80808080u) >> 7) * 0x00204081u >> 21) & 0xfu) << (4 * (k & 7));
+                                }
+                                nub[wd] = scan ? nw : 0u;
+                            }
+                        }
+                    }
                     if (P.max_poly_n != 0u) {
 #pragma unroll
                         for (int w = 0; w < NWORD; ++w) run[w] = nub[w] & bit_range_(med3i(a - 32 * w, 0, 32), med3i(a + n - 32 * w, 0, 32));

@@ -92,6 +92,9 @@ int main(int argc, char **argv)
     p.split_size = 1000000;
     p.num_subsample = 10;
     p.max_read_length = L <= 256 ? 256 : FAQCS_MAX_READ_LENGTH;
+    if (getenv("TRIM_AB_POLYN")) p.max_num_poly_N = (uint32_t)atoi(getenv("TRIM_AB_POLYN")); // (!= 2: the EXT variants of trim_lds)
+    if (getenv("TRIM_AB_AVGQ")) p.average_quality = (float)atof(getenv("TRIM_AB_AVGQ"));
+    if (getenv("TRIM_AB_TRIM5")) p.trim_5 = (uint32_t)atoi(getenv("TRIM_AB_TRIM5"));             // (the WINDOWED variants)
     std::vector<uint32_t> seg;
     for (uint32_t s = 0; s < n; s += 32768) seg.push_back(s);
     seg.push_back(n);

@@ -114,3 +114,46 @@ def test_bgzf_reader_reports_what_gzread_reports(tmp_path):
         import gzip
         with pytest.raises(Exception):
             gzip.open(p).read()
+
+
+def test_report_script_is_structurally_sound():
+    """No R in the build image: the script the report step pipes into `R --vanilla --silent --slave` has never been rendered (README,
+    INTEGRATION.md say so).  What CAN be checked without R: every bracket / quote is balanced outside comments and strings, and every
+    table the script reads is one that write_tables() writes (faqcs_cli.cpp:table_files), under the name the script builds."""
+    import re
+
+    r = subprocess.run([CLI, "--report_script", "-1", "a.fastq", "-2", "b.fastq", "-d", "/tmp/out dir", "--prefix", "S1", "--kmer_rarefaction"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 0, r.stderr.decode()
+    script = r.stdout.decode()
+    # a tiny R lexer: strings ("...", '...' with backslash escapes), comments (# to the end of the line), brackets
+    stack, i, n = [], 0, len(script)
+    pairs = {")": "(", "]": "[", "}": "{"}
+    while i < n:
+        c = script[i]
+        if c == "#":
+            while i < n and script[i] != "\n":
+                i += 1
+            continue
+        if c in "\"'":
+            q, i = c, i + 1
+            while i < n and script[i] != q:
+                i += 2 if script[i] == "\\" else 1
+            assert i < n, "unterminated string"
+        elif c in "([{":
+            stack.append((c, script.count("\n", 0, i) + 1))
+        elif c in ")]}":
+            assert stack and stack[-1][0] == pairs[c], "unbalanced %r on line %d" % (c, script.count("\n", 0, i) + 1)
+            stack.pop()
+        i += 1
+    assert not stack, "unclosed %r opened on line %d" % stack[-1]
+    # the tables: names handed to pre() / post() / both() vs the files write_tables() produces
+    used = set(re.findall(r'\b(?:pre|post|both)\("([^"]+)"\)', script))
+    written = {"quality.matrix", "base.matrix", "for_qual_histogram.txt", "base_content.txt", "length_count.txt", "kmerH.txt", "Kmercount.txt"}
+    assert used and used <= written, used - written
+    assert {"quality.matrix", "base.matrix", "length_count.txt", "base_content.txt", "for_qual_histogram.txt"} <= used
+    assert 'paste0("qa.", "S1", ".", name)' in script and 'file.path("/tmp/out dir"' in script
+    # every function the script defines is used, every plotting page is closed
+    for fn in re.findall(r"^(\w+) <- function", script, flags=re.M):
+        assert len(re.findall(r"\b%s\b" % re.escape(fn), script)) >= 2, fn  # (its definition and at least one use, called or passed on)
+    assert "dev.off()" in script
