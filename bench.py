@@ -331,8 +331,12 @@ def main():
         seg[-1] = m
         if len(seg) > 1 and seg[-2] >= m:
             seg = seg[:-1]
-        bt = capi.Batch(seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, len(seg) - 1, seg.ctypes.data, L)
-        batches.append((seq, qual, off, res, seg, bt, m))
+        # the optional per-read flags of the batch layout (faqcs_batch::terminal_n: first / last base is 'N'), as a parser would set
+        # them while laying the reads down; computed on the device here, with the rest of the synthetic input
+        tn = torch.empty(m, dtype=torch.uint8, device=dev)
+        _check(lib, lib.faqcs_terminal_n_flags(local, seq.data_ptr(), off.data_ptr(), m, tn.data_ptr()))
+        bt = capi.Batch(seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, len(seg) - 1, seg.ctypes.data, L, tn.data_ptr())
+        batches.append((seq, qual, off, res, seg, bt, m, tn))
         done += m
     torch.cuda.synchronize()
 
@@ -345,7 +349,7 @@ def main():
     if a.config == "kmer" and world > 1:
         sizes = []
         for _r in range(world):
-            for (_s, _q, _o, _res, seg, _bt, _m) in batches:  # (every rank holds batches of the same shape)
+            for (_s, _q, _o, _res, seg, _bt, _m, _tn) in batches:  # (every rank holds batches of the same shape)
                 sizes.extend(int(seg[i + 1] - seg[i]) for i in range(len(seg) - 1))
         ep, kmer_points_seq = parallel.rarefaction_schedule(sizes, opt.split_size, opt.num_subsample)
         per_rank = len(sizes) // world
@@ -359,7 +363,7 @@ def main():
             kmer_seen[0], kmer_seen[1] = eng.kmer_totals()
             eng.kmer_end_table()
         e0 = 0
-        for (_s, _q, _o, res, seg, bt, _m) in batches:
+        for (_s, _q, _o, res, seg, bt, _m, _tn) in batches:
             if kx is not None:
                 eng.kmer_set_epochs(kmer_epochs[e0:e0 + len(seg) - 1])
                 e0 += len(seg) - 1

@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NUM_STAT = 25
 NQ = 42
 NBASE = 5
@@ -50,6 +50,7 @@ class Batch(C.Structure):
     _fields_ = [
         ("seq", C.c_void_p), ("qual", C.c_void_p), ("offset", C.c_void_p), ("n_reads", C.c_uint32),
         ("n_segments", C.c_uint32), ("segment_start", C.c_void_p), ("max_read_len", C.c_uint32),
+        ("terminal_n", C.c_void_p),  # optional per-read flags (faqcs_submit_device only); None = the kernels look themselves
     ]
 
 
@@ -166,6 +167,7 @@ def load_library():
         "faqcs_kmer_epoch_counts": (i32, [vp, vp, vp, u32]),
         "faqcs_synth_fill": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, C.c_float]),
         "faqcs_synth_fill_genome": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, u64]),
+        "faqcs_terminal_n_flags": (i32, [i32, vp, vp, u32, vp]),
         "faqcs_kernel_time_ms": (i32, [vp, C.POINTER(C.c_double), C.POINTER(u64)]),
         "faqcs_debug_words": (i32, [vp, vp, u32]),
         "faqcs_kernel_report": (i32, [vp, C.POINTER(KernelTimes)]),

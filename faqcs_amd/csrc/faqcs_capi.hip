@@ -56,7 +56,8 @@ const char *faqcs_last_trim_kernel();
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
-                             uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st);
+                             uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st, const uint8_t *tn_flags);
+hipError_t faqcs_launch_terminal_n_flags(const uint8_t *seq, const uint32_t *off, uint32_t n_reads, uint8_t *flags, hipStream_t st);
 hipError_t faqcs_launch_composition(const unsigned long long *rec_pre, const unsigned long long *rec_post, uint32_t n, bool wide,
                                     const float *comp_norm, uint64_t *dst_pre, uint64_t *dst_post, int n_cu, hipStream_t st);
 hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
@@ -450,7 +451,7 @@ extern "C" int faqcs_set_quality(faqcs_ctx *c, int quality)
 // seq/qual/off are device pointers valid for indices off[0]..off[n]; host_off is the host copy of the offsets
 // (needed for the max read length and k-mer bookkeeping), d_res a device result array.
 static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, const uint32_t *d_off, uint32_t n,
-                   uint32_t max_len, const uint32_t *seg, uint32_t n_seg, faqcs_read_result *d_res)
+                   uint32_t max_len, const uint32_t *seg, uint32_t n_seg, faqcs_read_result *d_res, const uint8_t *d_tn = nullptr)
 {
     const faqcs_params &p = c->prm;
     uint32_t *d_sl = nullptr; uint16_t *d_hit = nullptr;
@@ -483,7 +484,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         if (need > rs.pre.cap) HIPCHK(hipStreamSynchronize(c->aux));
         HIPCHK(rs.pre.reserve(need)); HIPCHK(rs.post.reserve(need));
         HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, rs.pre.p, rs.post.p,
-                                 c->d_counters, c->d_err, c->n_cu, c->compute));
+                                 c->d_counters, c->d_err, c->n_cu, c->compute, d_tn));
         HIPCHK(hipEventRecord(t.b, c->compute));
         c->trim_kernel = faqcs_last_trim_kernel();
         if (!(c->dp.dbg & 1u)) {
@@ -677,7 +678,16 @@ extern "C" int faqcs_submit_device(faqcs_ctx *c, const faqcs_batch *b, faqcs_rea
     if (max_len > c->prm.max_read_length) return fail(FAQCS_E_INVAL, "faqcs_submit_device: max_read_len exceeds the context capacity");
     if (max_len > FAQCS_MAX_READ_LENGTH) return fail(FAQCS_E_INVAL, "faqcs_submit_device: reads longer than FAQCS_MAX_READ_LENGTH bases are not supported by the HIP kernels");
     if (!d_results) { HIPCHK(c->s_res.reserve((size_t)n + 1)); d_results = c->s_res.p; }
-    return enqueue(c, b->seq, b->qual, b->offset, n, max_len, b->segment_start, b->n_segments, d_results);
+    return enqueue(c, b->seq, b->qual, b->offset, n, max_len, b->segment_start, b->n_segments, d_results, b->terminal_n);
+}
+
+extern "C" int faqcs_terminal_n_flags(int device_id, const uint8_t *d_seq, const uint32_t *d_offset, uint32_t n_reads, uint8_t *d_flags)
+{
+    if (!d_seq || !d_offset || !d_flags) return fail(FAQCS_E_INVAL, "null argument");
+    if (device_id >= 0) HIPCHK(hipSetDevice(device_id));
+    HIPCHK(faqcs_launch_terminal_n_flags(d_seq, d_offset, n_reads, d_flags, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
 }
 
 static int resolve_points(faqcs_ctx *c)

@@ -21,15 +21,16 @@ static inline hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes, un
 
 namespace {
 
-template <int C, int LPR> struct RowCfg {
+template <int C, int LPR, int WQ_ = 0> struct RowCfg {
     static constexpr int D = (C + 3) / 4;          // dwords per lane per arena
     static constexpr int W = LPR * C;              // positions covered by a row == columns of the LDS matrices
+    static constexpr int WQ = WQ_ ? WQ_ : W;       // columns of the position x quality matrix (trim_lds: a multiple of 32, see its Q-B pass)
     // position x quality in LDS: one dword per cell (pre count lo16 / post count hi16) while that fits next to the
     // other tables (W <= 768); wider rows pack two cells per dword as 8-bit pre/post counters and the block flushes
     // them every 16 reads per wave (HQ8_EVERY x NW <= 255 increments per cell between flushes)
     static constexpr bool HQ8 = W > 768;           // (768 wide: 158 KB of the CU's 160 KB LDS, one block per CU)
     static constexpr int HQ8_EVERY = 16;
-    static constexpr int HQ = HQ8 ? FAQCS_NQ * W / 2 : FAQCS_NQ * W;
+    static constexpr int HQ = HQ8 ? FAQCS_NQ * W / 2 : FAQCS_NQ * WQ;
     // |sum of (Q - q)| <= W * 168: key bias and the bit width of a position field inside the argmax keys
     static constexpr int KEY_BIAS = LPR <= 16 ? (1 << 16) : (1 << 18);
     static constexpr int PB = LPR <= 16 ? 9 : 11;
@@ -233,13 +234,13 @@ struct ReadOutcome {
 };
 // FilterStat sums kept per lane over several chunks (trim_lds: folded into the block's cells every few chunks, next to the register
 // spill, instead of seven wave reductions per chunk): read count << 20 | base count, at most 2^12 reads and 2^20 bases per wave
-struct FsAcc { uint32_t tot = 0, trim = 0, len = 0, nn = 0, qt = 0, lc = 0, avg = 0; };
+struct FsAcc { uint32_t tot = 0, trim = 0, len = 0, qt = 0; }; // (poly-N, low complexity, average quality: rare, added per chunk when they occur)
 __device__ __forceinline__ void fs_acc_flush(FsAcc &f, const int lane, uint32_t *lfs)
 {
     const uint32_t m = (1u << 20) - 1u;
     const uint32_t s_tot = (uint32_t)wave_sum_i32((int)f.tot), s_trim = (uint32_t)wave_sum_i32((int)f.trim), s_len = (uint32_t)wave_sum_i32((int)f.len);
-    const uint32_t s_nn = (uint32_t)wave_sum_i32((int)f.nn), s_qt = (uint32_t)wave_sum_i32((int)f.qt), s_lc = (uint32_t)wave_sum_i32((int)f.lc);
-    const uint32_t s_avg = (uint32_t)wave_sum_i32((int)f.avg);
+    const uint32_t s_qt = (uint32_t)wave_sum_i32((int)f.qt);
+    const uint32_t s_nn = 0, s_lc = 0, s_avg = 0;
     if (lane == 0) {
         if (s_tot) { atomicAdd(&lfs[FAQCS_TOTAL_COUNT], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_NUMBER], s_tot >> 20); atomicAdd(&lfs[FAQCS_TOTAL_LENGTH], s_tot & m); }
         if (s_trim) { atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_NUMBER], s_trim >> 20); atomicAdd(&lfs[FAQCS_TOTAL_TRIMMED_LENGTH], s_trim & m); }
@@ -338,10 +339,13 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
             defer->tot += mine ? one | e_len : 0u;
             defer->trim += e_ret ? one | e_n : 0u;
             defer->len += e_rlen ? one | e_n : 0u;
-            defer->nn += (o.fl & FAQCS_F_POLY_N_SEEN) ? one | e_n : 0u;
             defer->qt += (o.fl & FAQCS_F_QUAL_TRIMMED) ? one | (o.fl >> 20) : 0u;
-            defer->lc += e_filt == FAQCS_FILT_LOW_COMPLEXITY ? one | e_n : 0u;
-            if (o_avgq_on) defer->avg += e_filt == FAQCS_FILT_AVG_Q ? one | e_n : 0u;
+            // the rare ones at once (a wave reduction only in a chunk that has such a read)
+            const uint32_t m = one - 1u;
+            const bool is_nn = (o.fl & FAQCS_F_POLY_N_SEEN) != 0, is_lc = e_filt == FAQCS_FILT_LOW_COMPLEXITY, is_avg = o_avgq_on && e_filt == FAQCS_FILT_AVG_Q;
+            if (__any(is_nn)) { const uint32_t v = (uint32_t)wave_sum_i32((int)(is_nn ? one | e_n : 0u)); if (lane == 0) { atomicAdd(&lfs[FAQCS_READ_NN], v >> 20); atomicAdd(&lfs[FAQCS_BASE_NN], v & m); } }
+            if (__any(is_lc)) { const uint32_t v = (uint32_t)wave_sum_i32((int)(is_lc ? one | e_n : 0u)); if (lane == 0) { atomicAdd(&lfs[FAQCS_READ_LOW_COMPLEXITY], v >> 20); atomicAdd(&lfs[FAQCS_BASE_LOW_COMPLEXITY], v & m); } }
+            if (__any(is_avg)) { const uint32_t v = (uint32_t)wave_sum_i32((int)(is_avg ? one | e_n : 0u)); if (lane == 0) { atomicAdd(&lfs[FAQCS_READ_AVG_Q], v >> 20); atomicAdd(&lfs[FAQCS_BASE_AVG_Q], v & m); } }
             return;
         }
         const uint32_t s_tot = (uint32_t)wave_sum_i32((int)(mine ? one | e_len : 0u));

@@ -1390,7 +1390,7 @@ static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const 
 hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                  uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                                  faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
-                                 uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st);
+                                 uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st, const uint8_t *tn_flags);
 
 static thread_local const char *g_last_trim_kernel = "";
 const char *faqcs_last_trim_kernel() { return g_last_trim_kernel; }
@@ -1398,12 +1398,12 @@ const char *faqcs_last_trim_kernel() { return g_last_trim_kernel; }
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
-                             uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
+                             uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st, const uint8_t *tn_flags)
 {
     {   // trim_lds (faqcs_trim_lds_kernel.hip): every byte from HBM once, through LDS; FAQCS_TRIM_LDS=0 switches it off
         static const bool lds_on = [] { const char *e = getenv("FAQCS_TRIM_LDS"); return !e || atoi(e) != 0; }();
         if (lds_on) {
-            const hipError_t e = faqcs_launch_trim_lds(P, seq, qual, off, n_reads, max_len, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st);
+            const hipError_t e = faqcs_launch_trim_lds(P, seq, qual, off, n_reads, max_len, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st, tn_flags);
             if (e != hipErrorNotSupported) { g_last_trim_kernel = "trim_lds"; return e; }
         }
     }

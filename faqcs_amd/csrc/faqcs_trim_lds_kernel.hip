@@ -45,8 +45,18 @@
 
 namespace {
 
+// Q-B's own partition of the positions (C = 19 only): 20 per lane instead of 19, quality rows of 160 cells.  With rows that are a
+// multiple of 32 cells the bank of a cell is its position mod 32 whatever the quality; lane rl of a read starts at position 20 rl
+// (banks 0, 20, 8, 28, 16, 4, 24, 12: the multiples of 4) and the four reads of a half wave walk their 20 positions ROTATED by
+// 0, 1, 2, 3 bytes, so the 32 lanes of one ds_add hit 32 different banks -- and four different positions: no two adds of an
+// instruction meet on a bank or on a cell (the round-2 kernel lost half of its LDS-atomic time to such conflicts).
+constexpr int lds_wq(int C) { return C == 19 ? 160 : 0; }
+constexpr int lds_cq(int C) { return C == 19 ? 20 : C; }
+
 template <int C, int NW> struct LdsCfg {
-    using Row = RowCfg<C, 8>;
+    using Row = RowCfg<C, 8, lds_wq(C)>;
+    static constexpr int CQ = lds_cq(C);                       // positions per lane in Q-B
+    static constexpr bool ROT = CQ != C;
     static constexpr int W = Row::W;
     static constexpr int ND = (W + 3) / 4;                     // dwords of the longest read
     static constexpr int NP = (W + 15) / 16;                   // 16-byte pieces (the out-of-line exact passes)
@@ -55,7 +65,8 @@ template <int C, int NW> struct LdsCfg {
     static constexpr int O_T3 = O_T2 + 512;                    // [256][2] S-B: 6-bit count fields, pre ; post (entry[b ^ 1]: b outside the kept window)
     static constexpr int O_CTR = O_T3 + 512;                   // [8] the block's chunk queue: [0] next unclaimed chunk number, [1] the block's chunk
                                                                // count once known, [4..7] ring: group number << 20 | group id
-    static constexpr int O_STG = O_CTR + 8;
+    static constexpr int O_TBQ = O_CTR + 8;                    // (ROT) [4][CQ + 1][8] rotated byte masks "positions < vb" of Q-B
+    static constexpr int O_STG = O_TBQ + (ROT ? 4 * (CQ + 1) * 8 : 0);
     static constexpr int STG_BYTES = 64 * W + 32;              // one arena's span of a chunk + 16-byte alignment slack
     static constexpr int STG_DW = (STG_BYTES + 15) / 16 * 4;
     static constexpr int TAIL_PAD = 64;                        // dwords: a lane may read W bytes from the start of the span's last read
@@ -227,7 +238,7 @@ constexpr int lds_waves(int C) { return C <= 19 ? 12 : 8; }
 template <int C, int LPR, int NW>
 __device__ __noinline__ void flush_block_partial(uint32_t *smem, uint32_t *__restrict__ row, const int tid)
 {
-    using Cfg = RowCfg<C, LPR>;
+    using Cfg = RowCfg<C, LPR, lds_wq(C)>;
     static_assert(Cfg::N_ZERO <= FAQCS_PARTIAL_ROW, "partial-sum row");
     __syncthreads();
     for (int i = tid; i < Cfg::N_ZERO; i += NW * 64) {
@@ -249,7 +260,7 @@ template <int C, int LPR>
 __global__ __launch_bounds__(1024) void fold_partials(uint32_t *__restrict__ partials, const uint32_t n_rows, uint64_t *__restrict__ counters, const uint32_t R,
                                                       uint32_t *__restrict__ g_next)
 {
-    using Cfg = RowCfg<C, LPR>;
+    using Cfg = RowCfg<C, LPR, lds_wq(C)>;
     constexpr int W = Cfg::W;
     if (blockIdx.x == 0 && threadIdx.x == 0) *g_next = 0u; // (the trim kernel's group counter: zero between launches)
     __shared__ unsigned long long part[2][16][64];
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(1024) void fold_partials(uint32_t *__restrict__ par
     const uint64_t post_base = o;
     auto add = [&](uint64_t idx, unsigned long long v) { if (v) atomicAdd((unsigned long long *)(counters + idx), v); };
     if (i < Cfg::O_HB) { // position x quality: pre in the low, post in the high half-word
-        const uint32_t q = (uint32_t)(i - Cfg::O_HQ) / W, p = (uint32_t)(i - Cfg::O_HQ) % W;
+        const uint32_t q = (uint32_t)(i - Cfg::O_HQ) / Cfg::WQ, p = (uint32_t)(i - Cfg::O_HQ) % Cfg::WQ;
         if (p < R) { add(pre_qual + (uint64_t)p * FAQCS_NQ + q, lo); add(post_qual + (uint64_t)p * FAQCS_NQ + q, hi); }
     } else if (i < Cfg::O_LEN) {
         const uint32_t c = (uint32_t)(i - Cfg::O_HB) / W, p = (uint32_t)(i - Cfg::O_HB) % W;
@@ -313,10 +324,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, unsigned long long *__restrict__ rec_pre,
-    unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err)
+    unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err,
+    const uint8_t *__restrict__ tn_flags)
 {
     constexpr int LPR = 8;
-    using Cfg = RowCfg<C, LPR>;
+    using Cfg = RowCfg<C, LPR, lds_wq(C)>;
     using T = LdsCfg<C, NW>;
     constexpr int D = Cfg::D, W = Cfg::W, ND = T::ND, NWORD = T::NWORD, NPOS = ND * 4, BMW = Cfg::BMW;
     constexpr int NI = (T::STG_BYTES + 1023) / 1024;
@@ -357,7 +369,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         const int nb = med3i((i / BMW) - 4 * (i % BMW), 0, 4);
         smem[Cfg::O_TBM + i] = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
     }
-    uint32_t three = 3u, wx4 = (uint32_t)(W * 4);
+    constexpr int CQ = T::CQ;                         // Q-B: positions per lane (LdsCfg)
+    constexpr bool ROT = T::ROT;
+    static_assert((CQ + 3) / 4 == D && (!ROT || CQ % 4 == 0), "Q-B works on the same number of dwords per lane");
+    const int pbase_q = rl * CQ;
+    const uint32_t rot = ROT ? (uint32_t)((lane >> 3) & 3) : 0u; // this read's byte rotation inside a half wave
+    if (ROT) { // rotated byte masks: byte i of row (rot, vb) <-> position (i + rot) mod CQ of the lane, 0xff when that is < vb
+        for (int i = tid; i < 4 * (CQ + 1) * 8; i += NW * 64) {
+            const int r_ = i / ((CQ + 1) * 8), vb_ = (i / 8) % (CQ + 1), k_ = i % 8;
+            uint32_t w_ = 0;
+            for (int b_ = 0; b_ < 4; ++b_)
+                if (4 * k_ + b_ < CQ && (4 * k_ + b_ + r_) % CQ < vb_) w_ |= 0xffu << (8 * b_);
+            smem[T::O_TBQ + i] = w_;
+        }
+    }
+    uint32_t three = 3u, wx4 = (uint32_t)(Cfg::WQ * 4);
     asm volatile("" : "+v"(three), "+v"(wx4)); // VGPR operands for the SDWA instructions
     if (tid == 0 && blockIdx.x == 0 && (uint32_t)(size_t)((lds_u32_ptr)smem) != 0u) atomicOr(err, 4u);
     const uint32_t total_chunks = (n_reads + 63) >> 6;
@@ -404,7 +430,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const uint32_t slot_b = (uint32_t)(T::O_STG + wave * T::STG_DW) * 4u; // LDS byte address of the wave's slot
     const uint32_t offb = ((uint32_t)in_off & 0xffu) * 0x01010101u;
     const bool swar_ok = in_off >= 0 && in_off <= 86; // else every read takes the exact quality pass
-    const uint32_t hq_lane = (uint32_t)(Cfg::O_HQ * 4 + pbase * 4) - (uint32_t)in_off * (uint32_t)(W * 4); // + raw byte * W * 4 = the cell
+    const uint32_t hq_lane = (uint32_t)(Cfg::O_HQ * 4 + pbase_q * 4) + rot * 4u - (uint32_t)in_off * (uint32_t)(Cfg::WQ * 4); // + raw byte * WQ * 4 = the cell
+    // (ROT) rotated byte i stands for position (i + rot) mod CQ: the last three wrap around for some rotations
+    const uint32_t *t_bmq = ROT ? smem + T::O_TBQ + rot * (uint32_t)((CQ + 1) * 8) : t_bm; // Q-B's mask rows of this lane
+    constexpr int BMQ = ROT ? 8 : BMW, VQ = ROT ? CQ : C + 1;
     uint32_t bpre[C], bpost[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) { bpre[j] = 0; bpost[j] = 0; }
@@ -445,13 +474,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     auto load_b = [&](const uint32_t i0, const uint32_t i1, RawB &x) {
         const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
         const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
-        const int vb = counted ? med3i(len - pbase, 0, C + 1) : 0; // (a read that is not counted: no byte of it is)
-        const int lo = post ? med3i(a - pbase, 0, C + 1) : 0, hi = post ? med3i(a + n - pbase, 0, C + 1) : 0;
-        const uint32_t qa = (slot_b + (i0 & 0xffffu) + (uint32_t)pbase) & ~3u;
+        const int vb = counted ? med3i(len - pbase_q, 0, VQ) : 0; // (a read that is not counted: no byte of it is)
+        const int lo = post ? med3i(a - pbase_q, 0, VQ) : 0, hi = post ? med3i(a + n - pbase_q, 0, VQ) : 0;
+        const uint32_t qa = (slot_b + (i0 & 0xffffu) + (uint32_t)pbase_q) & ~3u;
 #pragma unroll
         for (int k = 0; k <= D; ++k) x.r[k] = lds_ld(qa + 4u * (uint32_t)k);
 #pragma unroll
-        for (int k = 0; k < D; ++k) { x.mv[k] = t_bm[BMW * vb + k]; x.mh[k] = t_bm[BMW * hi + k]; x.ml[k] = t_bm[BMW * lo + k]; }
+        for (int k = 0; k < D; ++k) { x.mv[k] = t_bmq[BMQ * vb + k]; x.mh[k] = t_bmq[BMQ * hi + k]; x.ml[k] = t_bmq[BMQ * lo + k]; }
     };
     // position x quality cells: DATA = +1 pre / +1 post per base (undo: -1 post, for a read S-A vetoed afterwards).
     // A byte past the read belongs to the next read of the span or to the pad behind it (valid quality bytes both: its
@@ -459,7 +488,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     uint32_t qb_sum = 0; // (Q-B, `sum` steps) this lane's read: the sum of its raw quality bytes
     auto quality_cells = [&](const RawB &x, const uint32_t i0, const uint32_t i1, auto undo_t, const int t, const bool sum) {
         constexpr bool undo = decltype(undo_t)::value;
-        const uint32_t sh = ((i0 & 0xffffu) + (uint32_t)pbase + slot_b) & 3u;
+        const uint32_t sh = ((i0 & 0xffffu) + (uint32_t)pbase_q + slot_b) & 3u;
         uint32_t cm[D], im[D], wq[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -467,25 +496,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             im[k] = (x.mh[k] ^ x.ml[k]) & (undo ? 0xffffffffu : 0x01010101u);
             wq[k] = __builtin_amdgcn_alignbyte(x.r[k + 1], x.r[k], sh);
         }
+        if (ROT) { // the lane's CQ bytes rotated by `rot` (the masks come rotated from their table)
+            uint32_t w0 = wq[0];
+#pragma unroll
+            for (int k = 0; k < D; ++k) wq[k] = __builtin_amdgcn_alignbyte(k + 1 < D ? wq[k + 1] : w0, wq[k], rot);
+        }
         if (!undo && sum) { // (wave-uniform) the read's quality sum: the lane's bytes inside the read, then the 8 lanes of the read
             uint32_t qs = 0;
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 uint32_t m = x.mv[k];
-                if (4 * k + 4 > C) m &= low_bytes_(C - 4 * k); // (the masks cover C + 1 positions)
+                if (4 * k + 4 > CQ) m &= low_bytes_(CQ - 4 * k); // (the unrotated masks cover C + 1 positions)
                 qs = __builtin_amdgcn_sad_u8(wq[k] & m, 0u, qs);
             }
             qs = (uint32_t)RowOps<8>::all_sum((int)qs);
             qb_sum = (rl == t) ? qs : qb_sum;
         }
 #pragma unroll
-        for (int j = 0; j < C; ++j) {
+        for (int j = 0; j < CQ; ++j) {
             const uint32_t b = (uint32_t)(j & 3);
             // byte 0 = cm.byte[b] (pre, lo16), bytes 2 (and 3 when undoing: 0xffff = -1 in the hi16) = im.byte[b] (post)
             const uint32_t sel = undo ? (((b) << 24) | ((b) << 16) | 0x0c0cu) : ((0x0cu << 24) | (b << 16) | (0x0cu << 8) | (4u + b));
             const uint32_t data = __builtin_amdgcn_perm(cm[j >> 2], im[j >> 2], sel);
             const uint32_t ad = ((j & 3) == 0 ? byte_mul<0>(wq[j >> 2], wx4) : (j & 3) == 1 ? byte_mul<1>(wq[j >> 2], wx4)
-                                 : (j & 3) == 2 ? byte_mul<2>(wq[j >> 2], wx4) : byte_mul<3>(wq[j >> 2], wx4)) + hq_lane;
+                                 : (j & 3) == 2 ? byte_mul<2>(wq[j >> 2], wx4) : byte_mul<3>(wq[j >> 2], wx4)) +
+                                ((ROT && j >= CQ - 3 && rot >= (uint32_t)(CQ - j)) ? hq_lane - (uint32_t)(CQ * 4) : hq_lane);
 #ifdef FAQCS_LDS_QB_NOCONFLICT // (diagnostic build, wrong results: every lane on a bank of its own -- what the conflicts of these adds cost)
             lds_add_u32((ad & 0x3u) + (uint32_t)(Cfg::O_HQ * 4) + (uint32_t)lane * 4u + 256u * (uint32_t)j, data);
 #elif !defined(FAQCS_LDS_NO_QB_ATOMICS)
@@ -616,8 +651,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     };
     // What a chunk needs from global memory before its first pass: the quality span (DMA into the wave's slot), the adapter pre-pass's
     // words, the first / last base of every read (mask_quality_terminal_N looks at them before the qualities are used).
-    struct ChunkLoads { uint32_t v_off, v_end, v_sl, v_hit, bfirst, blast; };
-    ChunkLoads ld = {0, 0, 0, 0, 0, 0};
+    struct ChunkLoads { uint32_t v_off, v_end, v_sl, v_hit; };
+    ChunkLoads ld = {0, 0, 0, 0};
     bool pre_issued = false;
     auto issue_loads = [&](const uint32_t chunk_, const uint32_t o_, const uint32_t e_, ChunkLoads &L) {
         const uint32_t my_ = (chunk_ << 6) + (uint32_t)lane;
@@ -630,8 +665,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         L.v_off = o_; L.v_end = e_;
         L.v_sl = (WINDOWED && ad_sl && mine_) ? ad_sl[my_] : (len_ << 16);
         L.v_hit = (ad_hit && mine_) ? ad_hit[my_] : 0u;
-        L.bfirst = 0; L.blast = 0;
-        if (len_) { L.bfirst = (uint32_t)seq[(size_t)o_]; L.blast = (uint32_t)seq[(size_t)o_ + len_ - 1]; }
     };
     uint32_t c_cur = (uint32_t)wave, n_flushed = 0, since_spill = 0;
     uint32_t chunk_cur = chunk_of(c_cur);
@@ -683,7 +716,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const int len = (int)v_len;
             const uint32_t shq = (uint32_t)((size_t)(qual + cs) & 15u);
             const uint32_t rowq = v_off - cs + shq; // this lane's read inside the slot
-            const uint32_t bfirst = ld.bfirst, blast = ld.blast;
+            // first / last base (mask_quality_terminal_N needs them before the qualities are looked at).  Requested HERE, not with the
+            // early loads: a sector of the base arena touched a whole chunk ahead of the base DMA has left the L2 by then and comes
+            // over the fabric twice (+100 B/read of fetches, measured)
+            uint32_t bfirst = 0, blast = 0;
+#ifndef FAQCS_LDS_NO_TERMINAL_LOADS // (diagnostic build: what these two scattered loads cost in fabric requests)
+            if (tn_flags) { // the submitter's per-read flags (faqcs_batch::terminal_n): one coalesced byte per read instead
+                const uint32_t f = mine ? (uint32_t)tn_flags[my] : 0u;
+                bfirst = (f & 1u) ? (uint32_t)'N' : 0u; blast = (f & 2u) ? (uint32_t)'N' : 0u;
+            } else if (len) { bfirst = (uint32_t)seq[(size_t)v_off]; blast = (uint32_t)seq[(size_t)v_off + len - 1]; }
+#endif
             fetch_offsets(chunk_next);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (fetch_group) { // publish group number L + 1 of the block, or the block's chunk count when the launch has no group left
@@ -698,7 +740,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const uint32_t o = ce - cs + shq + (uint32_t)(64 * i + lane);
-                if (64 * i + lane < W + 12 && o < (uint32_t)T::STG_BYTES) lds_st_u8(slot_b + o, (uint32_t)in_off);
+                if (64 * i + lane < W + 20 && o < (uint32_t)T::STG_BYTES) lds_st_u8(slot_b + o, (uint32_t)in_off);
             }
             FAQCS_STAMP(0)
 
@@ -939,12 +981,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // ---- length filters and the kept window (trim.cpp:317-360) -------------------------------------
             int a = wa, n = wn;
             bool ret = mine;
-            uint32_t qt_removed = 0;
             if (ret && (n < (int)P.min_len || n == 0)) { ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
             if (ret && do_trim) {
                 // BWA_plus: final_pos_3 <= final_pos_5 empties the read (trim.cpp:781-790); BWA keeps [0, final_pos_3]; HARD [5', 3']
                 const int kept = mode == FAQCS_MODE_BWA_PLUS ? (fp3 <= fp5 ? 0 : fp3 - fp5 + 1) : fp3 - fp5 + 1;
-                if (kept != n) { qt_removed = (uint32_t)(n - kept); flags |= FAQCS_F_QUAL_TRIMMED; }
+                if (kept != n) { flags |= FAQCS_F_QUAL_TRIMMED | ((uint32_t)(n - kept) << 20); } // (bits 20..: the bases the quality trim removed)
                 a += fp5;
                 n = kept;
                 if (n < (int)P.min_len || n == 0) { ret = false; filt = FAQCS_FILT_LENGTH_POST; }
@@ -1020,6 +1061,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t si0 = rows | ((uint32_t)len << 16);
             const uint32_t si1 = (uint32_t)a | ((uint32_t)n << 8) | (retc ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u) |
                                  ((ret && !retc) ? 1u << 18 : 0u);
+            const uint32_t vpk = ((uint32_t)V_pre & 0xffffu) | ((uint32_t)V_post << 16); // (|sums| < 2^15: 152 bases x at most 192 per base)
+            const uint32_t fpk = flags | (filt << FAQCS_F_FILTER_SHIFT);
+            const uint32_t v_hit_w = v_hit;
 #define FAQCS_S_LOOP(I1, MODE)                                                                                        \
     {                                                                                                                 \
         _Pragma("unroll 1") for (int t = 0; t < LPR; ++t) {                                                          \
@@ -1047,6 +1091,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 
             FAQCS_STAMP(6)
             // ================= one read per lane again: the verdicts that depend on the bases ==========================
+            // (The S loop is the kernel's register peak.  What it does not use is packed into vpk / fpk in front of it, and the read's
+            // offsets and window are taken back out of the two words the loop was given: nothing else stays live across it.)
+            {
+            const int len = (int)(si0 >> 16), a = (int)(si1 & 0xffu), n = (int)((si1 >> 8) & 0xffu);
+            const uint32_t rows = si0 & 0xffffu, rowq = rows - shs + shq, v_off = cs + rows - shs, v_len = (uint32_t)len;
+            const uint32_t qi0 = rowq | ((uint32_t)len << 16);
+            int V_pre = (int)(int16_t)(uint16_t)(vpk & 0xffffu), V_post = (int)vpk >> 16;
+            uint32_t flags = fpk & ~(uint32_t)FAQCS_F_FILTER_MASK, filt = (fpk & (uint32_t)FAQCS_F_FILTER_MASK) >> FAQCS_F_FILTER_SHIFT;
+            const uint32_t v_hit = WINDOWED ? v_hit_w : 0u;
             uint32_t pA = tot_pe & 0xfffu, pC = (tot_pe >> 12) & 0xfffu, pN = tot_pe >> 24, pT = tot_po & 0xfffu, pG = tot_po >> 12;
             uint32_t cA = tot_ce & 0xfffu, cC = (tot_ce >> 12) & 0xfffu, cN = tot_ce >> 24, cT = tot_co & 0xfffu, cG = tot_co >> 12;
             {
@@ -1205,7 +1258,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 
             if (read_err) { any_err = 1; flags |= FAQCS_F_ERR_QUALITY; }
             oc.an = (uint32_t)a | ((uint32_t)n << 16);
-            oc.fl = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT) | (qt_removed << 20);
+            oc.fl = flags | (ret ? FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT);
             oc.pAT = pA | (pT << 16); oc.pCG = pC | (pG << 16);
             oc.cAT = cA | (cT << 16); oc.cCG = cC | (cG << 16);
             oc.N = pN | (cN << 16);
@@ -1215,6 +1268,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             chunk_epilogue<LPR>(oc, mine, my, v_len, v_hit, lane, smem + Cfg::O_LEN, smem + Cfg::O_RQ, smem + Cfg::O_BQPRE,
                                 smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, EXT && P.avgq_on != 0, 0u, &fs_acc);
             ld = ld_next;
+            }
         }
 
         FAQCS_STAMP(8)
@@ -1249,11 +1303,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #undef FAQCS_STAMP
 }
 
+// faqcs_terminal_n_flags(): bit 0 = the read's first base is an upper-case 'N', bit 1 = its last base is
+__global__ __launch_bounds__(256) void terminal_n_flags(const uint8_t *__restrict__ seq, const uint32_t *__restrict__ off, const uint32_t n, uint8_t *__restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = off[i], b = off[i + 1];
+    flags[i] = b > a ? (uint8_t)((seq[a] == 'N' ? 1u : 0u) | (seq[(size_t)b - 1] == 'N' ? 2u : 0u)) : (uint8_t)0;
+}
+hipError_t faqcs_launch_terminal_n_flags(const uint8_t *seq, const uint32_t *off, uint32_t n_reads, uint8_t *flags, hipStream_t st)
+{
+    if (!n_reads) return hipSuccess;
+    hipLaunchKernelGGL(terminal_n_flags, dim3((n_reads + 255) / 256), dim3(256), 0, st, seq, off, n_reads, flags);
+    return hipGetLastError();
+}
+
 template <int C, bool WINDOWED, bool EXT>
 static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                   uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
                                   unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
-                                  int n_cu, hipStream_t st)
+                                  int n_cu, hipStream_t st, const uint8_t *tn_flags)
 {
     constexpr int NW = lds_waves(C);
     constexpr size_t lds = (size_t)LdsCfg<C, NW>::lds_dwords() * 4;
@@ -1265,9 +1334,9 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
     if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu; // one block per CU: its LDS holds a slot per wave
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
-                       reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err);
+                       reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err, tn_flags);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, grid, counters, P.R, err + 8);
+    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8, lds_wq(C)>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, grid, counters, P.R, err + 8);
     return hipGetLastError();
 }
 
@@ -1276,7 +1345,7 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
 hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                  uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                                  faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
-                                 uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st)
+                                 uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st, const uint8_t *tn_flags)
 {
     const bool windowed = P.has_adapters || ((P.trim5 || P.trim3) && !P.qc_only);
     const bool plain = P.mode == FAQCS_MODE_BWA_PLUS && !P.protect5 && !P.qc_only && P.replace_q == 0 && !P.avgq_on &&
@@ -1284,7 +1353,7 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
     // every option set except --replace_to_N_q (its G -> N edit needs base and quality of a position together) and the ablation bits
     const bool ext = !plain && P.replace_q == 0 && P.dbg == 0;
     if (!plain && !ext) return hipErrorNotSupported;
-#define FAQCS_LDS_ARGS P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st
+#define FAQCS_LDS_ARGS P, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st, tn_flags
 #define FAQCS_LDS_CASE(C)                                                                                                 \
     return ext ? (windowed ? launch_trim_lds<C, true, true>(FAQCS_LDS_ARGS) : launch_trim_lds<C, false, true>(FAQCS_LDS_ARGS)) \
                : (windowed ? launch_trim_lds<C, true, false>(FAQCS_LDS_ARGS) : launch_trim_lds<C, false, false>(FAQCS_LDS_ARGS))

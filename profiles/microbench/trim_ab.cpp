@@ -32,9 +32,12 @@ struct Lib {
     decltype(&faqcs_kernel_report) report;
     decltype(&faqcs_last_error) last_error;
     decltype(&faqcs_debug_words) debug_words;
+    decltype(&faqcs_abi_version) abi;
+    decltype(&faqcs_terminal_n_flags) tn_flags; // (ABI 2; absent from older builds)
     faqcs_ctx *ctx = nullptr;
     double ms_sum = 0;
     int n = 0;
+    bool uses_flags = false;
 };
 
 static uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull)
@@ -60,7 +63,8 @@ int main(int argc, char **argv)
 #define SYM(f, name) l.f = (decltype(l.f))dlsym(l.h, name); if (!l.f) { fprintf(stderr, "%s: no %s\n", argv[i], name); return 1; }
         SYM(create, "faqcs_create") SYM(destroy, "faqcs_destroy") SYM(submit_device, "faqcs_submit_device") SYM(sync, "faqcs_sync")
         SYM(finish, "faqcs_finish") SYM(reset, "faqcs_reset_counters") SYM(layout, "faqcs_counters_layout") SYM(synth, "faqcs_synth_fill")
-        SYM(report, "faqcs_kernel_report") SYM(last_error, "faqcs_last_error") SYM(debug_words, "faqcs_debug_words")
+        SYM(report, "faqcs_kernel_report") SYM(last_error, "faqcs_last_error") SYM(debug_words, "faqcs_debug_words") SYM(abi, "faqcs_abi_version")
+        l.tn_flags = (decltype(l.tn_flags))dlsym(l.h, "faqcs_terminal_n_flags");
         libs.push_back(l);
     }
     HC(hipSetDevice(0));
@@ -101,11 +105,18 @@ int main(int argc, char **argv)
     faqcs_batch b;
     b.seq = d_seq; b.qual = d_qual; b.offset = d_off; b.n_reads = n; b.n_segments = (uint32_t)seg.size() - 1; b.segment_start = seg.data();
     b.max_read_len = L;
+    b.terminal_n = nullptr;
     faqcs_layout lay;
     libs[0].layout(p.max_read_length, 0, &lay);
     std::vector<uint64_t> counters(lay.total);
     std::vector<faqcs_read_result> res(n);
+    uint8_t *d_tn = nullptr;
+    HC(hipMalloc((void **)&d_tn, (size_t)n + 64));
     for (auto &l : libs) {
+        p.abi_version = (uint32_t)l.abi(); // (an ABI 1 build reads the batch up to max_read_len only)
+        b.terminal_n = nullptr;
+        if (l.tn_flags && !getenv("TRIM_AB_NO_FLAGS")) { l.tn_flags(0, d_seq, d_off, n, d_tn); b.terminal_n = d_tn; }
+        l.uses_flags = b.terminal_n != nullptr;
         if (l.create(&p, 0, &l.ctx) != 0) { fprintf(stderr, "%s: create: %s\n", l.path.c_str(), l.last_error()); return 1; }
         // one checked pass: hashes
         if (l.submit_device(l.ctx, &b, d_res) != 0 || l.sync(l.ctx) != 0) { fprintf(stderr, "%s: submit: %s\n", l.path.c_str(), l.last_error()); return 1; }
@@ -122,6 +133,7 @@ int main(int argc, char **argv)
         for (auto &l : libs) {
             faqcs_kernel_times kt;
             l.report(l.ctx, &kt); // resets the timers
+            b.terminal_n = l.uses_flags ? d_tn : nullptr;
             for (int k = 0; k < reps; ++k) {
                 if (l.submit_device(l.ctx, &b, d_res) != 0) { fprintf(stderr, "%s: submit: %s\n", l.path.c_str(), l.last_error()); return 1; }
                 if (getenv("TRIM_AB_SYNC_EACH")) l.sync(l.ctx); // (the composition fold of a launch then never runs beside the next launch)
@@ -150,6 +162,7 @@ int main(int argc, char **argv)
             {   // one more launch on its own: when do the blocks finish?
                 uint64_t z[16];
                 l.debug_words(l.ctx, z, 16);
+                b.terminal_n = l.uses_flags ? d_tn : nullptr;
                 l.submit_device(l.ctx, &b, d_res); l.sync(l.ctx);
                 l.debug_words(l.ctx, z, 16);
                 const double t_last = (double)z[13], t_first = (double)~z[14], t_start = (double)~z[15];

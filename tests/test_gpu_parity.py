@@ -581,6 +581,72 @@ def test_launch_at_the_4gib_arena_limit_matches_oracle(L, kernel, ragged):
     assert int(fs[capi.TOTAL_TRIMMED_LENGTH]) == int(r[valid, 1].astype(np.int64).sum())
 
 
+@pytest.mark.parametrize("args", [[], ["--5end", "3", "--3end", "5"], ["-n", "0"], ["-n", "3"], ["--avg_q", "25"], ["--adapter", "--polyA"],
+                                  ["--5trim_off"], ["--mode", "HARD", "-q", "10"]], ids=lambda a: " ".join(a) or "default")
+@pytest.mark.parametrize("maxlen", [150, 250, 700])
+def test_terminal_n_flags_in_the_batch_equal_the_kernels_own_lookup(args, maxlen):
+    """faqcs_batch.terminal_n (ABI 2): per-read flags -- bit 0 the read's first base is N, bit 1 its last -- computed by
+    faqcs_terminal_n_flags() or the caller's parser.  Results with the flags must equal results without them (the kernels then
+    read the two bases themselves) and the oracle's, on reads whose ends are N / n / empty / one base long."""
+    import ctypes as C
+
+    import torch
+
+    from faqcs_amd import driver
+    from faqcs_amd.engine import HipEngine, _check
+    from oracle_engine import OracleEngine
+
+    rng = np.random.Generator(np.random.PCG64([11, maxlen, len(args), SEED]))
+    reads = random_batch(rng, 4000, maxlen, "adv")
+    for k in range(0, len(reads), 7):  # force terminal N / n on a share of the reads
+        d, s, q = reads[k]
+        if len(s):
+            s = bytearray(s)
+            if k % 3 != 1:
+                s[0] = ord("N") if k % 2 else ord("n")
+            if k % 3 != 2:
+                s[-1] = ord("N")
+            reads[k] = (d, bytes(s), q)
+    reads[5] = (b"@x", b"", b"")
+    reads[6] = (b"@x", b"N", b"I")
+    reads[8] = (b"@x", b"NN", b"II")
+    R = 256 if maxlen <= 256 else 1024
+    opt = parse_args(["-u", "x", "-d", "y", "--ascii", "33"] + args)
+    seq, qual, offset, seg = driver.pack_segments([reads[i:i + 517] for i in range(0, len(reads), 517)])
+    n = len(reads)
+    want = OracleEngine(opt, R, 33)
+    want_res = want.process(seq, qual, offset, seg)
+    dev = torch.device("cuda:0")
+    pad = np.zeros(64, np.uint8)
+    d_seq = torch.from_numpy(np.concatenate([pad, seq, pad])).to(dev)
+    d_qual = torch.from_numpy(np.concatenate([pad, qual, pad])).to(dev)
+    d_off = torch.from_numpy(offset.view(np.int32)).to(dev)
+    tn = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    outs = []
+    for use_flags in (False, True):
+        eng = HipEngine(opt, R, 33, device=0)
+        lib = eng.lib
+        if use_flags:
+            _check(lib, lib.faqcs_terminal_n_flags(0, d_seq.data_ptr() + 64, d_off.data_ptr(), n, tn.data_ptr()))
+            torch.cuda.synchronize()
+            f = tn[:n].cpu().numpy()
+            lens = np.diff(offset.astype(np.int64))
+            first = np.array([lens[i] > 0 and seq[offset[i]] == ord("N") for i in range(n)])
+            last = np.array([lens[i] > 0 and seq[offset[i + 1] - 1] == ord("N") for i in range(n)])
+            assert ((f & 1) == first).all() and (((f >> 1) & 1) == last).all() and (f < 4).all()
+        res = torch.empty((n, 4), dtype=torch.int16, device=dev)
+        b = capi.Batch(d_seq.data_ptr() + 64, d_qual.data_ptr() + 64, d_off.data_ptr(), n, len(seg) - 1, seg.ctypes.data,
+                       int(np.diff(offset.astype(np.int64)).max()), tn.data_ptr() if use_flags else None)
+        _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(b), res.data_ptr()))
+        eng.sync()
+        got = res.cpu().numpy().view(np.uint16).view(capi.RESULT_DTYPE).ravel()
+        bad = np.nonzero(got != want_res)[0]
+        assert len(bad) == 0, "flags=%s: first differing read %d: hip=%s oracle=%s" % (use_flags, bad[0], got[bad[0]], want_res[bad[0]])
+        assert (eng.counters() == want.counters()).all(), "flags=%s" % use_flags
+        outs.append(got)
+    assert (outs[0] == outs[1]).all()
+
+
 def test_full_size_adapter_polya():
     """BASELINE configs[2]'s option set (--adapter --polyA, 5 % read-through) on 4 M reads: a size at which the adapter pre-pass runs
     thousands of 32 768-read segments and the trim kernel's flush / register-spill paths with an adapter window trigger.  Invariants
