@@ -125,7 +125,7 @@ struct faqcs_ctx {
     uint32_t *d_astart = nullptr, *d_aplanes = nullptr, *d_awstart = nullptr;
     float match_rate = 0.f;
     // staging for host submissions: two input slots so the H2D copy of batch k+1 overlaps the kernels of batch k
-    struct Slot { DevBuf<uint8_t> seq, qual; DevBuf<uint32_t> off; hipEvent_t done = nullptr; bool used = false; };
+    struct Slot { DevBuf<uint8_t> seq, qual, tn; DevBuf<uint32_t> off; hipEvent_t done = nullptr; bool used = false; };
     Slot slot[2];
     uint64_t n_submits = 0;
     hipEvent_t ticket_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -615,10 +615,11 @@ extern "C" int faqcs_submit_async(faqcs_ctx *c, const faqcs_batch *b, faqcs_read
     // the slot may still feed the kernels of submission k-2: growing it (hipFree) needs them finished, reusing it
     // only needs the copy stream to wait for them
     if (sl.used) {
-        if (bytes + FAQCS_ARENA_PAD_BEFORE + FAQCS_ARENA_PAD_AFTER > sl.seq.cap || (size_t)n + 1 > sl.off.cap) HIPCHK(hipEventSynchronize(sl.done));
+        if (bytes + FAQCS_ARENA_PAD_BEFORE + FAQCS_ARENA_PAD_AFTER > sl.seq.cap || (size_t)n + 1 > sl.off.cap || (b->terminal_n && (size_t)n + 64 > sl.tn.cap)) HIPCHK(hipEventSynchronize(sl.done));
         else HIPCHK(hipStreamWaitEvent(c->copy, sl.done, 0));
     }
     HIPCHK(sl.seq.reserve(bytes + FAQCS_ARENA_PAD_BEFORE + FAQCS_ARENA_PAD_AFTER)); HIPCHK(sl.qual.reserve(bytes + FAQCS_ARENA_PAD_BEFORE + FAQCS_ARENA_PAD_AFTER)); HIPCHK(sl.off.reserve((size_t)n + 1));
+    if (b->terminal_n) HIPCHK(sl.tn.reserve((size_t)n + 64));
     if ((size_t)n + 1 > c->s_res.cap) HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(c->s_res.reserve((size_t)n + 1));
     // arena bytes land 16 bytes into the staging buffer; the kernels index with the ORIGINAL offsets
@@ -627,10 +628,15 @@ extern "C" int faqcs_submit_async(faqcs_ctx *c, const faqcs_batch *b, faqcs_read
         HIPCHK(hipMemcpyAsync(sl.qual.p + 16, b->qual + o0, bytes, hipMemcpyHostToDevice, c->copy));
     }
     HIPCHK(hipMemcpyAsync(sl.off.p, b->offset, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->copy));
+    const uint8_t *d_tn = nullptr;
+    if (b->terminal_n && n) { // the caller's parser has looked at the ends of each read: n more bytes instead of two scattered loads per read
+        HIPCHK(hipMemcpyAsync(sl.tn.p, b->terminal_n, n, hipMemcpyHostToDevice, c->copy));
+        d_tn = sl.tn.p;
+    }
     HIPCHK(hipEventRecord(c->copied, c->copy));
     HIPCHK(hipStreamWaitEvent(c->compute, c->copied, 0));
     const uint8_t *d_seq = sl.seq.p + 16 - o0, *d_qual = sl.qual.p + 16 - o0;
-    if (int rc = enqueue(c, d_seq, d_qual, sl.off.p, n, max_len, b->segment_start, b->n_segments, c->s_res.p)) return rc;
+    if (int rc = enqueue(c, d_seq, d_qual, sl.off.p, n, max_len, b->segment_start, b->n_segments, c->s_res.p, d_tn)) return rc;
     if (n && results) HIPCHK(hipMemcpyAsync(results, c->s_res.p, (size_t)n * sizeof(faqcs_read_result), hipMemcpyDeviceToHost, c->compute));
     HIPCHK(hipEventRecord(sl.done, c->compute));
     HIPCHK(hipEventRecord(tk, c->compute));

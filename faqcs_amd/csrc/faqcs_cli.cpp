@@ -271,6 +271,7 @@ struct RecBuf {
     size_t cap = 0;              // bytes in seq / qual (pinned)
     uint32_t *off = nullptr;     // BUF_READS + 1 (pinned)
     faqcs_read_result *res = nullptr; // BUF_READS (pinned)
+    uint8_t *tn = nullptr;       // BUF_READS (pinned): faqcs_batch.terminal_n, filled by the parser (bit 0: first base is 'N', bit 1: last)
     std::string defs;
     std::vector<uint32_t> def_off; // n + 1 (deflines copied into `defs`: the streaming path)
     const char *map_base = nullptr; // deflines left in the memory-mapped input (the mapped path): dpos / dlen
@@ -287,7 +288,8 @@ struct RecBuf {
         seq = (uint8_t *)faqcs_host_alloc(cap + 64); qual = (uint8_t *)faqcs_host_alloc(cap + 64);
         off = (uint32_t *)faqcs_host_alloc((BUF_READS + 1) * sizeof(uint32_t));
         res = (faqcs_read_result *)faqcs_host_alloc(BUF_READS * sizeof(faqcs_read_result));
-        if (!seq || !qual || !off || !res) throw Fatal("faqcs_mi: unable to allocate pinned host memory");
+        tn = (uint8_t *)faqcs_host_alloc(BUF_READS + 64);
+        if (!seq || !qual || !off || !res || !tn) throw Fatal("faqcs_mi: unable to allocate pinned host memory");
         memset(seq, 0, cap + 64); memset(qual, 0, cap + 64);
     }
     void grow(size_t need)
@@ -301,7 +303,7 @@ struct RecBuf {
         faqcs_host_free(seq); faqcs_host_free(qual);
         seq = s; qual = q; cap = nc;
     }
-    void release() { faqcs_host_free(seq); faqcs_host_free(qual); faqcs_host_free(off); faqcs_host_free(res); }
+    void release() { faqcs_host_free(seq); faqcs_host_free(qual); faqcs_host_free(off); faqcs_host_free(res); faqcs_host_free(tn); }
 };
 
 template <class T> class Queue {
@@ -615,7 +617,7 @@ struct Source {
         size_t o = 32; // slack in front of the first read
         b->off[0] = (uint32_t)o;
         const char *p = t->text.data(), *end = p + t->text.size();
-        if (t->text.size() + 128 > b->cap) b->grow(t->text.size() + 128);
+        if (t->text.size() / 2 + 128 > b->cap) b->grow(t->text.size() / 2 + 128); // (|bases| == |qualities|: an arena takes less than half of the text)
         while (p < end) {
             const char *nx; bool term;
             const char *e = line_end(p, end, nx, term);
@@ -624,6 +626,7 @@ struct Source {
             if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read sequence"; break; }
             e = line_end(p, end, nx, term);
             const size_t slen = (size_t)(e - p);
+            if (o + slen + 64 > b->cap) b->grow(o + slen + 128); // (only a malformed record: a base line longer than half of the block's text)
             memcpy(b->seq + o, p, slen);
             p = nx;
             if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read '+'"; break; }
@@ -636,6 +639,7 @@ struct Source {
             if (slen != qlen) { b->error = "fastq.cpp:next_read: |Sequence| != |Quality|"; break; }
             memcpy(b->qual + o, p, qlen);
             p = nx;
+            b->tn[b->n] = slen ? (uint8_t)((b->seq[o] == 'N' ? 1 : 0) | (b->seq[o + slen - 1] == 'N' ? 2 : 0)) : (uint8_t)0;
             o += slen;
             b->def_off.push_back((uint32_t)b->defs.size());
             ++b->n;
@@ -776,6 +780,7 @@ struct Run {
         const uint32_t seg[2] = {0, b->n};
         faqcs_batch bt; memset(&bt, 0, sizeof(bt));
         bt.seq = b->seq; bt.qual = b->qual; bt.offset = b->off; bt.n_reads = b->n; bt.n_segments = 1; bt.segment_start = seg;
+        bt.terminal_n = b->tn;
         check(faqcs_submit_async(ctxs[b->dev], &bt, b->res, &b->ticket));
     }
     // writes one surviving record with the reference's byte edits (trim.cpp:390-403,516-525,1191-1216; fastq.cpp:127-138)
@@ -948,7 +953,8 @@ void parse_range(const char *base, size_t b0, size_t b1, bool eof, RecBuf *b)
     b->dpos.reserve(BUF_READS); b->dlen.reserve(BUF_READS);
     size_t o = 32;
     b->off[0] = (uint32_t)o;
-    if ((b1 - b0) + 128 > b->cap) b->grow((b1 - b0) + 128);
+    // a record is defline + bases + '+' line + qualities, |bases| == |qualities|: an arena takes less than half of the text
+    if ((b1 - b0) / 2 + 128 > b->cap) b->grow((b1 - b0) / 2 + 128);
     const char *p = base + b0, *end = base + b1;
     while (p < end) {
         const char *nx; bool term;
@@ -958,6 +964,7 @@ void parse_range(const char *base, size_t b0, size_t b1, bool eof, RecBuf *b)
         if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read sequence"; break; }
         e = line_end_fast(p, end, nx, term);
         const size_t slen = (size_t)(e - p);
+        if (o + slen + 64 > b->cap) b->grow(o + slen + 128); // (only a malformed record: a base line longer than half of the range's text)
         memcpy(b->seq + o, p, slen);
         p = nx;
         if (p >= end) { b->error = "fastq.cpp:next_read: Unable to read '+'"; break; }
@@ -970,6 +977,7 @@ void parse_range(const char *base, size_t b0, size_t b1, bool eof, RecBuf *b)
         if (slen != qlen) { b->error = "fastq.cpp:next_read: |Sequence| != |Quality|"; break; }
         memcpy(b->qual + o, p, qlen);
         p = nx;
+        b->tn[b->n] = slen ? (uint8_t)((b->seq[o] == 'N' ? 1 : 0) | (b->seq[o + slen - 1] == 'N' ? 2 : 0)) : (uint8_t)0;
         o += slen;
         b->dpos.push_back((uint64_t)(d - base)); b->dlen.push_back((uint32_t)dl);
         ++b->n;
@@ -1000,8 +1008,20 @@ char *render_read(const faqcs_params &prm, const RecBuf *b, uint32_t i, char *o)
 }
 
 // FaQCs.cpp:153-538 (paired == true) and :540-757 (paired == false) on mapped inputs
+// The mapped outputs are written through MAP_SHARED mappings of files sized to their inputs: when the file system runs out of space
+// (or a quota is hit, or an input file is truncated by someone else while it is mapped) the store or load raises SIGBUS instead of
+// returning an error.  Reserving the space first (posix_fallocate) would zero every page of the outputs up front, on tmpfs as slow as
+// the whole run; the handler reports the failure the way the streaming path reports a failed write and ends the process.
+static void sigbus_handler(int)
+{
+    static const char msg[] = "Caught the error I/O error (SIGBUS on a mapped file: no space left on the output file system, or an input file was truncated)\n";
+    if (write(2, msg, sizeof(msg) - 1) < 0) {}
+    _exit(EXIT_FAILURE);
+}
+
 void process_mapped(Run &r, bool paired)
 {
+    signal(SIGBUS, sigbus_handler);
     Opt &opt = r.opt;
     const int nsrc = paired ? 2 : 1;
     MapFile mf[2];
@@ -1276,7 +1296,10 @@ void process_mapped(Run &r, bool paired)
     if (getenv("FAQCS_MI_TIMING")) fprintf(stderr, "[faqcs_mi] %u parsers: %.3f s parsing, %.3f s waiting for a buffer; %u formatters: %.3f s rendering, %.3f s in pwrite, %.3f s idle (thread-seconds)\n",
                                            n_parse, t_parse_work, t_parse_wait, n_format, t_fmt_render, t_fmt_write, t_fmt_idle);
     for (int s = 0; s < nsrc; ++s)
-        if (fd_out[s] >= 0) { munmap(out_map[s], out_cap[s]); if (ftruncate(fd_out[s], (off_t)out_len[s]) != 0) throw Fatal("I/O error"); ::close(fd_out[s]); }
+        if (fd_out[s] >= 0) { // (the mapping itself is left to process exit like the pinned buffers: unmapping gigabytes of written pages takes ~50 ms per file)
+            if (ftruncate(fd_out[s], (off_t)out_len[s]) != 0) throw Fatal("I/O error");
+            ::close(fd_out[s]);
+        }
     // (pinned buffers and mappings are left to process exit: unpinning a gigabyte takes longer than the rest of the epilogue)
     static std::vector<std::vector<RecBuf>> keep; keep.emplace_back(std::move(bufs[0])); keep.emplace_back(std::move(bufs[1]));
     fu.close(); fdisc.close();
@@ -1846,17 +1869,22 @@ struct ReportHelper {
         if (pid < 0) { close(pf[0]); close(pf[1]); pid = -1; return; }
         if (pid == 0) {
             close(pf[1]);
+            // the script arrives behind its length: a parent that died half way through must not make R run half a script
+            uint64_t want = 0;
             std::string script;
             char buf[65536];
             ssize_t n;
-            while ((n = read(pf[0], buf, sizeof buf)) > 0) script.append(buf, (size_t)n);
+            size_t got = 0;
+            while (got < sizeof want && (n = read(pf[0], (char *)&want + got, sizeof want - got)) > 0) got += (size_t)n;
+            if (got == sizeof want) while ((n = read(pf[0], buf, sizeof buf)) > 0) script.append(buf, (size_t)n);
             close(pf[0]);
-            if (!script.empty()) {
-                FILE *r = popen("R --vanilla --silent --slave", "w"); // plot.cpp:507
-                if (!r) fprintf(stderr, "Warning: Unable to run R for plot generation\n");
-                else { fwrite(script.data(), 1, script.size(), r); pclose(r); }
-            }
-            _exit(0);
+            if (got != sizeof want || want == 0) _exit(0); // (no report wanted: --trim_only decided later, or the run failed)
+            if (script.size() != want) { fprintf(stderr, "Warning: Unable to run R for plot generation\n"); _exit(1); }
+            FILE *r = popen("R --vanilla --silent --slave", "w"); // plot.cpp:507
+            if (!r) { fprintf(stderr, "Warning: Unable to run R for plot generation\n"); _exit(1); }
+            const bool ok = fwrite(script.data(), 1, script.size(), r) == script.size();
+            const int rc = pclose(r);
+            _exit(ok && rc == 0 ? 0 : 1);
         }
         close(pf[0]);
         fd = pf[1];
@@ -1865,12 +1893,16 @@ struct ReportHelper {
     void run(const std::string &script)
     {
         if (pid < 0) return;
+        const uint64_t len = script.size();
+        std::string msg((const char *)&len, sizeof len);
+        msg += script;
         size_t off = 0;
-        while (off < script.size()) { const ssize_t n = write(fd, script.data() + off, script.size() - off); if (n <= 0) break; off += (size_t)n; }
+        while (off < msg.size()) { const ssize_t n = write(fd, msg.data() + off, msg.size() - off); if (n <= 0) break; off += (size_t)n; } // (SIGPIPE is ignored: a dead helper = EPIPE)
         close(fd); fd = -1;
         int st = 0;
         waitpid(pid, &st, 0);
         pid = -1;
+        if (off != msg.size()) fprintf(stderr, "Warning: Unable to run R for plot generation\n"); // (the helper says so itself when popen or R fails, as plot.cpp:507-513 does)
     }
 };
 

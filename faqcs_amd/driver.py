@@ -107,6 +107,19 @@ def pack_segments(buffers):
     return seq[PAD:], qual[PAD:], offset, np.asarray(seg, dtype=np.uint32)
 
 
+def terminal_n_flags(seq, offset):
+    """faqcs_batch.terminal_n for a packed host arena: bit 0 = a read's first base is 'N', bit 1 = its last (what
+    mask_quality_terminal_N, trim.cpp:1191-1216, tests first); 0 for an empty read."""
+    off = offset.astype(np.int64)
+    n = len(off) - 1
+    if n <= 0:
+        return np.zeros(0, dtype=np.uint8)
+    nonempty = off[1:] > off[:-1]
+    first = seq[np.minimum(off[:-1], max(len(seq) - 1, 0))] == ord("N")
+    last = seq[np.maximum(off[1:] - 1, 0)] == ord("N")
+    return ((first & nonempty).astype(np.uint8) | ((last & nonempty).astype(np.uint8) << 1))
+
+
 def edited_arenas(opt, in_off, seq, qual, offset):
     """The rule-based byte edits of include/faqcs_mi.h faqcs_read_result, vectorised over a whole arena:
     terminal-N quality masking (trim.cpp:1191-1216), G->N (trim.cpp:390-403), offset re-encode
@@ -202,7 +215,7 @@ class Run:
             eng = self.ensure_engine()
             bufs = [b for pair in pending for b in pair]  # reference call order: trim(buffer1), trim(buffer2)
             seq, qual, offset, seg = pack_segments(bufs)
-            res = eng.process(seq, qual, offset, seg)
+            res = eng.process(seq, qual, offset, seg, terminal_n_flags(seq, offset))
             es, eq = edited_arenas(opt, self.in_off, seq, qual, offset) if not opt.qc_only else (None, None)
             valid = (res["flags"] & capi.F_VALID) != 0
             for k, (x1, x2) in enumerate(pending):
@@ -298,7 +311,7 @@ class Run:
                 return
             eng = self.ensure_engine()
             seq, qual, offset, seg = pack_segments(pending)
-            res = eng.process(seq, qual, offset, seg)
+            res = eng.process(seq, qual, offset, seg, terminal_n_flags(seq, offset))
             if not opt.qc_only:
                 es, eq = edited_arenas(opt, self.in_off, seq, qual, offset)
                 valid = (res["flags"] & capi.F_VALID) != 0

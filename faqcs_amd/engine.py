@@ -40,15 +40,19 @@ class HipEngine:
         self.n_counters = int(lay.total)
 
     # -- the trim() seam ---------------------------------------------------------------------------
-    def process(self, seq, qual, offset, segment_start):
+    def process(self, seq, qual, offset, segment_start, terminal_n=None):
         """seq/qual: uint8 arenas (host memory: the library copies them into padded device buffers), offset: uint32[n+1],
-        segment_start: uint32[n_segments+1].  Returns the per-read result array."""
+        segment_start: uint32[n_segments+1]; terminal_n: optional uint8[n] (faqcs_batch.terminal_n, see terminal_n_flags()).
+        Returns the per-read result array."""
         offset = np.ascontiguousarray(offset, dtype=np.uint32)
         segment_start = np.ascontiguousarray(segment_start, dtype=np.uint32)
         n = len(offset) - 1
         res = np.zeros(n, dtype=capi.RESULT_DTYPE)
+        if terminal_n is not None:
+            terminal_n = np.ascontiguousarray(terminal_n, dtype=np.uint8)
+            assert len(terminal_n) >= n
         b = capi.Batch(seq.ctypes.data, qual.ctypes.data, offset.ctypes.data, n, len(segment_start) - 1,
-                       segment_start.ctypes.data, 0)
+                       segment_start.ctypes.data, 0, terminal_n.ctypes.data if terminal_n is not None and n else None)
         _check(self.lib, self.lib.faqcs_submit(self.ctx, C.byref(b), res.ctypes.data))
         _check(self.lib, self.lib.faqcs_sync(self.ctx))
         return res

@@ -114,11 +114,12 @@ typedef struct faqcs_batch {
     uint32_t        max_read_len;   /* upper bound on the read lengths of this batch (selects the kernel
                                        variant); 0 = unknown: faqcs_submit() scans the offsets,
                                        faqcs_submit_device() falls back to the context capacity */
-    const uint8_t  *terminal_n;     /* OPTIONAL (ABI 2), faqcs_submit_device() only: one byte per read, bit 0 = the read's first base is an
-                                       upper-case 'N', bit 1 = its last base is (what mask_quality_terminal_N, trim.cpp:1191-1216, looks
-                                       at first); a device pointer, e.g. from faqcs_terminal_n_flags().  NULL = the kernels look themselves
-                                       (two scattered byte loads per read into the base arena ahead of its streaming copy: +100 B/read of
-                                       fabric requests).  A parser has both bytes in hand when it lays a read down. */
+    const uint8_t  *terminal_n;     /* OPTIONAL (ABI 2): one byte per read, bit 0 = the read's first base is an upper-case 'N', bit 1 = its
+                                       last base is (what mask_quality_terminal_N, trim.cpp:1191-1216, looks at first).  A host pointer for
+                                       faqcs_submit() / faqcs_submit_async() (uploaded with the offsets), a device pointer for
+                                       faqcs_submit_device() (e.g. from faqcs_terminal_n_flags()).  NULL = the kernels look themselves: two
+                                       scattered byte loads per read into the base arena ahead of its streaming copy, +100 B/read of fabric
+                                       requests.  A parser has both bytes in hand when it lays a read down. */
 } faqcs_batch;
 
 /* Per-read outcome (8 bytes).  For a valid read the reference's output record is
@@ -271,10 +272,10 @@ int  faqcs_kmer_epoch_counts(faqcs_ctx *ctx, uint64_t *distinct_by_first_epoch, 
  * (seed, first_read + i)); stride == L (packed).  d_offset gets n_reads+1 entries. */
 int  faqcs_synth_fill(int device_id, uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads,
                       uint32_t L, uint64_t seed, uint64_t first_read, float adapter_frac);
-/* The k-mer configuration of SURVEY section 8(d): reads are windows of a fixed synthetic genome of genome_len bases
- * (either strand, 0.5 % substitutions, the same quality recipe), so distinct k-mers grow as on real data. */
 /* terminal_n flags (faqcs_batch) of a device-resident batch, computed on the device: d_flags[i], i < n_reads */
 int  faqcs_terminal_n_flags(int device_id, const uint8_t *d_seq, const uint32_t *d_offset, uint32_t n_reads, uint8_t *d_flags);
+/* The k-mer configuration of SURVEY section 8(d): reads are windows of a fixed synthetic genome of genome_len bases
+ * (either strand, 0.5 % substitutions, the same quality recipe), so distinct k-mers grow as on real data. */
 int  faqcs_synth_fill_genome(int device_id, uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads,
                              uint32_t L, uint64_t seed, uint64_t first_read, uint64_t genome_len);
 /* diagnostic builds only: section clocks accumulated by the trim kernel (16 words; read and cleared) */

@@ -58,7 +58,7 @@ class OracleEngine:
         self.n_counters = self.layout["total"]
         self.block = np.zeros(self.n_counters, dtype=np.uint64)
 
-    def process(self, seq, qual, offset, segment_start):
+    def process(self, seq, qual, offset, segment_start, terminal_n=None):  # (the oracle looks at the bases itself)
         offset = np.ascontiguousarray(offset, dtype=np.uint32)
         n = len(offset) - 1
         res = np.zeros(n, dtype=capi.RESULT_DTYPE)

@@ -645,6 +645,12 @@ def test_terminal_n_flags_in_the_batch_equal_the_kernels_own_lookup(args, maxlen
         assert (eng.counters() == want.counters()).all(), "flags=%s" % use_flags
         outs.append(got)
     assert (outs[0] == outs[1]).all()
+    # the host-buffer entry points take host flags (the native CLI's parser and the Python driver fill them while packing)
+    eng = HipEngine(opt, R, 33, device=0)
+    f = driver.terminal_n_flags(seq, offset)
+    assert (f == tn[:n].cpu().numpy()).all()
+    got = eng.process(seq, qual, offset, seg, f)
+    assert (got == want_res).all() and (eng.counters() == want.counters()).all()
 
 
 def test_full_size_adapter_polya():
