@@ -12,7 +12,8 @@ NBASE = 5
 NCOMP_BIN = 10001
 NCOMP_KIND = 6
 SEGMENT_READS = 32768
-MAX_READ_LENGTH = 1024
+MAX_READ_LENGTH = 32767       # FAQCS_MAX_READ_LENGTH: longest read the library takes (batches with a read > 1 024 bases run on trim_long)
+FAST_READ_LENGTH = 1024       # longest read of the chunked kernels
 
 (TOTAL_COUNT, TOTAL_NUMBER, TOTAL_LENGTH, TOTAL_TRIMMED_NUMBER, TOTAL_TRIMMED_LENGTH, PAIRED_READ_NUMBER,
  PAIRED_BASE_LENGTH, READ_LENGTH, BASE_LENGTH, READ_NN, BASE_NN, READ_PHIX, BASE_PHIX, READ_ADAPTER,

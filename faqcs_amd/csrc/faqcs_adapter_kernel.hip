@@ -157,7 +157,10 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
     // A wave takes chunks of 64 consecutive reads: offsets load and results store as one coalesced vector per chunk,
     // per-read scalars come out of the lanes with v_readlane, and the bases of read t+1 are fetched while read t is
     // processed -- no dependent global load sits in front of a read.
-    constexpr int NCH = MAXLEN / 64;
+    // LONG (reads of 1 025 ... 32 767 bases: one wave per block, its LDS holds the per-base arrays of ONE read): the bases are not
+    // kept in registers a read ahead -- the loops over a read's 64-base pieces are run-time loops that fetch from global memory
+    constexpr bool LONG = MAXLEN > 1024;
+    constexpr int NCH = LONG ? 1 : MAXLEN / 64;
     const uint32_t total_chunks = (n_reads + 63u) >> 6;
 #pragma unroll 1
     for (uint32_t chunk = blockIdx.x * NW + wave; chunk < total_chunks; chunk += n_waves) {
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
       while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= base) lo = mid; else hi = mid; }
       uint32_t s0 = seg_start[lo], s1 = seg_start[lo + 1];
       uint32_t nbyte[NCH]; // bases of the next read, one byte per lane per 64-base chunk
-      {
+      if (!LONG) {
           const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)v_off, 0);
           const int l0 = __builtin_amdgcn_readlane((int)v_len, 0);
 #pragma unroll
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
         uint32_t cbyte[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) cbyte[c] = nbyte[c];
-        if (t + 1 < 64 && r + 1 < n_reads) {
+        if (!LONG && t + 1 < 64 && r + 1 < n_reads) {
             const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)v_off, t + 1);
             const int l1 = __builtin_amdgcn_readlane((int)v_len, t + 1);
 #pragma unroll
@@ -208,13 +211,14 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
         bool badbase = false;
         const int span = qlen > prev_qlen ? qlen : prev_qlen;
         prev_qlen = qlen;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
+#pragma unroll(LONG ? 1 : NCH)
+        for (int c = 0; c < (LONG ? MAXLEN / 64 : NCH); ++c) { // (LONG: a run-time loop, left at the first piece past the span)
+            if (LONG && c * 64 >= span) break;
             if (c * 64 < span) {
                 const int p = c * 64 + lane;
                 uint32_t bits = 0;
                 if (p < qlen) {
-                    bits = s_na[cbyte[c]];
+                    bits = s_na[LONG ? (uint32_t)seq[(size_t)o + p] : cbyte[LONG ? 0 : c]];
                     badbase |= bits == 0u;
                 }
                 // every chunk the previous read touched is rewritten (zeros past this read) so nothing of it survives
@@ -562,10 +566,14 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
             // the per-base arrays of stage 2 are only needed here (a few percent of the reads)
             // (from the bytes this lane fetched for pack_query: a second global load here stalled every such read -- a fifth of them
             // with --polyA, whose weak threshold lets ~15 % of random reads through the prefilter -- for a memory latency)
+            if (LONG) {
+                for (int p = lane; p < qlen; p += 64) { q[p] = s_na[seq[(size_t)o + p]]; mk[p] = 1; }
+            } else {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int p = c * 64 + lane;
-                if (p < qlen) { q[p] = s_na[cbyte[c]]; mk[p] = 1; }
+                for (int c = 0; c < NCH; ++c) {
+                    const int p = c * 64 + lane;
+                    if (p < qlen) { q[p] = s_na[cbyte[c]]; mk[p] = 1; }
+                }
             }
             lds_sync_wave();
 #pragma unroll 1
@@ -605,8 +613,9 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
             uint32_t pending = 0;      // start of the open unmasked run
             bool open = false;
             uint64_t carry = 0;        // mask bit of the previous position (position -1 counts as masked)
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
+#pragma unroll(LONG ? 1 : NCH)
+            for (int c = 0; c < (LONG ? MAXLEN / 64 : NCH); ++c) {
+                if (LONG && c * 64 >= qlen) break;
                 if (c * 64 < qlen) {
                     const int p = c * 64 + lane;
                     const uint64_t m = __ballot(p < qlen && mk[p] != 0);
@@ -669,6 +678,13 @@ hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const u
         const uint32_t cap = (uint32_t)n_cu * 4u;
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((adapter_overlap<NW, 1024>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
+                           n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
+    } else if (max_len <= FAQCS_MAX_READ_LENGTH) { // long reads: one wave per block (its LDS: 2 x 32 KB per-base arrays + 16 KB of planes), one block per CU
+        constexpr int NW = 1;
+        uint32_t grid = n_reads;
+        const uint32_t cap = (uint32_t)n_cu;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL((adapter_overlap<NW, 32768>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
                            n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
     } else {
         return hipErrorInvalidValue;

@@ -390,6 +390,7 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     d.replace_q = p->replace_to_N_q; d.protect5 = p->protect_5; d.qc_only = p->qc_only;
     d.has_adapters = p->n_adapters ? 1 : 0; d.avgq_on = p->average_quality > 0.0f ? 1 : 0;
     d.R = p->max_read_length; d.n_adapters = p->n_adapters;
+    d.lc_ratio = p->low_complexity_cutoff_ratio; d.avg_q = p->average_quality;
     if (const char *e = getenv("FAQCS_DBG")) d.dbg = (uint32_t)strtoul(e, nullptr, 0);
     d.lc_thr = c->d_lcthr; d.avgq_min_v = c->d_avgq; d.comp_norm = c->d_norm; d.div_magic = c->d_magic; d.base_tab = c->d_basetab;
     d.partials = c->d_partials;
@@ -424,7 +425,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_partials, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
                     c->kt.slots, c->kt.stats, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
     for (void *q : ptrs) if (q) (void)hipFree(q);
-    for (auto &sl : c->slot) { sl.seq.release(); sl.qual.release(); sl.off.release(); if (sl.done) (void)hipEventDestroy(sl.done); }
+    for (auto &sl : c->slot) { sl.seq.release(); sl.qual.release(); sl.tn.release(); sl.off.release(); if (sl.done) (void)hipEventDestroy(sl.done); }
     for (auto &e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
     c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
     for (auto &rs : c->rec) { rs.pre.release(); rs.post.release(); if (rs.trimmed) (void)hipEventDestroy(rs.trimmed); if (rs.folded) (void)hipEventDestroy(rs.folded); }
@@ -480,14 +481,17 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         const bool wide = max_len > 256; // the long-read kernels write two-word composition records
         faqcs_ctx::RecSet &rs = c->rec[c->n_enqueued++ & 1];
         if (rs.used) HIPCHK(hipStreamWaitEvent(c->compute, rs.folded, 0)); // the set's previous records have been folded
-        const size_t need = (size_t)n * (wide ? 2 : 1);
+        const char *e_long = getenv("FAQCS_TRIM_LONG");
+        const bool force_long = e_long && atoi(e_long) != 0;
+        const bool long_reads = max_len > FAQCS_FAST_READ_LENGTH || force_long; // trim_long: composition bins are added by the kernel itself, no records
+        const size_t need = long_reads ? 1 : (size_t)n * (wide ? 2 : 1);
         if (need > rs.pre.cap) HIPCHK(hipStreamSynchronize(c->aux));
         HIPCHK(rs.pre.reserve(need)); HIPCHK(rs.post.reserve(need));
         HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, rs.pre.p, rs.post.p,
                                  c->d_counters, c->d_err, c->n_cu, c->compute, d_tn));
         HIPCHK(hipEventRecord(t.b, c->compute));
         c->trim_kernel = faqcs_last_trim_kernel();
-        if (!(c->dp.dbg & 1u)) {
+        if (!(c->dp.dbg & 1u) && !long_reads) {
             HIPCHK(hipEventRecord(rs.trimmed, c->compute));
             HIPCHK(hipStreamWaitEvent(c->aux, rs.trimmed, 0));
             HIPCHK(faqcs_launch_composition(rs.pre.p, rs.post.p, n, wide, c->d_norm, c->d_counters + c->lay.pre_comp,

@@ -16,7 +16,8 @@
 #include "../../include/faqcs_mi.h"
 
 #define FAQCS_WAVE 64
-#define FAQCS_TAB_LEN FAQCS_MAX_READ_LENGTH /* per-length lookup tables: every length the kernels support */
+#define FAQCS_FAST_READ_LENGTH 1024 /* longest read the chunked trim kernels and composition_histogram take; longer reads: trim_long */
+#define FAQCS_TAB_LEN FAQCS_FAST_READ_LENGTH /* per-length lookup tables: every length the chunked kernels support */
 
 // Everything the kernels need from faqcs_params + host-precomputed integer lookup tables, passed by value.
 struct DevParams {
@@ -26,6 +27,8 @@ struct DevParams {
     uint32_t R;                   // row capacity of the global matrices
     uint32_t n_adapters;
     uint32_t dbg;                 // FAQCS_DBG ablation bits (diagnostics only; 0 in production)
+    float lc_ratio, avg_q;        // --lc / --avg_q as given (trim_long evaluates the reference's float expressions directly; the chunked
+                                  // kernels use the per-length integer tables below)
     // per-length tables, index 0..FAQCS_TAB_LEN (float32 semantics folded into integers on the host)
     const uint32_t *lc_thr;       // lo16: min base count that trips `count*float(1.0/len) > lc` (trim.cpp:483-488)
                                   // hi16: min transition count that trips `dc*(norm*2) > lc`     (trim.cpp:499-503)

@@ -1387,6 +1387,9 @@ static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const 
     return hipGetLastError();
 }
 
+hipError_t faqcs_launch_trim_long(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off, uint32_t n_reads,
+                                  const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out, uint64_t *counters, uint32_t *err,
+                                  int n_cu, hipStream_t st); // faqcs_trim_long_kernel.hip
 hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                  uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                                  faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
@@ -1400,6 +1403,14 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
                              uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st, const uint8_t *tn_flags)
 {
+    {   // trim_long (faqcs_trim_long_kernel.hip): a batch that holds a read of more than 1 024 bases; FAQCS_TRIM_LONG=1 sends every batch there (tests)
+        const char *e_long = getenv("FAQCS_TRIM_LONG"); // (read per launch: the tests switch it inside one process)
+        const bool force_long = e_long && atoi(e_long) != 0;
+        if (max_len > FAQCS_FAST_READ_LENGTH || force_long) {
+            g_last_trim_kernel = "trim_long";
+            return faqcs_launch_trim_long(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, counters, err, n_cu, st);
+        }
+    }
     {   // trim_lds (faqcs_trim_lds_kernel.hip): every byte from HBM once, through LDS; FAQCS_TRIM_LDS=0 switches it off
         static const bool lds_on = [] { const char *e = getenv("FAQCS_TRIM_LDS"); return !e || atoi(e) != 0; }();
         if (lds_on) {

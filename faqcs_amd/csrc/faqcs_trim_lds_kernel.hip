@@ -480,7 +480,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #pragma unroll
         for (int k = 0; k <= D; ++k) x.r[k] = lds_ld(qa + 4u * (uint32_t)k);
 #pragma unroll
-        for (int k = 0; k < D; ++k) { x.mv[k] = t_bmq[BMQ * vb + k]; x.mh[k] = t_bmq[BMQ * hi + k]; x.ml[k] = t_bmq[BMQ * lo + k]; }
+        for (int k = 0; k < D; ++k) { x.mv[k] = t_bmq[BMQ * vb + k]; x.mh[k] = t_bmq[BMQ * hi + k]; }
+        // row 0 of the mask table is all zeros, and a kept window that starts at the read's first base is the common case: the third
+        // row is fetched only when some read of this step is trimmed at its 5' end
+        if (__any(lo != 0)) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) x.ml[k] = t_bmq[BMQ * lo + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) x.ml[k] = 0u;
+        }
     };
     // position x quality cells: DATA = +1 pre / +1 post per base (undo: -1 post, for a read S-A vetoed afterwards).
     // A byte past the read belongs to the next read of the span or to the pad behind it (valid quality bytes both: its
@@ -554,9 +563,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         for (int k = 0; k <= D; ++k) r[k] = lds_ld(qa + 4u * (uint32_t)k);
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            const uint32_t mv = t_bm[BMW * vb + k], mh = t_bm[BMW * hi + k], ml = t_bm[BMW * lo + k];
+            const uint32_t mv = t_bm[BMW * vb + k], mh = t_bm[BMW * hi + k];
             w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & mv; // a byte past the read: 0, no class
-            inw[k] = mh ^ ml;                                           // 0xff: inside the kept window
+            inw[k] = mh;                                                // 0xff: inside the kept window
+        }
+        if (__any(lo != 0)) { // (row 0 of the mask table is all zeros: fetched only when some read of this step is trimmed at its 5' end)
+#pragma unroll
+            for (int k = 0; k < D; ++k) inw[k] ^= t_bm[BMW * lo + k];
         }
         uint32_t tp = 0, tq = 0;
 #pragma unroll

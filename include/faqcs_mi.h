@@ -44,7 +44,10 @@ enum {
 #define FAQCS_NCOMP_BIN 10001  /* NUM_COMPOSITION_BIN, FaQCs.h:20 */
 #define FAQCS_NCOMP_KIND 6     /* NucleotideCount fields A,T,C,G,N,GC, FaQCs.h:167-174 */
 #define FAQCS_SEGMENT_READS 32768 /* buffer_size, FaQCs.cpp:232,585 */
-#define FAQCS_MAX_READ_LENGTH 1024 /* longest read the HIP kernels take (the reference: int16 aligner, < 32 768) */
+#define FAQCS_MAX_READ_LENGTH 32767 /* longest read the HIP kernels take: the reference's aligner works in int16 (seq_overlap.h:80), and
+                                       faqcs_read_result holds window coordinates in 16 bits.  Reads of up to 1 024 bases run on the
+                                       chunked kernels (64 reads per wave pass); a batch with a longer read runs on trim_long /
+                                       adapter_overlap<1, 32768> (one wave per read) */
 #define FAQCS_ARENA_PAD_BEFORE 16 /* readable bytes required in front of / behind a batch's arenas (faqcs_batch) */
 #define FAQCS_ARENA_PAD_AFTER 64
 #define FAQCS_MAX_ADAPTERS 64
@@ -87,7 +90,7 @@ typedef struct faqcs_params {
     uint32_t kmer;                        /* -m, 2..31 */
     uint32_t split_size;                  /* --split_size */
     uint32_t num_subsample;               /* --subset (already doubled per options.cpp:506-523) */
-    uint32_t max_read_length;             /* capacity R of the per-position matrices (<= FAQCS_MAX_READ_LENGTH) */
+    uint32_t max_read_length;             /* capacity R of the per-position matrices (<= FAQCS_MAX_READ_LENGTH); no read of a batch may be longer */
     uint32_t n_adapters;                  /* 0 == !(filter_adapter || filter_phiX) */
     const char *const *adapter_seq;       /* n_adapters NUL-terminated IUPAC strings (Options::adapter[j].second) */
     uint64_t kmer_table_slots;            /* device hash-table capacity (0 = library default) */

@@ -41,7 +41,7 @@ struct Shim {
     vector<uint64_t> prev, cur;
     vector<string> adapter_names;
     int quality = 0;
-    uint32_t R = FAQCS_MAX_READ_LENGTH; // row capacity of the per-position matrices == longest read the HIP kernels take
+    uint32_t R = 1024;           // row capacity of the per-position matrices: grown (the context is rebuilt) when a call brings a longer read
     // reusable host arenas
     vector<uint8_t> seq, qual;
     vector<uint32_t> off;
@@ -147,8 +147,20 @@ void trim(vector<Read> &m_buffer, vector<size_t> &m_filter_stats,
           MAP<string, pair<size_t, size_t> > &m_adapter_stats, MAP<Word, size_t> &m_kmer_table, PlotInfo &m_info,
           Options &m_opt)
 {
-    ensure_ctx(m_opt);
     const uint32_t n = (uint32_t)m_buffer.size();
+    {   // the reference's matrices grow with the reads (trim.cpp:797-805,880); the context has a fixed row capacity: every accumulator
+        // of a call is handed to the caller at its end, so a longer read only needs a new context with more rows
+        size_t longest = 0;
+        for (uint32_t i = 0; i < n; ++i) longest = m_buffer[i].seq.size() > longest ? m_buffer[i].seq.size() : longest;
+        if (longest > FAQCS_MAX_READ_LENGTH) throw "trim_shim: reads of more than 32767 bases are not supported (seq_overlap.h:80 aligns in int16)";
+        if (longest > g.R) {
+            uint32_t r = g.R;
+            while (r < longest) r *= 2;
+            g.R = r > FAQCS_MAX_READ_LENGTH ? FAQCS_MAX_READ_LENGTH : r;
+            if (g.ctx) { faqcs_destroy(g.ctx); g.ctx = NULL; g.adapter_names.clear(); g.adapter_ptr.clear(); }
+        }
+    }
+    ensure_ctx(m_opt);
     // ---- vector<Read> (array of 3 std::string) -> structure of arrays ---------------------------------------
     size_t total = 0;
     for (uint32_t i = 0; i < n; ++i) total += m_buffer[i].seq.size();

@@ -103,6 +103,50 @@ def adversarial(n_pairs, seed=7, maxlen=150, id_prefix="R"):
     return r1, r2
 
 
+def long_reads(seed=51, n_pairs=36, maxlen=8000):
+    """Ragged reads of 20..8 000 bases from the adversarial recipe, plus hand-made ones: the longest read the drop-in takes (32 767),
+    1 025 bases (one past the chunked kernels), terminal N runs and low-quality tails longer than a 64-base piece, a low-complexity
+    read, lower-case stretches, an adapter near the end of a long read, and short reads in the same file."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    r1, r2 = [], []
+    for i in range(n_pairs):
+        for mate, out in ((1, r1), (2, r2)):
+            ml = int(rng.integers(1100, maxlen + 1)) if rng.random() < 0.7 else int(rng.integers(30, 1100))
+            s, q = _adv_read(rng, ml)
+            out.append((("@K%d/%d extra" % (i, mate)).encode(), s.tobytes(), q.tobytes()))
+
+    def put(lst, k, s, q):
+        lst[k] = (lst[k][0], bytes(s.tobytes()), bytes((np.asarray(q) + 33).astype(np.uint8).tobytes()))
+
+    L = 32767
+    s = ACGT[rng.integers(0, 4, L)]; q = rng.integers(12, 41, L); q[L - 700:] = 2
+    put(r1, 3, s, q)
+    L = 1025
+    put(r2, 3, ACGT[rng.integers(0, 4, L)], rng.integers(20, 41, L))
+    L = 2000
+    s = ACGT[rng.integers(0, 4, L)]; s[:200] = ord("N"); s[L - 300:] = ord("N"); q = rng.integers(25, 41, L)
+    put(r1, 5, s, q)
+    L = 5000
+    s = ACGT[rng.integers(0, 4, L)]; q = rng.integers(15, 41, L); q[2000:] = rng.integers(0, 5, L - 2000); q[:90] = 3
+    put(r2, 5, s, q)
+    L = 3000
+    put(r1, 7, np.resize(np.frombuffer(b"AT", np.uint8), L).copy(), rng.integers(20, 41, L))
+    L = 4100
+    s = ACGT[rng.integers(0, 4, L)]; s[1000:1400] |= 0x20; s[2000:2002] = ord("N"); s[3000:3003] = ord("N")
+    put(r2, 7, s, rng.integers(20, 41, L))
+    L = 6000
+    s = ACGT[rng.integers(0, 4, L)]
+    ad = np.frombuffer(ADV_ADAPTERS[1].encode(), np.uint8)
+    s[5800:5800 + len(ad)] = ad
+    put(r1, 9, s, rng.integers(25, 41, L))
+    L = 1500
+    put(r2, 9, np.full(L, ord("N"), np.uint8), rng.integers(25, 41, L))
+    L = 2500
+    s = ACGT[rng.integers(0, 4, L)]; s[s == ord("G")] = ord("G"); q = rng.integers(2, 41, L)
+    put(r1, 11, s, q)
+    return r1, r2
+
+
 def headline_arrays(n_reads, L=150, seed=20260101, adapter_frac=0.0, mate=1):
     """Vectorised section-8(d) generator: returns (seq[n,L] u8, qual[n,L] u8)."""
     rng = np.random.Generator(np.random.PCG64([seed, mate]))
@@ -199,6 +243,8 @@ def materialise(name, outdir):
         r1, r2 = adversarial(700, seed=21, maxlen=300, id_prefix="M")
     elif name == "long1000":  # ragged 20..1000-base reads (Ion Torrent / 454 lengths)
         r1, r2 = adversarial(260, seed=23, maxlen=1000, id_prefix="L")
+    elif name == "long8k":  # reads past 1 024 bases (long-read platforms, contigs): the one-wave-per-read kernels
+        r1, r2 = long_reads(seed=51)
     else:
         raise KeyError(name)
     write_fastq(p1, r1)

@@ -26,6 +26,7 @@ import make_fixtures  # noqa: E402
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "FaQCs_ref")
 CACHE = os.path.join(HERE, "_cache")
 CASES_DIR = os.path.join(HERE, "cases")
+BIG_TEXT = 128 * 1024  # a text output above this size is stored as md5 + size + line count
 
 # (case name, fixture, args).  {1} {2} {U} {D} {ART} are substituted.  -t 1 everywhere: SURVEY.md H1.
 P = ["-1", "{1}", "-2", "{2}", "-d", "{D}", "-t", "1", "--debug"]
@@ -71,6 +72,13 @@ CASES = [
     ("long1000_bwa_avgq", "long1000", P + ["--mode", "BWA", "--avg_q", "20", "-n", "3"]),
     ("long1000_hard_lc", "long1000", P + ["--mode", "HARD", "-q", "12", "--lc", "0.6", "--5end", "7", "--3end", "9"]),
     ("long1000_adapter_polyA", "long1000", P + ["--adapter", "--polyA", "--discard"]),
+    # reads of up to 32 767 bases (trim_long, adapter_overlap<1, 32768>); their position tables are stored as md5 (see collect_outputs)
+    ("long8k_default", "long8k", P),
+    ("long8k_adapter_polyA", "long8k", P + ["--adapter", "--polyA", "--discard"]),
+    ("long8k_hard_lc", "long8k", P + ["--mode", "HARD", "-q", "12", "--lc", "0.6", "--5end", "7", "--3end", "9"]),
+    ("long8k_bwa_avgq_n3", "long8k", P + ["--mode", "BWA", "--avg_q", "20", "-n", "3", "--out_ascii", "64"]),
+    ("long8k_kmer_replaceN", "long8k", P + ["--kmer_rarefaction", "--split_size", "10", "-q", "20", "--replace_to_N_q", "12", "--min_L", "30"]),
+    ("long8k_qc_only_5off", "long8k", P + ["--qc_only", "--5trim_off"]),
     # --stats is honoured (options.cpp:291-293,739-740): the statistics go to the named file instead of <prefix>.stats.txt
     ("adv_prefix_stats", "adv", P + ["--prefix", "SAMPLE7", "--stats", "{D}/custom.stats.txt"]),
     ("adv_single_dash_long_options", "adv", ["-1", "{1}", "-2", "{2}", "-d", "{D}", "-t", "1", "-debug", "-min_L", "40", "-q", "12", "-lc", "0.7", "-discard", "-substitute"]),
@@ -121,8 +129,12 @@ def collect_outputs(outdir):
         elif fn.endswith(".pdf"):
             continue
         else:
-            with open(path, "r", errors="replace") as f:
-                out["text"][fn] = f.read()
+            with open(path, "rb") as f:
+                data = f.read()
+            if len(data) > BIG_TEXT: # (the per-position tables of reads with tens of thousands of bases: megabytes of text)
+                out.setdefault("text_md5", {})[fn] = {"md5": hashlib.md5(data).hexdigest(), "bytes": len(data), "lines": data.count(b"\n")}
+            else:
+                out["text"][fn] = data.decode(errors="replace")
     return out
 
 

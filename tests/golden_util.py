@@ -33,6 +33,25 @@ def fixture_paths(fixture, cache):
     return make_fixtures.materialise(fixture, cache)
 
 
+def _compare_big_texts(case, outdir, have):
+    """Text outputs the case holds as md5 + size + line count (make_golden.BIG_TEXT: the position tables of very long reads)."""
+    bad = []
+    for fn, meta in case.get("text_md5", {}).items():
+        if fn not in have:
+            bad.append("missing " + fn)
+            continue
+        with open(os.path.join(outdir, fn), "rb") as f:
+            data = f.read()
+        if hashlib.md5(data).hexdigest() != meta["md5"]:
+            bad.append("%s: md5 mismatch (bytes %d vs %d, lines %d vs %d)" % (fn, len(data), meta["bytes"], data.count(b"\n"), meta["lines"]))
+    return bad
+
+
+def case_max_read_length(case):
+    """Row capacity the Python driver gives its engine for a case (the native CLI always uses FAQCS_MAX_READ_LENGTH)."""
+    return 32767 if case["fixture"] == "long8k" else 1024
+
+
 def run_case(case, cache, tmp_path, engine_factory, **kw):
     """Runs our host driver with the given engine on the case's command line; returns a list of
     human-readable mismatches against the reference outputs stored in the case (empty == parity)."""
@@ -57,6 +76,7 @@ def run_case(case, cache, tmp_path, engine_factory, **kw):
             gl, tl = got.splitlines(), text.splitlines()
             k = next((i for i in range(min(len(gl), len(tl))) if gl[i] != tl[i]), min(len(gl), len(tl)))
             bad.append("%s differs at line %d: got %r want %r" % (fn, k + 1, gl[k:k + 1], tl[k:k + 1]))
+    bad += _compare_big_texts(case, outdir, have)
     for fn, meta in case["fastq"].items():
         if fn not in have:
             bad.append("missing " + fn)
@@ -66,7 +86,7 @@ def run_case(case, cache, tmp_path, engine_factory, **kw):
         if hashlib.md5(data).hexdigest() != meta["md5"]:
             bad.append("%s: md5 mismatch (records %d vs %d, bytes %d vs %d)" % (
                 fn, data.count(b"\n") // 4, meta["records"], len(data), meta["bytes"]))
-    extra = {f for f in have if not f.endswith(".pdf")} - set(case["text"]) - set(case["fastq"])
+    extra = {f for f in have if not f.endswith(".pdf")} - set(case["text"]) - set(case["fastq"]) - set(case.get("text_md5", {}))
     if extra:
         bad.append("unexpected files: %s" % sorted(extra))
     return bad
@@ -87,6 +107,7 @@ def compare_outputs(case, outdir, rc, err_text):
             gl, tl = got.splitlines(), text.splitlines()
             k = next((i for i in range(min(len(gl), len(tl))) if gl[i] != tl[i]), min(len(gl), len(tl)))
             bad.append("%s differs at line %d: got %r want %r" % (fn, k + 1, gl[k:k + 1], tl[k:k + 1]))
+    bad += _compare_big_texts(case, outdir, have)
     for fn, meta in case["fastq"].items():
         if fn not in have:
             bad.append("missing " + fn)

@@ -156,20 +156,69 @@ def test_phix_reads_match_oracle(args, maxlen):
     compare_engines(opt, reads, R=256 if maxlen <= 256 else 1024, seg_size=211)
 
 
-def test_long_read_limits():
-    """Exactly FAQCS_MAX_READ_LENGTH bases is accepted, one more is refused loudly (no silent truncation)."""
+def test_longest_read():
+    """Exactly FAQCS_MAX_READ_LENGTH (32 767) bases is accepted, one more is refused loudly (no silent truncation)."""
     from faqcs_amd.engine import FaqcsError
 
-    opt = parse_args(["-u", "x", "-d", "y", "--min_L", "1"])
     L = capi.MAX_READ_LENGTH
+    rng = np.random.Generator(np.random.PCG64([L, SEED]))
+    s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)]
+    q = rng.integers(5, 42, L) + 33
+    q[L - 900:] = 35
+    reads = [(b"@e", s.tobytes(), q.astype(np.uint8).tobytes()), (b"@e", b"N" * L, bytes([33 + 20] * L)), (b"@e", b"ACGT" * 30, bytes([70] * 120))]
+    for args in ([], ["--adapter", "--polyA"], ["--mode", "BWA", "--min_L", "1"], ["--kmer_rarefaction", "--split_size", "1"]):
+        hip, ora = compare_engines(parse_args(["-u", "x", "-d", "y"] + args), reads, R=L, seg_size=1)
+        if "--kmer_rarefaction" in args:
+            hip.kmer_end_table()
+            ora.kmer_end_table()
+            assert len(hip.kmer_points()) == 3 and (hip.kmer_points() == ora.kmer_points()).all()
+            h1, h2 = hip.kmer_histogram(), ora.kmer_histogram()
+            assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
+    with pytest.raises(FaqcsError) as ei:
+        compare_engines(parse_args(["-u", "x", "-d", "y"]), [(b"@e", b"A" * (L + 1), bytes([70] * (L + 1)))], R=L)
+    assert ei.value.code == capi.E_INVAL
+
+
+@pytest.mark.parametrize("args", OPTION_SETS, ids=lambda a: " ".join(a) or "default")
+@pytest.mark.parametrize("kind,maxlen", [("adv", 1025), ("ragged", 3000), ("adv", 9000)])
+def test_reads_past_1024_bases_match_oracle(args, kind, maxlen):
+    """Batches that hold a read of more than 1 024 bases: trim_long and adapter_overlap<1, 32768> (one wave per read) against the
+    oracle, every option set; short reads ride in the same batches."""
+    rng = np.random.Generator(np.random.PCG64([13, len(kind), maxlen, OPTION_SETS.index(args), SEED]))
+    opt = parse_args(["-u", "x", "-d", "y"] + args)
+    n = 40 if "--adapter" in args else 120
+    reads = random_batch(rng, n, maxlen, kind)
+    if kind == "adv":  # (the adversarial recipe makes most reads `maxlen` long: mix in every scale)
+        reads += random_batch(rng, n // 2, 150, "adv") + random_batch(rng, n // 4, maxlen // 3, "adv")
+    hip, _ = compare_engines(opt, reads, R=16384, seg_size=37)
+    import ctypes as C
+
+    kt = capi.KernelTimes()
+    hip.lib.faqcs_kernel_report(hip.ctx, C.byref(kt))
+    assert (kt.trim_kernel or b"").decode() == "trim_long"
+
+
+@pytest.mark.parametrize("args", OPTION_SETS, ids=lambda a: " ".join(a) or "default")
+@pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 250), ("adv", 700)])
+def test_trim_long_equals_the_chunked_kernels_on_short_reads(args, kind, maxlen, monkeypatch):
+    """FAQCS_TRIM_LONG=1 sends every batch to trim_long: the same results as the oracle (and therefore as the chunked kernels) on the
+    shapes the rest of the suite runs, where a wave's 64 lanes mostly idle past the read's end and several reads share a 64-base piece."""
+    monkeypatch.setenv("FAQCS_TRIM_LONG", "1")
+    rng = np.random.Generator(np.random.PCG64([17, len(kind), maxlen, OPTION_SETS.index(args), SEED]))
+    opt = parse_args(["-u", "x", "-d", "y"] + args)
+    reads = random_batch(rng, 300 if "--adapter" in args else 1200, maxlen, kind)
+    compare_engines(opt, reads, R=256 if maxlen <= 256 else 1024, seg_size=211)
+
+
+def test_long_read_limits():
+    """The chunked kernels' own limit: exactly 1 024 bases stays on them, constant qualities included."""
+    opt = parse_args(["-u", "x", "-d", "y", "--min_L", "1"])
+    L = capi.FAST_READ_LENGTH
     ok = [(b"@e", (b"ACGT" * 300)[:L], bytes([33 + 38] * (L - 40) + [35] * 40)), (b"@e", b"N" * L, bytes([33 + 20] * L))]
     compare_engines(opt, ok, R=L)
     # constant quality (FASTA converted to FASTQ): every read hits the same position x quality cells, the worst case for
     # the 8-bit packed LDS counters of the 1024-wide kernel
     compare_engines(opt, [(b"@e", (b"ACGGT" * 205)[:L], bytes([33 + 40] * L))] * 1500 + [(b"@e", b"ACGT" * 150, bytes([33 + 40] * 600))] * 300, R=L)
-    with pytest.raises(FaqcsError) as ei:
-        compare_engines(opt, [(b"@e", b"A" * (L + 1), bytes([70] * (L + 1)))], R=L)
-    assert ei.value.code == capi.E_INVAL
 
 
 @pytest.mark.parametrize("args", [OPTION_SETS[i] for i in (0, 1, 2, 8, 10, 13, 15, 18, 21, 23)], ids=lambda a: " ".join(a) or "default")
@@ -244,10 +293,10 @@ def test_quality_error_is_reported():
 @pytest.mark.parametrize("name", __import__("golden_util").case_names())
 def test_golden_cases_on_gpu(name, fixture_cache, tmp_path):
     """The reference's own outputs (QC.stats.txt, trimmed FASTQ, --debug tables) reproduced by the HIP path."""
-    from golden_util import load_case, run_case
+    from golden_util import case_max_read_length, load_case, run_case
 
     case = load_case(name)
-    bad = run_case(case, fixture_cache, tmp_path, hip_factory, max_read_length=1024)
+    bad = run_case(case, fixture_cache, tmp_path, hip_factory, max_read_length=case_max_read_length(case))
     assert not bad, "\n".join(bad)
     assert case["exit_code"] != 0 or _native_loaded()  # (an input error can stop the run before any read reaches the engine)
 
