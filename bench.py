@@ -301,7 +301,7 @@ def main():
         a.pairs = 25e6 if a.config == "kmer" else (125e6 if (a.config == "plain" and world == 8) else 100e6)
     opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "1000000"]}.get(a.config, [])
     opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
-    eng = HipEngine(opt, 256 if L <= 256 else capi.MAX_READ_LENGTH, 33, device=local,
+    eng = HipEngine(opt, 256 if L <= 256 else (capi.FAST_READ_LENGTH if L <= capi.FAST_READ_LENGTH else capi.MAX_READ_LENGTH), 33, device=local,
                     kmer_table_slots=(1 << 31) if a.config == "kmer" else 0)
     lib = eng.lib
 
@@ -311,7 +311,7 @@ def main():
     need = n_reads * (2 * L + 12) + (1 << 30)
     if need > free * 0.9:
         n_reads = int((free * 0.9 - (1 << 30)) // (2 * L + 12))
-    batch = min(a.batch_reads, (0xFFFFFFFF - 4096) // L)
+    batch = min(a.batch_reads, (0xFFFFFFFF - max(4096, L)) // L)
     batches = []
     first = rank * n_reads
     done = 0

@@ -11,22 +11,34 @@
 // "its" read with per-lane LDS addresses (dynamic indexing that a register-resident copy cannot give) -- as two ALIGNED
 // dwords and one v_alignbyte per four bytes: a misaligned ds_read_b32 is legal on gfx950 but serialises the wave.
 //
-//   Q-A  one read per lane      terminal-N patch (in place, rare), sum + range check of the qualities four bytes per
-//                               instruction, the two BWA_plus walks exactly as trim.cpp:714-793 states them -- every lane
-//                               starts at ITS window end and reads the dword under its own cursor --, length filters
-//   Q-B  8 lanes per read       position x quality accumulation: one ds_add per base, address = raw byte x row stride
-//                               (v_mul_u32_u24 with an SDWA byte select) + lane base, data = one v_perm_b32 of two byte masks
-//                               (position inside the read -> pre count, inside the kept window -> post count)
-//   S-A  one read per lane      base classes (LDS table, 8-bit one-hot A,T,C,G fields + upper-case-N bit), counts before /
-//                               inside the kept window, poly-N, low complexity -> the read's verdict
-//   S-B  8 lanes per read       position x base accumulation in registers (6-bit fields): ONE 8-byte table entry yields the pre
-//                               and the post increment; a base outside the kept window is looked up at (byte ^ 1), whose entry
-//                               carries that base's pre increment and no post increment (b and b ^ 1 are never both bases)
-//   epilogue, one read per lane result word, composition records, small histograms, FilterStat (chunk_epilogue)
+//   Q, one read per lane        terminal-N patch (in place, rare; whether a read starts / ends with N comes from the batch's
+//                               terminal_n flags, or from two byte loads per read when the caller has none), a flat range check of the
+//                               whole slot 16 bytes per lane, the two BWA_plus walks exactly as trim.cpp:714-793 states them -- every
+//                               lane starts at ITS window end and reads the dword under its own cursor --, length filters
+//   Q-B, 8 lanes per read       position x quality accumulation: one ds_add per base (20 positions per lane, the rows of a half wave
+//                               rotated against each other: conflict-free, below), address = raw byte x row stride (v_mul_u32_u24 with
+//                               an SDWA byte select) + lane base, data = one v_perm_b32 of two byte masks (position inside the read ->
+//                               pre count, inside the kept window -> post count); the reads' quality sums fall out of the same bytes
+//   S, 8 lanes per read         ONE pass over the staged bases: an 8-byte table entry per base carries the pre and the post increment
+//                               of the position x base registers (6-bit fields per class); a base outside the kept window is looked up
+//                               at (byte | 0x80), whose entry has the pre increment only.  The same increments, summed over the lane's
+//                               19 positions and then over the 8 lanes of the read (DPP), ARE the read's base counts before / inside
+//                               the window -- what a separate lane-per-read class pass (S-A, round 2) used to compute.  Two adjacent
+//                               upper-case N (the default -n 2) are found by a SWAR test on the same registers, only in reads with >= 2 N
+//   verdicts, one read per lane poly-N, average quality, low complexity (dinucleotide counts only for reads whose two commonest bases
+//                               both reach the threshold) -> the read's verdict
+//   epilogue, one read per lane result word, composition records, small histograms (equal cells of a chunk combined by one lane),
+//                               FilterStat sums kept in registers across chunks (chunk_epilogue)
 //
-// The post-trim quality cells are added in Q-B, before S-A can veto the read (poly-N / low complexity / average quality):
-// a vetoed read is rare, and its post cells are taken back by a small corrective pass over the chunk (Q-B with a negative
-// increment) after the bases have been judged.
+// The post-trim cells are added before a read can be vetoed (poly-N / low complexity / average quality): a vetoed read is rare,
+// and its post cells are taken back by corrective passes over the chunk (S and Q-B with negative increments) afterwards.
+//
+// Work distribution: blocks claim GROUPS of NW consecutive chunks from a global counter, waves claim chunks of the block's groups
+// from an LDS counter (a 4-entry ring of group ids), so a block that falls behind simply takes fewer chunks -- the static
+// chunk -> wave map of round 2 ended every launch with a tail of idle CUs.  The offsets / DMA of a wave's NEXT chunk are issued
+// under the epilogue of the current one.  Every FLUSH_CHUNKS chunks the block adds its LDS accumulators to ITS row of a partial-sum
+// array in global memory (plain adds, no atomics: the row is private to the block) and fold_partials, launched behind the kernel,
+// adds the rows to the u64 counter block.
 //
 // Dispatch (faqcs_launch_trim_lds at the end of the file): every option set except --replace_to_N_q; batches whose longest
 // read is a multiple of 32 bases stay on trim_tpr (LDS bank stride of the lane-per-read passes).
@@ -61,8 +73,8 @@ template <int C, int NW> struct LdsCfg {
     static constexpr int ND = (W + 3) / 4;                     // dwords of the longest read
     static constexpr int NP = (W + 15) / 16;                   // 16-byte pieces (the out-of-line exact passes)
     static constexpr int NWORD = (ND * 4 + 31) / 32;
-    static constexpr int O_T2 = (Row::LDS_DWORDS + 3) & ~3;    // [256][2] S-A: A,T,C,G one-hot in 8-bit fields ; isN(upper) | isN(any) << 1
-    static constexpr int O_T3 = O_T2 + 512;                    // [256][2] S-B: 6-bit count fields, pre ; post (entry[b ^ 1]: b outside the kept window)
+    static constexpr int O_T2 = (Row::LDS_DWORDS + 3) & ~3;    // [256][2] (exact passes of rare reads) A,T,C,G one-hot in 8-bit fields ; isN(upper) | isN(any) << 1
+    static constexpr int O_T3 = O_T2 + 512;                    // [256][2] S: 6-bit count fields, pre ; post (entry[b | 0x80]: b outside the kept window, pre only)
     static constexpr int O_CTR = O_T3 + 512;                   // [8] the block's chunk queue: [0] next unclaimed chunk number, [1] the block's chunk
                                                                // count once known, [4..7] ring: group number << 20 | group id
     static constexpr int O_TBQ = O_CTR + 8;                    // (ROT) [4][CQ + 1][8] rotated byte masks "positions < vb" of Q-B
@@ -562,15 +574,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #pragma unroll
         for (int k = 0; k <= D; ++k) r[k] = lds_ld(qa + 4u * (uint32_t)k);
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const uint32_t mv = t_bm[BMW * vb + k], mh = t_bm[BMW * hi + k];
-            w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & mv; // a byte past the read: 0, no class
-            inw[k] = mh;                                                // 0xff: inside the kept window
-        }
-        if (__any(lo != 0)) { // (row 0 of the mask table is all zeros: fetched only when some read of this step is trimmed at its 5' end)
+        for (int k = 0; k < D; ++k) inw[k] = t_bm[BMW * hi + k] ^ t_bm[BMW * lo + k]; // 0xff: inside the kept window
+        // (the third row is NOT made conditional here as it is in load_b: with both conditional the allocator spills two registers per
+        // chunk to scratch -- 8.4 -> 8.8 G reads/s without, same-box A/B profiles/r3g/ab_cond.txt, and 15 B/read of scratch traffic)
 #pragma unroll
-            for (int k = 0; k < D; ++k) inw[k] ^= t_bm[BMW * lo + k];
-        }
+        for (int k = 0; k < D; ++k) w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & t_bm[BMW * vb + k]; // a byte past the read: 0, no class
         uint32_t tp = 0, tq = 0;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
