@@ -347,8 +347,11 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     HIPCHK(hipMemset(c->d_counters, 0, c->lay.total * sizeof(uint64_t)));
     HIPCHK(hipMalloc((void **)&c->d_err, 256)); // [0] error bits ; bytes 64.. : 16 diagnostic u64 words (FAQCS_LDS_STAMPS builds)
     HIPCHK(hipMemset(c->d_err, 0, 256));
-    HIPCHK(hipMalloc((void **)&c->d_partials, (size_t)c->n_cu * 2 * FAQCS_PARTIAL_ROW * sizeof(uint32_t)));
-    HIPCHK(hipMemset(c->d_partials, 0, (size_t)c->n_cu * 2 * FAQCS_PARTIAL_ROW * sizeof(uint32_t)));
+    {   // trim_lds: one row per block and flush, then the rows each block used
+        const size_t dwords = (size_t)c->n_cu * FAQCS_PARTIAL_FLUSHES * FAQCS_PARTIAL_ROW + (size_t)c->n_cu;
+        HIPCHK(hipMalloc((void **)&c->d_partials, dwords * sizeof(uint32_t)));
+        HIPCHK(hipMemset(c->d_partials, 0, dwords * sizeof(uint32_t)));
+    }
 
     if (p->n_adapters) {
         std::vector<uint8_t> bits; std::vector<uint32_t> start(1, 0);
@@ -394,6 +397,7 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     if (const char *e = getenv("FAQCS_DBG")) d.dbg = (uint32_t)strtoul(e, nullptr, 0);
     d.lc_thr = c->d_lcthr; d.avgq_min_v = c->d_avgq; d.comp_norm = c->d_norm; d.div_magic = c->d_magic; d.base_tab = c->d_basetab;
     d.partials = c->d_partials;
+    d.partial_rows = c->d_partials + (size_t)c->n_cu * FAQCS_PARTIAL_FLUSHES * FAQCS_PARTIAL_ROW;
     d.lay = c->lay;
 
     c->kmer_active = p->kmer_rarefaction ? 1 : 0;

@@ -36,13 +36,15 @@ struct DevParams {
     const uint32_t *div_magic;    // floor(2^32/len)+1: floor(V/len) == mulhi(V, magic), V < 2^16 (trim.cpp:254,539 int())
     const float    *comp_norm;    // float(10000)/len                                             (trim.cpp:860)
     const uint32_t *base_tab;     // [256] per input byte: 6-bit count fields A,T,C,G,N | isG<<30 | isN<<31
-    uint32_t *partials;           // [n_cu][2][FAQCS_PARTIAL_ROW] per-block partial sums of the LDS accumulators (trim_lds: flush without
+    uint32_t *partials;           // [n_cu][FAQCS_PARTIAL_FLUSHES][FAQCS_PARTIAL_ROW] + [n_cu] rows used: a row per block and flush (trim_lds: flush without
                                   // global atomics; a fold kernel behind the trim kernel adds them to the counter block and zeroes them)
+    uint32_t *partial_rows;       // [n_cu] rows of `partials` each block of the last trim_lds launch wrote
     faqcs_layout lay;
 };
 
 enum { FS_SLOTS = 32 };
-enum { FAQCS_PARTIAL_ROW = 8192 }; // >= RowCfg<19, 8>::N_ZERO: dwords of one half (low / high 16 bits) of a block's partial-sum row
+enum { FAQCS_PARTIAL_ROW = 8192 };   // >= RowCfg<19, 8>::N_ZERO rounded up to 4: dwords of one flushed copy of a block's LDS accumulators
+enum { FAQCS_PARTIAL_FLUSHES = 8 };  // flushes (rows) a block has room for in one launch: it stops claiming chunks before it would need more
 
 // base_tab fields (6 bits each so a lane can sum up to 63 reads before flushing)
 #define BT_SHIFT(code) (6 * (code))

@@ -242,35 +242,34 @@ __device__ __noinline__ ExactB exact_bases(const uint8_t *__restrict__ seq, cons
 
 constexpr int lds_waves(int C) { return C <= 19 ? 12 : 8; }
 
-// LDS accumulators -> this block's OWN row of partial sums in global memory (coalesced adds without a return value: only
-// this block touches the row), low and high half-words apart; fold_partials, launched behind the trim kernel, adds the rows of all
-// blocks to the u64 counter block and zeroes them.  (The direct flush of faqcs_trim_common.h costs one 64-bit global atomic per
-// non-zero counter and block -- 256 blocks x ~14 000 counters, each on a sector of its own, all at the end of the launch: 15 % of
-// the kernel time, measured with the section stamps.)
+// LDS accumulators -> a row of global memory that belongs to THIS block and THIS flush, as plain coalesced 16-byte stores of the
+// cells as they are (pre count in the low, post count in the high half-word); fold_partials, launched behind the trim kernel, adds
+// the rows of all blocks to the u64 counter block.  History: the direct flush of faqcs_trim_common.h costs one 64-bit global atomic
+// per non-zero counter and block -- 256 blocks x ~14 000 counters, each on a sector of its own, all at the end of the launch: 15 % of
+// the kernel time; one row per block with no-return atomic adds (first form of this function) still sent 2 atomics per non-zero
+// cell and block to the memory side, all blocks at once at the end of a launch -- the chip retires 13.5 G of them per second.
 template <int C, int LPR, int NW>
 __device__ __noinline__ void flush_block_partial(uint32_t *smem, uint32_t *__restrict__ row, const int tid)
 {
     using Cfg = RowCfg<C, LPR, lds_wq(C)>;
-    static_assert(Cfg::N_ZERO <= FAQCS_PARTIAL_ROW, "partial-sum row");
+    constexpr int N4 = (Cfg::N_ZERO + 3) / 4; // (the dwords behind N_ZERO belong to the base table: copied along, never read back)
+    static_assert(N4 * 4 <= FAQCS_PARTIAL_ROW, "partial-sum row");
     __syncthreads();
-    for (int i = tid; i < Cfg::N_ZERO; i += NW * 64) {
-        const uint32_t v = smem[i];
-        if (v) {
-            smem[i] = 0;
-            // (no-return atomics on the block's own row: nothing to wait for, unlike a load-add-store per cell)
-            if (v & 0xffffu) __hip_atomic_fetch_add(&row[i], v & 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v >> 16) __hip_atomic_fetch_add(&row[FAQCS_PARTIAL_ROW + i], v >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    for (int i = tid; i < N4; i += NW * 64) {
+        const uint4 v = reinterpret_cast<const uint4 *>(smem)[i];
+        reinterpret_cast<uint4 *>(row)[i] = v;
+        if (4 * i + 3 < Cfg::N_ZERO) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+        else for (int k = 4 * i; k < Cfg::N_ZERO; ++k) smem[k] = 0u;
     }
     __syncthreads();
 }
 
-// One thread per LDS accumulator cell i and sixteenth of the rows: the sum over the blocks' partial rows -> the counter block (the index mapping of
-// flush_block in faqcs_trim_common.h); the rows are left zeroed for the next launch.  Only one thread adds to a given counter and
-// kernels on one stream do not overlap, but the add stays atomic: another context's kernels may share the block in a caller's design.
+// One thread per LDS accumulator cell i and sixteenth of the rows: the sum over the rows the blocks flushed -> the counter block (the index
+// mapping of flush_block in faqcs_trim_common.h).  Only one thread adds to a given counter and kernels on one stream do not overlap,
+// but the add stays atomic: another context's kernels may share the block in a caller's design.
 template <int C, int LPR>
-__global__ __launch_bounds__(1024) void fold_partials(uint32_t *__restrict__ partials, const uint32_t n_rows, uint64_t *__restrict__ counters, const uint32_t R,
-                                                      uint32_t *__restrict__ g_next)
+__global__ __launch_bounds__(1024) void fold_partials(const uint32_t *__restrict__ partials, const uint32_t *__restrict__ rows_used, const uint32_t n_blocks,
+                                                      uint64_t *__restrict__ counters, const uint32_t R, uint32_t *__restrict__ g_next)
 {
     using Cfg = RowCfg<C, LPR, lds_wq(C)>;
     constexpr int W = Cfg::W;
@@ -279,12 +278,12 @@ __global__ __launch_bounds__(1024) void fold_partials(uint32_t *__restrict__ par
     const int i = blockIdx.x * 64 + (threadIdx.x & 63); // 64 cells x 16 interleaved sets of rows per block
     unsigned long long lo = 0, hi = 0;
     if (i < Cfg::N_ZERO) {
-#pragma unroll 8
-        for (uint32_t b = threadIdx.x >> 6; b < n_rows; b += 16) {
-            uint32_t *row = partials + (size_t)b * 2 * FAQCS_PARTIAL_ROW;
-            const uint32_t x = row[i], y = row[FAQCS_PARTIAL_ROW + i];
-            if (x) { row[i] = 0; lo += x; }
-            if (y) { row[FAQCS_PARTIAL_ROW + i] = 0; hi += y; }
+        const bool halves = i < Cfg::O_BQPRE; // two 16-bit counters per cell (the other cells are one 32-bit number)
+#pragma unroll 4
+        for (uint32_t r = threadIdx.x >> 6; r < n_blocks * FAQCS_PARTIAL_FLUSHES; r += 16) {
+            if (r % FAQCS_PARTIAL_FLUSHES >= rows_used[r / FAQCS_PARTIAL_FLUSHES]) continue;
+            const uint32_t x = partials[(size_t)r * FAQCS_PARTIAL_ROW + i];
+            if (halves) { lo += x & 0xffffu; hi += x >> 16; } else lo += x;
         }
     }
     part[0][threadIdx.x >> 6][threadIdx.x & 63] = lo;
@@ -322,12 +321,12 @@ __global__ __launch_bounds__(1024) void fold_partials(uint32_t *__restrict__ par
         const uint32_t k = (uint32_t)(i - Cfg::O_RQ);
         if (k < FAQCS_NQ) { add(pre_read_qhist + k, lo); add(post_read_qhist + k, hi); }
     } else if (i < Cfg::O_BQPOST) { // 32-bit cells: the two halves of one number
-        add(pre_base_qhist + (uint32_t)(i - Cfg::O_BQPRE), lo + (hi << 16));
+        add(pre_base_qhist + (uint32_t)(i - Cfg::O_BQPRE), lo);
     } else if (i < Cfg::O_FS) {
-        add(post_base_qhist + (uint32_t)(i - Cfg::O_BQPOST), lo + (hi << 16));
+        add(post_base_qhist + (uint32_t)(i - Cfg::O_BQPOST), lo);
     } else {
         const uint32_t k = (uint32_t)(i - Cfg::O_FS);
-        if (k < FAQCS_NUM_STAT) add(filter_stats + k, lo + (hi << 16));
+        if (k < FAQCS_NUM_STAT) add(filter_stats + k, lo);
     }
 }
 
@@ -423,6 +422,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     // the LDS cells take FLUSH_CHUNKS x 64 <= 65535 increments in between (chunks are claimed in order, so a wave that holds a chunk
     // >= k * FLUSH_CHUNKS waits at flush k while exactly the chunks below it are being finished)
     constexpr uint32_t FLUSH_CHUNKS = 65535u / 64u / NW * NW;
+    constexpr uint32_t MAX_GROUPS = (uint32_t)FAQCS_PARTIAL_FLUSHES * FLUSH_CHUNKS / NW; // groups a block takes at most: one flush row per FLUSH_CHUNKS chunks
     constexpr uint32_t REG_FLUSH_EVERY = 7; // 6-bit fields: 7 chunks x 8 reads per row <= 63
     constexpr uint32_t NO_CHUNK = 0xffffffffu;
     auto lds_word = [&](const int i) { return uniu(*(volatile const __attribute__((address_space(3))) uint32_t *)(size_t)(uint32_t)((T::O_CTR + i) * 4)); };
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #pragma unroll 1
             while (n_flushed < due) {
                 spill_base_regs();
-                flush_block_partial<C, LPR, NW>(smem, P.partials + (size_t)blockIdx.x * 2 * FAQCS_PARTIAL_ROW, tid);
+                flush_block_partial<C, LPR, NW>(smem, P.partials + ((size_t)blockIdx.x * FAQCS_PARTIAL_FLUSHES + n_flushed) * FAQCS_PARTIAL_ROW, tid);
                 ++n_flushed; since_spill = 0;
             }
         }
@@ -717,7 +717,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         if (lane == 0) c_next = __hip_atomic_fetch_add((lds_u32_mut)(size_t)(uint32_t)(T::O_CTR * 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         c_next = uniu(c_next);
         // the first chunk of group number L: ask for the id of group number L + 1 (published below, behind this chunk's loads)
-        const bool fetch_group = c_next % NW == 0 && c_next < lds_word(1);
+        // (a block has FAQCS_PARTIAL_FLUSHES rows to flush into: before it would need another one it stops asking for groups, and the
+        // blocks that have room take what is left -- faqcs_launch_trim_lds makes sure they have)
+        const bool at_group_start = c_next % NW == 0 && c_next < lds_word(1);
+        const bool fetch_group = at_group_start && c_next / NW + 1u < MAX_GROUPS;
         uint32_t g_new = 0;
         if (fetch_group && lane == 0) g_new = atomicAdd(g_next, 1u);
         const uint32_t chunk_next = chunk_of(c_next);
@@ -749,8 +752,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #endif
             fetch_offsets(chunk_next);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (fetch_group) { // publish group number L + 1 of the block, or the block's chunk count when the launch has no group left
-                const uint32_t L1 = c_next / NW + 1u, gid = gridDim.x + uniu(g_new);
+            if (at_group_start) { // publish group number L + 1 of the block, or the block's chunk count when the launch has no group left
+                const uint32_t L1 = c_next / NW + 1u, gid = fetch_group ? gridDim.x + uniu(g_new) : n_groups;
                 if (lane == 0) {
                     if (gid < n_groups) *(volatile __attribute__((address_space(3))) uint32_t *)(size_t)(uint32_t)((T::O_CTR + 4 + (int)(L1 & 3u)) * 4) = ((L1 & 0xfffu) << 20) | gid;
                     else *(volatile __attribute__((address_space(3))) uint32_t *)(size_t)(uint32_t)((T::O_CTR + 1) * 4) = L1 * NW;
@@ -1300,6 +1303,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         c_cur = c_next; chunk_cur = chunk_next;
     }
     if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
+    if (tid == 0) P.partial_rows[blockIdx.x] = n_flushed; // rows of P.partials this block wrote (fold_partials)
 #ifdef FAQCS_LDS_STAMPS
     if (lane == 0) {
 #pragma unroll
@@ -1354,10 +1358,12 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
     uint32_t grid = (chunks + NW - 1) / NW;
     if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu; // one block per CU: its LDS holds a slot per wave
     if (grid == 0) return hipSuccess;
+    // every block can take FAQCS_PARTIAL_FLUSHES x 1020 chunks: a launch the blocks could not take between them goes to another kernel
+    if ((uint64_t)chunks > (uint64_t)grid * FAQCS_PARTIAL_FLUSHES * (65535u / 64u / NW * NW) * 3 / 4) return hipErrorNotSupported;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
                        reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err, tn_flags);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8, lds_wq(C)>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, grid, counters, P.R, err + 8);
+    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8, lds_wq(C)>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, P.partial_rows, grid, counters, P.R, err + 8);
     return hipGetLastError();
 }
 
