@@ -266,7 +266,10 @@ def main():
     if world != a.gpus:
         raise SystemExit("bench: --gpus %d disagrees with WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (a.gpus, world))
     backend = os.environ.get("FAQCS_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # under torch.distributed.run the process group is formed even for ONE rank: `--nproc-per-node 1` on a one-GPU box then runs the very
+    # code an 8-GPU launch runs (RCCL communicator, counter all-reduce on a torch-owned tensor, MAX of the step times)
+    use_dist = world > 1 or "WORLD_SIZE" in os.environ
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -288,7 +291,7 @@ def main():
 
     if rank == 0:
         g.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     from faqcs_amd import _capi as capi
@@ -374,18 +377,18 @@ def main():
             pts, _hist = kx.finish(kmer_points_seq, n_reads * world)
             kmer_last["points"] = len(pts)
             kmer_last["distinct"], kmer_last["total"] = (pts[-1][1], pts[-1][2]) if pts else (0, 0)
-        if world > 1:
+        if use_dist:
             parallel.allreduce_counters_device(eng)
         else:
             eng.sync()
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     ranks_seen = [[rank, local]]
-    if world > 1:
+    if use_dist:
         got = [None] * world
         dist.all_gather_object(got, [rank, local, torch.cuda.get_device_properties(local).name])
         ranks_seen = got
@@ -400,7 +403,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -512,7 +515,7 @@ def main():
             out["e2e"] = e2e_run(opt_args, es, eq, L, ne)
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -317,7 +317,7 @@ def test_kmer_matches_oracle():
         assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
 
 
-def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150):
+def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150, backend="gloo"):
     import os
     import sys
 
@@ -333,7 +333,9 @@ def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150):
     from faqcs_amd import driver, parallel
     from faqcs_amd.engine import HipEngine
 
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     rng = np.random.Generator(np.random.PCG64(4242))
     reads = random_batch(rng, n_reads, maxlen, "adv")
@@ -386,7 +388,7 @@ def test_two_rank_kmer_exchange(args, n_reads, maxlen, tmp_path):
     assert open(out).read() == "ok", open(out).read()
 
 
-def _counter_rank(rank, world, port, args, n_reads, out):
+def _counter_rank(rank, world, port, args, n_reads, out, backend="gloo"):
     import os
     import sys
 
@@ -402,7 +404,9 @@ def _counter_rank(rank, world, port, args, n_reads, out):
     from faqcs_amd import driver, parallel
     from faqcs_amd.engine import HipEngine
 
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     rng = np.random.Generator(np.random.PCG64(777))
     reads = random_batch(rng, n_reads, 150, "adv")
@@ -447,6 +451,28 @@ def test_two_rank_hip_counters_allreduce(args, tmp_path):
     assert open(out).read() == "ok", open(out).read()
 
 
+def test_rccl_code_paths_on_one_rank(tmp_path):
+    """The `nccl` (= RCCL) branches of parallel.py -- the counter all-reduce on a torch-owned CUDA tensor, the device all-to-all of
+    the k-mer items, the epoch-histogram all-reduce -- need one GPU per rank, and a test box has one GPU: they run here with a
+    process group of ONE rank, which still goes through RCCL's communicator setup, its registration of the staging tensors and its
+    collective kernels on the real device (the two-rank tests above use gloo with both ranks on this GPU)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    for fn, args in ((_counter_rank, (["--adapter", "--polyA"], 2000)), (_kmer_rank, (["--kmer_rarefaction", "--split_size", "300", "--subset", "4"], 2000, 333))):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        out = str(tmp_path / ("result_%s.txt" % fn.__name__))
+        if fn is _counter_rank:
+            mp.spawn(fn, args=(1, port, args[0], args[1], out, "nccl"), nprocs=1, join=True)
+        else:
+            mp.spawn(fn, args=(1, port, args[0], args[1], args[2], out, 150, "nccl"), nprocs=1, join=True)
+        assert open(out).read() == "ok", open(out).read()
+
+
 def test_bench_gpus_2_runs_two_ranks(tmp_path):
     """`bench.py --gpus 2` with no launcher must START two ranks (here sharing the one GPU over gloo, FAQCS_BENCH_SHARE_GPU=1)
     and say so in its line; a disagreement between --gpus and WORLD_SIZE is an error, not a silent 1-GPU run."""
@@ -466,6 +492,31 @@ def test_bench_gpus_2_runs_two_ranks(tmp_path):
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--pairs", "1e6"], env=env2,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r2.returncode != 0 and b"disagrees" in r2.stderr
+
+
+def test_bench_under_the_drivers_launcher_with_one_rank():
+    """The command line the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
+    with N = 1: bench.py then forms the `nccl` process group, all-reduces the counter block through RCCL every step and takes the MAX of
+    the step times, exactly as on an 8-GPU node."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FAQCS_BENCH_SHARE_GPU", "FAQCS_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--pairs", "4e6", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--e2e-pairs", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    line = json.loads([l for l in r.stdout.decode().strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["kernel"] == "trim_lds"
 
 
 def test_full_size_properties():
