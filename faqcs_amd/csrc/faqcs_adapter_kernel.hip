@@ -679,13 +679,22 @@ hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const u
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((adapter_overlap<NW, 1024>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
                            n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
-    } else if (max_len <= FAQCS_MAX_READ_LENGTH) { // long reads: one wave per block (its LDS: 2 x 32 KB per-base arrays + 16 KB of planes), one block per CU
-        constexpr int NW = 1;
-        uint32_t grid = n_reads;
-        const uint32_t cap = (uint32_t)n_cu;
-        if (grid > cap) grid = cap;
-        hipLaunchKernelGGL((adapter_overlap<NW, 32768>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
-                           n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
+    } else if (max_len <= FAQCS_MAX_READ_LENGTH) {
+        // long reads: one wave per block, its LDS holds the per-base arrays of ONE read (2.5 bytes per base + 20 KB): the variant is picked by
+        // the batch's longest read so that reads of a few thousand bases still get several waves per CU (5 / 4 / 2 / 1 blocks)
+#define FAQCS_ADAPTER_LONG(ML, PER_CU)                                                                                             \
+        {                                                                                                                          \
+            uint32_t grid = n_reads;                                                                                               \
+            const uint32_t cap = (uint32_t)n_cu * PER_CU;                                                                          \
+            if (grid > cap) grid = cap;                                                                                            \
+            hipLaunchKernelGGL((adapter_overlap<1, ML>), dim3(grid), dim3(64), 0, st, A, seq, off, n_reads, seg_start, n_segments, \
+                               ad_sl, ad_hit, adapter_stats, err, dbg);                                                            \
+        }
+        if (max_len <= 4096) FAQCS_ADAPTER_LONG(4096, 5u)
+        else if (max_len <= 8192) FAQCS_ADAPTER_LONG(8192, 4u)
+        else if (max_len <= 16384) FAQCS_ADAPTER_LONG(16384, 2u)
+        else FAQCS_ADAPTER_LONG(32768, 1u)
+#undef FAQCS_ADAPTER_LONG
     } else {
         return hipErrorInvalidValue;
     }

@@ -488,7 +488,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         const char *e_long = getenv("FAQCS_TRIM_LONG");
         const bool force_long = e_long && atoi(e_long) != 0;
         const bool long_reads = max_len > FAQCS_FAST_READ_LENGTH || force_long; // trim_long: composition bins are added by the kernel itself, no records
-        const size_t need = long_reads ? 1 : (size_t)n * (wide ? 2 : 1);
+        const size_t need = long_reads ? (size_t)n / 2 + 1 : (size_t)n * (wide ? 2 : 1); // (trim_long: rec_pre is its scratch, one u32 per read)
         if (need > rs.pre.cap) HIPCHK(hipStreamSynchronize(c->aux));
         HIPCHK(rs.pre.reserve(need)); HIPCHK(rs.post.reserve(need));
         HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, rs.pre.p, rs.post.p,

@@ -1389,7 +1389,7 @@ static hipError_t launch_trim_tpr(const DevParams &P, const uint8_t *seq, const 
 
 hipError_t faqcs_launch_trim_long(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off, uint32_t n_reads,
                                   const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out, uint64_t *counters, uint32_t *err,
-                                  int n_cu, hipStream_t st); // faqcs_trim_long_kernel.hip
+                                  int n_cu, hipStream_t st, uint32_t *lead_trail, uint32_t max_len); // faqcs_trim_long_kernel.hip
 hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                  uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                                  faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
@@ -1408,7 +1408,8 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
         const bool force_long = e_long && atoi(e_long) != 0;
         if (max_len > FAQCS_FAST_READ_LENGTH || force_long) {
             g_last_trim_kernel = "trim_long";
-            return faqcs_launch_trim_long(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, counters, err, n_cu, st);
+            // (scratch: a word per read for the terminal-N runs; the composition record array is free, trim_long writes no records)
+            return faqcs_launch_trim_long(P, seq, qual, off, n_reads, ad_sl, ad_hit, out, counters, err, n_cu, st, reinterpret_cast<uint32_t *>(rec_pre), max_len);
         }
     }
     {   // trim_lds (faqcs_trim_lds_kernel.hip): every byte from HBM once, through LDS; FAQCS_TRIM_LDS=0 switches it off

@@ -11,7 +11,10 @@
 //     turns negative, i.e. after a handful of steps on a good read, and costs |tail| steps on a bad one;
 //   * the float expressions of the average-quality and low-complexity tests and of the composition bins are evaluated as the
 //     reference writes them (IEEE single / double operations, no contraction), not through tables;
-//   * accumulators are global u64 atomics on the counter block (position x quality, position x base: one per base and table).
+//   * the per-position matrices (position x quality, position x base, before and after trimming: four counters per base) are NOT
+//     added by this kernel: it leaves the read's verdict in the result array and its terminal-N runs in a scratch word, and
+//     long_accumulate (below) adds the matrices tile by tile through LDS.  (The first form of this kernel added them itself, one
+//     64-bit global atomic per counter and base: 13 G atomics/s, the chip's memory-side atomic rate, = 3.3 G bases/s.)
 // Results are bit-identical to the chunked kernels on reads both can take (tests/test_gpu_parity.py runs short batches through
 // this kernel with FAQCS_TRIM_LONG=1).
 #include "faqcs_trim_common.h"
@@ -57,7 +60,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
                                                     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
                                                     const uint16_t *__restrict__ ad_hit, uint2 *__restrict__ out, uint64_t *__restrict__ counters,
-                                                    uint32_t *__restrict__ err)
+                                                    uint32_t *__restrict__ err, uint32_t *__restrict__ lead_trail)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)uni((int)(threadIdx.x >> 6));
@@ -66,6 +69,17 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
     uint64_t *fs = counters + L.filter_stats;
     const int in_off = P.in_off;
     bool any_err = false;
+    // Counters every read adds to (FilterStat, the 42-bin histograms, the length histograms of equal-length reads) are hot ADDRESSES: as
+    // one global atomic per read and counter they serialise at the memory side (2 M reads x 12 same-address atomics = 130 ms, measured).
+    // FilterStat: sums in wave-uniform registers, added once per wave at the end; quality-bin histograms: the block's LDS, flushed at the
+    // end; length histograms: consecutive reads of one length are counted up and added when the length changes.
+    __shared__ uint32_t s_qh[4][FAQCS_NQ]; // pre reads, pre bases, post reads, post bases per int(average quality)
+    for (int i = threadIdx.x; i < 4 * FAQCS_NQ; i += NW * 64) (&s_qh[0][0])[i] = 0u;
+    __syncthreads();
+    uint64_t w_fs[FAQCS_NUM_STAT];
+#pragma unroll
+    for (int k = 0; k < FAQCS_NUM_STAT; ++k) w_fs[k] = 0;
+    uint32_t pre_key = 0xffffffffu, pre_run = 0, post_key = 0xffffffffu, post_run = 0;
 #pragma unroll 1
     for (uint32_t r = blockIdx.x * NW + wave; r < n_reads; r += n_waves) {
         const uint32_t o = uniu(off[r]);                       // (wave-uniform: everything derived from these stays in scalar registers)
@@ -93,19 +107,30 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
 
         // ---- pass 1 over the whole read: range check, the sum of the raw bytes, base counts (trim.cpp:247-258) ----
         int total0 = 0;
-        uint32_t pA = 0, pT = 0, pC = 0, pG = 0, pN = 0;
+        uint32_t nAT = 0, nCG = 0, nNN = 0; // per-lane counts, two 16-bit fields each (a lane sees <= 512 positions of a read)
         bool bad_q = false;
 #pragma unroll 1
-        for (int c = 0; c < len0; c += 64) {
-            const int p = c + lane;
-            const bool in = p < len0;
-            const uint32_t rq = in ? raw_q(p) : 0u;
-            bad_q = bad_q || (in && q_score(rq, in_off) > 41);
-            total0 += in ? (int)(int8_t)rq : 0;
-            const uint32_t col = in ? base_col(s[p]) : 5u;
-            pA += popc64(__ballot(col == 0u)); pT += popc64(__ballot(col == 1u)); pC += popc64(__ballot(col == 2u));
-            pG += popc64(__ballot(col == 3u)); pN += popc64(__ballot(col == 4u));
+        for (int c = 0; c < len0; c += 256) { // four 64-position pieces per round: their loads are in flight together
+            uint32_t rqv[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = c + 64 * u + lane;
+                rqv[u] = p < len0 ? raw_q(p) : 0u;
+                bv[u] = p < len0 ? (uint32_t)s[p] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = c + 64 * u + lane < len0;
+                bad_q = bad_q || (in && q_score(rqv[u], in_off) > 41);
+                total0 += in ? (int)(int8_t)rqv[u] : 0;
+                const uint32_t col = in ? base_col(bv[u]) : 5u;
+                nAT += (col == 0u ? 1u : 0u) + (col == 1u ? 0x10000u : 0u);
+                nCG += (col == 2u ? 1u : 0u) + (col == 3u ? 0x10000u : 0u);
+                nNN += col == 4u ? 1u : 0u;
+            }
         }
+        nAT = (uint32_t)wave_sum_i32((int)nAT); nCG = (uint32_t)wave_sum_i32((int)nCG); // (a read has <= 32 767 bases: the low field cannot carry)
+        const uint32_t pA = nAT & 0xffffu, pT = nAT >> 16, pC = nCG & 0xffffu, pG = nCG >> 16, pN = (uint32_t)wave_sum_i32((int)nNN);
         const bool read_err = __any(bad_q);
         total0 = wave_sum_i32(total0);
 
@@ -204,11 +229,22 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
         uint32_t prev_cls = 4; // class of the position in front of the chunk (4 = none / not a base)
         if (!read_err) {
 #pragma unroll 1
-            for (int c = 0; c < len; c += 64) {
-                const int i = c + lane, p = w0 + i;
+            for (int cc = 0; cc < len; cc += 256) { // the loads of four 64-position pieces are issued together; the pieces are then judged in order
+              uint32_t b0v[4], rqv[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                  const int i = cc + 64 * u + lane;
+                  b0v[u] = i < len ? (uint32_t)s[w0 + i] : 0u;
+                  rqv[u] = i < len ? raw_q(w0 + i) : 0u;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int c = cc + 64 * u;
+                if (c >= len) break; // (wave-uniform)
+                const int i = c + lane;
                 const bool in = i < len;
-                const uint32_t b0 = in ? (uint32_t)s[p] : 0u;
-                const uint32_t rq = in ? raw_q(p) : 0u;
+                const uint32_t b0 = b0v[u];
+                const uint32_t rq = rqv[u];
                 totalw += in ? (int)(int8_t)rq : 0;
                 // count_poly_n: the longest run of upper-case N
                 const uint64_t mN = __ballot(in && b0 == 'N');
@@ -235,6 +271,7 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
                     if ((k >> 2) != (k & 3)) dc[k] += popc64(__ballot(pair == (uint32_t)k));
+              }
             }
         }
         totalw = wave_sum_i32(totalw);
@@ -256,65 +293,168 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
             }
             if (trip) { f_lc_bases += (uint64_t)len; ++f_lc_reads; ret = false; filt = FAQCS_FILT_LOW_COMPLEXITY; }
         }
-        // ---- pass 3: the per-position matrices (trim.cpp:795-875; a read with a quality error counts nothing: the run ends there) ----
-        if (!read_err) {
-            uint64_t *pre_q = counters + L.pre_qual, *post_q = counters + L.post_qual, *pre_b = counters + L.pre_base, *post_b = counters + L.post_base;
-            const int R = (int)P.R;
-            const int k0 = ret ? w0 : 0, k1 = ret ? w0 + len : 0; // kept window in read coordinates
-            // post-trim rows are i + offset_5 (trim.cpp:533-535); for a kept read offset_5 == w0, so row == read position
-#pragma unroll 1
-            for (int c = 0; c < len0; c += 64) {
-                const int p = c + lane;
-                if (p < len0 && p < R) {
-                    const uint32_t rq = raw_q(p);
-                    const int sc = q_score(rq, in_off);
-                    const uint32_t b0 = (uint32_t)s[p];
-                    add64(pre_q + (size_t)p * FAQCS_NQ + sc, 1);
-                    const uint32_t col0 = base_col(b0);
-                    if (col0 < 5u) add64(pre_b + (size_t)p * FAQCS_NBASE + col0, 1);
-                    if (p >= k0 && p < k1) {
-                        add64(post_q + (size_t)p * FAQCS_NQ + sc, 1);
-                        const uint32_t b = (P.replace_q > 0 && b0 == 'G' && sc < (int)P.replace_q) ? (uint32_t)'N' : b0;
-                        const uint32_t col = base_col(b);
-                        if (col < 5u) add64(post_b + (size_t)p * FAQCS_NBASE + col, 1);
-                    }
-                }
-            }
-        }
+        // (pass 3, the per-position matrices: long_accumulate, from the verdict below and these two run lengths)
         // ---- per-read scalars: one lane ----
         if (lane == 0) {
             const uint32_t hit = P.has_adapters ? (uint32_t)ad_hit[r] : 0u;
             const bool bad_base = hit == 0xffffu;
+            lead_trail[r] = (uint32_t)lead | ((uint32_t)trail << 16);
             out[r] = make_uint2(ret ? ((offset_5 & 0xffffu) | ((uint32_t)len << 16)) : 0u,
                                 ((flags | (ret ? (uint32_t)FAQCS_F_VALID : 0u) | (filt << FAQCS_F_FILTER_SHIFT)) & 0x3ffu) |
                                     (bad_base ? (uint32_t)FAQCS_F_ERR_BASE : (hit << 16)));
-            add64(fs + FAQCS_TOTAL_COUNT, 1); add64(fs + FAQCS_TOTAL_NUMBER, 1); add64(fs + FAQCS_TOTAL_LENGTH, (uint64_t)len0);
+        }
+        // (wave-uniform values: every lane keeps the same sums, lane 0 adds them at the end)
+        w_fs[FAQCS_TOTAL_COUNT] += 1; w_fs[FAQCS_TOTAL_NUMBER] += 1; w_fs[FAQCS_TOTAL_LENGTH] += (uint64_t)len0;
+        w_fs[FAQCS_READ_LENGTH] += f_len_reads; w_fs[FAQCS_BASE_LENGTH] += f_len_bases;
+        if (flags & FAQCS_F_QUAL_TRIMMED) { w_fs[FAQCS_READ_QUAL_TRIM] += 1; w_fs[FAQCS_BASE_QUAL_TRIM] += qt_bases; }
+        w_fs[FAQCS_READ_NN] += f_nn_reads; w_fs[FAQCS_BASE_NN] += f_nn_bases;
+        w_fs[FAQCS_READ_AVG_Q] += f_avg_reads; w_fs[FAQCS_BASE_AVG_Q] += f_avg_bases;
+        w_fs[FAQCS_READ_LOW_COMPLEXITY] += f_lc_reads; w_fs[FAQCS_BASE_LOW_COMPLEXITY] += f_lc_bases;
+        if (ret) { w_fs[FAQCS_TOTAL_TRIMMED_NUMBER] += 1; w_fs[FAQCS_TOTAL_TRIMMED_LENGTH] += (uint64_t)len; }
+        if (!read_err) {
+            if ((uint32_t)len0 != pre_key) {
+                if (pre_run && lane == 0) add64(counters + L.pre_len_hist + pre_key, pre_run);
+                pre_key = (uint32_t)len0; pre_run = 0;
+            }
+            ++pre_run;
+        }
+        if (ret) {
+            if ((uint32_t)len != post_key) {
+                if (post_run && lane == 0) add64(counters + L.post_len_hist + post_key, post_run);
+                post_key = (uint32_t)len; post_run = 0;
+            }
+            ++post_run;
+        }
+        if (lane == 0) {
             if (!read_err) {
-                add64(counters + L.pre_len_hist + len0, 1);
                 const int qb = (int)average_q(total0, (uint32_t)len0, in_off);
-                add64(counters + L.pre_read_qhist + qb, 1); add64(counters + L.pre_base_qhist + qb, (uint64_t)len0);
+                atomicAdd(&s_qh[0][qb], 1u); atomicAdd(&s_qh[1][qb], (uint32_t)len0);
                 composition_bins(counters + L.pre_comp, (uint32_t)len0, pA, pT, pC, pG, pN);
             }
-            if (f_len_reads) { add64(fs + FAQCS_READ_LENGTH, f_len_reads); add64(fs + FAQCS_BASE_LENGTH, f_len_bases); }
-            if (flags & FAQCS_F_QUAL_TRIMMED) { add64(fs + FAQCS_READ_QUAL_TRIM, 1); add64(fs + FAQCS_BASE_QUAL_TRIM, qt_bases); }
-            if (f_nn_reads) { add64(fs + FAQCS_READ_NN, 1); add64(fs + FAQCS_BASE_NN, f_nn_bases); }
-            if (f_avg_reads) { add64(fs + FAQCS_READ_AVG_Q, 1); add64(fs + FAQCS_BASE_AVG_Q, f_avg_bases); }
-            if (f_lc_reads) { add64(fs + FAQCS_READ_LOW_COMPLEXITY, 1); add64(fs + FAQCS_BASE_LOW_COMPLEXITY, f_lc_bases); }
             if (ret) {
-                add64(fs + FAQCS_TOTAL_TRIMMED_NUMBER, 1); add64(fs + FAQCS_TOTAL_TRIMMED_LENGTH, (uint64_t)len);
-                add64(counters + L.post_len_hist + len, 1);
                 const int qb = (int)ave_Q;
-                add64(counters + L.post_read_qhist + qb, 1); add64(counters + L.post_base_qhist + qb, (uint64_t)len);
+                atomicAdd(&s_qh[2][qb], 1u); atomicAdd(&s_qh[3][qb], (uint32_t)len);
                 composition_bins(counters + L.post_comp, (uint32_t)len, cA, cT, cC, cG, cN);
             }
         }
     }
+    if (lane == 0) {
+        if (pre_run) add64(counters + L.pre_len_hist + pre_key, pre_run);
+        if (post_run) add64(counters + L.post_len_hist + post_key, post_run);
+#pragma unroll
+        for (int k = 0; k < FAQCS_NUM_STAT; ++k) if (w_fs[k]) add64(fs + k, w_fs[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * FAQCS_NQ; i += NW * 64) {
+        const uint32_t v = (&s_qh[0][0])[i];
+        const int which = i / FAQCS_NQ, qb = i % FAQCS_NQ;
+        if (v) add64(counters + (which == 0 ? L.pre_read_qhist : which == 1 ? L.pre_base_qhist : which == 2 ? L.post_read_qhist : L.post_base_qhist) + qb, v);
+    }
     if (__any(any_err) && lane == 0) atomicOr(err, 1u);
+}
+
+// ---- long_accumulate: the per-position matrices of a trim_long batch (update_quality_matrix / update_base_statistics,
+// trim.cpp:795-875), tile by tile.  A block walks the positions in tiles of 512: for one tile its LDS holds position x quality
+// [42][512] and position x base [5][512] as dwords (pre count low, post count high half-word), its sixteen waves take the block's reads one
+// each -- lane = position inside the tile, so the 64 adds of an instruction fall on 64 consecutive cells: no bank conflicts -- and
+// at the end of the tile the non-zero cells go to the u64 counter block.  A base costs two LDS adds (quality, class) instead of four
+// memory-side atomics; the global atomics left are one per non-zero cell, tile and block.
+constexpr int LA_TILE = 512, LA_NW = 16; // (16 waves per CU: the loop waits on global loads)
+__global__ __launch_bounds__(LA_NW * 64) void long_accumulate(const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
+                                                             const uint32_t *__restrict__ off, const uint32_t n_reads, const uint2 *__restrict__ out,
+                                                             const uint32_t *__restrict__ lead_trail, uint64_t *__restrict__ counters, const uint32_t max_len)
+{
+    __shared__ uint32_t s_q[FAQCS_NQ][LA_TILE];
+    __shared__ uint32_t s_b[FAQCS_NBASE][LA_TILE];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)uni((int)(threadIdx.x >> 6));
+    const faqcs_layout &L = P.lay;
+    const int in_off = P.in_off;
+    const uint32_t limit = max_len < P.R ? max_len : P.R; // rows past the matrices' capacity are not counted (trim.cpp:797-805 grows them: R is that capacity)
+    for (int i = threadIdx.x; i < FAQCS_NQ * LA_TILE; i += LA_NW * 64) (&s_q[0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < FAQCS_NBASE * LA_TILE; i += LA_NW * 64) (&s_b[0][0])[i] = 0u;
+    __syncthreads();
+    auto flush = [&](const uint32_t t0) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < FAQCS_NQ * LA_TILE; i += LA_NW * 64) {
+            const uint32_t v = (&s_q[0][0])[i];
+            if (v) {
+                (&s_q[0][0])[i] = 0u;
+                const uint32_t q = (uint32_t)i / LA_TILE, p = t0 + (uint32_t)i % LA_TILE;
+                if (v & 0xffffu) add64(counters + L.pre_qual + (size_t)p * FAQCS_NQ + q, v & 0xffffu);
+                if (v >> 16) add64(counters + L.post_qual + (size_t)p * FAQCS_NQ + q, v >> 16);
+            }
+        }
+        for (int i = threadIdx.x; i < FAQCS_NBASE * LA_TILE; i += LA_NW * 64) {
+            const uint32_t v = (&s_b[0][0])[i];
+            if (v) {
+                (&s_b[0][0])[i] = 0u;
+                const uint32_t c = (uint32_t)i / LA_TILE, p = t0 + (uint32_t)i % LA_TILE;
+                if (v & 0xffffu) add64(counters + L.pre_base + (size_t)p * FAQCS_NBASE + c, v & 0xffffu);
+                if (v >> 16) add64(counters + L.post_base + (size_t)p * FAQCS_NBASE + c, v >> 16);
+            }
+        }
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < limit; t0 += LA_TILE) {
+        const uint32_t t1 = t0 + LA_TILE < limit ? t0 + LA_TILE : limit;
+        uint32_t since = 0; // reads of this block since the tile's last flush: a 16-bit half takes 65 535 increments
+#pragma unroll 1
+        for (uint32_t k = 0;; ++k) { // (every wave runs the same number of rounds: the flush inside is a block barrier)
+            const uint32_t r0 = blockIdx.x + k * LA_NW * gridDim.x;
+            if (r0 >= n_reads) break; // (block-uniform: r0 belongs to wave 0)
+            const uint32_t r = r0 + wave * gridDim.x;
+            if (r < n_reads) {
+                const uint32_t o = uniu(off[r]);
+                const uint32_t len0 = uniu(off[r + 1]) - o;
+                const uint2 res = out[r];
+                if (len0 > t0 && !(uniu(res.y) & FAQCS_F_ERR_QUALITY)) {
+                    const uint32_t lt = uniu(lead_trail[r]);
+                    const uint32_t lead = lt & 0xffffu, tail_from = len0 - (lt >> 16);
+                    const bool kept = (uniu(res.y) & FAQCS_F_VALID) != 0u;
+                    const uint32_t k0 = kept ? (uniu(res.x) & 0xffffu) : 0u, k1 = kept ? k0 + (uniu(res.x) >> 16) : 0u;
+                    const uint32_t e = len0 < t1 ? len0 : t1;
+#pragma unroll 1
+                    for (uint32_t pb = t0; pb < e; pb += 256) { // four 64-position pieces per round: their eight loads are in flight together
+                        uint32_t rq[4], b0v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t p = pb + 64u * (uint32_t)u + (uint32_t)lane;
+                            const bool ok = p < e;
+                            rq[u] = ok ? ((p < lead || p >= tail_from) ? (uint32_t)(in_off & 0xff) : (uint32_t)qual[(size_t)o + p]) : 0u;
+                            b0v[u] = ok ? (uint32_t)seq[(size_t)o + p] : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t p = pb + 64u * (uint32_t)u + (uint32_t)lane;
+                            if (p < e) {
+                                int sc = q_score(rq[u], in_off);
+                                sc = sc > 41 ? 41 : sc; // (cannot happen: a read with such a score carries FAQCS_F_ERR_QUALITY)
+                                const uint32_t b0 = b0v[u];
+                                const bool in = p >= k0 && p < k1;
+                                const uint32_t x = p - t0;
+                                atomicAdd(&s_q[sc][x], in ? 0x10001u : 1u);
+                                const uint32_t col0 = base_col(b0);
+                                const uint32_t b = (P.replace_q > 0 && b0 == 'G' && sc < (int)P.replace_q) ? (uint32_t)'N' : b0;
+                                const uint32_t col = in ? base_col(b) : 5u;
+                                if (col0 < 5u) atomicAdd(&s_b[col0][x], col == col0 ? 0x10001u : 1u);
+                                if (col < 5u && col != col0) atomicAdd(&s_b[col][x], 0x10000u);
+                            }
+                        }
+                    }
+                }
+            }
+            since += LA_NW;
+            if (since + LA_NW > 65535u) { flush(t0); since = 0; }
+        }
+        flush(t0);
+    }
 }
 
 hipError_t faqcs_launch_trim_long(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off, uint32_t n_reads,
                                   const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out, uint64_t *counters, uint32_t *err,
-                                  int n_cu, hipStream_t st)
+                                  int n_cu, hipStream_t st, uint32_t *lead_trail, uint32_t max_len)
 {
     if (n_reads == 0) return hipSuccess;
     constexpr int NW = 4;
@@ -322,6 +462,11 @@ hipError_t faqcs_launch_trim_long(const DevParams &P, const uint8_t *seq, const 
     const uint32_t cap = (uint32_t)n_cu * 8u; // 32 waves per CU: the passes wait on memory, not on issue slots
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL((trim_long<NW>), dim3(grid), dim3(NW * 64), 0, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
-                       reinterpret_cast<uint2 *>(out), counters, err);
+                       reinterpret_cast<uint2 *>(out), counters, err, lead_trail);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    uint32_t g2 = (n_reads + LA_NW - 1) / LA_NW;
+    if (g2 > (uint32_t)n_cu) g2 = (uint32_t)n_cu; // one block per CU (its 94 KB of LDS)
+    hipLaunchKernelGGL(long_accumulate, dim3(g2), dim3(LA_NW * 64), 0, st, P, seq, qual, off, n_reads, reinterpret_cast<const uint2 *>(out), lead_trail,
+                       counters, max_len);
     return hipGetLastError();
 }

@@ -180,7 +180,7 @@ def test_longest_read():
 
 
 @pytest.mark.parametrize("args", OPTION_SETS, ids=lambda a: " ".join(a) or "default")
-@pytest.mark.parametrize("kind,maxlen", [("adv", 1025), ("ragged", 3000), ("adv", 9000)])
+@pytest.mark.parametrize("kind,maxlen", [("adv", 1025), ("ragged", 3000), ("ragged", 6000), ("adv", 9000)])
 def test_reads_past_1024_bases_match_oracle(args, kind, maxlen):
     """Batches that hold a read of more than 1 024 bases: trim_long and adapter_overlap<1, 32768> (one wave per read) against the
     oracle, every option set; short reads ride in the same batches."""
