@@ -367,7 +367,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         smem[T::O_T2 + 2 * i + 1] = (w >> 31) | (((w >> BT_SHIFT(4)) & 1u) << 1);
     }
     for (int i = tid; i < 256; i += NW * 64) { // S: entry[b] = (pre, post) increments of the ASCII byte b; entry[b | 0x80] = (pre, 0): b outside the kept window
-        const uint32_t f = P.base_tab[i & 127] & BT_FIELDS; // (a byte >= 0x80 in the INPUT is no base: such a chunk is patched and redone, see the S pass)
+        // entries 128..255: a base OUTSIDE the kept window, looked up at (byte ^ 0x88) -- bit 7 says "outside", bit 3 moves the entry 64 bytes on:
+        // the in-window entries of A, C, G, T, N sit on banks 2, 6, 14, 8, 28 (8-byte entries), their out-of-window twins 1 024 bytes further on
+        // would sit on the SAME banks (a half wave that mixes both -- the lanes at a trimmed 3' end -- pays a two-way conflict per look-up);
+        // with the extra 64 bytes they sit on banks 18, 22, 30, 24, 12.
+        const uint32_t f = P.base_tab[(i & 128) ? ((i ^ 0x88) & 127) : i] & BT_FIELDS; // (a byte >= 0x80 in the INPUT is no base: such a chunk is patched and redone, see the S pass)
         smem[T::O_T3 + 2 * i] = f;
         smem[T::O_T3 + 2 * i + 1] = i < 128 ? f : 0u;
     }
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const int k = j >> 2;
             if ((j & 3) == 0) {
                 if (MODE == 0) seen7 |= w[k];
-                w[k] ^= ~((EXT && chk) ? 0u : inw[k]) & 0x80808080u; // (w[k] is the table index from here on; bit 7 is put back for the N tests)
+                w[k] ^= ~((EXT && chk) ? 0u : inw[k]) & 0x88888888u; // (w[k] is the table index from here on; the byte is put back for the N tests)
             }
             const uint32_t ad = ((j & 3) == 0 ? byte_x8<0>(w[k], three) : (j & 3) == 1 ? byte_x8<1>(w[k], three)
                                  : (j & 3) == 2 ? byte_x8<2>(w[k], three) : byte_x8<3>(w[k], three)) + (uint32_t)(T::O_T3 * 4);
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 uint32_t nb[D]; // bit 7 of a byte: upper-case 'N' inside the kept window
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    const uint32_t orig = w[k] ^ (~((EXT && chk) ? 0u : inw[k]) & 0x80808080u); // (the byte itself again)
+                    const uint32_t orig = w[k] ^ (~((EXT && chk) ? 0u : inw[k]) & 0x88888888u); // (the byte itself again)
                     const uint32_t x = (orig & inw[k]) ^ 0x4e4e4e4eu;
                     const uint32_t sx = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
                     nb[k] = ~(sx | x) & 0x80808080u;
