@@ -492,11 +492,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
         const int vb = counted ? med3i(len - pbase_q, 0, VQ) : 0; // (a read that is not counted: no byte of it is)
         const int lo = post ? med3i(a - pbase_q, 0, VQ) : 0, hi = post ? med3i(a + n - pbase_q, 0, VQ) : 0;
+#ifdef FAQCS_LDS_DIAG_LINEAR_LOADS // (diagnostic build, wrong results: what the bank conflicts of these per-lane loads cost)
+        const uint32_t qa = slot_b + (uint32_t)lane * 4u;
+#pragma unroll
+        for (int k = 0; k <= D; ++k) x.r[k] = lds_ld(qa + 256u * (uint32_t)k);
+#else
         const uint32_t qa = (slot_b + (i0 & 0xffffu) + (uint32_t)pbase_q) & ~3u;
 #pragma unroll
         for (int k = 0; k <= D; ++k) x.r[k] = lds_ld(qa + 4u * (uint32_t)k);
+#endif
 #pragma unroll
+#ifdef FAQCS_LDS_DIAG_UNIFORM_MASKROWS // (diagnostic build, wrong results: every lane fetches the same mask row -- a broadcast, no conflicts)
+        for (int k = 0; k < D; ++k) { x.mv[k] = t_bmq[BMQ * VQ + k]; x.mh[k] = t_bmq[BMQ * VQ + k]; }
+#else
         for (int k = 0; k < D; ++k) { x.mv[k] = t_bmq[BMQ * vb + k]; x.mh[k] = t_bmq[BMQ * hi + k]; }
+#endif
         // row 0 of the mask table is all zeros, and a kept window that starts at the read's first base is the common case: the third
         // row is fetched only when some read of this step is trimmed at its 5' end
         if (__any(lo != 0)) {
@@ -575,14 +585,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         const uint32_t qa = (slot_b + (i0 & 0xffffu) + (uint32_t)pbase) & ~3u;
         const uint32_t sh = ((i0 & 0xffffu) + (uint32_t)pbase + slot_b) & 3u;
         uint32_t r[D + 1], w[D], inw[D];
+#ifdef FAQCS_LDS_DIAG_LINEAR_LOADS
+#pragma unroll
+        for (int k = 0; k <= D; ++k) r[k] = lds_ld(slot_b + (uint32_t)lane * 4u + 256u * (uint32_t)k);
+#else
 #pragma unroll
         for (int k = 0; k <= D; ++k) r[k] = lds_ld(qa + 4u * (uint32_t)k);
+#endif
 #pragma unroll
+#ifdef FAQCS_LDS_DIAG_UNIFORM_MASKROWS
+        for (int k = 0; k < D; ++k) inw[k] = t_bm[BMW * (C + 1) + k] ^ t_bm[k];
+#else
         for (int k = 0; k < D; ++k) inw[k] = t_bm[BMW * hi + k] ^ t_bm[BMW * lo + k]; // 0xff: inside the kept window
+#endif
         // (the third row is NOT made conditional here as it is in load_b: with both conditional the allocator spills two registers per
         // chunk to scratch -- 8.4 -> 8.8 G reads/s without, same-box A/B profiles/r3g/ab_cond.txt, and 15 B/read of scratch traffic)
 #pragma unroll
+#ifdef FAQCS_LDS_DIAG_UNIFORM_MASKROWS
+        for (int k = 0; k < D; ++k) w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & t_bm[BMW * (C + 1) + k];
+#else
         for (int k = 0; k < D; ++k) w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh) & t_bm[BMW * vb + k]; // a byte past the read: 0, no class
+#endif
         uint32_t tp = 0, tq = 0;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -593,7 +616,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             }
             const uint32_t ad = ((j & 3) == 0 ? byte_x8<0>(w[k], three) : (j & 3) == 1 ? byte_x8<1>(w[k], three)
                                  : (j & 3) == 2 ? byte_x8<2>(w[k], three) : byte_x8<3>(w[k], three)) + (uint32_t)(T::O_T3 * 4);
+#ifdef FAQCS_LDS_DIAG_UNIFORM_SLOOKUP // (diagnostic build, wrong results: every lane looks up the same entry)
+            const LdsPair2 e = *(lds_u2c_ptr)(size_t)((ad & 0u) + (uint32_t)(T::O_T3 * 4 + 8 * 'A'));
+#else
             const LdsPair2 e = *(lds_u2c_ptr)(size_t)ad;
+#endif
             if (MODE == 0) { bpre[j] += e.x; bpost[j] += e.y; tp += e.x; tq += e.y; }
             if (MODE == 1) bpost[j] -= e.y;
             if (MODE == 2) { bpre[j] -= e.x; bpost[j] -= e.y; }
