@@ -279,11 +279,13 @@ __global__ __launch_bounds__(1024) void fold_partials(const uint32_t *__restrict
     unsigned long long lo = 0, hi = 0;
     if (i < Cfg::N_ZERO) {
         const bool halves = i < Cfg::O_BQPRE; // two 16-bit counters per cell (the other cells are one 32-bit number)
-#pragma unroll 4
-        for (uint32_t r = threadIdx.x >> 6; r < n_blocks * FAQCS_PARTIAL_FLUSHES; r += 16) {
-            if (r % FAQCS_PARTIAL_FLUSHES >= rows_used[r / FAQCS_PARTIAL_FLUSHES]) continue;
-            const uint32_t x = partials[(size_t)r * FAQCS_PARTIAL_ROW + i];
-            if (halves) { lo += x & 0xffffu; hi += x >> 16; } else lo += x;
+        for (uint32_t b = threadIdx.x >> 6; b < n_blocks; b += 16) { // (a block's rows: one or two per launch, 8 at most)
+            const uint32_t cnt = rows_used[b];
+            const uint32_t *row = partials + (size_t)b * FAQCS_PARTIAL_FLUSHES * FAQCS_PARTIAL_ROW + i;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t x = row[(size_t)k * FAQCS_PARTIAL_ROW];
+                if (halves) { lo += x & 0xffffu; hi += x >> 16; } else lo += x;
+            }
         }
     }
     part[0][threadIdx.x >> 6][threadIdx.x & 63] = lo;

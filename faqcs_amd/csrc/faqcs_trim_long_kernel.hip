@@ -90,20 +90,27 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
 #pragma unroll 1
         for (int c = 0; c < len0; c += 64) {
             const int p = c + lane;
-            const uint64_t m = __ballot(p < len0 && s[p] != 'N');
+            const uint64_t m = __ballot(p < len0 && s[p < len0 ? p : len0 - 1] != 'N'); // (clamped index, unconditional load: a per-lane `cond ? load : 0` costs an EXEC region)
             if (m) { lead = c + (int)__builtin_ctzll(m); break; }
         }
         if (lead < len0) {
 #pragma unroll 1
             for (int c = 0; c < len0; c += 64) {
                 const int p = len0 - 1 - c - lane; // descending
-                const uint64_t m = __ballot(p >= 0 && s[p] != 'N');
+                const uint64_t m = __ballot(p >= 0 && s[p >= 0 ? p : 0] != 'N');
                 if (m) { trail = c + (int)__builtin_ctzll(m); break; }
             }
         }
         lead = uni(lead); trail = uni(trail);
         const int tail_from = len0 - trail; // positions >= tail_from are patched
-        auto raw_q = [&](const int p) -> uint32_t { return (p < lead || p >= tail_from) ? (uint32_t)(in_off & 0xff) : (uint32_t)q[p]; };
+        // the quality byte of position p as trim_read() sees it; p is clamped into the read so that the load needs no EXEC region (the callers
+        // mask what lies outside): the branchy form made the kernel scalar-bound -- 335 SALU instructions per 64 positions, measured
+        const int last_p = len0 > 0 ? len0 - 1 : 0;
+        auto raw_q = [&](const int p) -> uint32_t {
+            const uint32_t v = (uint32_t)q[p < 0 ? 0 : (p > last_p ? last_p : p)];
+            return (p < lead || p >= tail_from) ? (uint32_t)(in_off & 0xff) : v;
+        };
+        auto base_at = [&](const int p) -> uint32_t { return (uint32_t)s[p < 0 ? 0 : (p > last_p ? last_p : p)]; };
 
         // ---- pass 1 over the whole read: range check, the sum of the raw bytes, base counts (trim.cpp:247-258) ----
         int total0 = 0;
@@ -115,8 +122,8 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = c + 64 * u + lane;
-                rqv[u] = p < len0 ? raw_q(p) : 0u;
-                bv[u] = p < len0 ? (uint32_t)s[p] : 0u;
+                rqv[u] = raw_q(p);
+                bv[u] = base_at(p);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
                 if (b != cbase) {
                     cbase = b;
                     const int p = w0 + b + lane;
-                    cq = (b + lane < len) ? q_score(raw_q(p), in_off) : 0;
+                    cq = q_score(raw_q(p), in_off); // (positions past the window are never asked for)
                 }
                 return __builtin_amdgcn_readlane(cq, i & 63);
             };
@@ -234,8 +241,8 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                   const int i = cc + 64 * u + lane;
-                  b0v[u] = i < len ? (uint32_t)s[w0 + i] : 0u;
-                  rqv[u] = i < len ? raw_q(w0 + i) : 0u;
+                  b0v[u] = base_at(w0 + i);
+                  rqv[u] = raw_q(w0 + i);
               }
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
@@ -421,9 +428,10 @@ __global__ __launch_bounds__(LA_NW * 64) void long_accumulate(const DevParams P,
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const uint32_t p = pb + 64u * (uint32_t)u + (uint32_t)lane;
-                            const bool ok = p < e;
-                            rq[u] = ok ? ((p < lead || p >= tail_from) ? (uint32_t)(in_off & 0xff) : (uint32_t)qual[(size_t)o + p]) : 0u;
-                            b0v[u] = ok ? (uint32_t)seq[(size_t)o + p] : 0u;
+                            const uint32_t pc = p < e ? p : e - 1u; // (clamped: unconditional loads, no EXEC region per load)
+                            const uint32_t qv = (uint32_t)qual[(size_t)o + pc];
+                            rq[u] = (p < lead || p >= tail_from) ? (uint32_t)(in_off & 0xff) : qv;
+                            b0v[u] = (uint32_t)seq[(size_t)o + pc];
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
