@@ -188,6 +188,17 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
             } else if (P.mode == FAQCS_MODE_BWA) {
                 int pos_3 = len - 1, final_pos_3 = pos_3, area = 0, maxArea = 0;
                 while (pos_3 > 0 && area >= 0) {
+                    if ((pos_3 & 63) == 63 && pos_3 - 63 > 0) { // a whole 64-position piece none of whose scores exceeds Q: the area only grows, the walk cannot stop inside
+                        (void)score(pos_3);
+                        const int d = Q - cq;
+                        if (!__any(d < 0)) {
+                            const uint64_t up = __ballot(d > 0);
+                            area += wave_sum_i32(d);
+                            if (up && area > maxArea) { maxArea = area; final_pos_3 = (pos_3 - 63) + (int)__builtin_ctzll(up) - 1; }
+                            pos_3 -= 64;
+                            continue;
+                        }
+                    }
                     area += Q - score(pos_3);
                     if (area > maxArea) { maxArea = area; final_pos_3 = pos_3 - 1; }
                     --pos_3;
@@ -198,6 +209,21 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
                 const int num_after_neg = len < 2 ? len : 2;
                 int pos_3 = len - 1, final_pos_5 = 0, final_pos_3 = pos_3, area = 0, maxArea = 0;
                 while (at_least_scan) {
+                    // A whole 64-position piece none of whose scores exceeds Q, with the piece's lowest position still past the first two: every
+                    // step of it re-arms the scan (area >= 0 throughout) and the area only grows, so the 64 steps are one: the area gains the
+                    // piece's sum, and the last record -- if the new area is one -- is set at the piece's lowest position with a score below Q
+                    // (trim_lds's fast-forward; a low-quality tail of a long read would otherwise be walked base by base in scalar code).
+                    if ((pos_3 & 63) == 63 && pos_3 - 63 > num_after_neg && area >= 0) {
+                        (void)score(pos_3);
+                        const int d = Q - cq;
+                        if (!__any(d < 0)) {
+                            const uint64_t up = __ballot(d > 0);
+                            area += wave_sum_i32(d);
+                            if (up && area > maxArea) { maxArea = area; final_pos_3 = (pos_3 - 63) + (int)__builtin_ctzll(up) - 1; }
+                            at_least_scan = num_after_neg; pos_3 -= 64;
+                            continue;
+                        }
+                    }
                     --at_least_scan;
                     if (pos_3 > num_after_neg && area >= 0) at_least_scan = num_after_neg;
                     area += Q - score(pos_3);
@@ -209,6 +235,17 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
                     maxArea = 0; area = 0;
                     at_least_scan = len < 5 ? len : 5;
                     while (at_least_scan) {
+                        if ((pos_5 & 63) == 0 && pos_5 + 63 < final_pos_3 - num_after_neg && area >= 0) { // (the mirror image of the 3' fast-forward)
+                            (void)score(pos_5);
+                            const int d = Q - cq;
+                            if (!__any(d < 0)) {
+                                const uint64_t up = __ballot(d > 0);
+                                area += wave_sum_i32(d);
+                                if (up && area > maxArea) { maxArea = area; final_pos_5 = pos_5 + (63 - (int)__builtin_clzll(up)) + 1; }
+                                at_least_scan = num_after_neg; pos_5 += 64;
+                                continue;
+                            }
+                        }
                         --at_least_scan;
                         if (pos_5 < final_pos_3 - num_after_neg && area >= 0) at_least_scan = num_after_neg;
                         area += Q - score(pos_5);
@@ -229,9 +266,11 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
         // ---- pass 2 over the window: poly-N (before G -> N, trim.cpp:363-371,578-597), the quality sum (:374), then with
         // --replace_to_N_q applied (:390-403) the base counts and the dinucleotide transitions of the low-complexity test (:405-513) ----
         int totalw = 0;
-        uint32_t cA = 0, cT = 0, cC = 0, cG = 0, cN = 0, dc[16];
+        // per-lane counters (16-bit fields: a lane sees <= 512 positions of a read), summed over the wave after the loop: as ballots + popcounts
+        // into scalar counters these 17 counts were 34 scalar instructions per 64 positions of a kernel that is bound by scalar issue
+        uint32_t wAT = 0, wCG = 0, wN = 0, dcw[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) dc[k] = 0;
+        for (int k = 0; k < 8; ++k) dcw[k] = 0;
         uint32_t run_max = 0, run_carry = 0;
         uint32_t prev_cls = 4; // class of the position in front of the chunk (4 = none / not a base)
         if (!read_err) {
@@ -268,20 +307,26 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
                 // the bases the rest of trim_read() sees
                 const uint32_t b = (P.replace_q > 0 && b0 == 'G' && q_score(rq, in_off) < (int)P.replace_q) ? (uint32_t)'N' : b0;
                 const uint32_t col = in ? base_col(b) : 5u;
-                cA += popc64(__ballot(col == 0u)); cT += popc64(__ballot(col == 1u)); cC += popc64(__ballot(col == 2u));
-                cG += popc64(__ballot(col == 3u)); cN += popc64(__ballot(col == 4u));
+                wAT += (col == 0u ? 1u : 0u) + (col == 1u ? 0x10000u : 0u);
+                wCG += (col == 2u ? 1u : 0u) + (col == 3u ? 0x10000u : 0u);
+                wN += col == 4u ? 1u : 0u;
                 const uint32_t cls = col < 4u ? col : 4u; // A T C G / none (the codes differ from trim.cpp:447-470; only equality matters)
                 uint32_t pv = (uint32_t)__shfl((int)cls, (lane + 63) & 63);
                 pv = lane == 0 ? prev_cls : pv;
                 prev_cls = (uint32_t)__builtin_amdgcn_readlane((int)cls, 63);
                 const uint32_t pair = (in && cls != 4u && pv != 4u && cls != pv) ? (pv << 2 | cls) : 16u;
+                const uint32_t inc = 1u << ((pair & 1u) * 16u), slot = pair >> 1; // (pair 16 = none: slot 8)
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if ((k >> 2) != (k & 3)) dc[k] += popc64(__ballot(pair == (uint32_t)k));
+                for (int k = 0; k < 8; ++k) dcw[k] += slot == (uint32_t)k ? inc : 0u;
               }
             }
         }
         totalw = wave_sum_i32(totalw);
+        wAT = (uint32_t)wave_sum_i32((int)wAT); wCG = (uint32_t)wave_sum_i32((int)wCG); // (<= 32 767 per field: no carry between the fields)
+        const uint32_t cA = wAT & 0xffffu, cT = wAT >> 16, cC = wCG & 0xffffu, cG = wCG >> 16, cN = (uint32_t)wave_sum_i32((int)wN);
+        uint32_t dc[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const uint32_t v = (uint32_t)wave_sum_i32((int)dcw[k]); dc[2 * k] = v & 0xffffu; dc[2 * k + 1] = v >> 16; }
         uint64_t f_nn_reads = 0, f_nn_bases = 0, f_avg_reads = 0, f_avg_bases = 0, f_lc_reads = 0, f_lc_bases = 0;
         if (ret && !read_err && run_max >= P.max_poly_n) {
             f_nn_bases += (uint64_t)len; ++f_nn_reads; flags |= FAQCS_F_POLY_N_SEEN;
