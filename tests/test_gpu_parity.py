@@ -198,6 +198,43 @@ def test_reads_past_1024_bases_match_oracle(args, kind, maxlen):
     assert (kt.trim_kernel or b"").decode() == "trim_long"
 
 
+@pytest.mark.parametrize("args", [[], ["-q", "2"], ["-q", "20"], ["--mode", "BWA", "-q", "12"], ["--5trim_off", "-q", "10"], ["--mode", "HARD", "-q", "7"],
+                                  ["-q", "15", "--5end", "37", "--3end", "101"]], ids=lambda a: " ".join(a) or "default")
+def test_long_reads_with_long_low_quality_ends_match_oracle(args):
+    """trim_long takes a whole 64-position piece of a low-quality head / tail in ONE step of its BWA_plus / BWA walk when none of the
+    piece's scores exceeds Q (the area is monotone there).  Reads of 1 100 ... 6 000 bases whose ends are low-quality stretches of
+    0 ... 3 000 bases -- at, just under and just over the threshold, with single good bases sprinkled in, of every alignment
+    against the 64-position pieces -- against the oracle's base-by-base walk."""
+    rng = np.random.Generator(np.random.PCG64([23, len(args), SEED]))
+    opt = parse_args(["-u", "x", "-d", "y", "--min_L", "1"] + args)
+    Q = opt.quality
+    reads = []
+    for k in range(160):
+        L = int(rng.integers(1100, 6001))
+        s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+        q = rng.integers(Q + 1, 42, L) if Q < 41 else np.full(L, 41)
+        for side in (0, 1):
+            n = int(rng.integers(0, 3001)) if rng.random() < 0.8 else int(rng.integers(0, 130))
+            n = min(n, L)
+            kind = rng.random()
+            if kind < 0.4:
+                low = rng.integers(0, Q + 1, n)                 # every score <= Q
+            elif kind < 0.7:
+                low = np.full(n, Q)                                # exactly at the threshold: the area does not move
+            else:
+                low = rng.integers(0, Q + 1, n)
+                hit = rng.random(n) < 0.01
+                low[hit] = rng.integers(Q + 1, 42, int(hit.sum())) if Q < 41 else 41  # a good base every ~100: the fast path must give way there
+            if side == 0:
+                q[:n] = low
+            else:
+                q[L - n:] = low
+        if rng.random() < 0.1:
+            s[: int(rng.integers(1, 200))] = ord("N")
+        reads.append((b"@t%d" % k, s.tobytes(), (q + 33).astype(np.uint8).tobytes()))
+    compare_engines(opt, reads, R=8192, seg_size=41)
+
+
 @pytest.mark.parametrize("args", OPTION_SETS, ids=lambda a: " ".join(a) or "default")
 @pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 250), ("adv", 700)])
 def test_trim_long_equals_the_chunked_kernels_on_short_reads(args, kind, maxlen, monkeypatch):
