@@ -975,6 +975,46 @@ def test_native_cli_reports_a_device_error_in_a_large_input(tmp_path):
     assert r.returncode == 1 and b"Caught the error fastq.h:quality_score" in r.stderr
 
 
+_REF_BIN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),
+                                      "oracle", "_ref", "FaQCs_ref")
+
+
+@pytest.mark.parametrize("args,n_reads", [([], 34000), (["--adapter", "--polyA", "--discard", "-t", "1"], 2600), (["--kmer_rarefaction", "--split_size", "9000", "-q", "15"], 34000)],
+                         ids=["default", "adapter", "kmer"])
+def test_native_cli_on_a_long_read_file_equals_the_reference_run_here(args, n_reads, tmp_path):
+    """A file of ragged reads of 60 ... 5 000 bases -- more than one 32 768-read buffer of them -- through faqcs_mi (trim_long, adapter_overlap<1, 8192>,
+    the k-mer kernels) and through the REAL reference binary built by `make -C oracle ref` (it travels to the GPU box under oracle/_ref), run
+    here on the same file: QC.stats.txt, every --debug table and the trimmed FASTQ must be byte-identical."""
+    import hashlib
+    import subprocess
+
+    if not os.path.exists(_REF_BIN):
+        pytest.skip("oracle/_ref/FaQCs_ref not built (needs /root/reference at build time: make -C oracle ref)")
+    import make_fixtures
+
+    rng = np.random.Generator(np.random.PCG64([29, n_reads, SEED]))
+    path = str(tmp_path / "long.fastq")
+    with open(path, "wb") as f:
+        for i in range(n_reads):
+            u = rng.random()
+            L = int(rng.integers(1100, 5001)) if u < 0.35 else (int(rng.integers(60, 1100)) if u < 0.9 else int(rng.integers(30, 60)))
+            sq, q = make_fixtures._adv_read(rng, L)
+            f.write(b"@L%d extra\n" % i + sq.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    outs = {}
+    for name, binary in (("ref", _REF_BIN), ("mi", _CLI_BIN)):
+        out = str(tmp_path / name)
+        for _ in range(6):  # (the reference can die of SIGPIPE feeding the absent R: see make_golden.py)
+            subprocess.run(["rm", "-rf", out])
+            r = subprocess.run([binary, "-u", path, "-d", out, "--debug", "--ascii", "33"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            if r.returncode != -13:
+                break
+        assert r.returncode == 0, (name, r.returncode, r.stderr.decode(errors="replace")[-800:])
+        outs[name] = {fn: hashlib.md5(open(os.path.join(out, fn), "rb").read()).hexdigest() for fn in sorted(os.listdir(out)) if not fn.endswith(".pdf")}
+    assert outs["ref"].keys() == outs["mi"].keys(), (sorted(outs["ref"]), sorted(outs["mi"]))
+    bad = [fn for fn in outs["ref"] if outs["ref"][fn] != outs["mi"][fn]]
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("args", [[], ["--discard", "--adapter"], ["-u"]], ids=["paired", "paired_discard_adapter", "unpaired"])
 def test_native_cli_mapped_path_equals_streaming_path(args, tmp_path):
     """faqcs_mi reads uncompressed regular files through the memory-mapped path (parallel index / parse / format, pwrite at
