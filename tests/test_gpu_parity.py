@@ -1015,6 +1015,42 @@ def test_native_cli_on_a_long_read_file_equals_the_reference_run_here(args, n_re
     assert not bad, bad
 
 
+@pytest.mark.parametrize("args,maxlen", [
+    ([], 150), (["--adapter", "--polyA", "--discard", "-t", "1"], 150), (["--kmer_rarefaction", "--split_size", "20000"], 250),
+    (["--mode", "HARD", "-q", "11", "--5trim_off"], 100), (["--mode", "BWA", "--avg_q", "22", "-n", "1"], 151),
+    (["--5end", "5", "--3end", "11", "--min_L", "30", "--lc", "0.6"], 126), (["--replace_to_N_q", "14", "-q", "12", "--out_ascii", "64"], 150),
+    (["--qc_only", "--adapter", "-t", "1"], 150), (["--phiX", "-t", "1"], 300)],
+    ids=["default", "adapter", "kmer250", "hard100", "bwa_avgq151", "ends126", "replaceN", "qc_only_adapter", "phix300"])
+def test_native_cli_equals_the_reference_run_here_on_fresh_pairs(args, maxlen, tmp_path):
+    """Beyond the committed goldens: 40 000 fresh adversarial pairs (FAQCS_TEST_SEED re-seeds them) through faqcs_mi and through the REAL
+    reference binary (oracle/_ref/FaQCs_ref travels to the GPU box), both run here: every output file byte-identical."""
+    import hashlib
+    import subprocess
+
+    if not os.path.exists(_REF_BIN):
+        pytest.skip("oracle/_ref/FaQCs_ref not built (needs /root/reference at build time: make -C oracle ref)")
+    import make_fixtures
+
+    n = 6000 if "--phiX" in args else 40000
+    r1, r2 = make_fixtures.adversarial(n, seed=1000 + SEED * 31 + maxlen, maxlen=maxlen, id_prefix="F")
+    p1, p2 = str(tmp_path / "f_1.fastq"), str(tmp_path / "f_2.fastq")
+    make_fixtures.write_fastq(p1, r1)
+    make_fixtures.write_fastq(p2, r2)
+    outs = {}
+    for name, binary in (("ref", _REF_BIN), ("mi", _CLI_BIN)):
+        out = str(tmp_path / name)
+        for _ in range(6):  # (the reference can die of SIGPIPE feeding the absent R: see make_golden.py)
+            subprocess.run(["rm", "-rf", out])
+            r = subprocess.run([binary, "-1", p1, "-2", p2, "-d", out, "--debug"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            if r.returncode != -13:
+                break
+        assert r.returncode == 0, (name, r.returncode, r.stderr.decode(errors="replace")[-800:])
+        outs[name] = {fn: hashlib.md5(open(os.path.join(out, fn), "rb").read()).hexdigest() for fn in sorted(os.listdir(out)) if not fn.endswith(".pdf")}
+    assert outs["ref"].keys() == outs["mi"].keys(), (sorted(outs["ref"]), sorted(outs["mi"]))
+    bad = [fn for fn in outs["ref"] if outs["ref"][fn] != outs["mi"][fn]]
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("args", [[], ["--discard", "--adapter"], ["-u"]], ids=["paired", "paired_discard_adapter", "unpaired"])
 def test_native_cli_mapped_path_equals_streaming_path(args, tmp_path):
     """faqcs_mi reads uncompressed regular files through the memory-mapped path (parallel index / parse / format, pwrite at
