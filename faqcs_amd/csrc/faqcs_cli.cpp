@@ -11,6 +11,7 @@
 
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -1963,6 +1964,7 @@ static void report_done(int status)
 {
     if (g_done_fd < 0) return;
     fflush(nullptr);
+    prctl(PR_SET_PDEATHSIG, 0); // (the parent exits on the byte below, as planned: the teardown is not to be cut short by its death signal)
     const unsigned char b = (unsigned char)status;
     if (write(g_done_fd, &b, 1) != 1) {}
     ::close(g_done_fd);
@@ -1994,7 +1996,10 @@ int main(int argc, char **argv)
                 if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); }
                 _exit(EXIT_FAILURE);
             }
-            if (pid == 0) { ::close(pfd[0]); g_done_fd = pfd[1]; }
+            if (pid == 0) {
+                ::close(pfd[0]); g_done_fd = pfd[1];
+                prctl(PR_SET_PDEATHSIG, SIGTERM); // a caller that kills the command it started (its pid is the parent's) ends the worker too
+            }
             else { ::close(pfd[0]); ::close(pfd[1]); } // (fork failed: run here)
         }
     }
