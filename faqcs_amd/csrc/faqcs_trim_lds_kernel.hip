@@ -427,7 +427,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     // flush k (k = 1, 2, ...) comes before the block's chunk k * FLUSH_CHUNKS, the last one after its last chunk: the 16-bit halves of
     // the LDS cells take FLUSH_CHUNKS x 64 <= 65535 increments in between (chunks are claimed in order, so a wave that holds a chunk
     // >= k * FLUSH_CHUNKS waits at flush k while exactly the chunks below it are being finished)
+#ifdef FAQCS_LDS_TEST_FLUSH_CHUNKS // (test build: flush every few chunks, so that a small launch goes through many flushes and fills every block's rows)
+    constexpr uint32_t FLUSH_CHUNKS = (uint32_t)(FAQCS_LDS_TEST_FLUSH_CHUNKS) / NW * NW;
+#else
     constexpr uint32_t FLUSH_CHUNKS = 65535u / 64u / NW * NW;
+#endif
     constexpr uint32_t MAX_GROUPS = (uint32_t)FAQCS_PARTIAL_FLUSHES * FLUSH_CHUNKS / NW; // groups a block takes at most: one flush row per FLUSH_CHUNKS chunks
     constexpr uint32_t REG_FLUSH_EVERY = 7; // 6-bit fields: 7 chunks x 8 reads per row <= 63
     constexpr uint32_t NO_CHUNK = 0xffffffffu;
@@ -1392,7 +1396,11 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
     if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu; // one block per CU: its LDS holds a slot per wave
     if (grid == 0) return hipSuccess;
     // every block can take FAQCS_PARTIAL_FLUSHES x 1020 chunks: a launch the blocks could not take between them goes to another kernel
+#ifdef FAQCS_LDS_TEST_FLUSH_CHUNKS
+    if ((uint64_t)chunks > (uint64_t)grid * FAQCS_PARTIAL_FLUSHES * ((uint32_t)(FAQCS_LDS_TEST_FLUSH_CHUNKS) / NW * NW)) return hipErrorNotSupported; // (up to the brim)
+#else
     if ((uint64_t)chunks > (uint64_t)grid * FAQCS_PARTIAL_FLUSHES * (65535u / 64u / NW * NW) * 3 / 4) return hipErrorNotSupported;
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
                        reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err, tn_flags);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
