@@ -4,11 +4,13 @@
 // ONE wavefront per read, lane = position modulo 64.  The chunked kernels keep a whole read (or 64 of them) in registers / LDS and
 // fold the reference's float tests into per-length integer tables; neither scales to 32 767 positions, and reads of this kind are
 // few and long, so this kernel trades their tricks for a plain structure:
-//   * every pass streams the read from global memory 64 positions at a time (a read is 2 x <= 32 KB: it stays in the L2 between
-//     the passes), per-read sums are ballots + popcounts into wave-uniform (scalar) counters;
+//   * every pass streams the read from global memory, four 64-position pieces per round (a read is 2 x <= 32 KB: it stays in the L2
+//     between the passes); per-read counts are per-lane 16-bit fields summed over the wave once per read (as ballots + popcounts into
+//     scalar counters they made the kernel scalar-issue bound: a CU retires one scalar instruction per clock);
 //   * the quality trimmers (BWA_plus / BWA / HARD, trim.cpp:629-793) are WALKED exactly as the reference walks them, as
 //     wave-uniform scalar code over a 64-score register chunk read with v_readlane: a walk ends two positions after the area
-//     turns negative, i.e. after a handful of steps on a good read, and costs |tail| steps on a bad one;
+//     turns negative, i.e. after a handful of steps on a good read; a whole 64-position piece none of whose scores exceeds Q is
+//     taken in one step (the area is monotone there), so a long low-quality tail costs |tail| / 64 steps;
 //   * the float expressions of the average-quality and low-complexity tests and of the composition bins are evaluated as the
 //     reference writes them (IEEE single / double operations, no contraction), not through tables;
 //   * the per-position matrices (position x quality, position x base, before and after trimming: four counters per base) are NOT
