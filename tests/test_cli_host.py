@@ -157,3 +157,24 @@ def test_report_script_is_structurally_sound():
     for fn in re.findall(r"^(\w+) <- function", script, flags=re.M):
         assert len(re.findall(r"\b%s\b" % re.escape(fn), script)) >= 2, fn  # (its definition and at least one use, called or passed on)
     assert "dev.off()" in script
+
+
+def test_terminal_n_flags_of_a_packed_arena():
+    """faqcs_batch.terminal_n as the Python driver fills it (bit 0: first base is an upper-case N, bit 1: last base is): against a
+    plain loop, on reads that are empty, one base long, all N, lower-case n at the ends."""
+    import numpy as np
+
+    from faqcs_amd import driver
+
+    rng = np.random.Generator(np.random.PCG64(5))
+    reads = []
+    for k in range(500):
+        L = int(rng.integers(0, 40))
+        s = np.frombuffer(b"ACGTNn", np.uint8)[rng.integers(0, 6, L)].tobytes()
+        reads.append((b"@r", s, b"I" * L))
+    reads += [(b"@r", b"", b""), (b"@r", b"N", b"I"), (b"@r", b"n", b"I"), (b"@r", b"NN", b"II"), (b"@r", b"AN", b"II"), (b"@r", b"NA", b"II")]
+    seq, qual, offset, seg = driver.pack_segments([reads[:300], reads[300:]])
+    got = driver.terminal_n_flags(seq, offset)
+    want = np.array([(1 if s[:1] == b"N" else 0) | (2 if s[-1:] == b"N" else 0) for _, s, _ in reads], dtype=np.uint8)
+    assert got.dtype == np.uint8 and (got == want).all()
+    assert len(driver.terminal_n_flags(seq[:0], offset[:1])) == 0
