@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
 // each -- lane = position inside the tile, so the 64 adds of an instruction fall on 64 consecutive cells: no bank conflicts -- and
 // at the end of the tile the non-zero cells go to the u64 counter block.  A base costs two LDS adds (quality, class) instead of four
 // memory-side atomics; the global atomics left are one per non-zero cell, tile and block.
-constexpr int LA_TILE = 512, LA_NW = 16; // (16 waves per CU: the loop waits on global loads)
+constexpr int LA_TILE = 512, LA_NW = 16, LA_UNR = LA_TILE / 64; // (16 waves per CU, a tile's 16 loads per read in flight: the loop waits on global loads)
 __global__ __launch_bounds__(LA_NW * 64) void long_accumulate(const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
                                                              const uint32_t *__restrict__ off, const uint32_t n_reads, const uint2 *__restrict__ out,
                                                              const uint32_t *__restrict__ lead_trail, uint64_t *__restrict__ counters, const uint32_t max_len)
@@ -470,10 +470,10 @@ __global__ __launch_bounds__(LA_NW * 64) void long_accumulate(const DevParams P,
                     const uint32_t k0 = kept ? (uniu(res.x) & 0xffffu) : 0u, k1 = kept ? k0 + (uniu(res.x) >> 16) : 0u;
                     const uint32_t e = len0 < t1 ? len0 : t1;
 #pragma unroll 1
-                    for (uint32_t pb = t0; pb < e; pb += 256) { // four 64-position pieces per round: their eight loads are in flight together
-                        uint32_t rq[4], b0v[4];
+                    for (uint32_t pb = t0; pb < e; pb += 64u * LA_UNR) { // the whole tile of a read in one round: its 2 x LA_UNR loads are in flight together (the loop waits on memory)
+                        uint32_t rq[LA_UNR], b0v[LA_UNR];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < LA_UNR; ++u) {
                             const uint32_t p = pb + 64u * (uint32_t)u + (uint32_t)lane;
                             const uint32_t pc = p < e ? p : e - 1u; // (clamped: unconditional loads, no EXEC region per load)
                             const uint32_t qv = (uint32_t)qual[(size_t)o + pc];
@@ -481,21 +481,22 @@ __global__ __launch_bounds__(LA_NW * 64) void long_accumulate(const DevParams P,
                             b0v[u] = (uint32_t)seq[(size_t)o + pc];
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < LA_UNR; ++u) {
+                            // (no EXEC regions: a lane past the read's end, or on a byte that is no base, adds 0 -- the kernel is bound by scalar issue)
                             const uint32_t p = pb + 64u * (uint32_t)u + (uint32_t)lane;
-                            if (p < e) {
-                                int sc = q_score(rq[u], in_off);
-                                sc = sc > 41 ? 41 : sc; // (cannot happen: a read with such a score carries FAQCS_F_ERR_QUALITY)
-                                const uint32_t b0 = b0v[u];
-                                const bool in = p >= k0 && p < k1;
-                                const uint32_t x = p - t0;
-                                atomicAdd(&s_q[sc][x], in ? 0x10001u : 1u);
-                                const uint32_t col0 = base_col(b0);
-                                const uint32_t b = (P.replace_q > 0 && b0 == 'G' && sc < (int)P.replace_q) ? (uint32_t)'N' : b0;
-                                const uint32_t col = in ? base_col(b) : 5u;
-                                if (col0 < 5u) atomicAdd(&s_b[col0][x], col == col0 ? 0x10001u : 1u);
-                                if (col < 5u && col != col0) atomicAdd(&s_b[col][x], 0x10000u);
-                            }
+                            const bool ok = p < e;
+                            int sc = q_score(rq[u], in_off);
+                            sc = sc > 41 ? 41 : sc; // (cannot happen: a read with such a score carries FAQCS_F_ERR_QUALITY)
+                            const uint32_t b0 = b0v[u];
+                            const bool in = ok && p >= k0 && p < k1;
+                            const uint32_t x = ok ? p - t0 : 0u;
+                            atomicAdd(&s_q[sc][x], ok ? (in ? 0x10001u : 1u) : 0u);
+                            const uint32_t col0 = base_col(b0);
+                            const uint32_t b = (P.replace_q > 0 && b0 == 'G' && sc < (int)P.replace_q) ? (uint32_t)'N' : b0;
+                            const uint32_t col = in ? base_col(b) : 5u;
+                            atomicAdd(&s_b[col0 < 5u ? col0 : 0u][x], (ok && col0 < 5u) ? (col == col0 ? 0x10001u : 1u) : 0u);
+                            const bool other = col < 5u && col != col0; // (a G that --replace_to_N_q turned into N inside the window)
+                            if (__any(other)) { if (other) atomicAdd(&s_b[col][x], 0x10000u); }
                         }
                     }
                 }
