@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "faqcs_dev.h"
+#include "faqcs_kmer.h"
 
 // kernels (other translation units)
 struct AdapterDev {
@@ -27,31 +28,6 @@ struct AdapterDev {
     uint32_t n_adapters;
     float match_rate;
 };
-struct __attribute__((aligned(16))) KmerSlot { unsigned long long key; uint32_t count_m1, first_epoch; };
-struct KmerTable {
-    KmerSlot *slots;
-    uint64_t mask;
-    unsigned long long *stats;
-    uint32_t partitioned;
-};
-struct KmerOutbox {
-    ulonglong2 *items;
-    unsigned long long *dest_count, *dest_offset, *dest_cursor;
-    uint32_t world;
-    uint32_t *wave_count;
-    unsigned long long *wave_offset;
-    uint32_t total_waves;
-};
-uint32_t faqcs_kmer_extract_waves(uint32_t n_reads, int n_cu);
-hipError_t faqcs_launch_kmer_extract(const DevParams &P, uint32_t k, const KmerOutbox &O, bool fill, const uint8_t *seq,
-                                     const uint8_t *qual, const uint32_t *off, uint32_t r_begin, uint32_t r_end,
-                                     const faqcs_read_result *results, uint32_t epoch, uint32_t wave_base, int n_cu, hipStream_t st);
-hipError_t faqcs_launch_kmer_outbox_offsets(const KmerOutbox &O, hipStream_t st);
-hipError_t faqcs_launch_kmer_insert_items(const KmerTable &T, const void *items, unsigned long long n,
-                                          unsigned long long *tot_by_epoch, uint32_t n_epochs, int n_cu, hipStream_t st);
-hipError_t faqcs_launch_kmer_table_init(const KmerTable &T, int n_cu, hipStream_t st);
-hipError_t faqcs_launch_kmer_first_epoch_histogram(const KmerTable &T, unsigned long long *hist, uint32_t n_epochs, int n_cu,
-                                                   hipStream_t st);
 const char *faqcs_last_trim_kernel();
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
@@ -63,12 +39,6 @@ hipError_t faqcs_launch_composition(const unsigned long long *rec_pre, const uns
 hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
                                 uint32_t max_len, const uint32_t *seg_start, uint32_t n_segments, uint32_t *ad_sl,
                                 uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, uint32_t dbg, int n_cu, hipStream_t st);
-hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T, const uint8_t *seq, const uint8_t *qual,
-                             const uint32_t *off, uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results,
-                             int n_cu, hipStream_t st);
-hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
-                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
-                                       hipStream_t st);
 hipError_t faqcs_launch_synth(uint8_t *d_seq, uint8_t *d_qual, uint32_t *d_offset, uint32_t n_reads, uint32_t L,
                               uint64_t seed, uint64_t first_read, float adapter_frac, uint64_t genome_len, float at_frac, hipStream_t st);
 
@@ -157,10 +127,26 @@ struct faqcs_ctx {
     unsigned long long *d_snaps = nullptr; // [snap_cap][2]
     size_t snap_cap = 0, n_snaps = 0;
     std::map<uint64_t, uint64_t> kmer_hist; // PlotInfo::kmer_frequency_histogram
+    // combine-before-insert k-mer counting (every context that is not owner-partitioned; faqcs_kmer_group_kernel.hip): the
+    // k-mers of a run of segments are appended to bucket buffers at submission time and reach the table group by group
+    struct KmerGroup {
+        bool ready = false;
+        bool direct = false;          // FAQCS_KMER_DIRECT=1 (diagnostics): one atomic insert per occurrence (kmer_count), as in rounds 1-3
+        uint64_t cap_items = 0;       // item bound of a group
+        uint64_t bound_items = 0;     // upper bound of the items the open group holds
+        std::vector<uint32_t> run_epoch, upload[2]; // epochs (relative to epoch_base) of the open group's runs; host copies in flight
+        unsigned n_flushes = 0;
+        uint32_t epoch_base = 0, split = 1;
+        KmerGroupDev dev{};           // (n_runs / epoch_base filled in at flush time)
+        uint32_t ep_cap = 0;          // entries of dev.first_hist / dev.tot_by_epoch
+        uint32_t ep_used = 0;         // 1 + largest epoch seen
+        size_t points_final = 0;      // points whose (distinct, total) are final (resolved before the table restarted)
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> flush_ev; size_t flush_ev_used = 0;
+    } kg;
     // kernel timing
     std::vector<Timing> timings;
     size_t timing_used = 0;
-    double kernel_ms = 0.0, adapter_ms = 0.0, kmer_ms = 0.0, kmer_insert_ms = 0.0;
+    double kernel_ms = 0.0, adapter_ms = 0.0, kmer_ms = 0.0, kmer_insert_ms = 0.0, kmer_flush_ms = 0.0;
     uint64_t kernel_launches = 0;
     hipEvent_t ins_a = nullptr, ins_b = nullptr;
     const char *trim_kernel = "";
@@ -404,7 +390,12 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     if (p->kmer_rarefaction) {
         uint64_t slots = p->kmer_table_slots ? p->kmer_table_slots : (1ull << 28);
         uint64_t pow2 = 1; while (pow2 < slots) pow2 <<= 1;
+        // every partition of the combine-before-insert path owns a slice of the table (faqcs_kmer_group_kernel.hip)
+        if (pow2 < (uint64_t)KG_SLICE_MIN << 16) pow2 = (uint64_t)KG_SLICE_MIN << 16;
+        if (pow2 > (uint64_t)KG_SLICE_MAX << 16) return fail(FAQCS_E_INVAL, "faqcs_create: kmer_table_slots above 2^32");
         c->kt.mask = pow2 - 1;
+        { uint32_t lg = 0; while ((1ull << lg) < pow2) ++lg; if (lg > 46) return fail(FAQCS_E_INVAL, "faqcs_create: kmer_table_slots too large"); c->kt.shift = 62 - lg; }
+        if (const char *e = getenv("FAQCS_KMER_DIRECT")) c->kg.direct = atoi(e) != 0;
         HIPCHK(hipMalloc((void **)&c->kt.slots, pow2 * sizeof(KmerSlot)));
         HIPCHK(hipMalloc((void **)&c->kt.stats, 64));
         HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute)); // empty key, count - 1 = 0, no epoch
@@ -435,6 +426,9 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     for (auto &rs : c->rec) { rs.pre.release(); rs.post.release(); if (rs.trimmed) (void)hipEventDestroy(rs.trimmed); if (rs.folded) (void)hipEventDestroy(rs.folded); }
     if (c->aux) (void)hipStreamDestroy(c->aux);
     c->ob_items.release(); c->ob_wave_count.release(); c->ob_wave_offset.release();
+    { void *kg_ptrs[] = {c->kg.dev.l1, c->kg.dev.l2, c->kg.dev.cur1, c->kg.dev.bounds, c->kg.dev.run_epoch, c->kg.dev.first_hist, c->kg.dev.tot_by_epoch};
+      for (void *q : kg_ptrs) if (q) (void)hipFree(q);
+      for (auto &ev : c->kg.flush_ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); } }
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -450,13 +444,163 @@ extern "C" int faqcs_set_quality(faqcs_ctx *c, int quality)
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// combine-before-insert k-mer counting: host side (kernels: faqcs_kmer_group_kernel.hip)
+// ---------------------------------------------------------------------------------------------------------
+static int kg_init(faqcs_ctx *c)
+{
+    faqcs_ctx::KmerGroup &g = c->kg;
+    if (g.ready) return 0;
+    const uint64_t slots = c->kt.mask + 1;
+    uint64_t G = slots / 2;
+    if (G < (1ull << 18)) G = 1ull << 18;
+    if (G > (1ull << 29)) G = 1ull << 29;
+    if (const char *e = getenv("FAQCS_KMER_GROUP_ITEMS")) { const uint64_t v = strtoull(e, nullptr, 0); if (v >= (1ull << 12) && v <= (1ull << 31)) G = v; }
+    g.cap_items = G;
+    KmerGroupDev &d = g.dev;
+    // level-2 scatter: blocks per level-1 bucket.  Every block pads one granule per partition it feeds, so small groups use one
+    g.split = G >= (1ull << 26) ? 8u : 1u;
+    d.cap1 = (uint32_t)(G / KG_FAN + G / (16 * KG_FAN) + 1024);
+    d.cap2 = (uint32_t)(G / (KG_FAN * KG_FAN) + G / (4 * KG_FAN * KG_FAN) + 64);
+    if (d.cap2 < (uint32_t)KG_MIN_CAP2) d.cap2 = KG_MIN_CAP2;
+    d.cap2 += g.split * KG_GRAN;
+    d.stride1 = d.cap1 + KG_GRAN; d.stride2 = d.cap2 + KG_GRAN;
+    HIPCHK(hipMalloc((void **)&d.l1, (size_t)KG_FAN * d.stride1 * 8));
+    HIPCHK(hipMalloc((void **)&d.l2, (size_t)KG_FAN * KG_FAN * d.stride2 * 8));
+    HIPCHK(hipMalloc((void **)&d.cur1, (size_t)(2 * KG_FAN + 2 * KG_FAN * KG_FAN) * 4));
+    d.lim1 = d.cur1 + KG_FAN; d.cur2 = d.lim1 + KG_FAN; d.lim2 = d.cur2 + KG_FAN * KG_FAN;
+    HIPCHK(hipMalloc((void **)&d.bounds, (size_t)KG_MAX_RUNS * KG_FAN * 4));
+    HIPCHK(hipMalloc((void **)&d.run_epoch, (size_t)KG_MAX_RUNS * 4));
+    HIPCHK(faqcs_launch_kmer_group_reset(d, c->compute));
+    g.ready = true;
+    return 0;
+}
+
+// first_hist / tot_by_epoch hold at least `need` epochs (grown with their contents)
+static int kg_ensure_epochs(faqcs_ctx *c, uint32_t need)
+{
+    faqcs_ctx::KmerGroup &g = c->kg;
+    if (need > g.ep_used) g.ep_used = need;
+    if (need <= g.ep_cap) return 0;
+    const uint32_t cap = need + need / 2 + 4096;
+    unsigned long long *f = nullptr, *t = nullptr;
+    HIPCHK(hipMalloc((void **)&f, (size_t)cap * 8)); HIPCHK(hipMalloc((void **)&t, (size_t)cap * 8));
+    HIPCHK(hipMemsetAsync(f, 0, (size_t)cap * 8, c->compute)); HIPCHK(hipMemsetAsync(t, 0, (size_t)cap * 8, c->compute));
+    if (g.ep_cap) {
+        HIPCHK(hipMemcpyAsync(f, g.dev.first_hist, (size_t)g.ep_cap * 8, hipMemcpyDeviceToDevice, c->compute));
+        HIPCHK(hipMemcpyAsync(t, g.dev.tot_by_epoch, (size_t)g.ep_cap * 8, hipMemcpyDeviceToDevice, c->compute));
+        HIPCHK(hipStreamSynchronize(c->compute)); // (kernels in flight hold the old pointers)
+        (void)hipFree(g.dev.first_hist); (void)hipFree(g.dev.tot_by_epoch);
+    }
+    g.dev.first_hist = f; g.dev.tot_by_epoch = t; g.dev.n_epochs = cap; g.ep_cap = cap;
+    return 0;
+}
+
+// the open group's items reach the table: level-2 scatter, combine + insert, cursors back to zero (all on the compute stream)
+// (timed: a flush outside a submission's k0 .. k1 events -- the one faqcs_sync() makes -- brings its own pair)
+static int kg_flush(faqcs_ctx *c, bool timed = false)
+{
+    faqcs_ctx::KmerGroup &g = c->kg;
+    if (!g.ready || g.run_epoch.empty()) return 0;
+    std::vector<uint32_t> &up = g.upload[g.n_flushes++ & 1]; // (kept alive past the asynchronous copy)
+    up = g.run_epoch;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (timed) {
+        if (g.flush_ev_used == g.flush_ev.size()) {
+            hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+            g.flush_ev.emplace_back(a, b);
+        }
+        ev = g.flush_ev[g.flush_ev_used++];
+        HIPCHK(hipEventRecord(ev.first, c->compute));
+    }
+    HIPCHK(hipMemcpyAsync(g.dev.run_epoch, up.data(), up.size() * 4, hipMemcpyHostToDevice, c->compute));
+    g.dev.n_runs = (uint32_t)up.size(); g.dev.epoch_base = g.epoch_base;
+    HIPCHK(faqcs_launch_kmer_group_flush(g.dev, c->kt, g.split, c->compute));
+    if (timed) HIPCHK(hipEventRecord(ev.second, c->compute));
+    g.run_epoch.clear(); g.bound_items = 0;
+    return 0;
+}
+
+// the k-mers of reads [r0, r1) -- one epoch -- join the open group.  host_off (may be null): the host copy of the offsets, for a
+// tight item bound (an occurrence starts at a distinct base); otherwise per_read items bound every read.
+static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, const uint32_t *d_off, uint32_t r0, uint32_t r1,
+                      const faqcs_read_result *d_res, uint64_t per_read, const uint32_t *host_off, uint32_t epoch)
+{
+    faqcs_ctx::KmerGroup &g = c->kg;
+    if (int rc = kg_init(c)) return rc;
+    if (int rc = kg_ensure_epochs(c, epoch + 1)) return rc;
+    if (per_read == 0) per_read = 1;
+    while (r0 < r1) {
+        if (g.run_epoch.size() == (size_t)KG_MAX_RUNS || (!g.run_epoch.empty() && epoch - g.epoch_base >= (uint32_t)KG_EPOCH_SPAN)) {
+            if (int rc = kg_flush(c)) return rc;
+        }
+        // every block of a launch pads one granule per bucket (<= KG_FAN * KG_GRAN items): part of the bound
+        const uint64_t pad = (uint64_t)faqcs_kmer_group_grid(r1 - r0, c->n_cu) * KG_FAN * KG_GRAN;
+        const uint64_t room = g.cap_items > g.bound_items + pad ? g.cap_items - g.bound_items - pad : 0;
+        uint32_t take; uint64_t bound;
+        if (host_off) { // largest take with off[r0 + take] - off[r0] <= room (offsets do not decrease)
+            uint32_t lo = 0, hi = r1 - r0;
+            while (lo < hi) { const uint32_t mid = lo + (hi - lo + 1) / 2; if ((uint64_t)(host_off[r0 + mid] - host_off[r0]) <= room) lo = mid; else hi = mid - 1; }
+            take = lo; bound = (uint64_t)(host_off[r0 + take] - host_off[r0]);
+        } else {
+            const uint64_t fit = room / per_read;
+            take = fit < (uint64_t)(r1 - r0) ? (uint32_t)fit : r1 - r0; bound = (uint64_t)take * per_read;
+        }
+        if (take == 0) { // (an empty group always has room for a read: a read gives < 2^15 items, a group takes >= 2^12 ... 2^18)
+            if (g.run_epoch.empty()) { take = 1; bound = g.cap_items; }
+            else { if (int rc = kg_flush(c)) return rc; continue; }
+        }
+        if (g.run_epoch.empty()) g.epoch_base = epoch;
+        HIPCHK(faqcs_launch_kmer_group_extract(c->dp, c->prm.kmer, g.dev, c->kt, (uint32_t)g.run_epoch.size(), epoch, d_seq, d_qual, d_off,
+                                               r0, r0 + take, d_res, c->n_cu, c->compute));
+        g.run_epoch.push_back(epoch - g.epoch_base);
+        g.bound_items += bound + (uint64_t)faqcs_kmer_group_grid(take, c->n_cu) * KG_FAN * KG_GRAN;
+        r0 += take;
+    }
+    return 0;
+}
+
+// (distinct, total) of the points that are not final yet, from the epoch histograms: distinct(point i) = keys whose first epoch
+// is <= i, total(point i) = occurrences with epoch <= i (both arrays restart with the table, faqcs_kmer_end_table)
+static int kg_resolve_points(faqcs_ctx *c)
+{
+    faqcs_ctx::KmerGroup &g = c->kg;
+    if (!g.ready || c->points.size() <= g.points_final) return 0;
+    const size_t n = std::min<size_t>(c->points.size(), g.ep_used);
+    std::vector<unsigned long long> f(n), t(n);
+    if (n) {
+        HIPCHK(hipMemcpy(f.data(), g.dev.first_hist, n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(t.data(), g.dev.tot_by_epoch, n * 8, hipMemcpyDeviceToHost));
+    }
+    unsigned long long df = 0, dt = 0;
+    for (size_t i = 0; i < c->points.size(); ++i) {
+        if (i < n) { df += f[i]; dt += t[i]; }
+        if (i >= g.points_final) { c->points[i].distinct_kmer = df; c->points[i].total_kmer = dt; }
+    }
+    return 0;
+}
+
+static int kg_totals(faqcs_ctx *c, unsigned long long *distinct, unsigned long long *total)
+{
+    faqcs_ctx::KmerGroup &g = c->kg;
+    *distinct = *total = 0;
+    if (!g.ready || !g.ep_used) return 0;
+    std::vector<unsigned long long> f(g.ep_used), t(g.ep_used);
+    HIPCHK(hipMemcpy(f.data(), g.dev.first_hist, (size_t)g.ep_used * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(t.data(), g.dev.tot_by_epoch, (size_t)g.ep_used * 8, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < g.ep_used; ++i) { *distinct += f[i]; *total += t[i]; }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // submission
 // ---------------------------------------------------------------------------------------------------------
 // seq/qual/off are device pointers valid for indices off[0]..off[n]; host_off is the host copy of the offsets
 // (needed for the max read length and k-mer bookkeeping), d_res a device result array.
 static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, const uint32_t *d_off, uint32_t n,
-                   uint32_t max_len, const uint32_t *seg, uint32_t n_seg, faqcs_read_result *d_res, const uint8_t *d_tn = nullptr)
+                   uint32_t max_len, const uint32_t *seg, uint32_t n_seg, faqcs_read_result *d_res, const uint8_t *d_tn = nullptr,
+                   const uint32_t *host_off = nullptr)
 {
     const faqcs_params &p = c->prm;
     uint32_t *d_sl = nullptr; uint16_t *d_hit = nullptr;
@@ -547,8 +691,14 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
     // (or at the end of the batch / of the curve): only there does the order of insertion become observable.
     uint32_t run_begin = seg[0];
     if (tm && c->kmer_active) { HIPCHK(hipEventRecord(tm->k0, c->compute)); tm->kmer = true; }
+    const bool direct = c->kg.direct;
+    const uint64_t per_read = max_len >= p.kmer ? (uint64_t)(max_len - p.kmer + 1) : 1;
     auto flush_run = [&](uint32_t run_end) -> int {
-        if (run_end > run_begin) HIPCHK(faqcs_launch_kmer(c->dp, p.kmer, c->kt, d_seq, d_qual, d_off, run_begin, run_end, d_res, c->n_cu, c->compute));
+        if (run_end > run_begin) {
+            if (direct) HIPCHK(faqcs_launch_kmer(c->dp, p.kmer, c->kt, d_seq, d_qual, d_off, run_begin, run_end, d_res, c->n_cu, c->compute));
+            // the run's epoch: the index of the next sampling point (the first one that will include these occurrences)
+            else if (int rc = kg_add_run(c, d_seq, d_qual, d_off, run_begin, run_end, d_res, per_read, host_off, (uint32_t)c->points.size())) return rc;
+        }
         run_begin = run_end;
         return 0;
     };
@@ -563,18 +713,20 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
                 (index > num_rarefaction && num_rarefaction < p.num_subsample))
                 if (int rc = flush_run(r1)) return rc;
             if (index > num_rarefaction && num_rarefaction < p.num_subsample) {
-                if (c->n_snaps == c->snap_cap) { // drain the snapshots taken so far
-                    HIPCHK(hipStreamSynchronize(c->compute));
-                    std::vector<unsigned long long> h(c->n_snaps * 2);
-                    HIPCHK(hipMemcpy(h.data(), c->d_snaps, c->n_snaps * 16, hipMemcpyDeviceToHost));
-                    for (auto &pp : c->pending) { c->points[pp.point_index].distinct_kmer = h[2 * pp.snap_index]; c->points[pp.point_index].total_kmer = h[2 * pp.snap_index + 1]; }
-                    c->pending.clear(); c->n_snaps = 0;
-                }
-                HIPCHK(hipMemcpyAsync(c->d_snaps + 2 * c->n_snaps, c->kt.stats, 16, hipMemcpyDeviceToDevice, c->compute));
                 faqcs_rarefaction pt{c->total_number, 0, 0};
                 c->points.push_back(pt);
-                c->pending.push_back({c->points.size() - 1, c->n_snaps});
-                ++c->n_snaps;
+                if (direct) { // the table's running (distinct, total) in stream order
+                    if (c->n_snaps == c->snap_cap) { // drain the snapshots taken so far
+                        HIPCHK(hipStreamSynchronize(c->compute));
+                        std::vector<unsigned long long> h(c->n_snaps * 2);
+                        HIPCHK(hipMemcpy(h.data(), c->d_snaps, c->n_snaps * 16, hipMemcpyDeviceToHost));
+                        for (auto &pp : c->pending) { c->points[pp.point_index].distinct_kmer = h[2 * pp.snap_index]; c->points[pp.point_index].total_kmer = h[2 * pp.snap_index + 1]; }
+                        c->pending.clear(); c->n_snaps = 0;
+                    }
+                    HIPCHK(hipMemcpyAsync(c->d_snaps + 2 * c->n_snaps, c->kt.stats, 16, hipMemcpyDeviceToDevice, c->compute));
+                    c->pending.push_back({c->points.size() - 1, c->n_snaps});
+                    ++c->n_snaps;
+                }
             }
             if (num_rarefaction >= p.num_subsample) c->kmer_active = 0; // trim.cpp:180-184
         }
@@ -644,7 +796,7 @@ extern "C" int faqcs_submit_async(faqcs_ctx *c, const faqcs_batch *b, faqcs_read
     HIPCHK(hipEventRecord(c->copied, c->copy));
     HIPCHK(hipStreamWaitEvent(c->compute, c->copied, 0));
     const uint8_t *d_seq = sl.seq.p + 16 - o0, *d_qual = sl.qual.p + 16 - o0;
-    if (int rc = enqueue(c, d_seq, d_qual, sl.off.p, n, max_len, b->segment_start, b->n_segments, c->s_res.p, d_tn)) return rc;
+    if (int rc = enqueue(c, d_seq, d_qual, sl.off.p, n, max_len, b->segment_start, b->n_segments, c->s_res.p, d_tn, b->offset)) return rc;
     if (n && results) HIPCHK(hipMemcpyAsync(results, c->s_res.p, (size_t)n * sizeof(faqcs_read_result), hipMemcpyDeviceToHost, c->compute));
     HIPCHK(hipEventRecord(sl.done, c->compute));
     HIPCHK(hipEventRecord(tk, c->compute));
@@ -723,8 +875,14 @@ extern "C" int faqcs_sync(faqcs_ctx *c)
     if (!c) return fail(FAQCS_E_INVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->copy));
+    if (int rc = kg_flush(c, true)) return rc; // "everything submitted is done" includes the k-mers still waiting in the open group
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipStreamSynchronize(c->aux));
+    for (size_t i = 0; i < c->kg.flush_ev_used; ++i) { // group flushes (they run behind a later submission or here): part of the k-mer time
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->kg.flush_ev[i].first, c->kg.flush_ev[i].second) == hipSuccess) c->kmer_flush_ms += ms;
+    }
+    c->kg.flush_ev_used = 0;
     for (size_t i = 0; i < c->timing_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->timings[i].a, c->timings[i].b) == hipSuccess) { c->kernel_ms += ms; ++c->kernel_launches; }
@@ -733,6 +891,7 @@ extern "C" int faqcs_sync(faqcs_ctx *c)
     }
     c->timing_used = 0;
     if (int rc = resolve_points(c)) return rc;
+    if (int rc = kg_resolve_points(c)) return rc;
     uint32_t e = 0;
     HIPCHK(hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
     if (e & 1u) return fail(FAQCS_E_QUALITY, "fastq.h:quality_score: Found a quality score value that is greater than the maximum allowed quality score");
@@ -814,7 +973,8 @@ extern "C" int faqcs_kmer_totals(faqcs_ctx *c, uint64_t *distinct, uint64_t *tot
     if (!c->kt.stats) return 0;
     if (int rc = faqcs_sync(c)) return rc;
     unsigned long long st[2];
-    HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    if (c->partitioned || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    else if (int rc = kg_totals(c, &st[0], &st[1])) return rc;
     *distinct = st[0]; *total = st[1];
     return 0;
 }
@@ -825,7 +985,8 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
     if (!c->kt.stats) return 0;
     if (int rc = faqcs_sync(c)) return rc;
     unsigned long long st[2];
-    HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    if (c->partitioned || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    else if (int rc = kg_totals(c, &st[0], &st[1])) return rc;
     if (st[0]) { // ++kmer_frequency_histogram[count] for every key, FaQCs.cpp:518-521
         const uint32_t DENSE = 1u << 16, BIGCAP = 1u << 20;
         unsigned long long *d_dense = nullptr, *d_big = nullptr, *d_nbig = nullptr;
@@ -854,6 +1015,11 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
     }
     HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute));
     HIPCHK(hipMemsetAsync(c->kt.stats, 0, 64, c->compute));
+    if (c->kg.ready && c->kg.ep_cap) { // the epoch histograms restart with the table; the points taken so far keep their values
+        c->kg.points_final = c->points.size();
+        HIPCHK(hipMemsetAsync(c->kg.dev.first_hist, 0, (size_t)c->kg.ep_cap * 8, c->compute));
+        HIPCHK(hipMemsetAsync(c->kg.dev.tot_by_epoch, 0, (size_t)c->kg.ep_cap * 8, c->compute));
+    }
     return 0;
 }
 
@@ -1002,7 +1168,7 @@ extern "C" int faqcs_kernel_time_ms(faqcs_ctx *c, double *avg_ms, uint64_t *n_la
     if (int rc = faqcs_sync(c)) return rc;
     *n_launches = c->kernel_launches;
     *avg_ms = c->kernel_launches ? c->kernel_ms / (double)c->kernel_launches : 0.0;
-    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kmer_ms = 0.0; c->kmer_insert_ms = 0.0; c->kernel_launches = 0;
+    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kmer_ms = 0.0; c->kmer_insert_ms = 0.0; c->kmer_flush_ms = 0.0; c->kernel_launches = 0;
     return 0;
 }
 
@@ -1016,8 +1182,8 @@ extern "C" int faqcs_kernel_report(faqcs_ctx *c, faqcs_kernel_times *out)
     out->trim_ms = c->kernel_launches ? c->kernel_ms / (double)c->kernel_launches : 0.0;
     out->adapter_ms = c->kernel_launches ? c->adapter_ms / (double)c->kernel_launches : 0.0;
     out->trim_kernel = c->trim_kernel;
-    out->kmer_ms = c->kernel_launches ? c->kmer_ms / (double)c->kernel_launches : 0.0;
+    out->kmer_ms = c->kernel_launches ? (c->kmer_ms + c->kmer_flush_ms) / (double)c->kernel_launches : 0.0;
     out->kmer_insert_ms = c->kernel_launches ? c->kmer_insert_ms / (double)c->kernel_launches : 0.0;
-    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kmer_ms = 0.0; c->kmer_insert_ms = 0.0; c->kernel_launches = 0;
+    c->kernel_ms = 0.0; c->adapter_ms = 0.0; c->kmer_ms = 0.0; c->kmer_insert_ms = 0.0; c->kmer_flush_ms = 0.0; c->kernel_launches = 0;
     return 0;
 }

@@ -11,120 +11,13 @@
 // counts), so any injective encoding with a consistent class representative yields identical integers.
 // Here enc = plane1 << 32 | plane0 (window bit t = t-th base), rc = reversed planes with plane0 inverted
 // (codes A=0,T=1,C=2,G=3: complement flips bit0, trim.cpp:904-917), key = min(enc, enc_rc).
-#include "faqcs_dev.h"
+#include "faqcs_kmer.h"
 
-// One 16-byte slot per key so that a probe touches ONE 64-byte sector (separate key / count arrays cost two random sectors
-// per insert).  An empty slot is {key = ~0, count_m1 = 0, first_epoch = ~0} (kmer_table_init): the count is stored MINUS ONE,
-// so the compare-and-swap that claims a slot already leaves the right count for a key seen once.
-// The path is bound by the chip's L2 atomic rate (~14 G atomics/s measured, independent of table size and key reuse), so
-// an insert costs ONE atomic wherever possible: a plain 16-byte load classifies the slot first (keys never change once
-// written, so a stale view can only say "empty" and fall through to the CAS); a new key costs the CAS only, a known key
-// the count add only, and the epoch min is issued only when it would lower the stored epoch.
-struct __attribute__((aligned(16))) KmerSlot {
-    unsigned long long key;
-    uint32_t count_m1;     // occurrences - 1
-    uint32_t first_epoch;  // owner-partitioned (multi-GPU) mode: smallest epoch that inserted the key
-};
-struct KmerTable {
-    KmerSlot *slots;           // [mask + 1]
-    uint64_t mask;             // slots - 1
-    unsigned long long *stats; // [0] distinct keys, [1] total occurrences, [2] overflow flag
-    uint32_t partitioned;      // maintain first_epoch
-};
-
-// multi-GPU exchange buffers of one submission (owner-partitioned mode)
-struct KmerOutbox {
-    ulonglong2 *items;              // (key, epoch) pairs, grouped by destination rank
-    unsigned long long *dest_count; // [world]  occurrences per destination (pass 1)
-    unsigned long long *dest_offset;// [world]  exclusive prefix of dest_count
-    unsigned long long *dest_cursor;// [world]  (unused by the kernels; kept zero)
-    uint32_t world;
-    // The fill pass takes NO atomics: the count pass leaves every wave's per-destination count in wave_count, a scan turns
-    // them into wave_offset (start of the wave's slice inside the destination's bucket), and a wave then advances private
-    // cursors.  Both passes use the same grid per launch, so a wave sees the same reads in both.
-    uint32_t *wave_count;            // [total waves of the submission][world]
-    unsigned long long *wave_offset; // same shape
-    uint32_t total_waves;
-};
-
-__device__ __forceinline__ uint64_t kmer_mix(uint64_t x)
-{
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-    return x;
-}
-// owner rank of a key: the HIGH half of the mix (the slot index uses the low bits), multiply-shift into [0, world)
-__device__ __forceinline__ uint32_t kmer_owner(uint64_t key, uint32_t world)
-{
-    return (uint32_t)(((kmer_mix(key) >> 32) * (uint64_t)world) >> 32);
-}
-
-// bits [p-k+1, p] (p = 64*c + lane) of the bit string whose 64-bit words are ... prev, cur
-__device__ __forceinline__ uint32_t window_bits(uint64_t cur, uint64_t prev, int lane, int k)
-{
-    const int lo = lane - (k - 1); // first bit relative to cur's bit 0 (may be negative: comes from prev)
-    uint64_t w;
-    if (lo >= 0) w = cur >> lo;
-    else w = (cur << (-lo)) | (prev >> (64 + lo));
-    return (uint32_t)(w & ((1ull << k) - 1ull));
-}
-
-// Calls emit(ok, key) once per 64-base chunk of read r in EVERY lane (ok = a canonical k-mer ends at this lane's
-// position), so emit may use wave-wide ballots.
-template <class F>
-__device__ __forceinline__ void kmer_enumerate(const DevParams &P, const uint32_t k, const uint8_t *__restrict__ seq,
-                                               const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off,
-                                               const uint32_t r, const uint2 *__restrict__ results, const int lane, F &&emit)
-{
-    const uint32_t o = off[r];
-    const int len = (int)(off[r + 1] - o);
-    int a = 0, n = len;
-    if (!P.qc_only) { // trimmed read of a valid record (trim.cpp:545-547); raw read under --qc_only (:260-262)
-        const uint2 res = results[r];
-        if (!(res.y & FAQCS_F_VALID)) return;
-        a = (int)(res.x & 0xffffu);
-        n = (int)(res.x >> 16);
-    }
-    uint64_t pv = 0, p0 = 0, p1 = 0;
-    const int c_begin = a >> 6, c_end = (a + n + 63) >> 6;
-#pragma unroll 1
-    for (int c = c_begin; c < c_end; ++c) {
-        const int p = c * 64 + lane;
-        const bool in = p >= a && p < a + n;
-        uint32_t b = in ? seq[(size_t)o + p] : 0u;
-        if (in && !P.qc_only && P.replace_q > 0 && b == 'G') { // G -> N precedes k-mer counting (trim.cpp:390-403)
-            int qv = (int)(int8_t)qual[(size_t)o + p] - P.in_off;
-            qv = qv < 0 ? 0 : qv;
-            if (qv < (int)P.replace_q) b = 'N';
-        }
-        const uint32_t l = b | 0x20u;
-        const bool isA = l == 'a', isT = l == 't', isC = l == 'c', isG = l == 'g';
-        const uint64_t cv = __ballot(isA | isT | isC | isG);
-        const uint64_t c0 = __ballot(isT | isG); // codes A=0 T=1 C=2 G=3 (FaQCs.h:35-42)
-        const uint64_t c1 = __ballot(isC | isG);
-        const uint32_t wv = window_bits(cv, pv, lane, (int)k);
-        const uint32_t w0 = window_bits(c0, p0, lane, (int)k);
-        const uint32_t w1 = window_bits(c1, p1, lane, (int)k);
-        pv = cv; p0 = c0; p1 = c1;
-        const uint32_t kmask = (uint32_t)((1ull << k) - 1ull);
-        const bool ok = wv == kmask; // k valid bases ending here (word_len >= k, trim.cpp:924)
-        const uint32_t r0 = __brev(~w0 & kmask) >> (32 - k), r1 = __brev(w1) >> (32 - k);
-        const uint64_t fwd = ((uint64_t)w1 << 32) | w0, rc = ((uint64_t)r1 << 32) | r0;
-        emit(ok, fwd < rc ? fwd : rc);
-    }
-}
-
-// The table's atomics, device scope.  (Checked in round 2: workgroup scope compiles to the SAME instructions on gfx950 -- the
-// atomics carry no scope bit below "device" -- and the counters show every one of them leaving the XCD's L2 for the memory
-// side (TCC_EA0_ATOMIC == TCC_ATOMIC, profiles/r2c/pmc_kmer_atomics.txt): with eight L2s that is where device-wide atomicity
-// lives.  There is no cheaper L2-local atomic to route XCD-partitioned slots to.)
-#define FAQCS_KMER_SCOPE __HIP_MEMORY_SCOPE_AGENT
-__device__ __forceinline__ unsigned long long slot_cas(unsigned long long *p, unsigned long long expect, unsigned long long v)
-{
-    __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FAQCS_KMER_SCOPE);
-    return expect;
-}
-__device__ __forceinline__ void slot_add(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, FAQCS_KMER_SCOPE); }
-__device__ __forceinline__ void slot_min(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, FAQCS_KMER_SCOPE); }
+// The path of kmer_count / kmer_insert_items is bound by the chip's memory-side atomic rate (~14 G atomics/s measured,
+// independent of table size and key reuse), so an insert costs ONE atomic wherever possible: a plain 16-byte load classifies
+// the slot first (keys never change once written, so a stale view can only say "empty" and fall through to the CAS); a new
+// key costs the CAS only, a known key the count add only, and the epoch min is issued only when it would lower the stored
+// epoch.  (The single-GPU path no longer inserts per occurrence at all: faqcs_kmer_group_kernel.hip.)
 
 // open-addressing insert; returns false when the probe budget is exhausted (table full)
 __device__ __forceinline__ bool kmer_insert(const KmerTable &T, const uint64_t key, const uint32_t epoch, bool &is_new)
