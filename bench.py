@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--at-frac", type=float, default=None, help="A+T fraction of the synthetic bases (default: uniform ACGT); 0.9 makes most "
                     "reads dinucleotide candidates of the low-complexity filter (an AT-rich genome)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="the default single-GPU run (config plain, 2x150) also runs BASELINE's adapter and k-mer "
+                    "configurations, two steps each, and reports them under \"configs\"; this switches that off")
     ap.add_argument("--e2e-pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_E2E_PAIRS", -1)),
                     help="pairs of the same workload written as FASTQ to /dev/shm for the end-to-end (files in, files out) run of faqcs_mi; 0 = skip; "
                          "default: 16 M pairs when /dev/shm has 64 GB free (20 GB of files; the fixed 0.4 s of HIP start-up weighs less), else 8 M")
@@ -88,15 +90,22 @@ def cpu_baseline(opt_args, hs, hq, L, n_sample):
                         a = (lo + i) * L
                         chunk.append(b"@SYN:%d/%d\n" % (i, mate) + hs[a:a + L].tobytes() + b"\n+\n" + hq[a:a + L].tobytes() + b"\n")
                     f.write(b"".join(chunk))
-            cmd = [ref, "-1", os.path.join(tmp, "r1.fq"), "-2", os.path.join(tmp, "r2.fq"), "-d", os.path.join(tmp, "out"),
-                   "-t", str(cores), "--ascii", "33", "--trim_only"] + opt_args
-            t0 = time.perf_counter()
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=600)
-            dt = time.perf_counter() - t0
+            # The reference's -t scaling is not monotone (its per-call `omp critical` merge of ~135 k counters per thread grows with the
+            # team, FaQCs trim.cpp:120-154): every thread count of {1, 8, 16, all cores} is timed on the same sample and the BEST is reported
+            tried = {}
+            for t in sorted({1, min(8, cores), min(16, cores), cores}):
+                cmd = [ref, "-1", os.path.join(tmp, "r1.fq"), "-2", os.path.join(tmp, "r2.fq"), "-d", os.path.join(tmp, "out%d" % t),
+                       "-t", str(t), "--ascii", "33", "--trim_only"] + opt_args
+                t0 = time.perf_counter()
+                subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=600)
+                tried[t] = round(2 * half / (time.perf_counter() - t0) / 1e6, 4)
             subprocess.run(["rm", "-rf", tmp])
-            return {"value": round(2 * half / dt / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "reference",
+            best = max(tried, key=lambda t: tried[t])
+            return {"value": tried[best], "unit": "M reads/s", "cores": best, "kind": "reference",
+                    "threads_tried": {str(t): v for t, v in tried.items()}, "host_cores": cores,
                     "sample": "%d pairs of the same synthetic 2x%d workload as uncompressed FASTQ, whole-process wall clock of "
-                              "FaQCs v2.10 -t %d --trim_only (parse+trim+write; the reference cannot separate them)" % (half, L, cores),
+                              "FaQCs v2.10 --trim_only (parse+trim+write; the reference cannot separate them) at -t 1 / 8 / 16 / all cores; "
+                              "value = the best of them (-t %d)" % (half, L, best),
                     "port_value": None if port is None else round(port, 4)}
         except Exception as e:
             print("cpu_baseline: reference run failed (%s)" % e, file=sys.stderr)
@@ -152,15 +161,22 @@ def e2e_run(opt_args, hs, hq, L, n_pairs):
         if r.returncode != 0:
             return {"error": r.stderr.decode(errors="replace")[-300:]}
         out_bytes = sum(os.path.getsize(os.path.join(tmp, "out", f)) for f in os.listdir(os.path.join(tmp, "out")))
+        # the same command in ONE process (FAQCS_MI_NO_FORK=1): its wall clock includes the release of the GPU context, the pinned buffers and
+        # the file mappings, which the default mode leaves to a worker process after the command has returned (report both)
+        subprocess.run(["rm", "-rf", os.path.join(tmp, "out")])
+        t0 = time.perf_counter()
+        r2 = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, env=dict(os.environ, FAQCS_MI_NO_FORK="1"))
+        dt_nofork = time.perf_counter() - t0
         in_bytes = sum(os.path.getsize(p) for p in paths)
         pipe = None
         if "first pair parsed" in marks and "outputs written" in marks and marks["outputs written"] > marks["first pair parsed"]:
             pipe = round(2 * n / (marks["outputs written"] - marks["first pair parsed"]) / 1e6, 3)
         return {"value": round(2 * n / dt / 1e6, 3), "unit": "M reads/s", "seconds": round(dt, 3), "pairs": n,
                 "pipeline_value": pipe, "stage_marks_s": marks,
+                "value_one_process": round(2 * n / dt_nofork / 1e6, 3) if r2.returncode == 0 else None, "seconds_one_process": round(dt_nofork, 3),
                 "input_GB": round(in_bytes / 1e9, 3), "output_GB": round(out_bytes / 1e9, 3),
                 "what": "faqcs_mi: uncompressed FASTQ in /dev/shm -> parse -> pinned SoA -> HIP trim -> trimmed FASTQ + QC.stats.txt in /dev/shm; "
-                        "wall clock of the command as its caller sees it, HIP start-up included (the command returns when every output file is complete; a worker process releases the GPU context and the mappings afterwards); pipeline_value = the same reads over the interval from the first "
+                        "wall clock of the command as its caller sees it, HIP start-up included (the command returns when every output file is complete; a worker process releases the GPU context and the mappings afterwards); value_one_process = the same command with FAQCS_MI_NO_FORK=1, teardown included; pipeline_value = the same reads over the interval from the first "
                         "parsed pair to the last output byte (faqcs_mi's own stage marks)"}
     except Exception as e:
         return {"error": str(e)}
@@ -294,22 +310,80 @@ def main():
     if use_dist:
         dist.barrier()
 
+    env = {"rank": rank, "world": world, "local": local, "dev": dev, "use_dist": use_dist, "backend": backend}
+    if a.e2e_pairs < 0:
+        try:
+            import shutil
+
+            a.e2e_pairs = 16e6 if shutil.disk_usage("/dev/shm").free > 64e9 else 8e6
+        except OSError:
+            a.e2e_pairs = 8e6
+    out, keep = run_workload(env, a, a.config, a.pairs, a.steps, a.warmup, a.read_len, want_host_sample=(rank == 0 and world == 1))
+    if rank == 0:
+        L = out["config"]["read_len"]
+        opt_args = keep["opt_args"]
+        if world == 1 and not a.no_cpu_baseline:
+            ns = min(200000, keep["sample_reads"])
+            pad = np.zeros(64, np.uint8)
+            out["cpu_baseline"] = cpu_baseline(opt_args, np.concatenate([keep["hs"][: ns * L], pad]), np.concatenate([keep["hq"][: ns * L], pad]), L, ns)
+        if world == 1 and a.e2e_pairs > 0 and a.config != "kmer" and os.path.exists(os.path.join(ROOT, "faqcs_amd", "faqcs_mi")):
+            ne = int(min(a.e2e_pairs, keep["sample_reads"] // 2))
+            out["e2e"] = e2e_run(opt_args, keep["hs"][: 2 * ne * L], keep["hq"][: 2 * ne * L], L, ne)
+    keep.clear()
+    # The other single-GPU configurations of BASELINE.json, at their sizes, next to the headline (N = 1, default invocation):
+    # configs[2] (--adapter --polyA on 100 M pairs) and configs[4]'s per-GPU share (25 M pairs 2x250 --kmer_rarefaction)
+    if world == 1 and a.config == "plain" and a.read_len is None and not a.no_other_configs:
+        others = {}
+        for cfg in ("adapter", "kmer"):
+            try:
+                o2, k2 = run_workload(env, a, cfg, 0.0, 2, 1, None, want_host_sample=False)
+                k2.clear()
+                rf = o2["roofline"]
+                others[cfg] = {"value": o2["value"], "unit": o2["unit"], "ms_per_step": o2["ms_per_step"], "steps": o2["steps"], "warmup": o2["warmup"],
+                               "workload": o2["config"]["workload"], "pairs_per_gpu": o2["config"]["pairs_per_gpu"], "read_len": o2["config"]["read_len"],
+                               "roofline": {k: rf[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch", "kernels_ms") if k in rf}}
+                for k in ("valu", "kmer_counters"):
+                    if k in rf:
+                        others[cfg]["roofline"][k] = rf[k]
+                if "kmer" in o2:
+                    others[cfg]["kmer"] = o2["kmer"]
+            except SystemExit as e:
+                others[cfg] = {"error": str(e)}
+        out["configs"] = others
+    if rank == 0:
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
+    if use_dist:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sample):
+    """One configuration: builds the resident data set, times `steps` steps, returns (the JSON object, a dict with a host
+    sample of the data for the CPU baseline / the end-to-end run).  Frees its device memory before it returns."""
+    import torch
+
     from faqcs_amd import _capi as capi
     from faqcs_amd import parallel
     from faqcs_amd.engine import HipEngine, _check
     from faqcs_amd.options import parse_args
 
-    L = a.read_len or (250 if a.config == "kmer" else 150)
-    if not a.pairs:
-        a.pairs = 25e6 if a.config == "kmer" else (125e6 if (a.config == "plain" and world == 8) else 100e6)
-    opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "1000000"]}.get(a.config, [])
+    rank, world, local, dev, use_dist, backend = env["rank"], env["world"], env["local"], env["dev"], env["use_dist"], env["backend"]
+    if use_dist:
+        import torch.distributed as dist
+    L = read_len or (250 if config == "kmer" else 150)
+    if not pairs:
+        pairs = 25e6 if config == "kmer" else (125e6 if (config == "plain" and world == 8) else 100e6)
+    opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "1000000"]}.get(config, [])
     opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
     eng = HipEngine(opt, 256 if L <= 256 else (capi.FAST_READ_LENGTH if L <= capi.FAST_READ_LENGTH else capi.MAX_READ_LENGTH), 33, device=local,
-                    kmer_table_slots=(1 << 31) if a.config == "kmer" else 0)
+                    kmer_table_slots=(1 << 31) if config == "kmer" else 0)
     lib = eng.lib
 
     # ---- resident synthetic data set ---------------------------------------------------------------------
-    n_reads = int(2 * a.pairs)
+    n_reads = int(2 * pairs)
     free, _ = torch.cuda.mem_get_info(dev)
     need = n_reads * (2 * L + 12) + (1 << 30)
     if need > free * 0.9:
@@ -318,14 +392,14 @@ def main():
     batches = []
     first = rank * n_reads
     done = 0
-    adapter_frac = 0.05 if a.config == "adapter" else 0.0
+    adapter_frac = 0.05 if config == "adapter" else 0.0
     while done < n_reads:
         m = min(batch, n_reads - done)
         seq = torch.empty(m * L + 64, dtype=torch.uint8, device=dev)
         qual = torch.empty(m * L + 64, dtype=torch.uint8, device=dev)
         off = torch.empty(m + 1, dtype=torch.int32, device=dev)
         res = torch.empty((m, 4), dtype=torch.int16, device=dev)
-        if a.config == "kmer":  # windows of a fixed 50 Mbp genome, either strand, 0.5 % substitutions
+        if config == "kmer":  # windows of a fixed 50 Mbp genome, either strand, 0.5 % substitutions
             _check(lib, lib.faqcs_synth_fill_genome(local, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, L, 20260101, first + done, 50_000_000))
         else:
             _check(lib, lib.faqcs_synth_fill(local, seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, L, 20260101, first + done, adapter_frac))
@@ -339,7 +413,8 @@ def main():
         tn = torch.empty(m, dtype=torch.uint8, device=dev)
         _check(lib, lib.faqcs_terminal_n_flags(local, seq.data_ptr(), off.data_ptr(), m, tn.data_ptr()))
         bt = capi.Batch(seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, len(seg) - 1, seg.ctypes.data, L, tn.data_ptr())
-        batches.append((seq, qual, off, res, seg, bt, m, tn))
+        bt_noflags = capi.Batch(seq.data_ptr(), qual.data_ptr(), off.data_ptr(), m, len(seg) - 1, seg.ctypes.data, L, None)
+        batches.append((seq, qual, off, res, seg, bt, m, tn, bt_noflags))
         done += m
     torch.cuda.synchronize()
 
@@ -349,10 +424,11 @@ def main():
     # shard by owner, RCCL all-to-all moves them, the owner inserts.  The epoch of a 32 768-read segment comes from the GLOBAL
     # sampling schedule (rank-major order of the shards): parallel.rarefaction_schedule.
     kx, kmer_epochs, kmer_points_seq = None, None, None
-    if a.config == "kmer" and world > 1:
+    if config == "kmer" and world > 1:
         sizes = []
         for _r in range(world):
-            for (_s, _q, _o, _res, seg, _bt, _m, _tn) in batches:  # (every rank holds batches of the same shape)
+            for bb in batches:  # (every rank holds batches of the same shape)
+                seg = bb[4]
                 sizes.extend(int(seg[i + 1] - seg[i]) for i in range(len(seg) - 1))
         ep, kmer_points_seq = parallel.rarefaction_schedule(sizes, opt.split_size, opt.num_subsample)
         per_rank = len(sizes) // world
@@ -360,13 +436,14 @@ def main():
         kx = parallel.KmerExchange(eng, rank, world, opt.num_subsample)
     kmer_last = {}
 
-    def step():
+    def step(flags=True):
         _check(lib, lib.faqcs_reset_counters(eng.ctx))  # one step = one job: its counter block starts at zero
-        if a.config == "kmer" and kx is None:  # ... and so does its k-mer table (the totals of the finished pass are kept for the report)
+        if config == "kmer" and kx is None:  # ... and so does its k-mer table (the totals of the finished pass are kept for the report)
             kmer_seen[0], kmer_seen[1] = eng.kmer_totals()
             eng.kmer_end_table()
         e0 = 0
-        for (_s, _q, _o, res, seg, bt, _m, _tn) in batches:
+        for bb in batches:
+            res, seg, bt = bb[3], bb[4], (bb[5] if flags else bb[8])
             if kx is not None:
                 eng.kmer_set_epochs(kmer_epochs[e0:e0 + len(seg) - 1])
                 e0 += len(seg) - 1
@@ -378,7 +455,7 @@ def main():
             kmer_last["points"] = len(pts)
             kmer_last["distinct"], kmer_last["total"] = (pts[-1][1], pts[-1][2]) if pts else (0, 0)
         if use_dist:
-            parallel.allreduce_counters_device(eng)
+            parallel.allreduce_counters_device(eng)  # the job's one collective: the 1.1 MB counter block, once per job (= step)
         else:
             eng.sync()
 
@@ -393,13 +470,13 @@ def main():
         dist.all_gather_object(got, [rank, local, torch.cuda.get_device_properties(local).name])
         ranks_seen = got
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     kt = capi.KernelTimes()
     lib.faqcs_kernel_report(eng.ctx, C.byref(kt))  # reset the kernel timers
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     fence()
     dt = time.perf_counter() - t0
@@ -414,73 +491,101 @@ def main():
     fs = blk[lay["filter_stats"][0]:lay["filter_stats"][0] + 32]
     if int(fs[capi.TOTAL_NUMBER]) != n_reads * world or int(fs[capi.TOTAL_LENGTH]) != n_reads * world * L:
         raise SystemExit("bench: counter block does not add up: %d reads counted, %d expected" % (int(fs[capi.TOTAL_NUMBER]), n_reads * world))
+    # the same job with batches that carry no terminal_n flags (the kernel then looks at the two end bases of every read itself):
+    # outside the timed region, reported beside the headline so that the effect of the flags is visible
+    noflag_value = None
+    if world == 1 and config == "plain":
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step(flags=False)
+        fence()
+        noflag_value = round(2 * n_reads / (time.perf_counter() - t1) / 1e6, 3)
+        lib.faqcs_kernel_report(eng.ctx, C.byref(capi.KernelTimes()))
 
+    out, keep = None, {"opt_args": opt_args}
     if rank == 0:
-        total_reads = n_reads * world * a.steps
+        total_reads = n_reads * world * steps
         value = total_reads / dt / 1e6
         reads_per_launch = n_reads / max(1, len(batches))
-        alg_bytes = reads_per_launch * (2 * L + 4 + 8)
+        bytes_per_read = 2 * L + 8 + 8  # seq + qual once, offset + length in (8), start / len / flags out (8): 316 B at L = 150
+        alg_bytes = reads_per_launch * bytes_per_read
         trim_kernel = (kt.trim_kernel or b"").decode() or "trim"
         # the roofline entry describes the DOMINANT kernel of the configuration: adapter_overlap for --config adapter
         # (its algorithmic bytes: the bases once + 6 bytes of result per read), the trim kernel otherwise
         dominant, dom_ms = trim_kernel, kt.trim_ms
-        if a.config == "adapter" and kt.adapter_ms > kt.trim_ms:
+        if config == "adapter" and kt.adapter_ms > kt.trim_ms:
             dominant, dom_ms = "adapter_overlap", kt.adapter_ms
             alg_bytes = reads_per_launch * (L + 4 + 6)
         kmer_k = 31
-        if a.config == "kmer" and (kt.kmer_ms + kt.kmer_insert_ms) > kt.trim_ms:
+        if config == "kmer" and (kt.kmer_ms + kt.kmer_insert_ms) > kt.trim_ms:
             # + (L - k + 1) x 16 bytes per read (8-byte key + 8-byte slot read-modify-write): 3 520 B/read at L = 250, k = 31
-            dominant, dom_ms = ("kmer_count" if kx is None else "kmer_extract + kmer_insert_items"), kt.kmer_ms + kt.kmer_insert_ms
+            dominant = "kmer_group_extract + kmer_group_split + kmer_group_combine" if kx is None else "kmer_extract + kmer_insert_items"
+            if os.environ.get("FAQCS_KMER_DIRECT") == "1" and kx is None:
+                dominant = "kmer_count"
+            dom_ms = kt.kmer_ms + kt.kmer_insert_ms
             alg_bytes = reads_per_launch * (L - kmer_k + 1) * 16
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.config)
+        traffic, traffic_src, traffic_at = None, None, None
+        tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % config)
         if os.path.exists(tf) and L == 150 and dominant != "adapter_overlap":  # (measured on the 2x150 shape only)
             try:
                 # NOT measured in this run: rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE separately, gfx950 correction applied)
-                # of the same kernel, stored per read by profiles/pmc_traffic.py and scaled to this run's launch size
+                # of the same kernel, stored per read by profiles/pmc_traffic2.sh and scaled to this run's launch size
                 tj = json.load(open(tf))
                 if tj.get("kernel", trim_kernel) == trim_kernel:
                     traffic = int(tj["hbm_bytes_per_read"] * reads_per_launch)
-                    traffic_src = "profiles/traffic_%s.json (rocprofv3 --pmc, %s)" % (a.config, tj.get("tag", "stored per read"))
+                    traffic_at = tj.get("reads_per_launch")
+                    traffic_src = "profiles/traffic_%s.json (rocprofv3 --pmc, %s)" % (config, tj.get("tag", "stored per read"))
             except Exception:
                 traffic = None
         out = {
             "metric": "M reads/sec (paired 2x%dbp)" % L, "value": round(value, 3), "unit": "M reads/s", "n_gpus": world if world == 1 else dist.get_world_size(),
             "ranks_seen": ranks_seen,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("synthetic %.0fM-pair 2x%dbp Q33 reads" + ("" if a.at_frac is None else " (A+T = %g of the bases)" % a.at_frac) + " resident in HBM per GPU, BWA_plus -q 5 --min_L 50%s, "
                                     "1 step = 1 pass (%s%s%s + counter all-reduce)")
-                                   % (n_reads / 2e6, L, {"adapter": " --adapter --polyA (5 percent read-through)", "kmer": " --kmer_rarefaction, genome-sampled reads"}.get(a.config, ""),
-                                      {"adapter": "adapter_overlap, then ", "kmer": ""}.get(a.config, ""), trim_kernel, {"kmer": " + kmer_count"}.get(a.config, "")),
-                       "pairs_per_gpu": n_reads // 2, "read_len": L, "launches_per_step": len(batches) * (2 if a.config == "adapter" else 1),
-                       "M_pairs_per_s": round(value / 2, 3)},
+                                   % (n_reads / 2e6, L, {"adapter": " --adapter --polyA (5 percent read-through)", "kmer": " --kmer_rarefaction, genome-sampled reads"}.get(config, ""),
+                                      {"adapter": "adapter_overlap, then ", "kmer": ""}.get(config, ""), trim_kernel, {"kmer": " + the k-mer kernels"}.get(config, "")),
+                       "pairs_per_gpu": n_reads // 2, "read_len": L, "launches_per_step": len(batches) * (2 if config == "adapter" else 1),
+                       "M_pairs_per_s": round(value / 2, 3), "terminal_n_supplied": True},
         }
-        if a.config == "kmer" and kx is not None:
-            out["kmer"] = {"G_inserts_per_s": round(kmer_last.get("total", 0) / (dt / a.steps) / 1e9, 3), "distinct_at_last_point": int(kmer_last.get("distinct", 0)),
+        if noflag_value is not None:
+            out["config"]["value_without_terminal_n_flags"] = noflag_value
+        if config == "kmer" and kx is not None:
+            out["kmer"] = {"G_inserts_per_s": round(kmer_last.get("total", 0) / (dt / steps) / 1e9, 3), "distinct_at_last_point": int(kmer_last.get("distinct", 0)),
                            "occurrences_at_last_point": int(kmer_last.get("total", 0)), "points": int(kmer_last.get("points", 0)),
                            "note": "owner-partitioned tables: (key, epoch) pairs bucketed by owner on the device, all-to-all over the process group, "
                                    "owner-side insert; distinct / total from the all-reduced epoch histograms"}
-        elif a.config == "kmer":
+        elif config == "kmer":
             d_, t_ = eng.kmer_totals()
-            out["kmer"] = {"G_inserts_per_s": round(t_ / (dt / a.steps) / 1e9, 3), "distinct_per_step": int(d_), "occurrences_per_step": int(t_),
-                           "note": "canonical 31-mers of the kept reads into the device hash table (reset every step); bound by the L2 atomic rate"}
+            out["kmer"] = {"G_inserts_per_s": round(t_ / (dt / steps) / 1e9, 3), "distinct_per_step": int(d_), "occurrences_per_step": int(t_),
+                           "points_per_step": len(eng.kmer_points()) // max(1, steps + warmup),
+                           "note": "canonical 31-mers of the kept reads, combined before they reach the table (reset every step): occurrences are bucketed, split "
+                                   "65 536 ways, counted per partition in LDS, then ONE plain table update per distinct key and group (DESIGN.md section 4.4)"}
         out.update({
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "kernel": dominant,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_measured_at_reads_per_launch": traffic_at, "kernel": dominant,
                          "kernel_ms": round(dom_ms, 4), "launches": int(kt.n_launches),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "kernels_ms": {trim_kernel: round(kt.trim_ms, 4), "adapter_overlap": round(kt.adapter_ms, 4),
-                                        "kmer (count, or extract)": round(kt.kmer_ms, 4), "kmer_insert_items": round(kt.kmer_insert_ms, 4)}},
+                                        "kmer kernels (per submission)": round(kt.kmer_ms, 4), "kmer_insert_items": round(kt.kmer_insert_ms, 4)}},
         })
-        if a.config == "kmer" and "kmer" in out and dom_ms > 0:
-            # the k-mer kernels are bound by the rate of device-scope atomics (one per occurrence), not by bytes: measured ceiling
-            # 13.5 G atomics/s (profiles/r2c/pmc_kmer_atomics.txt, TCC_EA0_ATOMIC = 1.00 per insert)
+        if config == "kmer" and "kmer" in out and dom_ms > 0:
             occ = out["kmer"].get("occurrences_per_step", out["kmer"].get("occurrences_at_last_point", 0)) / max(1, len(batches))
             rate = occ / (dom_ms * 1e-3) / 1e9
-            out["roofline"]["atomics"] = {"G_atomics_per_s": round(rate, 3), "measured_peak_G_per_s": 13.5, "frac": round(rate / 13.5, 4),
-                                          "note": "occurrences inserted per launch / the k-mer kernels' time; one memory-side atomic per occurrence"}
+            kc = {"G_occurrences_per_s": round(rate, 3),
+                  "note": "occurrences per submission / the k-mer kernels' time.  Rounds 1-3 paid one memory-side atomic per occurrence (13.5 G/s measured ceiling); "
+                          "the counters of the combine-before-insert kernels are in profiles/r4*/pmc_kmer_group*.txt"}
+            pj = os.path.join(ROOT, "profiles", "kmer_counters.json")
+            if os.path.exists(pj):
+                try:
+                    kc.update(json.load(open(pj)))
+                except Exception:
+                    pass
+            out["roofline"]["kmer_counters"] = kc
         if dominant == "adapter_overlap":
             # adapter_overlap is bound by integer VALU issue, not by HBM: the work is L x sum|adapter| cell updates per
             # read (62 850 for the 9 built-ins + polyA at L = 150); the instruction count per read comes from the PMC profile
@@ -495,29 +600,16 @@ def main():
                                        "G_wave_instr_per_s": round(g_instr, 1), "measured_peak_G_wave_instr_per_s": 575.0, "frac": round(g_instr / 575.0, 4),
                                        "valu_instr_per_read": valu_per_read,
                                        "note": "bound by VALU issue: instruction count per read from profiles/r2c/pmc_adapter.txt, peak from profiles/r3a/valu_lds_peak.txt"}
-        if world == 1 and not a.no_cpu_baseline:
-            ns = min(400000, batches[0][6])
-            hs = batches[0][0][: ns * L].cpu().numpy()
-            hq = batches[0][1][: ns * L].cpu().numpy()
-            pad = np.zeros(64, np.uint8)
-            out["cpu_baseline"] = cpu_baseline(opt_args, np.concatenate([hs, pad]), np.concatenate([hq, pad]), L, ns)
-        if a.e2e_pairs < 0:
-            try:
-                import shutil
-
-                a.e2e_pairs = 16e6 if shutil.disk_usage("/dev/shm").free > 64e9 else 8e6
-            except OSError:
-                a.e2e_pairs = 8e6
-        if world == 1 and a.e2e_pairs > 0 and a.config != "kmer" and os.path.exists(os.path.join(ROOT, "faqcs_amd", "faqcs_mi")):
-            ne = int(min(a.e2e_pairs, batches[0][6] // 2))
-            es = batches[0][0][: 2 * ne * L].cpu().numpy()
-            eq = batches[0][1][: 2 * ne * L].cpu().numpy()
-            out["e2e"] = e2e_run(opt_args, es, eq, L, ne)
-        real_stdout.write(json.dumps(out) + "\n")
-        real_stdout.flush()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        if want_host_sample:
+            ns = int(min(max(400000, 2 * a.e2e_pairs if config != "kmer" else 0), batches[0][6]))
+            keep["hs"] = batches[0][0][: ns * L].cpu().numpy()
+            keep["hq"] = batches[0][1][: ns * L].cpu().numpy()
+            keep["sample_reads"] = ns
+    # release the device memory of this configuration (the next one builds its own data set)
+    eng.close()
+    del batches
+    torch.cuda.empty_cache()
+    return out, keep
 
 
 if __name__ == "__main__":

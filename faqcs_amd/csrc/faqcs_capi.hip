@@ -136,7 +136,8 @@ struct faqcs_ctx {
         uint64_t bound_items = 0;     // upper bound of the items the open group holds
         std::vector<uint32_t> run_epoch, upload[2]; // epochs (relative to epoch_base) of the open group's runs; host copies in flight
         unsigned n_flushes = 0;
-        uint32_t epoch_base = 0, split = 1;
+        uint32_t epoch_base = 0;
+        std::vector<uint64_t> sub_fill; // [256] upper bound of the items in the level-1 sub-regions written by block slot i
         KmerGroupDev dev{};           // (n_runs / epoch_base filled in at flush time)
         uint32_t ep_cap = 0;          // entries of dev.first_hist / dev.tot_by_epoch
         uint32_t ep_used = 0;         // 1 + largest epoch seen
@@ -426,7 +427,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     for (auto &rs : c->rec) { rs.pre.release(); rs.post.release(); if (rs.trimmed) (void)hipEventDestroy(rs.trimmed); if (rs.folded) (void)hipEventDestroy(rs.folded); }
     if (c->aux) (void)hipStreamDestroy(c->aux);
     c->ob_items.release(); c->ob_wave_count.release(); c->ob_wave_offset.release();
-    { void *kg_ptrs[] = {c->kg.dev.l1, c->kg.dev.l2, c->kg.dev.cur1, c->kg.dev.bounds, c->kg.dev.run_epoch, c->kg.dev.first_hist, c->kg.dev.tot_by_epoch};
+    { void *kg_ptrs[] = {c->kg.dev.l1, c->kg.dev.l2, c->kg.dev.cur1, c->kg.dev.cur2, c->kg.dev.run_epoch, c->kg.dev.first_hist, c->kg.dev.tot_by_epoch};
       for (void *q : kg_ptrs) if (q) (void)hipFree(q);
       for (auto &ev : c->kg.flush_ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); } }
     if (c->copied) (void)hipEventDestroy(c->copied);
@@ -455,24 +456,25 @@ static int kg_init(faqcs_ctx *c)
     const uint64_t slots = c->kt.mask + 1;
     uint64_t G = slots / 2;
     if (G < (1ull << 18)) G = 1ull << 18;
-    if (G > (1ull << 29)) G = 1ull << 29;
-    if (const char *e = getenv("FAQCS_KMER_GROUP_ITEMS")) { const uint64_t v = strtoull(e, nullptr, 0); if (v >= (1ull << 12) && v <= (1ull << 31)) G = v; }
+    if (G > (1ull << 30)) G = 1ull << 30;
+    if (const char *e = getenv("FAQCS_KMER_GROUP_ITEMS")) { const uint64_t v = strtoull(e, nullptr, 0); if (v >= (1ull << 14) && v <= (1ull << 31)) G = v; }
     g.cap_items = G;
     KmerGroupDev &d = g.dev;
-    // level-2 scatter: blocks per level-1 bucket.  Every block pads one granule per partition it feeds, so small groups use one
-    g.split = G >= (1ull << 26) ? 8u : 1u;
-    d.cap1 = (uint32_t)(G / KG_FAN + G / (16 * KG_FAN) + 1024);
-    d.cap2 = (uint32_t)(G / (KG_FAN * KG_FAN) + G / (4 * KG_FAN * KG_FAN) + 64);
-    if (d.cap2 < (uint32_t)KG_MIN_CAP2) d.cap2 = KG_MIN_CAP2;
-    d.cap2 += g.split * KG_GRAN;
-    d.stride1 = d.cap1 + KG_GRAN; d.stride2 = d.cap2 + KG_GRAN;
-    HIPCHK(hipMalloc((void **)&d.l1, (size_t)KG_FAN * d.stride1 * 8));
-    HIPCHK(hipMalloc((void **)&d.l2, (size_t)KG_FAN * KG_FAN * d.stride2 * 8));
-    HIPCHK(hipMalloc((void **)&d.cur1, (size_t)(2 * KG_FAN + 2 * KG_FAN * KG_FAN) * 4));
-    d.lim1 = d.cur1 + KG_FAN; d.cur2 = d.lim1 + KG_FAN; d.lim2 = d.cur2 + KG_FAN * KG_FAN;
-    HIPCHK(hipMalloc((void **)&d.bounds, (size_t)KG_MAX_RUNS * KG_FAN * 4));
+    // Either scatter level writes 65 536 sub-regions: (bucket, writing block) at level 1, (partition, writing block) at level 2.
+    // A sub-region of the expected G / 65 536 items gets 1/4 + 8 standard deviations (+ a granule) on top.
+    d.split = G >= (1ull << 26) ? 8u : 1u;
+    const double mean1 = (double)G / (KG_FAN * KG_FAN), mean2 = mean1 / d.split;
+    d.cap1 = (uint32_t)(mean1 * 1.25 + 8.0 * std::sqrt(mean1) + 64.0);
+    d.cap2 = (uint32_t)(mean2 * 1.25 + 8.0 * std::sqrt(mean2) + 64.0);
+    if (d.cap1 < (uint32_t)KG_MIN_CAP) d.cap1 = KG_MIN_CAP;
+    if (d.cap2 < (uint32_t)KG_MIN_CAP) d.cap2 = KG_MIN_CAP;
+    HIPCHK(hipMalloc((void **)&d.l1, (size_t)KG_FAN * KG_FAN * d.cap1 * 8));
+    HIPCHK(hipMalloc((void **)&d.l2, (size_t)KG_FAN * KG_FAN * d.split * d.cap2 * 8));
+    HIPCHK(hipMalloc((void **)&d.cur1, (size_t)KG_FAN * KG_FAN * 4));
+    HIPCHK(hipMalloc((void **)&d.cur2, (size_t)KG_FAN * KG_FAN * d.split * 4));
     HIPCHK(hipMalloc((void **)&d.run_epoch, (size_t)KG_MAX_RUNS * 4));
     HIPCHK(faqcs_launch_kmer_group_reset(d, c->compute));
+    g.sub_fill.assign(KG_FAN, 0);
     g.ready = true;
     return 0;
 }
@@ -516,9 +518,10 @@ static int kg_flush(faqcs_ctx *c, bool timed = false)
     }
     HIPCHK(hipMemcpyAsync(g.dev.run_epoch, up.data(), up.size() * 4, hipMemcpyHostToDevice, c->compute));
     g.dev.n_runs = (uint32_t)up.size(); g.dev.epoch_base = g.epoch_base;
-    HIPCHK(faqcs_launch_kmer_group_flush(g.dev, c->kt, g.split, c->compute));
+    HIPCHK(faqcs_launch_kmer_group_flush(g.dev, c->kt, c->compute));
     if (timed) HIPCHK(hipEventRecord(ev.second, c->compute));
     g.run_epoch.clear(); g.bound_items = 0;
+    std::fill(g.sub_fill.begin(), g.sub_fill.end(), 0);
     return 0;
 }
 
@@ -535,27 +538,36 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
         if (g.run_epoch.size() == (size_t)KG_MAX_RUNS || (!g.run_epoch.empty() && epoch - g.epoch_base >= (uint32_t)KG_EPOCH_SPAN)) {
             if (int rc = kg_flush(c)) return rc;
         }
-        // every block of a launch pads one granule per bucket (<= KG_FAN * KG_GRAN items): part of the bound
-        const uint64_t pad = (uint64_t)faqcs_kmer_group_grid(r1 - r0, c->n_cu) * KG_FAN * KG_GRAN;
-        const uint64_t room = g.cap_items > g.bound_items + pad ? g.cap_items - g.bound_items - pad : 0;
-        uint32_t take; uint64_t bound;
-        if (host_off) { // largest take with off[r0 + take] - off[r0] <= room (offsets do not decrease)
-            uint32_t lo = 0, hi = r1 - r0;
-            while (lo < hi) { const uint32_t mid = lo + (hi - lo + 1) / 2; if ((uint64_t)(host_off[r0 + mid] - host_off[r0]) <= room) lo = mid; else hi = mid - 1; }
-            take = lo; bound = (uint64_t)(host_off[r0 + take] - host_off[r0]);
-        } else {
-            const uint64_t fit = room / per_read;
-            take = fit < (uint64_t)(r1 - r0) ? (uint32_t)fit : r1 - r0; bound = (uint64_t)take * per_read;
+        // A launch of `take` reads runs on grid blocks; block i appends to sub-region (i + rot) % 256 of every bucket: a share
+        // 1 / (256 grid) of the launch's items each (hashing spreads a block's items over the buckets; the blocks take equal
+        // numbers of reads).  sub_fill bounds every sub-region from above, 1/8 + 64 items of variance included; the group is
+        // flushed before a sub-region could overflow (an overflow would be exact too, but slow: kmer_insert_atomic).
+        const uint32_t run = (uint32_t)g.run_epoch.size(), rot = (run * 37u) % KG_FAN;
+        auto fits = [&](uint32_t take, uint64_t bound) {
+            const uint32_t grid = faqcs_kmer_group_grid(take, c->n_cu);
+            const uint64_t share = bound / ((uint64_t)grid * KG_FAN) + bound / ((uint64_t)grid * KG_FAN * 8) + 64;
+            for (uint32_t i = 0; i < grid; ++i) if (g.sub_fill[(i + rot) % KG_FAN] + share > g.dev.cap1) return false;
+            return g.bound_items + bound <= g.cap_items;
+        };
+        auto bound_of = [&](uint32_t take) { return host_off ? (uint64_t)(host_off[r0 + take] - host_off[r0]) : (uint64_t)take * per_read; };
+        uint32_t take = r1 - r0;
+        if (!fits(take, bound_of(take))) { // the largest prefix that fits (the bound grows with take; the per-block share may not)
+            uint32_t lo = 0, hi = take;
+            while (lo < hi) { const uint32_t mid = lo + (hi - lo + 1) / 2; if (fits(mid, bound_of(mid))) lo = mid; else hi = mid - 1; }
+            take = lo;
         }
-        if (take == 0) { // (an empty group always has room for a read: a read gives < 2^15 items, a group takes >= 2^12 ... 2^18)
-            if (g.run_epoch.empty()) { take = 1; bound = g.cap_items; }
-            else { if (int rc = kg_flush(c)) return rc; continue; }
+        if (take == 0) {
+            if (!g.run_epoch.empty()) { if (int rc = kg_flush(c)) return rc; continue; }
+            take = 1; // (a read that no empty group has room for: whatever overflows is counted by the per-occurrence path)
         }
+        const uint64_t bound = bound_of(take);
+        const uint32_t grid = faqcs_kmer_group_grid(take, c->n_cu);
         if (g.run_epoch.empty()) g.epoch_base = epoch;
-        HIPCHK(faqcs_launch_kmer_group_extract(c->dp, c->prm.kmer, g.dev, c->kt, (uint32_t)g.run_epoch.size(), epoch, d_seq, d_qual, d_off,
+        HIPCHK(faqcs_launch_kmer_group_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
                                                r0, r0 + take, d_res, c->n_cu, c->compute));
         g.run_epoch.push_back(epoch - g.epoch_base);
-        g.bound_items += bound + (uint64_t)faqcs_kmer_group_grid(take, c->n_cu) * KG_FAN * KG_GRAN;
+        g.bound_items += bound;
+        for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += bound / ((uint64_t)grid * KG_FAN) + bound / ((uint64_t)grid * KG_FAN * 8) + 64;
         r0 += take;
     }
     return 0;

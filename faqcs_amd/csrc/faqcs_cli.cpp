@@ -343,8 +343,9 @@ struct BgzfReader {
     uint64_t issued = 0, taken = 0; // task numbers handed to the workers / consumed by next()
     uint64_t claimed = 0;
     bool closing = false, failed = false;
-    // what follows the last whole BGZF member (ordinary gzip members appended to a bgzip file, or garbage): inflated by the
-    // consumer itself through zlib's gzip decoder, as gzread would go on reading; a failure there fails the input
+    // what follows the last whole BGZF member (ordinary gzip members appended to a bgzip file): inflated by the consumer itself
+    // through zlib's gzip decoder, as gzread would go on reading; a failure there fails the input; bytes that do not start
+    // with the gzip magic are trailing garbage and end the data, as in zlib
     bool tail = false, tail_init = false, tail_done = false, tail_mid = false;
     z_stream tz;
     std::vector<char> tail_out;
@@ -479,6 +480,13 @@ struct BgzfReader {
             tail_init = true;
         }
         for (;;) {
+            if (!tail_mid) { // at the start of a member: zlib's gz_look() takes anything that does not begin with the gzip magic,
+                             // behind at least one decoded member, for trailing garbage and ends the data there WITHOUT an error
+                             // (gzread.c: "if we were decoding gzip before, then this is trailing garbage") -- so does the reference
+                const uint8_t *q = tz.avail_in ? (const uint8_t *)tz.next_in : base + scan;
+                const size_t avail = (size_t)tz.avail_in + (size - scan);
+                if (avail > 0 && (avail < 2 || q[0] != 31 || q[1] != 139)) { tail_done = true; inflateEnd(&tz); return 0; }
+            }
             if (tz.avail_in == 0) {
                 const size_t left = size - scan;
                 if (left == 0) { tail_done = true; inflateEnd(&tz); if (tail_mid) failed = true; return 0; } // (the file ends inside a member)
@@ -1965,6 +1973,10 @@ static void report_done(int status)
     if (g_done_fd < 0) return;
     fflush(nullptr);
     prctl(PR_SET_PDEATHSIG, 0); // (the parent exits on the byte below, as planned: the teardown is not to be cut short by its death signal)
+    // From here on nobody watches this process: the release of the GPU context, the pinned buffers and the mappings gets a bounded
+    // time.  A teardown that hangs ends with SIGALRM's default action instead of holding the GPU for ever (every output is complete).
+    signal(SIGALRM, SIG_DFL);
+    alarm(120);
     const unsigned char b = (unsigned char)status;
     if (write(g_done_fd, &b, 1) != 1) {}
     ::close(g_done_fd);
@@ -1980,9 +1992,17 @@ int main(int argc, char **argv)
 {
     { const int rc = host_self_check(argc, argv); if (rc >= 0) return rc; }
     const char *nf = getenv("FAQCS_MI_NO_FORK");
-    if (!(nf && atoi(nf) != 0)) {
+    // One process when asked for, and ALWAYS under a profiler or any other preloaded tool: rocprofv3 --pmc (and anything that
+    // comes in through LD_PRELOAD) has initialised the GPU before main() runs, a child forked from such a process must not touch
+    // it, and the tool would follow the wrong process anyway.
+    static const char *const tool_env[] = {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH",
+                                           "ROCPROFILER_LIBRARY_CTOR", "HSA_TOOLS_LIB", "ROCP_METRICS"};
+    bool tool = false;
+    for (const char *name : tool_env) { const char *v = getenv(name); if (v && *v) tool = true; }
+    if (!(nf && atoi(nf) != 0) && !tool) {
         int pfd[2];
         if (pipe(pfd) == 0) {
+            const pid_t parent = getpid();
             const pid_t pid = fork(); // (nothing has touched the GPU, no thread is running)
             if (pid > 0) {
                 ::close(pfd[1]);
@@ -1999,6 +2019,7 @@ int main(int argc, char **argv)
             if (pid == 0) {
                 ::close(pfd[0]); g_done_fd = pfd[1];
                 prctl(PR_SET_PDEATHSIG, SIGTERM); // a caller that kills the command it started (its pid is the parent's) ends the worker too
+                if (getppid() != parent) _exit(EXIT_FAILURE); // (the parent died between fork() and prctl(): nobody is left to signal us)
             }
             else { ::close(pfd[0]); ::close(pfd[1]); } // (fork failed: run here)
         }

@@ -37,7 +37,8 @@ struct DevParams {
     const float    *comp_norm;    // float(10000)/len                                             (trim.cpp:860)
     const uint32_t *base_tab;     // [256] per input byte: 6-bit count fields A,T,C,G,N | isG<<30 | isN<<31
     uint32_t *partials;           // [n_cu][FAQCS_PARTIAL_FLUSHES][FAQCS_PARTIAL_ROW] + [n_cu] rows used: a row per block and flush (trim_lds: flush without
-                                  // global atomics; a fold kernel behind the trim kernel adds them to the counter block and zeroes them)
+                                  // global atomics; a fold kernel behind the trim kernel adds the rows a block USED in this launch to the counter
+                                  // block -- stale rows are never read, so nothing is zeroed)
     uint32_t *partial_rows;       // [n_cu] rows of `partials` each block of the last trim_lds launch wrote
     faqcs_layout lay;
 };

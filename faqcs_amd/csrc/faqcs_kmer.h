@@ -47,25 +47,25 @@ enum {
     KG_FAN = 256,          // fan-out of either scatter level
     KG_GRAN = 32,          // items per global write of a bucket (256 bytes)
     KG_STAGE = 64,         // LDS staging slots per bucket (2 granules)
-    KG_MAX_RUNS = 1000,    // extraction launches (runs of segments with one epoch) per group
+    KG_MAX_RUNS = 1000,    // extraction launches (runs of segments with one epoch) per group (a level-1 item has 10 bits for the run)
     KG_EPOCH_SPAN = 1000,  // epochs a group may span (the combine kernel's LDS histogram)
     KG_LDS_SLOTS = 4096,   // LDS hash table of the combine kernel
-    KG_MIN_CAP2 = 256,     // smallest partition region
+    KG_MIN_CAP = 128,      // smallest sub-region
     KG_SLICE_MAX = 65536,  // largest table slice of a partition (table <= 2^32 slots): the combine kernel's claim bitmap is 8 KB of LDS
     KG_SLICE_MIN = 64      // smallest (table >= 2^22 slots)
 };
 #define KG_M62 ((1ull << 62) - 1ull)
 #define KG_M46 ((1ull << 46) - 1ull)
+#define KG_M54 ((1ull << 54) - 1ull)
 
 struct KmerGroupDev {
-    unsigned long long *l1;   // [256][stride1]    h
-    unsigned long long *l2;   // [65536][stride2]  epoch_rel << 46 | (h & KG_M46)
-    uint32_t *cur1, *lim1;    // [256]   append cursor / start of the first allocation that did not fit (~0: none)
-    uint32_t *cur2, *lim2;    // [65536]
-    uint32_t *bounds;         // [KG_MAX_RUNS][256]  cur1 after each extraction launch of the group
-    uint32_t *run_epoch;      // [KG_MAX_RUNS]       epoch of run j minus epoch_base
-    uint32_t cap1, cap2;      // items a region takes before allocations are refused (physical size: + KG_GRAN)
-    uint32_t stride1, stride2;
+    unsigned long long *l1;   // [256 buckets][256 sub-regions][cap1]  run << 54 | (h & KG_M54); sub-region = the block that wrote it
+    unsigned long long *l2;   // [65536 partitions][split sub-regions][cap2]  epoch_rel << 46 | (h & KG_M46)
+    uint32_t *cur1;           // [256 sub-regions][256 buckets]  items a level-1 sub-region holds
+    uint32_t *cur2;           // [65536][split]
+    uint32_t *run_epoch;      // [KG_MAX_RUNS]  epoch of run j minus epoch_base
+    uint32_t cap1, cap2;      // items per sub-region
+    uint32_t split;           // blocks per bucket of the level-2 scatter = sub-regions per partition (1, 2, 4 or 8)
     uint32_t n_runs, epoch_base;
     unsigned long long *first_hist;   // [n_epochs] keys by first epoch
     unsigned long long *tot_by_epoch; // [n_epochs] occurrences by epoch
@@ -91,10 +91,10 @@ hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *d
                                        hipStream_t st);
 // combine-before-insert: one extraction launch per run (appends to the level-1 buckets, snapshots the cursors into
 // bounds[run]), then per group: level-2 scatter, combine + insert, cursor reset
-hipError_t faqcs_launch_kmer_group_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run,
+hipError_t faqcs_launch_kmer_group_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
                                            uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                            uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st);
-hipError_t faqcs_launch_kmer_group_flush(const KmerGroupDev &G, const KmerTable &T, uint32_t split, hipStream_t st);
+hipError_t faqcs_launch_kmer_group_flush(const KmerGroupDev &G, const KmerTable &T, hipStream_t st);
 uint32_t faqcs_kmer_group_grid(uint32_t n_reads, int n_cu);
 hipError_t faqcs_launch_kmer_group_reset(const KmerGroupDev &G, hipStream_t st);
 

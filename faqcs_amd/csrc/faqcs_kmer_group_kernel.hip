@@ -25,6 +25,7 @@
 namespace {
 
 typedef unsigned long long u64;
+#define KG_PAD (~0ull) /* "no item" in the prefetch registers of the scatter / combine loops */
 
 __device__ __forceinline__ void hist_add(u64 *h, uint32_t e, uint32_t n_epochs, long long v)
 {
@@ -77,33 +78,31 @@ __device__ void kmer_insert_atomic(const KmerTable &T, const u64 h, const uint32
 
 // ---- LDS staging shared by the two scatter kernels ----------------------------------------------------------------------
 // 256 buckets x 64 slots.  put(): a ticket from the bucket's LDS counter; a lane whose ticket is past the last slot keeps
-// its item for the next round.  drain(): wave w owns buckets [16 w, 16 w + 16) -- lane l < 16 of the wave is the OWNER of bucket
-// 16 w + l and holds, in `res`, the position of a granule (32 items, 256 bytes) it has reserved in the bucket's region ahead
-// of time.  A bucket with >= 32 staged items is written to its reserved granule by the whole wave; the owners of the buckets
-// that were written then reserve their next granule with ONE atomic instruction whose result is not needed before the
-// bucket fills again, rounds later -- the latency of a returning device-scope atomic (microseconds under load) stays off
-// the critical path (the first version took a granule's position when it needed it: one round trip per flush, serialised
-// per wave, and 27 us per round of 2 800 items).  The final drain pads each bucket's last granule with KG_PAD items, so every
-// reserved granule is written.
-#define KG_PAD (~0ull)
+// its item for the next round.  drain(): wave w owns buckets [16 w, 16 w + 16) and writes every full granule (32 items, 256
+// bytes) of them -- the whole wave takes part, lane i < take holds item i -- then moves what is left to the front.
+// WHERE a granule goes needs no atomic: a block appends to sub-regions that are its own (one per bucket), so the cursors
+// live in its LDS.  (The first versions appended to shared regions behind a returning device-scope atomic per granule: a
+// round trip of microseconds per flush, 27 us per round of 2 800 items when taken on the spot, and still a wait per round
+// when reserved a round ahead -- every s_waitcnt vmcnt counts loads, stores and atomics together, in issue order.)
 template <int NW> struct Staging {
     static constexpr int BPW = KG_FAN / NW;
     u64 *items;     // [KG_FAN][KG_STAGE]
     uint32_t *cnt;  // [KG_FAN]
+    uint32_t *cur;  // [KG_FAN] items this block's sub-region of every bucket holds
+    uint32_t *flag; // [3] block_or
     __device__ __forceinline__ bool put(const uint32_t b, const u64 item) const
     {
         const uint32_t pos = atomicAdd(&cnt[b], 1u);
         if (pos < (uint32_t)KG_STAGE) { items[b * KG_STAGE + pos] = item; return true; }
         return false;
     }
-    // write(b, pos, item): the wave stores a granule (lane i < 32 holds item i) at position pos of bucket b's region, or takes
-    // the slow path when the reservation was refused; alloc(b): reserves a granule, returns its position
-    template <class Write, class Alloc>
-    __device__ __forceinline__ void drain(const int wave, const int lane, const bool final, uint32_t &res, Write &&write, Alloc &&alloc) const
+    // write(b, pos, item, take): lanes < take store their item at position pos + lane of the block's sub-region of bucket b;
+    // returns false (wave-uniform) when the sub-region is full -- the items then take the slow path
+    template <class Write, class Slow>
+    __device__ __forceinline__ void drain(const int wave, const int lane, const bool final, const uint32_t cap, Write &&write, Slow &&slow) const
     {
         const uint32_t n_l = lane < BPW ? cnt[wave * BPW + lane] : 0u;
-        const uint64_t todo = __ballot(lane < BPW && (final || n_l >= (uint32_t)KG_GRAN));
-        uint64_t m = todo;
+        uint64_t m = __ballot(final ? n_l > 0u : n_l >= (uint32_t)KG_GRAN);
 #pragma unroll 1
         while (m) {
             const int i = uni(__ffsll((long long)m) - 1);
@@ -111,68 +110,74 @@ template <int NW> struct Staging {
             const int b = wave * BPW + i;
             uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_l, i);
             n = n < (uint32_t)KG_STAGE ? n : (uint32_t)KG_STAGE;
-            uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)res, i);
+            uint32_t pos = uniu(cur[b]);
             uint32_t done = 0;
 #pragma unroll 1
-            for (;;) {
+            while (n - done >= (uint32_t)KG_GRAN || (final && n > done)) {
                 const uint32_t take = n - done < (uint32_t)KG_GRAN ? n - done : (uint32_t)KG_GRAN;
-                const u64 it = (uint32_t)lane < take ? items[b * KG_STAGE + done + lane] : KG_PAD;
-                write((uint32_t)b, pos, it);
+                const u64 it = (uint32_t)lane < take ? items[b * KG_STAGE + done + lane] : 0ull;
+                if (pos + take <= cap) { write((uint32_t)b, pos, it, take); pos += take; }
+                else if ((uint32_t)lane < take) slow((uint32_t)b, it);
                 done += take;
-                if (!(n - done >= (uint32_t)KG_GRAN || (final && n > done))) break;
-                uint32_t p2 = 0; // a second granule of the same bucket in one drain (64 staged items): allocated on the spot
-                if (lane == 0) p2 = alloc((uint32_t)b);
-                pos = uniu(p2);
             }
             const uint32_t left = n - done;
             if (left) { // (one wave: the reads of an instruction complete before the writes of the next)
                 const u64 it = (uint32_t)lane < left ? items[b * KG_STAGE + done + lane] : 0ull;
                 if ((uint32_t)lane < left) items[b * KG_STAGE + lane] = it;
             }
-            if (lane == 0) cnt[b] = left;
+            if (lane == 0) { cnt[b] = left; cur[b] = pos; }
         }
-        if (!final && lane < BPW && ((todo >> lane) & 1ull)) res = alloc((uint32_t)(wave * BPW + lane));
+    }
+    // OR of `bits` over the block; one barrier.  (s_barrier behind a wait for the wave's LDS operations only: outstanding
+    // global loads and stores stay in flight across it.)  Three flag words in rotation: call k writes word k % 3, reads it
+    // behind the barrier, and clears the word of call k - 1, which every wave has read before it arrived here.
+    __device__ __forceinline__ uint32_t block_or(const uint32_t bits, uint32_t &phase, const int tid) const
+    {
+        const uint32_t wb = (__ballot(bits & 1u) ? 1u : 0u) | (__ballot(bits & 2u) ? 2u : 0u);
+        if ((tid & 63) == 0 && wb) atomicOr(&flag[phase], wb);
+        __syncthreads();
+        const uint32_t v = flag[phase];
+        const uint32_t prev = phase == 0 ? 2u : phase - 1u;
+        if (tid == 0) flag[prev] = 0u;
+        phase = phase == 2 ? 0u : phase + 1u;
+        return v;
     }
 };
+constexpr size_t KG_STAGE_BYTES = (size_t)KG_FAN * KG_STAGE * 8 + (size_t)KG_FAN * 8 + 16;
 
-// the granule in lanes 0..31 to position pos of a bucket region; a refused reservation (pos >= cap) is remembered in lim[b] and its
-// items take the slow path
-template <class Slow>
-__device__ __forceinline__ void granule_out(u64 *region, uint32_t *lim, const uint32_t cap, const uint32_t pos, const u64 it,
-                                            const int lane, Slow &&slow)
-{
-    if (pos < cap) {
-        if (lane < KG_GRAN) region[pos + lane] = it; // (the region is KG_GRAN items longer than cap)
-    } else {
-        if (lane == 0) atomicMin(lim, pos);
-        if (lane < KG_GRAN && it != KG_PAD) slow(it);
-    }
-}
+// keeps the registers of a prefetch "used" here: the compiler's wait for those loads lands at this point and not at their
+// first arithmetic use
+__device__ __forceinline__ void touch4(const uint32_t (&v)[4]) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); }
+__device__ __forceinline__ void touch4(const u64 (&v)[4]) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); }
 
 // ---- level 1: reads -> 256 buckets -------------------------------------------------------------------------------------
 // Block-synchronous rounds: every wave brings the k-mers of up to four 64-base chunks of ITS read (one 250-base read = one
-// round), the block stages them, the bucket owners write full granules.  The bytes of a wave's next piece and the header
-// (offset, kept window) of its next read are fetched a round ahead.
+// round), the block stages them, the bucket owners write full granules.  An item is run << 54 | low 54 bits of h (the bucket is
+// h's top 8 bits).  The bytes of a wave's next piece are fetched a round ahead and waited for between the two barriers of
+// the round, when everything older is long done.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void kmer_group_extract(
-    const DevParams P, const uint32_t k, const KmerGroupDev G, const KmerTable T, const uint32_t epoch,
+    const DevParams P, const uint32_t k, const KmerGroupDev G, const KmerTable T, const uint32_t run, const uint32_t rot, const uint32_t epoch,
     const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off, const uint32_t r_begin,
     const uint32_t r_end, const uint2 *__restrict__ results)
 {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const Staging<NW> S{lds, reinterpret_cast<uint32_t *>(lds + KG_FAN * KG_STAGE)};
-    uint32_t *s_total = S.cnt + KG_FAN; // occurrences of this block
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(lds + KG_FAN * KG_STAGE);
+    const Staging<NW> S{lds, w32, w32 + KG_FAN, w32 + 2 * KG_FAN};
+    uint32_t *s_total = w32 + 2 * KG_FAN + 3; // occurrences of this block
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-    for (int i = tid; i < KG_FAN + 2; i += NW * 64) S.cnt[i] = 0u;
+    const uint32_t sub = (blockIdx.x + rot) % KG_FAN; // this block's sub-region of every bucket
+    for (int i = tid; i < KG_FAN; i += NW * 64) { S.cnt[i] = 0u; S.cur[i] = G.cur1[sub * KG_FAN + i]; }
+    if (tid < 4) S.flag[tid] = 0u; // (flags and s_total)
     const uint32_t n_waves = gridDim.x * NW;
     const bool g2n = !P.qc_only && P.replace_q > 0;
-    auto alloc = [&](const uint32_t b) { return atomicAdd(&G.cur1[b], (uint32_t)KG_GRAN); };
-    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it) {
-        granule_out(G.l1 + (size_t)b * G.stride1, &G.lim1[b], G.cap1, pos, it, lane,
-                    [&](const u64 h) { kmer_insert_atomic(T, h, epoch, 1u, G.first_hist, G.n_epochs); });
+    const u64 tag = (u64)run << 54;
+    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it, const uint32_t take) {
+        if ((uint32_t)lane < take) G.l1[((size_t)b * KG_FAN + sub) * G.cap1 + pos + lane] = it;
     };
-    uint32_t res = 0;
-    if (lane < S.BPW) res = alloc((uint32_t)(wave * S.BPW + lane));
+    auto slow = [&](const uint32_t b, const u64 it) {
+        kmer_insert_atomic(T, ((u64)b << 54) | (it & KG_M54), epoch, 1u, G.first_hist, G.n_epochs);
+    };
     __syncthreads();
 
     struct Hdr { uint32_t o; int a, n; }; // kept window [a, a + n) of the read at byte o; n == 0: nothing to count
@@ -194,41 +199,43 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_extract(
     uint32_t r_cur = r_begin + blockIdx.x * NW + wave, r_nxt = r_cur + n_waves;
     Hdr hc = load_hdr(r_cur), hn = load_hdr(r_nxt);
     int c = hc.a >> 6, c_end = hc.n ? (hc.a + hc.n + 63) >> 6 : c;
-    bool first = true;
-    uint32_t nb[4], nq[4]; // the next piece's bytes (and qualities, --replace_to_N_q)
+    uint32_t nb[4], nq[4] = {0u, 0u, 0u, 0u}; // the next piece's bytes (and qualities, --replace_to_N_q)
     auto load_piece = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = (c + j) * 64 + lane;
             const bool in = c + j < c_end && p >= hc.a && p < hc.a + hc.n;
             nb[j] = in ? seq[(size_t)hc.o + p] : 0u;
-            nq[j] = g2n && in ? qual[(size_t)hc.o + p] : 0u;
+            if (g2n) nq[j] = in ? qual[(size_t)hc.o + p] : 0u;
         }
     };
     load_piece();
+    uint32_t bb[4], bq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bb[j] = nb[j]; bq[j] = nq[j]; }
+    int pn = c_end - c < 4 ? c_end - c : 4; // chunks of the piece in bb
+    bool first = true;                      // ... which is the first piece of its read
     KmerPlanes pl{0, 0, 0};
-    uint32_t my_total = 0;
+    uint32_t my_total = 0, phase = 0;
 #pragma unroll 1
     for (;;) {
-        // the piece whose bytes arrived: chunks [pc, pc + pn) of the current read
-        uint32_t bb[4], bq[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { bb[j] = nb[j]; bq[j] = nq[j]; }
-        const int pn = c_end - c < 4 ? c_end - c : 4;
-        if (first) pl = KmerPlanes{0, 0, 0};
-        // advance the cursor and fetch ahead
+        // advance the cursor past the piece in bb and fetch the piece after it
+        const int pn_now = pn;
+        const bool first_now = first;
         c += 4; first = false;
         if (c >= c_end && r_cur < r_end) {
             hc = hn; r_cur = r_nxt; r_nxt += n_waves;
             hn = load_hdr(r_nxt);
             c = hc.a >> 6; c_end = hc.n ? (hc.a + hc.n + 63) >> 6 : c; first = true;
         }
+        pn = c_end - c < 4 ? c_end - c : 4;
         load_piece();
+        if (first_now) pl = KmerPlanes{0, 0, 0};
         u64 h[4];
         uint32_t pend = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (j < pn) { // (wave-uniform)
+            if (j < pn_now) { // (wave-uniform)
                 uint32_t b = bb[j];
                 if (g2n && b == 'G') { // G -> N precedes k-mer counting (trim.cpp:390-403)
                     int qv = (int)(int8_t)bq[j] - P.in_off;
@@ -241,19 +248,31 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_extract(
         }
         my_total += (uint32_t)__popc(pend);
         // block-wide rounds: tickets, then the owners of the buckets write the full granules
+        bool more;
 #pragma unroll 1
-        for (;;) {
+        for (bool fetched = false;;) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if ((pend >> j) & 1u)
-                    if (S.put((uint32_t)(h[j] >> 54), h[j])) pend &= ~(1u << j);
+                    if (S.put((uint32_t)(h[j] >> 54), tag | (h[j] & KG_M54))) pend &= ~(1u << j);
             __syncthreads();
-            S.drain(wave, lane, false, res, write, alloc);
-            if (!__syncthreads_or((int)pend)) break;
+            if (!fetched) { // the prefetched piece: its loads are a round's arithmetic old, the stores of the last drain older
+                touch4(nb);
+                if (g2n) touch4(nq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bb[j] = nb[j]; bq[j] = nq[j]; }
+                fetched = true;
+            }
+            S.drain(wave, lane, false, G.cap1, write, slow);
+            const uint32_t f = S.block_or((pend ? 1u : 0u) | (r_cur < r_end ? 2u : 0u), phase, tid);
+            more = (f & 2u) != 0u;
+            if (!(f & 1u)) break;
         }
-        if (!__syncthreads_or(r_cur < r_end)) break;
+        if (!more) break;
     }
-    S.drain(wave, lane, true, res, write, alloc);
+    S.drain(wave, lane, true, G.cap1, write, slow);
+    __syncthreads();
+    for (int i = tid; i < KG_FAN; i += NW * 64) G.cur1[sub * KG_FAN + i] = S.cur[i];
     // occurrences of this launch's epoch (total_kmer of the sampling points, trim.cpp:170-176)
     const uint32_t wt = (uint32_t)wave_sum_i32((int)my_total); // (a wave sees < 2^31 occurrences per launch)
     if (lane == 0 && wt) atomicAdd(s_total, wt);                // (a block sees < 2^32)
@@ -264,81 +283,79 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_extract(
     }
 }
 
-// bounds[run][b] = cur1[b] after the run's launch
-__global__ void kmer_group_bounds(const KmerGroupDev G, const uint32_t run)
-{
-    const uint32_t b = threadIdx.x;
-    if (b < (uint32_t)KG_FAN) G.bounds[run * KG_FAN + b] = G.cur1[b];
-}
-
-// ---- level 2: every bucket 256 ways; the epoch moves from the position into the item ---------------------------------------
+// ---- level 2: every bucket 256 ways; the run number becomes the epoch -------------------------------------------------------
+// Block (b1, part) reads the sub-regions [part * 256 / split, (part + 1) * 256 / split) of bucket b1 and appends to sub-region
+// `part` of the partitions b1 * 256 + (next 8 bits of h): again a block writes only where no other block does.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void kmer_group_split(const KmerGroupDev G, const KmerTable T, const uint32_t split)
+__global__ __launch_bounds__(NW * 64) void kmer_group_split(const KmerGroupDev G, const KmerTable T)
 {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const Staging<NW> S{lds, reinterpret_cast<uint32_t *>(lds + KG_FAN * KG_STAGE)};
-    uint32_t *s_eb = S.cnt + KG_FAN;          // [KG_MAX_RUNS] end of run j inside this bucket
-    uint32_t *s_er = s_eb + KG_MAX_RUNS;      // [KG_MAX_RUNS] its epoch, relative
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(lds + KG_FAN * KG_STAGE);
+    const Staging<NW> S{lds, w32, w32 + KG_FAN, w32 + 2 * KG_FAN};
+    uint32_t *s_er = w32 + 2 * KG_FAN + 4;     // [KG_MAX_RUNS] epoch of run j, relative
+    uint32_t *s_n = s_er + KG_MAX_RUNS;        // [256] items of the bucket's sub-regions
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-    const uint32_t b1 = blockIdx.x / split, part = blockIdx.x % split;
-    uint32_t n_b = G.cur1[b1];
-    { const uint32_t l = G.lim1[b1]; n_b = n_b < l ? n_b : l; }
-    for (int i = tid; i < KG_FAN; i += NW * 64) S.cnt[i] = 0u;
-    for (uint32_t j = tid; j < G.n_runs; j += NW * 64) {
-        const uint32_t e = G.bounds[j * KG_FAN + b1];
-        s_eb[j] = e < n_b ? e : n_b;
-        s_er[j] = G.run_epoch[j];
-    }
-    constexpr uint32_t TILE = NW * 64 * 4;
-    const uint32_t per = ((n_b + split - 1) / split + TILE - 1) / TILE * TILE;
-    const uint32_t lo = part * per < n_b ? part * per : n_b, hi = lo + per < n_b ? lo + per : n_b;
-    if (lo >= hi) return; // (block-uniform: nothing reserved, nothing to pad)
-    const u64 *src = G.l1 + (size_t)b1 * G.stride1;
-    auto alloc = [&](const uint32_t b) { return atomicAdd(&G.cur2[b1 * KG_FAN + b], (uint32_t)KG_GRAN); };
-    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it) {
-        const uint32_t p = b1 * KG_FAN + b;
-        granule_out(G.l2 + (size_t)p * G.stride2, &G.lim2[p], G.cap2, pos, it, lane, [&](const u64 item) {
-            kmer_insert_atomic(T, ((u64)p << 46) | (item & KG_M46), G.epoch_base + (uint32_t)(item >> 46), 1u, G.first_hist, G.n_epochs);
-        });
-    };
-    uint32_t res = 0;
-    if (lane < S.BPW) res = alloc((uint32_t)(wave * S.BPW + lane));
+    const uint32_t b1 = blockIdx.x / G.split, part = blockIdx.x % G.split;
+    for (int i = tid; i < KG_FAN; i += NW * 64) { S.cnt[i] = 0u; S.cur[i] = 0u; s_n[i] = G.cur1[i * KG_FAN + b1]; }
+    if (tid < 3) S.flag[tid] = 0u;
+    for (uint32_t j = tid; j < G.n_runs; j += NW * 64) s_er[j] = G.run_epoch[j];
     __syncthreads();
-    uint32_t jt = 0; // first run that ends behind the tile's start (block-uniform)
-    u64 nx[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint32_t i = lo + j * NW * 64 + tid; nx[j] = i < hi ? src[i] : KG_PAD; }
+    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it, const uint32_t take) {
+        if ((uint32_t)lane < take) G.l2[(((size_t)b1 * KG_FAN + b) * G.split + part) * G.cap2 + pos + lane] = it;
+    };
+    auto slow = [&](const uint32_t b, const u64 item) {
+        kmer_insert_atomic(T, (((u64)b1 * KG_FAN + b) << 46) | (item & KG_M46), G.epoch_base + (uint32_t)(item >> 46), 1u, G.first_hist, G.n_epochs);
+    };
+    constexpr uint32_t TILE = NW * 64 * 4;
+    const uint32_t per = KG_FAN / G.split;
+    uint32_t phase = 0;
 #pragma unroll 1
-    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
-        u64 cur[4];
-        uint32_t pend = 0, sub = 0; // pending flags / sub-buckets of this thread's four items
-        while (jt + 1 < G.n_runs && s_eb[jt] <= t0) ++jt;
+    for (uint32_t sr = part * per; sr < (part + 1) * per; ++sr) {
+        const uint32_t n_s = s_n[sr];
+        if (n_s == 0) continue; // (block-uniform)
+        const u64 *src = G.l1 + ((size_t)b1 * KG_FAN + sr) * G.cap1;
+        u64 nx[4], cx[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t i = t0 + j * NW * 64 + tid;
-            if (nx[j] != KG_PAD) { // (padding of a bucket's last granules)
-                uint32_t jr = jt;
-                while (jr + 1 < G.n_runs && s_eb[jr] <= i) ++jr;
-                cur[j] = ((u64)s_er[jr] << 46) | (nx[j] & KG_M46);
-                sub |= (uint32_t)((nx[j] >> 46) & 255u) << (8 * j);
-                pend |= 1u << j;
+        for (int j = 0; j < 4; ++j) { const uint32_t i = j * NW * 64 + tid; nx[j] = i < n_s ? src[i] : KG_PAD; }
+        touch4(nx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cx[j] = nx[j];
+#pragma unroll 1
+        for (uint32_t t0 = 0; t0 < n_s; t0 += TILE) {
+            u64 cur[4];
+            uint32_t pend = 0, sb = 0; // pending flags / sub-buckets of this thread's four items
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const uint32_t i = t0 + TILE + j * NW * 64 + tid; nx[j] = i < n_s ? src[i] : KG_PAD; } // next tile
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (cx[j] != KG_PAD) {
+                    cur[j] = ((u64)s_er[cx[j] >> 54] << 46) | (cx[j] & KG_M46);
+                    sb |= (uint32_t)((cx[j] >> 46) & 255u) << (8 * j);
+                    pend |= 1u << j;
+                }
+            }
+#pragma unroll 1
+            for (bool fetched = false;;) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((pend >> j) & 1u)
+                        if (S.put((sb >> (8 * j)) & 255u, cur[j])) pend &= ~(1u << j);
+                __syncthreads();
+                if (!fetched) {
+                    touch4(nx);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cx[j] = nx[j];
+                    fetched = true;
+                }
+                S.drain(wave, lane, false, G.cap2, write, slow);
+                if (!(S.block_or(pend ? 1u : 0u, phase, tid) & 1u)) break;
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t i = t0 + TILE + j * NW * 64 + tid; nx[j] = i < hi ? src[i] : KG_PAD; } // next tile
-#pragma unroll 1
-        for (;;) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((pend >> j) & 1u)
-                    if (S.put((sub >> (8 * j)) & 255u, cur[j])) pend &= ~(1u << j);
-            __syncthreads();
-            S.drain(wave, lane, false, res, write, alloc);
-            if (!__syncthreads_or((int)pend)) break;
-        }
     }
     __syncthreads();
-    S.drain(wave, lane, true, res, write, alloc);
+    S.drain(wave, lane, true, G.cap2, write, slow);
+    __syncthreads();
+    for (int i = tid; i < KG_FAN; i += NW * 64) G.cur2[((size_t)b1 * KG_FAN + i) * G.split + part] = S.cur[i];
 }
 
 // ---- combine + insert: one workgroup per partition --------------------------------------------------------------------------
@@ -353,17 +370,32 @@ __global__ __launch_bounds__(NT) void kmer_group_combine(const KmerGroupDev G, c
     __shared__ uint32_t s_claim[KG_SLICE_MAX / 32]; // slots of the slice this launch has claimed
     __shared__ uint32_t s_fail;
     const uint32_t p = blockIdx.x;
-    uint32_t n_p = G.cur2[p];
-    { const uint32_t l = G.lim2[p]; n_p = n_p < l ? n_p : l; }
+    // the partition's items: `split` sub-regions of cap2 items each, sub-region j holding cur2[p][j] of them
+    uint32_t n_sub[8], n_p = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { n_sub[j] = (uint32_t)j < G.split ? G.cur2[(size_t)p * G.split + j] : 0u; n_p += n_sub[j]; }
     if (n_p == 0) return; // (block-uniform)
     const int tid = threadIdx.x;
     const Slice sc = slice_of(T, (u64)p << 46);
+    const u64 *src = G.l2 + (size_t)p * G.split * G.cap2;
+    // flat index over the sub-regions -> address (a gap of cap2 - n_sub[j] items behind sub-region j)
+    auto item_at = [&](uint32_t i) -> u64 {
+        uint32_t base = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (i < n_sub[j]) return src[base + i];
+            i -= n_sub[j]; base += G.cap2;
+        }
+        return KG_PAD;
+    };
+    u64 nx[4]; // the partition's items, four per thread in flight; the first four while the LDS tables are cleared
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t i = (uint32_t)(j * NT + tid); nx[j] = i < n_p ? item_at(i) : KG_PAD; }
     for (int i = tid; i < KG_LDS_SLOTS; i += NT) { s_key[i] = ~0ull; s_cnt[i] = 0u; }
     for (int i = tid; i < KG_EPOCH_SPAN; i += NT) s_hist[i] = 0;
     for (uint32_t i = tid; i < (uint32_t)(sc.mask + 32) / 32; i += NT) s_claim[i] = 0u;
     if (tid == 0) s_fail = 0u;
     __syncthreads();
-    const u64 *src = G.l2 + (size_t)p * G.stride2;
     constexpr uint32_t LMASK = KG_LDS_SLOTS - 1;
     constexpr int LSHIFT = 46 - 12; // slot = top 12 bits of the remainder: LDS order == table order
     static_assert(KG_LDS_SLOTS == 4096, "LSHIFT");
@@ -387,17 +419,14 @@ __global__ __launch_bounds__(NT) void kmer_group_combine(const KmerGroupDev G, c
         return -1;
     };
     bool failed = false;
-    { // the partition's items, four per thread in flight
-        u64 nx[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t i = (uint32_t)(j * NT + tid); nx[j] = i < n_p ? src[i] : KG_PAD; }
+    {
 #pragma unroll 1
         for (uint32_t i0 = 0; i0 < n_p; i0 += 4 * NT) {
             u64 it[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) it[j] = nx[j];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + (uint32_t)((4 + j) * NT + tid); nx[j] = i < n_p ? src[i] : KG_PAD; }
+            for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + (uint32_t)((4 + j) * NT + tid); nx[j] = i < n_p ? item_at(i) : KG_PAD; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (it[j] == KG_PAD) continue;
@@ -471,7 +500,7 @@ __global__ __launch_bounds__(NT) void kmer_group_combine(const KmerGroupDev G, c
         __syncthreads();
 #pragma unroll 1
         for (uint32_t i = tid; i < n_p; i += NT) {
-            const u64 item = src[i];
+            const u64 item = item_at(i);
             if (item == KG_PAD) continue;
             const u64 rem = item & KG_M46;
             if (find_or_add(rem, 0ull, false) < 0)
@@ -485,37 +514,35 @@ __global__ __launch_bounds__(NT) void kmer_group_combine(const KmerGroupDev G, c
 __global__ void kmer_group_reset(const KmerGroupDev G)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (uint32_t)KG_FAN) { G.cur1[i] = 0u; G.lim1[i] = 0xffffffffu; }
-    if (i < (uint32_t)KG_FAN * KG_FAN) { G.cur2[i] = 0u; G.lim2[i] = 0xffffffffu; }
+    if (i < (uint32_t)KG_FAN * KG_FAN) G.cur1[i] = 0u;
 }
 
 constexpr int KG_NW = 16;
-constexpr size_t KG_STAGE_BYTES = (size_t)KG_FAN * KG_STAGE * 8 + (size_t)KG_FAN * 4;
 
 } // namespace
 
-// blocks of an extraction launch over n_reads reads (each block pads up to 256 granules: the host's item bound counts them)
+// blocks of an extraction launch over n_reads reads
 uint32_t faqcs_kmer_group_grid(uint32_t n_reads, int n_cu)
 {
     uint32_t grid = (n_reads + 4 * KG_NW - 1) / (4 * KG_NW);
-    if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu; // one block per CU: its staging area is 129 KB of the CU's LDS
+    if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu; // one block per CU: its staging area is 130 KB of the CU's LDS
+    if (grid > (uint32_t)KG_FAN) grid = KG_FAN;       // ... and one sub-region of every bucket per block
     return grid ? grid : 1u;
 }
 
-hipError_t faqcs_launch_kmer_group_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run,
+hipError_t faqcs_launch_kmer_group_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
                                            uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                            uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st)
 {
     if (r_end > r_begin)
         hipLaunchKernelGGL((kmer_group_extract<KG_NW>), dim3(faqcs_kmer_group_grid(r_end - r_begin, n_cu)), dim3(KG_NW * 64), KG_STAGE_BYTES + 16, st,
-                           P, k, G, T, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
-    hipLaunchKernelGGL(kmer_group_bounds, dim3(1), dim3(KG_FAN), 0, st, G, run);
+                           P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
     return hipGetLastError();
 }
 
-hipError_t faqcs_launch_kmer_group_flush(const KmerGroupDev &G, const KmerTable &T, uint32_t split, hipStream_t st)
+hipError_t faqcs_launch_kmer_group_flush(const KmerGroupDev &G, const KmerTable &T, hipStream_t st)
 {
-    hipLaunchKernelGGL((kmer_group_split<KG_NW>), dim3(KG_FAN * split), dim3(KG_NW * 64), KG_STAGE_BYTES + (size_t)KG_MAX_RUNS * 8, st, G, T, split);
+    hipLaunchKernelGGL((kmer_group_split<KG_NW>), dim3(KG_FAN * G.split), dim3(KG_NW * 64), KG_STAGE_BYTES + (size_t)(KG_MAX_RUNS + KG_FAN) * 4 + 16, st, G, T);
     hipLaunchKernelGGL((kmer_group_combine<1024>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T);
     hipLaunchKernelGGL(kmer_group_reset, dim3(KG_FAN * KG_FAN / 256), dim3(256), 0, st, G);
     return hipGetLastError();

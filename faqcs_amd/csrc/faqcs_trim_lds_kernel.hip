@@ -269,7 +269,7 @@ __device__ __noinline__ void flush_block_partial(uint32_t *smem, uint32_t *__res
 // but the add stays atomic: another context's kernels may share the block in a caller's design.
 template <int C, int LPR>
 __global__ __launch_bounds__(1024) void fold_partials(const uint32_t *__restrict__ partials, const uint32_t *__restrict__ rows_used, const uint32_t n_blocks,
-                                                      uint64_t *__restrict__ counters, const uint32_t R, uint32_t *__restrict__ g_next)
+                                                      uint64_t *__restrict__ counters, const faqcs_layout lay, uint32_t *__restrict__ g_next)
 {
     using Cfg = RowCfg<C, LPR, lds_wq(C)>;
     constexpr int W = Cfg::W;
@@ -296,19 +296,12 @@ __global__ __launch_bounds__(1024) void fold_partials(const uint32_t *__restrict
 #pragma unroll
     for (int g = 0; g < 16; ++g) { lo += part[0][g][threadIdx.x]; hi += part[1][g][threadIdx.x]; }
     if (!(lo | hi)) return;
-    // faqcs_counters_layout() restated (include/faqcs_mi.h)
-    uint64_t o = 0;
-    const uint64_t filter_stats = o;    o += 32;
-    const uint64_t pre_read_qhist = o;  o += FAQCS_NQ;
-    const uint64_t pre_base_qhist = o;  o += FAQCS_NQ;
-    const uint64_t post_read_qhist = o; o += FAQCS_NQ;
-    const uint64_t post_base_qhist = o; o += FAQCS_NQ;
-    const uint64_t pre_len_hist = o;    o += (uint64_t)R + 1;
-    const uint64_t post_len_hist = o;   o += (uint64_t)R + 1;
-    const uint64_t pre_qual = o;        o += (uint64_t)R * FAQCS_NQ;
-    const uint64_t post_qual = o;       o += (uint64_t)R * FAQCS_NQ;
-    const uint64_t pre_base = o;        o += (uint64_t)R * FAQCS_NBASE;
-    const uint64_t post_base = o;
+    // the counter block's layout: the one faqcs_counters_layout() made (DevParams::lay), not a restatement of it
+    const uint64_t filter_stats = lay.filter_stats, pre_read_qhist = lay.pre_read_qhist, pre_base_qhist = lay.pre_base_qhist,
+                   post_read_qhist = lay.post_read_qhist, post_base_qhist = lay.post_base_qhist, pre_len_hist = lay.pre_len_hist,
+                   post_len_hist = lay.post_len_hist, pre_qual = lay.pre_qual, post_qual = lay.post_qual, pre_base = lay.pre_base,
+                   post_base = lay.post_base;
+    const uint32_t R = lay.max_read_length;
     auto add = [&](uint64_t idx, unsigned long long v) { if (v) atomicAdd((unsigned long long *)(counters + idx), v); };
     if (i < Cfg::O_HB) { // position x quality: pre in the low, post in the high half-word
         const uint32_t q = (uint32_t)(i - Cfg::O_HQ) / Cfg::WQ, p = (uint32_t)(i - Cfg::O_HQ) % Cfg::WQ;
@@ -1404,7 +1397,7 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
                        reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err, tn_flags);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8, lds_wq(C)>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, P.partial_rows, grid, counters, P.R, err + 8);
+    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8, lds_wq(C)>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, P.partial_rows, grid, counters, P.lay, err + 8);
     return hipGetLastError();
 }
 

@@ -7,10 +7,10 @@
 //   * every pass streams the read from global memory, four 64-position pieces per round (a read is 2 x <= 32 KB: it stays in the L2
 //     between the passes); per-read counts are per-lane 16-bit fields summed over the wave once per read (as ballots + popcounts into
 //     scalar counters they made the kernel scalar-issue bound: a CU retires one scalar instruction per clock);
-//   * the quality trimmers (BWA_plus / BWA / HARD, trim.cpp:629-793) are WALKED exactly as the reference walks them, as
-//     wave-uniform scalar code over a 64-score register chunk read with v_readlane: a walk ends two positions after the area
-//     turns negative, i.e. after a handful of steps on a good read; a whole 64-position piece none of whose scores exceeds Q is
-//     taken in one step (the area is monotone there), so a long low-quality tail costs |tail| / 64 steps;
+//   * the quality trimmers (BWA_plus / BWA / HARD, trim.cpp:629-793) run as wave-parallel scans: a lane stands for one STEP of the
+//     reference's walk, the running area is a DPP prefix sum, the step that ends the walk and the step of the cut come out of
+//     ballots and a wave maximum (64 steps per ~40 vector and ~25 scalar instructions; rounds 3's form walked the steps one by
+//     one in scalar code over v_readlane, which made the kernel scalar-issue bound);
 //   * the float expressions of the average-quality and low-complexity tests and of the composition bins are evaluated as the
 //     reference writes them (IEEE single / double operations, no contraction), not through tables;
 //   * the per-position matrices (position x quality, position x base, before and after trimming: four counters per base) are NOT
@@ -162,98 +162,117 @@ __global__ __launch_bounds__(NW * 64) void trim_long(const DevParams P, const ui
         uint64_t f_len_reads = 0, f_len_bases = 0;
         if (len < (int)P.min_len || len == 0) { f_len_bases += (uint64_t)len; ++f_len_reads; ret = false; filt = FAQCS_FILT_LENGTH_PRE; }
 
-        // ---- quality trimming, walked as written (trim.cpp:629-793).  score(i) = quality of window position i, from a 64-score
-        // register chunk (cq holds window positions [cbase, cbase + 64)) ----
+        // ---- quality trimming (hard_trim / BWA_trim / BWA_plus_trim, trim.cpp:629-793) as wave-parallel scans over 64-position
+        // pieces of the window: lane l of piece k stands for STEP t = 64 k + l of the reference's walk -- window position len - 1 - t
+        // of a 3' walk, position t of a 5' walk.  What a walk carries from step to step is a running sum (the "area") and a small
+        // counter that a step re-arms; both have closed forms over a piece:
+        //   area before step t        A(t) = sum over the earlier steps of (Q - score): an inclusive prefix sum over the lanes (DPP) plus
+        //                             the total of the earlier pieces;
+        //   re-arm R(t)               BWA_plus: the position is more than 2 away from the far end and A(t) >= 0 (trim.cpp:739-741,767-769);
+        //   where the walk ends       BWA_plus: the counter starts at min(len, 5) and a re-arming step sets it to min(len, 2), so the walk
+        //                             ends after step min(len, 5) - 1 when none of those steps re-arms, else after the first step t at least
+        //                             two past the first re-arming one with !R(t - 1) and !R(t): two ballots and a count-trailing-zeros;
+        //                             BWA: before the first step with A(t) < 0 or position 0 (:690); HARD: at the first score above Q (:640-668);
+        //   the cut                   the step with the largest area after it among the visited ones, the EARLIEST on ties, if that
+        //                             area is positive (`if (area > maxArea)` is strict, :745,:773): a wave maximum and a ballot.
+        // A good read ends its walks inside the first piece; a long low-quality tail costs one piece per 64 positions.
         uint32_t qt_bases = 0;
         if (!P.qc_only && ret && !read_err) {
-            int cbase = -64;
-            int cq = 0;
-            auto score = [&](const int i) -> int {
-                const int b = i & ~63;
-                if (b != cbase) {
-                    cbase = b;
-                    const int p = w0 + b + lane;
-                    cq = q_score(raw_q(p), in_off); // (positions past the window are never asked for)
-                }
-                return __builtin_amdgcn_readlane(cq, i & 63);
-            };
             const int Q = P.Q;
+            // scores of the 64 steps of piece k (desc: from the window's 3' end), 0 and `valid` false past the window
+            auto piece = [&](const int k, const bool desc, bool &valid) -> int {
+                const int t = 64 * k + lane, i = desc ? len - 1 - t : t;
+                valid = t < len;
+                return valid ? q_score(raw_q(w0 + i), in_off) : 0;
+            };
+            const uint64_t lane_lt = (1ull << lane) - 1ull; // lanes below this one
+            // One area walk (BWA_plus 3' / 5', BWA): returns the step after which the area was largest and positive (-1: none).
+            // far_lim: BWA_plus re-arms while (distance to the far end, in steps) ... see the call sites; plus = false: the BWA rule.
+            auto area_walk = [&](const bool desc, const bool plus, const int rearm_below) -> int {
+                const int a0 = len < 5 ? len : 5, nan2 = len < 2 ? len : 2; // at_least_scan / num_after_neg of trim.cpp:723-724
+                (void)nan2;
+                int carry = 0, best = 0, best_t = -1;
+                bool seen = false, prev_nr = false;
+#pragma unroll 1
+                for (int k = 0; 64 * k < len; ++k) {
+                    bool valid;
+                    const int sc = piece(k, desc, valid);
+                    const int d = valid ? Q - sc : 0;
+                    const int incl = wave_incl_scan_add(d);
+                    const int a_before = carry + incl - d, a_after = carry + incl;
+                    const int t = 64 * k + lane;
+                    int stop_lane = 64; // last visited lane of this piece when the walk ends in it
+                    uint64_t visited;
+                    if (plus) {
+                        // re-arm: 3' walk: position > num_after_neg (:739); 5' walk: position < final_pos_3 - num_after_neg (:767) -- both
+                        // "step index below rearm_below"
+                        const uint64_t rm = __ballot(valid && t < rearm_below && a_before >= 0);
+                        const uint64_t nr = ~rm;
+                        uint64_t cand;
+                        if (!seen) { // (piece 0) the initial count of min(len, 5)
+                            const int f = rm ? (int)__builtin_ctzll(rm) : 64;
+                            if (f >= a0) { stop_lane = a0 - 1; cand = 0; }
+                            else { seen = true; cand = nr & (nr << 1) & ~((1ull << (f + 2)) - 1ull); }
+                        } else {
+                            cand = nr & ((nr << 1) | (prev_nr ? 1ull : 0ull));
+                        }
+                        if (cand) stop_lane = (int)__builtin_ctzll(cand);
+                        prev_nr = (nr >> 63) != 0;
+                        visited = stop_lane < 64 ? ((2ull << stop_lane) - 1ull) : ~0ull;
+                    } else { // BWA: `while (pos_3 > 0 && area >= 0)`: the steps before the first one that fails the test
+                        const uint64_t go = __ballot(valid && t < len - 1 && a_before >= 0);
+                        const int first_fail = ~go ? (int)__builtin_ctzll(~go) : 64;
+                        visited = first_fail < 64 ? ((1ull << first_fail) - 1ull) : ~0ull;
+                        if (first_fail < 64) stop_lane = first_fail; // (ends here; lane first_fail itself is not visited)
+                    }
+                    const bool mine = valid && ((visited >> lane) & 1ull);
+                    const uint32_t key = mine ? (uint32_t)a_after ^ 0x80000000u : 0u; // signed order as unsigned
+                    const uint32_t mx = wave_max_u32(key);
+                    const int m = (int)(mx ^ 0x80000000u);
+                    if (mx != 0u && m > best) { // strictly larger than every earlier piece's: the earliest step wins ties
+                        best = m;
+                        best_t = 64 * k + (int)__builtin_ctzll(__ballot(mine && key == mx));
+                    }
+                    if (stop_lane < 64) break;
+                    carry += __builtin_amdgcn_readlane(incl, 63);
+                }
+                (void)lane_lt;
+                return best_t;
+            };
             int cut5 = 0, kept = len;
             if (P.mode == FAQCS_MODE_HARD) {
-                int pos_3 = len - 1, final_pos_5 = 0, final_pos_3 = pos_3;
-                while (pos_3 > 0) { if (Q < score(pos_3)) { final_pos_3 = pos_3; break; } --pos_3; }
-                if (!P.protect5) {
-                    int pos_5 = final_pos_5;
-                    while (pos_5 < pos_3) { if (Q < score(pos_5)) { final_pos_5 = pos_5; break; } ++pos_5; }
+                // 3': the last window position >= 1 whose score exceeds Q (none: the window's end stays, and the 5' scan has no room)
+                int pos_3 = 0, final_pos_3 = len - 1, final_pos_5 = 0;
+#pragma unroll 1
+                for (int k = 0; 64 * k < len; ++k) {
+                    bool valid;
+                    const int sc = piece(k, true, valid);
+                    const uint64_t hit = __ballot(valid && 64 * k + lane < len - 1 && Q < sc); // (position 0 is not looked at, :640)
+                    if (hit) { pos_3 = len - 1 - (64 * k + (int)__builtin_ctzll(hit)); final_pos_3 = pos_3; break; }
+                }
+                if (!P.protect5) { // 5': the first position below pos_3 whose score exceeds Q (:655-668)
+#pragma unroll 1
+                    for (int k = 0; 64 * k < pos_3; ++k) {
+                        bool valid;
+                        const int sc = piece(k, false, valid);
+                        const uint64_t hit = __ballot(valid && 64 * k + lane < pos_3 && Q < sc);
+                        if (hit) { final_pos_5 = 64 * k + (int)__builtin_ctzll(hit); break; }
+                    }
                 }
                 kept = final_pos_3 - final_pos_5 + 1; cut5 = final_pos_5;
             } else if (P.mode == FAQCS_MODE_BWA) {
-                int pos_3 = len - 1, final_pos_3 = pos_3, area = 0, maxArea = 0;
-                while (pos_3 > 0 && area >= 0) {
-                    if ((pos_3 & 63) == 63 && pos_3 - 63 > 0) { // a whole 64-position piece none of whose scores exceeds Q: the area only grows, the walk cannot stop inside
-                        (void)score(pos_3);
-                        const int d = Q - cq;
-                        if (!__any(d < 0)) {
-                            const uint64_t up = __ballot(d > 0);
-                            area += wave_sum_i32(d);
-                            if (up && area > maxArea) { maxArea = area; final_pos_3 = (pos_3 - 63) + (int)__builtin_ctzll(up) - 1; }
-                            pos_3 -= 64;
-                            continue;
-                        }
-                    }
-                    area += Q - score(pos_3);
-                    if (area > maxArea) { maxArea = area; final_pos_3 = pos_3 - 1; }
-                    --pos_3;
-                }
+                const int bt = area_walk(true, false, 0);
+                const int final_pos_3 = bt >= 0 ? (len - 1 - bt) - 1 : len - 1;
                 kept = final_pos_3 + 1; cut5 = 0;
             } else {
-                int at_least_scan = len < 5 ? len : 5;
-                const int num_after_neg = len < 2 ? len : 2;
-                int pos_3 = len - 1, final_pos_5 = 0, final_pos_3 = pos_3, area = 0, maxArea = 0;
-                while (at_least_scan) {
-                    // A whole 64-position piece none of whose scores exceeds Q, with the piece's lowest position still past the first two: every
-                    // step of it re-arms the scan (area >= 0 throughout) and the area only grows, so the 64 steps are one: the area gains the
-                    // piece's sum, and the last record -- if the new area is one -- is set at the piece's lowest position with a score below Q
-                    // (trim_lds's fast-forward; a low-quality tail of a long read would otherwise be walked base by base in scalar code).
-                    if ((pos_3 & 63) == 63 && pos_3 - 63 > num_after_neg && area >= 0) {
-                        (void)score(pos_3);
-                        const int d = Q - cq;
-                        if (!__any(d < 0)) {
-                            const uint64_t up = __ballot(d > 0);
-                            area += wave_sum_i32(d);
-                            if (up && area > maxArea) { maxArea = area; final_pos_3 = (pos_3 - 63) + (int)__builtin_ctzll(up) - 1; }
-                            at_least_scan = num_after_neg; pos_3 -= 64;
-                            continue;
-                        }
-                    }
-                    --at_least_scan;
-                    if (pos_3 > num_after_neg && area >= 0) at_least_scan = num_after_neg;
-                    area += Q - score(pos_3);
-                    if (area > maxArea) { maxArea = area; final_pos_3 = pos_3 - 1; }
-                    --pos_3;
-                }
-                if (!P.protect5) {
-                    int pos_5 = 0;
-                    maxArea = 0; area = 0;
-                    at_least_scan = len < 5 ? len : 5;
-                    while (at_least_scan) {
-                        if ((pos_5 & 63) == 0 && pos_5 + 63 < final_pos_3 - num_after_neg && area >= 0) { // (the mirror image of the 3' fast-forward)
-                            (void)score(pos_5);
-                            const int d = Q - cq;
-                            if (!__any(d < 0)) {
-                                const uint64_t up = __ballot(d > 0);
-                                area += wave_sum_i32(d);
-                                if (up && area > maxArea) { maxArea = area; final_pos_5 = pos_5 + (63 - (int)__builtin_clzll(up)) + 1; }
-                                at_least_scan = num_after_neg; pos_5 += 64;
-                                continue;
-                            }
-                        }
-                        --at_least_scan;
-                        if (pos_5 < final_pos_3 - num_after_neg && area >= 0) at_least_scan = num_after_neg;
-                        area += Q - score(pos_5);
-                        if (area > maxArea) { maxArea = area; final_pos_5 = pos_5 + 1; }
-                        ++pos_5;
-                    }
+                const int nan2 = len < 2 ? len : 2;
+                // 3' walk: step t is at position len - 1 - t; it re-arms while that is > num_after_neg, i.e. t < len - 1 - num_after_neg
+                const int bt3 = area_walk(true, true, len - 1 - nan2);
+                const int final_pos_3 = bt3 >= 0 ? (len - 1 - bt3) - 1 : len - 1;
+                int final_pos_5 = 0;
+                if (!P.protect5) { // 5' walk: step t is at position t; it re-arms while t < final_pos_3 - num_after_neg
+                    const int bt5 = area_walk(false, true, final_pos_3 - nan2);
+                    final_pos_5 = bt5 >= 0 ? bt5 + 1 : 0;
                 }
                 kept = final_pos_3 <= final_pos_5 ? 0 : final_pos_3 - final_pos_5 + 1;
                 cut5 = final_pos_5;

@@ -29,7 +29,7 @@ fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_plain -o plain -- python3 bench.py --pairs 42949630 --steps 3 --no-cpu-baseline --e2e-pairs 0 > $out/prof_plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_adapter -o adapter -- python3 bench.py --config adapter --pairs 4e6 --steps 3 --no-cpu-baseline --e2e-pairs 0 > $out/prof_adapter.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python3 tests/ablate.py 0 16e6 > $out/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python3 tools/ablate.py 0 16e6 > $out/pmc_$c.log 2>&1
 done
 python3 profiles/pmc_traffic.py $out 16000000 $tag > $out/traffic_plain.json 2> $out/traffic.err
 # 4. instruction / wait / LDS counters per read: the trim kernel (two passes), adapter_overlap, kmer_count's atomics

@@ -28,8 +28,8 @@ cp $out/prof_kmer/kmer_kernel_stats.csv $out/rocprofv3_kernel_stats_bench_kmer_8
 # 3. the trim kernel: SQ counters per read (three --pmc passes), HBM traffic (four --pmc passes), section clocks (stamps build)
 bash profiles/pmc_trim.sh $tag/pmc > $out/pmc_instruction_mix.txt 2>&1
 bash profiles/pmc_traffic2.sh $tag/traffic > $out/traffic_plain.json 2> $out/traffic.err
-TRIM_AB_STAMPS=1 ./profiles/microbench/trim_ab 16777216 150 3 faqcs_amd/libfaqcs_mi_stamps.so > $out/section_stamps.txt 2>&1
-./profiles/microbench/trim_ab 16777216 150 4 faqcs_amd/libfaqcs_mi_r2.so faqcs_amd/libfaqcs_mi.so > $out/ab_round2_vs_round3.txt 2>&1
+TRIM_AB_STAMPS=1 ./profiles/microbench/trim_ab 16777216 150 3 profiles/microbench/libfaqcs_mi_stamps.so > $out/section_stamps.txt 2>&1
+./profiles/microbench/trim_ab 16777216 150 4 profiles/microbench/libfaqcs_mi_r2.so faqcs_amd/libfaqcs_mi.so > $out/ab_round2_vs_round3.txt 2>&1
 TRIM_AB_SYNC_EACH=1 ./profiles/microbench/trim_ab 16777216 150 4 faqcs_amd/libfaqcs_mi.so > $out/ab_no_composition_overlap.txt 2>&1
 # 4. adapter_overlap and kmer_count counters (scripts of round 2)
 bash profiles/pmc_adapter.sh $tag/adapter 0.05 > $out/pmc_adapter.txt 2>&1

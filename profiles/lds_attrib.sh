@@ -9,5 +9,5 @@ for v in "" _noqb _nosb _nosa; do
   [ -f "$lib" ] || continue
   PMC="SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" bash profiles/pmc_insts.sh $tag/pmc$v FAQCS_MI_LIB=$lib > gpurun_out/$tag/pmc$v.txt 2>&1
   echo "variant '${v:-product}':"; grep -v "^$" gpurun_out/$tag/pmc$v.txt | tail -1
-  FAQCS_MI_LIB=$lib python tests/ablate.py 0 16e6 | tail -1
+  FAQCS_MI_LIB=$lib python tools/ablate.py 0 16e6 | tail -1
 done | tee gpurun_out/$tag/summary.txt

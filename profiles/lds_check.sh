@@ -10,4 +10,4 @@ tail -12 $out/pytest.log
 bash profiles/pmc_insts.sh $tag/insts1 "$@" > $out/insts1.txt 2>&1
 PMC="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH" bash profiles/pmc_insts.sh $tag/insts2 "$@" > $out/insts2.txt 2>&1
 cat $out/insts1.txt $out/insts2.txt | grep -v "^$" | tail -4
-python tests/ablate.py 0 16e6 | tee $out/ablate.txt
+python tools/ablate.py 0 16e6 | tee $out/ablate.txt

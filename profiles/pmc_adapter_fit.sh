@@ -3,7 +3,7 @@
 out=gpurun_out/${1:-adfit}; mkdir -p $out; export TMPDIR=/tmp FAQCS_ABLATE_ADAPTER_FRAC=0
 for cfg in "--polyA" "--adapter" "--adapter --polyA"; do
   tag=$(echo $cfg | tr -d ' -')
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_BRANCH --output-format csv -d $out/$tag -o pmc -- python3 tests/ablate.py 0 8e6 $cfg > $out/$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_BRANCH --output-format csv -d $out/$tag -o pmc -- python3 tools/ablate.py 0 8e6 $cfg > $out/$tag.log 2>&1
   python3 - "$out/$tag" "$cfg" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(float); n = collections.Counter()

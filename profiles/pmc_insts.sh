@@ -6,7 +6,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
-rocprofv3 --kernel-trace --pmc ${PMC:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES} --output-format csv -d $out/pmc -o pmc -- python3 tests/ablate.py 0 16e6 > $out/pmc.log 2>&1
+rocprofv3 --kernel-trace --pmc ${PMC:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES} --output-format csv -d $out/pmc -o pmc -- python3 tools/ablate.py 0 16e6 > $out/pmc.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

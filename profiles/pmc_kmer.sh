@@ -1,14 +1,14 @@
 #!/bin/bash
-# What bounds kmer_count: L2 atomic requests per second.  rocprofv3 --pmc over tests/kmer_bench.py (8 M reads of 250 bases
+# What bounds kmer_count: L2 atomic requests per second.  rocprofv3 --pmc over tools/kmer_bench.py (8 M reads of 250 bases
 # sampled from a 50 Mbp synthetic genome, 2^30-slot table): bash profiles/pmc_kmer.sh <tag>
 set -u
 tag=${1:-kmer}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-python3 tests/kmer_bench.py 8e6 250 30 50e6 > $out/kmer_bench.txt 2>&1
-rocprofv3 --kernel-trace --pmc TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_REQ_sum TCC_HIT_sum --output-format csv -d $out/pmc -o pmc -- python3 tests/kmer_bench.py 8e6 250 30 50e6 > $out/pmc.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_MISS_sum --output-format csv -d $out/pmc2 -o pmc -- python3 tests/kmer_bench.py 8e6 250 30 50e6 > $out/pmc2.log 2>&1
+python3 tools/kmer_bench.py 8e6 250 30 50e6 > $out/kmer_bench.txt 2>&1
+rocprofv3 --kernel-trace --pmc TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_REQ_sum TCC_HIT_sum --output-format csv -d $out/pmc -o pmc -- python3 tools/kmer_bench.py 8e6 250 30 50e6 > $out/pmc.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_MISS_sum --output-format csv -d $out/pmc2 -o pmc -- python3 tools/kmer_bench.py 8e6 250 30 50e6 > $out/pmc2.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

@@ -1,5 +1,5 @@
 """Diagnostic (not a test): times trim_filter_accumulate with FAQCS_DBG ablation bits, one process per setting
-so every run builds its own context.  Usage: python tests/ablate.py <dbg> [pairs]"""
+so every run builds its own context.  Usage: python tools/ablate.py <dbg> [pairs]"""
 import ctypes as C
 import os
 import sys

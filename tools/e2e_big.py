@@ -1,5 +1,5 @@
 """Diagnostic (not a test): end-to-end timing of faqcs_mi on synthetic 2x150 FASTQ files in /dev/shm with stage marks.
-python tests/e2e_big.py [pairs] [extra faqcs_mi args...]      FAQCS_E2E_GZ=1: also as bgzip (BGZF) and as plain gzip input"""
+python tools/e2e_big.py [pairs] [extra faqcs_mi args...]      FAQCS_E2E_GZ=1: also as bgzip (BGZF) and as plain gzip input"""
 import os
 import subprocess
 import sys

@@ -1,12 +1,12 @@
 """Diagnostic (not a test): whole-process wall clock of the reference binary vs the reference driver linked against
-libfaqcs_mi.so (integration/trim_shim.cpp) on the same FASTQ pair.  Usage: python tests/e2e_compare.py [pairs] [threads]"""
+libfaqcs_mi.so (integration/trim_shim.cpp) on the same FASTQ pair.  Usage: python tools/e2e_compare.py [pairs] [threads]"""
 import os
 import subprocess
 import sys
 import tempfile
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import make_fixtures  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

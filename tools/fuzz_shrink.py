@@ -1,15 +1,15 @@
 """Developer tool (GPU box): rebuild the batch of a failing seeded parity test and shrink it to a small failing batch.
 
-    python tests/fuzz_shrink.py width <seed> <maxlen> <kind> <option-set index>
-    python tests/fuzz_shrink.py qoff  <seed> <maxlen> <kind> <in_off>
+    python tools/fuzz_shrink.py width <seed> <maxlen> <kind> <option-set index>
+    python tools/fuzz_shrink.py qoff  <seed> <maxlen> <kind> <in_off>
 """
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 which, seed, maxlen, kind, last = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])

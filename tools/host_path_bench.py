@@ -1,5 +1,5 @@
 """Diagnostic: PCIe-inclusive rate of the host-buffer path (faqcs_submit_async from pinned arenas, results copied back).
-Usage: python tests/host_path_bench.py [reads per batch] [batches]"""
+Usage: python tools/host_path_bench.py [reads per batch] [batches]"""
 import ctypes as C
 import os
 import sys

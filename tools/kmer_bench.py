@@ -1,4 +1,4 @@
-"""Diagnostic: throughput of the k-mer path (trim + kmer_count).  Usage: python tests/kmer_bench.py [reads] [L] [log2 slots] [genome length]"""
+"""Diagnostic: throughput of the k-mer path (trim + kmer_count).  Usage: python tools/kmer_bench.py [reads] [L] [log2 slots] [genome length]"""
 import ctypes as C
 import os
 import sys

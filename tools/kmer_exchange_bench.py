@@ -1,5 +1,5 @@
 """Diagnostic: owner-partitioned k-mer path on ONE rank (world = 1: every bucket is local): extraction + insertion rates.
-Usage: python tests/kmer_exchange_bench.py [reads] [L] [world for bucketing only]"""
+Usage: python tools/kmer_exchange_bench.py [reads] [L] [world for bucketing only]"""
 import ctypes as C
 import os
 import sys

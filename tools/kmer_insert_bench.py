@@ -1,5 +1,5 @@
 """Diagnostic: raw insert rate of the device k-mer table (faqcs_kmer_insert_device) vs table size and key reuse.
-Usage: python tests/kmer_insert_bench.py"""
+Usage: python tools/kmer_insert_bench.py"""
 import os
 import sys
 import time

@@ -1,4 +1,4 @@
-"""Diagnostic: adapter pre-pass on reads that ARE PhiX (stage 2 runs for every read).  Usage: python tests/phix_bench.py [reads] [hit fraction]"""
+"""Diagnostic: adapter pre-pass on reads that ARE PhiX (stage 2 runs for every read).  Usage: python tools/phix_bench.py [reads] [hit fraction]"""
 import os
 import sys
 import time
@@ -6,7 +6,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import torch  # noqa: E402
 
 torch.cuda.init()

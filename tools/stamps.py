@@ -1,5 +1,5 @@
 """Diagnostic (not a test): section clocks of trim_lds from a -DFAQCS_LDS_STAMPS build of the library
-(FAQCS_MI_LIB=faqcs_amd/libfaqcs_mi_stamps.so python tests/stamps.py [reads])."""
+(FAQCS_MI_LIB=profiles/microbench/libfaqcs_mi_stamps.so python tools/stamps.py [reads])."""
 import ctypes as C
 import os
 import sys
