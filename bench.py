@@ -376,7 +376,7 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
     L = read_len or (250 if config == "kmer" else 150)
     if not pairs:
         pairs = 25e6 if config == "kmer" else (125e6 if (config == "plain" and world == 8) else 100e6)
-    opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "1000000"]}.get(config, [])
+    opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "400"]}.get(config, [])
     opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
     eng = HipEngine(opt, 256 if L <= 256 else (capi.FAST_READ_LENGTH if L <= capi.FAST_READ_LENGTH else capi.MAX_READ_LENGTH), 33, device=local,
                     kmer_table_slots=(1 << 31) if config == "kmer" else 0)
@@ -435,6 +435,7 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         kmer_epochs = ep[rank * per_rank:(rank + 1) * per_rank]
         kx = parallel.KmerExchange(eng, rank, world, opt.num_subsample)
     kmer_last = {}
+    coll = [0.0, 0]  # seconds in the counter all-reduce (export, all-reduce, import; behind a sync, so it is the collective alone), calls
 
     def step(flags=True):
         _check(lib, lib.faqcs_reset_counters(eng.ctx))  # one step = one job: its counter block starts at zero
@@ -455,7 +456,11 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
             kmer_last["points"] = len(pts)
             kmer_last["distinct"], kmer_last["total"] = (pts[-1][1], pts[-1][2]) if pts else (0, 0)
         if use_dist:
+            eng.sync()
+            tc = time.perf_counter()
             parallel.allreduce_counters_device(eng)  # the job's one collective: the 1.1 MB counter block, once per job (= step)
+            coll[0] += time.perf_counter() - tc
+            coll[1] += 1
         else:
             eng.sync()
 
@@ -553,6 +558,10 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         }
         if noflag_value is not None:
             out["config"]["value_without_terminal_n_flags"] = noflag_value
+        if coll[1]:
+            out["collective"] = {"what": "all-reduce(sum) of the %d-word u64 counter block, once per job: device-to-device export into a torch tensor, "
+                                         "dist.all_reduce (%s), import" % (eng.n_counters, backend),
+                                 "ms_per_step": round(coll[0] / coll[1] * 1e3, 4), "calls": coll[1]}
         if config == "kmer" and kx is not None:
             out["kmer"] = {"G_inserts_per_s": round(kmer_last.get("total", 0) / (dt / steps) / 1e9, 3), "distinct_at_last_point": int(kmer_last.get("distinct", 0)),
                            "occurrences_at_last_point": int(kmer_last.get("total", 0)), "points": int(kmer_last.get("points", 0)),

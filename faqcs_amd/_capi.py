@@ -166,6 +166,7 @@ def load_library():
         "faqcs_kmer_outbox_host": (i32, [vp, vp, u64, C.POINTER(u64)]),
         "faqcs_kmer_insert_device": (i32, [vp, vp, u64]),
         "faqcs_kmer_epoch_counts": (i32, [vp, vp, vp, u32]),
+        "faqcs_kmer_forward": (i32, [vp, vp, u32]),
         "faqcs_synth_fill": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, C.c_float]),
         "faqcs_synth_fill_genome": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, u64]),
         "faqcs_terminal_n_flags": (i32, [i32, vp, vp, u32, vp]),

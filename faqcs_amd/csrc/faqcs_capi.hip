@@ -120,6 +120,7 @@ struct faqcs_ctx {
     uint32_t part_rank = 0, part_world = 1, n_epochs = 0;
     std::vector<uint32_t> seg_epoch;             // epochs of the NEXT submission's segments
     DevBuf<ulonglong2> ob_items;
+    DevBuf<ulonglong2> fwd_items;                // pairs another device's context forwarded to this one (faqcs_kmer_forward)
     DevBuf<uint32_t> ob_wave_count;
     DevBuf<unsigned long long> ob_wave_offset;
     unsigned long long *d_ob = nullptr;          // [3 * world]: dest_count, dest_offset, dest_cursor
@@ -132,10 +133,12 @@ struct faqcs_ctx {
     struct KmerGroup {
         bool ready = false;
         bool direct = false;          // FAQCS_KMER_DIRECT=1 (diagnostics): one atomic insert per occurrence (kmer_count), as in rounds 1-3
+        bool owner = false;           // owner-partitioned context whose received pairs go through the group buffers too (n_epochs <= KG_EPOCH_SPAN)
         uint64_t cap_items = 0;       // item bound of a group
         uint64_t bound_items = 0;     // upper bound of the items the open group holds
         std::vector<uint32_t> run_epoch, upload[2]; // epochs (relative to epoch_base) of the open group's runs; host copies in flight
         unsigned n_flushes = 0;
+        uint64_t n_launches = 0;      // (owner side) launches so far: rotates the sub-regions
         uint32_t epoch_base = 0;
         std::vector<uint64_t> sub_fill; // [256] upper bound of the items in the level-1 sub-regions written by block slot i
         KmerGroupDev dev{};           // (n_runs / epoch_base filled in at flush time)
@@ -426,7 +429,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
     for (auto &rs : c->rec) { rs.pre.release(); rs.post.release(); if (rs.trimmed) (void)hipEventDestroy(rs.trimmed); if (rs.folded) (void)hipEventDestroy(rs.folded); }
     if (c->aux) (void)hipStreamDestroy(c->aux);
-    c->ob_items.release(); c->ob_wave_count.release(); c->ob_wave_offset.release();
+    c->ob_items.release(); c->fwd_items.release(); c->ob_wave_count.release(); c->ob_wave_offset.release();
     { void *kg_ptrs[] = {c->kg.dev.l1, c->kg.dev.l2, c->kg.dev.cur1, c->kg.dev.cur2, c->kg.dev.run_epoch, c->kg.dev.first_hist, c->kg.dev.tot_by_epoch};
       for (void *q : kg_ptrs) if (q) (void)hipFree(q);
       for (auto &ev : c->kg.flush_ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); } }
@@ -569,6 +572,44 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
         g.bound_items += bound;
         for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += bound / ((uint64_t)grid * KG_FAN) + bound / ((uint64_t)grid * KG_FAN * 8) + 64;
         r0 += take;
+    }
+    return 0;
+}
+
+// owner side of the multi-GPU exchange: n (key, epoch) pairs (device memory) join the open group; epochs are absolute (the group's
+// run -> epoch table is the identity)
+static int kg_add_items(faqcs_ctx *c, const void *d_items, uint64_t n)
+{
+    faqcs_ctx::KmerGroup &g = c->kg;
+    if (int rc = kg_init(c)) return rc;
+    if (int rc = kg_ensure_epochs(c, c->n_epochs)) return rc;
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(d_items);
+    while (n) {
+        const uint32_t rot = (uint32_t)((g.n_launches * 37u) % KG_FAN);
+        auto fits = [&](uint64_t take) {
+            const uint32_t grid = faqcs_kmer_group_items_grid(take, c->n_cu);
+            const uint64_t share = take / ((uint64_t)grid * KG_FAN) + take / ((uint64_t)grid * KG_FAN * 8) + 64;
+            for (uint32_t i = 0; i < grid; ++i) if (g.sub_fill[(i + rot) % KG_FAN] + share > g.dev.cap1) return false;
+            return g.bound_items + take <= g.cap_items;
+        };
+        uint64_t take = n;
+        if (!fits(take)) {
+            uint64_t lo = 0, hi = take;
+            while (lo < hi) { const uint64_t mid = lo + (hi - lo + 1) / 2; if (fits(mid)) lo = mid; else hi = mid - 1; }
+            take = lo;
+        }
+        if (take == 0) {
+            if (g.bound_items) { if (int rc = kg_flush(c)) return rc; continue; }
+            take = 1;
+        }
+        const uint32_t grid = faqcs_kmer_group_items_grid(take, c->n_cu);
+        g.epoch_base = 0;
+        HIPCHK(faqcs_launch_kmer_group_items(g.dev, c->kt, rot, p, take, c->n_cu, c->compute));
+        ++g.n_launches;
+        if (g.run_epoch.empty()) { g.run_epoch.resize(c->n_epochs); for (uint32_t j = 0; j < c->n_epochs; ++j) g.run_epoch[j] = j; }
+        g.bound_items += take;
+        for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += take / ((uint64_t)grid * KG_FAN) + take / ((uint64_t)grid * KG_FAN * 8) + 64;
+        p += take * 16; n -= take;
     }
     return 0;
 }
@@ -985,7 +1026,7 @@ extern "C" int faqcs_kmer_totals(faqcs_ctx *c, uint64_t *distinct, uint64_t *tot
     if (!c->kt.stats) return 0;
     if (int rc = faqcs_sync(c)) return rc;
     unsigned long long st[2];
-    if (c->partitioned || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    if ((c->partitioned && !c->kg.owner) || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
     else if (int rc = kg_totals(c, &st[0], &st[1])) return rc;
     *distinct = st[0]; *total = st[1];
     return 0;
@@ -997,7 +1038,7 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
     if (!c->kt.stats) return 0;
     if (int rc = faqcs_sync(c)) return rc;
     unsigned long long st[2];
-    if (c->partitioned || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    if ((c->partitioned && !c->kg.owner) || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
     else if (int rc = kg_totals(c, &st[0], &st[1])) return rc;
     if (st[0]) { // ++kmer_frequency_histogram[count] for every key, FaQCs.cpp:518-521
         const uint32_t DENSE = 1u << 16, BIGCAP = 1u << 20;
@@ -1051,6 +1092,9 @@ extern "C" int faqcs_kmer_partition(faqcs_ctx *c, uint32_t rank, uint32_t world,
     HIPCHK(hipMalloc((void **)&c->d_first_hist, (size_t)n_epochs * 8));
     HIPCHK(hipMemset(c->d_tot_by_epoch, 0, (size_t)n_epochs * 8));
     c->partitioned = true; c->part_rank = rank; c->part_world = world; c->n_epochs = n_epochs;
+    // the pairs this rank receives are combined before they reach its table like a single GPU's own occurrences (a group's items carry
+    // their epoch in 10 bits: up to KG_EPOCH_SPAN epochs; more, or FAQCS_KMER_DIRECT=1: one atomic insert per pair, kmer_insert_items)
+    c->kg.owner = !c->kg.direct && n_epochs <= (uint32_t)KG_EPOCH_SPAN;
     return 0;
 }
 
@@ -1104,10 +1148,42 @@ extern "C" int faqcs_kmer_insert_device(faqcs_ctx *c, const void *d_items, uint6
     HIPCHK(hipSetDevice(c->device));
     if (!c->ins_a) { HIPCHK(hipEventCreate(&c->ins_a)); HIPCHK(hipEventCreate(&c->ins_b)); }
     HIPCHK(hipEventRecord(c->ins_a, c->compute));
-    HIPCHK(faqcs_launch_kmer_insert_items(c->kt, d_items, n_items, c->d_tot_by_epoch, c->n_epochs, c->n_cu, c->compute));
+    if (c->kg.owner) { if (int rc = kg_add_items(c, d_items, n_items)) return rc; }
+    else HIPCHK(faqcs_launch_kmer_insert_items(c->kt, d_items, n_items, c->d_tot_by_epoch, c->n_epochs, c->n_cu, c->compute));
     HIPCHK(hipEventRecord(c->ins_b, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute)); // the caller may recycle d_items as soon as this returns
     { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ins_a, c->ins_b) == hipSuccess) c->kmer_insert_ms += ms; }
+    return 0;
+}
+
+// In-process form of the exchange (one process driving several devices: faqcs_mi --gpus N --kmer_rarefaction): the last submission's
+// outbox of `from` goes to the owner contexts -- owners[r] = the context of rank r -- and is inserted there.  Same device: the
+// owner reads the outbox in place; another device: a peer copy into the owner's staging buffer first.
+extern "C" int faqcs_kmer_forward(faqcs_ctx *from, faqcs_ctx *const *owners, uint32_t world)
+{
+    if (!from || !owners) return fail(FAQCS_E_INVAL, "null argument");
+    if (!from->partitioned || world != from->part_world) return fail(FAQCS_E_INVAL, "faqcs_kmer_forward: the context is not partitioned over `world` ranks");
+    for (uint32_t r = 0; r < world; ++r)
+        if (!owners[r] || !owners[r]->partitioned || owners[r]->part_rank != r || owners[r]->part_world != world)
+            return fail(FAQCS_E_INVAL, "faqcs_kmer_forward: owners[r] must be the context of rank r");
+    HIPCHK(hipSetDevice(from->device));
+    HIPCHK(hipStreamSynchronize(from->compute));
+    std::vector<unsigned long long> cnt(world);
+    HIPCHK(hipMemcpy(cnt.data(), from->d_ob, (size_t)world * 8, hipMemcpyDeviceToHost));
+    size_t at = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        const unsigned long long n = cnt[r];
+        if (!n) continue;
+        const ulonglong2 *src = from->ob_items.p + at;
+        at += (size_t)n;
+        faqcs_ctx *o = owners[r];
+        if (o->device == from->device) { if (int rc = faqcs_kmer_insert_device(o, src, n)) return rc; continue; }
+        HIPCHK(hipSetDevice(o->device));
+        if ((size_t)n > o->fwd_items.cap) HIPCHK(hipStreamSynchronize(o->compute));
+        HIPCHK(o->fwd_items.reserve((size_t)n));
+        HIPCHK(hipMemcpyPeer(o->fwd_items.p, o->device, src, from->device, (size_t)n * 16));
+        if (int rc = faqcs_kmer_insert_device(o, o->fwd_items.p, n)) return rc;
+    }
     return 0;
 }
 
@@ -1116,6 +1192,14 @@ extern "C" int faqcs_kmer_epoch_counts(faqcs_ctx *c, uint64_t *distinct_by_first
     if (!c || !distinct_by_first_epoch || !total_by_epoch) return fail(FAQCS_E_INVAL, "null argument");
     if (!c->partitioned || cap < c->n_epochs) return fail(FAQCS_E_INVAL, "faqcs_kmer_epoch_counts: not partitioned / buffers too small");
     if (int rc = faqcs_sync(c)) return rc;
+    if (c->kg.owner) { // kept up to date by the combine kernel: no pass over the table
+        for (uint32_t i = 0; i < c->n_epochs; ++i) { distinct_by_first_epoch[i] = 0; total_by_epoch[i] = 0; }
+        if (c->kg.ready && c->kg.ep_cap) {
+            HIPCHK(hipMemcpy(distinct_by_first_epoch, c->kg.dev.first_hist, (size_t)c->n_epochs * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(total_by_epoch, c->kg.dev.tot_by_epoch, (size_t)c->n_epochs * 8, hipMemcpyDeviceToHost));
+        }
+        return 0;
+    }
     HIPCHK(hipMemsetAsync(c->d_first_hist, 0, (size_t)c->n_epochs * 8, c->compute));
     HIPCHK(faqcs_launch_kmer_first_epoch_histogram(c->kt, c->d_first_hist, c->n_epochs, c->n_cu, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));

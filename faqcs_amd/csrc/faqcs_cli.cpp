@@ -762,12 +762,79 @@ struct Run {
         }
         std::vector<int> devs = opt.devices;
         if (devs.empty()) devs.push_back(-1);
-        if (devs.size() > 1 && opt.kmer_rarefaction) { // the rarefaction curve depends on the order of the trim() calls: one table, one device
-            fprintf(stderr, "faqcs_mi: --kmer_rarefaction runs on one device (the first of the list)\n");
-            devs.resize(1);
-        }
         for (int d : devs) { faqcs_ctx *c = nullptr; check(faqcs_create(&prm, d, &c)); ctxs.push_back(c); }
         ctx = ctxs[0];
+        if (ctxs.size() > 1 && opt.kmer_rarefaction) {
+            // Several devices and k-mers: the buffers are still dealt round robin -- every device trims its share --
+            // and every canonical k-mer has ONE owner context; a buffer's (key, epoch) pairs are forwarded to their owners right
+            // behind its submission (faqcs_kmer_forward).  epoch = index of the first sampling point that includes the buffer,
+            // from the sampling rule over the buffers in file order (kmer_epoch_of below); distinct / total of a point are sums
+            // over the owners of what their epoch histograms say (kmer_finish_pass).
+            kmer_multi = true;
+            kmer_n_epochs = opt.num_subsample + 1;
+            for (size_t k = 0; k < ctxs.size(); ++k) check(faqcs_kmer_partition(ctxs[k], (uint32_t)k, (uint32_t)ctxs.size(), kmer_n_epochs));
+        }
+    }
+    // ---- k-mers over several device contexts ----------------------------------------------------------------------------------
+    bool kmer_multi = false, kmer_curve_open = true;
+    uint32_t kmer_n_epochs = 0;
+    uint64_t kmer_total_number = 0;               // reads of every trim() call so far (FilterStat TOTAL_NUMBER)
+    std::vector<faqcs_rarefaction> kmer_points;   // every point of the run; [kmer_points_final, size) belong to the table in use
+    size_t kmer_points_final = 0;
+    std::map<uint64_t, uint64_t> kmer_hist;
+    // the reference's sampling rule (trim.cpp:157-185) for the next trim() call of n reads: its epoch, FAQCS_EPOCH_NONE once the curve is complete
+    uint32_t kmer_epoch_of(uint32_t n)
+    {
+        const uint32_t epoch = kmer_curve_open ? (uint32_t)kmer_points.size() : FAQCS_EPOCH_NONE;
+        kmer_total_number += n;
+        if (kmer_curve_open) {
+            const uint64_t index = kmer_total_number / opt.split_size;
+            const size_t have = kmer_points.size();
+            if (index > have && have < opt.num_subsample) { faqcs_rarefaction pt{kmer_total_number, 0, 0}; kmer_points.push_back(pt); }
+            if (have >= opt.num_subsample) kmer_curve_open = false; // (tested on the count before this call's point, trim.cpp:180-184)
+        }
+        return epoch;
+    }
+    // end of a process_paired() / process_unpaired() pass (FaQCs.cpp:518-537): the points taken during the pass get their values,
+    // the count histograms of the owners' tables are merged, the tables restart
+    void kmer_finish_pass()
+    {
+        if (!kmer_multi) { if (ctx) check(faqcs_kmer_end_table(ctx)); return; }
+        std::vector<uint64_t> d(kmer_n_epochs, 0), t(kmer_n_epochs, 0), pd(kmer_n_epochs), pt(kmer_n_epochs);
+        for (faqcs_ctx *c : ctxs) {
+            check(faqcs_kmer_epoch_counts(c, pd.data(), pt.data(), kmer_n_epochs));
+            for (uint32_t i = 0; i < kmer_n_epochs; ++i) { d[i] += pd[i]; t[i] += pt[i]; }
+        }
+        uint64_t sd = 0, st = 0;
+        for (uint32_t i = 0; i < kmer_n_epochs; ++i) {
+            sd += d[i]; st += t[i];
+            if (i >= kmer_points_final && i < kmer_points.size()) { kmer_points[i].distinct_kmer = sd; kmer_points[i].total_kmer = st; }
+        }
+        if (kmer_curve_open && kmer_points.empty()) { faqcs_rarefaction pt1{kmer_total_number, sd, st}; kmer_points.push_back(pt1); } // FaQCs.cpp:523-537
+        kmer_points_final = kmer_points.size();
+        for (faqcs_ctx *c : ctxs) check(faqcs_kmer_end_table(c));
+    }
+    // the run's count histogram and points, whichever way they were made
+    void kmer_results(std::vector<uint64_t> &cnt, std::vector<uint64_t> &nk, std::vector<faqcs_rarefaction> &pts)
+    {
+        cnt.clear(); nk.clear(); pts.clear();
+        if (!ctx) return;
+        std::map<uint64_t, uint64_t> h;
+        for (faqcs_ctx *c : kmer_multi ? ctxs : std::vector<faqcs_ctx *>(1, ctx)) {
+            uint64_t np = 0;
+            faqcs_kmer_histogram(c, nullptr, nullptr, 0, &np);
+            std::vector<uint64_t> a(np ? np : 1), b(np ? np : 1);
+            if (np) faqcs_kmer_histogram(c, a.data(), b.data(), np, &np);
+            for (uint64_t i = 0; i < np; ++i) h[a[i]] += b[i];
+        }
+        for (auto &kv : h) { cnt.push_back(kv.first); nk.push_back(kv.second); }
+        if (kmer_multi) pts = kmer_points;
+        else {
+            uint32_t np = 0;
+            faqcs_kmer_points(ctx, nullptr, 0, &np);
+            pts.resize(np);
+            if (np) faqcs_kmer_points(ctx, pts.data(), np, &np);
+        }
     }
     void nextseq_check(const RecBuf *b) // trim.cpp:619-626, FaQCs.cpp:272-277,404-414
     {
@@ -790,7 +857,9 @@ struct Run {
         faqcs_batch bt; memset(&bt, 0, sizeof(bt));
         bt.seq = b->seq; bt.qual = b->qual; bt.offset = b->off; bt.n_reads = b->n; bt.n_segments = 1; bt.segment_start = seg;
         bt.terminal_n = b->tn;
+        if (kmer_multi) { const uint32_t epoch = kmer_epoch_of(b->n); check(faqcs_kmer_set_epochs(ctxs[b->dev], &epoch, 1)); }
         check(faqcs_submit_async(ctxs[b->dev], &bt, b->res, &b->ticket));
+        if (kmer_multi) check(faqcs_kmer_forward(ctxs[b->dev], ctxs.data(), (uint32_t)ctxs.size())); // (waits for this buffer's kernels)
     }
     // writes one surviving record with the reference's byte edits (trim.cpp:390-403,516-525,1191-1216; fastq.cpp:127-138)
     void write_read(OutFile &f, const RecBuf *b, uint32_t i, std::string &s, std::string &q)
@@ -1312,7 +1381,7 @@ void process_mapped(Run &r, bool paired)
     // (pinned buffers and mappings are left to process exit: unpinning a gigabyte takes longer than the rest of the epilogue)
     static std::vector<std::vector<RecBuf>> keep; keep.emplace_back(std::move(bufs[0])); keep.emplace_back(std::move(bufs[1]));
     fu.close(); fdisc.close();
-    if (r.ctx) Run::check(faqcs_kmer_end_table(r.ctx)); // FaQCs.cpp:518-537
+    r.kmer_finish_pass(); // FaQCs.cpp:518-537
 }
 
 // FaQCs.cpp:153-538
@@ -1432,7 +1501,7 @@ void process_paired(Run &r)
     }
     s1.stop(); s2.stop();
     f1.close(); f2.close(); fu.close(); fd.close();
-    if (r.ctx) Run::check(faqcs_kmer_end_table(r.ctx)); // FaQCs.cpp:518-537
+    r.kmer_finish_pass(); // FaQCs.cpp:518-537
 }
 
 // FaQCs.cpp:540-757
@@ -1501,7 +1570,7 @@ void process_unpaired(Run &r)
     }
     s.stop();
     fo.close(); fd.close();
-    if (r.ctx) Run::check(faqcs_kmer_end_table(r.ctx));
+    r.kmer_finish_pass();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1597,7 +1666,7 @@ std::string stats_text(const Opt &o, const uint64_t *fs, std::map<std::string, s
 
 void put_file(const std::string &path, const std::string &text) { FILE *f = fopen(path.c_str(), "w"); if (f) { fwrite(text.data(), 1, text.size(), f); fclose(f); } }
 
-void write_tables(const Opt &o, const faqcs_layout &L, const uint64_t *c, uint32_t R, faqcs_ctx *ctx)
+void write_tables(const Opt &o, const faqcs_layout &L, const uint64_t *c, uint32_t R, Run &run)
 {
     const std::string d = o.output_dir + "/", p = o.prefix;
     const uint32_t rows_pre = faqcs_counter_rows(c + L.pre_qual, R, FAQCS_NQ), rows_post = faqcs_counter_rows(c + L.post_qual, R, FAQCS_NQ);
@@ -1635,21 +1704,16 @@ void write_tables(const Opt &o, const faqcs_layout &L, const uint64_t *c, uint32
     };
     lenhist("qa." + p + ".length_count.txt", c + L.pre_len_hist);
     lenhist(p + ".length_count.txt", c + L.post_len_hist);
-    uint64_t npairs = 0;
-    faqcs_kmer_histogram(ctx, nullptr, nullptr, 0, &npairs);
-    if (npairs) { // plot.cpp:683-733
-        std::vector<uint64_t> cnt(npairs), nk(npairs);
-        faqcs_kmer_histogram(ctx, cnt.data(), nk.data(), npairs, &npairs);
+    std::vector<uint64_t> cnt, nk;
+    std::vector<faqcs_rarefaction> pts;
+    run.kmer_results(cnt, nk, pts);
+    if (!cnt.empty()) { // plot.cpp:683-733
         std::string t;
-        for (uint64_t i = 0; i < npairs; ++i) t += fmt("%llu %llu\n", (unsigned long long)cnt[i], (unsigned long long)nk[i]);
+        for (size_t i = 0; i < cnt.size(); ++i) t += fmt("%llu %llu\n", (unsigned long long)cnt[i], (unsigned long long)nk[i]);
         put_file(d + p + ".kmerH.txt", t);
-        uint32_t np = 0;
-        faqcs_kmer_points(ctx, nullptr, 0, &np);
-        std::vector<faqcs_rarefaction> pts(np ? np : 1);
-        faqcs_kmer_points(ctx, pts.data(), np, &np);
         t.clear();
         uint64_t lastn = 0;
-        for (uint32_t i = 0; i < np; ++i) { t += fmt("%llu\t%llu\t%llu\n", (unsigned long long)(pts[i].num_seq - lastn), (unsigned long long)pts[i].distinct_kmer, (unsigned long long)pts[i].total_kmer); lastn = pts[i].num_seq; }
+        for (size_t i = 0; i < pts.size(); ++i) { t += fmt("%llu\t%llu\t%llu\n", (unsigned long long)(pts[i].num_seq - lastn), (unsigned long long)pts[i].distinct_kmer, (unsigned long long)pts[i].total_kmer); lastn = pts[i].num_seq; }
         put_file(d + p + ".Kmercount.txt", t);
     }
 }
@@ -2083,7 +2147,7 @@ static int run_command(int argc, char **argv)
             else { const std::string t = stats_text(opt, fs, ast, r.quality); fwrite(t.data(), 1, t.size(), f); fclose(f); }
         }
         if (!opt.trim_only) { // plot.cpp:20-515: tables, R, then the tables go unless --debug
-            write_tables(opt, L, c.data(), r.R, r.ctx);
+            write_tables(opt, L, c.data(), r.R, r);
             report.run(report_script(opt));
             if (!opt.debug) for (const std::string &f : table_files(opt)) unlink(f.c_str());
         }

@@ -96,6 +96,9 @@ hipError_t faqcs_launch_kmer_group_extract(const DevParams &P, uint32_t k, const
                                            uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_group_flush(const KmerGroupDev &G, const KmerTable &T, hipStream_t st);
 uint32_t faqcs_kmer_group_grid(uint32_t n_reads, int n_cu);
+uint32_t faqcs_kmer_group_items_grid(unsigned long long n_items, int n_cu);
+hipError_t faqcs_launch_kmer_group_items(const KmerGroupDev &G, const KmerTable &T, uint32_t rot, const void *items, unsigned long long n_items,
+                                         int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_group_reset(const KmerGroupDev &G, hipStream_t st);
 
 #ifdef __HIPCC__

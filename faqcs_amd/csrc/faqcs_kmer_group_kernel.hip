@@ -283,6 +283,63 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_extract(
     }
 }
 
+// ---- level 1 from (key, epoch) pairs: the owner side of the multi-GPU exchange (faqcs_kmer_insert_device) ---------------------
+// The pairs other ranks extracted for the keys this rank owns join the same group buffers; a pair's epoch travels in the item's
+// run field (the group's run -> epoch table is the identity in this mode: at most KG_MAX_RUNS epochs).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void kmer_group_items(const KmerGroupDev G, const KmerTable T, const uint32_t rot,
+                                                            const ulonglong2 *__restrict__ items, const u64 n_items)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(lds + KG_FAN * KG_STAGE);
+    const Staging<NW> S{lds, w32, w32 + KG_FAN, w32 + 2 * KG_FAN};
+    uint32_t *s_tot = w32 + 2 * KG_FAN + 4; // [KG_EPOCH_SPAN] occurrences of this block by epoch
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const uint32_t sub = (blockIdx.x + rot) % KG_FAN;
+    for (int i = tid; i < KG_FAN; i += NW * 64) { S.cnt[i] = 0u; S.cur[i] = G.cur1[sub * KG_FAN + i]; }
+    for (int i = tid; i < KG_EPOCH_SPAN; i += NW * 64) s_tot[i] = 0u;
+    if (tid < 3) S.flag[tid] = 0u;
+    __syncthreads();
+    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it, const uint32_t take) {
+        if ((uint32_t)lane < take) G.l1[((size_t)b * KG_FAN + sub) * G.cap1 + pos + lane] = it;
+    };
+    auto slow = [&](const uint32_t b, const u64 it) {
+        kmer_insert_atomic(T, ((u64)b << 54) | (it & KG_M54), (uint32_t)(it >> 54), 1u, G.first_hist, G.n_epochs);
+    };
+    constexpr uint32_t PER = NW * 64;
+    const u64 per_block = ((n_items + gridDim.x - 1) / gridDim.x + PER - 1) / PER * PER;
+    const u64 lo = (u64)blockIdx.x * per_block < n_items ? (u64)blockIdx.x * per_block : n_items;
+    const u64 hi = lo + per_block < n_items ? lo + per_block : n_items;
+    uint32_t phase = 0;
+    ulonglong2 nx = lo + tid < hi ? items[lo + tid] : make_ulonglong2(KG_PAD, 0ull);
+#pragma unroll 1
+    for (u64 t0 = lo; t0 < hi; t0 += PER) {
+        const ulonglong2 cur = nx;
+        nx = t0 + PER + tid < hi ? items[t0 + PER + tid] : make_ulonglong2(KG_PAD, 0ull);
+        uint32_t pend = 0;
+        u64 h = 0, it = 0;
+        if (cur.x != KG_PAD && (uint32_t)cur.y < (uint32_t)KG_EPOCH_SPAN) {
+            h = kmer_mix62(cur.x);
+            it = ((u64)(uint32_t)cur.y << 54) | (h & KG_M54);
+            pend = 1u;
+            atomicAdd(&s_tot[(uint32_t)cur.y], 1u);
+        }
+#pragma unroll 1
+        for (;;) {
+            if (pend && S.put((uint32_t)(h >> 54), it)) pend = 0u;
+            __syncthreads();
+            S.drain(wave, lane, false, G.cap1, write, slow);
+            if (!(S.block_or(pend, phase, tid) & 1u)) break;
+        }
+    }
+    __syncthreads();
+    S.drain(wave, lane, true, G.cap1, write, slow);
+    __syncthreads();
+    for (int i = tid; i < KG_FAN; i += NW * 64) G.cur1[sub * KG_FAN + i] = S.cur[i];
+    for (int i = tid; i < KG_EPOCH_SPAN; i += NW * 64)
+        if (s_tot[i]) hist_add(G.tot_by_epoch, (uint32_t)i, G.n_epochs, (long long)s_tot[i]);
+}
+
 // ---- level 2: every bucket 256 ways; the run number becomes the epoch -------------------------------------------------------
 // Block (b1, part) reads the sub-regions [part * 256 / split, (part + 1) * 256 / split) of bucket b1 and appends to sub-region
 // `part` of the partitions b1 * 256 + (next 8 bits of h): again a block writes only where no other block does.
@@ -537,6 +594,24 @@ hipError_t faqcs_launch_kmer_group_extract(const DevParams &P, uint32_t k, const
     if (r_end > r_begin)
         hipLaunchKernelGGL((kmer_group_extract<KG_NW>), dim3(faqcs_kmer_group_grid(r_end - r_begin, n_cu)), dim3(KG_NW * 64), KG_STAGE_BYTES + 16, st,
                            P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
+    return hipGetLastError();
+}
+
+// blocks of an owner-side launch over n_items (key, epoch) pairs
+uint32_t faqcs_kmer_group_items_grid(unsigned long long n_items, int n_cu)
+{
+    unsigned long long grid = (n_items + 16 * KG_NW * 64 - 1) / (16ull * KG_NW * 64);
+    if (grid > (unsigned long long)n_cu) grid = (unsigned long long)n_cu;
+    if (grid > (unsigned long long)KG_FAN) grid = KG_FAN;
+    return grid ? (uint32_t)grid : 1u;
+}
+
+hipError_t faqcs_launch_kmer_group_items(const KmerGroupDev &G, const KmerTable &T, uint32_t rot, const void *items, unsigned long long n_items,
+                                         int n_cu, hipStream_t st)
+{
+    if (n_items)
+        hipLaunchKernelGGL((kmer_group_items<KG_NW>), dim3(faqcs_kmer_group_items_grid(n_items, n_cu)), dim3(KG_NW * 64),
+                           KG_STAGE_BYTES + (size_t)KG_EPOCH_SPAN * 4 + 16, st, G, T, rot, reinterpret_cast<const ulonglong2 *>(items), n_items);
     return hipGetLastError();
 }
 

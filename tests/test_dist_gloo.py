@@ -1,4 +1,4 @@
-"""Multi-process (world_size = 2, gloo, CPU) test of the only collective on the path: shards of reads are
+"""Multi-process (world_size = 2, 3, 4 and 8; gloo, CPU) tests of the only collective on the path: shards of reads are
 processed independently and the additive u64 counter block is all-reduced (faqcs_amd/parallel.py).  The
 per-rank engine here is the CPU checker standing in for the HIP engine -- the sharding / reduction logic under
 test is identical (everything except k-mers is per-read results + integer sums)."""
@@ -66,6 +66,38 @@ def test_two_rank_allreduce_equals_single_process(args, tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, port, args, 1203, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+@pytest.mark.parametrize("world,args", [(3, []), (4, ["--adapter", "--polyA"]), (8, [])], ids=["w3_plain", "w4_adapter", "w8_plain"])
+def test_more_ranks_allreduce_equals_single_process(world, args, tmp_path):
+    """The same job on 3, 4 and 8 ranks (gloo, CPU): shard counts that do not divide the 150 adapter groups of the input evenly
+    (1 203 reads: the last rank also takes the 3 reads behind the last whole group), the 8-rank shape of BASELINE configs[3]."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(world, port, args, 1203, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_schedule_slices_for_every_rank_count():
+    """bench.py --config kmer --gpus N hands rank r the epochs of ITS shard of the global sequence of trim() calls (rank-major
+    order): for 1 ... 8 ranks the slices tile the schedule, and the epoch of a segment never depends on how many ranks there are."""
+    from faqcs_amd import parallel
+
+    sizes_one = [32768] * 13 + [1234]
+    for world in range(1, 9):
+        sizes = sizes_one * world
+        ep, pts = parallel.rarefaction_schedule(sizes, 100000, 40)
+        per = len(sizes) // world
+        got = []
+        for r in range(world):
+            got.extend(ep[r * per:(r + 1) * per])
+        assert got == ep and len(ep) == len(sizes)
+        total = 0
+        for e, sz in zip(ep, sizes):
+            assert e == parallel.EPOCH_NONE or e == sum(1 for p in pts if p <= total)  # the points taken before this call
+            total += sz
 
 
 def test_shard_bounds_cover_everything():

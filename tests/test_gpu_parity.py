@@ -409,7 +409,7 @@ def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150, back
     (["--kmer_rarefaction", "--split_size", "5000", "--qc_only"], 1500, 150),         # no scheduled point: the fallback one
     (["--kmer_rarefaction", "--split_size", "400", "--subset", "200"], 2400, 250),    # BASELINE configs[4]'s shape: 2x250, --subset 200
 ], ids=["complete", "open", "fallback", "len250_subset200"])
-def test_two_rank_kmer_exchange(args, n_reads, maxlen, tmp_path):
+def test_two_rank_kmer_exchange(args, n_reads, maxlen, tmp_path, world=2):
     """owner-partitioned k-mer tables, (key, epoch) all-to-all (gloo here, two ranks sharing the
     one GPU of the box), additive epoch histograms -> the same rarefaction points and count histogram as one process."""
     import socket
@@ -421,8 +421,13 @@ def test_two_rank_kmer_exchange(args, n_reads, maxlen, tmp_path):
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "result.txt")
-    mp.spawn(_kmer_rank, args=(2, port, args, n_reads, 333, out, maxlen), nprocs=2, join=True)
+    mp.spawn(_kmer_rank, args=(world, port, args, n_reads, 333, out, maxlen), nprocs=world, join=True)
     assert open(out).read() == "ok", open(out).read()
+
+
+def test_three_rank_kmer_exchange(tmp_path):
+    """Three owners: a rank count that does not divide the key space (or the 9 segments of the input) evenly."""
+    test_two_rank_kmer_exchange(["--kmer_rarefaction", "--split_size", "400", "--subset", "200"], 2900, 250, tmp_path, world=3)
 
 
 def _counter_rank(rank, world, port, args, n_reads, out, backend="gloo"):
@@ -932,7 +937,8 @@ def test_native_cli_reproduces_reference(name, fixture_cache, tmp_path):
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("name", ["advbig_default", "advbig_adapter_polyA", "adv_default", "adv_discard", "adv_unpaired_only"])
+@pytest.mark.parametrize("name", ["advbig_default", "advbig_adapter_polyA", "adv_default", "adv_discard", "adv_unpaired_only",
+                                  "adv_kmer", "adv_kmer_qc_only_subset1", "advbig_kmer", "head250_kmer", "long300_kmer_q20", "long8k_kmer_replaceN"])
 def test_native_cli_on_two_devices(name, fixture_cache, tmp_path):
     """faqcs_mi --gpu_ids 0,0: the 32 768-read buffers are dealt round robin to TWO device contexts (both on this box's one GPU),
     the ordered writers re-serialise by buffer number and the two counter blocks are summed -- one QC.stats.txt, the same
@@ -943,6 +949,10 @@ def test_native_cli_on_two_devices(name, fixture_cache, tmp_path):
         pytest.skip("no such golden case")
     bad = run_case_binary(load_case(name), fixture_cache, tmp_path, _CLI_BIN, extra_args=["--gpu_ids", "0,0"])
     assert not bad, "\n".join(bad)
+    if "kmer" in name:  # --kmer_rarefaction on several contexts: every context trims its buffers, every k-mer has one owner context
+        (tmp_path / "three").mkdir()  # (faqcs_kmer_forward; three contexts: an owner count that does not divide the key space evenly)
+        bad = run_case_binary(load_case(name), fixture_cache, tmp_path / "three", _CLI_BIN, extra_args=["--gpu_ids", "0,0,0"])
+        assert not bad, "\n".join(bad)
 
 
 def test_native_cli_reports_a_device_error_in_a_large_input(tmp_path):
