@@ -430,7 +430,13 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                 const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)va, (int)j), sb = (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)j);
                 const int tlen = (int)(sa & 0xffffu);
                 const int thr = (int)(sb & 0xffffu);
-                const int need_j = (int)(sb >> 16) - 32768;                  // (mcap + bound) / 2 >= thr  <=>  bound >= need
+                const int need_j = (int)(sb >> 16) - 32768;                  // (mcap + best score) / 2 >= thr  <=>  best score >= need
+                // What an adapter needs to mask or be credited is num_match = (match_length + score) / 2 >= thr (trim.cpp:1024-1027), and
+                // num_match IS the number of matching positions inside the alignment (match_length = matches + mismatches, score = matches -
+                // mismatches): it cannot exceed the matches on the alignment's diagonal.  So a diagonal's MATCH COUNT has to reach thr itself --
+                // a far stronger skip test than "count >= need" (polyA: 16 of 20 instead of 12 of 20, which 15 % of random reads met);
+                // `need` stays the test for a block's best SCORE (second filter below).
+                const int need_cnt = need_j > thr ? need_j : thr;
                 bool any_match = true, may_pass = true;
                 const int mcap = qlen < tlen ? qlen : tlen;
                 if (prefilter_on && MAXLEN <= 320 && tlen <= 128 && tpl_cached) {
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                     else maxcnt = nb <= 5 ? prefilter_max<(NBR >= 5 ? 5 : NBR), NBR>(R, tpl, nw, cb) : prefilter_max<NBR, NBR>(R, tpl, nw, cb); // 257..320-base reads
                     // bound = max over diagonals; only two threshold tests of it are needed
                     any_match = __any(maxcnt > 0u);
-                    may_pass = __any((int)maxcnt + slack >= need_j);
+                    may_pass = __any((int)maxcnt + slack >= need_cnt);
                     if (may_pass) { // rare: the per-block bounds for stage 2 (it aligns the most promising block first and prunes the rest)
                         uint32_t cw[8];
                         (void)prefilter_max<NBR, NBR, true>(R, tpl, nw, cw);
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                         for (int b = 0; b < 8; ++b) {
                             if (b < NBR && b < nb) {
                                 uint32_t bnd = wave_max_u32(cw[b]) + (uint32_t)slack;
-                                if ((int)bnd >= need_j && bnd > 0u) { // (wave-uniform)
+                                if ((int)bnd >= need_cnt && bnd > 0u) { // (wave-uniform)
                                     int M = -1, best = -1;
 #pragma unroll
                                     for (int w = 0; w < 4; ++w) {
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                         cnt[NACC - 1] = 0;
                     }
                     any_match = __any(maxcnt > 0u);
-                    may_pass = __any((int)maxcnt >= need_j);
+                    may_pass = __any((int)maxcnt >= need_cnt);
                 } else if (prefilter_on) {
                     const uint32_t w0 = s_wstart[j];
                     const int nw = (int)(s_wstart[j + 1] - w0);
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                     }
                     const int bound = (int)wave_max_u32(maxcnt);             // >= best local-alignment score
                     any_match = bound > 0;
-                    may_pass = (mcap + bound) / 2 >= thr;
+                    may_pass = (mcap + bound) / 2 >= thr && bound >= thr;        // (bound = the largest match count of a diagonal)
                 }
                 // (wave-uniform flags: kept in SGPRs -- as lane values each adapter paid two 64-bit VALU shifts and four ors)
                 m_any |= (uint64_t)(uint32_t)uni((int)any_match) << j;

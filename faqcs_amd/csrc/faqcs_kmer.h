@@ -112,9 +112,13 @@ __device__ __forceinline__ uint64_t kmer_mix(uint64_t x)
 // the partition of occurrences into keys), and its TOP bits select the bucket, the partition and the table slot.
 __device__ __forceinline__ uint64_t kmer_mix62(uint64_t x)
 {
-    x ^= x >> 31; x = (x * 0xff51afd7ed558ccdull) & KG_M62;
-    x ^= x >> 29; x = (x * 0xc4ceb9fe1a85ec53ull) & KG_M62;
-    x ^= x >> 32;
+    // ONE multiplication: only the TOP bits of h are used as an index (bucket 8, partition 16, table slot <= 32, LDS slot 12 bits of
+    // the remainder), and the top bits of a product depend on every bit below them; the first xor-shift folds the high plane into the
+    // low one so that keys that differ in high bits only still move the low bits.  Bucket / partition / cell occupancies of random,
+    // AT-rich and repeat-rich k-mer sets are Poisson to within 5 % (profiles/microbench/kmer_mix_check.py), like the two-round form's;
+    // a 62-bit multiplication is 3-4 quarter-rate instructions on gfx950, a sixth of the extraction's issue cycles.
+    x ^= x >> 31; x = (x * 0x9E3779B97F4A7C15ull) & KG_M62;
+    x ^= x >> 29;
     return x;
 }
 // owner rank of a key: the HIGH half of the mix (the slot index uses the low bits), multiply-shift into [0, world)
@@ -156,6 +160,40 @@ __device__ __forceinline__ bool kmer_chunk_key(const uint32_t b, const int lane,
     const uint32_t r0 = __brev(~w0 & kmask) >> (32 - k), r1 = __brev(w1) >> (32 - k);
     const uint64_t fwd = ((uint64_t)w1 << 32) | w0, rc = ((uint64_t)r1 << 32) | r0;
     key = fwd < rc ? fwd : rc;
+    return wv == kmask; // k valid bases ending here (word_len >= k, trim.cpp:924)
+}
+
+// The same with 32-bit funnel shifts (kmer_group_extract).  The window of lane l starts at bit s = 65 + l - k of the 128-bit string
+// prev : cur, i.e. in dword d = s >> 5 (1, 2 or 3) at bit s & 31: which two of the four dwords a lane needs depends on the lane
+// alone, so the selection masks are made once (KmerWin) and a plane costs 4 v_cndmask + v_alignbit + v_and instead of three
+// 64-bit variable shifts (quarter rate on gfx950).
+struct KmerWin { uint32_t sh; bool d1, d2; };
+__device__ __forceinline__ KmerWin kmer_win(const int lane, const uint32_t k)
+{
+    const uint32_t s = 65u + (uint32_t)lane - k;
+    return KmerWin{s & 31u, (s >> 5) == 1u, (s >> 5) == 2u};
+}
+__device__ __forceinline__ uint32_t window_bits32(const uint64_t cur, const uint64_t prev, const KmerWin w, const uint32_t kmask)
+{
+    const uint32_t d1 = (uint32_t)(prev >> 32), d2 = (uint32_t)cur, d3 = (uint32_t)(cur >> 32);
+    const uint32_t lo = w.d1 ? d1 : (w.d2 ? d2 : d3), hi = w.d1 ? d2 : (w.d2 ? d3 : 0u);
+    return __builtin_amdgcn_alignbit(hi, lo, w.sh) & kmask;
+}
+__device__ __forceinline__ bool kmer_chunk_key32(const uint32_t b, const KmerWin w, const uint32_t k, KmerPlanes &S, uint64_t &key)
+{
+    const uint32_t l = b | 0x20u;
+    const bool isA = l == 'a', isT = l == 't', isC = l == 'c', isG = l == 'g';
+    const uint64_t cv = __ballot(isA | isT | isC | isG);
+    const uint64_t c0 = __ballot(isT | isG); // codes A=0 T=1 C=2 G=3 (FaQCs.h:35-42)
+    const uint64_t c1 = __ballot(isC | isG);
+    const uint32_t kmask = (uint32_t)((1ull << k) - 1ull);
+    const uint32_t wv = window_bits32(cv, S.pv, w, kmask);
+    const uint32_t w0 = window_bits32(c0, S.p0, w, kmask);
+    const uint32_t w1 = window_bits32(c1, S.p1, w, kmask);
+    S.pv = cv; S.p0 = c0; S.p1 = c1;
+    const uint32_t r0 = __brev(~w0 & kmask) >> (32 - k), r1 = __brev(w1) >> (32 - k);
+    const bool fwd_less = w1 < r1 || (w1 == r1 && w0 < r0);
+    key = fwd_less ? (((uint64_t)w1 << 32) | w0) : (((uint64_t)r1 << 32) | r0);
     return wv == kmask; // k valid bases ending here (word_len >= k, trim.cpp:924)
 }
 

@@ -200,27 +200,32 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_extract(
     Hdr hc = load_hdr(r_cur), hn = load_hdr(r_nxt);
     int c = hc.a >> 6, c_end = hc.n ? (hc.a + hc.n + 63) >> 6 : c;
     uint32_t nb[4], nq[4] = {0u, 0u, 0u, 0u}; // the next piece's bytes (and qualities, --replace_to_N_q)
-    auto load_piece = [&]() {
+    const uint32_t safe_o = off[r_begin];     // (a byte of the arena that is there whatever the cursor says)
+    auto load_piece = [&]() { // no branches: the index is clamped into the kept window (or onto safe_o), what lies outside is zeroed
+        const bool any = hc.n > 0 && c < c_end;
+        const int lo_p = any ? hc.a : 0, hi_p = any ? hc.a + hc.n - 1 : 0;
+        const size_t ob = any ? (size_t)hc.o : (size_t)safe_o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = (c + j) * 64 + lane;
-            const bool in = c + j < c_end && p >= hc.a && p < hc.a + hc.n;
-            nb[j] = in ? seq[(size_t)hc.o + p] : 0u;
-            if (g2n) nq[j] = in ? qual[(size_t)hc.o + p] : 0u;
+            const bool in = any && c + j < c_end && p >= lo_p && p <= hi_p;
+            const int pc = p < lo_p ? lo_p : (p > hi_p ? hi_p : p);
+            const uint32_t v = seq[ob + pc];
+            nb[j] = in ? v : 0u;
+            if (g2n) { const uint32_t qv = qual[ob + pc]; nq[j] = in ? qv : 0u; }
         }
     };
     load_piece();
     uint32_t bb[4], bq[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { bb[j] = nb[j]; bq[j] = nq[j]; }
-    int pn = c_end - c < 4 ? c_end - c : 4; // chunks of the piece in bb
-    bool first = true;                      // ... which is the first piece of its read
+    bool first = true; // the piece in bb is the first of its read
     KmerPlanes pl{0, 0, 0};
+    const KmerWin win = kmer_win(lane, k);
     uint32_t my_total = 0, phase = 0;
 #pragma unroll 1
     for (;;) {
         // advance the cursor past the piece in bb and fetch the piece after it
-        const int pn_now = pn;
         const bool first_now = first;
         c += 4; first = false;
         if (c >= c_end && r_cur < r_end) {
@@ -228,23 +233,22 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_extract(
             hn = load_hdr(r_nxt);
             c = hc.a >> 6; c_end = hc.n ? (hc.a + hc.n + 63) >> 6 : c; first = true;
         }
-        pn = c_end - c < 4 ? c_end - c : 4;
         load_piece();
         if (first_now) pl = KmerPlanes{0, 0, 0};
         u64 h[4];
         uint32_t pend = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j < pn_now) { // (wave-uniform)
-                uint32_t b = bb[j];
-                if (g2n && b == 'G') { // G -> N precedes k-mer counting (trim.cpp:390-403)
-                    int qv = (int)(int8_t)bq[j] - P.in_off;
-                    qv = qv < 0 ? 0 : qv;
-                    if (qv < (int)P.replace_q) b = 'N';
-                }
-                uint64_t key;
-                if (kmer_chunk_key(b, lane, k, pl, key)) { h[j] = kmer_mix62(key); pend |= 1u << j; }
+        for (int j = 0; j < 4; ++j) { // (a chunk past the piece's last one is all zero bytes: no key; the planes restart with the next read)
+            uint32_t b = bb[j];
+            if (g2n && b == 'G') { // G -> N precedes k-mer counting (trim.cpp:390-403)
+                int qv = (int)(int8_t)bq[j] - P.in_off;
+                qv = qv < 0 ? 0 : qv;
+                if (qv < (int)P.replace_q) b = 'N';
             }
+            uint64_t key;
+            const bool ok = kmer_chunk_key32(b, win, k, pl, key);
+            h[j] = kmer_mix62(key);
+            pend |= ok ? 1u << j : 0u;
         }
         my_total += (uint32_t)__popc(pend);
         // block-wide rounds: tickets, then the owners of the buckets write the full granules
