@@ -93,7 +93,9 @@ typedef struct faqcs_params {
     uint32_t max_read_length;             /* capacity R of the per-position matrices (<= FAQCS_MAX_READ_LENGTH); no read of a batch may be longer */
     uint32_t n_adapters;                  /* 0 == !(filter_adapter || filter_phiX) */
     const char *const *adapter_seq;       /* n_adapters NUL-terminated IUPAC strings (Options::adapter[j].second) */
-    uint64_t kmer_table_slots;            /* device hash-table capacity (0 = library default) */
+    uint64_t kmer_table_slots;            /* device hash-table capacity (0 = library default 2^28; rounded up to a power of two in [2^22, 2^32]:
+                                             the table is cut into 65 536 slices, one per key partition, and a slice that fills up raises
+                                             FAQCS_E_KMER_FULL even if others have room -- size it for <= 0.7 x slots distinct k-mers) */
 } faqcs_params;
 
 /* One submission: reads packed back to back in two byte arenas (structure of arrays).
@@ -229,8 +231,9 @@ int  faqcs_counters_import(faqcs_ctx *ctx, const void *d_src, uint64_t n_u64);
 int  faqcs_finish(faqcs_ctx *ctx, uint64_t *counters, uint64_t n_u64);
 int  faqcs_reset_counters(faqcs_ctx *ctx);
 
-/* k-mer rarefaction (trim.cpp:157-185, FaQCs.cpp:518-537).  Points are appended at segment ends during
- * submit; after faqcs_sync():  */
+/* k-mer rarefaction (trim.cpp:157-185, FaQCs.cpp:518-537).  The k-mers of a submission are extracted when it is submitted and reach
+ * the table in groups (combine-before-insert); faqcs_sync() -- which the calls below make -- completes the open
+ * group.  Points are appended at segment ends during submit; their (distinct, total) are filled in after faqcs_sync():  */
 int  faqcs_kmer_points(faqcs_ctx *ctx, faqcs_rarefaction *out, uint32_t cap, uint32_t *n_points);
 /* (count, number of keys with that count) pairs, ascending count -- PlotInfo::kmer_frequency_histogram */
 int  faqcs_kmer_histogram(faqcs_ctx *ctx, uint64_t *count, uint64_t *nkeys, uint64_t cap, uint64_t *n_pairs);
