@@ -531,7 +531,7 @@ static int kg_flush(faqcs_ctx *c, bool timed = false)
 // the k-mers of reads [r0, r1) -- one epoch -- join the open group.  host_off (may be null): the host copy of the offsets, for a
 // tight item bound (an occurrence starts at a distinct base); otherwise per_read items bound every read.
 static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, const uint32_t *d_off, uint32_t r0, uint32_t r1,
-                      const faqcs_read_result *d_res, uint64_t per_read, const uint32_t *host_off, uint32_t epoch)
+                      const faqcs_read_result *d_res, uint64_t per_read, const uint32_t *host_off, uint32_t epoch, uint32_t max_len)
 {
     faqcs_ctx::KmerGroup &g = c->kg;
     if (int rc = kg_init(c)) return rc;
@@ -567,7 +567,7 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
         const uint32_t grid = faqcs_kmer_group_grid(take, c->n_cu);
         if (g.run_epoch.empty()) g.epoch_base = epoch;
         HIPCHK(faqcs_launch_kmer_group_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
-                                               r0, r0 + take, d_res, c->n_cu, c->compute));
+                                               r0, r0 + take, d_res, max_len, c->n_cu, c->compute));
         g.run_epoch.push_back(epoch - g.epoch_base);
         g.bound_items += bound;
         for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += bound / ((uint64_t)grid * KG_FAN) + bound / ((uint64_t)grid * KG_FAN * 8) + 64;
@@ -750,7 +750,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         if (run_end > run_begin) {
             if (direct) HIPCHK(faqcs_launch_kmer(c->dp, p.kmer, c->kt, d_seq, d_qual, d_off, run_begin, run_end, d_res, c->n_cu, c->compute));
             // the run's epoch: the index of the next sampling point (the first one that will include these occurrences)
-            else if (int rc = kg_add_run(c, d_seq, d_qual, d_off, run_begin, run_end, d_res, per_read, host_off, (uint32_t)c->points.size())) return rc;
+            else if (int rc = kg_add_run(c, d_seq, d_qual, d_off, run_begin, run_end, d_res, per_read, host_off, (uint32_t)c->points.size(), max_len)) return rc;
         }
         run_begin = run_end;
         return 0;

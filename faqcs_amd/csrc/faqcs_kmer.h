@@ -93,7 +93,7 @@ hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *d
 // bounds[run]), then per group: level-2 scatter, combine + insert, cursor reset
 hipError_t faqcs_launch_kmer_group_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
                                            uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
-                                           uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st);
+                                           uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, uint32_t max_len, int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_group_flush(const KmerGroupDev &G, const KmerTable &T, hipStream_t st);
 uint32_t faqcs_kmer_group_grid(uint32_t n_reads, int n_cu);
 uint32_t faqcs_kmer_group_items_grid(unsigned long long n_items, int n_cu);

@@ -22,6 +22,8 @@
 // through kmer_insert_atomic, the per-occurrence path, so exactness never depends on a capacity.
 #include "faqcs_kmer.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef unsigned long long u64;
@@ -96,36 +98,42 @@ template <int NW> struct Staging {
         if (pos < (uint32_t)KG_STAGE) { items[b * KG_STAGE + pos] = item; return true; }
         return false;
     }
-    // write(b, pos, item, take): lanes < take store their item at position pos + lane of the block's sub-region of bucket b;
-    // returns false (wave-uniform) when the sub-region is full -- the items then take the slow path
+    // Two buckets per step, one per half wave: lane l of a half holds item l of its bucket's granule, so a step's instructions
+    // move 64 items.  write(b, pos, item): this lane's item goes to position pos of the block's sub-region of bucket b;
+    // slow(b, item): the sub-region is full, the item takes the per-occurrence path.  A bucket that still holds a granule after its
+    // step (64 staged items, or the final drain's remainder) stays in the mask for another one.
     template <class Write, class Slow>
     __device__ __forceinline__ void drain(const int wave, const int lane, const bool final, const uint32_t cap, Write &&write, Slow &&slow) const
     {
         const uint32_t n_l = lane < BPW ? cnt[wave * BPW + lane] : 0u;
         uint64_t m = __ballot(final ? n_l > 0u : n_l >= (uint32_t)KG_GRAN);
+        const int half = lane >> 5, l32 = lane & 31;
 #pragma unroll 1
         while (m) {
-            const int i = uni(__ffsll((long long)m) - 1);
-            m &= m - 1;
-            const int b = wave * BPW + i;
-            uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_l, i);
+            const int i0 = uni(__ffsll((long long)m) - 1);
+            const uint64_t m1 = m & (m - 1);
+            const int i1 = m1 ? uni(__ffsll((long long)m1) - 1) : -1;
+            const int bsel = half ? i1 : i0;
+            const bool act = bsel >= 0;
+            const uint32_t b = (uint32_t)(wave * BPW + (act ? bsel : i0));
+            uint32_t n = cnt[b];
             n = n < (uint32_t)KG_STAGE ? n : (uint32_t)KG_STAGE;
-            uint32_t pos = uniu(cur[b]);
-            uint32_t done = 0;
-#pragma unroll 1
-            while (n - done >= (uint32_t)KG_GRAN || (final && n > done)) {
-                const uint32_t take = n - done < (uint32_t)KG_GRAN ? n - done : (uint32_t)KG_GRAN;
-                const u64 it = (uint32_t)lane < take ? items[b * KG_STAGE + done + lane] : 0ull;
-                if (pos + take <= cap) { write((uint32_t)b, pos, it, take); pos += take; }
-                else if ((uint32_t)lane < take) slow((uint32_t)b, it);
-                done += take;
-            }
-            const uint32_t left = n - done;
-            if (left) { // (one wave: the reads of an instruction complete before the writes of the next)
-                const u64 it = (uint32_t)lane < left ? items[b * KG_STAGE + done + lane] : 0ull;
-                if ((uint32_t)lane < left) items[b * KG_STAGE + lane] = it;
-            }
-            if (lane == 0) { cnt[b] = left; cur[b] = pos; }
+            const uint32_t pos = cur[b];
+            const uint32_t take = n < (uint32_t)KG_GRAN ? n : (uint32_t)KG_GRAN;
+            const bool mine = act && (uint32_t)l32 < take;
+            const u64 it = items[b * KG_STAGE + (uint32_t)l32];
+            const bool fits = pos + take <= cap;
+            if (mine) { if (fits) write(b, pos + (uint32_t)l32, it); else slow(b, it); }
+            const uint32_t left = n - take;
+            const bool mv = act && (uint32_t)l32 < left;
+            const u64 nx = items[b * KG_STAGE + (uint32_t)KG_GRAN + (uint32_t)l32]; // (one wave: the reads of an instruction complete before the writes of the next)
+            if (mv) items[b * KG_STAGE + (uint32_t)l32] = nx;
+            if (act && l32 == 0) { cnt[b] = left; cur[b] = fits ? pos + take : pos; }
+            const bool again = act && l32 == 0 && (left >= (uint32_t)KG_GRAN || (final && left > 0u));
+            const uint64_t keep = __ballot(again); // bit 0: bucket i0 stays, bit 32: bucket i1 stays
+            m = m1 ? (m1 & (m1 - 1)) : 0ull;
+            if (keep & 1ull) m |= 1ull << i0;
+            if (keep >> 32) m |= 1ull << i1;
         }
     }
     // OR of `bits` over the block; one barrier.  (s_barrier behind a wait for the wave's LDS operations only: outstanding
@@ -144,6 +152,13 @@ template <int NW> struct Staging {
     }
 };
 constexpr size_t KG_STAGE_BYTES = (size_t)KG_FAN * KG_STAGE * 8 + (size_t)KG_FAN * 8 + 16;
+
+// a wave's LDS operations execute in order; this only stops the compiler from moving them across the point
+__device__ __forceinline__ void lds_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // keeps the registers of a prefetch "used" here: the compiler's wait for those loads lands at this point and not at their
 // first arithmetic use
@@ -172,9 +187,7 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_extract(
     const uint32_t n_waves = gridDim.x * NW;
     const bool g2n = !P.qc_only && P.replace_q > 0;
     const u64 tag = (u64)run << 54;
-    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it, const uint32_t take) {
-        if ((uint32_t)lane < take) G.l1[((size_t)b * KG_FAN + sub) * G.cap1 + pos + lane] = it;
-    };
+    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it) { G.l1[((size_t)b * KG_FAN + sub) * G.cap1 + pos] = it; };
     auto slow = [&](const uint32_t b, const u64 it) {
         kmer_insert_atomic(T, ((u64)b << 54) | (it & KG_M54), epoch, 1u, G.first_hist, G.n_epochs);
     };
@@ -287,6 +300,169 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_extract(
     }
 }
 
+// ---- level 1 for reads of up to 256 bases: a lane owns FOUR consecutive positions --------------------------------------------
+// kmer_group_extract spends a wave instruction on 64 positions, of which a 250-base read fills 44 on average, and builds every
+// lane's window out of wave-wide ballots (2.8 vector + 2.3 scalar instructions per occurrence).  Here a lane loads the dword of
+// positions 4 l ... 4 l + 3 -- the whole read is ONE load instruction --, classifies its four bases (2-bit code: A 0, C 1, T 2, G 3,
+// complement = code ^ 2; any injective encoding gives the same classes, trim.cpp:904-917) and gets its eight predecessors'
+// codes through the wave's LDS exchange row: nine dwords, no ballot.  The four k-mers that end in the lane's positions are then
+// shifts of one 72-bit window; the reverse complement is the window with its 2-bit groups reversed, made once per lane.
+template <int NW, bool K31>
+__global__ __launch_bounds__(NW * 64) void kmer_group_extract4(
+    const DevParams P, const uint32_t k_arg, const KmerGroupDev G, const KmerTable T, const uint32_t run, const uint32_t rot, const uint32_t epoch,
+    const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off, const uint32_t r_begin,
+    const uint32_t r_end, const uint2 *__restrict__ results)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(lds + KG_FAN * KG_STAGE);
+    const Staging<NW> S{lds, w32, w32 + KG_FAN, w32 + 2 * KG_FAN};
+    uint32_t *s_total = w32 + 2 * KG_FAN + 3;
+    const uint32_t k = K31 ? 31u : k_arg; // (the reference's command line cannot set another k, SURVEY Q19: its shifts are compile-time constants)
+    uint32_t *s_xch = w32 + 2 * KG_FAN + 4;                          // [NW][72]: 8 zero dwords, then the wave's 64 packed lanes
+    uint8_t *s_cls = reinterpret_cast<uint8_t *>(s_xch + NW * 72);   // [256] code | valid << 2 of every byte value
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const uint32_t sub = (blockIdx.x + rot) % KG_FAN;
+    for (int i = tid; i < KG_FAN; i += NW * 64) { S.cnt[i] = 0u; S.cur[i] = G.cur1[sub * KG_FAN + i]; }
+    if (tid < 4) S.flag[tid] = 0u;
+    for (int i = tid; i < NW * 72; i += NW * 64) s_xch[i] = 0u;
+    for (int i = tid; i < 256; i += NW * 64) {
+        const uint32_t l = (uint32_t)i | 0x20u;
+        s_cls[i] = (uint8_t)(l == 'a' ? 4u : l == 'c' ? 5u : l == 't' ? 6u : l == 'g' ? 7u : 0u);
+    }
+    const uint32_t n_waves = gridDim.x * NW;
+    const bool g2n = !P.qc_only && P.replace_q > 0;
+    const u64 tag = (u64)run << 54;
+    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it) { G.l1[((size_t)b * KG_FAN + sub) * G.cap1 + pos] = it; };
+    auto slow = [&](const uint32_t b, const u64 it) {
+        kmer_insert_atomic(T, ((u64)b << 54) | (it & KG_M54), epoch, 1u, G.first_hist, G.n_epochs);
+    };
+    __syncthreads();
+    struct Hdr { uint32_t o; int a, n; };
+    auto load_hdr = [&](const uint32_t r) -> Hdr {
+        Hdr h{0u, 0, 0};
+        if (r < r_end) {
+            h.o = off[r];
+            h.n = (int)(off[r + 1] - h.o);
+            if (!P.qc_only) { // trimmed read of a valid record (trim.cpp:545-547); raw read under --qc_only (:260-262)
+                const uint2 rs = results[r];
+                h.a = (int)(rs.x & 0xffffu);
+                h.n = (rs.y & FAQCS_F_VALID) ? (int)(rs.x >> 16) : 0;
+            }
+            if (h.n < (int)k) h.n = 0;
+        }
+        return h;
+    };
+    struct __attribute__((packed, aligned(1))) U32u { uint32_t w; };
+    const uint32_t safe_o = off[r_begin];
+    uint32_t r_cur = r_begin + blockIdx.x * NW + wave, r_nxt = r_cur + n_waves;
+    Hdr hc = load_hdr(r_cur), hn = load_hdr(r_nxt);
+    uint32_t nw = 0, nqw = 0; // the next read's four bases (qualities) of this lane
+    auto load_bytes = [&]() { // (positions past the kept window are not needed: nothing behind a short last read is touched)
+        const bool need = hc.n > 0 && 4 * lane < hc.a + hc.n;
+        const size_t at = need ? (size_t)hc.o + 4u * (uint32_t)lane : (size_t)safe_o;
+        const uint32_t v = reinterpret_cast<const U32u *>(seq + at)->w;
+        nw = need ? v : 0u;
+        if (g2n) { const uint32_t qv = reinterpret_cast<const U32u *>(qual + at)->w; nqw = need ? qv : 0u; }
+    };
+    load_bytes();
+    uint32_t bw = nw, bqw = nqw;
+    Hdr hb = hc; // the read whose bytes are in bw
+    uint32_t my_total = 0, phase = 0;
+    uint32_t *xrow = s_xch + wave * 72;
+    const uint32_t kmask = (uint32_t)((1ull << k) - 1ull);
+    const u64 kmask2 = (1ull << (2 * k)) - 1ull;
+    const int sh0 = 2 * (33 - (int)k); // bit shift of the window for the k-mer that ends in the lane's first position
+#pragma unroll 1
+    for (;;) {
+        // advance the cursor and fetch ahead (one read per round)
+        if (r_cur < r_end) { hc = hn; r_cur = r_nxt; r_nxt += n_waves; hn = load_hdr(r_nxt); }
+        load_bytes();
+        // ---- this lane's four bases -> 2-bit codes + "an ACGT inside the kept window" flags ----
+        uint32_t t = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t b = (bw >> (8 * j)) & 0xffu;
+            uint32_t cls = s_cls[b];
+            if (g2n && b == 'G') { // G -> N precedes k-mer counting (trim.cpp:390-403)
+                int qv = (int)(int8_t)((bqw >> (8 * j)) & 0xffu) - P.in_off;
+                qv = qv < 0 ? 0 : qv;
+                if (qv < (int)P.replace_q) cls = 0u;
+            }
+            const int p = 4 * lane + j;
+            const bool inw = p >= hb.a && p < hb.a + hb.n;
+            t |= (cls & 3u) << (2 * j);
+            t |= (inw ? (cls >> 2) : 0u) << (8 + j);
+        }
+        xrow[8 + lane] = t;
+        lds_wave_sync();
+        uint32_t x[9]; // lanes l - 8 ... l
+#pragma unroll
+        for (int i = 0; i < 9; ++i) x[i] = xrow[lane + i];
+        lds_wave_sync();
+        // window of the 36 positions 4 l - 32 ... 4 l + 3: codes in wlo (32 positions) : whi (4 positions), flags in vw
+        u64 wlo = 0, vw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wlo |= (u64)(x[i] & 0xffu) << (8 * i); vw |= (u64)((x[i] >> 8) & 0xfu) << (4 * i); }
+        const u64 whi = x[8] & 0xffu;
+        vw |= (u64)((x[8] >> 8) & 0xfu) << 32;
+        // the window with its 2-bit groups in reverse order (36 groups: group m -> group 35 - m), complemented: rev : rlo
+        auto rev2 = [](u64 v) -> u64 { // reverses the 32 two-bit groups of a 64-bit word
+            v = ((u64)__brev((uint32_t)v) << 32) | (u64)__brev((uint32_t)(v >> 32));
+            return ((v >> 1) & 0x5555555555555555ull) | ((v & 0x5555555555555555ull) << 1);
+        };
+        // R = rev2 of the 72-bit window = rev2(whi, 4 groups) at the bottom, rev2(wlo) above it
+        const u64 r_hi4 = rev2(whi) >> 56;       // groups 35 ... 32 -> bits 0 ... 7
+        const u64 r_lo = rev2(wlo);              // group m (< 32) -> group 31 - m
+        const u64 Rlo = (r_lo << 8) | r_hi4;     // bits 0 ... 63 of R
+        const u64 Rhi = r_lo >> 56;              // bits 64 ... 71
+        u64 h[4];
+        uint32_t pend = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // the k-mer that ends at window group 32 + j: groups 33 + j - k ... 32 + j
+            const int s = sh0 + 2 * j;                                   // first bit of the k-mer in the window (wave-uniform)
+            const u64 fwd = (s < 64 ? ((wlo >> s) | (s ? whi << (64 - s) : 0ull)) : (whi >> (s - 64))) & kmask2;
+            // in R the k-mer's groups are 35 - (32 + j) = 3 - j ... 3 - j + k - 1
+            const int rs = 2 * (3 - j);
+            const u64 rc = (((Rlo >> rs) | (rs ? Rhi << (64 - rs) : 0ull)) & kmask2) ^ (0xAAAAAAAAAAAAAAAAull & kmask2);
+            const int vs = 33 + j - (int)k;
+            const bool ok = ((uint32_t)(vw >> vs) & kmask) == kmask; // k valid bases ending here (word_len >= k, trim.cpp:924)
+            h[j] = kmer_mix62(fwd < rc ? fwd : rc);
+            pend |= ok ? 1u << j : 0u;
+        }
+        my_total += (uint32_t)__popc(pend);
+        bool more;
+#pragma unroll 1
+        for (bool fetched = false;;) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((pend >> j) & 1u)
+                    if (S.put((uint32_t)(h[j] >> 54), tag | (h[j] & KG_M54))) pend &= ~(1u << j);
+            __syncthreads();
+            if (!fetched) { // the prefetched read: its loads are a round's arithmetic old, the stores of the last drain older
+                asm volatile("" ::"v"(nw), "v"(nqw));
+                bw = nw; bqw = nqw; hb = hc;
+                fetched = true;
+            }
+            S.drain(wave, lane, false, G.cap1, write, slow);
+            const uint32_t f = S.block_or((pend ? 1u : 0u) | (r_cur < r_end ? 2u : 0u), phase, tid);
+            more = (f & 2u) != 0u;
+            if (!(f & 1u)) break;
+        }
+        if (!more) break;
+    }
+    S.drain(wave, lane, true, G.cap1, write, slow);
+    __syncthreads();
+    for (int i = tid; i < KG_FAN; i += NW * 64) G.cur1[sub * KG_FAN + i] = S.cur[i];
+    const uint32_t wt = (uint32_t)wave_sum_i32((int)my_total);
+    if (lane == 0 && wt) atomicAdd(s_total, wt);
+    __syncthreads();
+    if (tid == 0 && s_total[0]) {
+        hist_add(G.tot_by_epoch, epoch, G.n_epochs, (long long)s_total[0]);
+        atomicAdd(&T.stats[1], (u64)s_total[0]);
+    }
+}
+
 // ---- level 1 from (key, epoch) pairs: the owner side of the multi-GPU exchange (faqcs_kmer_insert_device) ---------------------
 // The pairs other ranks extracted for the keys this rank owns join the same group buffers; a pair's epoch travels in the item's
 // run field (the group's run -> epoch table is the identity in this mode: at most KG_MAX_RUNS epochs).
@@ -304,9 +480,7 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_items(const KmerGroupDev G
     for (int i = tid; i < KG_EPOCH_SPAN; i += NW * 64) s_tot[i] = 0u;
     if (tid < 3) S.flag[tid] = 0u;
     __syncthreads();
-    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it, const uint32_t take) {
-        if ((uint32_t)lane < take) G.l1[((size_t)b * KG_FAN + sub) * G.cap1 + pos + lane] = it;
-    };
+    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it) { G.l1[((size_t)b * KG_FAN + sub) * G.cap1 + pos] = it; };
     auto slow = [&](const uint32_t b, const u64 it) {
         kmer_insert_atomic(T, ((u64)b << 54) | (it & KG_M54), (uint32_t)(it >> 54), 1u, G.first_hist, G.n_epochs);
     };
@@ -361,9 +535,7 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_split(const KmerGroupDev G
     if (tid < 3) S.flag[tid] = 0u;
     for (uint32_t j = tid; j < G.n_runs; j += NW * 64) s_er[j] = G.run_epoch[j];
     __syncthreads();
-    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it, const uint32_t take) {
-        if ((uint32_t)lane < take) G.l2[(((size_t)b1 * KG_FAN + b) * G.split + part) * G.cap2 + pos + lane] = it;
-    };
+    auto write = [&](const uint32_t b, const uint32_t pos, const u64 it) { G.l2[(((size_t)b1 * KG_FAN + b) * G.split + part) * G.cap2 + pos] = it; };
     auto slow = [&](const uint32_t b, const u64 item) {
         kmer_insert_atomic(T, (((u64)b1 * KG_FAN + b) << 46) | (item & KG_M46), G.epoch_base + (uint32_t)(item >> 46), 1u, G.first_hist, G.n_epochs);
     };
@@ -593,10 +765,20 @@ uint32_t faqcs_kmer_group_grid(uint32_t n_reads, int n_cu)
 
 hipError_t faqcs_launch_kmer_group_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
                                            uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
-                                           uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st)
+                                           uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, uint32_t max_len, int n_cu, hipStream_t st)
 {
-    if (r_end > r_begin)
-        hipLaunchKernelGGL((kmer_group_extract<KG_NW>), dim3(faqcs_kmer_group_grid(r_end - r_begin, n_cu)), dim3(KG_NW * 64), KG_STAGE_BYTES + 16, st,
+    if (r_end <= r_begin) return hipSuccess;
+    const dim3 grid(faqcs_kmer_group_grid(r_end - r_begin, n_cu)), block(KG_NW * 64);
+    static const bool chunked = getenv("FAQCS_KMER_EXTRACT_CHUNKED") && atoi(getenv("FAQCS_KMER_EXTRACT_CHUNKED")) != 0; // (A/B switch)
+    constexpr size_t LDS4 = KG_STAGE_BYTES + 16 + (size_t)KG_NW * 72 * 4 + 256;
+    if (max_len <= 256 && !chunked && k == 31) // a lane owns four positions: the whole read in one round
+        hipLaunchKernelGGL((kmer_group_extract4<KG_NW, true>), grid, block, LDS4, st,
+                           P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
+    else if (max_len <= 256 && !chunked)
+        hipLaunchKernelGGL((kmer_group_extract4<KG_NW, false>), grid, block, LDS4, st,
+                           P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
+    else
+        hipLaunchKernelGGL((kmer_group_extract<KG_NW>), grid, block, KG_STAGE_BYTES + 16, st,
                            P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
     return hipGetLastError();
 }

@@ -339,11 +339,12 @@ def test_golden_cases_on_gpu(name, fixture_cache, tmp_path):
 
 
 def test_kmer_matches_oracle():
-    rng = np.random.Generator(np.random.PCG64(99))
+    rng = np.random.Generator(np.random.PCG64(99 + SEED))
     import make_fixtures
 
     for args in (["--kmer_rarefaction", "--split_size", "300"], ["--kmer_rarefaction", "--split_size", "400", "--qc_only", "--subset", "2"],
-                 ["--kmer_rarefaction", "--split_size", "250", "-m", "5", "--replace_to_N_q", "20"]):
+                 ["--kmer_rarefaction", "--split_size", "250", "-m", "5", "--replace_to_N_q", "20"],
+                 ["--kmer_rarefaction", "--split_size", "150", "-m", "17", "--subset", "30"], ["--kmer_rarefaction", "--split_size", "500", "-m", "2"]):
         opt = parse_args(["-u", "x", "-d", "y"] + args)
         reads = random_batch(rng, 2500, 150, "adv")
         hip, ora = compare_engines(opt, reads, seg_size=333)
@@ -352,6 +353,65 @@ def test_kmer_matches_oracle():
         assert (hip.kmer_points() == ora.kmer_points()).all()
         h1, h2 = hip.kmer_histogram(), ora.kmer_histogram()
         assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
+
+
+@pytest.mark.parametrize("group_items,maxlen", [(1 << 14, 150), (1 << 16, 250), (1 << 20, 250), (1 << 16, 600)], ids=["g14", "g16", "g20", "g16_long"])
+def test_kmer_groups_of_every_size_match_oracle(group_items, maxlen, monkeypatch):
+    """The combine-before-insert path with groups far smaller than a submission (FAQCS_KMER_GROUP_ITEMS): runs are cut into many
+    launches, groups are flushed in the middle of a segment, sub-regions overflow into the per-occurrence path -- and every point and
+    every histogram bin still equals the oracle's (trim.cpp:157-185,887-931; FaQCs.cpp:518-521).  maxlen 600: the chunked extraction
+    kernel (reads past 256 bases); the others: four positions per lane."""
+    monkeypatch.setenv("FAQCS_KMER_GROUP_ITEMS", str(group_items))
+    rng = np.random.Generator(np.random.PCG64(4321 + SEED))
+    for args in (["--kmer_rarefaction", "--split_size", "700", "--subset", "6"], ["--kmer_rarefaction", "--split_size", "450", "-m", "11", "--qc_only"]):
+        opt = parse_args(["-u", "x", "-d", "y"] + args)
+        reads = random_batch(rng, 6000, maxlen, "adv")
+        if maxlen > 256:
+            hip, ora = compare_engines(opt, reads, R=1024, seg_size=977)
+        else:
+            hip, ora = compare_engines(opt, reads, seg_size=977)
+        hip.kmer_end_table()
+        ora.kmer_end_table()
+        assert len(ora.kmer_points()) > 0 and (hip.kmer_points() == ora.kmer_points()).all()
+        h1, h2 = hip.kmer_histogram(), ora.kmer_histogram()
+        assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
+
+
+def test_kmer_group_path_equals_the_per_occurrence_path_at_scale(monkeypatch):
+    """3 M genome-sampled reads of 250 bases (0.5 G occurrences, several groups, 40x coverage of a 12 Mbp genome): the combine-before-insert
+    path and round 3's one-atomic-per-occurrence path (FAQCS_KMER_DIRECT=1, kmer_count) are two implementations of update_kmer()
+    (trim.cpp:887-931) that share no insert code -- the sampling points and the whole count histogram must be identical."""
+    import ctypes as C
+
+    import torch
+
+    from faqcs_amd.engine import HipEngine, _check
+
+    n, L = 3_000_000, 250
+    opt = parse_args(["-u", "x", "-d", "y", "--ascii", "33", "--kmer_rarefaction", "--split_size", "200000", "--subset", "50"])
+    dev = torch.device("cuda:0")
+    seq = torch.empty(n * L + 128, dtype=torch.uint8, device=dev)
+    qual = torch.empty(n * L + 128, dtype=torch.uint8, device=dev)
+    off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    res = torch.empty((n, 4), dtype=torch.int16, device=dev)
+    results = []
+    for direct in ("0", "1"):
+        monkeypatch.setenv("FAQCS_KMER_DIRECT", direct)
+        eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << 29)
+        _check(eng.lib, eng.lib.faqcs_synth_fill_genome(0, seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, L, 20260101 + SEED, 0, 12_000_000))
+        seg = np.arange(0, n + 32768, 32768, dtype=np.uint32)
+        seg[-1] = n
+        b = capi.Batch(seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, len(seg) - 1, seg.ctypes.data, L)
+        _check(eng.lib, eng.lib.faqcs_submit_device(eng.ctx, C.byref(b), res.data_ptr()))
+        eng.sync()
+        tot = eng.kmer_totals()
+        eng.kmer_end_table()
+        results.append((tot, eng.kmer_points().copy(), [a.copy() for a in eng.kmer_histogram()]))
+        eng.close()
+    (t0, p0, h0), (t1, p1, h1) = results
+    assert t0 == t1 and t0[1] > 400_000_000 and len(p0) >= 10
+    assert (p0 == p1).all()
+    assert (h0[0] == h1[0]).all() and (h0[1] == h1[1]).all()
 
 
 def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150, backend="gloo"):
