@@ -97,6 +97,43 @@ __device__ __forceinline__ uint32_t prefilter_max(const uint32_t (&R)[4][2 * NBR
     return m;
 }
 
+// the same with the number of plane words a compile-time constant: straight-line code (with a run-time word count the compiler
+// guards every word of every block with scalar compares and branches -- 18 branches per adapter of a kernel that is bound by
+// scalar issue)
+template <int NB, int NBR, int NWC>
+__device__ __forceinline__ uint32_t prefilter_max_words(const uint32_t (&R)[4][2 * NBR + 2], const uint32_t *tpl)
+{
+    uint32_t cnt[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) cnt[b] = 0;
+#pragma unroll
+    for (int w = 0; w < NWC; ++w) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(tpl + 4 * w);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int e = w - 2 * b + 2 * (NBR - 1);
+            cnt[b] += __popc(plane_match(R[0][e], R[1][e], R[2][e], R[3][e], t));
+        }
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) m = umax_(m, cnt[b]);
+    return m;
+}
+// the same for the adapter's FIRST plane word only (the coarse test of stage 1): NB steps, no loop over words
+template <int NB, int NBR>
+__device__ __forceinline__ uint32_t first_word_max(const uint32_t (&R)[4][2 * NBR + 2], const uint32_t *tpl)
+{
+    const uint4 t = *reinterpret_cast<const uint4 *>(tpl);
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int e = -2 * b + 2 * (NBR - 1);
+        m = umax_(m, (uint32_t)__popc(plane_match(R[0][e], R[1][e], R[2][e], R[3][e], t)));
+    }
+    return m;
+}
+
 #ifndef FAQCS_ADAPTER_WAVES
 #define FAQCS_ADAPTER_WAVES 4 /* waves per SIMD the 256-base variant is compiled for (5 = 96 VGPRs with 12 spilled: measured, no faster) */
 #endif
@@ -140,7 +177,10 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
     for (uint32_t i = threadIdx.x; i < 2 * FAQCS_MAX_ADAPTERS; i += NW * 64) s_ast[i] = 0u;
     for (uint32_t i = threadIdx.x; i < A.n_adapters; i += NW * 64) {
         const uint32_t tl = A.start[i + 1] - A.start[i];
-        s_meta[i] = make_uint4(tl, A.wstart[i], (uint32_t)(int)__fmul_rn(A.match_rate, (float)(int)tl), 0u);
+        uint32_t amask = 0; // which of the four base planes the adapter has a bit in (any_match below)
+        for (uint32_t w = A.wstart[i]; w < A.wstart[i + 1]; ++w)
+            for (uint32_t b = 0; b < 4; ++b) amask |= A.planes[4 * w + b] ? 1u << b : 0u;
+        s_meta[i] = make_uint4(tl, A.wstart[i], (uint32_t)(int)__fmul_rn(A.match_rate, (float)(int)tl), amask);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 256; i += NW * 64) s_na[i] = (uint8_t)na_bits(i, s_iupac);
@@ -209,6 +249,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
 
         // ---- pack_query: bases -> the four bit-planes (the per-base arrays of stage 2 are filled on demand) --------
         bool badbase = false;
+        uint32_t rmask = 0; // which base planes the read has a bit in
         const int span = qlen > prev_qlen ? qlen : prev_qlen;
         prev_qlen = qlen;
 #pragma unroll(LONG ? 1 : NCH)
@@ -225,6 +266,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint64_t m = __ballot((bits >> b) & 1u);
+                    rmask |= m ? 1u << b : 0u;
                     if (lane == 0) { pl[b * PW + PADL + 2 * c] = (uint32_t)m; pl[b * PW + PADL + 1 + 2 * c] = (uint32_t)(m >> 32); }
                 }
             }
@@ -414,48 +456,66 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
 #pragma unroll
                     for (int e = 0; e < 2 * NBR + 2; ++e) R[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
             }
-            // per-adapter scalars of this read, computed once with lane = adapter (n_adapters <= 64) and read back with
-            // v_readlane inside the loop: |adapter|, first plane word, threshold, and "need" = 2 thr - min(|read|, |adapter|)
-            uint32_t va = 0, vb = 0;
+            // per-adapter scalars of this read, computed once with lane = adapter (n_adapters <= 64) and read back with v_readlane inside
+            // the loop (the kernel is co-bound by scalar issue: what the loop does per adapter in scalar code is kept to a few unpacks):
+            //   va = |adapter| (14 bits) | first plane word << 14 (14) | plane words << 28
+            //   vb = need_cnt (16) | coarse need << 16        vc = need + 32768 (16) | thr << 16
+            // thr = the reference's threshold (trim.cpp:1007-1008 / :1082); need = 2 thr - min(|read|, |adapter|): what a block's best SCORE has
+            // to reach ((mcap + score) / 2 >= thr); need_cnt = max(need, thr): what a diagonal's MATCH COUNT has to reach -- num_match =
+            // (match_length + score) / 2 IS the number of matching positions inside the alignment (trim.cpp:1024-1027), it cannot exceed the
+            // matches on the alignment's diagonal (polyA: 16 of 20, not the 12 of 20 that 15 % of random reads meet); coarse need = need_cnt -
+            // (|adapter| - 32): what the diagonal has to collect on the adapter's FIRST plane word for that (the bases behind it can add at
+            // most their number) -- for a two-word adapter (33 ... 64 bases) the first word alone ends the adapter for almost every random read.
+            uint32_t va = 0, vb = 0, vc = 0;
+            bool share = false; // the read and the adapter share a base plane <=> some cell of the (read x adapter) matrix matches: exact
             if ((uint32_t)lane < A.n_adapters) {
                 const uint4 me = s_meta[lane];
                 const int tl = (int)me.x;
                 const int mm = tail ? tl : (len8 < tl ? len8 : tl);
                 const int th = mm == tl ? (int)me.z : (int)__fmul_rn(A.match_rate, (float)mm); // trim.cpp:1007-1008 / :1082
-                va = (uint32_t)tl | (me.y << 16);
-                vb = (uint32_t)th | ((uint32_t)(2 * th - (qlen < tl ? qlen : tl) + 32768) << 16);
+                const int need = 2 * th - (qlen < tl ? qlen : tl);
+                const int need_cnt = need > th ? need : th;
+                const int coarse = need_cnt - (tl > 32 ? tl - 32 : 0);
+                va = (uint32_t)tl | (me.y << 14) | ((uint32_t)((tl + 31) >> 5 > 7 ? 7 : (tl + 31) >> 5) << 28);
+                vb = (uint32_t)need_cnt | ((uint32_t)(coarse > 0 ? coarse : 0) << 16);
+                vc = (uint32_t)(need + 32768) | ((uint32_t)th << 16);
+                share = (me.w & rmask) != 0u;
             }
+            m_any = prefilter_on ? __ballot(share) : ~0ull; // (prefilter off, a diagnostic: every adapter goes to stage 2)
 #pragma unroll 1
             for (uint32_t j = 0; j < A.n_adapters; ++j) {
                 const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)va, (int)j), sb = (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)j);
-                const int tlen = (int)(sa & 0xffffu);
-                const int thr = (int)(sb & 0xffffu);
-                const int need_j = (int)(sb >> 16) - 32768;                  // (mcap + best score) / 2 >= thr  <=>  best score >= need
-                // What an adapter needs to mask or be credited is num_match = (match_length + score) / 2 >= thr (trim.cpp:1024-1027), and
-                // num_match IS the number of matching positions inside the alignment (match_length = matches + mismatches, score = matches -
-                // mismatches): it cannot exceed the matches on the alignment's diagonal.  So a diagonal's MATCH COUNT has to reach thr itself --
-                // a far stronger skip test than "count >= need" (polyA: 16 of 20 instead of 12 of 20, which 15 % of random reads met);
-                // `need` stays the test for a block's best SCORE (second filter below).
-                const int need_cnt = need_j > thr ? need_j : thr;
-                bool any_match = true, may_pass = true;
-                const int mcap = qlen < tlen ? qlen : tlen;
+                const int tlen = (int)(sa & 0x3fffu);
+                const int need_cnt = (int)(sb & 0xffffu);
+                bool may_pass = true;
                 if (prefilter_on && MAXLEN <= 320 && tlen <= 128 && tpl_cached) {
-                    const uint32_t *tpl = s_tpl + 4 * (sa >> 16);
+                    const uint32_t *tpl = s_tpl + 4 * ((sa >> 14) & 0x3fffu);
                     // (Measured and rejected: fetching the next adapter's first two plane words an adapter ahead, so that no LDS broadcast
                     // sits in front of its 20 dependent instructions: 128 VGPRs with a spill, 523 -> 470 M reads/s.)
                     // (Measured and rejected: leaving a last plane word of <= 3 bases uncompared and counting those bases as matches.
                     // The weaker bound lets enough random reads through to stage 2 to cost more than the word saves: -8 %.)
-                    const int nw = (tlen + 31) >> 5;
+                    const int nw = (int)(sa >> 28);
                     constexpr int slack = 0;
                     const int nb = (qlen + tlen - 1 + 63) >> 6;              // blocks past the last diagonal would only add zeros
                     uint32_t maxcnt, cb[8];
-                    if (NBR == 4) maxcnt = nb <= 3 ? prefilter_max<3, NBR>(R, tpl, nw, cb) : prefilter_max<4, NBR>(R, tpl, nw, cb);
-                    else if (NBR == 6) maxcnt = nb <= 4 ? prefilter_max<4, NBR>(R, tpl, nw, cb) : prefilter_max<(NBR >= 6 ? 6 : NBR), NBR>(R, tpl, nw, cb);
-                    else maxcnt = nb <= 5 ? prefilter_max<(NBR >= 5 ? 5 : NBR), NBR>(R, tpl, nw, cb) : prefilter_max<NBR, NBR>(R, tpl, nw, cb); // 257..320-base reads
-                    // bound = max over diagonals; only two threshold tests of it are needed
-                    any_match = __any(maxcnt > 0u);
-                    may_pass = __any((int)maxcnt + slack >= need_cnt);
+                    constexpr int NB_LO = NBR == 4 ? 3 : (NBR == 6 ? 4 : 5), NB_HI = NBR == 4 ? 4 : (NBR == 6 ? 6 : NBR);
+                    auto count = [&](auto nb_tag) {
+                        constexpr int NB = decltype(nb_tag)::value;
+                        switch (nw) {
+                        case 1: maxcnt = prefilter_max_words<NB, NBR, 1>(R, tpl); break;
+                        case 2: // coarse test on the first word, the full count only for what passes it
+                            maxcnt = first_word_max<NB, NBR>(R, tpl);
+                            may_pass = __any((int)maxcnt >= (int)(sb >> 16));
+                            if (may_pass) maxcnt = prefilter_max_words<NB, NBR, 2>(R, tpl);
+                            break;
+                        case 3: maxcnt = prefilter_max_words<NB, NBR, 3>(R, tpl); break;
+                        default: maxcnt = prefilter_max_words<NB, NBR, 4>(R, tpl); break;
+                        }
+                    };
+                    if (nb <= NB_LO) count(std::integral_constant<int, NB_LO>{}); else count(std::integral_constant<int, NB_HI>{});
+                    if (may_pass) may_pass = __any((int)maxcnt + slack >= need_cnt);
                     if (may_pass) { // rare: the per-block bounds for stage 2 (it aligns the most promising block first and prunes the rest)
+                        const int need_j = (int)((uint32_t)__builtin_amdgcn_readlane((int)vc, (int)j) & 0xffffu) - 32768;
                         uint32_t cw[8];
                         (void)prefilter_max<NBR, NBR, true>(R, tpl, nw, cw);
                         // Second filter.  The match-count bound is weak for short adapters with a low threshold (polyA: 16 of 20 lets
@@ -501,7 +561,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                     // per step.  Words 2u and 2u+1 face exactly the NBR+1 blocks u-1 .. u+NBR-1 (window index 2 NBR - 2i and
                     // 2 NBR + 1 - 2i for block u-1+i); block u-1 has seen all of its words after step u and leaves the accumulator.
                     constexpr int NACC = NBR + 1;
-                    const uint32_t *tpl = s_tpl + 4 * (sa >> 16);
+                    const uint32_t *tpl = s_tpl + 4 * ((sa >> 14) & 0x3fffu);
                     const int nw = (tlen + 31) >> 5;
                     const int nb = (qlen + tlen - 1 + 63) >> 6;
                     uint32_t cnt[NACC], maxcnt = 0;
@@ -523,7 +583,6 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                         for (int i = 0; i + 1 < NACC; ++i) cnt[i] = cnt[i + 1];
                         cnt[NACC - 1] = 0;
                     }
-                    any_match = __any(maxcnt > 0u);
                     may_pass = __any((int)maxcnt >= need_cnt);
                 } else if (prefilter_on) {
                     const uint32_t w0 = s_wstart[j];
@@ -551,12 +610,10 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                         }
                         maxcnt = umax_(maxcnt, cnt);
                     }
-                    const int bound = (int)wave_max_u32(maxcnt);             // >= best local-alignment score
-                    any_match = bound > 0;
-                    may_pass = (mcap + bound) / 2 >= thr && bound >= thr;        // (bound = the largest match count of a diagonal)
+                    const int bound = (int)wave_max_u32(maxcnt);             // the largest match count of a diagonal
+                    may_pass = bound >= need_cnt;
                 }
-                // (wave-uniform flags: kept in SGPRs -- as lane values each adapter paid two 64-bit VALU shifts and four ors)
-                m_any |= (uint64_t)(uint32_t)uni((int)any_match) << j;
+                // (wave-uniform flag: kept in SGPRs -- as a lane value each adapter paid a 64-bit VALU shift and two ors)
                 m_pass |= (uint64_t)(uint32_t)uni((int)may_pass) << j;
             }
         };

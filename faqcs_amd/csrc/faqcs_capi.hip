@@ -466,6 +466,7 @@ static int kg_init(faqcs_ctx *c)
     // Either scatter level writes 65 536 sub-regions: (bucket, writing block) at level 1, (partition, writing block) at level 2.
     // A sub-region of the expected G / 65 536 items gets 1/4 + 8 standard deviations (+ a granule) on top.
     d.split = G >= (1ull << 26) ? 8u : 1u;
+    d.lds_slots = G > (1ull << 30) ? 8192u : 4096u;
     const double mean1 = (double)G / (KG_FAN * KG_FAN), mean2 = mean1 / d.split;
     d.cap1 = (uint32_t)(mean1 * 1.25 + 8.0 * std::sqrt(mean1) + 64.0);
     d.cap2 = (uint32_t)(mean2 * 1.25 + 8.0 * std::sqrt(mean2) + 64.0);

@@ -66,6 +66,7 @@ struct KmerGroupDev {
     uint32_t *run_epoch;      // [KG_MAX_RUNS]  epoch of run j minus epoch_base
     uint32_t cap1, cap2;      // items per sub-region
     uint32_t split;           // blocks per bucket of the level-2 scatter = sub-regions per partition (1, 2, 4 or 8)
+    uint32_t lds_slots;       // LDS hash table of the combine kernel: 4 096 (two workgroups per CU) or 8 192 (groups past 2^30 items)
     uint32_t n_runs, epoch_base;
     unsigned long long *first_hist;   // [n_epochs] keys by first epoch
     unsigned long long *tot_by_epoch; // [n_epochs] occurrences by epoch

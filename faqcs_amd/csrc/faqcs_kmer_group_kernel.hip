@@ -594,9 +594,10 @@ __global__ __launch_bounds__(NW * 64) void kmer_group_split(const KmerGroupDev G
 // ---- combine + insert: one workgroup per partition --------------------------------------------------------------------------
 // LDS table: word = remainder (46 bits) << 18 | epoch (relative, < 2^18 - 1): equal keys differ only in the epoch bits, so an
 // atomic min on the word keeps the key and its smallest epoch; the count sits in a second array.
-template <int NT>
+template <int NT, int LS>
 __global__ __launch_bounds__(NT) void kmer_group_combine(const KmerGroupDev G, const KmerTable T)
 {
+    constexpr int KG_LDS_SLOTS = LS; // (shadows the enum: 4 096 slots, two workgroups per CU; 8 192 for groups past 2^30 items, one per CU)
     __shared__ u64 s_key[KG_LDS_SLOTS];
     __shared__ uint32_t s_cnt[KG_LDS_SLOTS];
     __shared__ int s_hist[KG_EPOCH_SPAN];
@@ -630,8 +631,8 @@ __global__ __launch_bounds__(NT) void kmer_group_combine(const KmerGroupDev G, c
     if (tid == 0) s_fail = 0u;
     __syncthreads();
     constexpr uint32_t LMASK = KG_LDS_SLOTS - 1;
-    constexpr int LSHIFT = 46 - 12; // slot = top 12 bits of the remainder: LDS order == table order
-    static_assert(KG_LDS_SLOTS == 4096, "LSHIFT");
+    constexpr int LSHIFT = 46 - (LS == 4096 ? 12 : 13); // slot = top 12 (13) bits of the remainder: LDS order == table order
+    static_assert(LS == 4096 || LS == 8192, "LSHIFT");
     // looks the item's key up; returns the slot, or -1 (table full and the key not in it)
     auto find_or_add = [&](const u64 rem, const u64 word, const bool add) -> int {
         uint32_t s = (uint32_t)(rem >> LSHIFT);
@@ -804,7 +805,8 @@ hipError_t faqcs_launch_kmer_group_items(const KmerGroupDev &G, const KmerTable 
 hipError_t faqcs_launch_kmer_group_flush(const KmerGroupDev &G, const KmerTable &T, hipStream_t st)
 {
     hipLaunchKernelGGL((kmer_group_split<KG_NW>), dim3(KG_FAN * G.split), dim3(KG_NW * 64), KG_STAGE_BYTES + (size_t)(KG_MAX_RUNS + KG_FAN) * 4 + 16, st, G, T);
-    hipLaunchKernelGGL((kmer_group_combine<1024>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T);
+    if (G.lds_slots > 4096) hipLaunchKernelGGL((kmer_group_combine<1024, 8192>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T);
+    else hipLaunchKernelGGL((kmer_group_combine<1024, 4096>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T);
     hipLaunchKernelGGL(kmer_group_reset, dim3(KG_FAN * KG_FAN / 256), dim3(256), 0, st, G);
     return hipGetLastError();
 }
