@@ -1041,12 +1041,14 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
     unsigned long long st[2];
     if ((c->partitioned && !c->kg.owner) || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
     else if (int rc = kg_totals(c, &st[0], &st[1])) return rc;
+    bool emptied = false;
     if (st[0]) { // ++kmer_frequency_histogram[count] for every key, FaQCs.cpp:518-521
         const uint32_t DENSE = 1u << 16, BIGCAP = 1u << 20;
         unsigned long long *d_dense = nullptr, *d_big = nullptr, *d_nbig = nullptr;
         HIPCHK(hipMalloc((void **)&d_dense, DENSE * 8)); HIPCHK(hipMalloc((void **)&d_big, (size_t)BIGCAP * 8)); HIPCHK(hipMalloc((void **)&d_nbig, 8));
         HIPCHK(hipMemsetAsync(d_dense, 0, DENSE * 8, c->compute)); HIPCHK(hipMemsetAsync(d_nbig, 0, 8, c->compute));
-        HIPCHK(faqcs_launch_kmer_histogram(c->kt, d_dense, DENSE, d_big, d_nbig, BIGCAP, c->n_cu, c->compute));
+        HIPCHK(faqcs_launch_kmer_histogram(c->kt, d_dense, DENSE, d_big, d_nbig, BIGCAP, true, c->n_cu, c->compute)); // (and empties the slots)
+        emptied = true;
         HIPCHK(hipStreamSynchronize(c->compute));
         std::vector<unsigned long long> dense(DENSE);
         unsigned long long nbig = 0;
@@ -1067,7 +1069,7 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
         faqcs_rarefaction pt{c->total_number, st[0], st[1]};
         c->points.push_back(pt);
     }
-    HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute));
+    if (!emptied) HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute));
     HIPCHK(hipMemsetAsync(c->kt.stats, 0, 64, c->compute));
     if (c->kg.ready && c->kg.ep_cap) { // the epoch histograms restart with the table; the points taken so far keep their values
         c->kg.points_final = c->points.size();

@@ -88,7 +88,7 @@ hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T,
                              const uint32_t *off, uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results,
                              int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
-                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
+                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, bool reset, int n_cu,
                                        hipStream_t st);
 // combine-before-insert: one extraction launch per run (appends to the level-1 buckets, snapshots the cursors into
 // bounds[run]), then per group: level-2 scatter, combine + insert, cursor reset

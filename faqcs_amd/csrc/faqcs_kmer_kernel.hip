@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256) void kmer_first_epoch_histogram(const KmerTabl
 // histogram of counts over the table (FaQCs.cpp:518-521): dense[c] for c < dense_n, (count) list otherwise.
 // Nearly every key of a real run has one of a few hundred small counts: the block counts those in LDS first (global
 // atomics on a few hundred addresses from 10^8..10^9 slots serialise in L2 -- seconds on a 34 GB table).
+// RESET: the slots are emptied in the same pass (faqcs_kmer_end_table counts the table and starts a fresh one: one read + one write
+// of the table instead of a read, and a write by kmer_table_init)
+template <bool RESET>
 __global__ __launch_bounds__(256) void kmer_count_histogram(const KmerTable T, unsigned long long *dense, uint32_t dense_n,
                                                             unsigned long long *big, unsigned long long *n_big, uint32_t big_cap)
 {
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(256) void kmer_count_histogram(const KmerTable T, u
     for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const KmerSlot sl = T.slots[i];
         if (sl.key != ~0ull) {
+            if (RESET) reinterpret_cast<ulonglong2 *>(T.slots)[i] = make_ulonglong2(~0ull, 0xffffffff00000000ull); // (as kmer_table_init)
             const uint32_t c = sl.count_m1 + 1u;
             if (c < LOCAL && c < dense_n) atomicAdd(&h[c], 1u);
             else if (c < dense_n) atomicAdd(&dense[c], 1ull);
@@ -267,10 +271,11 @@ hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T,
 }
 
 hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
-                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
+                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, bool reset, int n_cu,
                                        hipStream_t st)
 {
-    hipLaunchKernelGGL(kmer_count_histogram, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap);
+    if (reset) hipLaunchKernelGGL(kmer_count_histogram<true>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap);
+    else hipLaunchKernelGGL(kmer_count_histogram<false>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap);
     return hipGetLastError();
 }
 

@@ -270,7 +270,8 @@ int  faqcs_kmer_outbox(faqcs_ctx *ctx, void **d_items, uint64_t *counts);
 int  faqcs_kmer_outbox_host(faqcs_ctx *ctx, uint64_t *keys, uint64_t cap, uint64_t *n_keys);
 /* Owner side: inserts n_items received pairs (device pointer; returns when the buffer may be reused). */
 int  faqcs_kmer_insert_device(faqcs_ctx *ctx, const void *d_items, uint64_t n_items);
-/* The exchange inside ONE process that drives several devices (faqcs_mi --gpus N --kmer_rarefaction): moves the last submission's
+/* (Replaces, like the calls around it, the per-call merge of thread-local k-mer tables into ONE map, trim.cpp:133-135, for a map that is
+ * partitioned over devices.)  The exchange inside ONE process that drives several devices (faqcs_mi --gpus N --kmer_rarefaction): moves the last submission's
  * outbox of `from` to the owner contexts (owners[r] = the context faqcs_kmer_partition() made rank r of `world`) and inserts
  * it there; a peer copy when the owner sits on another device.  Returns when the outbox may be overwritten. */
 int  faqcs_kmer_forward(faqcs_ctx *from, faqcs_ctx *const *owners, uint32_t world);
