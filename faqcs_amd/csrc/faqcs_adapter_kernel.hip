@@ -158,7 +158,9 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
     __shared__ uint8_t s_iupac[32];
     __shared__ uint8_t s_na[256];              // na_to_bits() of every byte value (0 = the reference throws)
     __shared__ uint32_t s_start[FAQCS_MAX_ADAPTERS + 1], s_wstart[FAQCS_MAX_ADAPTERS + 1]; // adapter table of contents
-    __shared__ __attribute__((aligned(16))) uint4 s_meta[FAQCS_MAX_ADAPTERS]; // {|adapter|, first plane word, int(rate * |adapter|), 0}
+    __shared__ __attribute__((aligned(16))) uint4 s_meta[FAQCS_MAX_ADAPTERS]; // {|adapter|, first plane word, int(rate * |adapter|), base planes present}
+    __shared__ uint32_t s_ord[FAQCS_MAX_ADAPTERS + 8];  // stage 1 visits the adapters class by class (1, 2, 3, 4 plane words; the rest): position -> adapter,
+                                                        // then [64 + c] = first position of class c + 1 ... (stage 1 is order-free: it only sets flags)
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
     // plain (non-volatile) pointers so the accesses stay ds_* instructions (a volatile generic pointer degrades
@@ -184,6 +186,18 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 256; i += NW * 64) s_na[i] = (uint8_t)na_bits(i, s_iupac);
+    if (wave == 0) { // the class order (one wave: ranks from ballots)
+        const bool on = (uint32_t)lane < A.n_adapters;
+        const int tl = on ? (int)s_meta[on ? lane : 0].x : 0;
+        const int cls = !on ? 6 : ((MAXLEN <= 320 && tl <= 128 && tpl_cached) ? (tl + 31) >> 5 : 5); // 1 ... 4 plane words; 5: long targets / uncached
+        uint32_t base = 0;
+        for (int c = 1; c <= 5; ++c) {
+            const uint64_t m = __ballot(cls == c);
+            if (cls == c) s_ord[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+            base += (uint32_t)__popcll(m);
+            if (lane == 0) s_ord[FAQCS_MAX_ADAPTERS + c] = base; // end of class c
+        }
+    }
     __syncthreads();
     int prev_qlen = 0; // longest span of plane words the previous read of this wave left behind
     int short_tlen_max = 0; // longest adapter the register-blocked prefilter handles (<= 128 bases)
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
 
         // ---- pack_query: bases -> the four bit-planes (the per-base arrays of stage 2 are filled on demand) --------
         bool badbase = false;
-        uint32_t rmask = 0; // which base planes the read has a bit in
+        uint64_t pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0; // OR of the read's plane words (which base planes the read has a bit in)
         const int span = qlen > prev_qlen ? qlen : prev_qlen;
         prev_qlen = qlen;
 #pragma unroll(LONG ? 1 : NCH)
@@ -266,12 +280,13 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint64_t m = __ballot((bits >> b) & 1u);
-                    rmask |= m ? 1u << b : 0u;
+                    if (b == 0) pm0 |= m; else if (b == 1) pm1 |= m; else if (b == 2) pm2 |= m; else pm3 |= m;
                     if (lane == 0) { pl[b * PW + PADL + 2 * c] = (uint32_t)m; pl[b * PW + PADL + 1 + 2 * c] = (uint32_t)(m >> 32); }
                 }
             }
         }
         const bool read_bad = __any(badbase);
+        const uint32_t rmask = (pm0 ? 1u : 0u) | (pm1 ? 2u : 0u) | (pm2 ? 4u : 0u) | (pm3 ? 8u : 0u);
         lds_sync_wave();
         // exact alignment of adapter j: best (M, i, j) over all diagonals -> (score or -1, start, stop)
         auto align_exact = [&](uint32_t j, int &gM, int &gS, int &gI) {
@@ -467,55 +482,54 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
             // (|adapter| - 32): what the diagonal has to collect on the adapter's FIRST plane word for that (the bases behind it can add at
             // most their number) -- for a two-word adapter (33 ... 64 bases) the first word alone ends the adapter for almost every random read.
             uint32_t va = 0, vb = 0, vc = 0;
-            bool share = false; // the read and the adapter share a base plane <=> some cell of the (read x adapter) matrix matches: exact
+            const uint32_t ja = (uint32_t)lane < A.n_adapters ? s_ord[lane] : 0u; // the adapter this lane stands for in the class order
             if ((uint32_t)lane < A.n_adapters) {
-                const uint4 me = s_meta[lane];
+                const uint4 me = s_meta[ja];
                 const int tl = (int)me.x;
                 const int mm = tail ? tl : (len8 < tl ? len8 : tl);
                 const int th = mm == tl ? (int)me.z : (int)__fmul_rn(A.match_rate, (float)mm); // trim.cpp:1007-1008 / :1082
                 const int need = 2 * th - (qlen < tl ? qlen : tl);
                 const int need_cnt = need > th ? need : th;
                 const int coarse = need_cnt - (tl > 32 ? tl - 32 : 0);
-                va = (uint32_t)tl | (me.y << 14) | ((uint32_t)((tl + 31) >> 5 > 7 ? 7 : (tl + 31) >> 5) << 28);
+                va = (uint32_t)tl | (me.y << 14);
                 vb = (uint32_t)need_cnt | ((uint32_t)(coarse > 0 ? coarse : 0) << 16);
                 vc = (uint32_t)(need + 32768) | ((uint32_t)th << 16);
-                share = (me.w & rmask) != 0u;
             }
-            m_any = prefilter_on ? __ballot(share) : ~0ull; // (prefilter off, a diagnostic: every adapter goes to stage 2)
-#pragma unroll 1
-            for (uint32_t j = 0; j < A.n_adapters; ++j) {
-                const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)va, (int)j), sb = (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)j);
+            {   // the read and the adapter share a base plane <=> some cell of the (read x adapter) matrix matches: exact; lane = adapter
+                const bool share = (uint32_t)lane < A.n_adapters && (s_meta[(uint32_t)lane < A.n_adapters ? lane : 0].w & rmask) != 0u;
+                m_any = prefilter_on ? __ballot(share) : ~0ull; // (prefilter off, a diagnostic: every adapter goes to stage 2)
+            }
+            // one adapter of class NWC (its number of plane words; 0: a long target or an uncached table) at position l of the class order
+            auto one = [&](const uint32_t l, auto nw_tag) {
+                constexpr int NWC = decltype(nw_tag)::value;
+                const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)va, (int)l), sb = (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)l);
+                const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)ja, (int)l);
                 const int tlen = (int)(sa & 0x3fffu);
                 const int need_cnt = (int)(sb & 0xffffu);
                 bool may_pass = true;
-                if (prefilter_on && MAXLEN <= 320 && tlen <= 128 && tpl_cached) {
-                    const uint32_t *tpl = s_tpl + 4 * ((sa >> 14) & 0x3fffu);
+                if (NWC > 0 && prefilter_on) {
+                    const uint32_t *tpl = s_tpl + 4 * (sa >> 14);
                     // (Measured and rejected: fetching the next adapter's first two plane words an adapter ahead, so that no LDS broadcast
                     // sits in front of its 20 dependent instructions: 128 VGPRs with a spill, 523 -> 470 M reads/s.)
                     // (Measured and rejected: leaving a last plane word of <= 3 bases uncompared and counting those bases as matches.
                     // The weaker bound lets enough random reads through to stage 2 to cost more than the word saves: -8 %.)
-                    const int nw = (int)(sa >> 28);
+                    constexpr int nw = NWC > 0 ? NWC : 1;
                     constexpr int slack = 0;
                     const int nb = (qlen + tlen - 1 + 63) >> 6;              // blocks past the last diagonal would only add zeros
-                    uint32_t maxcnt, cb[8];
+                    uint32_t maxcnt;
                     constexpr int NB_LO = NBR == 4 ? 3 : (NBR == 6 ? 4 : 5), NB_HI = NBR == 4 ? 4 : (NBR == 6 ? 6 : NBR);
                     auto count = [&](auto nb_tag) {
                         constexpr int NB = decltype(nb_tag)::value;
-                        switch (nw) {
-                        case 1: maxcnt = prefilter_max_words<NB, NBR, 1>(R, tpl); break;
-                        case 2: // coarse test on the first word, the full count only for what passes it
+                        if (nw == 2) { // coarse test on the first word, the full count only for what passes it
                             maxcnt = first_word_max<NB, NBR>(R, tpl);
                             may_pass = __any((int)maxcnt >= (int)(sb >> 16));
                             if (may_pass) maxcnt = prefilter_max_words<NB, NBR, 2>(R, tpl);
-                            break;
-                        case 3: maxcnt = prefilter_max_words<NB, NBR, 3>(R, tpl); break;
-                        default: maxcnt = prefilter_max_words<NB, NBR, 4>(R, tpl); break;
-                        }
+                        } else maxcnt = prefilter_max_words<NB, NBR, nw>(R, tpl);
                     };
                     if (nb <= NB_LO) count(std::integral_constant<int, NB_LO>{}); else count(std::integral_constant<int, NB_HI>{});
                     if (may_pass) may_pass = __any((int)maxcnt + slack >= need_cnt);
                     if (may_pass) { // rare: the per-block bounds for stage 2 (it aligns the most promising block first and prunes the rest)
-                        const int need_j = (int)((uint32_t)__builtin_amdgcn_readlane((int)vc, (int)j) & 0xffffu) - 32768;
+                        const int need_j = (int)((uint32_t)__builtin_amdgcn_readlane((int)vc, (int)l) & 0xffffu) - 32768;
                         uint32_t cw[8];
                         (void)prefilter_max<NBR, NBR, true>(R, tpl, nw, cw);
                         // Second filter.  The match-count bound is weak for short adapters with a low threshold (polyA: 16 of 20 lets
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                         may_pass = pass2;
                         if (may_pass) m_bnd |= 1ull << j;
                     }
-                } else if (prefilter_on && MAXLEN <= 320 && NBR >= 6 && tpl_cached) {
+                } else if (NWC == 0 && prefilter_on && MAXLEN <= 320 && NBR >= 6 && tpl_cached) {
                     // long target (PhiX, artifact sequences): the same register windows, sliding over the target two words
                     // per step.  Words 2u and 2u+1 face exactly the NBR+1 blocks u-1 .. u+NBR-1 (window index 2 NBR - 2i and
                     // 2 NBR + 1 - 2i for block u-1+i); block u-1 has seen all of its words after step u and leaves the accumulator.
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                         cnt[NACC - 1] = 0;
                     }
                     may_pass = __any((int)maxcnt >= need_cnt);
-                } else if (prefilter_on) {
+                } else if (NWC == 0 && prefilter_on) {
                     const uint32_t w0 = s_wstart[j];
                     const int nw = (int)(s_wstart[j + 1] - w0);
                     const int ndiag = qlen + tlen - 1;
@@ -615,7 +629,22 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                 }
                 // (wave-uniform flag: kept in SGPRs -- as a lane value each adapter paid a 64-bit VALU shift and two ors)
                 m_pass |= (uint64_t)(uint32_t)uni((int)may_pass) << j;
-            }
+            };
+            // class by class: inside a class the number of plane words is a compile-time constant (with the classes mixed in one loop the
+            // compiler turns the choice into chains of scalar flag tests: 36 scalar instructions and 17 branches per adapter, measured)
+            uint32_t l = 0;
+            const uint32_t e1 = uniu(s_ord[FAQCS_MAX_ADAPTERS + 1]), e2 = uniu(s_ord[FAQCS_MAX_ADAPTERS + 2]), e3 = uniu(s_ord[FAQCS_MAX_ADAPTERS + 3]),
+                           e4 = uniu(s_ord[FAQCS_MAX_ADAPTERS + 4]);
+#pragma unroll 1
+            for (; l < e1; ++l) one(l, std::integral_constant<int, 1>{});
+#pragma unroll 1
+            for (; l < e2; ++l) one(l, std::integral_constant<int, 2>{});
+#pragma unroll 1
+            for (; l < e3; ++l) one(l, std::integral_constant<int, 3>{});
+#pragma unroll 1
+            for (; l < e4; ++l) one(l, std::integral_constant<int, 4>{});
+#pragma unroll 1
+            for (; l < A.n_adapters; ++l) one(l, std::integral_constant<int, 0>{});
         };
         if (!read_bad && qlen > 0) {
             if (MAXLEN == 320) stage1(std::integral_constant<int, 7>{});   // up to (320 + 128) / 64 = 7 blocks
