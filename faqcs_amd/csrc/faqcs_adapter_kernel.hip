@@ -159,6 +159,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
     __shared__ uint8_t s_na[256];              // na_to_bits() of every byte value (0 = the reference throws)
     __shared__ uint32_t s_start[FAQCS_MAX_ADAPTERS + 1], s_wstart[FAQCS_MAX_ADAPTERS + 1]; // adapter table of contents
     __shared__ __attribute__((aligned(16))) uint4 s_meta[FAQCS_MAX_ADAPTERS]; // {|adapter|, first plane word, int(rate * |adapter|), base planes present}
+    __shared__ uint32_t s_pos[FAQCS_MAX_ADAPTERS];      // adapter -> position in the class order
     __shared__ uint32_t s_ord[FAQCS_MAX_ADAPTERS + 8];  // stage 1 visits the adapters class by class (1, 2, 3, 4 plane words; the rest): position -> adapter,
                                                         // then [64 + c] = first position of class c + 1 ... (stage 1 is order-free: it only sets flags)
     const int lane = threadIdx.x & 63;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
         uint32_t base = 0;
         for (int c = 1; c <= 5; ++c) {
             const uint64_t m = __ballot(cls == c);
-            if (cls == c) s_ord[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+            if (cls == c) { const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); s_ord[at] = (uint32_t)lane; s_pos[lane] = at; }
             base += (uint32_t)__popcll(m);
             if (lane == 0) s_ord[FAQCS_MAX_ADAPTERS + c] = base; // end of class c
         }
@@ -271,18 +272,20 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
             if (LONG && c * 64 >= span) break;
             if (c * 64 < span) {
                 const int p = c * 64 + lane;
-                uint32_t bits = 0;
-                if (p < qlen) {
-                    bits = s_na[LONG ? (uint32_t)seq[(size_t)o + p] : cbyte[LONG ? 0 : c]];
-                    badbase |= bits == 0u;
-                }
-                // every chunk the previous read touched is rewritten (zeros past this read) so nothing of it survives
+                // (a position past the read holds byte 0 -- the prefetch loads zeros there -- whose mask is 0: no test per lane for the short variants)
+                uint32_t bits = LONG ? (p < qlen ? (uint32_t)s_na[(uint32_t)seq[(size_t)o + p]] : 0u) : (uint32_t)s_na[cbyte[LONG ? 0 : c]];
+                badbase |= bits == 0u && p < qlen;
+                // every chunk the previous read touched is rewritten (zeros past this read) so nothing of it survives.  The chunk's eight plane
+                // dwords are gathered into lanes 0 ... 7 (two selects per plane) and stored by ONE instruction (as four lane-0 stores each plane paid an
+                // EXEC region: the kernel is bound by scalar issue)
+                uint32_t wv = 0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint64_t m = __ballot((bits >> b) & 1u);
                     if (b == 0) pm0 |= m; else if (b == 1) pm1 |= m; else if (b == 2) pm2 |= m; else pm3 |= m;
-                    if (lane == 0) { pl[b * PW + PADL + 2 * c] = (uint32_t)m; pl[b * PW + PADL + 1 + 2 * c] = (uint32_t)(m >> 32); }
+                    wv = lane == 2 * b ? (uint32_t)m : (lane == 2 * b + 1 ? (uint32_t)(m >> 32) : wv);
                 }
+                if (lane < 8) pl[(lane >> 1) * PW + PADL + 2 * c + (lane & 1)] = wv;
             }
         }
         const bool read_bad = __any(badbase);
@@ -459,6 +462,8 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
         int rs = 0, re = 0;
         // ---- stage 1 for every adapter: two bits per adapter (any cell matches / the threshold is reachable) ---------
         uint64_t m_any = 0, m_pass = 0, m_bnd = 0; // m_bnd: stage 1 left the adapter's per-block bounds in s_sb
+                                                   // (m_any, m_bnd: bit = adapter; m_pass: bit = the adapter's position in the class order)
+        uint32_t pass_v = 0;                       // lane l: the adapter at position l may pass (a lane flag: no 64-bit scalar shifts per adapter)
         auto stage1 = [&](auto nbr_tag) {
             constexpr int NBR = decltype(nbr_tag)::value;
             uint32_t R[4][2 * NBR + 2];
@@ -503,7 +508,6 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
             auto one = [&](const uint32_t l, auto nw_tag) {
                 constexpr int NWC = decltype(nw_tag)::value;
                 const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)va, (int)l), sb = (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)l);
-                const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)ja, (int)l);
                 const int tlen = (int)(sa & 0x3fffu);
                 const int need_cnt = (int)(sb & 0xffffu);
                 bool may_pass = true;
@@ -529,6 +533,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                     if (nb <= NB_LO) count(std::integral_constant<int, NB_LO>{}); else count(std::integral_constant<int, NB_HI>{});
                     if (may_pass) may_pass = __any((int)maxcnt + slack >= need_cnt);
                     if (may_pass) { // rare: the per-block bounds for stage 2 (it aligns the most promising block first and prunes the rest)
+                        const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)ja, (int)l);
                         const int need_j = (int)((uint32_t)__builtin_amdgcn_readlane((int)vc, (int)l) & 0xffffu) - 32768;
                         uint32_t cw[8];
                         (void)prefilter_max<NBR, NBR, true>(R, tpl, nw, cw);
@@ -599,6 +604,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                     }
                     may_pass = __any((int)maxcnt >= need_cnt);
                 } else if (NWC == 0 && prefilter_on) {
+                    const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)ja, (int)l);
                     const uint32_t w0 = s_wstart[j];
                     const int nw = (int)(s_wstart[j + 1] - w0);
                     const int ndiag = qlen + tlen - 1;
@@ -627,8 +633,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                     const int bound = (int)wave_max_u32(maxcnt);             // the largest match count of a diagonal
                     may_pass = bound >= need_cnt;
                 }
-                // (wave-uniform flag: kept in SGPRs -- as a lane value each adapter paid a 64-bit VALU shift and two ors)
-                m_pass |= (uint64_t)(uint32_t)uni((int)may_pass) << j;
+                pass_v = ((uint32_t)lane == l && may_pass) ? 1u : pass_v;
             };
             // class by class: inside a class the number of plane words is a compile-time constant (with the classes mixed in one loop the
             // compiler turns the choice into chains of scalar flag tests: 36 scalar instructions and 17 branches per adapter, measured)
@@ -645,6 +650,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
             for (; l < e4; ++l) one(l, std::integral_constant<int, 4>{});
 #pragma unroll 1
             for (; l < A.n_adapters; ++l) one(l, std::integral_constant<int, 0>{});
+            m_pass = __ballot(pass_v != 0u);
         };
         if (!read_bad && qlen > 0) {
             if (MAXLEN == 320) stage1(std::integral_constant<int, 7>{});   // up to (320 + 128) / 64 = 7 blocks
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
                 const int tlen = (int)(s_start[j + 1] - s_start[j]);
                 const int m = tail ? tlen : (len8 < tlen ? len8 : tlen);
                 const int thr = (int)__fmul_rn(A.match_rate, (float)m);      // trim.cpp:1007-1008 / :1082
-                const bool any_match = (m_any >> j) & 1ull, may_pass = (m_pass >> j) & 1ull;
+                const bool any_match = (m_any >> j) & 1ull, may_pass = (m_pass >> uniu(s_pos[j])) & 1ull;
                 int score = 0;
                 if (any_match) {
                     if (!may_pass) { have = true; known = false; last_j = j; continue; } // cannot mask, cannot be credited
