@@ -2000,10 +2000,30 @@ void remove_file(const std::string &p)
 
 } // namespace
 
+// Whether the command runs in a forked worker (see report_done() below) or in this process.
+static bool worker_process_wanted()
+{
+    const char *nf = getenv("FAQCS_MI_NO_FORK");
+    // One process when asked for, and ALWAYS under a profiler: rocprofv3 --pmc has initialised the GPU before main() runs, a child
+    // forked from such a process must not touch it, and the tool would follow the wrong process anyway.  LD_PRELOAD by
+    // itself is not that sign (job launchers preload guards of their own that never touch the GPU): only a profiler's library in it.
+    static const char *const tool_env[] = {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH",
+                                           "ROCPROFILER_LIBRARY_CTOR", "HSA_TOOLS_LIB", "ROCP_METRICS"};
+    bool tool = false;
+    for (const char *name : tool_env) { const char *v = getenv(name); if (v && *v) tool = true; }
+    if (const char *pre = getenv("LD_PRELOAD")) {
+        static const char *const prof[] = {"rocprof", "roctracer", "roctx", "rocsys", "omnitrace", "rocpd"};
+        for (const char *w : prof) if (strstr(pre, w)) tool = true;
+    }
+    return !(nf && atoi(nf) != 0) && !tool;
+}
+
 // Host-only self checks (no device is touched): `faqcs_mi --bgzf_cat <file>` writes the inflated bytes of a BGZF file to stdout
-// through BgzfReader, `faqcs_mi --report_script <FaQCs options...>` prints the R script the report step would pipe.
+// through BgzfReader, `faqcs_mi --report_script <FaQCs options...>` prints the R script the report step would pipe,
+// `faqcs_mi --process_plan` says whether a command started in this environment would run in a worker process.
 int host_self_check(int argc, char **argv)
 {
+    if (argc >= 2 && !strcmp(argv[1], "--process_plan")) { puts(worker_process_wanted() ? "worker" : "one process"); return 0; }
     if (argc >= 3 && !strcmp(argv[1], "--bgzf_cat")) {
         if (!BgzfReader::looks_like_bgzf(argv[2])) { fprintf(stderr, "not a BGZF file\n"); return 2; }
         BgzfReader r;
@@ -2055,15 +2075,7 @@ static int run_command(int argc, char **argv);
 int main(int argc, char **argv)
 {
     { const int rc = host_self_check(argc, argv); if (rc >= 0) return rc; }
-    const char *nf = getenv("FAQCS_MI_NO_FORK");
-    // One process when asked for, and ALWAYS under a profiler or any other preloaded tool: rocprofv3 --pmc (and anything that
-    // comes in through LD_PRELOAD) has initialised the GPU before main() runs, a child forked from such a process must not touch
-    // it, and the tool would follow the wrong process anyway.
-    static const char *const tool_env[] = {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH",
-                                           "ROCPROFILER_LIBRARY_CTOR", "HSA_TOOLS_LIB", "ROCP_METRICS"};
-    bool tool = false;
-    for (const char *name : tool_env) { const char *v = getenv(name); if (v && *v) tool = true; }
-    if (!(nf && atoi(nf) != 0) && !tool) {
+    if (worker_process_wanted()) {
         int pfd[2];
         if (pipe(pfd) == 0) {
             const pid_t parent = getpid();

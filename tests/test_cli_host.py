@@ -212,3 +212,23 @@ def test_terminal_n_flags_of_a_packed_arena():
     want = np.array([(1 if s[:1] == b"N" else 0) | (2 if s[-1:] == b"N" else 0) for _, s, _ in reads], dtype=np.uint8)
     assert got.dtype == np.uint8 and (got == want).all()
     assert len(driver.terminal_n_flags(seq[:0], offset[:1])) == 0
+
+
+def test_worker_process_only_outside_profilers():
+    """faqcs_mi hands the command to a forked worker so that its caller gets control back when the outputs are complete
+    (faqcs_cli.cpp:main); never under a profiler (its library has initialised the GPU before main()), and a preloaded library
+    that is not a profiler -- a launcher's guard, a malloc replacement -- does not switch the worker off."""
+    def plan(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "FAQCS_MI_NO_FORK") and not k.startswith(("ROCP", "HSA_TOOLS"))}
+        # (LD_PRELOAD of a file that is not there only makes ld.so print a warning: the decision reads the variable, not the file)
+        r = subprocess.run([CLI, "--process_plan"], env=dict(e, **env), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        assert r.returncode == 0
+        return r.stdout.decode().strip()
+
+    assert plan() == "worker"
+    assert plan(LD_PRELOAD="/nonexistent/libexecguard.so") == "worker"
+    assert plan(LD_PRELOAD="/opt/rocm/lib/librocprofiler-sdk-tool.so") == "one process"
+    assert plan(ROCPROF_OUTPUT_PATH="/tmp/x") == "one process"
+    assert plan(HSA_TOOLS_LIB="libx.so") == "one process"
+    assert plan(FAQCS_MI_NO_FORK="1") == "one process"
+    assert plan(FAQCS_MI_NO_FORK="0") == "worker"
