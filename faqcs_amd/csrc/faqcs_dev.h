@@ -44,7 +44,7 @@ struct DevParams {
 };
 
 enum { FS_SLOTS = 32 };
-enum { FAQCS_PARTIAL_ROW = 8192 };   // >= RowCfg<19, 8>::N_ZERO rounded up to 4: dwords of one flushed copy of a block's LDS accumulators
+enum { FAQCS_PARTIAL_ROW = 13824 };  // >= N_ZERO of every trim_lds variant (RowCfg<19, 8, 160>: 7 962, RowCfg<16, 16, 288>: 13 792): dwords of one flushed copy of a block's LDS accumulators
 enum { FAQCS_PARTIAL_FLUSHES = 8 };  // flushes (rows) a block has room for in one launch: it stops claiming chunks before it would need more
 
 // base_tab fields (6 bits each so a lane can sum up to 63 reads before flushing)

@@ -57,19 +57,30 @@
 
 namespace {
 
-// Q-B's own partition of the positions (C = 19 only): 20 per lane instead of 19, quality rows of 160 cells.  With rows that are a
+// Q-B's own partition of the positions (8 lanes per read, C = 19): 20 per lane instead of 19, quality rows of 160 cells.  With rows that are a
 // multiple of 32 cells the bank of a cell is its position mod 32 whatever the quality; lane rl of a read starts at position 20 rl
 // (banks 0, 20, 8, 28, 16, 4, 24, 12: the multiples of 4) and the four reads of a half wave walk their 20 positions ROTATED by
 // 0, 1, 2, 3 bytes, so the 32 lanes of one ds_add hit 32 different banks -- and four different positions: no two adds of an
 // instruction meet on a bank or on a cell (the round-2 kernel lost half of its LDS-atomic time to such conflicts).
-constexpr int lds_wq(int C) { return C == 19 ? 160 : 0; }
-constexpr int lds_cq(int C) { return C == 19 ? 20 : C; }
+// 16 lanes per read (C = 16, reads of 161 ... 252 bases): a lane's 16 cells are followed by one cell of padding, so lane rl starts on
+// cell 17 rl -- 16 different banks in rows of 288 cells -- and the two reads of a half wave are rotated by 0 and 1 bytes
+// (17 rl + 1 = 17 rl' has no solution with both lanes below 16): conflict-free as well.
+constexpr int lds_wq(int C, int LPR = 8) { return LPR == 16 ? 288 : (C == 19 ? 160 : 0); }
+constexpr int lds_cq(int C, int LPR = 8) { return LPR == 16 ? C : (C == 19 ? 20 : C); }
+constexpr int lds_qstride(int C, int LPR = 8) { return LPR == 16 ? C + 1 : lds_cq(C, LPR); } // cells from one lane's first position to the next lane's
+constexpr int lds_nrot(int C, int LPR = 8) { return LPR == 16 ? 2 : (C == 19 ? 4 : 1); }   // reads of a half wave = byte rotations in use
+// the longest read a variant takes: the step index of a walk lives in the low byte of the argmax keys (codes 254 - step), a window's start
+// and length in a byte each, a read's N count in 8 bits
+constexpr int lds_maxlen(int C, int LPR = 8) { return LPR * C < 252 ? LPR * C : 252; }
 
-template <int C, int NW> struct LdsCfg {
-    using Row = RowCfg<C, 8, lds_wq(C)>;
-    static constexpr int CQ = lds_cq(C);                       // positions per lane in Q-B
-    static constexpr bool ROT = CQ != C;
+template <int C, int NW, int LPR = 8> struct LdsCfg {
+    using Row = RowCfg<C, LPR, lds_wq(C, LPR)>;
+    static constexpr int CQ = lds_cq(C, LPR);                  // positions per lane in Q-B
+    static constexpr int QSTRIDE = lds_qstride(C, LPR);        // cells per lane in a quality row
+    static constexpr int NROT = lds_nrot(C, LPR);
+    static constexpr bool ROT = NROT > 1;
     static constexpr int W = Row::W;
+    static constexpr int MAXLEN = lds_maxlen(C, LPR);
     static constexpr int ND = (W + 3) / 4;                     // dwords of the longest read
     static constexpr int NP = (W + 15) / 16;                   // 16-byte pieces (the out-of-line exact passes)
     static constexpr int NWORD = (ND * 4 + 31) / 32;
@@ -77,11 +88,11 @@ template <int C, int NW> struct LdsCfg {
     static constexpr int O_T3 = O_T2 + 512;                    // [256][2] S: 6-bit count fields, pre ; post (entry[b | 0x80]: b outside the kept window, pre only)
     static constexpr int O_CTR = O_T3 + 512;                   // [8] the block's chunk queue: [0] next unclaimed chunk number, [1] the block's chunk
                                                                // count once known, [4..7] ring: group number << 20 | group id
-    static constexpr int O_TBQ = O_CTR + 8;                    // (ROT) [4][CQ + 1][8] rotated byte masks "positions < vb" of Q-B
-    static constexpr int O_STG = O_TBQ + (ROT ? 4 * (CQ + 1) * 8 : 0);
-    static constexpr int STG_BYTES = 64 * W + 32;              // one arena's span of a chunk + 16-byte alignment slack
+    static constexpr int O_TBQ = O_CTR + 8;                    // (ROT) [NROT][CQ + 1][8] rotated byte masks "positions < vb" of Q-B
+    static constexpr int O_STG = O_TBQ + (ROT ? NROT * (CQ + 1) * 8 : 0);
+    static constexpr int STG_BYTES = 64 * MAXLEN + 32;         // one arena's span of a chunk + 16-byte alignment slack
     static constexpr int STG_DW = (STG_BYTES + 15) / 16 * 4;
-    static constexpr int TAIL_PAD = 64;                        // dwords: a lane may read W bytes from the start of the span's last read
+    static constexpr int TAIL_PAD = W + 64 > 256 ? (W + 64) / 4 : 64; // dwords: a lane may read W + 20 bytes from the start of the span's last read
     static constexpr int lds_dwords() { return O_STG + NW * STG_DW + TAIL_PAD; }
 };
 
@@ -240,7 +251,8 @@ __device__ __noinline__ ExactB exact_bases(const uint8_t *__restrict__ seq, cons
 
 } // namespace
 
-constexpr int lds_waves(int C) { return C <= 19 ? 12 : 8; }
+// waves per block = slots of 64 x MAXLEN bytes next to the accumulators in 160 KB: 12 x 9.8 KB + 37 KB (8 lanes per read), 6 x 16.2 KB + 63 KB (16)
+constexpr int lds_waves(int C, int LPR = 8) { return LPR == 16 ? 6 : (C <= 19 ? 12 : 8); }
 
 // LDS accumulators -> a row of global memory that belongs to THIS block and THIS flush, as plain coalesced 16-byte stores of the
 // cells as they are (pre count in the low, post count in the high half-word); fold_partials, launched behind the trim kernel, adds
@@ -251,7 +263,7 @@ constexpr int lds_waves(int C) { return C <= 19 ? 12 : 8; }
 template <int C, int LPR, int NW>
 __device__ __noinline__ void flush_block_partial(uint32_t *smem, uint32_t *__restrict__ row, const int tid)
 {
-    using Cfg = RowCfg<C, LPR, lds_wq(C)>;
+    using Cfg = RowCfg<C, LPR, lds_wq(C, LPR)>;
     constexpr int N4 = (Cfg::N_ZERO + 3) / 4; // (the dwords behind N_ZERO belong to the base table: copied along, never read back)
     static_assert(N4 * 4 <= FAQCS_PARTIAL_ROW, "partial-sum row");
     __syncthreads();
@@ -271,8 +283,9 @@ template <int C, int LPR>
 __global__ __launch_bounds__(1024) void fold_partials(const uint32_t *__restrict__ partials, const uint32_t *__restrict__ rows_used, const uint32_t n_blocks,
                                                       uint64_t *__restrict__ counters, const faqcs_layout lay, uint32_t *__restrict__ g_next)
 {
-    using Cfg = RowCfg<C, LPR, lds_wq(C)>;
+    using Cfg = RowCfg<C, LPR, lds_wq(C, LPR)>;
     constexpr int W = Cfg::W;
+    constexpr int CQ = lds_cq(C, LPR), QSTRIDE = lds_qstride(C, LPR);
     if (blockIdx.x == 0 && threadIdx.x == 0) *g_next = 0u; // (the trim kernel's group counter: zero between launches)
     __shared__ unsigned long long part[2][16][64];
     const int i = blockIdx.x * 64 + (threadIdx.x & 63); // 64 cells x 16 interleaved sets of rows per block
@@ -304,7 +317,9 @@ __global__ __launch_bounds__(1024) void fold_partials(const uint32_t *__restrict
     const uint32_t R = lay.max_read_length;
     auto add = [&](uint64_t idx, unsigned long long v) { if (v) atomicAdd((unsigned long long *)(counters + idx), v); };
     if (i < Cfg::O_HB) { // position x quality: pre in the low, post in the high half-word
-        const uint32_t q = (uint32_t)(i - Cfg::O_HQ) / Cfg::WQ, p = (uint32_t)(i - Cfg::O_HQ) % Cfg::WQ;
+        const uint32_t q = (uint32_t)(i - Cfg::O_HQ) / Cfg::WQ, cell = (uint32_t)(i - Cfg::O_HQ) % Cfg::WQ;
+        // (a lane's CQ cells may be followed by padding, see lds_qstride: such cells and the ones past the last lane's stay zero)
+        const uint32_t p = QSTRIDE == CQ ? cell : ((cell % QSTRIDE < (uint32_t)CQ && cell / QSTRIDE < (uint32_t)LPR) ? cell / QSTRIDE * CQ + cell % QSTRIDE : R);
         if (p < R) { add(pre_qual + (uint64_t)p * FAQCS_NQ + q, lo); add(post_qual + (uint64_t)p * FAQCS_NQ + q, hi); }
     } else if (i < Cfg::O_LEN) {
         const uint32_t c = (uint32_t)(i - Cfg::O_HB) / W, p = (uint32_t)(i - Cfg::O_HB) % W;
@@ -325,7 +340,7 @@ __global__ __launch_bounds__(1024) void fold_partials(const uint32_t *__restrict
     }
 }
 
-template <int C, int NW, bool WINDOWED, bool EXT>
+template <int C, int NW, bool WINDOWED, bool EXT, int LPR>
 __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
@@ -333,12 +348,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err,
     const uint8_t *__restrict__ tn_flags)
 {
-    constexpr int LPR = 8;
-    using Cfg = RowCfg<C, LPR, lds_wq(C)>;
-    using T = LdsCfg<C, NW>;
+    static_assert(LPR == 8 || (LPR == 16 && C == 16), "lanes per read");
+    using Cfg = RowCfg<C, LPR, lds_wq(C, LPR)>;
+    using T = LdsCfg<C, NW, LPR>;
+    using RW = RowOps<LPR>;
     constexpr int D = Cfg::D, W = Cfg::W, ND = T::ND, NWORD = T::NWORD, NPOS = ND * 4, BMW = Cfg::BMW;
     constexpr int NI = (T::STG_BYTES + 1023) / 1024;
-    static_assert(!Cfg::HQ8 && NPOS <= 255, "step indices must fit the low byte of the argmax keys");
+    static_assert(!Cfg::HQ8 && T::MAXLEN <= 254, "step indices must fit the low byte of the argmax keys");
     static_assert(T::lds_dwords() * 4 <= 160 * 1024, "LDS");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *hb = smem + Cfg::O_HB;
@@ -382,10 +398,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     constexpr int CQ = T::CQ;                         // Q-B: positions per lane (LdsCfg)
     constexpr bool ROT = T::ROT;
     static_assert((CQ + 3) / 4 == D && (!ROT || CQ % 4 == 0), "Q-B works on the same number of dwords per lane");
+    static_assert(T::QSTRIDE * LPR <= Cfg::WQ, "quality rows");
     const int pbase_q = rl * CQ;
-    const uint32_t rot = ROT ? (uint32_t)((lane >> 3) & 3) : 0u; // this read's byte rotation inside a half wave
+    const uint32_t rot = ROT ? (uint32_t)((lane / LPR) & (T::NROT - 1)) : 0u; // this read's byte rotation inside a half wave
     if (ROT) { // rotated byte masks: byte i of row (rot, vb) <-> position (i + rot) mod CQ of the lane, 0xff when that is < vb
-        for (int i = tid; i < 4 * (CQ + 1) * 8; i += NW * 64) {
+        for (int i = tid; i < T::NROT * (CQ + 1) * 8; i += NW * 64) {
             const int r_ = i / ((CQ + 1) * 8), vb_ = (i / 8) % (CQ + 1), k_ = i % 8;
             uint32_t w_ = 0;
             for (int b_ = 0; b_ < 4; ++b_)
@@ -426,7 +443,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     constexpr uint32_t FLUSH_CHUNKS = 65535u / 64u / NW * NW;
 #endif
     constexpr uint32_t MAX_GROUPS = (uint32_t)FAQCS_PARTIAL_FLUSHES * FLUSH_CHUNKS / NW; // groups a block takes at most: one flush row per FLUSH_CHUNKS chunks
-    constexpr uint32_t REG_FLUSH_EVERY = 7; // 6-bit fields: 7 chunks x 8 reads per row <= 63
+    constexpr uint32_t REG_FLUSH_EVERY = LPR == 16 ? 3 : 7; // 6-bit fields: 7 chunks x 8 reads (3 x 16) per row <= 63
     constexpr uint32_t NO_CHUNK = 0xffffffffu;
     auto lds_word = [&](const int i) { return uniu(*(volatile const __attribute__((address_space(3))) uint32_t *)(size_t)(uint32_t)((T::O_CTR + i) * 4)); };
     // the global chunk of the block's chunk number c_ (NO_CHUNK: past the block's last chunk); waits for the group's id if need be
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const uint32_t slot_b = (uint32_t)(T::O_STG + wave * T::STG_DW) * 4u; // LDS byte address of the wave's slot
     const uint32_t offb = ((uint32_t)in_off & 0xffu) * 0x01010101u;
     const bool swar_ok = in_off >= 0 && in_off <= 86; // else every read takes the exact quality pass
-    const uint32_t hq_lane = (uint32_t)(Cfg::O_HQ * 4 + pbase_q * 4) + rot * 4u - (uint32_t)in_off * (uint32_t)(Cfg::WQ * 4); // + raw byte * WQ * 4 = the cell
+    const uint32_t hq_lane = (uint32_t)(Cfg::O_HQ * 4 + rl * T::QSTRIDE * 4) + rot * 4u - (uint32_t)in_off * (uint32_t)(Cfg::WQ * 4); // + raw byte * WQ * 4 = the cell
     // (ROT) rotated byte i stands for position (i + rot) mod CQ: the last three wrap around for some rotations
     const uint32_t *t_bmq = ROT ? smem + T::O_TBQ + rot * (uint32_t)((CQ + 1) * 8) : t_bm; // Q-B's mask rows of this lane
     constexpr int BMQ = ROT ? 8 : BMW, VQ = ROT ? CQ : C + 1;
@@ -458,12 +475,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const uint32_t hb_lane = (uint32_t)(Cfg::O_HB * 4 + pbase * 4);
     FsAcc fs_acc; // FilterStat sums of the chunks since the last spill (7 chunks x 64 reads x 152 bases per wave: inside the packed fields)
     auto spill_base_regs = [&]() {
-        // the 8 rows of the wave hold the same positions: each row starts with another class, so that an add meets at most one other
+        // the 8 (4) rows of the wave hold the same positions: each row starts with another class, so that an add meets at most one other
         // row on its cell instead of seven
         uint32_t sh_c[FAQCS_NBASE], ad_c[FAQCS_NBASE];
 #pragma unroll
         for (int c = 0; c < FAQCS_NBASE; ++c) {
-            uint32_t cp = (uint32_t)c + (uint32_t)(lane >> 3) % FAQCS_NBASE;
+            uint32_t cp = (uint32_t)c + (uint32_t)(lane / LPR) % FAQCS_NBASE;
             cp = cp >= FAQCS_NBASE ? cp - FAQCS_NBASE : cp;
             sh_c[c] = cp * 6u;
             ad_c[c] = hb_lane + cp * (uint32_t)(W * 4);
@@ -543,7 +560,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 if (4 * k + 4 > CQ) m &= low_bytes_(CQ - 4 * k); // (the unrotated masks cover C + 1 positions)
                 qs = __builtin_amdgcn_sad_u8(wq[k] & m, 0u, qs);
             }
-            qs = (uint32_t)RowOps<8>::all_sum((int)qs);
+            qs = (uint32_t)RW::all_sum((int)qs);
             qb_sum = (rl == t) ? qs : qb_sum;
         }
 #pragma unroll
@@ -637,6 +654,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             po += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)po, 0x141, 0xf, 0xf, false);
             ce += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ce, 0x141, 0xf, 0xf, false);
             co += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)co, 0x141, 0xf, 0xf, false);
+            if (LPR == 16) { // the other half of the row (a read of <= 252 bases: 12-bit fields, an N count below 256)
+                pe += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x140, 0xf, 0xf, false);
+                po += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)po, 0x140, 0xf, 0xf, false);
+                ce += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ce, 0x140, 0xf, 0xf, false);
+                co += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)co, 0x140, 0xf, 0xf, false);
+            }
             const bool turn = rl == t;
             tot_pe = turn ? pe : tot_pe; tot_po = turn ? po : tot_po; tot_ce = turn ? ce : tot_ce; tot_co = turn ? co : tot_co;
             // ---- upper-case N inside the kept window (count_poly_n, trim.cpp:578-597): looked at only when the read has enough N
@@ -661,7 +684,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                         const uint32_t next = k + 1 < D ? __builtin_amdgcn_alignbyte(nb[k + 1], nb[k], 1u) : (nb[k] >> 8);
                         hit |= here & next;
                     }
-                    const bool rowhit = RowOps<8>::all_or(hit) != 0u;
+                    // (C a multiple of 4: the neighbour of the lane's last position is not among its D dwords -- the next lane's first byte)
+                    if (C % 4 == 0) hit |= (nb[D - 1] >> 24) & RW::next(nb[0] & 0x80u);
+                    const bool rowhit = RW::all_or(hit) != 0u;
                     pairhit = turn ? rowhit : pairhit;
                 }
             } else if (MODE == 0) {
@@ -792,7 +817,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // pad behind the span: the position-parallel passes read up to W + 5 bytes past a short last read, and what they
             // find there must be a valid quality byte (see quality_cells)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < (W + 20 + 63) / 64; ++i) {
                 const uint32_t o = ce - cs + shq + (uint32_t)(64 * i + lane);
                 if (64 * i + lane < W + 20 && o < (uint32_t)T::STG_BYTES) lds_st_u8(slot_b + o, (uint32_t)in_off);
             }
@@ -1373,16 +1398,16 @@ hipError_t faqcs_launch_terminal_n_flags(const uint8_t *seq, const uint32_t *off
     return hipGetLastError();
 }
 
-template <int C, bool WINDOWED, bool EXT>
+template <int C, bool WINDOWED, bool EXT, int LPR = 8>
 static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                   uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
                                   unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
                                   int n_cu, hipStream_t st, const uint8_t *tn_flags)
 {
-    constexpr int NW = lds_waves(C);
-    constexpr size_t lds = (size_t)LdsCfg<C, NW>::lds_dwords() * 4;
+    constexpr int NW = lds_waves(C, LPR);
+    constexpr size_t lds = (size_t)LdsCfg<C, NW, LPR>::lds_dwords() * 4;
     static unsigned long long attr_done = 0;
-    auto kern = trim_lds<C, NW, WINDOWED, EXT>;
+    auto kern = trim_lds<C, NW, WINDOWED, EXT, LPR>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const uint32_t chunks = (n_reads + 63) / 64;
     uint32_t grid = (chunks + NW - 1) / NW;
@@ -1397,7 +1422,7 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
                        reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err, tn_flags);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    hipLaunchKernelGGL((fold_partials<C, 8>), dim3((RowCfg<C, 8, lds_wq(C)>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, P.partial_rows, grid, counters, P.lay, err + 8);
+    hipLaunchKernelGGL((fold_partials<C, LPR>), dim3((RowCfg<C, LPR, lds_wq(C, LPR)>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, P.partial_rows, grid, counters, P.lay, err + 8);
     return hipGetLastError();
 }
 
@@ -1428,6 +1453,11 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
     if (max_len > 76 && max_len <= 104) FAQCS_LDS_CASE(13);  // 2x100
     if (max_len > 104 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x125, 2x150
 #undef FAQCS_LDS_CASE
+    // 16 lanes per read: 161 ... 252 bases (2x250, 2x251); FAQCS_TRIM_LDS16=0 switches it off (A/B against trim_filter_accumulate)
+    static const bool lds16_on = [] { const char *e = getenv("FAQCS_TRIM_LDS16"); return !e || atoi(e) != 0; }();
+    if (lds16_on && max_len > 160 && max_len <= (uint32_t)lds_maxlen(16, 16))
+        return ext ? (windowed ? launch_trim_lds<16, true, true, 16>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, true, 16>(FAQCS_LDS_ARGS))
+                   : (windowed ? launch_trim_lds<16, true, false, 16>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, false, 16>(FAQCS_LDS_ARGS));
 #undef FAQCS_LDS_ARGS
     return hipErrorNotSupported;
 }

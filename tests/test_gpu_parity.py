@@ -259,9 +259,11 @@ def test_long_read_limits():
 
 
 @pytest.mark.parametrize("args", [OPTION_SETS[i] for i in (0, 1, 2, 8, 10, 13, 15, 18, 21, 23)], ids=lambda a: " ".join(a) or "default")
-@pytest.mark.parametrize("kind,maxlen", [("adv", 157), ("adv", 120), ("ragged", 104), ("adv", 200), ("ragged", 112), ("adv", 75), ("ragged", 50)])
+@pytest.mark.parametrize("kind,maxlen", [("adv", 157), ("adv", 120), ("ragged", 104), ("adv", 200), ("ragged", 112), ("adv", 75), ("ragged", 50),
+                                         ("adv", 252), ("adv", 256), ("ragged", 224)])
 def test_every_kernel_width_matches_oracle(args, kind, maxlen):
-    """One batch per position-slot width the dispatcher can pick (4 lanes per read: C = 16/19; 8 lanes: C = 13/16/19/20; 16 lanes: C = 13/16)."""
+    """One batch per position-slot width the dispatcher can pick (4 lanes per read: C = 16/19; 8 lanes: C = 13/16/19/20; 16 lanes: C = 13/16;
+    trim_lds with 16 lanes per read up to 252 bases, trim_filter_accumulate past that and for multiples of 32)."""
     rng = np.random.Generator(np.random.PCG64([3, len(kind), maxlen, OPTION_SETS.index(args), SEED]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     reads = random_batch(rng, 500 if "--adapter" in args else 1500, maxlen, kind)
@@ -269,7 +271,7 @@ def test_every_kernel_width_matches_oracle(args, kind, maxlen):
 
 
 @pytest.mark.parametrize("in_off", [40, 64, 90, 100])
-@pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 100), ("adv", 70)])
+@pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 100), ("adv", 70), ("adv", 250), ("ragged", 251)])
 def test_quality_offsets_that_leave_scores_outside_the_valid_range(in_off, kind, maxlen):
     """Raw quality bytes are generated for Phred+33; decoding them with a larger offset makes most scores negative (clamped to
     0 by the trimmers, not by the averages) -- the per-position exact pass of the two-phase kernel instead of its four-bytes-per-
@@ -1194,7 +1196,7 @@ def test_at_rich_reads_match_oracle(args):
 
 
 @pytest.mark.parametrize("args", [[], ["--lc", "0.5"], ["--mode", "BWA"], ["--avg_q", "20", "-n", "1"]], ids=["default", "lc05", "bwa", "avgq"])
-@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 128, 144, 148, 150, 152, 156, 160])
+@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 128, 144, 148, 150, 152, 156, 160, 161, 164, 200, 240, 248, 250, 251, 252])
 def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, args):
     """Every read of the batch has the same length (mostly a multiple of 4: the wave's dword loops stop exactly at the read's
     end), a low-quality head that the 5' walk cuts and a high-quality tail, so the kept window is [a, L) with a > 0: its base
@@ -1217,7 +1219,9 @@ def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, a
 @pytest.mark.parametrize("L,args,kernel", [
     (150, [], "trim_lds"), (151, ["--adapter"], "trim_lds"), (100, ["--mode", "HARD", "-q", "10"], "trim_lds"), (125, ["--qc_only"], "trim_lds"),
     (128, [], "trim_tpr"), (96, [], "trim_tpr"), (75, [], "trim_tpr"), (160, [], "trim_tpr"),
-    (150, ["--replace_to_N_q", "15"], "trim_filter_accumulate"), (250, [], "trim_filter_accumulate"), (128, ["--qc_only"], "trim_filter_accumulate"),
+    (150, ["--replace_to_N_q", "15"], "trim_filter_accumulate"), (128, ["--qc_only"], "trim_filter_accumulate"),
+    (250, [], "trim_lds"), (251, ["--adapter", "--polyA"], "trim_lds"), (200, ["--mode", "BWA", "--avg_q", "20"], "trim_lds"), (161, [], "trim_lds"), (252, [], "trim_lds"),
+    (253, [], "trim_filter_accumulate"), (224, [], "trim_filter_accumulate"), (250, ["--replace_to_N_q", "15"], "trim_filter_accumulate"),
 ])
 def test_dispatcher_picks_the_documented_trim_kernel(L, args, kernel):
     """DESIGN.md section 4 names the trim kernel of every (read length, option set) class; faqcs_kernel_report() says which one ran."""
