@@ -51,6 +51,13 @@
 #ifndef FAQCS_LDS_SUM_UNROLL
 #define FAQCS_LDS_SUM_UNROLL 4
 #endif
+// reads per chunk of the 16-lanes-per-read variants (A/B on MI355X: see faqcs_launch_trim_lds)
+#ifndef FAQCS_LDS16_RPC
+#define FAQCS_LDS16_RPC 32
+#endif
+#ifndef FAQCS_LDS16_NW
+#define FAQCS_LDS16_NW 12
+#endif
 #ifndef FAQCS_LDS_SA_UNROLL
 #define FAQCS_LDS_SA_UNROLL 2
 #endif
@@ -73,7 +80,7 @@ constexpr int lds_nrot(int C, int LPR = 8) { return LPR == 16 ? 2 : (C == 19 ? 4
 // and length in a byte each, a read's N count in 8 bits
 constexpr int lds_maxlen(int C, int LPR = 8) { return LPR * C < 252 ? LPR * C : 252; }
 
-template <int C, int NW, int LPR = 8> struct LdsCfg {
+template <int C, int NW, int LPR = 8, int RPC = 64> struct LdsCfg {
     using Row = RowCfg<C, LPR, lds_wq(C, LPR)>;
     static constexpr int CQ = lds_cq(C, LPR);                  // positions per lane in Q-B
     static constexpr int QSTRIDE = lds_qstride(C, LPR);        // cells per lane in a quality row
@@ -90,7 +97,7 @@ template <int C, int NW, int LPR = 8> struct LdsCfg {
                                                                // count once known, [4..7] ring: group number << 20 | group id
     static constexpr int O_TBQ = O_CTR + 8;                    // (ROT) [NROT][CQ + 1][8] rotated byte masks "positions < vb" of Q-B
     static constexpr int O_STG = O_TBQ + (ROT ? NROT * (CQ + 1) * 8 : 0);
-    static constexpr int STG_BYTES = 64 * MAXLEN + 32;         // one arena's span of a chunk + 16-byte alignment slack
+    static constexpr int STG_BYTES = RPC * MAXLEN + 32;        // one arena's span of a chunk (RPC reads) + 16-byte alignment slack
     static constexpr int STG_DW = (STG_BYTES + 15) / 16 * 4;
     static constexpr int TAIL_PAD = W + 64 > 256 ? (W + 64) / 4 : 64; // dwords: a lane may read W + 20 bytes from the start of the span's last read
     static constexpr int lds_dwords() { return O_STG + NW * STG_DW + TAIL_PAD; }
@@ -187,11 +194,15 @@ __device__ __forceinline__ void walk_step(const uint32_t w, const int it, const 
 template <int NI>
 __device__ __forceinline__ void dma_span(const uint8_t *g, const uint32_t nbytes, uint32_t *slot, const int lane)
 {
+    // (written so that nothing per-lane depends on i: the lane's address once, i x 1 024 in the instruction's offset field or a scalar
+    // operand -- otherwise the compiler keeps NI lane-dependent values alive across the whole kernel and spills them)
+    const uint8_t *gl = g + lane * 16;
+    const uint32_t l16 = (uint32_t)lane * 16u;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         if ((uint32_t)(i * 1024) >= nbytes) break; // wave-uniform
-        if ((uint32_t)(i * 1024 + lane * 16) < nbytes)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i * 1024 + lane * 16),
+        if (l16 < nbytes - (uint32_t)(i * 1024))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gl + i * 1024),
                                              (__attribute__((address_space(3))) void *)(slot + i * 256), 16, 0, 0);
     }
 }
@@ -252,7 +263,7 @@ __device__ __noinline__ ExactB exact_bases(const uint8_t *__restrict__ seq, cons
 } // namespace
 
 // waves per block = slots of 64 x MAXLEN bytes next to the accumulators in 160 KB: 12 x 9.8 KB + 37 KB (8 lanes per read), 6 x 16.2 KB + 63 KB (16)
-constexpr int lds_waves(int C, int LPR = 8) { return LPR == 16 ? 6 : (C <= 19 ? 12 : 8); }
+constexpr int lds_waves(int C, int LPR = 8, int RPC = 64) { return LPR == 16 ? (RPC == 64 ? 6 : FAQCS_LDS16_NW) : (C <= 19 ? 12 : 8); }
 
 // LDS accumulators -> a row of global memory that belongs to THIS block and THIS flush, as plain coalesced 16-byte stores of the
 // cells as they are (pre count in the low, post count in the high half-word); fold_partials, launched behind the trim kernel, adds
@@ -340,7 +351,10 @@ __global__ __launch_bounds__(1024) void fold_partials(const uint32_t *__restrict
     }
 }
 
-template <int C, int NW, bool WINDOWED, bool EXT, int LPR>
+// RPC = reads per chunk: 64 (one per lane in the lane-per-read passes) or 32 -- half the lanes idle there, but a slot of half the size: reads of
+// 161 ... 252 bases get 12 waves per CU instead of 6.  The position-parallel passes run TPR = RPC x LPR / 64 steps per chunk; the lane that owns a
+// read in the lane-per-read passes is lane t of the row of LPR lanes that works on it in step t.
+template <int C, int NW, bool WINDOWED, bool EXT, int LPR, int RPC>
 __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
     const uint32_t *__restrict__ off, const uint32_t n_reads, const uint32_t *__restrict__ ad_sl,
@@ -350,8 +364,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 {
     static_assert(LPR == 8 || (LPR == 16 && C == 16), "lanes per read");
     using Cfg = RowCfg<C, LPR, lds_wq(C, LPR)>;
-    using T = LdsCfg<C, NW, LPR>;
+    static_assert(RPC <= 64 && (RPC * LPR) % 64 == 0, "reads per chunk: the same number for every row of LPR lanes");
+    using T = LdsCfg<C, NW, LPR, RPC>;
     using RW = RowOps<LPR>;
+    constexpr int TPR = RPC * LPR / 64;               // reads a row of LPR lanes works on per chunk
     constexpr int D = Cfg::D, W = Cfg::W, ND = T::ND, NWORD = T::NWORD, NPOS = ND * 4, BMW = Cfg::BMW;
     constexpr int NI = (T::STG_BYTES + 1023) / 1024;
     static_assert(!Cfg::HQ8 && T::MAXLEN <= 254, "step indices must fit the low byte of the argmax keys");
@@ -370,6 +386,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const int rowb = lane & (64 - LPR);
     const int wave = uni(tid >> 6);
     const int pbase = rl * C;
+    const bool owner = RPC == 64 || rl < TPR;                                            // this lane stands for a read in the lane-per-read passes
+    const uint32_t ridx = RPC == 64 ? (uint32_t)lane : (uint32_t)((lane / LPR) * TPR + rl); // ... for read `ridx` of the chunk
 
     for (int i = tid; i < Cfg::N_ZERO; i += NW * 64) smem[i] = 0u;
     for (int i = tid; i < 256; i += NW * 64) {
@@ -413,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     uint32_t three = 3u, wx4 = (uint32_t)(Cfg::WQ * 4);
     asm volatile("" : "+v"(three), "+v"(wx4)); // VGPR operands for the SDWA instructions
     if (tid == 0 && blockIdx.x == 0 && (uint32_t)(size_t)((lds_u32_ptr)smem) != 0u) atomicOr(err, 4u);
-    const uint32_t total_chunks = (n_reads + 63) >> 6;
+    const uint32_t total_chunks = (n_reads + RPC - 1) / RPC;
     const uint32_t n_groups = (total_chunks + NW - 1) / NW;
     uint32_t *g_next = err + 8; // groups handed out beyond the first gridDim.x (zero between launches: fold_partials resets it)
     if (tid == 0) {
@@ -440,10 +458,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #ifdef FAQCS_LDS_TEST_FLUSH_CHUNKS // (test build: flush every few chunks, so that a small launch goes through many flushes and fills every block's rows)
     constexpr uint32_t FLUSH_CHUNKS = (uint32_t)(FAQCS_LDS_TEST_FLUSH_CHUNKS) / NW * NW;
 #else
-    constexpr uint32_t FLUSH_CHUNKS = 65535u / 64u / NW * NW;
+    constexpr uint32_t FLUSH_CHUNKS = 65535u / RPC / NW * NW;
 #endif
     constexpr uint32_t MAX_GROUPS = (uint32_t)FAQCS_PARTIAL_FLUSHES * FLUSH_CHUNKS / NW; // groups a block takes at most: one flush row per FLUSH_CHUNKS chunks
-    constexpr uint32_t REG_FLUSH_EVERY = LPR == 16 ? 3 : 7; // 6-bit fields: 7 chunks x 8 reads (3 x 16) per row <= 63
+    constexpr uint32_t REG_FLUSH_EVERY = 63 / TPR; // 6-bit fields: 7 chunks x 8 reads (3 x 16) per row <= 63
     constexpr uint32_t NO_CHUNK = 0xffffffffu;
     auto lds_word = [&](const int i) { return uniu(*(volatile const __attribute__((address_space(3))) uint32_t *)(size_t)(uint32_t)((T::O_CTR + i) * 4)); };
     // the global chunk of the block's chunk number c_ (NO_CHUNK: past the block's last chunk); waits for the group's id if need be
@@ -702,7 +720,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     // was measured: +5 VALU per read for the register copies and no shorter waits; the LDS pipeline itself is the limit)
 #define FAQCS_B_LOOP(I0, I1, CELLS)                                                                                   \
     {                                                                                                                 \
-        _Pragma("unroll 1") for (int t = 0; t < LPR; ++t) {                                                          \
+        _Pragma("unroll 1") for (int t = 0; t < TPR; ++t) {                                                          \
             if (base + (uint32_t)t >= n_reads) break; /* wave-uniform: no row has a read left */                      \
             const uint32_t a0_ = (uint32_t)__shfl((int)(I0), rowb + t), a1_ = (uint32_t)__shfl((int)(I1), rowb + t);   \
             RawB cur_;                                                                                                \
@@ -720,9 +738,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     uint32_t p_off = 0, p_end = 0;
     auto fetch_offsets = [&](const uint32_t chunk_) { // (a chunk past the last one of the launch: a chunk of no reads)
         if (chunk_ != NO_CHUNK) {
-            const uint32_t my_ = (chunk_ << 6) + (uint32_t)lane;
-            p_off = off[my_ < n_reads ? my_ : n_reads];
-            p_end = off[my_ < n_reads ? my_ + 1 : n_reads];
+            // (a lane that owns no read sits at the end of the chunk's last read, with length 0)
+            const uint32_t lim_ = umin_(chunk_ * RPC + RPC, n_reads), my_ = owner ? chunk_ * RPC + ridx : lim_;
+            p_off = off[my_ < lim_ ? my_ : lim_];
+            p_end = off[my_ < lim_ ? my_ + 1 : lim_];
         }
     };
     // What a chunk needs from global memory before its first pass: the quality span (DMA into the wave's slot), the adapter pre-pass's
@@ -731,8 +750,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     ChunkLoads ld = {0, 0, 0, 0};
     bool pre_issued = false;
     auto issue_loads = [&](const uint32_t chunk_, const uint32_t o_, const uint32_t e_, ChunkLoads &L) {
-        const uint32_t my_ = (chunk_ << 6) + (uint32_t)lane;
-        const bool mine_ = my_ < n_reads;
+        const uint32_t my_ = chunk_ * RPC + ridx;
+        const bool mine_ = owner && my_ < n_reads;
         const uint32_t len_ = e_ - o_;
         const uint32_t cs_ = uniu(o_), ce_ = (uint32_t)__builtin_amdgcn_readlane((int)e_, 63);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (every read of the slot's previous content has returned)
@@ -781,9 +800,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         const uint32_t chunk_next = chunk_of(c_next);
         {
             const uint32_t chunk = chunk_cur;
-            const uint32_t base = chunk << 6;
-            const uint32_t my = base + lane;
-            const bool mine = my < n_reads;
+            const uint32_t base = chunk * RPC;
+            const uint32_t my = base + ridx;
+            const bool mine = owner && my < n_reads;
             // ---- the span of the QUALITY arena -> LDS, and the per-read words that come from global memory.  Requested at the end
             // of the previous chunk (issue_loads below, once the slot is no longer read); here for a wave's first chunk only.
             if (!pre_issued) issue_loads(chunk_cur, p_off, p_end, ld);
@@ -816,10 +835,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             }
             // pad behind the span: the position-parallel passes read up to W + 5 bytes past a short last read, and what they
             // find there must be a valid quality byte (see quality_cells)
+            {
+                const uint32_t o0 = ce - cs + shq + (uint32_t)lane;
 #pragma unroll
-            for (int i = 0; i < (W + 20 + 63) / 64; ++i) {
-                const uint32_t o = ce - cs + shq + (uint32_t)(64 * i + lane);
-                if (64 * i + lane < W + 20 && o < (uint32_t)T::STG_BYTES) lds_st_u8(slot_b + o, (uint32_t)in_off);
+                for (int i = 0; i < (W + 20 + 63) / 64; ++i)
+                    if (lane < W + 20 - 64 * i && o0 < (uint32_t)(T::STG_BYTES - 64 * i)) lds_st_u8((slot_b + o0) + (uint32_t)(64 * i), (uint32_t)in_off);
             }
             FAQCS_STAMP(0)
 
@@ -868,8 +888,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     if ((uint32_t)(i * 64) >= n16) break; // wave-uniform
-                    if ((uint32_t)(i * 64 + lane) < n16) {
-                        const U4 v = *(const __attribute__((address_space(3))) U4 *)(size_t)(slot_b + (uint32_t)(i * 1024 + lane * 16));
+                    if ((uint32_t)lane < n16 - (uint32_t)(i * 64)) {
+                        const U4 v = *(const __attribute__((address_space(3))) U4 *)(size_t)((slot_b + (uint32_t)(lane * 16)) + (uint32_t)(i * 1024));
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { const uint32_t x = v[e] - offb; acc |= x | (x + c_hi) | v[e]; }
                     }
@@ -1145,7 +1165,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t v_hit_w = v_hit;
 #define FAQCS_S_LOOP(I1, MODE)                                                                                        \
     {                                                                                                                 \
-        _Pragma("unroll 1") for (int t = 0; t < LPR; ++t) {                                                          \
+        _Pragma("unroll 1") for (int t = 0; t < TPR; ++t) {                                                          \
             if (base + (uint32_t)t >= n_reads) break; /* wave-uniform: no row has a read left */                      \
             const uint32_t a1_ = (uint32_t)__shfl((int)(I1), rowb + t);                                               \
             if (MODE == 1 && !__any(((a1_ >> 16) & 1u) != 0u)) continue;                                              \
@@ -1317,7 +1337,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 }
                 const uint32_t ui1 = (uint32_t)a | ((uint32_t)n << 8) | (veto ? 1u << 16 : 0u);
 #pragma unroll 1
-                for (int t = 0; t < LPR; ++t) {
+                for (int t = 0; t < TPR; ++t) {
                     const uint32_t i1 = (uint32_t)__shfl((int)ui1, rowb + t);
                     if (!__any(((i1 >> 16) & 1u) != 0u)) continue;
                     const uint32_t i0 = (uint32_t)__shfl((int)qi0, rowb + t);
@@ -1398,18 +1418,18 @@ hipError_t faqcs_launch_terminal_n_flags(const uint8_t *seq, const uint32_t *off
     return hipGetLastError();
 }
 
-template <int C, bool WINDOWED, bool EXT, int LPR = 8>
+template <int C, bool WINDOWED, bool EXT, int LPR = 8, int RPC = 64>
 static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                   uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
                                   unsigned long long *rec_pre, unsigned long long *rec_post, uint64_t *counters, uint32_t *err,
                                   int n_cu, hipStream_t st, const uint8_t *tn_flags)
 {
-    constexpr int NW = lds_waves(C, LPR);
-    constexpr size_t lds = (size_t)LdsCfg<C, NW, LPR>::lds_dwords() * 4;
+    constexpr int NW = lds_waves(C, LPR, RPC);
+    constexpr size_t lds = (size_t)LdsCfg<C, NW, LPR, RPC>::lds_dwords() * 4;
     static unsigned long long attr_done = 0;
-    auto kern = trim_lds<C, NW, WINDOWED, EXT, LPR>;
+    auto kern = trim_lds<C, NW, WINDOWED, EXT, LPR, RPC>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
-    const uint32_t chunks = (n_reads + 63) / 64;
+    const uint32_t chunks = (n_reads + RPC - 1) / RPC;
     uint32_t grid = (chunks + NW - 1) / NW;
     if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu; // one block per CU: its LDS holds a slot per wave
     if (grid == 0) return hipSuccess;
@@ -1417,7 +1437,7 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
 #ifdef FAQCS_LDS_TEST_FLUSH_CHUNKS
     if ((uint64_t)chunks > (uint64_t)grid * FAQCS_PARTIAL_FLUSHES * ((uint32_t)(FAQCS_LDS_TEST_FLUSH_CHUNKS) / NW * NW)) return hipErrorNotSupported; // (up to the brim)
 #else
-    if ((uint64_t)chunks > (uint64_t)grid * FAQCS_PARTIAL_FLUSHES * (65535u / 64u / NW * NW) * 3 / 4) return hipErrorNotSupported;
+    if ((uint64_t)chunks > (uint64_t)grid * FAQCS_PARTIAL_FLUSHES * (65535u / RPC / NW * NW) * 3 / 4) return hipErrorNotSupported;
 #endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
                        reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err, tn_flags);
@@ -1456,8 +1476,8 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
     // 16 lanes per read: 161 ... 252 bases (2x250, 2x251); FAQCS_TRIM_LDS16=0 switches it off (A/B against trim_filter_accumulate)
     static const bool lds16_on = [] { const char *e = getenv("FAQCS_TRIM_LDS16"); return !e || atoi(e) != 0; }();
     if (lds16_on && max_len > 160 && max_len <= (uint32_t)lds_maxlen(16, 16))
-        return ext ? (windowed ? launch_trim_lds<16, true, true, 16>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, true, 16>(FAQCS_LDS_ARGS))
-                   : (windowed ? launch_trim_lds<16, true, false, 16>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, false, 16>(FAQCS_LDS_ARGS));
+        return ext ? (windowed ? launch_trim_lds<16, true, true, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, true, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS))
+                   : (windowed ? launch_trim_lds<16, true, false, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, false, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS));
 #undef FAQCS_LDS_ARGS
     return hipErrorNotSupported;
 }
