@@ -490,18 +490,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     uint32_t any_err = 0;
     // the register fields -> the block's position x base cells.  Straight-line: one LDS add per field, no test per lane (the
     // branchy form -- skip a zero field -- cost 23 000 clocks per call: 95 divergent regions with an LDS round trip each)
-    const uint32_t hb_lane = (uint32_t)(Cfg::O_HB * 4 + pbase * 4);
     FsAcc fs_acc; // FilterStat sums of the chunks since the last spill (7 chunks x 64 reads x 152 bases per wave: inside the packed fields)
     auto spill_base_regs = [&]() {
         // the 8 (4) rows of the wave hold the same positions: each row starts with another class, so that an add meets at most one other
         // row on its cell instead of seven
-        uint32_t sh_c[FAQCS_NBASE], ad_c[FAQCS_NBASE];
+        // (from a lane number the compiler cannot see through: these ten values are needed once in seven chunks -- hoisted out of the chunk loop
+        // they would occupy ten registers for the whole kernel)
+        uint32_t sh_c[FAQCS_NBASE], ad_c[FAQCS_NBASE], lane_o = (uint32_t)lane;
+        asm volatile("" : "+v"(lane_o));
+        const uint32_t hb_lane_o = (uint32_t)(Cfg::O_HB * 4) + (lane_o & (uint32_t)(LPR - 1)) * (uint32_t)(C * 4);
 #pragma unroll
         for (int c = 0; c < FAQCS_NBASE; ++c) {
-            uint32_t cp = (uint32_t)c + (uint32_t)(lane / LPR) % FAQCS_NBASE;
+            uint32_t cp = (uint32_t)c + (lane_o / (uint32_t)LPR) % FAQCS_NBASE;
             cp = cp >= FAQCS_NBASE ? cp - FAQCS_NBASE : cp;
             sh_c[c] = cp * 6u;
-            ad_c[c] = hb_lane + cp * (uint32_t)(W * 4);
+            ad_c[c] = hb_lane_o + cp * (uint32_t)(W * 4);
         }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t data = __builtin_amdgcn_perm(cm[j >> 2], im[j >> 2], sel);
             const uint32_t ad = ((j & 3) == 0 ? byte_mul<0>(wq[j >> 2], wx4) : (j & 3) == 1 ? byte_mul<1>(wq[j >> 2], wx4)
                                  : (j & 3) == 2 ? byte_mul<2>(wq[j >> 2], wx4) : byte_mul<3>(wq[j >> 2], wx4)) +
-                                ((ROT && j >= CQ - 3 && rot >= (uint32_t)(CQ - j)) ? hq_lane - (uint32_t)(CQ * 4) : hq_lane);
+                                ((ROT && j >= CQ - (T::NROT - 1) && rot >= (uint32_t)(CQ - j)) ? hq_lane - (uint32_t)(CQ * 4) : hq_lane);
 #ifdef FAQCS_LDS_QB_NOCONFLICT // (diagnostic build, wrong results: every lane on a bank of its own -- what the conflicts of these adds cost)
             lds_add_u32((ad & 0x3u) + (uint32_t)(Cfg::O_HQ * 4) + (uint32_t)lane * 4u + 256u * (uint32_t)j, data);
 #elif !defined(FAQCS_LDS_NO_QB_ATOMICS)
@@ -644,6 +647,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const int k = j >> 2;
+#ifdef FAQCS_LDS16_S_HALVES
+            if (LPR == 16 && j == FAQCS_LDS16_S_HALVES) __builtin_amdgcn_sched_barrier(0); // (the look-ups of one half in flight at a time: registers)
+#endif
             if ((j & 3) == 0) {
                 if (MODE == 0) seen7 |= w[k];
                 w[k] ^= ~((EXT && chk) ? 0u : inw[k]) & 0x88888888u; // (w[k] is the table index from here on; the byte is put back for the N tests)
