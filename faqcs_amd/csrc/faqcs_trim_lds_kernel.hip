@@ -97,7 +97,8 @@ template <int C, int NW, int LPR = 8, int RPC = 64> struct LdsCfg {
                                                                // count once known, [4..7] ring: group number << 20 | group id
     static constexpr int O_TBQ = O_CTR + 8;                    // (ROT) [NROT][CQ + 1][8] rotated byte masks "positions < vb" of Q-B
     static constexpr int O_STG = O_TBQ + (ROT ? NROT * (CQ + 1) * 8 : 0);
-    static constexpr int STG_BYTES = RPC * MAXLEN + 32;        // one arena's span of a chunk (RPC reads) + 16-byte alignment slack
+    static constexpr int PADLEN = MAXLEN / 32 * 32;            // the longest read of a chunk staged as padded rows (dma_rows): L + 16 bytes each
+    static constexpr int STG_BYTES = RPC * (PADLEN + 16 > MAXLEN ? PADLEN + 16 : MAXLEN) + 32; // one arena's span of a chunk (RPC reads) + 16-byte alignment slack
     static constexpr int STG_DW = (STG_BYTES + 15) / 16 * 4;
     static constexpr int TAIL_PAD = W + 64 > 256 ? (W + 64) / 4 : 64; // dwords: a lane may read W + 20 bytes from the start of the span's last read
     static constexpr int lds_dwords() { return O_STG + NW * STG_DW + TAIL_PAD; }
@@ -204,6 +205,28 @@ __device__ __forceinline__ void dma_span(const uint8_t *g, const uint32_t nbytes
         if (l16 < nbytes - (uint32_t)(i * 1024))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gl + i * 1024),
                                              (__attribute__((address_space(3))) void *)(slot + i * 256), 16, 0, 0);
+    }
+}
+
+// The same for a chunk of n_rows reads that all have L bases, L a multiple of 32: read r goes to row r of L + 16 bytes.  With the reads
+// back to back, equal lengths of 4 x 32 k bytes put "dword d of my read" of EVERY lane on one LDS bank (2x128: each ds_read of the
+// lane-per-read walks took 32 passes); rows of L / 4 + 4 dwords spread them over 8 banks.  Each lane of a DMA instruction names its own
+// global address, so the padded layout costs one instruction more per span: unit u = 64 i + lane of the slot is unit u mod U of row u / U
+// (U = L / 16 + 1 units of 16 bytes per row; the last unit of a row holds the 16 bytes behind the read -- the head of the next one).
+template <int NI>
+__device__ __forceinline__ void dma_rows(const uint8_t *g, const uint32_t L, const uint32_t n_rows, uint32_t *slot, const int lane)
+{
+    const uint32_t U = L / 16u + 1u, total = n_rows * U;
+    const uint32_t M = (65536u + U - 1u) / U; // u / U == (u * M) >> 16 for u < 4 096 (U <= 16)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if ((uint32_t)(i * 64) >= total) break; // wave-uniform
+        const uint32_t u = (uint32_t)(i * 64 + lane);
+        if (u < total) {
+            const uint32_t r = (u * M) >> 16, col = u - r * U;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (size_t)(r * L + col * 16u)),
+                                             (__attribute__((address_space(3))) void *)(slot + i * 256), 16, 0, 0);
+        }
     }
 }
 
@@ -752,8 +775,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     };
     // What a chunk needs from global memory before its first pass: the quality span (DMA into the wave's slot), the adapter pre-pass's
     // words, the first / last base of every read (mask_quality_terminal_N looks at them before the qualities are used).
-    struct ChunkLoads { uint32_t v_off, v_end, v_sl, v_hit; };
-    ChunkLoads ld = {0, 0, 0, 0};
+    struct ChunkLoads { uint32_t v_off, v_end, v_sl, v_hit, pad_len; }; // pad_len (wave-uniform): 0, or the length all reads of the chunk have (padded rows)
+    ChunkLoads ld = {0, 0, 0, 0, 0};
+    // one arena's bytes of the chunk -> the wave's slot: the contiguous span, or one padded row per read (dma_rows)
+    auto stage = [&](const uint8_t *arena, const uint32_t cs_, const uint32_t ce_, const uint32_t sh_, const uint32_t pad_len_) {
+        if (pad_len_) dma_rows<NI>(arena + cs_ - sh_, pad_len_, (uint32_t)RPC, slot, lane);
+        else dma_span<NI>(arena + cs_ - sh_, ce_ - cs_ + sh_, slot, lane);
+    };
     bool pre_issued = false;
     auto issue_loads = [&](const uint32_t chunk_, const uint32_t o_, const uint32_t e_, ChunkLoads &L) {
         const uint32_t my_ = chunk_ * RPC + ridx;
@@ -762,7 +790,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         const uint32_t cs_ = uniu(o_), ce_ = (uint32_t)__builtin_amdgcn_readlane((int)e_, 63);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (every read of the slot's previous content has returned)
         const uint32_t shq_ = (uint32_t)((size_t)(qual + cs_) & 15u);
-        dma_span<NI>(qual + cs_ - shq_, ce_ - cs_ + shq_, slot, lane);
+        // every read of the chunk as long as the first one, a multiple of 32 bases: padded rows (a chunk with fewer than RPC reads: never)
+        const uint32_t len0_ = uniu(len_);
+        const bool rows_ = (len0_ & 31u) == 0u && len0_ != 0u && len0_ <= (uint32_t)T::PADLEN && __all(!owner || (mine_ && len_ == len0_));
+        L.pad_len = rows_ ? len0_ : 0u;
+        stage(qual, cs_, ce_, shq_, L.pad_len);
         L.v_off = o_; L.v_end = e_;
         L.v_sl = (WINDOWED && ad_sl && mine_) ? ad_sl[my_] : (len_ << 16);
         L.v_hit = (ad_hit && mine_) ? ad_hit[my_] : 0u;
@@ -819,7 +851,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t cs = uniu(v_off), ce = (uint32_t)__builtin_amdgcn_readlane((int)v_end, 63);
             const int len = (int)v_len;
             const uint32_t shq = (uint32_t)((size_t)(qual + cs) & 15u);
-            const uint32_t rowq = v_off - cs + shq; // this lane's read inside the slot
+            const uint32_t pad_len = uniu(ld.pad_len), pad_stride = pad_len + 16u;
+            const uint32_t rowq = pad_len ? ridx * pad_stride + shq : v_off - cs + shq; // this lane's read inside the slot
+            const uint32_t span_q = pad_len ? (uint32_t)RPC * pad_stride + shq : ce - cs + shq; // bytes of the slot that hold the chunk
             // first / last base (mask_quality_terminal_N needs them before the qualities are looked at).  Requested HERE, not with the
             // early loads: a sector of the base arena touched a whole chunk ahead of the base DMA has left the L2 by then and comes
             // over the fabric twice (+100 B/read of fetches, measured)
@@ -842,7 +876,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // pad behind the span: the position-parallel passes read up to W + 5 bytes past a short last read, and what they
             // find there must be a valid quality byte (see quality_cells)
             {
-                const uint32_t o0 = ce - cs + shq + (uint32_t)lane;
+                const uint32_t o0 = span_q + (uint32_t)lane;
 #pragma unroll
                 for (int i = 0; i < (W + 20 + 63) / 64; ++i)
                     if (lane < W + 20 - 64 * i && o0 < (uint32_t)(T::STG_BYTES - 64 * i)) lds_st_u8((slot_b + o0) + (uint32_t)(64 * i), (uint32_t)in_off);
@@ -890,7 +924,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             if (!sum_pass) {
                 typedef uint32_t U4 __attribute__((ext_vector_type(4)));
                 uint32_t acc = 0;
-                const uint32_t n16 = (ce - cs + shq + 15u) >> 4;
+                const uint32_t n16 = (span_q + 15u) >> 4;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     if ((uint32_t)(i * 64) >= n16) break; // wave-uniform
@@ -1155,8 +1189,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // ---- the span of the BASE arena -> the same slot ---------------------------------------------------------
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every LDS read of the slot has returned
             const uint32_t shs = (uint32_t)((size_t)(seq + cs) & 15u);
-            dma_span<NI>(seq + cs - shs, ce - cs + shs, slot, lane);
-            const uint32_t rows = v_off - cs + shs;
+            stage(seq, cs, ce, shs, pad_len);
+            const uint32_t rows = pad_len ? ridx * pad_stride + shs : v_off - cs + shs;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FAQCS_STAMP(5)
 
@@ -1200,7 +1234,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // offsets and window are taken back out of the two words the loop was given: nothing else stays live across it.)
             {
             const int len = (int)(si0 >> 16), a = (int)(si1 & 0xffu), n = (int)((si1 >> 8) & 0xffu);
-            const uint32_t rows = si0 & 0xffffu, rowq = rows - shs + shq, v_off = cs + rows - shs, v_len = (uint32_t)len;
+            const uint32_t rows = si0 & 0xffffu, rowq = rows - shs + shq, v_off = pad_len ? cs + ridx * pad_len : cs + rows - shs, v_len = (uint32_t)len;
             const uint32_t qi0 = rowq | ((uint32_t)len << 16);
             int V_pre = (int)(int16_t)(uint16_t)(vpk & 0xffffu), V_post = (int)vpk >> 16;
             uint32_t flags = fpk & ~(uint32_t)FAQCS_F_FILTER_MASK, filt = (fpk & (uint32_t)FAQCS_F_FILTER_MASK) >> FAQCS_F_FILTER_SHIFT;
@@ -1326,7 +1360,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 const uint32_t vi1 = (uint32_t)a | ((uint32_t)n << 8) | (veto ? 1u << 16 : 0u) | (veto ? 1u << 17 : 0u);
                 FAQCS_S_LOOP(vi1, 1)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                dma_span<NI>(qual + cs - shq, ce - cs + shq, slot, lane);
+                stage(qual, cs, ce, shq, pad_len);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // the in-place edits of Q-A again: terminal-N runs and clamped bytes
                 if (__any(veto && (tn || badq))) {
@@ -1475,7 +1509,6 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
     // Lane-per-read passes read "their" read at a lane stride of one read length: equal-length reads of 4 x (a multiple of 8)
     // bases put 8 (96 bases) or 32 (128 bases) lanes on each LDS bank -- 2x128 runs at 3.2 G reads/s here against 5.0 on
     // trim_tpr, 2x96 6.2 against 6.7 (profiles/r2c/len_sweep.txt); 4-way strides (112, 144) are a toss-up and stay.
-    if (max_len % 32 == 0) return hipErrorNotSupported;
     if (max_len > 76 && max_len <= 104) FAQCS_LDS_CASE(13);  // 2x100
     if (max_len > 104 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x125, 2x150
 #undef FAQCS_LDS_CASE

@@ -1196,7 +1196,7 @@ def test_at_rich_reads_match_oracle(args):
 
 
 @pytest.mark.parametrize("args", [[], ["--lc", "0.5"], ["--mode", "BWA"], ["--avg_q", "20", "-n", "1"]], ids=["default", "lc05", "bwa", "avgq"])
-@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 128, 144, 148, 150, 152, 156, 160, 161, 164, 200, 240, 248, 250, 251, 252])
+@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 128, 144, 148, 150, 152, 156, 160, 161, 164, 192, 200, 224, 240, 248, 250, 251, 252])
 def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, args):
     """Every read of the batch has the same length (mostly a multiple of 4: the wave's dword loops stop exactly at the read's
     end), a low-quality head that the 5' walk cuts and a high-quality tail, so the kept window is [a, L) with a > 0: its base
@@ -1216,12 +1216,42 @@ def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, a
     compare_engines(opt, reads, seg_size=300)
 
 
+@pytest.mark.parametrize("args", [[], ["--adapter", "--polyA"], ["--lc", "0.5", "-n", "1"], ["--mode", "HARD", "-q", "10", "--avg_q", "30"], ["--5end", "7", "--3end", "3", "--mode", "BWA"]],
+                         ids=["default", "adapter", "lc05_n1", "hard_avgq", "ends_bwa"])
+@pytest.mark.parametrize("L", [96, 128, 192, 224])
+def test_chunks_of_equal_length_reads_in_padded_rows(L, args):
+    """trim_lds stages a chunk whose reads all have the same length, a multiple of 32 bases, as padded rows (dma_rows) and any other chunk as
+    one contiguous span: a batch that holds both kinds of chunk -- runs of equal-length reads broken by a shorter read here and there --
+    with terminal-N runs, low-quality heads and tails, reads the filters reject after their cells were counted (the take-back passes
+    stage the qualities a second time) and out-of-range quality bytes in some reads."""
+    rng = np.random.Generator(np.random.PCG64([92, L, SEED]))
+    opt = parse_args(["-u", "x", "-d", "y", "--min_L", "20"] + args)
+    reads = []
+    for i in range(2600):
+        l = L if (i % 211) or i < 300 else int(rng.integers(1, L))   # the first 300 reads: whole chunks of equal length for sure
+        if 900 <= i < 1100:
+            l = int(rng.integers(max(1, L - 40), L + 1))               # a ragged stretch
+        s = np.frombuffer(b"ACGTNacgt", np.uint8)[rng.choice(9, l, p=[.235, .235, .235, .235, .02, .01, .01, .01, .01])].copy()
+        q = (rng.integers(25, 41, l) + 33).astype(np.uint8)
+        k = i % 13
+        if k == 0 and l > 8: s[:int(rng.integers(1, 6))] = ord("N")              # terminal N runs
+        if k == 1 and l > 8: s[l - int(rng.integers(1, 6)):] = ord("N")
+        if k == 2 and l > 30: q[l - int(rng.integers(1, 30)):] = 35               # '#' tail
+        if k == 3 and l > 12: q[:int(rng.integers(1, 12))] = 33 + rng.integers(0, 4)
+        if k == 4 and l > 40: s[10:10 + int(rng.integers(2, 30))] = ord("N")      # poly-N: vetoed after counting
+        if k == 5: s[:] = np.frombuffer(b"AT", np.uint8)[np.arange(l) % 2]         # dinucleotide repeat: low complexity
+        if k == 6: s[:] = ord("A")                                                 # mononucleotide
+        if i % 401 == 7 and l > 3: q[int(rng.integers(0, l))] = 20                 # a byte below the offset (clamped)
+        reads.append((b"@x", s.tobytes(), q.tobytes()))
+    compare_engines(opt, reads, seg_size=700)
+
+
 @pytest.mark.parametrize("L,args,kernel", [
     (150, [], "trim_lds"), (151, ["--adapter"], "trim_lds"), (100, ["--mode", "HARD", "-q", "10"], "trim_lds"), (125, ["--qc_only"], "trim_lds"),
-    (128, [], "trim_tpr"), (96, [], "trim_tpr"), (75, [], "trim_tpr"), (160, [], "trim_tpr"),
-    (150, ["--replace_to_N_q", "15"], "trim_filter_accumulate"), (128, ["--qc_only"], "trim_filter_accumulate"),
+    (128, [], "trim_lds"), (96, [], "trim_lds"), (75, [], "trim_tpr"), (160, [], "trim_tpr"), (64, [], "trim_tpr"),
+    (150, ["--replace_to_N_q", "15"], "trim_filter_accumulate"), (128, ["--qc_only"], "trim_lds"), (192, ["--adapter"], "trim_lds"),
     (250, [], "trim_lds"), (251, ["--adapter", "--polyA"], "trim_lds"), (200, ["--mode", "BWA", "--avg_q", "20"], "trim_lds"), (161, [], "trim_lds"), (252, [], "trim_lds"),
-    (253, [], "trim_filter_accumulate"), (224, [], "trim_filter_accumulate"), (250, ["--replace_to_N_q", "15"], "trim_filter_accumulate"),
+    (253, [], "trim_filter_accumulate"), (224, [], "trim_lds"), (256, [], "trim_filter_accumulate"), (250, ["--replace_to_N_q", "15"], "trim_filter_accumulate"),
 ])
 def test_dispatcher_picks_the_documented_trim_kernel(L, args, kernel):
     """DESIGN.md section 4 names the trim kernel of every (read length, option set) class; faqcs_kernel_report() says which one ran."""
