@@ -725,8 +725,8 @@ def _check_slices(opt, R, seq, qual, off_host, res_dev, slices, L):
         assert len(bad) == 0, "reads %d..%d: first differing read %d: hip=%s oracle=%s" % (lo, hi, lo + bad[0], got[bad[0]], want[bad[0]])
 
 
-@pytest.mark.parametrize("L,kernel,ragged", [(150, "trim_lds", False), (150, "trim_lds", True), (128, "trim_tpr", False),
-                                             (250, "trim_filter_accumulate", False), (250, "trim_filter_accumulate", True)])
+@pytest.mark.parametrize("L,kernel,ragged", [(150, "trim_lds", False), (150, "trim_lds", True), (128, "trim_lds", False), (160, "trim_tpr", False),
+                                             (250, "trim_lds", False), (250, "trim_lds", True), (256, "trim_filter_accumulate", False)])
 def test_launch_at_the_4gib_arena_limit_matches_oracle(L, kernel, ragged):
     """The launch size bench.py uses: an arena of (2^32 - 4096) // L reads (u32 offsets up to 4 GiB).  The kernels do 32-bit
     arithmetic on offsets, so the END of such an arena -- the last chunk is partial -- and the reads either side of 2^31 are
