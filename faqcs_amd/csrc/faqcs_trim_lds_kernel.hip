@@ -1514,7 +1514,7 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
 #undef FAQCS_LDS_CASE
     // 16 lanes per read: 161 ... 252 bases (2x250, 2x251); FAQCS_TRIM_LDS16=0 switches it off (A/B against trim_filter_accumulate)
     static const bool lds16_on = [] { const char *e = getenv("FAQCS_TRIM_LDS16"); return !e || atoi(e) != 0; }();
-    if (lds16_on && max_len > 160 && max_len <= (uint32_t)lds_maxlen(16, 16))
+    if (lds16_on && max_len > 152 && max_len <= (uint32_t)lds_maxlen(16, 16))
         return ext ? (windowed ? launch_trim_lds<16, true, true, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, true, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS))
                    : (windowed ? launch_trim_lds<16, true, false, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, false, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS));
 #undef FAQCS_LDS_ARGS

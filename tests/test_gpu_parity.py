@@ -725,7 +725,7 @@ def _check_slices(opt, R, seq, qual, off_host, res_dev, slices, L):
         assert len(bad) == 0, "reads %d..%d: first differing read %d: hip=%s oracle=%s" % (lo, hi, lo + bad[0], got[bad[0]], want[bad[0]])
 
 
-@pytest.mark.parametrize("L,kernel,ragged", [(150, "trim_lds", False), (150, "trim_lds", True), (128, "trim_lds", False), (160, "trim_tpr", False),
+@pytest.mark.parametrize("L,kernel,ragged", [(150, "trim_lds", False), (150, "trim_lds", True), (128, "trim_lds", False), (75, "trim_tpr", False),
                                              (250, "trim_lds", False), (250, "trim_lds", True), (256, "trim_filter_accumulate", False)])
 def test_launch_at_the_4gib_arena_limit_matches_oracle(L, kernel, ragged):
     """The launch size bench.py uses: an arena of (2^32 - 4096) // L reads (u32 offsets up to 4 GiB).  The kernels do 32-bit
@@ -1248,7 +1248,7 @@ def test_chunks_of_equal_length_reads_in_padded_rows(L, args):
 
 @pytest.mark.parametrize("L,args,kernel", [
     (150, [], "trim_lds"), (151, ["--adapter"], "trim_lds"), (100, ["--mode", "HARD", "-q", "10"], "trim_lds"), (125, ["--qc_only"], "trim_lds"),
-    (128, [], "trim_lds"), (96, [], "trim_lds"), (75, [], "trim_tpr"), (160, [], "trim_tpr"), (64, [], "trim_tpr"),
+    (128, [], "trim_lds"), (96, [], "trim_lds"), (75, [], "trim_tpr"), (160, [], "trim_lds"), (157, ["--5trim_off"], "trim_lds"), (64, [], "trim_tpr"),
     (150, ["--replace_to_N_q", "15"], "trim_filter_accumulate"), (128, ["--qc_only"], "trim_lds"), (192, ["--adapter"], "trim_lds"),
     (250, [], "trim_lds"), (251, ["--adapter", "--polyA"], "trim_lds"), (200, ["--mode", "BWA", "--avg_q", "20"], "trim_lds"), (161, [], "trim_lds"), (252, [], "trim_lds"),
     (253, [], "trim_filter_accumulate"), (224, [], "trim_lds"), (256, [], "trim_filter_accumulate"), (250, ["--replace_to_N_q", "15"], "trim_filter_accumulate"),
