@@ -27,6 +27,7 @@ struct DevParams {
     uint32_t R;                   // row capacity of the global matrices
     uint32_t n_adapters;
     uint32_t dbg;                 // FAQCS_DBG ablation bits (diagnostics only; 0 in production)
+    uint32_t wide_records;        // (set per launch by faqcs_launch_trim_lds) the batch's longest read has more than 256 bases: two-word composition records
     float lc_ratio, avg_q;        // --lc / --avg_q as given (trim_long evaluates the reference's float expressions directly; the chunked
                                   // kernels use the per-length integer tables below)
     // per-length tables, index 0..FAQCS_TAB_LEN (float32 semantics folded into integers on the host)
@@ -44,7 +45,7 @@ struct DevParams {
 };
 
 enum { FS_SLOTS = 32 };
-enum { FAQCS_PARTIAL_ROW = 13824 };  // >= N_ZERO of every trim_lds variant (RowCfg<19, 8, 160>: 7 962, RowCfg<16, 16, 288>: 13 792): dwords of one flushed copy of a block's LDS accumulators
+enum { FAQCS_PARTIAL_ROW = 16896 };  // >= N_ZERO of every trim_lds variant (RowCfg<19, 8, 160>: 7 962, <16, 16, 288>: 13 792, <19, 16, 352>: 16 768): dwords of one flushed copy of a block's LDS accumulators
 enum { FAQCS_PARTIAL_FLUSHES = 8 };  // flushes (rows) a block has room for in one launch: it stops claiming chunks before it would need more
 
 // base_tab fields (6 bits each so a lane can sum up to 63 reads before flushing)

@@ -258,7 +258,7 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
                                                const uint32_t v_hit, const int lane, uint32_t *hlen, uint32_t *hrq, uint32_t *hbqpre,
                                                uint32_t *hbqpost, uint32_t *lfs, const uint32_t *t_magic, uint2 *__restrict__ out,
                                                unsigned long long *__restrict__ rec_pre, unsigned long long *__restrict__ rec_post,
-                                               const bool o_avgq_on, const uint32_t o_dbg, FsAcc *defer = nullptr)
+                                               const bool o_avgq_on, const uint32_t o_dbg, FsAcc *defer = nullptr, const bool wide_rt = false)
 {
         const bool e_ret = (o.fl & FAQCS_F_VALID) != 0, e_err = (o.fl & FAQCS_F_ERR_QUALITY) != 0;
         const uint32_t e_len = v_len, e_n = o.an >> 16, e_filt = (o.fl & FAQCS_F_FILTER_MASK) >> FAQCS_F_FILTER_SHIFT;
@@ -321,7 +321,7 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
             const bool pre_on = !e_err, post_on = e_ret && !e_err;
             const unsigned long long pA = o.pAT & 0xffffu, pT = o.pAT >> 16, pC = o.pCG & 0xffffu, pG = o.pCG >> 16, pn = o.N & 0xffffu;
             const unsigned long long cA = o.cAT & 0xffffu, cT = o.cAT >> 16, cC = o.cCG & 0xffffu, cG = o.cCG >> 16, cn = o.N >> 16;
-            if (LPR <= 16) {
+            if (LPR <= 16 && !wide_rt) { // (wide_rt, wave-uniform: a 16-lane kernel whose batch holds a read of more than 256 bases)
                 rec_pre[my] = pre_on ? (CR_VALID | e_len | (pA << 9) | (pT << 18) | (pC << 27) | (pG << 36) | (pn << 45)) : 0ull;
                 rec_post[my] = post_on ? (CR_VALID | e_n | (cA << 9) | (cT << 18) | (cC << 27) | (cG << 36) | (cn << 45)) : 0ull;
             } else { // reads past 511 bases do not fit 9-bit fields: 11-bit fields over two words

@@ -72,13 +72,16 @@ namespace {
 // 16 lanes per read (C = 16, reads of 161 ... 252 bases): a lane's 16 cells are followed by one cell of padding, so lane rl starts on
 // cell 17 rl -- 16 different banks in rows of 288 cells -- and the two reads of a half wave are rotated by 0 and 1 bytes
 // (17 rl + 1 = 17 rl' has no solution with both lanes below 16): conflict-free as well.
-constexpr int lds_wq(int C, int LPR = 8) { return LPR == 16 ? 288 : (C == 19 ? 160 : 0); }
-constexpr int lds_cq(int C, int LPR = 8) { return LPR == 16 ? C : (C == 19 ? 20 : C); }
-constexpr int lds_qstride(int C, int LPR = 8) { return LPR == 16 ? C + 1 : lds_cq(C, LPR); } // cells from one lane's first position to the next lane's
+// 16 lanes per read, C = 19 (reads of 253 ... 304 bases: 2x300): 20 positions per lane in Q-B as in the 8-lane variant, 21 cells per lane, rows of 352.
+constexpr int lds_cq(int C, int LPR = 8) { return C == 19 ? 20 : C; }
+constexpr int lds_qstride(int C, int LPR = 8) { return LPR == 16 ? lds_cq(C, LPR) + 1 : lds_cq(C, LPR); } // cells from one lane's first position to the next lane's
+constexpr int lds_wq(int C, int LPR = 8) { return LPR == 16 ? (16 * lds_qstride(C, 16) + 31) / 32 * 32 : (C == 19 ? 160 : 0); }
 constexpr int lds_nrot(int C, int LPR = 8) { return LPR == 16 ? 2 : (C == 19 ? 4 : 1); }   // reads of a half wave = byte rotations in use
-// the longest read a variant takes: the step index of a walk lives in the low byte of the argmax keys (codes 254 - step), a window's start
-// and length in a byte each, a read's N count in 8 bits
-constexpr int lds_maxlen(int C, int LPR = 8) { return LPR * C < 252 ? LPR * C : 252; }
+// The longest read a variant takes.  Up to 252 bases the step index of a walk lives in the low byte of the argmax keys (codes 254 - step), a
+// window's start and length in a byte each, a read's N count in 8 bits; the 304-base variant (lds_wide) has nine-bit codes and fields, the
+// N counts in a register of their own and two-word composition records.
+constexpr int lds_maxlen(int C, int LPR = 8) { return LPR * C <= 252 ? LPR * C : (LPR * C == 256 ? 252 : LPR * C); }
+constexpr bool lds_wide(int C, int LPR = 8) { return lds_maxlen(C, LPR) > 252; }
 
 template <int C, int NW, int LPR = 8, int RPC = 64> struct LdsCfg {
     using Row = RowCfg<C, LPR, lds_wq(C, LPR)>;
@@ -157,7 +160,7 @@ __device__ __forceinline__ uint32_t bit_range_(int s, int e)
 //          before the step, step index < rlim) makes it j + 2; the caller's view moves on by 4 per dword
 //   DESC   the walk visits the dword's bytes 3, 2, 1, 0 (3' walk) or 0, 1, 2, 3 (5' walk)
 // Per position: v_cmpx (alive), 2 x v_cmp + s_or (no reset), v_cndmask (rb), v_sub_sdwa (area), v_lshl_add (key), v_max.
-template <bool DESC>
+template <bool DESC, int CB>
 __device__ __forceinline__ void walk_step(const uint32_t w, const int it, const int c0, const int dc, int &rb, const int rlim, int &a, int &K, int &best)
 {
     unsigned long long sv, t;
@@ -169,7 +172,7 @@ __device__ __forceinline__ void walk_step(const uint32_t w, const int it, const 
     "s_or_b64 vcc, vcc, %[t]\n\t"                                                                                  \
     "v_cndmask_b32 %[rb], " #J2 ", %[rb], vcc\n\t"                                                                 \
     "v_sub_u32_sdwa %[a], %[a], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B "\n\t"  \
-    "v_lshl_add_u32 %[K], %[a], 8, %[c]\n\t"                                                                       \
+    "v_lshl_add_u32 %[K], %[a], %[cb], %[c]\n\t"                                                                   \
     "v_max_i32 %[best], %[best], %[K]\n\t"                                                                         \
     "s_add_i32 %[s], %[s], 1\n\t"                                                                                  \
     "s_add_i32 %[c], %[c], %[dc]\n\t"
@@ -178,14 +181,14 @@ __device__ __forceinline__ void walk_step(const uint32_t w, const int it, const 
                      "s_mov_b64 exec, %[sv]\n\t"
                      "v_add_u32 %[rb], -4, %[rb]"
                      : [rb] "+v"(rb), [a] "+v"(a), [K] "+v"(K), [best] "+v"(best), [s] "+s"(s), [c] "+s"(c), [sv] "=&s"(sv), [t] "=&s"(t)
-                     : [w] "v"(w), [rlim] "v"(rlim), [dc] "s"(dc)
+                     : [w] "v"(w), [rlim] "v"(rlim), [dc] "s"(dc), [cb] "n"(CB)
                      : "vcc");
     else
         asm volatile("s_mov_b64 %[sv], exec\n\t" FAQCS_WALK_POS(0, 2, 0) FAQCS_WALK_POS(1, 3, 1) FAQCS_WALK_POS(2, 4, 2) FAQCS_WALK_POS(3, 5, 3)
                      "s_mov_b64 exec, %[sv]\n\t"
                      "v_add_u32 %[rb], -4, %[rb]"
                      : [rb] "+v"(rb), [a] "+v"(a), [K] "+v"(K), [best] "+v"(best), [s] "+s"(s), [c] "+s"(c), [sv] "=&s"(sv), [t] "=&s"(t)
-                     : [w] "v"(w), [rlim] "v"(rlim), [dc] "s"(dc)
+                     : [w] "v"(w), [rlim] "v"(rlim), [dc] "s"(dc), [cb] "n"(CB)
                      : "vcc");
 #undef FAQCS_WALK_POS
 }
@@ -232,11 +235,11 @@ __device__ __forceinline__ void dma_rows(const uint8_t *g, const uint32_t L, con
 
 // ---- rare exact passes over the GLOBAL arenas (entered only by a chunk that holds such a read; out of line) -----------
 struct ExactQ { int sv, svp, mq; };   // sum(raw - offset) over the read / over the kept window, max(raw - offset)
-// patch = lead | trail << 8: terminal-N positions (< lead or >= trail) read as the offset (mask_quality_terminal_N)
+// patch = lead | trail << 16: terminal-N positions (< lead or >= trail) read as the offset (mask_quality_terminal_N)
 __device__ __noinline__ ExactQ exact_quality(const uint8_t *__restrict__ qual, const uint32_t v_off, const int len, const uint32_t patch,
                                              const int a, const int n, const int in_off, const bool need)
 {
-    const int lead = (int)(patch & 0xffu), trail = (int)(patch >> 8);
+    const int lead = (int)(patch & 0xffffu), trail = (int)(patch >> 16);
     ExactQ r{0, 0, 0};
 #pragma unroll 1
     for (int p = 0; __any(need && p < len); ++p) {
@@ -286,7 +289,7 @@ __device__ __noinline__ ExactB exact_bases(const uint8_t *__restrict__ seq, cons
 } // namespace
 
 // waves per block = slots of 64 x MAXLEN bytes next to the accumulators in 160 KB: 12 x 9.8 KB + 37 KB (8 lanes per read), 6 x 16.2 KB + 63 KB (16)
-constexpr int lds_waves(int C, int LPR = 8, int RPC = 64) { return LPR == 16 ? (RPC == 64 ? 6 : FAQCS_LDS16_NW) : (C <= 19 ? 12 : 8); }
+constexpr int lds_waves(int C, int LPR = 8, int RPC = 64) { return LPR == 16 ? (RPC == 64 ? 6 : (C == 19 ? 12 : FAQCS_LDS16_NW)) : (C <= 19 ? 12 : 8); }
 
 // LDS accumulators -> a row of global memory that belongs to THIS block and THIS flush, as plain coalesced 16-byte stores of the
 // cells as they are (pre count in the low, post count in the high half-word); fold_partials, launched behind the trim kernel, adds
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err,
     const uint8_t *__restrict__ tn_flags)
 {
-    static_assert(LPR == 8 || (LPR == 16 && C == 16), "lanes per read");
+    static_assert(LPR == 8 || (LPR == 16 && (C == 16 || C == 19)), "lanes per read");
     using Cfg = RowCfg<C, LPR, lds_wq(C, LPR)>;
     static_assert(RPC <= 64 && (RPC * LPR) % 64 == 0, "reads per chunk: the same number for every row of LPR lanes");
     using T = LdsCfg<C, NW, LPR, RPC>;
@@ -393,7 +396,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     constexpr int TPR = RPC * LPR / 64;               // reads a row of LPR lanes works on per chunk
     constexpr int D = Cfg::D, W = Cfg::W, ND = T::ND, NWORD = T::NWORD, NPOS = ND * 4, BMW = Cfg::BMW;
     constexpr int NI = (T::STG_BYTES + 1023) / 1024;
-    static_assert(!Cfg::HQ8 && T::MAXLEN <= 254, "step indices must fit the low byte of the argmax keys");
+    constexpr bool WIDE = lds_wide(C, LPR);           // reads past 252 bases
+    constexpr int AB = WIDE ? 9 : 8;                  // bits of a window start / length in the words handed to the position-parallel passes
+    constexpr uint32_t AM = (1u << AB) - 1u;
+    constexpr int FB = 2 * AB;                        // ... their flags: post << FB | counted << (FB + 1) | chk << (FB + 2)
+    constexpr int CB = WIDE ? 9 : 8, CMAX = (1 << CB) - 1; // bits of a walk's step code inside the argmax keys: code = CMAX - 1 - step, CMAX = no step yet
+    static_assert(!Cfg::HQ8 && T::MAXLEN <= CMAX - 1, "step indices must fit the code field of the argmax keys");
     static_assert(T::lds_dwords() * 4 <= 160 * 1024, "LDS");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *hb = smem + Cfg::O_HB;
@@ -545,11 +553,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     // ---- the position-parallel passes (8 lanes per read).  What a lane fetches from LDS for one read: six aligned dwords
     // that hold its C bytes and three rows of the byte-mask table (positions inside the read / in front of the kept
     // window's end / in front of its start).  Fetched one read AHEAD of its use so that the LDS latency is covered.
-    // i0 = slot offset of the read | len << 16 ; i1 = a | n << 8 | post << 16 | counted << 17
+    // i0 = slot offset of the read | len << 16 ; i1 = a | n << AB | post << FB | counted << (FB + 1)
     struct RawB { uint32_t r[D + 1], mv[D], mh[D], ml[D]; };
     auto load_b = [&](const uint32_t i0, const uint32_t i1, RawB &x) {
-        const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
-        const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u;
+        const int len = (int)(i0 >> 16), a = (int)(i1 & AM), n = (int)((i1 >> AB) & AM);
+        const bool post = ((i1 >> FB) & 1u) != 0u, counted = ((i1 >> (FB + 1)) & 1u) != 0u;
         const int vb = counted ? med3i(len - pbase_q, 0, VQ) : 0; // (a read that is not counted: no byte of it is)
         const int lo = post ? med3i(a - pbase_q, 0, VQ) : 0, hi = post ? med3i(a + n - pbase_q, 0, VQ) : 0;
 #ifdef FAQCS_LDS_DIAG_LINEAR_LOADS // (diagnostic build, wrong results: what the bank conflicts of these per-lane loads cost)
@@ -633,12 +641,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     // totals: what S-A used to compute with a second lookup per base in the lane-per-read layout.
     // MODE 0: count ; 1: take back the post increments of the reads flagged in i1 (vetoed after counting) ; 2: take back everything
     uint32_t tot_pe = 0, tot_po = 0, tot_ce = 0, tot_co = 0; // this lane's read: pre A | C << 12 | N << 24, pre T | G << 12, post ...
+    uint32_t tot_pn = 0;                                      // (WIDE) pre N | post N << 16
     uint32_t seen7 = 0;                                       // OR of every counted base byte of the chunk (bit 7: abnormal input)
     bool pairhit = false;                                     // this lane's read: two adjacent upper-case N inside the kept window
     auto base_step = [&](const int t, const uint32_t i0, const uint32_t i1, auto mode_t) {
         constexpr int MODE = decltype(mode_t)::value;
-        const int len = (int)(i0 >> 16), a = (int)(i1 & 0xffu), n = (int)((i1 >> 8) & 0xffu);
-        const bool post = ((i1 >> 16) & 1u) != 0u, counted = ((i1 >> 17) & 1u) != 0u, chk = ((i1 >> 18) & 1u) != 0u;
+        const int len = (int)(i0 >> 16), a = (int)(i1 & AM), n = (int)((i1 >> AB) & AM);
+        const bool post = ((i1 >> FB) & 1u) != 0u, counted = ((i1 >> (FB + 1)) & 1u) != 0u, chk = ((i1 >> (FB + 2)) & 1u) != 0u;
         const int vb = counted ? med3i(len - pbase, 0, C + 1) : 0; // (a read that is not counted: every byte reads as "past the read")
         // the kept window as the table lookups see it: empty for a read that is not kept (every base outside: pre increments only)
         const int lo = med3i(a - pbase, 0, C + 1), hi = (post || chk) ? med3i(a + n - pbase, 0, C + 1) : lo;
@@ -692,7 +701,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // the read's totals: 8 lanes, <= 19 per 6-bit field each; one step in 6-bit fields (<= 38), the rest in 12-bit fields
             tp += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tp, 0xB1, 0xf, 0xf, false);
             tq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tq, 0xB1, 0xf, 0xf, false);
-            uint32_t pe = tp & 0x3f03f03fu, po = (tp >> 6) & 0x0003f03fu, ce = tq & 0x3f03f03fu, co = (tq >> 6) & 0x0003f03fu;
+            // (WIDE: a read can hold more than 255 N -- the two N counts get a register of their own, pre in the low and post in the high half)
+            uint32_t pe = tp & (WIDE ? 0x0003f03fu : 0x3f03f03fu), po = (tp >> 6) & 0x0003f03fu, ce = tq & (WIDE ? 0x0003f03fu : 0x3f03f03fu), co = (tq >> 6) & 0x0003f03fu;
+            uint32_t pn = WIDE ? ((tp >> 24) | ((tq >> 24) << 16)) : 0u;
+            if (WIDE) {
+                pn += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pn, 0x4E, 0xf, 0xf, false);
+                pn += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pn, 0x141, 0xf, 0xf, false);
+                pn += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pn, 0x140, 0xf, 0xf, false);
+            }
             pe += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x4E, 0xf, 0xf, false);
             po += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)po, 0x4E, 0xf, 0xf, false);
             ce += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ce, 0x4E, 0xf, 0xf, false);
@@ -709,9 +725,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             }
             const bool turn = rl == t;
             tot_pe = turn ? pe : tot_pe; tot_po = turn ? po : tot_po; tot_ce = turn ? ce : tot_ce; tot_co = turn ? co : tot_co;
+            if (WIDE) tot_pn = turn ? pn : tot_pn;
             // ---- upper-case N inside the kept window (count_poly_n, trim.cpp:578-597): looked at only when the read has enough N
             // (any case) in its window to matter, or when it is judged without being counted (chk) ----
-            const uint32_t cN = ce >> 24;
+            const uint32_t cN = WIDE ? pn >> 16 : ce >> 24;
             // -n 2 (the default): two adjacent N, tested here; any other -n: judged after the loop, from the staged bases
             if ((!EXT || P.max_poly_n == 2u) && __any(cN >= 2u || chk)) {
                 uint32_t nb[D]; // bit 7 of a byte: upper-case 'N' inside the kept window
@@ -885,7 +902,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 
             // ================= Q-A: one read per lane ===============================================================
             ReadOutcome oc;
-            uint32_t v_patch = (uint32_t)len << 8; // lead | trail << 8
+            uint32_t v_patch = (uint32_t)len << 16; // lead | trail << 16
             // ---- mask_quality_terminal_N (trim.cpp:1191-1216): upper-case 'N' runs at either end get Q0, in place ----
             const bool tn = len > 0 && (bfirst == 'N' || blast == 'N');
             if (__any(tn)) {
@@ -901,7 +918,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 while (__any(go)) {
                     if (go) { --trail; go = trail > 0 && seq[(size_t)v_off + trail - 1] == 'N'; }
                 }
-                if (tn) v_patch = (uint32_t)lead | ((uint32_t)trail << 8);
+                if (tn) v_patch = (uint32_t)lead | ((uint32_t)trail << 16);
                 const int ntail = tn ? len - trail : 0;
 #pragma unroll 1
                 for (int i = 0; __any(tn && (i < lead || i < ntail)); ++i) {
@@ -1002,7 +1019,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // n2 away from the far end) moves its end to s + 2 (n2 == 2 whenever a reset can fire).
             // key = area << 8 | code, code falling with time: the FIRST maximum wins (walk_step above).
             const int a5 = wn < 5 ? wn : 5, nn2 = wn < 2 ? wn : 2, qoff = Q + in_off;
-            const int dc = uni(qoff * 256 - 1);
+            const int dc = uni(qoff * (1 << CB) - 1);
             int S3 = 0, fp3 = wn - 1, S5 = 0, fp5 = 0;
             const int mode = EXT ? P.mode : FAQCS_MODE_BWA_PLUS;
             bool sum_kept = false; // the kept window's quality sum needs its own pass (no walk areas to derive it from)
@@ -1077,11 +1094,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                         if (!__any(run)) break;
                     }
                 }
-                int rb = a5 - 1, area = 0, best = 255, K = 255; // rb: steps still to go after the current one
+                int rb = a5 - 1, area = 0, best = CMAX, K = CMAX; // rb: steps still to go after the current one
                 if (__any(m > 0)) {
                     const int A0 = 4 * m * dq0;
                     area = A0;
-                    best = K = (A0 << 8) + 255; // (m == 0: 255)
+                    best = K = (A0 << CB) + CMAX; // (m == 0: CMAX)
                     rb = m > 0 ? 1 : rb;
                     rlim -= 4 * m;
                     e4 -= 4u * (uint32_t)m;
@@ -1092,16 +1109,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     const uint32_t nx = lds_ld(e4 - 8u - (uint32_t)it);
                     const uint32_t w = __builtin_amdgcn_alignbyte(hi, cur, esh); // positions wend-4-it .. wend-1-it
                     hi = cur; cur = nx;
-                    walk_step<true>(w, it, (it + 1) * qoff * 256 + 254 - it, dc, rb, rlim, area, K, best);
+                    walk_step<true, CB>(w, it, (it + 1) * qoff * (1 << CB) + CMAX - 1 - it, dc, rb, rlim, area, K, best);
                 }
-                S3 = best >> 8;
-                const int code = best & 255;
-                const int sb = code == 255 ? 4 * m - 1 : 4 * m + 254 - code;
+                S3 = best >> CB;
+                const int code = best & CMAX;
+                const int sb = code == CMAX ? 4 * m - 1 : 4 * m + CMAX - 1 - code;
                 fp3 = S3 > 0 ? (wn - 1 - sb) - 1 : wn - 1;
             }
             FAQCS_STAMP(2)
             if (do_trim && mode == FAQCS_MODE_BWA_PLUS && !(EXT && P.protect5)) { // --5trim_off (trim.cpp:752)
-                int rb = a5 - 1, area = 0, best = 255, K = 255;
+                int rb = a5 - 1, area = 0, best = CMAX, K = CMAX;
                 const int rlim = fp3 - nn2; // a reset at step s needs s < final_pos_3 - n2
                 const uint32_t begq = slot_b + rowq + (uint32_t)wa;
                 const uint32_t b4 = begq & ~3u, bsh = begq & 3u;
@@ -1111,10 +1128,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                     const uint32_t nx = lds_ld(b4 + 8u + (uint32_t)it);
                     const uint32_t w = __builtin_amdgcn_alignbyte(cur, lo, bsh);
                     lo = cur; cur = nx;
-                    walk_step<false>(w, it, (it + 1) * qoff * 256 + 254 - it, dc, rb, rlim, area, K, best);
+                    walk_step<false, CB>(w, it, (it + 1) * qoff * (1 << CB) + CMAX - 1 - it, dc, rb, rlim, area, K, best);
                 }
-                S5 = best >> 8;
-                fp5 = S5 > 0 ? (254 - (best & 255)) + 1 : 0;
+                S5 = best >> CB;
+                fp5 = S5 > 0 ? (CMAX - 1 - (best & CMAX)) + 1 : 0;
             }
 
             // ---- length filters and the kept window (trim.cpp:317-360) -------------------------------------
@@ -1176,7 +1193,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t qi0 = rowq | ((uint32_t)len << 16);
             // retc: the read is still kept as far as the qualities can tell (an average-quality failure is final whatever poly-N says later)
             const bool retc = ret && !avgq_fail;
-            const uint32_t qi1 = (uint32_t)a | ((uint32_t)n << 8) | (retc ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u);
+            const uint32_t qi1 = (uint32_t)a | ((uint32_t)n << AB) | (retc ? 1u << FB : 0u) | ((mine && !read_err) ? 1u << (FB + 1) : 0u);
 #define FAQCS_QCELLS(X, A, B, T_) quality_cells(X, A, B, std::false_type{}, T_, !sum_pass)
             FAQCS_B_LOOP(qi0, qi1, FAQCS_QCELLS)
 #undef FAQCS_QCELLS
@@ -1198,9 +1215,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // i1: a | n << 8 | post << 16 | counted << 17 | chk << 18.  chk: the read fails the average quality but is still judged for
             // poly-N, which the reference tests first (trim.cpp:363-382).
             const uint32_t si0 = rows | ((uint32_t)len << 16);
-            const uint32_t si1 = (uint32_t)a | ((uint32_t)n << 8) | (retc ? 1u << 16 : 0u) | ((mine && !read_err) ? 1u << 17 : 0u) |
-                                 ((ret && !retc) ? 1u << 18 : 0u);
-            const uint32_t vpk = ((uint32_t)V_pre & 0xffffu) | ((uint32_t)V_post << 16); // (|sums| < 2^15: 152 bases x at most 192 per base)
+            const uint32_t si1 = (uint32_t)a | ((uint32_t)n << AB) | (retc ? 1u << FB : 0u) | ((mine && !read_err) ? 1u << (FB + 1) : 0u) |
+                                 ((ret && !retc) ? 1u << (FB + 2) : 0u);
+            // (|sums| < 2^15 up to 252 bases: at most 127 per base; the 304-base variant keeps a register for each)
+            const uint32_t vpk = WIDE ? (uint32_t)V_pre : (((uint32_t)V_pre & 0xffffu) | ((uint32_t)V_post << 16)), vpk2 = WIDE ? (uint32_t)V_post : 0u;
             const uint32_t fpk = flags | (filt << FAQCS_F_FILTER_SHIFT);
             const uint32_t v_hit_w = v_hit;
 #define FAQCS_S_LOOP(I1, MODE)                                                                                        \
@@ -1208,7 +1226,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
         _Pragma("unroll 1") for (int t = 0; t < TPR; ++t) {                                                          \
             if (base + (uint32_t)t >= n_reads) break; /* wave-uniform: no row has a read left */                      \
             const uint32_t a1_ = (uint32_t)__shfl((int)(I1), rowb + t);                                               \
-            if (MODE == 1 && !__any(((a1_ >> 16) & 1u) != 0u)) continue;                                              \
+            if (MODE == 1 && !__any(((a1_ >> FB) & 1u) != 0u)) continue;                                              \
             const uint32_t a0_ = (uint32_t)__shfl((int)si0, rowb + t);                                                \
             base_step(t, a0_, a1_, std::integral_constant<int, MODE>{});                                              \
         }                                                                                                             \
@@ -1233,14 +1251,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // (The S loop is the kernel's register peak.  What it does not use is packed into vpk / fpk in front of it, and the read's
             // offsets and window are taken back out of the two words the loop was given: nothing else stays live across it.)
             {
-            const int len = (int)(si0 >> 16), a = (int)(si1 & 0xffu), n = (int)((si1 >> 8) & 0xffu);
+            const int len = (int)(si0 >> 16), a = (int)(si1 & AM), n = (int)((si1 >> AB) & AM);
             const uint32_t rows = si0 & 0xffffu, rowq = rows - shs + shq, v_off = pad_len ? cs + ridx * pad_len : cs + rows - shs, v_len = (uint32_t)len;
             const uint32_t qi0 = rowq | ((uint32_t)len << 16);
-            int V_pre = (int)(int16_t)(uint16_t)(vpk & 0xffffu), V_post = (int)vpk >> 16;
+            int V_pre = WIDE ? (int)vpk : (int)(int16_t)(uint16_t)(vpk & 0xffffu), V_post = WIDE ? (int)vpk2 : (int)vpk >> 16;
             uint32_t flags = fpk & ~(uint32_t)FAQCS_F_FILTER_MASK, filt = (fpk & (uint32_t)FAQCS_F_FILTER_MASK) >> FAQCS_F_FILTER_SHIFT;
             const uint32_t v_hit = WINDOWED ? v_hit_w : 0u;
-            uint32_t pA = tot_pe & 0xfffu, pC = (tot_pe >> 12) & 0xfffu, pN = tot_pe >> 24, pT = tot_po & 0xfffu, pG = tot_po >> 12;
-            uint32_t cA = tot_ce & 0xfffu, cC = (tot_ce >> 12) & 0xfffu, cN = tot_ce >> 24, cT = tot_co & 0xfffu, cG = tot_co >> 12;
+            uint32_t pA = tot_pe & 0xfffu, pC = (tot_pe >> 12) & 0xfffu, pN = WIDE ? tot_pn & 0xffffu : tot_pe >> 24, pT = tot_po & 0xfffu, pG = tot_po >> 12;
+            uint32_t cA = tot_ce & 0xfffu, cC = (tot_ce >> 12) & 0xfffu, cN = WIDE ? tot_pn >> 16 : tot_ce >> 24, cT = tot_co & 0xfffu, cG = tot_co >> 12;
             {
                 // ---- poly-N (trim.cpp:363-371, :578-597): -n 2 = two adjacent upper-case N inside the kept window ----
                 bool polyn;
@@ -1357,7 +1375,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             // the qualities (staged again) ----
             const bool veto = retc && !ret;
             if (__any(veto)) {
-                const uint32_t vi1 = (uint32_t)a | ((uint32_t)n << 8) | (veto ? 1u << 16 : 0u) | (veto ? 1u << 17 : 0u);
+                const uint32_t vi1 = (uint32_t)a | ((uint32_t)n << AB) | (veto ? 1u << FB : 0u) | (veto ? 1u << (FB + 1) : 0u);
                 FAQCS_S_LOOP(vi1, 1)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 stage(qual, cs, ce, shq, pad_len);
@@ -1370,16 +1388,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                             const uint32_t r = lds_ld_u8(slot_b + rowq + (uint32_t)p);
                             int v = (int)(int8_t)r - in_off;
                             v = v < 0 ? 0 : (v > 41 ? 41 : v);
-                            if (p < (int)(v_patch & 0xffu) || p >= (int)(v_patch >> 8)) v = 0;
+                            if (p < (int)(v_patch & 0xffffu) || p >= (int)(v_patch >> 16)) v = 0;
                             lds_st_u8(slot_b + rowq + (uint32_t)p, (uint32_t)(v + in_off));
                         }
                     }
                 }
-                const uint32_t ui1 = (uint32_t)a | ((uint32_t)n << 8) | (veto ? 1u << 16 : 0u);
+                const uint32_t ui1 = (uint32_t)a | ((uint32_t)n << AB) | (veto ? 1u << FB : 0u);
 #pragma unroll 1
                 for (int t = 0; t < TPR; ++t) {
                     const uint32_t i1 = (uint32_t)__shfl((int)ui1, rowb + t);
-                    if (!__any(((i1 >> 16) & 1u) != 0u)) continue;
+                    if (!__any(((i1 >> FB) & 1u) != 0u)) continue;
                     const uint32_t i0 = (uint32_t)__shfl((int)qi0, rowb + t);
                     RawB x;
                     load_b(i0, i1, x);
@@ -1405,7 +1423,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 
             // ---- chunk epilogue: one read per lane ----------------------------------------------------------
             chunk_epilogue<LPR>(oc, mine, my, v_len, v_hit, lane, smem + Cfg::O_LEN, smem + Cfg::O_RQ, smem + Cfg::O_BQPRE,
-                                smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, EXT && P.avgq_on != 0, 0u, &fs_acc);
+                                smem + Cfg::O_BQPOST, smem + Cfg::O_FS, smem + Cfg::O_TMAGIC, out, rec_pre, rec_post, EXT && P.avgq_on != 0, 0u, &fs_acc,
+                                WIDE && P.wide_records != 0u); // (a batch with a read past 256 bases: the two-word records composition_histogram then expects)
             ld = ld_next;
             }
         }
@@ -1517,6 +1536,14 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
     if (lds16_on && max_len > 152 && max_len <= (uint32_t)lds_maxlen(16, 16))
         return ext ? (windowed ? launch_trim_lds<16, true, true, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, true, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS))
                    : (windowed ? launch_trim_lds<16, true, false, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, false, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS));
+    // 253 ... 304 bases (2x300, 2x301): 16 lanes x 19 positions, chunks of 20 reads (6 KB slots: 12 waves beside a [42][352] quality matrix)
+    DevParams Pw = P;
+    Pw.wide_records = max_len > 256 ? 1u : 0u;
+#undef FAQCS_LDS_ARGS
+#define FAQCS_LDS_ARGS Pw, seq, qual, off, n_reads, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st, tn_flags
+    if (lds16_on && max_len > (uint32_t)lds_maxlen(16, 16) && max_len <= (uint32_t)lds_maxlen(19, 16))
+        return ext ? (windowed ? launch_trim_lds<19, true, true, 16, 20>(FAQCS_LDS_ARGS) : launch_trim_lds<19, false, true, 16, 20>(FAQCS_LDS_ARGS))
+                   : (windowed ? launch_trim_lds<19, true, false, 16, 20>(FAQCS_LDS_ARGS) : launch_trim_lds<19, false, false, 16, 20>(FAQCS_LDS_ARGS));
 #undef FAQCS_LDS_ARGS
     return hipErrorNotSupported;
 }

@@ -260,25 +260,25 @@ def test_long_read_limits():
 
 @pytest.mark.parametrize("args", [OPTION_SETS[i] for i in (0, 1, 2, 8, 10, 13, 15, 18, 21, 23)], ids=lambda a: " ".join(a) or "default")
 @pytest.mark.parametrize("kind,maxlen", [("adv", 157), ("adv", 120), ("ragged", 104), ("adv", 200), ("ragged", 112), ("adv", 75), ("ragged", 50),
-                                         ("adv", 252), ("adv", 256), ("ragged", 224)])
+                                         ("adv", 252), ("adv", 256), ("ragged", 224), ("adv", 300), ("ragged", 304), ("adv", 320)])
 def test_every_kernel_width_matches_oracle(args, kind, maxlen):
     """One batch per position-slot width the dispatcher can pick (4 lanes per read: C = 16/19; 8 lanes: C = 13/16/19/20; 16 lanes: C = 13/16;
     trim_lds with 16 lanes per read up to 252 bases, trim_filter_accumulate past that and for multiples of 32)."""
     rng = np.random.Generator(np.random.PCG64([3, len(kind), maxlen, OPTION_SETS.index(args), SEED]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     reads = random_batch(rng, 500 if "--adapter" in args else 1500, maxlen, kind)
-    compare_engines(opt, reads, seg_size=389)
+    compare_engines(opt, reads, R=256 if maxlen <= 256 else 1024, seg_size=389)
 
 
 @pytest.mark.parametrize("in_off", [40, 64, 90, 100])
-@pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 100), ("adv", 70), ("adv", 250), ("ragged", 251)])
+@pytest.mark.parametrize("kind,maxlen", [("adv", 150), ("ragged", 100), ("adv", 70), ("adv", 250), ("ragged", 251), ("adv", 300)])
 def test_quality_offsets_that_leave_scores_outside_the_valid_range(in_off, kind, maxlen):
     """Raw quality bytes are generated for Phred+33; decoding them with a larger offset makes most scores negative (clamped to
     0 by the trimmers, not by the averages) -- the per-position exact pass of the two-phase kernel instead of its four-bytes-per-
     instruction sums.  Offsets above 86 switch the packed range check off altogether."""
     rng = np.random.Generator(np.random.PCG64([11, in_off, maxlen, SEED]))
     opt = parse_args(["-u", "x", "-d", "y", "--ascii", str(in_off), "--min_L", "20"])
-    compare_engines(opt, random_batch(rng, 1200, maxlen, kind), in_off=in_off, seg_size=500)
+    compare_engines(opt, random_batch(rng, 1200, maxlen, kind), R=256 if maxlen <= 256 else 1024, in_off=in_off, seg_size=500)
 
 
 def test_single_pass_kernel_variants_still_match_oracle():
@@ -726,7 +726,7 @@ def _check_slices(opt, R, seq, qual, off_host, res_dev, slices, L):
 
 
 @pytest.mark.parametrize("L,kernel,ragged", [(150, "trim_lds", False), (150, "trim_lds", True), (128, "trim_lds", False), (75, "trim_tpr", False),
-                                             (250, "trim_lds", False), (250, "trim_lds", True), (256, "trim_filter_accumulate", False)])
+                                             (250, "trim_lds", False), (250, "trim_lds", True), (300, "trim_lds", False), (320, "trim_filter_accumulate", False)])
 def test_launch_at_the_4gib_arena_limit_matches_oracle(L, kernel, ragged):
     """The launch size bench.py uses: an arena of (2^32 - 4096) // L reads (u32 offsets up to 4 GiB).  The kernels do 32-bit
     arithmetic on offsets, so the END of such an arena -- the last chunk is partial -- and the reads either side of 2^31 are
@@ -737,7 +737,7 @@ def test_launch_at_the_4gib_arena_limit_matches_oracle(L, kernel, ragged):
 
     from faqcs_amd.engine import HipEngine, _check
 
-    R = 256
+    R = 256 if L <= 256 else 320
     opt = parse_args(["-u", "x", "-d", "y", "--ascii", "33"])
     eng = HipEngine(opt, R, 33, device=0)
     lib = eng.lib
@@ -1196,7 +1196,7 @@ def test_at_rich_reads_match_oracle(args):
 
 
 @pytest.mark.parametrize("args", [[], ["--lc", "0.5"], ["--mode", "BWA"], ["--avg_q", "20", "-n", "1"]], ids=["default", "lc05", "bwa", "avgq"])
-@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 128, 144, 148, 150, 152, 156, 160, 161, 164, 192, 200, 224, 240, 248, 250, 251, 252])
+@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 128, 144, 148, 150, 152, 156, 160, 161, 164, 192, 200, 224, 240, 248, 250, 251, 252, 253, 256, 288, 300, 301, 304])
 def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, args):
     """Every read of the batch has the same length (mostly a multiple of 4: the wave's dword loops stop exactly at the read's
     end), a low-quality head that the 5' walk cuts and a high-quality tail, so the kept window is [a, L) with a > 0: its base
@@ -1213,12 +1213,12 @@ def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, a
         if i % 7 == 0 and L > 20:
             q[L - int(rng.integers(1, 9)):] = 34      # some reads do lose their tail
         reads.append((b"@x", s.tobytes(), q.tobytes()))
-    compare_engines(opt, reads, seg_size=300)
+    compare_engines(opt, reads, R=256 if L <= 256 else 1024, seg_size=300)
 
 
 @pytest.mark.parametrize("args", [[], ["--adapter", "--polyA"], ["--lc", "0.5", "-n", "1"], ["--mode", "HARD", "-q", "10", "--avg_q", "30"], ["--5end", "7", "--3end", "3", "--mode", "BWA"]],
                          ids=["default", "adapter", "lc05_n1", "hard_avgq", "ends_bwa"])
-@pytest.mark.parametrize("L", [96, 128, 192, 224])
+@pytest.mark.parametrize("L", [96, 128, 192, 224, 256, 288])
 def test_chunks_of_equal_length_reads_in_padded_rows(L, args):
     """trim_lds stages a chunk whose reads all have the same length, a multiple of 32 bases, as padded rows (dma_rows) and any other chunk as
     one contiguous span: a batch that holds both kinds of chunk -- runs of equal-length reads broken by a shorter read here and there --
@@ -1243,7 +1243,7 @@ def test_chunks_of_equal_length_reads_in_padded_rows(L, args):
         if k == 6: s[:] = ord("A")                                                 # mononucleotide
         if i % 401 == 7 and l > 3: q[int(rng.integers(0, l))] = 20                 # a byte below the offset (clamped)
         reads.append((b"@x", s.tobytes(), q.tobytes()))
-    compare_engines(opt, reads, seg_size=700)
+    compare_engines(opt, reads, R=256 if L <= 256 else 1024, seg_size=700)
 
 
 @pytest.mark.parametrize("L,args,kernel", [
@@ -1251,7 +1251,9 @@ def test_chunks_of_equal_length_reads_in_padded_rows(L, args):
     (128, [], "trim_lds"), (96, [], "trim_lds"), (75, [], "trim_tpr"), (160, [], "trim_lds"), (157, ["--5trim_off"], "trim_lds"), (64, [], "trim_tpr"),
     (150, ["--replace_to_N_q", "15"], "trim_filter_accumulate"), (128, ["--qc_only"], "trim_lds"), (192, ["--adapter"], "trim_lds"),
     (250, [], "trim_lds"), (251, ["--adapter", "--polyA"], "trim_lds"), (200, ["--mode", "BWA", "--avg_q", "20"], "trim_lds"), (161, [], "trim_lds"), (252, [], "trim_lds"),
-    (253, [], "trim_filter_accumulate"), (224, [], "trim_lds"), (256, [], "trim_filter_accumulate"), (250, ["--replace_to_N_q", "15"], "trim_filter_accumulate"),
+    (253, [], "trim_lds"), (224, [], "trim_lds"), (256, [], "trim_lds"), (250, ["--replace_to_N_q", "15"], "trim_filter_accumulate"),
+    (300, [], "trim_lds"), (301, ["--adapter", "--polyA"], "trim_lds"), (304, ["--mode", "HARD", "-q", "10"], "trim_lds"), (305, [], "trim_filter_accumulate"),
+    (300, ["--replace_to_N_q", "15"], "trim_filter_accumulate"),
 ])
 def test_dispatcher_picks_the_documented_trim_kernel(L, args, kernel):
     """DESIGN.md section 4 names the trim kernel of every (read length, option set) class; faqcs_kernel_report() says which one ran."""
@@ -1260,7 +1262,7 @@ def test_dispatcher_picks_the_documented_trim_kernel(L, args, kernel):
     rng = np.random.Generator(np.random.PCG64([5, L, SEED]))
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     reads = [(b"@x", make_uniform(rng, L), bytes((rng.integers(20, 41, L) + 33).astype(np.uint8))) for _ in range(300)]
-    hip, _ = compare_engines(opt, reads)
+    hip, _ = compare_engines(opt, reads, R=256 if L <= 256 else 1024)
     kt = capi.KernelTimes()
     assert hip.lib.faqcs_kernel_report(hip.ctx, C.byref(kt)) == 0
     assert (kt.trim_kernel or b"").decode() == kernel
