@@ -3,10 +3,10 @@
 // Replaces trim_read() and its helpers (trim.cpp:225-551, :553-597, :629-885, :1191-1216) for every read
 // of a batch.  Three kernels share the accumulators, the flush and the per-chunk epilogue (faqcs_trim_common.h);
 // faqcs_launch_trim at the end of this file picks one per submission:
-//   trim_lds (faqcs_trim_lds_kernel.hip)   reads of 77 ... 152 bases, every option set but --replace_to_N_q: the headline shapes
-//   trim_tpr                 the default-like option sets on reads of up to 160 bases that trim_lds does not take (<= 76,
-//                            153 ... 160 and multiple-of-32 lengths): two phases per 64-read chunk, described at its definition
-//   trim_filter_accumulate   every other option set and read length: one pass, described here
+//   trim_lds (faqcs_trim_lds_kernel.hip)   reads of 77 ... 304 bases, every option set but --replace_to_N_q: the headline shapes
+//   trim_tpr                 the default-like option sets on reads of up to 76 bases: two phases per 64-read chunk, described at
+//                            its definition (its wider instantiations are kept for A/B runs: FAQCS_TRIM_LDS=0)
+//   trim_filter_accumulate   every other option set and read length up to 1 024 bases: one pass, described here
 //
 // Mapping (trim_filter_accumulate).  LPR lanes share one read and lane l of the group owns the C consecutive positions [l*C, l*C+C), fetched
 // with ONE unaligned global_load_dwordx{D} per arena; a wave takes chunks of 64 reads.

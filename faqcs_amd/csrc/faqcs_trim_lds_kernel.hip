@@ -1,9 +1,12 @@
 // faqcs_trim_lds_kernel.hip -- trim_lds: the trim / filter / accumulate pass with every byte read from HBM ONCE, as
-// coalesced 16-byte LDS-DMA loads (global_load_lds_dwordx4), for reads of 77 ... 152 bases (gfx950, wave64).
+// coalesced 16-byte LDS-DMA loads (global_load_lds_dwordx4), for reads of 77 ... 304 bases (gfx950, wave64).
 //
 // Replaces trim_read() and its helpers (trim.cpp:225-551, :553-597, :629-885, :1191-1216) like the other trim kernels;
 // the accumulators, the block flush and the chunk epilogue are shared with them (faqcs_trim_common.h).
 //
+// (What follows describes the variant of the headline shape, 77 ... 152 bases: 8 lanes per read in the position-parallel passes, chunks of
+// 64 reads.  Reads of 153 ... 252 / 253 ... 304 bases run the same kernel text with 16 lanes per read and chunks of 32 / 20 reads --
+// template parameters LPR and RPC, see trim_lds's definition and DESIGN.md section 4.1e.)
 // A wave owns a chunk of 64 consecutive reads.  Reads are packed back to back in the arenas, so the chunk is ONE
 // contiguous span of <= 64 x W bytes per arena: the wave copies the span of the QUALITY arena into its 9.8 KB slot of LDS
 // with <= 10 wave-wide DMA instructions (1 KB each, no VGPR round trip), works on it, then copies the span of the BASE
@@ -40,8 +43,8 @@
 // array in global memory (plain adds, no atomics: the row is private to the block) and fold_partials, launched behind the kernel,
 // adds the rows to the u64 counter block.
 //
-// Dispatch (faqcs_launch_trim_lds at the end of the file): every option set except --replace_to_N_q; batches whose longest
-// read is a multiple of 32 bases stay on trim_tpr (LDS bank stride of the lane-per-read passes).
+// Dispatch (faqcs_launch_trim_lds at the end of the file): every option set except --replace_to_N_q.  A chunk whose reads all have the
+// same length, a multiple of 32 bases, is staged as padded rows instead of one span (dma_rows: LDS bank stride of the lane-per-read passes).
 #include "faqcs_trim_common.h"
 
 #include <stdlib.h>
@@ -1524,14 +1527,13 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
                : (windowed ? launch_trim_lds<C, true, false>(FAQCS_LDS_ARGS) : launch_trim_lds<C, false, false>(FAQCS_LDS_ARGS))
     // measured on MI355X (kernel-only, G reads/s, trim_lds vs trim_tpr): 2x100 7.46 vs 7.10 (C = 13), 2x125 5.64 vs 5.06 on the
     // C = 19 grid (4.44 on C = 16, whose 128-dword rows put every read of a half wave on the same banks), 2x150 5.8 vs 5.2;
-    // 153..160 bases stay on trim_tpr (the 160-wide slots leave room for 8 waves only: 4.38 vs 4.69)
-    // Lane-per-read passes read "their" read at a lane stride of one read length: equal-length reads of 4 x (a multiple of 8)
-    // bases put 8 (96 bases) or 32 (128 bases) lanes on each LDS bank -- 2x128 runs at 3.2 G reads/s here against 5.0 on
-    // trim_tpr, 2x96 6.2 against 6.7 (profiles/r2c/len_sweep.txt); 4-way strides (112, 144) are a toss-up and stay.
+    // (rounds 2-3: 153..160 bases and every multiple of 32 stayed on trim_tpr -- 8 waves with 160-wide slots; 2x128 at 3.2 G reads/s
+    // here against 5.0 there, every lane of a lane-per-read pass on one LDS bank.  Round 4: 16 lanes per read with smaller chunks
+    // from 153 bases on, padded rows for equal-length chunks of a multiple of 32 bases: 2x128 8.3, 2x155 5.2)
     if (max_len > 76 && max_len <= 104) FAQCS_LDS_CASE(13);  // 2x100
     if (max_len > 104 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x125, 2x150
 #undef FAQCS_LDS_CASE
-    // 16 lanes per read: 161 ... 252 bases (2x250, 2x251); FAQCS_TRIM_LDS16=0 switches it off (A/B against trim_filter_accumulate)
+    // 16 lanes per read: 153 ... 252 bases (2x250, 2x251); FAQCS_TRIM_LDS16=0 switches it off (A/B against trim_filter_accumulate)
     static const bool lds16_on = [] { const char *e = getenv("FAQCS_TRIM_LDS16"); return !e || atoi(e) != 0; }();
     if (lds16_on && max_len > 152 && max_len <= (uint32_t)lds_maxlen(16, 16))
         return ext ? (windowed ? launch_trim_lds<16, true, true, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS) : launch_trim_lds<16, false, true, 16, FAQCS_LDS16_RPC>(FAQCS_LDS_ARGS))
