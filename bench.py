@@ -599,16 +599,32 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
             # adapter_overlap is bound by integer VALU issue, not by HBM: the work is L x sum|adapter| cell updates per
             # read (62 850 for the 9 built-ins + polyA at L = 150); the instruction count per read comes from the PMC profile
             cells = 62850.0 * L / 150.0
-            # VALU issue: SQ_INSTS_VALU per read of adapter_overlap from its PMC profile (profiles/r2c/pmc_adapter.txt: 683 at L = 150, 5 %
-            # read-through) x reads/s, against the MEASURED issue rate of the instruction class the kernel is made of (v_bitop3, v_bcnt,
-            # v_alignbit, DPP, compares: 4 cycles per wave instruction = 575 G/s chip-wide; only plain VOP1/VOP2 integer ops reach
-            # 1 000 G/s -- profiles/r3a/valu_lds_peak.txt)
-            valu_per_read = 683.0 * L / 150.0
-            g_instr = reads_per_launch * valu_per_read / (dom_ms * 1e-3) / 1e9
-            out["roofline"]["valu"] = {"cell_updates_per_s": round(reads_per_launch * cells / (dom_ms * 1e-3) / 1e12, 3), "unit": "T cell updates/s",
-                                       "G_wave_instr_per_s": round(g_instr, 1), "measured_peak_G_wave_instr_per_s": 575.0, "frac": round(g_instr / 575.0, 4),
-                                       "valu_instr_per_read": valu_per_read,
-                                       "note": "bound by VALU issue: instruction count per read from profiles/r2c/pmc_adapter.txt, peak from profiles/r3a/valu_lds_peak.txt"}
+            # VALU and scalar issue: SQ_INSTS_VALU / SQ_INSTS_SALU + SQ_INSTS_BRANCH per read of adapter_overlap from its latest PMC profile
+            # (profiles/adapter_counters.json, stored like the k-mer counters) x reads/s.  The vector side is priced against the MEASURED issue
+            # rate of the instruction class the kernel is made of (v_bitop3, v_bcnt, v_alignbit, DPP, compares: 4 cycles per wave instruction =
+            # 575 G/s chip-wide; only plain VOP1/VOP2 integer ops reach 1 000 G/s -- profiles/r3a/valu_lds_peak.txt), the scalar side against
+            # one scalar instruction per clock and CU (measured with trim_long).
+            ac = {}
+            try:
+                ac = json.load(open(os.path.join(ROOT, "profiles", "adapter_counters.json")))
+            except Exception:
+                pass
+            valu = {"cell_updates_per_s": round(reads_per_launch * cells / (dom_ms * 1e-3) / 1e12, 3), "unit": "T cell updates/s",
+                    "measured_peak_G_wave_instr_per_s": 575.0, "G_wave_instr_per_s": None, "frac": None}
+            if ac.get("valu_per_read"):
+                reads_per_s = reads_per_launch / (dom_ms * 1e-3)
+                valu_per_read = float(ac["valu_per_read"]) * L / 150.0
+                g_instr = reads_per_s * valu_per_read / 1e9
+                scal_per_read = (float(ac.get("salu_per_read", 0.0)) + float(ac.get("branches_per_read", 0.0))) * L / 150.0
+                n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+                clk = float(getattr(torch.cuda.get_device_properties(0), "clock_rate", 0) or 2.4e6) * 1e3  # (kHz; MI355X: 2.4 GHz peak)
+                valu.update({"G_wave_instr_per_s": round(g_instr, 1), "frac": round(g_instr / 575.0, 4), "valu_instr_per_read": round(valu_per_read, 1),
+                             "scalar_instr_per_read": round(scal_per_read, 1),
+                             "scalar_instr_per_cu_clock": round(reads_per_s * scal_per_read / (n_cu * clk), 3),
+                             "counters_source": ac.get("counters_source"),
+                             "note": "co-bound by vector issue (frac: wave instructions/s against the measured 575 G/s of 4-cycle instructions) and scalar issue "
+                                     "(scalar_instr_per_cu_clock against 1 per clock and CU at the device's peak clock); peak from profiles/r3a/valu_lds_peak.txt"})
+            out["roofline"]["valu"] = valu
         if want_host_sample:
             ns = int(min(max(400000, 2 * a.e2e_pairs if config != "kmer" else 0), batches[0][6]))
             keep["hs"] = batches[0][0][: ns * L].cpu().numpy()
