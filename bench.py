@@ -435,6 +435,13 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         kmer_epochs = ep[rank * per_rank:(rank + 1) * per_rank]
         kx = parallel.KmerExchange(eng, rank, world, opt.num_subsample)
     kmer_last = {}
+    # FAQCS_BENCH_NATIVE_RCCL=1 (opt-in; needs the nccl backend): the library's own communicator -- the counter block is all-reduced in place on
+    # the engine's compute stream (faqcs_comm_allreduce_counters) instead of through a torch staging tensor.  Not the default: with two or
+    # more ranks it has never run on hardware.
+    native_rccl = False
+    if use_dist and os.environ.get("FAQCS_BENCH_NATIVE_RCCL", "0") not in ("", "0") and dist.get_backend() == "nccl":
+        parallel.native_comm_init(eng)
+        native_rccl = True
     coll = [0.0, 0]  # seconds in the counter all-reduce (export, all-reduce, import; behind a sync, so it is the collective alone), calls
 
     def step(flags=True):
@@ -455,7 +462,13 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
             pts, _hist = kx.finish(kmer_points_seq, n_reads * world)
             kmer_last["points"] = len(pts)
             kmer_last["distinct"], kmer_last["total"] = (pts[-1][1], pts[-1][2]) if pts else (0, 0)
-        if use_dist:
+        if use_dist and native_rccl:  # enqueued behind the kernels: no sync in front of it, the one behind it is the step's own
+            tc = time.perf_counter()
+            parallel.allreduce_counters_device(eng)
+            eng.sync()
+            coll[0] += time.perf_counter() - tc  # (here: the tail of the kernels + the collective)
+            coll[1] += 1
+        elif use_dist:
             eng.sync()
             tc = time.perf_counter()
             parallel.allreduce_counters_device(eng)  # the job's one collective: the 1.1 MB counter block, once per job (= step)
@@ -559,8 +572,10 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         if noflag_value is not None:
             out["config"]["value_without_terminal_n_flags"] = noflag_value
         if coll[1]:
-            out["collective"] = {"what": "all-reduce(sum) of the %d-word u64 counter block, once per job: device-to-device export into a torch tensor, "
-                                         "dist.all_reduce (%s), import" % (eng.n_counters, backend),
+            out["collective"] = {"what": ("all-reduce(sum) of the %d-word u64 counter block, once per job, IN PLACE on the engine's compute stream by the library's own RCCL "
+                                          "communicator (faqcs_comm_allreduce_counters); ms_per_step includes the wait for the step's last kernels" % eng.n_counters) if native_rccl else
+                                         ("all-reduce(sum) of the %d-word u64 counter block, once per job: device-to-device export into a torch tensor, "
+                                          "dist.all_reduce (%s), import" % (eng.n_counters, backend)),
                                  "ms_per_step": round(coll[0] / coll[1] * 1e3, 4), "calls": coll[1]}
         if config == "kmer" and kx is not None:
             out["kmer"] = {"G_inserts_per_s": round(kmer_last.get("total", 0) / (dt / steps) / 1e9, 3), "distinct_at_last_point": int(kmer_last.get("distinct", 0)),

@@ -167,6 +167,11 @@ def load_library():
         "faqcs_kmer_insert_device": (i32, [vp, vp, u64]),
         "faqcs_kmer_epoch_counts": (i32, [vp, vp, vp, u32]),
         "faqcs_kmer_forward": (i32, [vp, vp, u32]),
+        "faqcs_comm_id": (i32, [vp]),
+        "faqcs_comm_init": (i32, [vp, vp, u32, u32]),
+        "faqcs_comm_allreduce_counters": (i32, [vp]),
+        "faqcs_comm_init_all": (i32, [vp, u32]),
+        "faqcs_comm_allreduce_counters_all": (i32, [vp, u32]),
         "faqcs_synth_fill": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, C.c_float]),
         "faqcs_synth_fill_genome": (i32, [i32, vp, vp, vp, u32, u32, u64, u64, u64]),
         "faqcs_terminal_n_flags": (i32, [i32, vp, vp, u32, vp]),

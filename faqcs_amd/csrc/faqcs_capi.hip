@@ -5,6 +5,7 @@
 // the additive u64 counter block, the adapter tables and the k-mer hash table.
 // There is NO CPU implementation of the hot path in this library: without a HIP device faqcs_create() fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -154,6 +155,8 @@ struct faqcs_ctx {
     uint64_t kernel_launches = 0;
     hipEvent_t ins_a = nullptr, ins_b = nullptr;
     const char *trim_kernel = "";
+    void *comm = nullptr;          // ncclComm_t (faqcs_comm_init / faqcs_comm_init_all)
+    hipEvent_t comm_ev = nullptr;  // the aux stream's work (composition fold) before the collective
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -411,6 +414,8 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     return 0;
 }
 
+static void comm_release(void *comm); // (ncclCommDestroy: defined with the rest of the RCCL glue further down)
+
 extern "C" void faqcs_destroy(faqcs_ctx *c)
 {
     if (!c) return;
@@ -419,6 +424,8 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
     for (auto &t : c->timings) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.p); (void)hipEventDestroy(t.k0); (void)hipEventDestroy(t.k1); }
+    if (c->comm) comm_release(c->comm);
+    if (c->comm_ev) (void)hipEventDestroy(c->comm_ev);
     if (c->ins_a) (void)hipEventDestroy(c->ins_a);
     if (c->ins_b) (void)hipEventDestroy(c->ins_b);
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_partials, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
@@ -986,6 +993,129 @@ extern "C" int faqcs_counters_import(faqcs_ctx *c, const void *d_src, uint64_t n
     HIPCHK(hipStreamSynchronize(c->aux));
     HIPCHK(hipMemcpyAsync(c->d_counters, d_src, c->lay.total * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// native collective: the counter block all-reduced in place by RCCL (loaded at run time; see include/faqcs_mi.h)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct RcclId { char internal[FAQCS_COMM_ID_BYTES]; }; // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES == 128), passed by value
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int kNcclUint64 = 5, kNcclSum = 0; // ncclDataType_t / ncclRedOp_t of rccl.h (ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5)
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        const char *names[] = {getenv("FAQCS_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) { if (n && *n && (x.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; }
+        if (!x.lib) return x;
+        auto sym = [&](const char *n) { return dlsym(x.lib, n); };
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+        x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommInitAll && x.CommDestroy && x.AllReduce && x.GroupStart && x.GroupEnd;
+        return x;
+    }();
+    return r;
+}
+int rccl_fail(const char *what, int rc)
+{
+    Rccl &r = rccl();
+    std::string m = std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+    return fail(FAQCS_E_NODEVICE, m.c_str());
+}
+#define RCCLCHK(call, what) do { const int rc_ = (call); if (rc_ != 0) return rccl_fail(what, rc_); } while (0)
+// the collective of one context, enqueued on its compute stream behind everything the context has submitted (both streams)
+int comm_enqueue(faqcs_ctx *c)
+{
+    Rccl &r = rccl();
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->comm_ev) HIPCHK(hipEventCreateWithFlags(&c->comm_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->comm_ev, c->aux));             // (the composition fold adds to the block on the aux stream)
+    HIPCHK(hipStreamWaitEvent(c->compute, c->comm_ev, 0));
+    RCCLCHK(r.AllReduce(c->d_counters, c->d_counters, (size_t)c->lay.total, kNcclUint64, kNcclSum, c->comm, c->compute), "ncclAllReduce");
+    return 0;
+}
+} // namespace
+
+static void comm_release(void *comm) { if (rccl().CommDestroy) (void)rccl().CommDestroy(comm); }
+
+extern "C" int faqcs_comm_id(void *id)
+{
+    if (!id) return fail(FAQCS_E_INVAL, "faqcs_comm_id: null id");
+    Rccl &r = rccl();
+    if (!r.ok) return fail(FAQCS_E_NODEVICE, "faqcs_comm_id: librccl.so could not be loaded (FAQCS_RCCL_LIB names another file)");
+    RcclId u;
+    RCCLCHK(r.GetUniqueId(&u), "ncclGetUniqueId");
+    memcpy(id, u.internal, FAQCS_COMM_ID_BYTES);
+    return 0;
+}
+
+extern "C" int faqcs_comm_init(faqcs_ctx *c, const void *id, uint32_t rank, uint32_t world)
+{
+    if (!c || !id || world == 0 || rank >= world) return fail(FAQCS_E_INVAL, "faqcs_comm_init: bad ctx / id / rank / world");
+    if (c->comm) return fail(FAQCS_E_INVAL, "faqcs_comm_init: the context already has a communicator");
+    Rccl &r = rccl();
+    if (!r.ok) return fail(FAQCS_E_NODEVICE, "faqcs_comm_init: librccl.so could not be loaded (FAQCS_RCCL_LIB names another file)");
+    HIPCHK(hipSetDevice(c->device));
+    RcclId u;
+    memcpy(u.internal, id, FAQCS_COMM_ID_BYTES);
+    RCCLCHK(r.CommInitRank(&c->comm, (int)world, u, (int)rank), "ncclCommInitRank");
+    return 0;
+}
+
+extern "C" int faqcs_comm_allreduce_counters(faqcs_ctx *c)
+{
+    if (!c || !c->comm) return fail(FAQCS_E_INVAL, "faqcs_comm_allreduce_counters: faqcs_comm_init() first");
+    return comm_enqueue(c);
+}
+
+extern "C" int faqcs_comm_init_all(faqcs_ctx *const *ctxs, uint32_t n)
+{
+    if (!ctxs || n == 0 || n > 64) return fail(FAQCS_E_INVAL, "faqcs_comm_init_all: bad context list");
+    Rccl &r = rccl();
+    if (!r.ok) return fail(FAQCS_E_NODEVICE, "faqcs_comm_init_all: librccl.so could not be loaded (FAQCS_RCCL_LIB names another file)");
+    std::vector<int> dev(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->comm) return fail(FAQCS_E_INVAL, "faqcs_comm_init_all: null context or one that has a communicator");
+        if (ctxs[i]->lay.total != ctxs[0]->lay.total) return fail(FAQCS_E_INVAL, "faqcs_comm_init_all: the contexts' counter blocks differ in size");
+        dev[i] = ctxs[i]->device;
+        for (uint32_t j = 0; j < i; ++j) if (dev[j] == dev[i]) return fail(FAQCS_E_INVAL, "faqcs_comm_init_all: two contexts on one device (RCCL wants one rank per device)");
+    }
+    std::vector<void *> comms(n, nullptr);
+    RCCLCHK(r.CommInitAll(comms.data(), (int)n, dev.data()), "ncclCommInitAll");
+    for (uint32_t i = 0; i < n; ++i) ctxs[i]->comm = comms[i];
+    return 0;
+}
+
+extern "C" int faqcs_comm_allreduce_counters_all(faqcs_ctx *const *ctxs, uint32_t n)
+{
+    if (!ctxs || n == 0) return fail(FAQCS_E_INVAL, "faqcs_comm_allreduce_counters_all: bad context list");
+    for (uint32_t i = 0; i < n; ++i) if (!ctxs[i] || !ctxs[i]->comm) return fail(FAQCS_E_INVAL, "faqcs_comm_allreduce_counters_all: faqcs_comm_init_all() first");
+    Rccl &r = rccl();
+    RCCLCHK(r.GroupStart(), "ncclGroupStart");
+    int rc = 0;
+    for (uint32_t i = 0; i < n && rc == 0; ++i) rc = comm_enqueue(ctxs[i]);
+    const int ge = r.GroupEnd();
+    if (rc) return rc;
+    RCCLCHK(ge, "ncclGroupEnd");
     return 0;
 }
 

@@ -2133,10 +2133,21 @@ static int run_command(int argc, char **argv)
         faqcs_layout L;
         faqcs_counters_layout(r.R, r.prm.n_adapters, &L);
         std::vector<uint64_t> c(L.total), part(L.total);
+        // Every accumulator is a sum of per-read integers (trim.cpp:120-154): the devices' blocks are added up -- by RCCL, in place on
+        // the devices (faqcs_comm_*: one grouped all-reduce over xGMI), when the contexts sit on different devices and librccl is there;
+        // on the host otherwise (two contexts on one device, no library, FAQCS_MI_HOST_SUM=1).
+        bool reduced = false;
+        if (r.ctxs.size() > 1 && !(getenv("FAQCS_MI_HOST_SUM") && atoi(getenv("FAQCS_MI_HOST_SUM")) != 0)) {
+            if (faqcs_comm_init_all(r.ctxs.data(), (uint32_t)r.ctxs.size()) == 0) {
+                Run::check(faqcs_comm_allreduce_counters_all(r.ctxs.data(), (uint32_t)r.ctxs.size())); // (a collective that fails half way leaves nothing to fall back on)
+                reduced = true;
+                tmark("counter blocks all-reduced on the devices");
+            }
+        }
         Run::check(faqcs_finish(r.ctx, c.data(), c.size()));
-        for (size_t k = 1; k < r.ctxs.size(); ++k) { // every accumulator is a sum of per-read integers (trim.cpp:120-154): add the devices' blocks
+        for (size_t k = 1; k < r.ctxs.size(); ++k) { // (every context is finished: a read that tripped an error on any device ends the run)
             Run::check(faqcs_finish(r.ctxs[k], part.data(), part.size()));
-            for (size_t i = 0; i < c.size(); ++i) c[i] += part[i];
+            if (!reduced) for (size_t i = 0; i < c.size(); ++i) c[i] += part[i];
         }
         uint64_t fs[FAQCS_NUM_STAT];
         for (int k = 0; k < FAQCS_NUM_STAT; ++k) fs[k] = c[L.filter_stats + k];

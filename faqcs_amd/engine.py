@@ -76,6 +76,21 @@ class HipEngine:
     def counters_import(self, d_src, n_u64):
         _check(self.lib, self.lib.faqcs_counters_import(self.ctx, d_src, int(n_u64)))
 
+    def comm_init(self, comm_id, rank, world):
+        """The library's own RCCL communicator (include/faqcs_mi.h): comm_id = the FAQCS_COMM_ID_BYTES bytes rank 0 got from comm_id()."""
+        buf = C.create_string_buffer(bytes(comm_id), 128)
+        _check(self.lib, self.lib.faqcs_comm_init(self.ctx, buf, int(rank), int(world)))
+        self.has_comm = True
+
+    def comm_id(self):
+        buf = C.create_string_buffer(128)
+        _check(self.lib, self.lib.faqcs_comm_id(buf))
+        return buf.raw
+
+    def comm_allreduce_counters(self):
+        """All-reduce(sum) of the counter block in place, enqueued on the context's compute stream (no copy, no host sync)."""
+        _check(self.lib, self.lib.faqcs_comm_allreduce_counters(self.ctx))
+
     def counters(self):
         out = np.zeros(self.n_counters, dtype=np.uint64)
         _check(self.lib, self.lib.faqcs_finish(self.ctx, out.ctypes.data, self.n_counters))

@@ -24,6 +24,19 @@ def shard_bounds(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def native_comm_init(engine, group=None):
+    """The library's own RCCL communicator for `engine` (faqcs_comm_init): rank 0 draws the id, the process group carries its 128
+    bytes to the other ranks, every rank joins.  After this, allreduce_counters_device() reduces the block in place on the engine's
+    compute stream -- no staging tensor, no stream synchronisation.  Opt-in (bench.py: FAQCS_BENCH_NATIVE_RCCL=1): with two or
+    more ranks this path has not run on hardware (no multi-GPU box was available to any round)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [engine.comm_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(box[0], rank, world)
+
+
 def allreduce_counters_device(engine, group=None):
     """All-reduce(sum) of the engine's device-resident counter block, in place.
 
@@ -37,6 +50,9 @@ def allreduce_counters_device(engine, group=None):
     import torch.distributed as dist
 
     n = engine.n_counters
+    if getattr(engine, "has_comm", False):  # native_comm_init() was called: in place, on the engine's own stream
+        engine.comm_allreduce_counters()
+        return None
     if dist.get_backend(group) == "nccl":
         t = getattr(engine, "_allreduce_buf", None)
         if t is None or t.numel() != n:

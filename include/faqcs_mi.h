@@ -231,6 +231,23 @@ int  faqcs_counters_import(faqcs_ctx *ctx, const void *d_src, uint64_t n_u64);
 int  faqcs_finish(faqcs_ctx *ctx, uint64_t *counters, uint64_t n_u64);
 int  faqcs_reset_counters(faqcs_ctx *ctx);
 
+/* The merge of the reference (trim.cpp:120-154: every OpenMP thread adds its private counters to the caller's under `omp critical`) across
+ * GPUs: all-reduce(sum) of the additive counter block IN PLACE, by RCCL over xGMI, enqueued on the context's compute stream behind its
+ * kernels -- no staging copy, no host round trip.  librccl.so is loaded at the first call (the library does not
+ * link it); every call fails with FAQCS_E_NODEVICE and a message when it is missing or reports an error, and the caller can fall back on
+ * faqcs_counters_export / _import + its own collective.
+ *   one process per GPU:  rank 0 calls faqcs_comm_id() and hands the FAQCS_COMM_ID_BYTES bytes to the other ranks (any channel); every rank
+ *                         calls faqcs_comm_init(ctx, id, rank, world) (collective), then faqcs_comm_allreduce_counters(ctx) per pass.
+ *   one process, n GPUs:  faqcs_comm_init_all(ctxs, n) once (the contexts must sit on n different devices), then
+ *                         faqcs_comm_allreduce_counters_all(ctxs, n) -- one grouped call for all of them.
+ * The communicator is released by faqcs_destroy(). */
+#define FAQCS_COMM_ID_BYTES 128
+int  faqcs_comm_id(void *id);
+int  faqcs_comm_init(faqcs_ctx *ctx, const void *id, uint32_t rank, uint32_t world);
+int  faqcs_comm_allreduce_counters(faqcs_ctx *ctx);
+int  faqcs_comm_init_all(faqcs_ctx *const *ctxs, uint32_t n);
+int  faqcs_comm_allreduce_counters_all(faqcs_ctx *const *ctxs, uint32_t n);
+
 /* k-mer rarefaction (trim.cpp:157-185, FaQCs.cpp:518-537).  The k-mers of a submission are extracted when it is submitted and reach
  * the table in groups (combine-before-insert); faqcs_sync() -- which the calls below make -- completes the open
  * group.  Points are appended at segment ends during submit; their (distinct, total) are filled in after faqcs_sync():  */

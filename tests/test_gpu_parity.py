@@ -492,7 +492,7 @@ def test_three_rank_kmer_exchange(tmp_path):
     test_two_rank_kmer_exchange(["--kmer_rarefaction", "--split_size", "400", "--subset", "200"], 2900, 250, tmp_path, world=3)
 
 
-def _counter_rank(rank, world, port, args, n_reads, out, backend="gloo"):
+def _counter_rank(rank, world, port, args, n_reads, out, backend="gloo", native=False):
     import os
     import sys
 
@@ -520,8 +520,10 @@ def _counter_rank(rank, world, port, args, n_reads, out, backend="gloo"):
     lo, hi = parallel.shard_bounds(len(segs), rank, world)
     eng = HipEngine(opt, 256, 33, device=0)
     seq, qual, offset, seg = driver.pack_segments(segs[lo:hi])
+    if native:  # the library's own RCCL communicator: the block is all-reduced in place on the engine's compute stream
+        parallel.native_comm_init(eng)
     res = eng.process(seq, qual, offset, seg)
-    parallel.allreduce_counters_device(eng)  # export -> all-reduce -> import: the block on the device is the job's total
+    parallel.allreduce_counters_device(eng)  # export -> all-reduce -> import (or in place): the block on the device is the job's total
     total = eng.counters()
     n_before = sum(len(x) for x in segs[:lo])
     ora = OracleEngine(opt, 256, 33)
@@ -572,6 +574,11 @@ def test_rccl_code_paths_on_one_rank(tmp_path):
         out = str(tmp_path / ("result_%s.txt" % fn.__name__))
         if fn is _counter_rank:
             mp.spawn(fn, args=(1, port, args[0], args[1], out, "nccl"), nprocs=1, join=True)
+            assert open(out).read() == "ok", open(out).read()
+            os.remove(out)
+            # ... and through the library's own communicator (faqcs_comm_init / faqcs_comm_allreduce_counters: librccl loaded by the library,
+            # the block reduced in place behind the kernels and the composition fold, no staging tensor)
+            mp.spawn(fn, args=(1, port, args[0], args[1], out, "nccl", True), nprocs=1, join=True)
         else:
             mp.spawn(fn, args=(1, port, args[0], args[1], args[2], out, 150, "nccl"), nprocs=1, join=True)
         assert open(out).read() == "ok", open(out).read()
@@ -598,7 +605,8 @@ def test_bench_gpus_2_runs_two_ranks(tmp_path):
     assert r2.returncode != 0 and b"disagrees" in r2.stderr
 
 
-def test_bench_under_the_drivers_launcher_with_one_rank():
+@pytest.mark.parametrize("native", [False, True], ids=["torch_allreduce", "native_rccl"])
+def test_bench_under_the_drivers_launcher_with_one_rank(native):
     """The command line the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
     with N = 1: bench.py then forms the `nccl` process group, all-reduces the counter block through RCCL every step and takes the MAX of
     the step times, exactly as on an 8-GPU node."""
@@ -613,14 +621,43 @@ def test_bench_under_the_drivers_launcher_with_one_rank():
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ)
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FAQCS_BENCH_SHARE_GPU", "FAQCS_BENCH_BACKEND"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FAQCS_BENCH_SHARE_GPU", "FAQCS_BENCH_BACKEND", "FAQCS_BENCH_NATIVE_RCCL"):
         env.pop(k, None)
+    if native:
+        env["FAQCS_BENCH_NATIVE_RCCL"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--pairs", "4e6", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--e2e-pairs", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
     line = json.loads([l for l in r.stdout.decode().strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["kernel"] == "trim_lds"
+    assert ("IN PLACE" in line["collective"]["what"]) == native and line["collective"]["calls"] >= 3
+
+
+def test_native_collective_in_one_process():
+    """faqcs_comm_init_all / faqcs_comm_allreduce_counters_all (what `faqcs_mi --gpus N` sums its devices' blocks with): a communicator over
+    ONE context leaves its block as it is -- through librccl's ncclCommInitAll and a grouped ncclAllReduce on the real device; two
+    contexts on one device are refused (the command line then adds the blocks on the host), and nothing is touched by the refusal."""
+    import ctypes as C
+
+    from faqcs_amd.engine import HipEngine
+
+    opt = parse_args(["-u", "x", "-d", "y", "--adapter"])
+    rng = np.random.Generator(np.random.PCG64([17, SEED]))
+    reads = random_batch(rng, 1500, 150, "adv")
+    hip, ora = compare_engines(opt, reads, seg_size=400)
+    want = ora.counters()
+    one = (C.c_void_p * 1)(hip.ctx)
+    assert hip.lib.faqcs_comm_init_all(one, 1) == 0, hip.lib.faqcs_last_error()
+    assert hip.lib.faqcs_comm_allreduce_counters_all(one, 1) == 0, hip.lib.faqcs_last_error()
+    assert (hip.counters() == want).all()
+    assert hip.lib.faqcs_comm_init_all(one, 1) != 0  # (it has a communicator already)
+    other = HipEngine(opt, 256, 33, device=0)
+    two = (C.c_void_p * 2)(other.ctx, C.c_void_p(0))  # (filled below: two DIFFERENT contexts, both on device 0)
+    third = HipEngine(opt, 256, 33, device=0)
+    two = (C.c_void_p * 2)(other.ctx, third.ctx)
+    assert hip.lib.faqcs_comm_init_all(two, 2) != 0 and b"one device" in (hip.lib.faqcs_last_error() or b"")
+    assert (hip.counters() == want).all()
 
 
 def test_full_size_properties():
