@@ -78,7 +78,7 @@ namespace {
 // 16 lanes per read, C = 19 (reads of 253 ... 304 bases: 2x300): 20 positions per lane in Q-B as in the 8-lane variant, 21 cells per lane, rows of 352.
 constexpr int lds_cq(int C, int LPR = 8) { return C == 19 ? 20 : C; }
 constexpr int lds_qstride(int C, int LPR = 8) { return LPR == 16 ? lds_cq(C, LPR) + 1 : lds_cq(C, LPR); } // cells from one lane's first position to the next lane's
-constexpr int lds_wq(int C, int LPR = 8) { return LPR == 16 ? (16 * lds_qstride(C, 16) + 31) / 32 * 32 : (C == 19 ? 160 : 0); }
+constexpr int lds_wq(int C, int LPR = 8) { return (LPR == 16 || C == 19) ? (LPR * lds_qstride(C, LPR) + 31) / 32 * 32 : 0; } // (8 lanes, C = 19: 160; 4 lanes: 96)
 constexpr int lds_nrot(int C, int LPR = 8) { return LPR == 16 ? 2 : (C == 19 ? 4 : 1); }   // reads of a half wave = byte rotations in use
 // The longest read a variant takes.  Up to 252 bases the step index of a walk lives in the low byte of the argmax keys (codes 254 - step), a
 // window's start and length in a byte each, a read's N count in 8 bits; the 304-base variant (lds_wide) has nine-bit codes and fields, the
@@ -292,7 +292,7 @@ __device__ __noinline__ ExactB exact_bases(const uint8_t *__restrict__ seq, cons
 } // namespace
 
 // waves per block = slots of 64 x MAXLEN bytes next to the accumulators in 160 KB: 12 x 9.8 KB + 37 KB (8 lanes per read), 6 x 16.2 KB + 63 KB (16)
-constexpr int lds_waves(int C, int LPR = 8, int RPC = 64) { return LPR == 16 ? (RPC == 64 ? 6 : (C == 19 ? 12 : FAQCS_LDS16_NW)) : (C <= 19 ? 12 : 8); }
+constexpr int lds_waves(int C, int LPR = 8, int RPC = 64) { return LPR == 4 ? 12 : LPR == 16 ? (RPC == 64 ? 6 : (C == 19 ? 12 : FAQCS_LDS16_NW)) : (C <= 19 ? 12 : 8); }
 
 // LDS accumulators -> a row of global memory that belongs to THIS block and THIS flush, as plain coalesced 16-byte stores of the
 // cells as they are (pre count in the low, post count in the high half-word); fold_partials, launched behind the trim kernel, adds
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     unsigned long long *__restrict__ rec_post, uint64_t *__restrict__ counters, uint32_t *__restrict__ err,
     const uint8_t *__restrict__ tn_flags)
 {
-    static_assert(LPR == 8 || (LPR == 16 && (C == 16 || C == 19)), "lanes per read");
+    static_assert(LPR == 8 || (LPR == 16 && (C == 16 || C == 19)) || (LPR == 4 && (C == 13 || C == 19)), "lanes per read");
     using Cfg = RowCfg<C, LPR, lds_wq(C, LPR)>;
     static_assert(RPC <= 64 && (RPC * LPR) % 64 == 0, "reads per chunk: the same number for every row of LPR lanes");
     using T = LdsCfg<C, NW, LPR, RPC>;
@@ -716,10 +716,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             po += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)po, 0x4E, 0xf, 0xf, false);
             ce += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ce, 0x4E, 0xf, 0xf, false);
             co += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)co, 0x4E, 0xf, 0xf, false);
-            pe += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x141, 0xf, 0xf, false);
-            po += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)po, 0x141, 0xf, 0xf, false);
-            ce += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ce, 0x141, 0xf, 0xf, false);
-            co += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)co, 0x141, 0xf, 0xf, false);
+            if (LPR >= 8) { // (4 lanes per read: the two steps above are the whole quad)
+                pe += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x141, 0xf, 0xf, false);
+                po += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)po, 0x141, 0xf, 0xf, false);
+                ce += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ce, 0x141, 0xf, 0xf, false);
+                co += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)co, 0x141, 0xf, 0xf, false);
+            }
             if (LPR == 16) { // the other half of the row (a read of <= 252 bases: 12-bit fields, an N count below 256)
                 pe += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x140, 0xf, 0xf, false);
                 po += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)po, 0x140, 0xf, 0xf, false);
@@ -1530,6 +1532,15 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
     // (rounds 2-3: 153..160 bases and every multiple of 32 stayed on trim_tpr -- 8 waves with 160-wide slots; 2x128 at 3.2 G reads/s
     // here against 5.0 there, every lane of a lane-per-read pass on one LDS bank.  Round 4: 16 lanes per read with smaller chunks
     // from 153 bases on, padded rows for equal-length chunks of a multiple of 32 bases: 2x128 8.3, 2x155 5.2)
+    // 4 lanes per read: reads of up to 76 bases (2x50, 2x75) -- sixteen reads per step of the position-parallel passes; FAQCS_TRIM_LDS4=0 leaves
+    // them to trim_tpr as in rounds 1-3
+    static const bool lds4_on = [] { const char *e = getenv("FAQCS_TRIM_LDS4"); return !e || atoi(e) != 0; }();
+    if (lds4_on && max_len > 0 && max_len <= 52)
+        return ext ? (windowed ? launch_trim_lds<13, true, true, 4>(FAQCS_LDS_ARGS) : launch_trim_lds<13, false, true, 4>(FAQCS_LDS_ARGS))
+                   : (windowed ? launch_trim_lds<13, true, false, 4>(FAQCS_LDS_ARGS) : launch_trim_lds<13, false, false, 4>(FAQCS_LDS_ARGS));
+    if (lds4_on && max_len > 52 && max_len <= 76)
+        return ext ? (windowed ? launch_trim_lds<19, true, true, 4>(FAQCS_LDS_ARGS) : launch_trim_lds<19, false, true, 4>(FAQCS_LDS_ARGS))
+                   : (windowed ? launch_trim_lds<19, true, false, 4>(FAQCS_LDS_ARGS) : launch_trim_lds<19, false, false, 4>(FAQCS_LDS_ARGS));
     if (max_len > 76 && max_len <= 104) FAQCS_LDS_CASE(13);  // 2x100
     if (max_len > 104 && max_len <= 152) FAQCS_LDS_CASE(19); // 2x125, 2x150
 #undef FAQCS_LDS_CASE

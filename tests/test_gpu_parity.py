@@ -260,7 +260,7 @@ def test_long_read_limits():
 
 @pytest.mark.parametrize("args", [OPTION_SETS[i] for i in (0, 1, 2, 8, 10, 13, 15, 18, 21, 23)], ids=lambda a: " ".join(a) or "default")
 @pytest.mark.parametrize("kind,maxlen", [("adv", 157), ("adv", 120), ("ragged", 104), ("adv", 200), ("ragged", 112), ("adv", 75), ("ragged", 50),
-                                         ("adv", 252), ("adv", 256), ("ragged", 224), ("adv", 300), ("ragged", 304), ("adv", 320)])
+                                         ("adv", 252), ("adv", 256), ("ragged", 224), ("adv", 300), ("ragged", 304), ("adv", 320), ("adv", 52), ("ragged", 30), ("adv", 53)])
 def test_every_kernel_width_matches_oracle(args, kind, maxlen):
     """One batch per position-slot width the dispatcher can pick (4 lanes per read: C = 16/19; 8 lanes: C = 13/16/19/20; 16 lanes: C = 13/16;
     trim_lds with 16 lanes per read up to 252 bases, trim_filter_accumulate past that and for multiples of 32)."""
@@ -281,12 +281,14 @@ def test_quality_offsets_that_leave_scores_outside_the_valid_range(in_off, kind,
     compare_engines(opt, random_batch(rng, 1200, maxlen, kind), R=256 if maxlen <= 256 else 1024, in_off=in_off, seg_size=500)
 
 
-def test_single_pass_kernel_variants_still_match_oracle():
-    """The default option set on reads of up to 160 bases runs trim_tpr; FAQCS_TRIM_TPR=0 (read once per process) sends the same
-    batches through the single-pass variants it replaced, which other option sets and A/B runs still use."""
+@pytest.mark.parametrize("switch", ["tpr_off", "lds_off"])
+def test_single_pass_kernel_variants_still_match_oracle(switch):
+    """Reads of up to 304 bases run trim_lds.  FAQCS_TRIM_LDS=0 (read once per process) sends the same batches through the kernels of
+    rounds 1-3 -- trim_tpr for the default-like option sets up to 160 bases, trim_filter_accumulate otherwise -- and FAQCS_TRIM_TPR=0 on top
+    of it through the single-pass variants alone: both are still what --replace_to_N_q, longer reads and A/B runs use."""
     import subprocess
     import sys
-    env = dict(os.environ, FAQCS_TRIM_TPR="0")
+    env = dict(os.environ, FAQCS_TRIM_LDS="0", **({"FAQCS_TRIM_TPR": "0"} if switch == "tpr_off" else {}))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "test_every_kernel_width_matches_oracle or test_edge_reads or test_quality_error_is_reported"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
@@ -762,7 +764,7 @@ def _check_slices(opt, R, seq, qual, off_host, res_dev, slices, L):
         assert len(bad) == 0, "reads %d..%d: first differing read %d: hip=%s oracle=%s" % (lo, hi, lo + bad[0], got[bad[0]], want[bad[0]])
 
 
-@pytest.mark.parametrize("L,kernel,ragged", [(150, "trim_lds", False), (150, "trim_lds", True), (128, "trim_lds", False), (75, "trim_tpr", False),
+@pytest.mark.parametrize("L,kernel,ragged", [(150, "trim_lds", False), (150, "trim_lds", True), (128, "trim_lds", False), (75, "trim_lds", False),
                                              (250, "trim_lds", False), (250, "trim_lds", True), (300, "trim_lds", False), (320, "trim_filter_accumulate", False)])
 def test_launch_at_the_4gib_arena_limit_matches_oracle(L, kernel, ragged):
     """The launch size bench.py uses: an arena of (2^32 - 4096) // L reads (u32 offsets up to 4 GiB).  The kernels do 32-bit
@@ -1233,7 +1235,7 @@ def test_at_rich_reads_match_oracle(args):
 
 
 @pytest.mark.parametrize("args", [[], ["--lc", "0.5"], ["--mode", "BWA"], ["--avg_q", "20", "-n", "1"]], ids=["default", "lc05", "bwa", "avgq"])
-@pytest.mark.parametrize("L", [4, 8, 76, 80, 96, 100, 104, 108, 120, 128, 144, 148, 150, 152, 156, 160, 161, 164, 192, 200, 224, 240, 248, 250, 251, 252, 253, 256, 288, 300, 301, 304])
+@pytest.mark.parametrize("L", [4, 8, 32, 36, 50, 51, 52, 53, 64, 75, 76, 80, 96, 100, 104, 108, 120, 128, 144, 148, 150, 152, 156, 160, 161, 164, 192, 200, 224, 240, 248, 250, 251, 252, 253, 256, 288, 300, 301, 304])
 def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, args):
     """Every read of the batch has the same length (mostly a multiple of 4: the wave's dword loops stop exactly at the read's
     end), a low-quality head that the 5' walk cuts and a high-quality tail, so the kept window is [a, L) with a > 0: its base
@@ -1255,7 +1257,7 @@ def test_equal_length_batches_with_a_kept_window_that_ends_on_the_last_base(L, a
 
 @pytest.mark.parametrize("args", [[], ["--adapter", "--polyA"], ["--lc", "0.5", "-n", "1"], ["--mode", "HARD", "-q", "10", "--avg_q", "30"], ["--5end", "7", "--3end", "3", "--mode", "BWA"]],
                          ids=["default", "adapter", "lc05_n1", "hard_avgq", "ends_bwa"])
-@pytest.mark.parametrize("L", [96, 128, 192, 224, 256, 288])
+@pytest.mark.parametrize("L", [32, 64, 96, 128, 192, 224, 256, 288])
 def test_chunks_of_equal_length_reads_in_padded_rows(L, args):
     """trim_lds stages a chunk whose reads all have the same length, a multiple of 32 bases, as padded rows (dma_rows) and any other chunk as
     one contiguous span: a batch that holds both kinds of chunk -- runs of equal-length reads broken by a shorter read here and there --
@@ -1285,7 +1287,8 @@ def test_chunks_of_equal_length_reads_in_padded_rows(L, args):
 
 @pytest.mark.parametrize("L,args,kernel", [
     (150, [], "trim_lds"), (151, ["--adapter"], "trim_lds"), (100, ["--mode", "HARD", "-q", "10"], "trim_lds"), (125, ["--qc_only"], "trim_lds"),
-    (128, [], "trim_lds"), (96, [], "trim_lds"), (75, [], "trim_tpr"), (160, [], "trim_lds"), (157, ["--5trim_off"], "trim_lds"), (64, [], "trim_tpr"),
+    (128, [], "trim_lds"), (96, [], "trim_lds"), (75, [], "trim_lds"), (160, [], "trim_lds"), (157, ["--5trim_off"], "trim_lds"), (64, [], "trim_lds"), (50, ["--adapter"], "trim_lds"), (36, ["--mode", "BWA"], "trim_lds"),
+    (75, ["--replace_to_N_q", "15"], "trim_filter_accumulate"),
     (150, ["--replace_to_N_q", "15"], "trim_filter_accumulate"), (128, ["--qc_only"], "trim_lds"), (192, ["--adapter"], "trim_lds"),
     (250, [], "trim_lds"), (251, ["--adapter", "--polyA"], "trim_lds"), (200, ["--mode", "BWA", "--avg_q", "20"], "trim_lds"), (161, [], "trim_lds"), (252, [], "trim_lds"),
     (253, [], "trim_lds"), (224, [], "trim_lds"), (256, [], "trim_lds"), (250, ["--replace_to_N_q", "15"], "trim_filter_accumulate"),
