@@ -700,7 +700,8 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
                                  c->d_counters, c->d_err, c->n_cu, c->compute, d_tn));
         HIPCHK(hipEventRecord(t.b, c->compute));
         c->trim_kernel = faqcs_last_trim_kernel();
-        if (!(c->dp.dbg & 1u) && !long_reads) {
+        static const bool no_comp = [] { const char *e = getenv("FAQCS_DIAG_NO_COMPOSITION"); return e && atoi(e) != 0; }(); // (diagnostic, wrong composition tables: what the fold costs a step)
+        if (!(c->dp.dbg & 1u) && !long_reads && !no_comp) {
             HIPCHK(hipEventRecord(rs.trimmed, c->compute));
             HIPCHK(hipStreamWaitEvent(c->aux, rs.trimmed, 0));
             HIPCHK(faqcs_launch_composition(rs.pre.p, rs.post.p, n, wide, c->d_norm, c->d_counters + c->lay.pre_comp,
