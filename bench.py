@@ -360,6 +360,59 @@ def main():
         dist.destroy_process_group()
 
 
+def verify_full_size(blk, lay, fs, results, n_reads, L, config, n_adapters):
+    """Consistency of the counter block of ONE job with itself and with the per-read results on the device (outside the timed region).
+    results: the batches' result tensors ([n, 4] int16 = start, kept, flags, 1 + credited adapter as u16)."""
+    import torch
+
+    from faqcs_amd import _capi as capi
+
+    def part(name):
+        o, n = lay[name]
+        return blk[o:o + n].astype(np.int64)
+
+    def fail(what, a, b):
+        raise SystemExit("bench: full-size check failed: %s: %d != %d" % (what, int(a), int(b)))
+
+    n_valid = kept_sum = 0
+    hits = torch.zeros(n_adapters + 2, dtype=torch.int64, device=results[0].device) if n_adapters else None
+    for r in results:
+        u = r.to(torch.int32) & 0xffff
+        valid = (u[:, 2] & 1) != 0
+        n_valid += int(valid.sum().item())
+        kept_sum += int((u[:, 1].to(torch.int64) * valid).sum().item())
+        if hits is not None:
+            hits += torch.bincount(u[:, 3].to(torch.int64).clamp(max=n_adapters + 1), minlength=n_adapters + 2)
+    tl, tn = int(fs[capi.TOTAL_LENGTH]), int(fs[capi.TOTAL_NUMBER])
+    ttl, ttn = int(fs[capi.TOTAL_TRIMMED_LENGTH]), int(fs[capi.TOTAL_TRIMMED_NUMBER])
+    if n_valid != ttn: fail("valid results vs TOTAL_TRIMMED_NUMBER", n_valid, ttn)
+    if kept_sum != ttl: fail("sum of kept lengths vs TOTAL_TRIMMED_LENGTH", kept_sum, ttl)
+    for name, want in (("pre_qual", tl), ("post_qual", ttl), ("pre_base", tl), ("post_base", ttl), ("pre_base_qhist", tl), ("post_base_qhist", ttl)):
+        if int(part(name).sum()) != want: fail("sum of " + name, part(name).sum(), want)
+    for name, want in (("pre_len_hist", tn), ("post_len_hist", ttn), ("pre_read_qhist", tn), ("post_read_qhist", ttn)):
+        if int(part(name).sum()) != want: fail("sum of " + name, part(name).sum(), want)
+    ln = np.arange(lay["pre_len_hist"][1], dtype=np.int64)
+    if int((part("pre_len_hist") * ln).sum()) != tl: fail("length histogram x length (pre)", (part("pre_len_hist") * ln).sum(), tl)
+    if int((part("post_len_hist") * ln).sum()) != ttl: fail("length histogram x length (post)", (part("post_len_hist") * ln).sum(), ttl)
+    # position p of the quality / base matrices holds one count per read that is longer than p
+    R = lay["pre_len_hist"][1] - 1
+    longer = tn - np.cumsum(part("pre_len_hist"))[:R]  # reads with length > p, p = 0 .. R - 1
+    for name, width in (("pre_qual", capi.NQ), ("pre_base", capi.NBASE)):
+        rows = part(name).reshape(R, width).sum(axis=1)
+        if not (rows == longer).all():
+            p = int(np.nonzero(rows != longer)[0][0])
+            fail("row %d of %s vs the reads longer than %d" % (p, name, p), rows[p], longer[p])
+    for name, want in (("pre_comp", tn), ("post_comp", ttn)):  # every read adds one count per kind
+        per_kind = part(name).reshape(capi.NCOMP_BIN, capi.NCOMP_KIND).sum(axis=0)
+        if not (per_kind == want).all(): fail("reads per kind of " + name, per_kind.min(), want)
+    if hits is not None:  # a read credited to adapter j is one of adapter_stats[j]'s reads
+        st = part("adapter_stats").reshape(n_adapters, 2)[:, 0]
+        h = hits.cpu().numpy()[1:n_adapters + 1]
+        if not (h == st).all():
+            j = int(np.nonzero(h != st)[0][0])
+            fail("reads credited to adapter %d vs adapter_stats" % j, h[j], st[j])
+
+
 def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sample):
     """One configuration: builds the resident data set, times `steps` steps, returns (the JSON object, a dict with a host
     sample of the data for the CPU baseline / the end-to-end run).  Frees its device memory before it returns."""
@@ -509,6 +562,10 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
     fs = blk[lay["filter_stats"][0]:lay["filter_stats"][0] + 32]
     if int(fs[capi.TOTAL_NUMBER]) != n_reads * world or int(fs[capi.TOTAL_LENGTH]) != n_reads * world * L:
         raise SystemExit("bench: counter block does not add up: %d reads counted, %d expected" % (int(fs[capi.TOTAL_NUMBER]), n_reads * world))
+    # ... and, at the job's full size, the accumulators must agree with each other and with the per-read results (size-independent
+    # properties: the oracle compares every counter on batches it can finish, tests/test_gpu_parity.py; this is the same block on 2 x 10^8 reads)
+    if world == 1:
+        verify_full_size(blk, lay, fs, [bb[3] for bb in batches], n_reads, L, config, eng.holder.n_adapters)
     # the same job with batches that carry no terminal_n flags (the kernel then looks at the two end bases of every read itself):
     # outside the timed region, reported beside the headline so that the effect of the flags is visible
     noflag_value = None

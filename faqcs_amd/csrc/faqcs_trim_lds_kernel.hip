@@ -236,6 +236,17 @@ __device__ __forceinline__ void dma_rows(const uint8_t *g, const uint32_t L, con
     }
 }
 
+// in_off bytes into the 16-byte alignment slack in front of a staged span and into the W + 20 bytes behind it (see where it is called)
+template <int W, int STG_BYTES>
+__device__ __forceinline__ void pad_behind_span(const uint32_t slot_b, const uint32_t span, const uint32_t slack, const int lane, const uint32_t in_off)
+{
+    if ((uint32_t)lane < slack) lds_st_u8(slot_b + (uint32_t)lane, in_off); // (the first read's first dword starts in the slack)
+    const uint32_t o0 = span + (uint32_t)lane;
+#pragma unroll
+    for (int i = 0; i < (W + 20 + 63) / 64; ++i)
+        if (lane < W + 20 - 64 * i && o0 < (uint32_t)(STG_BYTES - 64 * i)) lds_st_u8((slot_b + o0) + (uint32_t)(64 * i), in_off);
+}
+
 // ---- rare exact passes over the GLOBAL arenas (entered only by a chunk that holds such a read; out of line) -----------
 struct ExactQ { int sv, svp, mq; };   // sum(raw - offset) over the read / over the kept window, max(raw - offset)
 // patch = lead | trail << 16: terminal-N positions (< lead or >= trail) read as the offset (mask_quality_terminal_N)
@@ -875,7 +886,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t shq = (uint32_t)((size_t)(qual + cs) & 15u);
             const uint32_t pad_len = uniu(ld.pad_len), pad_stride = pad_len + 16u;
             const uint32_t rowq = pad_len ? ridx * pad_stride + shq : v_off - cs + shq; // this lane's read inside the slot
-            const uint32_t span_q = pad_len ? (uint32_t)RPC * pad_stride + shq : ce - cs + shq; // bytes of the slot that hold the chunk
+            // bytes of the slot up to the end of the chunk's last read (padded rows: the 16 bytes behind the last row's read are whatever follows
+            // the chunk in the arena -- they belong to the pad that is filled below, like the bytes behind a contiguous span)
+            const uint32_t span_q = pad_len ? (uint32_t)(RPC - 1) * pad_stride + pad_len + shq : ce - cs + shq;
             // first / last base (mask_quality_terminal_N needs them before the qualities are looked at).  Requested HERE, not with the
             // early loads: a sector of the base arena touched a whole chunk ahead of the base DMA has left the L2 by then and comes
             // over the fabric twice (+100 B/read of fetches, measured)
@@ -896,13 +909,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 }
             }
             // pad behind the span: the position-parallel passes read up to W + 5 bytes past a short last read, and what they
-            // find there must be a valid quality byte (see quality_cells)
-            {
-                const uint32_t o0 = span_q + (uint32_t)lane;
-#pragma unroll
-                for (int i = 0; i < (W + 20 + 63) / 64; ++i)
-                    if (lane < W + 20 - 64 * i && o0 < (uint32_t)(T::STG_BYTES - 64 * i)) lds_st_u8((slot_b + o0) + (uint32_t)(64 * i), (uint32_t)in_off);
-            }
+            // find there must be a valid quality byte (see quality_cells): the ADDRESS of a Q-B add comes from the byte even when its
+            // increment is zero, and an add of zero is still a read-modify-write.  With a base letter there ('a' ... 't' are rows 64 ... 83 of
+            // a 42-row table) it lands in ANOTHER wave's slot, and when that wave's LDS-DMA writes the same dword between the add's read and
+            // its write, the add puts the old bytes back -- one stale dword, once in a thousand chunks (found by re-seeded runs in round 4:
+            // profiles/r4c/restage_race.txt).  So the pad is written again whenever qualities are staged again (the take-back pass below).
+            pad_behind_span<W, T::STG_BYTES>(slot_b, span_q, shq, lane, (uint32_t)in_off);
             FAQCS_STAMP(0)
 
             // ================= Q-A: one read per lane ===============================================================
@@ -1385,11 +1397,30 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 stage(qual, cs, ce, shq, pad_len);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef FAQCS_LDS_DIAG_VERIFY_RESTAGE // (diagnostic: is every byte of the re-staged span in the slot once the wait above has passed?)
+                if (!pad_len) {
+                    const uint32_t nb_ = ce - cs + shq;
+                    uint32_t bad_ = 0, first_ = 0xffffffffu;
+                    for (uint32_t u_ = (uint32_t)lane; u_ * 16u < nb_; u_ += 64u) {
+                        const uint4 g_ = *reinterpret_cast<const uint4 *>(qual + cs - shq + (size_t)u_ * 16u);
+                        const uint32_t l0_ = lds_ld(slot_b + u_ * 16u), l1_ = lds_ld(slot_b + u_ * 16u + 4u), l2_ = lds_ld(slot_b + u_ * 16u + 8u), l3_ = lds_ld(slot_b + u_ * 16u + 12u);
+                        if (g_.x != l0_ || g_.y != l1_ || g_.z != l2_ || g_.w != l3_) { ++bad_; first_ = first_ == 0xffffffffu ? u_ : first_; }
+                    }
+                    if (bad_) {
+                        atomicAdd(reinterpret_cast<unsigned long long *>(err + 16), (unsigned long long)bad_);
+                        atomicMax(reinterpret_cast<unsigned long long *>(err + 16) + 1, ((unsigned long long)nb_ << 32) | first_);
+                    }
+                    atomicAdd(reinterpret_cast<unsigned long long *>(err + 16) + 2, 1ull);
+                }
+#endif
+                // (the bases of the S pass lie behind the span now; the span's end is worked out again here rather than kept across the S pass)
+                pad_behind_span<W, T::STG_BYTES>(slot_b, pad_len ? (uint32_t)(RPC - 1) * pad_stride + pad_len + shq : ce - cs + shq, shq, lane, (uint32_t)in_off);
                 // the in-place edits of Q-A again: terminal-N runs and clamped bytes
-                if (__any(veto && (tn || badq))) {
+                // (a read with an out-of-range byte is clamped again whether it is taken back or not: its neighbours' lanes read into it)
+                if (__any((veto && tn) || badq)) {
 #pragma unroll 1
-                    for (int p = 0; __any(veto && (tn || badq) && p < len); ++p) {
-                        if (veto && (tn || badq) && p < len) {
+                    for (int p = 0; __any(((veto && tn) || badq) && p < len); ++p) {
+                        if (((veto && tn) || badq) && p < len) {
                             const uint32_t r = lds_ld_u8(slot_b + rowq + (uint32_t)p);
                             int v = (int)(int8_t)r - in_off;
                             v = v < 0 ? 0 : (v > 41 ? 41 : v);

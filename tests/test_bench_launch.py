@@ -58,3 +58,47 @@ def test_a_rank_that_dies_before_the_rendezvous_fails_the_job_fast():
     assert r.returncode == 7, (r.returncode, r.stderr.decode()[-1500:])
     assert dt < 30, dt
     assert os.path.exists(os.path.join(ROOT, "gpurun_out", "rank1.err"))
+
+
+def test_full_size_checks_accept_a_consistent_block_and_reject_a_broken_one():
+    """bench.verify_full_size(): the size-independent properties bench.py checks on the counter block of its full-size jobs (sums of the
+    matrices against FilterStat, rows against the length histogram, one composition count per read and kind, reads credited per adapter
+    against adapter_stats).  Here on the CPU checker's block and results for ragged reads with adapters: it must pass, and a block with
+    ONE counter off by one must not."""
+    import numpy as np
+    import pytest
+    import torch
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import bench
+    import make_fixtures
+    from oracle_engine import OracleEngine
+
+    from faqcs_amd import _capi as capi
+    from faqcs_amd import driver
+    from faqcs_amd.options import parse_args
+
+    opt = parse_args(["-u", "x", "-d", "y", "--adapter", "--polyA", "--min_L", "30"])
+    rng = np.random.Generator(np.random.PCG64(99))
+    reads = []
+    for _ in range(1500):
+        s, q = make_fixtures._adv_read(rng, 150)
+        reads.append((b"@r", s.tobytes(), q.tobytes()))
+    eng = OracleEngine(opt, 160, 33)
+    seq, qual, offset, seg = driver.pack_segments([reads[:700], reads[700:]])
+    res = eng.process(seq, qual, offset, seg)
+    blk = eng.counters()
+    n_ad = eng.holder.n_adapters if hasattr(eng, "holder") else len(opt.adapter)
+    lay = capi.python_layout(160, n_ad)
+    fs = blk[lay["filter_stats"][0]:lay["filter_stats"][0] + 32]
+    r = torch.from_numpy(res.view(np.uint16).reshape(-1, 4).astype(np.int32).astype(np.int16))
+    L = 0  # (ragged: the function takes the lengths from the block itself)
+    bench.verify_full_size(blk, lay, fs, [r[:800], r[800:]], len(reads), L, "adapter", n_ad)
+    for name in ("post_qual", "pre_comp", "adapter_stats", "post_len_hist"):
+        bad = blk.copy()
+        k = lay[name][0] + int(np.nonzero(blk[lay[name][0]:lay[name][0] + lay[name][1]])[0][0])
+        bad[k] += 1
+        with pytest.raises(SystemExit):
+            bench.verify_full_size(bad, lay, fs, [r], len(reads), L, "adapter", n_ad)

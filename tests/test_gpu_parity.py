@@ -64,9 +64,16 @@ def compare_engines(opt, reads, R=256, in_off=33, seg_size=None):
     c1, c2 = hip.counters(), ora.counters()
     if not (c1 == c2).all():
         lay = capi.python_layout(R, hip.holder.n_adapters)
-        k = int(np.nonzero(c1 != c2)[0][0])
-        name = [nm for nm, v in lay.items() if nm != "total" and v[0] <= k < v[0] + v[1]][0]
-        raise AssertionError("counter block differs in %s[%d]: hip=%d oracle=%d" % (name, k - lay[name][0], c1[k], c2[k]))
+        ks = np.nonzero(c1 != c2)[0]
+        what = []
+        for k in ks[:8]:
+            k = int(k)
+            name = [nm for nm, v in lay.items() if nm != "total" and v[0] <= k < v[0] + v[1]][0]
+            what.append("%s[%d]: hip=%d oracle=%d" % (name, k - lay[name][0], c1[k], c2[k]))
+        import ctypes as C
+        dbg = (C.c_uint64 * 4)()
+        hip.lib.faqcs_debug_words(hip.ctx, dbg, 4)
+        raise AssertionError("counter block differs in %d places: %s ; debug words %s" % (len(ks), "; ".join(what), [hex(int(x)) for x in dbg]))
     assert _native_loaded()
     return hip, ora
 
