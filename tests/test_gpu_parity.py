@@ -1292,6 +1292,24 @@ def test_chunks_of_equal_length_reads_in_padded_rows(L, args):
     compare_engines(opt, reads, R=256 if L <= 256 else 1024, seg_size=700)
 
 
+@pytest.mark.parametrize("L", [75, 150, 250])
+def test_take_back_pass_under_load(L):
+    """Most reads of this batch are rejected AFTER their post-trim cells were counted (-n 1 on reads with 2 % N), so nearly every chunk
+    stages its qualities a second time and takes cells back -- with hundreds of chunks in flight on every CU, lower-case bases in the
+    reads and a length that leaves the lanes of a chunk's last read reading behind the span.  The zero-increment adds of that pass once
+    went wherever the byte behind the span pointed (profiles/r4c/restage_race.txt: a race that needed another wave's LDS-DMA to hit the same
+    dword at the same moment -- this batch did NOT reproduce it on the build that had it, the re-seeded runs of profiles/fuzz.sh did);
+    the whole counter block must match the oracle."""
+    rng = np.random.Generator(np.random.PCG64([93, L, SEED]))
+    opt = parse_args(["-u", "x", "-d", "y", "--min_L", "1", "--avg_q", "20", "-n", "1"])
+    n = 48000
+    s = np.frombuffer(b"ACGTNacgt", np.uint8)[rng.choice(9, (n, L), p=[.2, .2, .2, .2, .02, .045, .045, .045, .045])]
+    q = (rng.integers(28, 41, (n, L)) + 33).astype(np.uint8)
+    q[::7, L - 5:] = 34
+    reads = [(b"@x", s[i].tobytes(), q[i].tobytes()) for i in range(n)]
+    compare_engines(opt, reads, seg_size=4000)
+
+
 @pytest.mark.parametrize("L,args,kernel", [
     (150, [], "trim_lds"), (151, ["--adapter"], "trim_lds"), (100, ["--mode", "HARD", "-q", "10"], "trim_lds"), (125, ["--qc_only"], "trim_lds"),
     (128, [], "trim_lds"), (96, [], "trim_lds"), (75, [], "trim_lds"), (160, [], "trim_lds"), (157, ["--5trim_off"], "trim_lds"), (64, [], "trim_lds"), (50, ["--adapter"], "trim_lds"), (36, ["--mode", "BWA"], "trim_lds"),
