@@ -12,6 +12,8 @@ b > $out/bench_default_all_configs.json
 # 2. other shapes through the same harness
 for L in 100 125 192 200 250 251 300; do b --read-len $L --pairs 40e6 --no-cpu-baseline --e2e-pairs 0 --no-other-configs > $out/bench_plain_${L}bp_40Mpairs.json; done
 for L in 96 128; do b --read-len $L --pairs 60e6 --no-cpu-baseline --e2e-pairs 0 --no-other-configs > $out/bench_plain_${L}bp_60Mpairs.json; done
+for L in 50 64 75; do b --read-len $L --pairs 100e6 --no-cpu-baseline --e2e-pairs 0 --no-other-configs > $out/bench_plain_${L}bp_100Mpairs.json; done
+for L in 50 75; do FAQCS_TRIM_LDS4=0 b --read-len $L --pairs 100e6 --no-cpu-baseline --e2e-pairs 0 --no-other-configs > $out/bench_plain_${L}bp_100Mpairs_trim_tpr.json; done   # rounds 1-3's kernel for these lengths
 FAQCS_TRIM_LDS16=0 b --read-len 250 --pairs 40e6 --no-cpu-baseline --e2e-pairs 0 --no-other-configs > $out/bench_plain_250bp_40Mpairs_trim_filter_accumulate.json   # round 3's kernel for this length, same build, same box
 FAQCS_KMER_DIRECT=1 b --config kmer --steps 2 --no-cpu-baseline > $out/bench_kmer_direct_one_atomic_per_occurrence.json   # rounds 1-3's path, same build, same box
 b --config kmer --steps 3 --no-cpu-baseline > $out/bench_kmer_250bp_25Mpairs.json
@@ -26,6 +28,7 @@ bash profiles/pmc_kmer_group.sh $tag/kmer_pmc 8e6 30 > $out/pmc_kmer_group.txt 2
 bash profiles/pmc_trim_long.sh $tag/trim_long > $out/pmc_trim_long.txt 2>&1
 bash profiles/pmc_adapter.sh $tag/adapter_pmc > $out/pmc_adapter.txt 2>&1
 [ -x profiles/microbench/trim_ab ] && bash profiles/pmc_trim.sh $tag/trim16_pmc faqcs_amd/libfaqcs_mi.so 8388608 250 > $out/pmc_trim_lds16.txt 2>&1
+[ -x profiles/microbench/trim_ab ] && bash profiles/pmc_trim.sh $tag/trim4_pmc faqcs_amd/libfaqcs_mi.so 33554432 75 > $out/pmc_trim_lds4.txt 2>&1
 [ -x profiles/microbench/trim_ab ] && bash profiles/pmc_trim.sh $tag/trim_pmc faqcs_amd/libfaqcs_mi.so 16777216 150 > $out/pmc_trim_lds.txt 2>&1
 bash tools/e2e_probe.sh > $out/e2e_probe.txt 2>&1
 ls -la $out
