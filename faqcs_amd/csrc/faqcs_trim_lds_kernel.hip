@@ -693,9 +693,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const int k = j >> 2;
-#ifdef FAQCS_LDS16_S_HALVES
-            if (LPR == 16 && j == FAQCS_LDS16_S_HALVES) __builtin_amdgcn_sched_barrier(0); // (the look-ups of one half in flight at a time: registers)
-#endif
             if ((j & 3) == 0) {
                 if (MODE == 0) seen7 |= w[k];
                 w[k] ^= ~((EXT && chk) ? 0u : inw[k]) & 0x88888888u; // (w[k] is the table index from here on; the byte is put back for the N tests)
