@@ -27,6 +27,8 @@
 extern "C" {
 #endif
 
+/* 2: faqcs_batch.terminal_n, faqcs_terminal_n_flags, the k-mer timers of faqcs_kernel_times.  Entry points added since then leave
+ * every existing structure and call as it was, so the number stands: faqcs_kmer_forward, faqcs_comm_* (round 4). */
 #define FAQCS_ABI_VERSION 2
 
 /* FilterStat enum order, FaQCs.h:46-75 */
