@@ -602,6 +602,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     // position x quality cells: DATA = +1 pre / +1 post per base (undo: -1 post, for a read S-A vetoed afterwards).
     // A byte past the read belongs to the next read of the span or to the pad behind it (valid quality bytes both: its
     // zero increment stays inside the table).
+#ifdef FAQCS_LDS_DIAG_CHECK_QB_ADDR
+    unsigned long long *dbg_qb_bad = reinterpret_cast<unsigned long long *>(err + 16) + 3; // debug words 3 (adds outside the matrix) and 4 (steps checked)
+#endif
     uint32_t qb_sum = 0; // (Q-B, `sum` steps) this lane's read: the sum of its raw quality bytes
     auto quality_cells = [&](const RawB &x, const uint32_t i0, const uint32_t i1, auto undo_t, const int t, const bool sum) {
         constexpr bool undo = decltype(undo_t)::value;
@@ -638,6 +641,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
             const uint32_t ad = ((j & 3) == 0 ? byte_mul<0>(wq[j >> 2], wx4) : (j & 3) == 1 ? byte_mul<1>(wq[j >> 2], wx4)
                                  : (j & 3) == 2 ? byte_mul<2>(wq[j >> 2], wx4) : byte_mul<3>(wq[j >> 2], wx4)) +
                                 ((ROT && j >= CQ - (T::NROT - 1) && rot >= (uint32_t)(CQ - j)) ? hq_lane - (uint32_t)(CQ * 4) : hq_lane);
+#ifdef FAQCS_LDS_DIAG_CHECK_QB_ADDR // (diagnostic build: the slot's validity rule -- every Q-B add, zero increments included, inside the quality matrix)
+            {
+                const uint32_t a_ = ad + 4u * (uint32_t)j;
+                if (a_ < (uint32_t)(Cfg::O_HQ * 4) || a_ >= (uint32_t)((Cfg::O_HQ + Cfg::HQ) * 4)) atomicAdd(dbg_qb_bad, 1ull);
+                else if (lane == 0 && j == 0) atomicAdd(dbg_qb_bad + 1, 1ull);
+            }
+#endif
 #ifdef FAQCS_LDS_QB_NOCONFLICT // (diagnostic build, wrong results: every lane on a bank of its own -- what the conflicts of these adds cost)
             lds_add_u32((ad & 0x3u) + (uint32_t)(Cfg::O_HQ * 4) + (uint32_t)lane * 4u + 256u * (uint32_t)j, data);
 #elif !defined(FAQCS_LDS_NO_QB_ATOMICS)
