@@ -19,6 +19,7 @@
 
 #include "faqcs_dev.h"
 #include "faqcs_kmer.h"
+#include "faqcs_skm.h"
 
 // kernels (other translation units)
 struct AdapterDev {
@@ -135,6 +136,8 @@ struct faqcs_ctx {
         bool ready = false;
         bool direct = false;          // FAQCS_KMER_DIRECT=1 (diagnostics): one atomic insert per occurrence (kmer_count), as in rounds 1-3
         bool owner = false;           // owner-partitioned context whose received pairs go through the group buffers too (n_epochs <= KG_EPOCH_SPAN)
+        bool skm = false;             // 16-byte super-k-mer items (faqcs_kmer_skm_kernel.hip): every context that is not owner-partitioned
+        uint32_t skm_w = 1;           // k-mers an item can hold (k - min(k, 15) + 1)
         uint64_t cap_items = 0;       // item bound of a group
         uint64_t bound_items = 0;     // upper bound of the items the open group holds
         std::vector<uint32_t> run_epoch, upload[2]; // epochs (relative to epoch_base) of the open group's runs; host copies in flight
@@ -403,7 +406,9 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
         c->kt.mask = pow2 - 1;
         { uint32_t lg = 0; while ((1ull << lg) < pow2) ++lg; if (lg > 46) return fail(FAQCS_E_INVAL, "faqcs_create: kmer_table_slots too large"); c->kt.shift = 62 - lg; }
         if (const char *e = getenv("FAQCS_KMER_DIRECT")) c->kg.direct = atoi(e) != 0;
-        HIPCHK(hipMalloc((void **)&c->kt.slots, pow2 * sizeof(KmerSlot)));
+        // the overflow area (1/16 of the table, at least 2^16 slots): keys whose probe window in their partition's slice is full
+        c->kt.ovf_mask = std::max<uint64_t>(pow2 >> 4, 1ull << 16) - 1;
+        HIPCHK(hipMalloc((void **)&c->kt.slots, kmer_table_total(c->kt) * sizeof(KmerSlot)));
         HIPCHK(hipMalloc((void **)&c->kt.stats, 64));
         HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute)); // empty key, count - 1 = 0, no epoch
         HIPCHK(hipMemset(c->kt.stats, 0, 64));
@@ -474,13 +479,20 @@ static int kg_init(faqcs_ctx *c)
     // A sub-region of the expected G / 65 536 items gets 1/4 + 8 standard deviations (+ a granule) on top.
     d.split = G >= (1ull << 26) ? 8u : 1u;
     d.lds_slots = G > (1ull << 30) ? 8192u : 4096u;
-    const double mean1 = (double)G / (KG_FAN * KG_FAN), mean2 = mean1 / d.split;
-    d.cap1 = (uint32_t)(mean1 * 1.25 + 8.0 * std::sqrt(mean1) + 64.0);
-    d.cap2 = (uint32_t)(mean2 * 1.25 + 8.0 * std::sqrt(mean2) + 64.0);
+    // super-k-mers (every context that is not owner-partitioned): an item is 16 bytes and holds a run of up to w k-mers,
+    // (w + 1) / 2 on average; the buffers are sized for three items per w + 1 occurrences.  Partitions are minimizer bins, which
+    // vary more than hash bins do: twice the mean at level 2.  What overflows is counted occurrence by occurrence (exact, slow).
+    g.skm = !c->partitioned;
+    g.skm_w = c->prm.kmer > 15 ? c->prm.kmer - 14 : 1;
+    const size_t item_bytes = g.skm ? 16 : 8;
+    const double G_items = !g.skm || g.skm_w == 1 ? (double)G : (double)G * 3.0 / (g.skm_w + 1);
+    const double mean1 = G_items / (KG_FAN * KG_FAN), mean2 = mean1 / d.split;
+    d.cap1 = (uint32_t)(mean1 * (g.skm ? 1.5 : 1.25) + 8.0 * std::sqrt(mean1) + 64.0);
+    d.cap2 = (uint32_t)(mean2 * (g.skm ? 2.0 : 1.25) + 8.0 * std::sqrt(mean2) + 64.0);
     if (d.cap1 < (uint32_t)KG_MIN_CAP) d.cap1 = KG_MIN_CAP;
     if (d.cap2 < (uint32_t)KG_MIN_CAP) d.cap2 = KG_MIN_CAP;
-    HIPCHK(hipMalloc((void **)&d.l1, (size_t)KG_FAN * KG_FAN * d.cap1 * 8));
-    HIPCHK(hipMalloc((void **)&d.l2, (size_t)KG_FAN * KG_FAN * d.split * d.cap2 * 8));
+    HIPCHK(hipMalloc((void **)&d.l1, (size_t)KG_FAN * KG_FAN * d.cap1 * item_bytes));
+    HIPCHK(hipMalloc((void **)&d.l2, (size_t)KG_FAN * KG_FAN * d.split * d.cap2 * item_bytes));
     HIPCHK(hipMalloc((void **)&d.cur1, (size_t)KG_FAN * KG_FAN * 4));
     HIPCHK(hipMalloc((void **)&d.cur2, (size_t)KG_FAN * KG_FAN * d.split * 4));
     HIPCHK(hipMalloc((void **)&d.run_epoch, (size_t)KG_MAX_RUNS * 4));
@@ -510,6 +522,76 @@ static int kg_ensure_epochs(faqcs_ctx *c, uint32_t need)
     return 0;
 }
 
+// FAQCS_KMER_DEBUG=1 (diagnostics): a flush step by step with the buffers checked on the host in between -- every level-1 item sits
+// in the bucket of its partition's top 8 bits, every level-2 item in its partition, no item holds more than w k-mers; prints the
+// item / occurrence / distinct-key counts and the fullest partition (the host expands the items with the kernels' own faqcs_skm.h)
+static int kg_debug_flush(faqcs_ctx *c)
+{
+    faqcs_ctx::KmerGroup &g = c->kg;
+    const KmerGroupDev &d = g.dev;
+    const SkmGeom geo = skm_geom(c->prm.kmer);
+    HIPCHK(hipStreamSynchronize(c->compute));
+    std::vector<uint32_t> cur1((size_t)KG_FAN * KG_FAN), cur2((size_t)KG_FAN * KG_FAN * d.split);
+    HIPCHK(hipMemcpy(cur1.data(), d.cur1, cur1.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long st[3];
+    HIPCHK(hipMemcpy(st, c->kt.stats, 24, hipMemcpyDeviceToHost));
+    uint64_t n1 = 0, occ1 = 0, bad1 = 0, long1 = 0;
+    std::vector<ulonglong2> buf(d.cap1);
+    for (uint32_t b = 0; b < (uint32_t)KG_FAN; ++b)
+        for (uint32_t s = 0; s < (uint32_t)KG_FAN; ++s) {
+            const uint32_t n = cur1[(size_t)s * KG_FAN + b];
+            if (!n) continue;
+            if (n > d.cap1) { fprintf(stderr, "[kmer debug] level-1 cursor %u > cap %u (bucket %u, sub %u)\n", n, d.cap1, b, s); continue; }
+            HIPCHK(hipMemcpy(buf.data(), reinterpret_cast<const ulonglong2 *>(d.l1) + ((size_t)b * KG_FAN + s) * d.cap1, (size_t)n * 16, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n; ++i) {
+                ++n1; occ1 += skm_item_kmers(buf[i].y);
+                if ((skm_item_part(buf[i].y) >> 8) != b) ++bad1;
+                if (skm_item_kmers(buf[i].y) > geo.w || skm_item_run(buf[i].y) >= g.run_epoch.size()) ++long1;
+            }
+        }
+    { uint32_t nb_used = 0, first_b = 0xffffffffu, last_b = 0, ns_used = 0;
+      for (uint32_t b = 0; b < (uint32_t)KG_FAN; ++b) { uint64_t t = 0; for (uint32_t s2 = 0; s2 < (uint32_t)KG_FAN; ++s2) t += cur1[(size_t)s2 * KG_FAN + b]; if (t) { ++nb_used; first_b = std::min(first_b, b); last_b = b; } }
+      for (uint32_t s2 = 0; s2 < (uint32_t)KG_FAN; ++s2) { uint64_t t = 0; for (uint32_t b = 0; b < (uint32_t)KG_FAN; ++b) t += cur1[(size_t)s2 * KG_FAN + b]; if (t) ++ns_used; }
+      fprintf(stderr, "[kmer debug] cap1 %u cap2 %u split %u runs %zu; buckets in use %u (%u .. %u), sub-regions in use %u\n", d.cap1, d.cap2, d.split, g.run_epoch.size(), nb_used, first_b, last_b, ns_used); }
+    fprintf(stderr, "[kmer debug] before the flush: %llu level-1 items, %llu occurrences, %llu in a wrong bucket, %llu with a bad length / run; overflow flag %llu, total %llu\n",
+            (unsigned long long)n1, (unsigned long long)occ1, (unsigned long long)bad1, (unsigned long long)long1, st[2], st[1]);
+    HIPCHK(faqcs_launch_skm_flush(d, c->kt, c->prm.kmer, c->compute, 1u));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemcpy(cur2.data(), d.cur2, cur2.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st, c->kt.stats, 24, hipMemcpyDeviceToHost));
+    uint64_t n2 = 0, occ2 = 0, bad2 = 0, max_keys = 0, max_items = 0, distinct = 0;
+    buf.resize((size_t)d.split * d.cap2);
+    std::vector<unsigned long long> keys;
+    for (uint32_t p = 0; p < (uint32_t)KG_FAN * KG_FAN; ++p) {
+        uint32_t np = 0;
+        for (uint32_t j = 0; j < d.split; ++j) np += cur2[(size_t)p * d.split + j];
+        if (!np) continue;
+        HIPCHK(hipMemcpy(buf.data(), reinterpret_cast<const ulonglong2 *>(d.l2) + (size_t)p * d.split * d.cap2, buf.size() * 16, hipMemcpyDeviceToHost));
+        keys.clear();
+        for (uint32_t j = 0; j < d.split; ++j)
+            for (uint32_t i = 0; i < cur2[(size_t)p * d.split + j] && i < d.cap2; ++i) {
+                const ulonglong2 it = buf[(size_t)j * d.cap2 + i];
+                ++n2; occ2 += skm_item_kmers(it.y);
+                if (skm_item_part(it.y) != p) ++bad2;
+                SkmRoll r = skm_roll_begin(it.x, it.y, geo);
+                for (uint32_t t = 0; t < skm_item_kmers(it.y) && t < 32; ++t) { keys.push_back(skm_mix62(skm_roll_key(r))); skm_roll_next(r, geo); }
+            }
+        std::sort(keys.begin(), keys.end());
+        const uint64_t nd = (uint64_t)(std::unique(keys.begin(), keys.end()) - keys.begin());
+        distinct += nd;
+        max_keys = std::max<uint64_t>(max_keys, nd); max_items = std::max<uint64_t>(max_items, np);
+    }
+    fprintf(stderr, "[kmer debug] after the split: %llu level-2 items, %llu occurrences, %llu in a wrong partition; %llu distinct keys in this group, fullest partition %llu keys / %llu items (slice: %llu slots); overflow flag %llu\n",
+            (unsigned long long)n2, (unsigned long long)occ2, (unsigned long long)bad2, (unsigned long long)distinct, (unsigned long long)max_keys, (unsigned long long)max_items,
+            (unsigned long long)((c->kt.mask + 1) >> 16), st[2]);
+    HIPCHK(faqcs_launch_skm_flush(d, c->kt, c->prm.kmer, c->compute, 2u));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemcpy(st, c->kt.stats, 24, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[kmer debug] after the combine: overflow flag %llu\n", st[2]);
+    HIPCHK(faqcs_launch_skm_flush(d, c->kt, c->prm.kmer, c->compute, 4u));
+    return 0;
+}
+
 // the open group's items reach the table: level-2 scatter, combine + insert, cursors back to zero (all on the compute stream)
 // (timed: a flush outside a submission's k0 .. k1 events -- the one faqcs_sync() makes -- brings its own pair)
 static int kg_flush(faqcs_ctx *c, bool timed = false)
@@ -529,7 +611,10 @@ static int kg_flush(faqcs_ctx *c, bool timed = false)
     }
     HIPCHK(hipMemcpyAsync(g.dev.run_epoch, up.data(), up.size() * 4, hipMemcpyHostToDevice, c->compute));
     g.dev.n_runs = (uint32_t)up.size(); g.dev.epoch_base = g.epoch_base;
-    HIPCHK(faqcs_launch_kmer_group_flush(g.dev, c->kt, c->compute));
+    static const bool debug = [] { const char *e = getenv("FAQCS_KMER_DEBUG"); return e && atoi(e) != 0; }();
+    if (g.skm && debug) { if (int rc = kg_debug_flush(c)) return rc; }
+    else if (g.skm) HIPCHK(faqcs_launch_skm_flush(g.dev, c->kt, c->prm.kmer, c->compute));
+    else HIPCHK(faqcs_launch_kmer_group_flush(g.dev, c->kt, c->compute));
     if (timed) HIPCHK(hipEventRecord(ev.second, c->compute));
     g.run_epoch.clear(); g.bound_items = 0;
     std::fill(g.sub_fill.begin(), g.sub_fill.end(), 0);
@@ -554,9 +639,13 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
         // numbers of reads).  sub_fill bounds every sub-region from above, 1/8 + 64 items of variance included; the group is
         // flushed before a sub-region could overflow (an overflow would be exact too, but slow: kmer_insert_atomic).
         const uint32_t run = (uint32_t)g.run_epoch.size(), rot = (run * 37u) % KG_FAN;
+        // items a launch can be expected to write at most (super-k-mers: three per w + 1 occurrences and two per read)
+        auto items_of = [&](uint32_t take, uint64_t bound) { return !g.skm || g.skm_w == 1 ? bound : bound * 3 / (g.skm_w + 1) + 2ull * take; };
+        auto grid_of = [&](uint32_t take) { return g.skm ? faqcs_skm_grid(take, c->n_cu) : faqcs_kmer_group_grid(take, c->n_cu); };
         auto fits = [&](uint32_t take, uint64_t bound) {
-            const uint32_t grid = faqcs_kmer_group_grid(take, c->n_cu);
-            const uint64_t share = bound / ((uint64_t)grid * KG_FAN) + bound / ((uint64_t)grid * KG_FAN * 8) + 64;
+            const uint32_t grid = grid_of(take);
+            const uint64_t ib = items_of(take, bound);
+            const uint64_t share = ib / ((uint64_t)grid * KG_FAN) + ib / ((uint64_t)grid * KG_FAN * 8) + 64;
             for (uint32_t i = 0; i < grid; ++i) if (g.sub_fill[(i + rot) % KG_FAN] + share > g.dev.cap1) return false;
             return g.bound_items + bound <= g.cap_items;
         };
@@ -571,14 +660,16 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
             if (!g.run_epoch.empty()) { if (int rc = kg_flush(c)) return rc; continue; }
             take = 1; // (a read that no empty group has room for: whatever overflows is counted by the per-occurrence path)
         }
-        const uint64_t bound = bound_of(take);
-        const uint32_t grid = faqcs_kmer_group_grid(take, c->n_cu);
+        const uint64_t bound = bound_of(take), ib = items_of(take, bound);
+        const uint32_t grid = grid_of(take);
         if (g.run_epoch.empty()) g.epoch_base = epoch;
-        HIPCHK(faqcs_launch_kmer_group_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
-                                               r0, r0 + take, d_res, max_len, c->n_cu, c->compute));
+        if (g.skm) HIPCHK(faqcs_launch_skm_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
+                                                   r0, r0 + take, d_res, c->n_cu, c->compute));
+        else HIPCHK(faqcs_launch_kmer_group_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
+                                                    r0, r0 + take, d_res, max_len, c->n_cu, c->compute));
         g.run_epoch.push_back(epoch - g.epoch_base);
         g.bound_items += bound;
-        for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += bound / ((uint64_t)grid * KG_FAN) + bound / ((uint64_t)grid * KG_FAN * 8) + 64;
+        for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += ib / ((uint64_t)grid * KG_FAN) + ib / ((uint64_t)grid * KG_FAN * 8) + 64;
         r0 += take;
     }
     return 0;

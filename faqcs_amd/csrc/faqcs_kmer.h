@@ -19,7 +19,13 @@ struct KmerTable {
     unsigned long long *stats; // [0] distinct keys, [1] total occurrences, [2] overflow flag
     uint32_t partitioned;      // (kmer_count / kmer_insert_items) maintain first_epoch
     uint32_t shift;            // 62 - log2(slots): combine-before-insert keys are 62-bit mixes, slot = key >> shift
+    uint64_t ovf_mask;         // overflow area behind the table: slots[mask + 1 .. mask + 1 + ovf_mask] (0: none).  A key whose probe window
+                               // inside its partition's slice is full lives there (faqcs_kmer_skm_kernel.hip): shared by all partitions, atomics only
 };
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint64_t kmer_table_total(const KmerTable &T) { return T.mask + 1 + (T.ovf_mask ? T.ovf_mask + 1 : 0); }
 
 // multi-GPU exchange buffers of one submission (owner-partitioned mode)
 struct KmerOutbox {
@@ -101,6 +107,19 @@ uint32_t faqcs_kmer_group_items_grid(unsigned long long n_items, int n_cu);
 hipError_t faqcs_launch_kmer_group_items(const KmerGroupDev &G, const KmerTable &T, uint32_t rot, const void *items, unsigned long long n_items,
                                          int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_group_reset(const KmerGroupDev &G, hipStream_t st);
+// super-k-mers (round 5; faqcs_kmer_skm_kernel.hip, faqcs_skm.h): the same group buffers with 16-byte items, a run of up to 17
+// consecutive k-mers each; l1 / l2 / cap1 / cap2 of KmerGroupDev count 16-byte items in this mode
+uint32_t faqcs_skm_grid(uint32_t n_reads, int n_cu);
+hipError_t faqcs_launch_skm_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
+                                    uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
+                                    uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st);
+hipError_t faqcs_launch_skm_flush(const KmerGroupDev &G, const KmerTable &T, uint32_t k, hipStream_t st, uint32_t stages = 7u);
+hipError_t faqcs_launch_skm_reset(const KmerGroupDev &G, hipStream_t st);
+uint32_t faqcs_skm_items_grid(unsigned long long n_items, int n_cu);
+hipError_t faqcs_launch_skm_items(const KmerGroupDev &G, const KmerTable &T, uint32_t k, uint32_t rot, const void *items, unsigned long long n_items,
+                                  int n_cu, hipStream_t st);
+hipError_t faqcs_launch_skm_outbox(const KmerGroupDev &G, uint32_t world, unsigned long long *dest_count, unsigned long long *region_offset,
+                                   void *out, hipStream_t st);
 
 #ifdef __HIPCC__
 __device__ __forceinline__ uint64_t kmer_mix(uint64_t x)

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void kmer_first_epoch_histogram(const KmerTabl
     __shared__ uint32_t h[LOCAL];
     for (uint32_t i = threadIdx.x; i < LOCAL; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    const uint64_t slots = T.mask + 1;
+    const uint64_t slots = kmer_table_total(T);
     const uint64_t per_block = (slots + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = lo + per_block < slots ? lo + per_block : slots;
     for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void kmer_count_histogram(const KmerTable T, u
     __shared__ uint32_t h[LOCAL];
     for (uint32_t i = threadIdx.x; i < LOCAL; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    const uint64_t slots = T.mask + 1;
+    const uint64_t slots = kmer_table_total(T);
     const uint64_t per_block = (slots + gridDim.x - 1) / gridDim.x; // contiguous slice per block: < 2^32 slots each
     const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = lo + per_block < slots ? lo + per_block : slots;
     for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
@@ -340,6 +340,6 @@ __global__ void kmer_table_init(KmerSlot *slots, const uint64_t n)
 
 hipError_t faqcs_launch_kmer_table_init(const KmerTable &T, int n_cu, hipStream_t st)
 {
-    hipLaunchKernelGGL(kmer_table_init, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T.slots, T.mask + 1);
+    hipLaunchKernelGGL(kmer_table_init, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T.slots, kmer_table_total(T));
     return hipGetLastError();
 }

@@ -1,0 +1,892 @@
+// faqcs_kmer_skm_kernel.hip -- k-mer counting over super-k-mers (gfx950, wave64; round 5).
+//
+// update_kmer() (trim.cpp:887-931) increments a hash-map entry per k-mer occurrence.  Only (distinct, total) at the sampling
+// points (trim.cpp:157-185) and the final histogram of counts (FaQCs.cpp:518-521) are observable, and both are functions of
+// {key -> (count, first epoch)}.  Round 4 moved every occurrence as an 8-byte item through two scatter passes before one
+// workgroup per partition combined them: 61 bytes of HBM traffic per occurrence.  Here the unit that travels is a RUN of up
+// to 17 consecutive k-mers of a read that share their minimizer (faqcs_skm.h): a 16-byte item per ~9 occurrences, partitioned
+// by a hash of the minimizer so that every occurrence of a canonical k-mer still reaches the same workgroup.
+//
+//   skm_extract   one wave per read piece (256 positions, a lane owns four); codes, minimizers, run boundaries through the
+//                 wave's LDS exchange rows; items staged per level-1 bucket in LDS and written as whole 256-byte granules into
+//                 sub-regions that belong to the writing block (no atomics)
+//   skm_split     every bucket 256 ways by the next 8 bits of the partition; the run number becomes the epoch
+//   skm_combine   one workgroup per partition: expands the items in registers (rolling forward / reverse-complement words),
+//                 counts the mixed canonical keys in an LDS hash table (key, count, smallest epoch) and applies ONE plain
+//                 read-modify-write per distinct key to the slice of the table the partition owns.  An LDS table that fills up
+//                 is written out and the workgroup goes on with an empty one: a partition of any size is exact without a
+//                 per-occurrence path.
+//   skm_items     (owner side of the multi-GPU exchange) items received from other ranks join the level-1 buckets
+//   skm_outbox    (sender side) the level-1 sub-regions of the buckets a rank owns, packed back to back
+//
+// What does not fit a sub-region (heavy hitters of a skewed input) is expanded and inserted occurrence by occurrence
+// (kmer_insert_atomic), so exactness never depends on a capacity.
+#include "faqcs_kmer.h"
+#include "faqcs_skm.h"
+#include "faqcs_trim_common.h" // ensure_dynamic_lds
+
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned long long u64;
+typedef ulonglong2 Item;
+#define KS_NONE (~0ull) /* w1 of "no item" in prefetch registers (a real item's run field never reaches 2^13 - 1 together with all other bits set) */
+
+enum { KS_STAGE = 32, KS_GRAN = 16 }; // staging slots per bucket / items per global write (256 bytes)
+
+__device__ __forceinline__ void hist_add(u64 *h, uint32_t e, uint32_t n_epochs, long long v)
+{
+    if (e < n_epochs) atomicAdd(&h[e], (u64)v);
+}
+
+// The table is cut into 65 536 slices, one per partition; a key lives in the slice of ITS partition (slot inside the slice = top
+// bits of the mixed key) and a probe sequence wraps inside the slice.  That is what lets skm_combine update the table without
+// device-scope atomics: the workgroup of a partition is the only one in its slice for the length of the launch.
+struct Slice { u64 base, mask; int shift; };
+__device__ __forceinline__ Slice slice_of(const KmerTable &T, const uint32_t part)
+{
+    const u64 size = (T.mask + 1) >> 16;
+    return Slice{(u64)part * size, size - 1, (int)T.shift + 16};
+}
+
+// One slot, atomically: key h gets `count` more occurrences and epoch as a candidate first epoch.  true: done (the key was there or
+// the slot was free); false: the slot holds another key.  This is also where the general first-epoch rule lives: old = atomic min;
+// a successful lowering moves the key from hist[old] to hist[epoch] -- the lowerings of one key form a chain, so the moves telescope
+// to exactly one count at the key's final first epoch.
+__device__ __forceinline__ bool slot_insert_atomic(KmerSlot *sl, const u64 h, const uint32_t epoch, const uint32_t count, u64 *first_hist,
+                                                   const uint32_t n_epochs)
+{
+    u64 seen = __hip_atomic_load(&sl->key, __ATOMIC_RELAXED, FAQCS_KMER_SCOPE);
+    uint32_t add = count;
+    if (seen == ~0ull) {
+        seen = slot_cas(&sl->key, ~0ull, h);
+        if (seen == ~0ull) { seen = h; add = count - 1u; } // claimed: count_m1 = 0 already says "seen once"
+    }
+    if (seen != h) return false;
+    if (add) slot_add(&sl->count_m1, add);
+    const uint32_t old = slot_min_rtn(&sl->first_epoch, epoch);
+    if (epoch < old) {
+        if (old != 0xffffffffu) hist_add(first_hist, old, n_epochs, -1);
+        hist_add(first_hist, epoch, n_epochs, 1);
+    }
+    return true;
+}
+// A key is looked for in a WINDOW of at most KS_PROBE_MAX slots behind its home slot, inside its partition's slice.  Minimizer
+// partitions are not hash partitions: reads that share a sequence (an adapter, a repeat) with different flanks put thousands of
+// distinct k-mers into one partition, and its slice can fill up while the table is half empty.  A key that finds its window full
+// lives in the overflow area behind the table instead -- slots never become free during a pass, so a window that was full when a
+// key arrived is full whenever the key is looked up again: the rule "window, else overflow area" always finds the same place.
+enum { KS_PROBE_MAX = 128 };
+__device__ void ovf_insert_atomic(const KmerTable &T, const u64 h, const uint32_t epoch, const uint32_t count, u64 *first_hist, const uint32_t n_epochs)
+{
+    if (T.ovf_mask) {
+        KmerSlot *ovf = T.slots + T.mask + 1;
+        u64 g = (h ^ (h >> 23)) & T.ovf_mask;
+#pragma unroll 1
+        for (u64 probe = 0; probe <= T.ovf_mask; ++probe) {
+            if (slot_insert_atomic(&ovf[g], h, epoch, count, first_hist, n_epochs)) return;
+            g = (g + 1) & T.ovf_mask;
+        }
+    }
+    atomicOr(&T.stats[2], 1ull); // table full
+}
+// per-occurrence insert of a mixed key (what does not fit a sub-region of the group buffers)
+__device__ void kmer_insert_atomic(const KmerTable &T, const uint32_t part, const u64 h, const uint32_t epoch, const uint32_t count,
+                                   u64 *first_hist, const uint32_t n_epochs)
+{
+    const Slice sc = slice_of(T, part);
+    u64 g = (h >> sc.shift) & sc.mask;
+    const u64 win = sc.mask + 1 < (u64)KS_PROBE_MAX ? sc.mask + 1 : (u64)KS_PROBE_MAX;
+#pragma unroll 1
+    for (u64 probe = 0; probe < win; ++probe) {
+        if (slot_insert_atomic(&T.slots[sc.base + g], h, epoch, count, first_hist, n_epochs)) return;
+        g = (g + 1) & sc.mask;
+    }
+    ovf_insert_atomic(T, h, epoch, count, first_hist, n_epochs);
+}
+// every k-mer of an item, one by one
+__device__ void skm_insert_item_atomic(const KmerTable &T, const Item it, const uint32_t epoch, const SkmGeom &g, u64 *first_hist, const uint32_t n_epochs)
+{
+    const uint32_t nk = skm_item_kmers(it.y), part = skm_item_part(it.y);
+    SkmRoll r = skm_roll_begin(it.x, it.y, g);
+#pragma unroll 1
+    for (uint32_t j = 0; j < nk; ++j) {
+        kmer_insert_atomic(T, part, skm_mix62(skm_roll_key(r)), epoch, 1u, first_hist, n_epochs);
+        skm_roll_next(r, g);
+    }
+}
+
+// ---- LDS staging shared by the scatter kernels --------------------------------------------------------------------------------
+// 256 buckets x 32 slots of 16 bytes.  put(): a ticket from the bucket's LDS counter; a lane whose ticket is past the last slot
+// keeps its item for the next round.  drain(): wave w owns buckets [16 w, 16 w + 16) and writes every full granule (16 items,
+// 256 bytes) of them, FOUR buckets per step -- lane i of a quarter wave holds item i of its bucket's granule -- then moves what
+// is left to the front.  WHERE a granule goes needs no atomic: a block appends to sub-regions that are its own (one per bucket),
+// so the cursors live in its LDS (round 4).
+template <int NW> struct Staging16 {
+    static constexpr int BPW = KG_FAN / NW;
+    Item *items;    // [KG_FAN][KS_STAGE]
+    uint32_t *cnt;  // [KG_FAN]
+    uint32_t *cur;  // [KG_FAN] items this block's sub-region of every bucket holds
+    uint32_t *flag; // [3] block_or
+    __device__ __forceinline__ bool put(const uint32_t b, const Item item) const
+    {
+        const uint32_t pos = atomicAdd(&cnt[b], 1u);
+        if (pos < (uint32_t)KS_STAGE) { items[b * KS_STAGE + pos] = item; return true; }
+        return false;
+    }
+    template <class Write, class Slow>
+    __device__ __forceinline__ void drain(const int wave, const int lane, const bool final, const uint32_t cap, Write &&write, Slow &&slow) const
+    {
+        const uint32_t n_l = lane < BPW ? cnt[wave * BPW + lane] : 0u;
+        uint64_t m = __ballot(final ? n_l > 0u : n_l >= (uint32_t)KS_GRAN);
+        const int q = lane >> 4, l16 = lane & 15;
+#pragma unroll 1
+        while (m) {
+            int sel[4];
+            uint64_t t = m;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sel[i] = t ? uni(__ffsll((long long)t) - 1) : -1; t = t ? t & (t - 1) : 0ull; }
+            const int bsel = q == 0 ? sel[0] : (q == 1 ? sel[1] : (q == 2 ? sel[2] : sel[3]));
+            const bool act = bsel >= 0;
+            const uint32_t b = (uint32_t)(wave * BPW + (act ? bsel : sel[0]));
+            uint32_t n = cnt[b];
+            n = n < (uint32_t)KS_STAGE ? n : (uint32_t)KS_STAGE;
+            const uint32_t pos = cur[b];
+            const uint32_t take = n < (uint32_t)KS_GRAN ? n : (uint32_t)KS_GRAN;
+            const bool mine = act && (uint32_t)l16 < take;
+            const Item it = items[b * KS_STAGE + (uint32_t)l16];
+            const bool fits = pos + take <= cap;
+            if (mine) { if (fits) write(b, pos + (uint32_t)l16, it); else slow(b, it); }
+            const uint32_t left = n - take;
+            const bool mv = act && (uint32_t)l16 < left;
+            const Item nx = items[b * KS_STAGE + (uint32_t)KS_GRAN + (uint32_t)l16]; // (one wave: the reads of an instruction complete before the writes of the next)
+            if (mv) items[b * KS_STAGE + (uint32_t)l16] = nx;
+            if (act && l16 == 0) { cnt[b] = left; cur[b] = fits ? pos + take : pos; }
+            const bool again = act && l16 == 0 && (left >= (uint32_t)KS_GRAN || (final && left > 0u));
+            const uint64_t keep = __ballot(again); // bits 0, 16, 32, 48: the step's buckets stay
+            m = t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if ((keep >> (16 * i)) & 1ull) m |= 1ull << sel[i];
+        }
+    }
+    // OR of `bits` over the block; one barrier.  Three flag words in rotation: call k writes word k % 3, reads it behind the
+    // barrier, and clears the word of call k - 1, which every wave has read before it arrived here.
+    __device__ __forceinline__ uint32_t block_or(const uint32_t bits, uint32_t &phase, const int tid) const
+    {
+        const uint32_t wb = (__ballot(bits & 1u) ? 1u : 0u) | (__ballot(bits & 2u) ? 2u : 0u);
+        if ((tid & 63) == 0 && wb) atomicOr(&flag[phase], wb);
+        __syncthreads();
+        const uint32_t v = flag[phase];
+        const uint32_t prev = phase == 0 ? 2u : phase - 1u;
+        if (tid == 0) flag[prev] = 0u;
+        phase = phase == 2 ? 0u : phase + 1u;
+        return v;
+    }
+};
+constexpr size_t KS_STAGE_BYTES = (size_t)KG_FAN * KS_STAGE * 16 + (size_t)KG_FAN * 8 + 16;
+
+// a wave's LDS operations execute in order; this only stops the compiler from moving them across the point
+__device__ __forceinline__ void lds_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ Item *l1_region(const KmerGroupDev &G, const uint32_t b, const uint32_t sub)
+{
+    return reinterpret_cast<Item *>(G.l1) + ((size_t)b * KG_FAN + sub) * G.cap1;
+}
+
+// ---- level 1: reads -> runs -> 256 buckets ------------------------------------------------------------------------------------
+// A wave works on one PIECE at a time: 256 consecutive positions of a read's kept window, lane l owning positions 4 l .. 4 l + 3
+// (one dword load).  A lane looks FORWARD: the k-mer at position p is bases p .. p + k - 1, its minimizer the smallest ord among
+// the m-mers at p .. p + w - 1, and a run that starts at p needs bases up to p + w + k - 2 -- at most 14 lanes ahead, read from
+// the wave's exchange row.  A read of up to 256 bases is one piece; a longer one advances by 200 positions per piece (the k-mer
+// starts of the last 56 positions belong to the next piece, which sees all their bases).  An N (or any non-ACGT byte, or a G
+// turned into N by --replace_to_N_q) inside the window cuts the piece into STRETCHES of valid bases, each handled like a window
+// of its own: inside a stretch every base is valid, so "k valid bases" is arithmetic on positions.
+// Per-wave LDS rows (dwords): A [80] codes of the lanes (8 bits each), later the run-break nibbles; B [288] the minima exchange.
+enum { KS_ROW_A = 80, KS_ROW_B = 288, KS_ROWS = KS_ROW_A + KS_ROW_B };
+
+template <int NW, bool K31>
+__global__ __launch_bounds__(NW * 64) void skm_extract(
+    const DevParams P, const uint32_t k_arg, const KmerGroupDev G, const KmerTable T, const uint32_t run, const uint32_t rot, const uint32_t epoch,
+    const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off, const uint32_t r_begin,
+    const uint32_t r_end, const uint2 *__restrict__ results)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    Item *s_items = reinterpret_cast<Item *>(lds);
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(s_items + KG_FAN * KS_STAGE);
+    const Staging16<NW> S{s_items, w32, w32 + KG_FAN, w32 + 2 * KG_FAN};
+    uint32_t *s_total = w32 + 2 * KG_FAN + 3; // occurrences of this block
+    uint32_t *s_rows = w32 + 2 * KG_FAN + 4;
+    const SkmGeom g = skm_geom(K31 ? 31u : k_arg);
+    const int k = (int)g.k, w = (int)g.w;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    uint32_t *rowA = s_rows + wave * KS_ROWS, *rowB = rowA + KS_ROW_A;
+    const uint32_t sub = (blockIdx.x + rot) % KG_FAN; // this block's sub-region of every bucket
+    for (int i = tid; i < KG_FAN; i += NW * 64) { S.cnt[i] = 0u; S.cur[i] = G.cur1[sub * KG_FAN + i]; }
+    if (tid < 4) S.flag[tid] = 0u; // (flags and s_total)
+    for (int i = tid; i < NW * KS_ROWS; i += NW * 64) s_rows[i] = 0xfu; // (the pads behind the 64 lanes read as "break" / unused codes)
+    const uint32_t n_waves = gridDim.x * NW;
+    const bool g2n = !P.qc_only && P.replace_q > 0;
+    auto write = [&](const uint32_t b, const uint32_t pos, const Item it) { l1_region(G, b, sub)[pos] = it; };
+    auto slow = [&](const uint32_t, const Item it) { skm_insert_item_atomic(T, it, epoch, g, G.first_hist, G.n_epochs); };
+    __syncthreads();
+
+    struct Hdr { uint32_t o; int a, n; }; // kept window [a, a + n) of the read at byte o; n == 0: nothing to count
+    auto load_hdr = [&](const uint32_t r) -> Hdr {
+        Hdr h{0u, 0, 0};
+        if (r < r_end) {
+            h.o = uniu(off[r]);
+            h.n = (int)(uniu(off[r + 1]) - h.o);
+            if (!P.qc_only) { // trimmed read of a valid record (trim.cpp:545-547); raw read under --qc_only (:260-262)
+                const uint2 rs = results[r];
+                h.a = uni((int)(rs.x & 0xffffu));
+                h.n = uni((rs.y & FAQCS_F_VALID) ? (int)(rs.x >> 16) : 0);
+            }
+            if (h.n < k) h.n = 0;
+        }
+        return h;
+    };
+    struct __attribute__((packed, aligned(1))) U32u { uint32_t w; };
+    const uint32_t safe_o = off[r_begin]; // (a byte of the arena that is there whatever the cursor says)
+    // the piece being fetched: read hn_ (header), first position pn; the piece in work: hc, pc
+    uint32_t r_nxt = r_begin + blockIdx.x * NW + wave;
+    Hdr hf = load_hdr(r_nxt), hc{0u, 0, 0};
+    int pf = hf.a, pc = 0;
+    bool f_live = r_nxt < r_end;   // the fetched piece exists
+    Hdr ha = load_hdr(r_nxt + n_waves); // the header after the fetched piece's read
+    uint32_t nw_ = 0, nqw = 0;
+    auto fetch = [&]() { // the fetched piece's four bytes of this lane (what lies past the window is not read)
+        const int p0 = pf + 4 * lane;
+        const bool need = f_live && hf.n > 0 && p0 < hf.a + hf.n;
+        const size_t at = need ? (size_t)hf.o + (uint32_t)p0 : (size_t)safe_o;
+        const uint32_t v = reinterpret_cast<const U32u *>(seq + at)->w;
+        nw_ = need ? v : 0u;
+        if (g2n) { const uint32_t qv = reinterpret_cast<const U32u *>(qual + at)->w; nqw = need ? qv : 0u; }
+    };
+    auto advance_fetch = [&]() { // the piece after the fetched one
+        if (f_live && hf.n > 0 && pf + SKM_PIECE < hf.a + hf.n) { pf += SKM_ADVANCE; return; }
+        r_nxt += n_waves;
+        f_live = r_nxt < r_end;
+        hf = ha; pf = hf.a;
+        ha = load_hdr(r_nxt + n_waves);
+    };
+    fetch();
+
+    // wave state of the piece in work
+    bool c_live = false;            // a piece is in work
+    int st_next = 0, st_end = 0;    // stretch cursor inside the piece's window
+    bool has_bad = false;
+    uint64_t bad[4] = {0, 0, 0, 0}; // bit l of bad[j]: position 4 l + j of the piece is inside the window and not a base
+    int limit = 0;                  // k-mer starts at or past it belong to the next piece
+    uint32_t codes = 0;             // this lane's four 2-bit codes
+    // the stretch in work, per lane
+    u64 c_lo = 0, c_hi = 0;
+    uint32_t omin[4] = {0, 0, 0, 0}, mask24 = 0, sbits = 0;
+    Item pend[2];
+    uint32_t n_pend = 0;
+    uint32_t my_total = 0, phase = 0;
+    const u64 tag = (u64)run;
+
+    auto stretch = [&](const int sa, const int sn) { // runs of the valid bases [sa, sa + sn) of piece pc
+        rowA[lane] = codes;
+        lds_wave_sync();
+        uint32_t x[SKM_LOOK];
+#pragma unroll
+        for (int i = 0; i < SKM_LOOK; ++i) x[i] = rowA[lane + i];
+        lds_wave_sync();
+        c_lo = 0; c_hi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c_lo |= (u64)x[i] << (8 * i);
+#pragma unroll
+        for (int i = 8; i < SKM_LOOK; ++i) c_hi |= (u64)x[i] << (8 * (i - 8));
+        uint32_t o[4];
+        if (K31) skm_mmer_ords15(c_lo, g, o);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = skm_mmer_ord_at(c_lo, j, g);
+        }
+        if (K31) { // w = 17: positions p .. p + 16 = the lane's own from j on, three whole lanes, the first j + 1 of the fourth
+            const uint32_t p2 = umin_(o[0], o[1]), p3 = umin_(p2, o[2]), m4 = umin_(p3, o[3]);
+            const uint32_t s2 = umin_(o[2], o[3]), s1 = umin_(o[1], s2);
+            rowB[lane] = m4; rowB[72 + lane] = o[0]; rowB[144 + lane] = p2; rowB[216 + lane] = p3;
+            lds_wave_sync();
+            const uint32_t mid = umin_(umin_(rowB[lane + 1], rowB[lane + 2]), rowB[lane + 3]);
+            omin[0] = umin_(umin_(m4, mid), rowB[72 + lane + 4]);
+            omin[1] = umin_(umin_(s1, mid), rowB[144 + lane + 4]);
+            omin[2] = umin_(umin_(s2, mid), rowB[216 + lane + 4]);
+            omin[3] = umin_(umin_(o[3], mid), rowB[lane + 4]);
+            lds_wave_sync();
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rowB[4 * lane + j] = o[j];
+            lds_wave_sync();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t mn = o[j];
+#pragma unroll 1
+                for (int t = 1; t < w; ++t) mn = umin_(mn, rowB[4 * lane + j + t]);
+                omin[j] = mn;
+            }
+            lds_wave_sync();
+        }
+        // valid k-mer starts of the stretch in this piece: [vlo, vhi)
+        const int vlo = sa > pc ? sa : pc;
+        int vhi = sa + sn - k + 1;
+        vhi = vhi < limit ? vhi : limit;
+        const uint32_t prev = (uint32_t)__shfl_up((int)omin[3], 1);
+        uint32_t vb = 0, st = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = pc + 4 * lane + j;
+            const bool v = p >= vlo && p < vhi;
+            const bool s = v && (p == vlo || omin[j] != (j ? omin[j - 1] : prev));
+            vb |= v ? 1u << j : 0u;
+            st |= s ? 1u << j : 0u;
+        }
+        my_total += (uint32_t)__popc(vb);
+        auto exchange_breaks = [&](const uint32_t brk) {
+            rowA[lane] = brk;
+            lds_wave_sync();
+            uint32_t m = brk;
+#pragma unroll
+            for (int i = 1; i <= 5; ++i) m |= rowA[lane + i] << (4 * i);
+            lds_wave_sync();
+            return m;
+        };
+        auto too_long = [&](const uint32_t m) { // some run of this lane's starts has more than w k-mers
+            bool bad_ = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bad_ |= ((st >> j) & 1u) && ((m >> (j + 1)) & ((1u << w) - 1u)) == 0u;
+            return bad_;
+        };
+        mask24 = exchange_breaks(st | (~vb & 0xfu));
+        if (__any(too_long(mask24))) { // equal minimizers over more than w k-mers (a repeat): cut the stretch's runs on a grid of w
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = pc + 4 * lane + j;
+                if (((vb >> j) & 1u) && (uint32_t)(p - vlo) % (uint32_t)w == 0u) st |= 1u << j;
+            }
+            mask24 = exchange_breaks(st | (~vb & 0xfu));
+        }
+        sbits = st;
+    };
+    // first valid stretch at or after st_next; false: none left in this piece
+    auto next_stretch = [&]() -> bool {
+#pragma unroll 1
+        while (st_next < st_end) {
+            const int lo = st_next;
+            int nb = st_end;
+            if (has_bad) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rel = lo - pc - j;
+                    const int ln = rel <= 0 ? 0 : (rel + 3) >> 2;
+                    if (ln < 64) {
+                        const uint64_t m = bad[j] >> ln;
+                        if (m) { const int cand = pc + 4 * (ln + (__ffsll((long long)m) - 1)) + j; nb = cand < nb ? cand : nb; }
+                    }
+                }
+            }
+            st_next = nb + 1;
+            if (nb - lo >= k) { stretch(lo, nb - lo); return true; }
+        }
+        return false;
+    };
+
+#pragma unroll 1
+    for (;;) {
+        // ---- produce: the lanes' next runs ----
+        if (!__any(n_pend != 0u || sbits != 0u)) {
+            bool got = c_live && next_stretch();
+#pragma unroll 1
+            while (!got && f_live) { // the fetched piece becomes the piece in work
+                asm volatile("" ::"v"(nw_), "v"(nqw));
+                const uint32_t bw = nw_, bqw = nqw;
+                hc = hf; pc = pf; c_live = true;
+                const bool last = !(hc.n > 0 && pc + SKM_PIECE < hc.a + hc.n);
+                limit = last ? 0x7fffffff : pc + SKM_ADVANCE;
+                advance_fetch();
+                fetch();
+                uint32_t valid;
+                skm_classify4(bw, codes, valid);
+                if (g2n) { // G -> N precedes k-mer counting (trim.cpp:390-403)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int qv = (int)(int8_t)((bqw >> (8 * j)) & 0xffu) - P.in_off;
+                        qv = qv < 0 ? 0 : qv;
+                        if (((bw >> (8 * j)) & 0xffu) == (uint32_t)'G' && qv < (int)P.replace_q) valid &= ~(1u << j);
+                    }
+                }
+                st_next = pc;
+                st_end = hc.a + hc.n < pc + SKM_PIECE ? hc.a + hc.n : pc + SKM_PIECE;
+                uint32_t nb = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nb |= (pc + 4 * lane + j < st_end && !((valid >> j) & 1u)) ? 1u << j : 0u;
+                has_bad = __any(nb != 0u);
+                if (has_bad) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bad[j] = __ballot((nb >> j) & 1u);
+                }
+                got = hc.n > 0 && next_stretch();
+            }
+            if (!got) c_live = false;
+        }
+        // ---- emit: up to two runs per lane and round ----
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (n_pend == (uint32_t)e && sbits) {
+                const uint32_t j = (uint32_t)__ffs((int)sbits) - 1u;
+                sbits &= sbits - 1u;
+                const uint32_t len = (uint32_t)__ffs((int)((mask24 >> (j + 1u)) | (1u << w)));
+                const uint32_t om = j == 0 ? omin[0] : (j == 1 ? omin[1] : (j == 2 ? omin[2] : omin[3]));
+                u64 w0, w1;
+                skm_pack(c_lo, c_hi, j, len, skm_part(om), (uint32_t)tag, w0, w1);
+                pend[e] = make_ulonglong2(w0, w1);
+                n_pend = (uint32_t)e + 1u;
+            }
+        }
+        // ---- stage ----
+        if (n_pend) {
+            bool ok0 = S.put(skm_item_part(pend[0].y) >> 8, pend[0]);
+            if (n_pend == 2u) {
+                const bool ok1 = S.put(skm_item_part(pend[1].y) >> 8, pend[1]);
+                if (ok0 && !ok1) { pend[0] = pend[1]; }
+                if (ok0 != ok1) n_pend = 1u; else n_pend = ok0 ? 0u : 2u;
+            } else n_pend = ok0 ? 0u : 1u;
+        }
+        __syncthreads();
+        S.drain(wave, lane, false, G.cap1, write, slow);
+        const uint32_t f = S.block_or((n_pend != 0u || sbits != 0u || c_live || f_live) ? 1u : 0u, phase, tid);
+        if (!(f & 1u)) break;
+    }
+    S.drain(wave, lane, true, G.cap1, write, slow);
+    __syncthreads();
+    for (int i = tid; i < KG_FAN; i += NW * 64) G.cur1[sub * KG_FAN + i] = S.cur[i];
+    // occurrences of this launch's epoch (total_kmer of the sampling points, trim.cpp:170-176)
+    const uint32_t wt = (uint32_t)wave_sum_i32((int)my_total); // (a wave sees < 2^31 occurrences per launch)
+    if (lane == 0 && wt) atomicAdd(s_total, wt);                // (a block sees < 2^32)
+    __syncthreads();
+    if (tid == 0 && s_total[0]) {
+        hist_add(G.tot_by_epoch, epoch, G.n_epochs, (long long)s_total[0]);
+        atomicAdd(&T.stats[1], (u64)s_total[0]);
+    }
+}
+
+// ---- level 1 from items another rank extracted: the owner side of the multi-GPU exchange (faqcs_kmer_insert_device) -----------
+// An item's run field holds its ABSOLUTE epoch (the group's run -> epoch table is the identity in this mode).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void skm_items(const KmerGroupDev G, const KmerTable T, const uint32_t k, const uint32_t rot,
+                                                     const Item *__restrict__ items, const u64 n_items)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    Item *s_items = reinterpret_cast<Item *>(lds);
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(s_items + KG_FAN * KS_STAGE);
+    const Staging16<NW> S{s_items, w32, w32 + KG_FAN, w32 + 2 * KG_FAN};
+    uint32_t *s_tot = w32 + 2 * KG_FAN + 4; // [KG_EPOCH_SPAN] occurrences of this block by epoch
+    const SkmGeom g = skm_geom(k);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const uint32_t sub = (blockIdx.x + rot) % KG_FAN;
+    for (int i = tid; i < KG_FAN; i += NW * 64) { S.cnt[i] = 0u; S.cur[i] = G.cur1[sub * KG_FAN + i]; }
+    for (int i = tid; i < KG_EPOCH_SPAN; i += NW * 64) s_tot[i] = 0u;
+    if (tid < 3) S.flag[tid] = 0u;
+    __syncthreads();
+    auto write = [&](const uint32_t b, const uint32_t pos, const Item it) { l1_region(G, b, sub)[pos] = it; };
+    auto slow = [&](const uint32_t, const Item it) { skm_insert_item_atomic(T, it, skm_item_run(it.y), g, G.first_hist, G.n_epochs); };
+    constexpr uint32_t PER = NW * 64;
+    const u64 per_block = ((n_items + gridDim.x - 1) / gridDim.x + PER - 1) / PER * PER;
+    const u64 lo = (u64)blockIdx.x * per_block < n_items ? (u64)blockIdx.x * per_block : n_items;
+    const u64 hi = lo + per_block < n_items ? lo + per_block : n_items;
+    uint32_t phase = 0;
+    Item nx = lo + tid < hi ? items[lo + tid] : make_ulonglong2(0ull, KS_NONE);
+#pragma unroll 1
+    for (u64 t0 = lo; t0 < hi; t0 += PER) {
+        const Item cur = nx;
+        nx = t0 + PER + tid < hi ? items[t0 + PER + tid] : make_ulonglong2(0ull, KS_NONE);
+        uint32_t pend = 0;
+        if (cur.y != KS_NONE && skm_item_run(cur.y) < (uint32_t)KG_EPOCH_SPAN) {
+            pend = 1u;
+            atomicAdd(&s_tot[skm_item_run(cur.y)], skm_item_kmers(cur.y));
+        }
+#pragma unroll 1
+        for (;;) {
+            if (pend && S.put(skm_item_part(cur.y) >> 8, cur)) pend = 0u;
+            __syncthreads();
+            S.drain(wave, lane, false, G.cap1, write, slow);
+            if (!(S.block_or(pend, phase, tid) & 1u)) break;
+        }
+    }
+    __syncthreads();
+    S.drain(wave, lane, true, G.cap1, write, slow);
+    __syncthreads();
+    for (int i = tid; i < KG_FAN; i += NW * 64) G.cur1[sub * KG_FAN + i] = S.cur[i];
+    for (int i = tid; i < KG_EPOCH_SPAN; i += NW * 64)
+        if (s_tot[i]) hist_add(G.tot_by_epoch, (uint32_t)i, G.n_epochs, (long long)s_tot[i]);
+}
+
+// ---- level 2: every bucket 256 ways; the run number becomes the epoch -------------------------------------------------------
+// Block (b1, part) reads the sub-regions [part * 256 / split, (part + 1) * 256 / split) of bucket b1 and appends to sub-region
+// `part` of the partitions b1 * 256 + (low 8 bits of the item's partition): again a block writes only where no other block does.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void skm_split(const KmerGroupDev G, const KmerTable T, const uint32_t k)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    Item *s_items = reinterpret_cast<Item *>(lds);
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(s_items + KG_FAN * KS_STAGE);
+    const Staging16<NW> S{s_items, w32, w32 + KG_FAN, w32 + 2 * KG_FAN};
+    uint32_t *s_er = w32 + 2 * KG_FAN + 4;     // [KG_MAX_RUNS] epoch of run j, relative
+    uint32_t *s_n = s_er + KG_MAX_RUNS;        // [256] items of the bucket's sub-regions
+    const SkmGeom g = skm_geom(k);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const uint32_t b1 = blockIdx.x / G.split, part = blockIdx.x % G.split;
+    for (int i = tid; i < KG_FAN; i += NW * 64) { S.cnt[i] = 0u; S.cur[i] = 0u; s_n[i] = G.cur1[i * KG_FAN + b1]; }
+    if (tid < 3) S.flag[tid] = 0u;
+    for (uint32_t j = tid; j < G.n_runs; j += NW * 64) s_er[j] = G.run_epoch[j];
+    __syncthreads();
+    Item *const l2 = reinterpret_cast<Item *>(G.l2);
+    auto write = [&](const uint32_t b, const uint32_t pos, const Item it) { l2[(((size_t)b1 * KG_FAN + b) * G.split + part) * G.cap2 + pos] = it; };
+    auto slow = [&](const uint32_t, const Item it) { skm_insert_item_atomic(T, it, G.epoch_base + skm_item_run(it.y), g, G.first_hist, G.n_epochs); };
+    constexpr uint32_t TILE = NW * 64 * 2;
+    const uint32_t per = KG_FAN / G.split;
+    uint32_t phase = 0;
+#pragma unroll 1
+    for (uint32_t sr = part * per; sr < (part + 1) * per; ++sr) {
+        const uint32_t n_s = s_n[sr];
+        if (n_s == 0) continue; // (block-uniform)
+        const Item *src = l1_region(G, b1, sr);
+        Item nx[2], cx[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const uint32_t i = j * NW * 64 + tid; nx[j] = i < n_s ? src[i] : make_ulonglong2(0ull, KS_NONE); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cx[j] = nx[j];
+#pragma unroll 1
+        for (uint32_t t0 = 0; t0 < n_s; t0 += TILE) {
+            Item cur[2];
+            uint32_t pend = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { const uint32_t i = t0 + TILE + j * NW * 64 + tid; nx[j] = i < n_s ? src[i] : make_ulonglong2(0ull, KS_NONE); } // next tile
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                cur[j] = cx[j];
+                if (cx[j].y != KS_NONE) {
+                    cur[j].y = (cx[j].y & ~SKM_RUN_MASK) | ((u64)s_er[skm_item_run(cx[j].y)] << SKM_RUN_SHIFT);
+                    pend |= 1u << j;
+                }
+            }
+#pragma unroll 1
+            for (bool fetched = false;;) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if ((pend >> j) & 1u)
+                        if (S.put(skm_item_part(cur[j].y) & 255u, cur[j])) pend &= ~(1u << j);
+                __syncthreads();
+                if (!fetched) {
+                    asm volatile("" ::"v"(nx[0].x), "v"(nx[0].y), "v"(nx[1].x), "v"(nx[1].y));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) cx[j] = nx[j];
+                    fetched = true;
+                }
+                S.drain(wave, lane, false, G.cap2, write, slow);
+                if (!(S.block_or(pend ? 1u : 0u, phase, tid) & 1u)) break;
+            }
+        }
+    }
+    __syncthreads();
+    S.drain(wave, lane, true, G.cap2, write, slow);
+    __syncthreads();
+    for (int i = tid; i < KG_FAN; i += NW * 64) G.cur2[((size_t)b1 * KG_FAN + i) * G.split + part] = S.cur[i];
+}
+
+// ---- combine + insert: one workgroup per partition --------------------------------------------------------------------------
+// A thread takes an item and walks its k-mers with the rolling pair (forward word >> one base, reverse complement << one base):
+// canonical key = the smaller, h = mix62(key); LDS table slot = the top 12 bits of h, table slot inside the partition's slice = the
+// top bits of h too, so LDS order is table order.  The LDS table holds (h, count, smallest epoch).  When it is nearly full every
+// thread stops where it is, the table is written out -- ONE update per distinct key -- and cleared, and the threads go on.
+template <int NT, bool K31>
+__global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const KmerTable T, const uint32_t k_arg)
+{
+    constexpr int LS = 4096;
+    constexpr uint32_t LMASK = LS - 1, LIMIT = LS - 1280; // stop adding keys at 69 % (every wave may add 64 more before it sees the count)
+    __shared__ u64 s_key[LS];
+    __shared__ uint32_t s_cnt[LS];
+    __shared__ uint32_t s_ep[LS];
+    __shared__ int s_hist[KG_EPOCH_SPAN];
+    __shared__ uint32_t s_claim[KG_SLICE_MAX / 32]; // slots of the slice this launch has claimed
+    __shared__ uint32_t s_nkeys, s_more;
+    static_assert(NT / 64 * 64 + LIMIT <= LS, "waves overshoot the limit by at most 64 keys each");
+    const uint32_t p = blockIdx.x;
+    uint32_t n_sub[8], n_p = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { n_sub[j] = (uint32_t)j < G.split ? G.cur2[(size_t)p * G.split + j] : 0u; n_p += n_sub[j]; }
+    if (n_p == 0) return; // (block-uniform)
+    const SkmGeom g = skm_geom(K31 ? 31u : k_arg);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const Slice sc = slice_of(T, p);
+    const Item *src = reinterpret_cast<const Item *>(G.l2) + (size_t)p * G.split * G.cap2;
+    auto item_at = [&](uint32_t i) -> Item { // flat index over the sub-regions (a gap of cap2 - n_sub[j] items behind sub-region j)
+        uint32_t base = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (i < n_sub[j]) return src[base + i];
+            i -= n_sub[j]; base += G.cap2;
+        }
+        return make_ulonglong2(0ull, KS_NONE);
+    };
+    Item nx = (uint32_t)tid < n_p ? item_at((uint32_t)tid) : make_ulonglong2(0ull, KS_NONE);
+    auto clear = [&]() {
+        for (int i = tid; i < LS; i += NT) { s_key[i] = ~0ull; s_cnt[i] = 0u; s_ep[i] = 0xffffffffu; }
+        if (tid == 0) { s_nkeys = 0u; s_more = 0u; }
+    };
+    clear();
+    for (int i = tid; i < KG_EPOCH_SPAN; i += NT) s_hist[i] = 0;
+    for (uint32_t i = tid; i < (uint32_t)(sc.mask + 32) / 32; i += NT) s_claim[i] = 0u;
+    __syncthreads();
+
+    // ONE table update per key of the LDS table, none of them a device-scope atomic: the slice belongs to this workgroup for the
+    // length of the launch, an empty slot is claimed through the workgroup's LDS bitmap, and no other thread holds this key.
+    // A thread's four keys are looked up together (their first probes are in flight at the same time).
+    auto write_out = [&]() {
+        constexpr int KPT = LS / NT, KB = 2; // keys per thread, looked up KB at a time
+        const u64 win = sc.mask + 1 < (u64)KS_PROBE_MAX ? sc.mask + 1 : (u64)KS_PROBE_MAX;
+        static_assert(LS % NT == 0 && KPT % KB == 0, "keys per thread");
+#pragma unroll 1
+        for (int j0 = 0; j0 < KPT; j0 += KB) {
+            u64 kw[KB];
+            ulonglong2 first[KB];
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                kw[j] = s_key[(j0 + j) * NT + tid];
+                const u64 gslot = (kw[j] >> sc.shift) & sc.mask;
+                first[j] = make_ulonglong2(0ull, 0ull);
+                if (kw[j] != ~0ull) first[j] = *reinterpret_cast<const ulonglong2 *>(&T.slots[sc.base + gslot]);
+            }
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const u64 h = kw[j];
+                if (h == ~0ull) continue;
+                const uint32_t e_rel = s_ep[(j0 + j) * NT + tid], e = G.epoch_base + e_rel, cnt = s_cnt[(j0 + j) * NT + tid];
+                u64 gslot = (h >> sc.shift) & sc.mask;
+                bool placed = false;
+                ulonglong2 cur = first[j];
+#pragma unroll 1
+                for (u64 probe = 0; probe < win; ++probe) {
+                    KmerSlot *sl = &T.slots[sc.base + gslot];
+                    if (probe) cur = *reinterpret_cast<const ulonglong2 *>(sl);
+                    if (cur.x == ~0ull) {
+                        const uint32_t bit = 1u << (gslot & 31);
+                        if (!(atomicOr(&s_claim[gslot >> 5], bit) & bit)) { // a new key: key, count - 1 and first epoch in one plain store
+                            *reinterpret_cast<ulonglong2 *>(sl) = make_ulonglong2(h, (u64)(cnt - 1u) | ((u64)e << 32));
+                            atomicAdd(&s_hist[e_rel], 1);
+                            placed = true;
+                            break;
+                        }
+                    } else if (cur.x == h) {
+                        uint32_t c1 = (uint32_t)cur.y + cnt, fe = (uint32_t)(cur.y >> 32);
+                        if (e < fe) { // (a key the overflow path inserted during this group, or an earlier write-out of this launch, can hold a later epoch)
+                            if (fe != 0xffffffffu) {
+                                if (fe >= G.epoch_base && fe - G.epoch_base < (uint32_t)KG_EPOCH_SPAN) atomicAdd(&s_hist[fe - G.epoch_base], -1);
+                                else hist_add(G.first_hist, fe, G.n_epochs, -1);
+                            }
+                            atomicAdd(&s_hist[e_rel], 1);
+                            fe = e;
+                        }
+                        *reinterpret_cast<u64 *>(&sl->count_m1) = (u64)c1 | ((u64)fe << 32);
+                        placed = true;
+                        break;
+                    }
+                    gslot = (gslot + 1) & sc.mask;
+                }
+                if (!placed) ovf_insert_atomic(T, h, e, cnt, G.first_hist, G.n_epochs); // the window is full: the key lives in the overflow area
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (uint32_t i0 = 0; i0 < n_p; i0 += NT) {
+        const Item it = nx;
+        { const uint32_t i = i0 + (uint32_t)NT + (uint32_t)tid; nx = i < n_p ? item_at(i) : make_ulonglong2(0ull, KS_NONE); }
+        const bool have = it.y != KS_NONE;
+        const uint32_t nk = have ? skm_item_kmers(it.y) : 0u, ep = skm_item_run(it.y);
+        SkmRoll r = skm_roll_begin(it.x, it.y, g);
+        uint32_t j = 0;
+#pragma unroll 1
+        for (;;) {
+#pragma unroll 1
+            for (;;) {
+                const bool act = j < nk;
+                if (!__any(act)) break;
+                if (uniu(*(volatile uint32_t *)&s_nkeys) >= LIMIT) break;
+                bool claimed = false;
+                if (act) {
+                    const u64 h = skm_mix62(skm_roll_key(r));
+                    uint32_t s = (uint32_t)(h >> 50);
+                    bool done = false;
+#pragma unroll 1
+                    for (uint32_t probe = 0; probe < (uint32_t)LS; ++probe) {
+                        u64 wk = s_key[s];
+                        if (wk == ~0ull) {
+                            wk = atomicCAS(&s_key[s], ~0ull, h);
+                            if (wk == ~0ull) { claimed = true; wk = h; }
+                        }
+                        if (wk == h) {
+                            atomicAdd(&s_cnt[s], 1u);
+                            if (ep < *(volatile uint32_t *)&s_ep[s]) atomicMin(&s_ep[s], ep);
+                            done = true;
+                            break;
+                        }
+                        s = (s + 1) & LMASK;
+                    }
+                    if (done) { ++j; skm_roll_next(r, g); }
+                }
+                const uint32_t c = (uint32_t)__popcll(__ballot(claimed));
+                if (lane == 0 && c) atomicAdd(&s_nkeys, c);
+            }
+            if (j < nk) s_more = 1u;
+            __syncthreads();
+            const bool more = s_more != 0u;
+            if (!more) break; // (s_more is only written above, before the barrier, and cleared below behind one)
+            write_out();
+            __syncthreads();
+            clear();
+            __threadfence(); // the table stores are in L2 and this CU's L1 forgets the slice before the next write-out reads it
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    write_out();
+    __syncthreads();
+    for (int i = tid; i < KG_EPOCH_SPAN; i += NT)
+        if (s_hist[i]) hist_add(G.first_hist, G.epoch_base + (uint32_t)i, G.n_epochs, (long long)s_hist[i]);
+}
+
+__global__ void skm_group_reset(const KmerGroupDev G)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (uint32_t)KG_FAN * KG_FAN) G.cur1[i] = 0u;
+}
+
+// ---- sender side of the multi-GPU exchange -----------------------------------------------------------------------------------
+// Bucket b (the top 8 bits of a partition) belongs to rank (b * world) >> 8, so the level-1 buffers ARE grouped by destination:
+// count[d] = items of d's buckets, then a copy of every (bucket, sub-region) to its place behind an exclusive scan.  The run
+// field of an item becomes its absolute epoch.
+__global__ __launch_bounds__(256) void skm_outbox_count(const KmerGroupDev G, const uint32_t world, u64 *dest_count, u64 *region_offset)
+{
+    // one block; region_offset[b * 256 + s] = items in front of (b, s) in the outbox; dest_count[d] = items for rank d
+    __shared__ u64 s_sum[256];
+    const uint32_t b = threadIdx.x;
+    u64 n = 0;
+    for (uint32_t s = 0; s < (uint32_t)KG_FAN; ++s) n += G.cur1[s * KG_FAN + b];
+    s_sum[b] = n;
+    __syncthreads();
+    if (b == 0) {
+        u64 run_ = 0;
+        for (uint32_t i = 0; i < 256; ++i) { const u64 v = s_sum[i]; s_sum[i] = run_; run_ += v; }
+    }
+    __syncthreads();
+    u64 o = s_sum[b];
+    for (uint32_t s = 0; s < (uint32_t)KG_FAN; ++s) { region_offset[b * KG_FAN + s] = o; o += G.cur1[s * KG_FAN + b]; }
+    if (b < world) dest_count[b] = 0;
+    __syncthreads();
+    atomicAdd(&dest_count[(b * world) >> 8], n);
+}
+__global__ __launch_bounds__(256) void skm_outbox_copy(const KmerGroupDev G, const u64 *__restrict__ region_offset, Item *__restrict__ out)
+{
+    const uint32_t b = blockIdx.x >> 8, s = blockIdx.x & 255u;
+    const uint32_t n = G.cur1[s * KG_FAN + b];
+    const Item *src = l1_region(G, b, s);
+    Item *dst = out + region_offset[b * KG_FAN + s];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        Item it = src[i];
+        it.y = (it.y & ~SKM_RUN_MASK) | ((u64)(G.epoch_base + G.run_epoch[skm_item_run(it.y)]) << SKM_RUN_SHIFT);
+        dst[i] = it;
+    }
+}
+
+constexpr int KS_NW = 16;
+constexpr size_t KS_EXTRACT_LDS = KS_STAGE_BYTES + (size_t)KS_NW * KS_ROWS * 4;
+
+} // namespace
+
+// blocks of an extraction launch over n_reads reads
+uint32_t faqcs_skm_grid(uint32_t n_reads, int n_cu)
+{
+    uint32_t grid = (n_reads + 4 * KS_NW - 1) / (4 * KS_NW);
+    if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu; // one block per CU: its staging area is most of the CU's LDS
+    if (grid > (uint32_t)KG_FAN) grid = KG_FAN;       // ... and one sub-region of every bucket per block
+    return grid ? grid : 1u;
+}
+
+hipError_t faqcs_launch_skm_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
+                                    uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
+                                    uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st)
+{
+    if (r_end <= r_begin) return hipSuccess;
+    static unsigned long long done31 = 0, doneg = 0;
+    const dim3 grid(faqcs_skm_grid(r_end - r_begin, n_cu)), block(KS_NW * 64);
+    if (k == 31) {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&skm_extract<KS_NW, true>), KS_EXTRACT_LDS, done31);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((skm_extract<KS_NW, true>), grid, block, KS_EXTRACT_LDS, st,
+                           P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
+    } else {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&skm_extract<KS_NW, false>), KS_EXTRACT_LDS, doneg);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((skm_extract<KS_NW, false>), grid, block, KS_EXTRACT_LDS, st,
+                           P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
+    }
+    return hipGetLastError();
+}
+
+// blocks of an owner-side launch over n_items received items
+uint32_t faqcs_skm_items_grid(unsigned long long n_items, int n_cu)
+{
+    unsigned long long grid = (n_items + 16 * KS_NW * 64 - 1) / (16ull * KS_NW * 64);
+    if (grid > (unsigned long long)n_cu) grid = (unsigned long long)n_cu;
+    if (grid > (unsigned long long)KG_FAN) grid = KG_FAN;
+    return grid ? (uint32_t)grid : 1u;
+}
+
+hipError_t faqcs_launch_skm_items(const KmerGroupDev &G, const KmerTable &T, uint32_t k, uint32_t rot, const void *items, unsigned long long n_items,
+                                  int n_cu, hipStream_t st)
+{
+    if (!n_items) return hipSuccess;
+    static unsigned long long done = 0;
+    const size_t lds = KS_STAGE_BYTES + (size_t)KG_EPOCH_SPAN * 4 + 16;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&skm_items<KS_NW>), lds, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((skm_items<KS_NW>), dim3(faqcs_skm_items_grid(n_items, n_cu)), dim3(KS_NW * 64), lds, st, G, T, k, rot,
+                       reinterpret_cast<const Item *>(items), n_items);
+    return hipGetLastError();
+}
+
+// stages: 1 split, 2 combine, 4 cursor reset (7: a whole flush; the steps one by one: FAQCS_KMER_DEBUG's checks between them)
+hipError_t faqcs_launch_skm_flush(const KmerGroupDev &G, const KmerTable &T, uint32_t k, hipStream_t st, uint32_t stages)
+{
+    static unsigned long long done = 0;
+    const size_t lds = KS_STAGE_BYTES + (size_t)(KG_MAX_RUNS + KG_FAN) * 4 + 16;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&skm_split<KS_NW>), lds, done);
+    if (e != hipSuccess) return e;
+    if (stages & 1u) hipLaunchKernelGGL((skm_split<KS_NW>), dim3(KG_FAN * G.split), dim3(KS_NW * 64), lds, st, G, T, k);
+    if ((stages & 2u) && k == 31) hipLaunchKernelGGL((skm_combine<1024, true>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k);
+    else if (stages & 2u) hipLaunchKernelGGL((skm_combine<1024, false>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k);
+    if (stages & 4u) hipLaunchKernelGGL(skm_group_reset, dim3(KG_FAN * KG_FAN / 256), dim3(256), 0, st, G);
+    return hipGetLastError();
+}
+
+hipError_t faqcs_launch_skm_reset(const KmerGroupDev &G, hipStream_t st)
+{
+    hipLaunchKernelGGL(skm_group_reset, dim3(KG_FAN * KG_FAN / 256), dim3(256), 0, st, G);
+    return hipGetLastError();
+}
+
+// sender side: counts per destination rank (dest_count[world]) and the packed items (out: room for every item of the open group)
+hipError_t faqcs_launch_skm_outbox(const KmerGroupDev &G, uint32_t world, unsigned long long *dest_count, unsigned long long *region_offset,
+                                   void *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(skm_outbox_count, dim3(1), dim3(256), 0, st, G, world, dest_count, region_offset);
+    hipLaunchKernelGGL(skm_outbox_copy, dim3(KG_FAN * KG_FAN), dim3(256), 0, st, G, region_offset, reinterpret_cast<Item *>(out));
+    return hipGetLastError();
+}
