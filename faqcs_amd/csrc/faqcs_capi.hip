@@ -484,6 +484,7 @@ static int kg_init(faqcs_ctx *c)
     // vary more than hash bins do: twice the mean at level 2.  What overflows is counted occurrence by occurrence (exact, slow).
     g.skm = !c->partitioned;
     g.skm_w = c->prm.kmer > 15 ? c->prm.kmer - 14 : 1;
+    if (g.skm) d.split = 1u; // (a partition's items in one piece: skm_combine fetches them by index; 256 blocks split 1/9 of round 4's items)
     const size_t item_bytes = g.skm ? 16 : 8;
     const double G_items = !g.skm || g.skm_w == 1 ? (double)G : (double)G * 3.0 / (g.skm_w + 1);
     const double mean1 = G_items / (KG_FAN * KG_FAN), mean2 = mean1 / d.split;

@@ -601,32 +601,44 @@ __global__ __launch_bounds__(NW * 64) void skm_split(const KmerGroupDev G, const
 }
 
 // ---- combine + insert: one workgroup per partition --------------------------------------------------------------------------
-// A thread takes an item and walks its k-mers with the rolling pair (forward word >> one base, reverse complement << one base):
-// canonical key = the smaller, h = mix62(key); LDS table slot = the top 12 bits of h, table slot inside the partition's slice = the
-// top bits of h too, so LDS order is table order.  The LDS table holds (h, count, smallest epoch).  When it is nearly full every
-// thread stops where it is, the table is written out -- ONE update per distinct key -- and cleared, and the threads go on.
+// A lane handles one OCCURRENCE, not one item: the items of a tile (one per thread, a coalesced load) get their first occurrence
+// index by a block-wide prefix sum of their k-mer counts; a bit per occurrence index marks "an item starts here" and a word per 64
+// occurrences holds the index of the first item that starts in it, so lane l of the wave that takes occurrences 64 r .. 64 r + 63
+// finds its item (rank of the last start bit at or before l) and its position inside it (distance to that bit) with a handful of
+// bit operations, fetches the item's 16 bytes again (a gather that hits the cache: the tile was just read) and cuts its k-mer out.
+// Every wave iteration has 64 busy lanes whatever the lengths of the runs are; the first form of this kernel walked an item per
+// lane with rolling words and ran at 31 % lane use (profiles/r5a/pmc_skm_first.txt: 5.7 scalar + 3.2 vector instructions per
+// occurrence, scalar-issue bound).
+// The LDS table holds (h, count, smallest epoch), h = mix62(canonical key); LDS slot = the top 12 bits of h and the table slot inside
+// the partition's slice = the top bits of h too, so LDS order is table order.  When the LDS table is nearly full every wave stops
+// where it is, the table is written out -- ONE update per distinct key -- and cleared, and the waves go on.
 template <int NT, bool K31>
 __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const KmerTable T, const uint32_t k_arg)
 {
-    constexpr int LS = 4096;
+    constexpr int LS = 4096, NWV = NT / 64;
     constexpr uint32_t LMASK = LS - 1, LIMIT = LS - 1280; // stop adding keys at 69 % (every wave may add 64 more before it sees the count)
+    constexpr int MAXW = (NT * SKM_W_MAX + 63) / 64;       // 64-occurrence words of a tile
     __shared__ u64 s_key[LS];
     __shared__ uint32_t s_cnt[LS];
     __shared__ uint32_t s_ep[LS];
     __shared__ int s_hist[KG_EPOCH_SPAN];
     __shared__ uint32_t s_claim[KG_SLICE_MAX / 32]; // slots of the slice this launch has claimed
+    __shared__ uint32_t s_bits[2 * MAXW];           // bit o: an item's first occurrence has index o inside the tile
+    __shared__ uint32_t s_rank[MAXW];               // index (inside the tile) of the first item that starts in the word
+    __shared__ uint32_t s_wsum[NWV];
     __shared__ uint32_t s_nkeys, s_more;
-    static_assert(NT / 64 * 64 + LIMIT <= LS, "waves overshoot the limit by at most 64 keys each");
+    static_assert(NWV * 64 + LIMIT <= LS, "waves overshoot the limit by at most 64 keys each");
     const uint32_t p = blockIdx.x;
     uint32_t n_sub[8], n_p = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { n_sub[j] = (uint32_t)j < G.split ? G.cur2[(size_t)p * G.split + j] : 0u; n_p += n_sub[j]; }
     if (n_p == 0) return; // (block-uniform)
     const SkmGeom g = skm_geom(K31 ? 31u : k_arg);
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const Slice sc = slice_of(T, p);
     const Item *src = reinterpret_cast<const Item *>(G.l2) + (size_t)p * G.split * G.cap2;
     auto item_at = [&](uint32_t i) -> Item { // flat index over the sub-regions (a gap of cap2 - n_sub[j] items behind sub-region j)
+        if (G.split == 1u) return src[i];
         uint32_t base = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -643,11 +655,9 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
     clear();
     for (int i = tid; i < KG_EPOCH_SPAN; i += NT) s_hist[i] = 0;
     for (uint32_t i = tid; i < (uint32_t)(sc.mask + 32) / 32; i += NT) s_claim[i] = 0u;
-    __syncthreads();
 
     // ONE table update per key of the LDS table, none of them a device-scope atomic: the slice belongs to this workgroup for the
     // length of the launch, an empty slot is claimed through the workgroup's LDS bitmap, and no other thread holds this key.
-    // A thread's four keys are looked up together (their first probes are in flight at the same time).
     auto write_out = [&]() {
         constexpr int KPT = LS / NT, KB = 2; // keys per thread, looked up KB at a time
         const u64 win = sc.mask + 1 < (u64)KS_PROBE_MAX ? sc.mask + 1 : (u64)KS_PROBE_MAX;
@@ -704,28 +714,75 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
         }
     };
 
+    const u64 lane_lt = (1ull << lane) - 1ull;
 #pragma unroll 1
     for (uint32_t i0 = 0; i0 < n_p; i0 += NT) {
         const Item it = nx;
         { const uint32_t i = i0 + (uint32_t)NT + (uint32_t)tid; nx = i < n_p ? item_at(i) : make_ulonglong2(0ull, KS_NONE); }
-        const bool have = it.y != KS_NONE;
-        const uint32_t nk = have ? skm_item_kmers(it.y) : 0u, ep = skm_item_run(it.y);
-        SkmRoll r = skm_roll_begin(it.x, it.y, g);
-        uint32_t j = 0;
+        const uint32_t n_t = n_p - i0 < (uint32_t)NT ? n_p - i0 : (uint32_t)NT; // items of this tile
+        const uint32_t nk = it.y != KS_NONE ? skm_item_kmers(it.y) : 0u;
+        // first occurrence index of every item: block-wide exclusive prefix sum of the k-mer counts
+        const uint32_t incl = (uint32_t)wave_incl_scan_add((int)nk);
+        if (lane == 63) s_wsum[wave] = incl;
+        for (int i = tid; i < 2 * MAXW; i += NT) s_bits[i] = 0u;
+        for (int i = tid; i < MAXW; i += NT) s_rank[i] = n_t;
+        __syncthreads();
+        const uint32_t wsc = (uint32_t)wave_incl_scan_add(lane < NWV ? (int)s_wsum[lane] : 0);
+        const uint32_t base = wave ? (uint32_t)__builtin_amdgcn_readlane((int)wsc, wave - 1) : 0u;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wsc, NWV - 1); // occurrences of the tile
+        if (nk) {
+            const uint32_t start = base + incl - nk;
+            atomicOr(&s_bits[start >> 5], 1u << (start & 31));
+            atomicMin(&s_rank[start >> 6], (uint32_t)tid);
+        }
+        __syncthreads();
+        const uint32_t n_words = (total + 63u) >> 6;
+        uint32_t r = (uint32_t)wave;
 #pragma unroll 1
         for (;;) {
 #pragma unroll 1
-            for (;;) {
-                const bool act = j < nk;
-                if (!__any(act)) break;
+            for (; r < n_words; r += NWV) {
                 if (uniu(*(volatile uint32_t *)&s_nkeys) >= LIMIT) break;
+                // this lane's occurrence: index o of the tile -> (item, position inside it)
+                const uint32_t wlo = uniu(s_bits[2 * r]), whi = uniu(s_bits[2 * r + 1]);
+                const u64 word = ((u64)whi << 32) | wlo;
+                const uint32_t o = 64u * r + (uint32_t)lane;
+                bool todo = o < total;
+                const uint32_t before = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u)); // start bits below this lane
+                const uint32_t own = (uint32_t)((word >> lane) & 1ull);
+                const uint32_t idx = uniu(s_rank[r]) + before + own - 1u;
+                uint32_t j = 0;
+                if (!own) {
+                    const u64 wl = word & lane_lt;
+                    if (wl) j = (uint32_t)lane - (63u - (uint32_t)__clzll((long long)wl));
+                    else { // the item started in the word before (a run has at most 17 k-mers)
+                        const u64 prev = r ? ((u64)s_bits[2 * r - 1] << 32) | s_bits[2 * r - 2] : 1ull; // (r == 0: only lanes past the tile's last occurrence)
+                        j = (uint32_t)lane + 1u + (uint32_t)__clzll((long long)prev);
+                    }
+                }
+                Item iw = make_ulonglong2(0ull, 0ull);
+                if (todo) iw = item_at(i0 + idx);
+                const uint32_t ep = skm_item_run(iw.y);
+                u64 fwd, rc;
+                if (K31) { // bases j .. j + 30: a 62-bit window at bit 2 j (<= 32) of the 94-bit string
+                    const uint32_t d0 = (uint32_t)iw.x, d1 = (uint32_t)(iw.x >> 32), d2 = (uint32_t)iw.y, sh = 2u * j;
+                    const uint32_t lo = sh < 32u ? __builtin_amdgcn_alignbit(d1, d0, sh) : d1;
+                    const uint32_t hi = (sh < 32u ? __builtin_amdgcn_alignbit(d2, d1, sh) : d2) & SKM_M30;
+                    fwd = ((u64)hi << 32) | lo;
+                    rc = (skm_rev2_64(fwd) >> 2) ^ 0x2AAAAAAAAAAAAAAAull;
+                } else {
+                    const uint32_t sh = 2u * j;
+                    const u64 hi94 = iw.y & (u64)SKM_M30;
+                    fwd = (sh ? (iw.x >> sh) | (hi94 << (64u - sh)) : iw.x) & g.kmask2;
+                    rc = (skm_rev2_64(fwd) >> (64u - 2u * g.k)) ^ (0xAAAAAAAAAAAAAAAAull & g.kmask2);
+                }
+                const u64 h = skm_mix62(fwd < rc ? fwd : rc);
+                // count h in the LDS table: a wave-uniform loop, lanes drop out as they find their key or claim a slot
+                uint32_t s = (uint32_t)(h >> 50);
                 bool claimed = false;
-                if (act) {
-                    const u64 h = skm_mix62(skm_roll_key(r));
-                    uint32_t s = (uint32_t)(h >> 50);
-                    bool done = false;
 #pragma unroll 1
-                    for (uint32_t probe = 0; probe < (uint32_t)LS; ++probe) {
+                for (uint32_t probe = 0; probe < (uint32_t)LS && __any(todo); ++probe) {
+                    if (todo) {
                         u64 wk = s_key[s];
                         if (wk == ~0ull) {
                             wk = atomicCAS(&s_key[s], ~0ull, h);
@@ -734,17 +791,15 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
                         if (wk == h) {
                             atomicAdd(&s_cnt[s], 1u);
                             if (ep < *(volatile uint32_t *)&s_ep[s]) atomicMin(&s_ep[s], ep);
-                            done = true;
-                            break;
+                            todo = false;
                         }
                         s = (s + 1) & LMASK;
                     }
-                    if (done) { ++j; skm_roll_next(r, g); }
                 }
                 const uint32_t c = (uint32_t)__popcll(__ballot(claimed));
                 if (lane == 0 && c) atomicAdd(&s_nkeys, c);
             }
-            if (j < nk) s_more = 1u;
+            if (r < n_words) s_more = 1u;
             __syncthreads();
             const bool more = s_more != 0u;
             if (!more) break; // (s_more is only written above, before the barrier, and cleared below behind one)
