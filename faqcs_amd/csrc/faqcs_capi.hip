@@ -138,6 +138,7 @@ struct faqcs_ctx {
         bool owner = false;           // owner-partitioned context whose received pairs go through the group buffers too (n_epochs <= KG_EPOCH_SPAN)
         bool skm = false;             // 16-byte super-k-mer items (faqcs_kmer_skm_kernel.hip): every context that is not owner-partitioned
         uint32_t skm_w = 1;           // k-mers an item can hold (k - min(k, 15) + 1)
+        DevBuf<uint32_t> defer;       // [0]: how many, [1 ..]: the reads skm_extract16 left to skm_extract (k = 31, reads of up to 256 bases)
         uint64_t cap_items = 0;       // item bound of a group
         uint64_t bound_items = 0;     // upper bound of the items the open group holds
         std::vector<uint32_t> run_epoch, upload[2]; // epochs (relative to epoch_base) of the open group's runs; host copies in flight
@@ -444,6 +445,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     c->ob_items.release(); c->fwd_items.release(); c->ob_wave_count.release(); c->ob_wave_offset.release();
     { void *kg_ptrs[] = {c->kg.dev.l1, c->kg.dev.l2, c->kg.dev.cur1, c->kg.dev.cur2, c->kg.dev.run_epoch, c->kg.dev.first_hist, c->kg.dev.tot_by_epoch};
       for (void *q : kg_ptrs) if (q) (void)hipFree(q);
+      c->kg.defer.release();
       for (auto &ev : c->kg.flush_ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); } }
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->compute) (void)hipStreamDestroy(c->compute);
@@ -554,6 +556,8 @@ static int kg_debug_flush(faqcs_ctx *c)
       for (uint32_t b = 0; b < (uint32_t)KG_FAN; ++b) { uint64_t t = 0; for (uint32_t s2 = 0; s2 < (uint32_t)KG_FAN; ++s2) t += cur1[(size_t)s2 * KG_FAN + b]; if (t) { ++nb_used; first_b = std::min(first_b, b); last_b = b; } }
       for (uint32_t s2 = 0; s2 < (uint32_t)KG_FAN; ++s2) { uint64_t t = 0; for (uint32_t b = 0; b < (uint32_t)KG_FAN; ++b) t += cur1[(size_t)s2 * KG_FAN + b]; if (t) ++ns_used; }
       fprintf(stderr, "[kmer debug] cap1 %u cap2 %u split %u runs %zu; buckets in use %u (%u .. %u), sub-regions in use %u\n", d.cap1, d.cap2, d.split, g.run_epoch.size(), nb_used, first_b, last_b, ns_used); }
+    if (g.defer.p) { uint32_t nd = 0; HIPCHK(hipMemcpy(&nd, g.defer.p, 4, hipMemcpyDeviceToHost)); std::vector<uint32_t> dl(std::min<uint32_t>(nd, 8)); if (!dl.empty()) HIPCHK(hipMemcpy(dl.data(), g.defer.p + 1, dl.size() * 4, hipMemcpyDeviceToHost));
+                     fprintf(stderr, "[kmer debug] the last 16-positions launch left %u reads to the general kernel:", nd); for (uint32_t v : dl) fprintf(stderr, " %u", v); fprintf(stderr, "\n"); }
     fprintf(stderr, "[kmer debug] before the flush: %llu level-1 items, %llu occurrences, %llu in a wrong bucket, %llu with a bad length / run; overflow flag %llu, total %llu\n",
             (unsigned long long)n1, (unsigned long long)occ1, (unsigned long long)bad1, (unsigned long long)long1, st[2], st[1]);
     HIPCHK(faqcs_launch_skm_flush(d, c->kt, c->prm.kmer, c->compute, 1u));
@@ -642,7 +646,9 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
         const uint32_t run = (uint32_t)g.run_epoch.size(), rot = (run * 37u) % KG_FAN;
         // items a launch can be expected to write at most (super-k-mers: three per w + 1 occurrences and two per read)
         auto items_of = [&](uint32_t take, uint64_t bound) { return !g.skm || g.skm_w == 1 ? bound : bound * 3 / (g.skm_w + 1) + 2ull * take; };
-        auto grid_of = [&](uint32_t take) { return g.skm ? faqcs_skm_grid(take, c->n_cu) : faqcs_kmer_group_grid(take, c->n_cu); };
+        static const bool no16g = [] { const char *e = getenv("FAQCS_KMER_EXTRACT16"); return e && atoi(e) == 0; }();
+        const bool x16 = g.skm && c->prm.kmer == 31 && max_len <= 256 && !no16g;
+        auto grid_of = [&](uint32_t take) { return x16 ? faqcs_skm_grid16(take, c->n_cu) : g.skm ? faqcs_skm_grid(take, c->n_cu) : faqcs_kmer_group_grid(take, c->n_cu); };
         auto fits = [&](uint32_t take, uint64_t bound) {
             const uint32_t grid = grid_of(take);
             const uint64_t ib = items_of(take, bound);
@@ -664,7 +670,15 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
         const uint64_t bound = bound_of(take), ib = items_of(take, bound);
         const uint32_t grid = grid_of(take);
         if (g.run_epoch.empty()) g.epoch_base = epoch;
-        if (g.skm) HIPCHK(faqcs_launch_skm_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
+        static const bool no16 = [] { const char *e = getenv("FAQCS_KMER_EXTRACT16"); return e && atoi(e) == 0; }(); // (A/B switch)
+        if (g.skm && c->prm.kmer == 31 && max_len <= 256 && !no16) { // four reads per wave and round; what it cannot take goes to the general kernel behind it
+            if ((size_t)take + 1 > g.defer.cap) HIPCHK(g.defer.reserve((size_t)(r1 - r0) + 1));
+            HIPCHK(hipMemsetAsync(g.defer.p, 0, 4, c->compute));
+            HIPCHK(faqcs_launch_skm_extract16(c->dp, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off, r0, r0 + take, d_res,
+                                              g.defer.p + 1, g.defer.p, c->n_cu, c->compute));
+            HIPCHK(faqcs_launch_skm_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off, r0, r0 + take, d_res,
+                                            c->n_cu, c->compute, g.defer.p + 1, g.defer.p, grid));
+        } else if (g.skm) HIPCHK(faqcs_launch_skm_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
                                                    r0, r0 + take, d_res, c->n_cu, c->compute));
         else HIPCHK(faqcs_launch_kmer_group_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
                                                     r0, r0 + take, d_res, max_len, c->n_cu, c->compute));

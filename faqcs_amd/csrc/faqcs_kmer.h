@@ -112,7 +112,13 @@ hipError_t faqcs_launch_kmer_group_reset(const KmerGroupDev &G, hipStream_t st);
 uint32_t faqcs_skm_grid(uint32_t n_reads, int n_cu);
 hipError_t faqcs_launch_skm_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
                                     uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
-                                    uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st);
+                                    uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st,
+                                    const uint32_t *list = nullptr, const uint32_t *list_n = nullptr, uint32_t grid_blocks = 0);
+uint32_t faqcs_skm_grid16(uint32_t n_reads, int n_cu);
+hipError_t faqcs_launch_skm_extract16(const DevParams &P, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
+                                      uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
+                                      uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, uint32_t *defer, uint32_t *defer_n,
+                                      int n_cu, hipStream_t st);
 hipError_t faqcs_launch_skm_flush(const KmerGroupDev &G, const KmerTable &T, uint32_t k, hipStream_t st, uint32_t stages = 7u);
 hipError_t faqcs_launch_skm_reset(const KmerGroupDev &G, hipStream_t st);
 uint32_t faqcs_skm_items_grid(unsigned long long n_items, int n_cu);

@@ -193,6 +193,14 @@ __device__ __forceinline__ void lds_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// b where the lane's bit of m is set, else a (one v_cndmask_b32)
+__device__ __forceinline__ uint32_t sel_(const uint32_t a, const uint32_t b, const uint64_t m)
+{
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
+
 __device__ __forceinline__ Item *l1_region(const KmerGroupDev &G, const uint32_t b, const uint32_t sub)
 {
     return reinterpret_cast<Item *>(G.l1) + ((size_t)b * KG_FAN + sub) * G.cap1;
@@ -212,9 +220,12 @@ enum { KS_ROW_A = 80, KS_ROW_B = 288, KS_ROWS = KS_ROW_A + KS_ROW_B };
 template <int NW, bool K31>
 __global__ __launch_bounds__(NW * 64) void skm_extract(
     const DevParams P, const uint32_t k_arg, const KmerGroupDev G, const KmerTable T, const uint32_t run, const uint32_t rot, const uint32_t epoch,
-    const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off, const uint32_t r_begin,
-    const uint32_t r_end, const uint2 *__restrict__ results)
+    const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off, const uint32_t r_begin_arg,
+    const uint32_t r_end_arg, const uint2 *__restrict__ results, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n)
 {
+    // list != null: the reads list[0 .. *list_n) (what skm_extract16 left to this kernel) instead of the range [r_begin, r_end)
+    const uint32_t r_begin = list ? 0u : r_begin_arg, r_end = list ? uniu(*list_n) : r_end_arg;
+    if (r_end <= r_begin) return;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     Item *s_items = reinterpret_cast<Item *>(lds);
     uint32_t *w32 = reinterpret_cast<uint32_t *>(s_items + KG_FAN * KS_STAGE);
@@ -236,9 +247,10 @@ __global__ __launch_bounds__(NW * 64) void skm_extract(
     __syncthreads();
 
     struct Hdr { uint32_t o; int a, n; }; // kept window [a, a + n) of the read at byte o; n == 0: nothing to count
-    auto load_hdr = [&](const uint32_t r) -> Hdr {
+    auto load_hdr = [&](const uint32_t ri) -> Hdr {
         Hdr h{0u, 0, 0};
-        if (r < r_end) {
+        if (ri < r_end) {
+            const uint32_t r = list ? uniu(list[ri]) : ri;
             h.o = uniu(off[r]);
             h.n = (int)(uniu(off[r + 1]) - h.o);
             if (!P.qc_only) { // trimmed read of a valid record (trim.cpp:545-547); raw read under --qc_only (:260-262)
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void skm_extract(
         return h;
     };
     struct __attribute__((packed, aligned(1))) U32u { uint32_t w; };
-    const uint32_t safe_o = off[r_begin]; // (a byte of the arena that is there whatever the cursor says)
+    const uint32_t safe_o = off[r_begin_arg]; // (a byte of the arena that is there whatever the cursor says)
     // the piece being fetched: read hn_ (header), first position pn; the piece in work: hc, pc
     uint32_t r_nxt = r_begin + blockIdx.x * NW + wave;
     Hdr hf = load_hdr(r_nxt), hc{0u, 0, 0};
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void skm_extract(
     uint32_t omin[4] = {0, 0, 0, 0}, mask24 = 0, sbits = 0;
     Item pend[2];
     uint32_t n_pend = 0;
-    uint32_t my_total = 0, phase = 0;
+    uint32_t my_total = 0, phase = 0, round_no = 0;
     const u64 tag = (u64)run;
 
     auto stretch = [&](const int sa, const int sn) { // runs of the valid bases [sa, sa + sn) of piece pc
@@ -423,9 +435,9 @@ __global__ __launch_bounds__(NW * 64) void skm_extract(
                 }
                 st_next = pc;
                 st_end = hc.a + hc.n < pc + SKM_PIECE ? hc.a + hc.n : pc + SKM_PIECE;
-                uint32_t nb = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) nb |= (pc + 4 * lane + j < st_end && !((valid >> j) & 1u)) ? 1u << j : 0u;
+                int inw = st_end - (pc + 4 * lane); // the lane's positions inside the window: the first inw of its four
+                inw = inw < 0 ? 0 : (inw > 4 ? 4 : inw);
+                const uint32_t nb = ((1u << inw) - 1u) & ~valid;
                 has_bad = __any(nb != 0u);
                 if (has_bad) {
 #pragma unroll
@@ -459,7 +471,9 @@ __global__ __launch_bounds__(NW * 64) void skm_extract(
             } else n_pend = ok0 ? 0u : 1u;
         }
         __syncthreads();
-        S.drain(wave, lane, false, G.cap1, write, slow);
+        // (a bucket gets about 1.5 of the block's items per round and holds 32: the owners write the full granules every fourth round,
+        // four buckets per step; a put that finds its bucket full waits a round)
+        if ((++round_no & 3u) == 0u) S.drain(wave, lane, false, G.cap1, write, slow);
         const uint32_t f = S.block_or((n_pend != 0u || sbits != 0u || c_live || f_live) ? 1u : 0u, phase, tid);
         if (!(f & 1u)) break;
     }
@@ -469,6 +483,221 @@ __global__ __launch_bounds__(NW * 64) void skm_extract(
     // occurrences of this launch's epoch (total_kmer of the sampling points, trim.cpp:170-176)
     const uint32_t wt = (uint32_t)wave_sum_i32((int)my_total); // (a wave sees < 2^31 occurrences per launch)
     if (lane == 0 && wt) atomicAdd(s_total, wt);                // (a block sees < 2^32)
+    __syncthreads();
+    if (tid == 0 && s_total[0]) {
+        hist_add(G.tot_by_epoch, epoch, G.n_epochs, (long long)s_total[0]);
+        atomicAdd(&T.stats[1], (u64)s_total[0]);
+    }
+}
+
+// ---- level 1 for reads of up to 256 bases, k = 31: a 16-lane DPP row per read, a lane owns SIXTEEN positions ------------------
+// skm_extract spends about 130 of its 530 vector instructions per round on the arithmetic of the runs; the rest -- classification,
+// the exchange rows, emission, staging, the round's barriers -- is paid per ROUND and shared by four positions per lane
+// (profiles/r5a/pmc_skm_*.txt: 2.4 vector + 1.8 scalar instructions per occurrence, issue-bound on both).  Here a wave works on FOUR
+// reads per round, one per row of 16 lanes, and a lane owns 16 consecutive positions (one 16-byte load): the same per-round costs are
+// shared by four times the positions, and everything a lane needs from its neighbours comes through DPP row shifts, which fill with
+// zeros past the end of the row -- exactly "no bases behind the read": the three following lanes' codes (row_shl 1 .. 3), the next
+// lane's prefix minima (the window of 17 m-mers at position j = the lane's own suffix j .. 15 and the next lane's prefix 0 .. j: one
+// v_min with a DPP source per position), the previous lane's last minimum, the following lanes' run bits.  No LDS but the staging.
+// A byte that is not a base cuts a read by bit arithmetic (the "unusable position" bits smeared over 31 places).  A read with a run of
+// more than 17 k-mers (a repeat) is not handled here: its index goes to `defer` and skm_extract takes it afterwards (grid cuts).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void skm_extract16(
+    const DevParams P, const KmerGroupDev G, const KmerTable T, const uint32_t run, const uint32_t rot, const uint32_t epoch,
+    const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, const uint32_t *__restrict__ off, const uint32_t r_begin,
+    const uint32_t r_end, const uint2 *__restrict__ results, uint32_t *__restrict__ defer, uint32_t *__restrict__ defer_n)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    Item *s_items = reinterpret_cast<Item *>(lds);
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(s_items + KG_FAN * KS_STAGE);
+    const Staging16<NW> S{s_items, w32, w32 + KG_FAN, w32 + 2 * KG_FAN};
+    uint32_t *s_total = w32 + 2 * KG_FAN + 3; // occurrences of this block
+    const SkmGeom g = skm_geom(31u);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), row = lane >> 4, l16 = lane & 15;
+    const uint32_t sub = (blockIdx.x + rot) % KG_FAN; // this block's sub-region of every bucket
+    for (int i = tid; i < KG_FAN; i += NW * 64) { S.cnt[i] = 0u; S.cur[i] = G.cur1[sub * KG_FAN + i]; }
+    if (tid < 4) S.flag[tid] = 0u; // (flags and s_total)
+    const uint32_t stride = gridDim.x * NW * 4u;
+    const bool g2n = !P.qc_only && P.replace_q > 0;
+    auto write = [&](const uint32_t b, const uint32_t pos, const Item it) { l1_region(G, b, sub)[pos] = it; };
+    auto slow = [&](const uint32_t, const Item it) { skm_insert_item_atomic(T, it, epoch, g, G.first_hist, G.n_epochs); };
+    __syncthreads();
+
+    struct Hdr { uint32_t o; int a, n; }; // kept window [a, a + n) of the row's read at byte o; n == 0: nothing to count
+    auto load_hdr = [&](const uint32_t r) -> Hdr {
+        Hdr h{0u, 0, 0};
+        if (r < r_end) {
+            h.o = off[r];
+            h.n = (int)(off[r + 1] - h.o);
+            if (!P.qc_only) { // trimmed read of a valid record (trim.cpp:545-547); raw read under --qc_only (:260-262)
+                const uint2 rs = results[r];
+                h.a = (int)(rs.x & 0xffffu);
+                h.n = (rs.y & FAQCS_F_VALID) ? (int)(rs.x >> 16) : 0;
+            }
+            if (h.n < 31) h.n = 0;
+        }
+        return h;
+    };
+    struct __attribute__((packed, aligned(1))) U128u { uint32_t w[4]; };
+    const uint32_t safe_o = off[r_begin];
+    uint32_t r_f = r_begin + (blockIdx.x * NW + (uint32_t)wave) * 4u + (uint32_t)row; // the row's read being fetched
+    Hdr hf = load_hdr(r_f), hn = load_hdr(r_f + stride);
+    uint32_t nb[4] = {0, 0, 0, 0}, nq[4] = {0, 0, 0, 0};
+    auto fetch = [&]() { // the lane's sixteen bytes of the fetched read (what lies past the window is not read)
+        const bool need = hf.n > 0 && 16 * l16 < hf.n;
+        const size_t at = need ? (size_t)hf.o + (uint32_t)(hf.a + 16 * l16) : (size_t)safe_o;
+        const U128u v = *reinterpret_cast<const U128u *>(seq + at);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) nb[d] = need ? v.w[d] : 0u;
+        if (g2n) {
+            const U128u q = *reinterpret_cast<const U128u *>(qual + at);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) nq[d] = need ? q.w[d] : 0u;
+        }
+    };
+    fetch();
+    auto shl = [](const uint32_t v, const int n) -> uint32_t { // the value of the lane n places on in the row, 0 past its end
+        return n == 1 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true)
+             : n == 2 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true)
+                      : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x103, 0xf, 0xf, true);
+    };
+    // the read in work, per lane
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; // codes of the positions 16 l .. 16 l + 63
+    uint32_t omin[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) omin[j] = 0u;
+    u64 brk64 = 0;     // bit i: position 16 l + i starts a run or holds no k-mer
+    uint32_t sb = 0;   // run starts of this lane still to be written
+    Item pend = make_ulonglong2(0ull, 0ull);
+    bool has_pend = false;
+    uint32_t my_total = 0, phase = 0;
+    bool more_reads = r_f < r_end; // (row-uniform) the fetched read exists
+
+#pragma unroll 1
+    for (;;) {
+        if (!__any(sb != 0u || has_pend) && __any(more_reads)) {
+            // ---- the fetched reads become the reads in work ----
+            asm volatile("" ::"v"(nb[0]), "v"(nb[1]), "v"(nb[2]), "v"(nb[3]));
+            const Hdr hc = hf;
+            const uint32_t r_c = r_f;
+            uint32_t bw[4], bq[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { bw[d] = nb[d]; bq[d] = nq[d]; }
+            r_f += stride; hf = hn; hn = load_hdr(r_f + stride);
+            more_reads = r_f < r_end;
+            fetch();
+            uint32_t valid = 0;
+            c0 = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t cd, vd;
+                skm_classify4(bw[d], cd, vd);
+                if (g2n) { // G -> N precedes k-mer counting (trim.cpp:390-403)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int qv = (int)(int8_t)((bq[d] >> (8 * j)) & 0xffu) - P.in_off;
+                        qv = qv < 0 ? 0 : qv;
+                        if (((bw[d] >> (8 * j)) & 0xffu) == (uint32_t)'G' && qv < (int)P.replace_q) vd &= ~(1u << j);
+                    }
+                }
+                c0 |= cd << (8 * d); valid |= vd << (4 * d);
+            }
+            int inw = hc.n - 16 * l16; // the lane's positions inside the window: the first inw of its sixteen
+            inw = inw < 0 ? 0 : (inw > 16 ? 16 : inw);
+            // positions that cannot be part of a k-mer: outside the kept window or not a base.  A position holds a k-mer iff none of
+            // the 31 positions from it on is one of them: the bits smeared over 31 places (an N cuts the read without any loop)
+            const uint32_t usable = ((1u << inw) - 1u) & valid;
+            u64 z = ~((u64)usable | ((u64)shl(usable, 1) << 16) | ((u64)shl(usable, 2) << 32)); // (past the end of the row: not usable)
+            z |= z >> 1; z |= z >> 2; z |= z >> 4; z |= z >> 8; // bit i: one of i .. i + 15
+            z |= z >> 15;                                       // ... i .. i + 30
+            const uint32_t vb = 0xffffu & ~(uint32_t)z;
+            c1 = shl(c0, 1); c2 = shl(c0, 2); c3 = shl(c0, 3);
+            // ord of the canonical m-mer at each of the sixteen positions: bases 0 .. 29 reversed once (base i -> group 29 - i)
+            const uint32_t r0 = skm_rev2_32((c1 << 4) | (c0 >> 28)), r1 = skm_rev2_32(c0 << 4);
+            uint32_t o[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t fwd = __builtin_amdgcn_alignbit(c1, c0, 2 * j) & SKM_M30;
+                const uint32_t rc = (__builtin_amdgcn_alignbit(r1, r0, 2 * (15 - j)) & SKM_M30) ^ 0x2AAAAAAAu;
+                o[j] = skm_ord(fwd < rc ? fwd : rc, g);
+            }
+            // smallest ord of the 17 m-mers at p .. p + 16: the lane's suffix j .. 15 and the next lane's prefix 0 .. j
+            uint32_t pre[16];
+            pre[0] = o[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) pre[j] = umin_(pre[j - 1], o[j]);
+            uint32_t suf = o[15];
+#pragma unroll
+            for (int j = 15; j >= 0; --j) {
+                suf = umin_(suf, o[j]);
+                omin[j] = umin_(suf, shl(pre[j], 1));
+            }
+            // run starts: a k-mer starts a run when the position before it holds none or its minimum changes
+            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)omin[15], 0x111, 0xf, 0xf, true); // row_shr:1
+            const uint32_t vprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vb, 0x111, 0xf, 0xf, true);
+            uint32_t st = ~((vb << 1) | (vprev >> 15));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) st |= (omin[j] != (j ? omin[j - 1] : prev)) ? 1u << j : 0u;
+            st &= vb;
+            const uint32_t cont = vb & ~st; // positions that continue a run
+            const u64 cont64 = (u64)cont | ((u64)shl(cont, 1) << 16) | ((u64)shl(cont, 2) << 32);
+            // a run of more than 17 k-mers: 17 continuing positions in a row right behind one of this lane's starts
+            u64 x = cont64;
+            x &= x >> 1; x &= x >> 2; x &= x >> 4; x &= x >> 8; // bit i: positions i .. i + 15 continue
+            x &= cont64 >> 16;                                  // ... and position i + 16
+            const bool too_long = ((uint32_t)(x >> 1) & st) != 0u;
+            const bool deferred = row_all_or(too_long ? 1u : 0u) != 0u;
+            if (deferred) {
+                if (l16 == 0 && hc.n > 0) defer[atomicAdd(defer_n, 1u)] = r_c;
+                sb = 0u;
+            } else {
+                sb = st;
+                my_total += (uint32_t)__popc(vb);
+            }
+            brk64 = ~cont64;
+        }
+        // ---- write the runs: a lane builds and stages one item per turn until its starts are used up or a bucket is full ----
+        bool stuck = false;
+#pragma unroll 1
+        while (__any((sb != 0u || has_pend) && !stuck)) {
+            if (!stuck) {
+                if (!has_pend && sb) {
+                    const uint32_t j = (uint32_t)__ffs((int)sb) - 1u;
+                    sb &= sb - 1u;
+                    const uint32_t len = (uint32_t)__ffsll((long long)(brk64 >> (j + 1u)));
+                    // omin[j]: a tree of fifteen selects on the bits of j (written as instructions: as C the compiler turns the tree
+                    // into an indexed load and moves omin[] to scratch memory)
+                    const uint64_t m0 = __ballot(j & 1u), m1 = __ballot(j & 2u), m2 = __ballot(j & 4u), m3 = __ballot(j & 8u);
+                    uint32_t t8[8], t4[4];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t8[i] = sel_(omin[2 * i], omin[2 * i + 1], m0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t4[i] = sel_(t8[2 * i], t8[2 * i + 1], m1);
+                    const uint32_t om = sel_(sel_(t4[0], t4[1], m2), sel_(t4[2], t4[3], m2), m3);
+                    const uint32_t sh = 2u * j;
+                    const uint32_t d0 = __builtin_amdgcn_alignbit(c1, c0, sh), d1 = __builtin_amdgcn_alignbit(c2, c1, sh);
+                    const uint32_t d2 = __builtin_amdgcn_alignbit(c3, c2, sh) & SKM_M30;
+                    pend.x = ((u64)d1 << 32) | d0;
+                    pend.y = (u64)d2 | ((u64)(len - 1u) << SKM_NK_SHIFT) | ((u64)skm_part(om) << SKM_PART_SHIFT) | ((u64)run << SKM_RUN_SHIFT);
+                    has_pend = true;
+                }
+                if (has_pend) {
+                    if (S.put(skm_item_part(pend.y) >> 8, pend)) has_pend = false;
+                    else stuck = true;
+                }
+            }
+        }
+        __syncthreads();
+        S.drain(wave, lane, false, G.cap1, write, slow);
+        const uint32_t f = S.block_or((sb != 0u || has_pend || more_reads) ? 1u : 0u, phase, tid);
+        if (!(f & 1u)) break;
+    }
+    S.drain(wave, lane, true, G.cap1, write, slow);
+    __syncthreads();
+    for (int i = tid; i < KG_FAN; i += NW * 64) G.cur1[sub * KG_FAN + i] = S.cur[i];
+    // occurrences of this launch's epoch (total_kmer of the sampling points, trim.cpp:170-176)
+    const uint32_t wt = (uint32_t)wave_sum_i32((int)my_total);
+    if (lane == 0 && wt) atomicAdd(s_total, wt);
     __syncthreads();
     if (tid == 0 && s_total[0]) {
         hist_add(G.tot_by_epoch, epoch, G.n_epochs, (long long)s_total[0]);
@@ -777,24 +1006,28 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
                     rc = (skm_rev2_64(fwd) >> (64u - 2u * g.k)) ^ (0xAAAAAAAAAAAAAAAAull & g.kmask2);
                 }
                 const u64 h = skm_mix62(fwd < rc ? fwd : rc);
-                // count h in the LDS table: a wave-uniform loop, lanes drop out as they find their key or claim a slot
-                uint32_t s = (uint32_t)(h >> 50);
+                // count h in the LDS table: a wave-uniform loop that finds the key's slot (lanes drop out as they find their key or claim
+                // an empty slot -- the table is never full, see LIMIT), then ONE count and epoch update per lane behind it
+                uint32_t s = (uint32_t)(h >> 50), sf = 0;
                 bool claimed = false;
+                const bool mine = todo;
 #pragma unroll 1
-                for (uint32_t probe = 0; probe < (uint32_t)LS && __any(todo); ++probe) {
-                    if (todo) {
-                        u64 wk = s_key[s];
-                        if (wk == ~0ull) {
-                            wk = atomicCAS(&s_key[s], ~0ull, h);
-                            if (wk == ~0ull) { claimed = true; wk = h; }
-                        }
-                        if (wk == h) {
-                            atomicAdd(&s_cnt[s], 1u);
-                            if (ep < *(volatile uint32_t *)&s_ep[s]) atomicMin(&s_ep[s], ep);
-                            todo = false;
-                        }
-                        s = (s + 1) & LMASK;
+                for (;;) {
+                    u64 wk = s_key[s];
+                    if (todo && wk == ~0ull) {
+                        const u64 old = atomicCAS(&s_key[s], ~0ull, h);
+                        claimed = claimed || old == ~0ull;
+                        wk = old == ~0ull ? h : old;
                     }
+                    const bool hit = todo && wk == h;
+                    sf = hit ? s : sf;
+                    todo = todo && !hit;
+                    s = (s + 1) & LMASK;
+                    if (!__any(todo)) break;
+                }
+                if (mine) {
+                    atomicAdd(&s_cnt[sf], 1u);
+                    if (ep < *(volatile uint32_t *)&s_ep[sf]) atomicMin(&s_ep[sf], ep);
                 }
                 const uint32_t c = (uint32_t)__popcll(__ballot(claimed));
                 if (lane == 0 && c) atomicAdd(&s_nkeys, c);
@@ -874,24 +1107,49 @@ uint32_t faqcs_skm_grid(uint32_t n_reads, int n_cu)
     return grid ? grid : 1u;
 }
 
+// list != null: the reads list[0 .. *list_n) (device memory; what a faqcs_launch_skm_extract16 over [r_begin, r_end) left) instead of the range
 hipError_t faqcs_launch_skm_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
                                     uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
-                                    uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st)
+                                    uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, int n_cu, hipStream_t st,
+                                    const uint32_t *list, const uint32_t *list_n, uint32_t grid_blocks)
 {
     if (r_end <= r_begin) return hipSuccess;
     static unsigned long long done31 = 0, doneg = 0;
-    const dim3 grid(faqcs_skm_grid(r_end - r_begin, n_cu)), block(KS_NW * 64);
+    const dim3 grid(grid_blocks ? grid_blocks : faqcs_skm_grid(r_end - r_begin, n_cu)), block(KS_NW * 64);
     if (k == 31) {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&skm_extract<KS_NW, true>), KS_EXTRACT_LDS, done31);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((skm_extract<KS_NW, true>), grid, block, KS_EXTRACT_LDS, st,
-                           P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
+                           P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results), list, list_n);
     } else {
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&skm_extract<KS_NW, false>), KS_EXTRACT_LDS, doneg);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((skm_extract<KS_NW, false>), grid, block, KS_EXTRACT_LDS, st,
-                           P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results));
+                           P, k, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results), list, list_n);
     }
+    return hipGetLastError();
+}
+
+// k = 31, reads of up to 256 bases: four reads per wave and round; reads it cannot take (a non-base inside the kept window, a run of more
+// than 17 k-mers) are listed in defer[0 .. *defer_n) for a faqcs_launch_skm_extract(list) behind it.  *defer_n must be zero.
+uint32_t faqcs_skm_grid16(uint32_t n_reads, int n_cu)
+{
+    uint32_t grid = (n_reads + 16 * KS_NW - 1) / (16 * KS_NW);
+    if (grid > (uint32_t)n_cu) grid = (uint32_t)n_cu;
+    if (grid > (uint32_t)KG_FAN) grid = KG_FAN;
+    return grid ? grid : 1u;
+}
+hipError_t faqcs_launch_skm_extract16(const DevParams &P, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
+                                      uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
+                                      uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, uint32_t *defer, uint32_t *defer_n,
+                                      int n_cu, hipStream_t st)
+{
+    if (r_end <= r_begin) return hipSuccess;
+    static unsigned long long done = 0;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&skm_extract16<KS_NW>), KS_STAGE_BYTES, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((skm_extract16<KS_NW>), dim3(faqcs_skm_grid16(r_end - r_begin, n_cu)), dim3(KS_NW * 64), KS_STAGE_BYTES, st,
+                       P, G, T, run, rot, epoch, seq, qual, off, r_begin, r_end, reinterpret_cast<const uint2 *>(results), defer, defer_n);
     return hipGetLastError();
 }
 

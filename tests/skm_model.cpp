@@ -166,6 +166,96 @@ static void extract_read(const std::string &seq, const std::vector<uint8_t> &g2n
     }
 }
 
+
+// skm_extract16: a row of 16 lanes, 16 positions per lane, k = 31, windows of up to 256 bases; false: the read is left to extract_read
+static bool extract_read16(const std::string &seq, const std::vector<uint8_t> &g2n_mask, int a, int n, const SkmGeom &g, uint32_t run,
+                           std::vector<Item> &out, uint64_t &total)
+{
+    if (n < 31) return true;
+    uint32_t c0[16], bad[16];
+    for (int l = 0; l < 16; ++l) {
+        uint32_t valid = 0;
+        c0[l] = 0;
+        const bool need = 16 * l < n;
+        for (int d = 0; d < 4; ++d) {
+            uint32_t bw = 0;
+            if (need)
+                for (int j = 0; j < 4; ++j) { const int p = a + 16 * l + 4 * d + j; bw |= (uint32_t)(uint8_t)(p < (int)seq.size() ? seq[p] : 'x') << (8 * j); }
+            uint32_t cd, vd;
+            skm_classify4(bw, cd, vd);
+            for (int j = 0; j < 4; ++j) { const int p = a + 16 * l + 4 * d + j; if (p < (int)seq.size() && g2n_mask[p]) vd &= ~(1u << j); }
+            c0[l] |= cd << (8 * d); valid |= vd << (4 * d);
+        }
+        int inw = n - 16 * l;
+        inw = inw < 0 ? 0 : (inw > 16 ? 16 : inw);
+        bad[l] = ((1u << inw) - 1u) & valid; // usable positions
+    }
+    auto at = [&](const uint32_t *v, int l) -> uint32_t { return l < 16 ? v[l] : 0u; }; // row_shl past the row's end: 0
+    uint32_t omin[16][16], pre[16][16], o[16][16];
+    for (int l = 0; l < 16; ++l) {
+        const uint32_t c1 = at(c0, l + 1);
+        const uint32_t r0 = skm_rev2_32((c1 << 4) | (c0[l] >> 28)), r1 = skm_rev2_32(c0[l] << 4);
+        for (int j = 0; j < 16; ++j) {
+            const u64 cc = ((u64)c1 << 32) | c0[l], rr = ((u64)r1 << 32) | r0;
+            const uint32_t fwd = (uint32_t)(cc >> (2 * j)) & SKM_M30;
+            const uint32_t rc = ((uint32_t)(rr >> (2 * (15 - j))) & SKM_M30) ^ 0x2AAAAAAAu;
+            o[l][j] = skm_ord(fwd < rc ? fwd : rc, g);
+            if (o[l][j] != skm_mmer_ord_at(cc, j, g)) { fprintf(stderr, "extract16: ord differs from mmer_ord_at\n"); exit(1); }
+        }
+        pre[l][0] = o[l][0];
+        for (int j = 1; j < 16; ++j) pre[l][j] = umin_(pre[l][j - 1], o[l][j]);
+    }
+    bool deferred = false;
+    uint32_t st[16], vb[16];
+    u64 cont64[16];
+    uint32_t cont[16];
+    for (int l = 0; l < 16; ++l) {
+        uint32_t suf = o[l][15];
+        for (int j = 15; j >= 0; --j) { suf = umin_(suf, o[l][j]); omin[l][j] = umin_(suf, l + 1 < 16 ? pre[l + 1][j] : 0u); }
+    }
+    for (int l = 0; l < 16; ++l) {
+        u64 z = ~((u64)bad[l] | ((u64)at(bad, l + 1) << 16) | ((u64)at(bad, l + 2) << 32));
+        z |= z >> 1; z |= z >> 2; z |= z >> 4; z |= z >> 8;
+        z |= z >> 15;
+        vb[l] = 0xffffu & ~(uint32_t)z;
+    }
+    for (int l = 0; l < 16; ++l) {
+        const uint32_t prev = l ? omin[l - 1][15] : 0u, vprev = l ? vb[l - 1] : 0u;
+        st[l] = ~((vb[l] << 1) | (vprev >> 15));
+        for (int j = 0; j < 16; ++j) st[l] |= (omin[l][j] != (j ? omin[l][j - 1] : prev)) ? 1u << j : 0u;
+        st[l] &= vb[l];
+        cont[l] = vb[l] & ~st[l];
+    }
+    for (int l = 0; l < 16; ++l) {
+        cont64[l] = (u64)cont[l] | ((u64)at(cont, l + 1) << 16) | ((u64)at(cont, l + 2) << 32);
+        u64 x = cont64[l];
+        x &= x >> 1; x &= x >> 2; x &= x >> 4; x &= x >> 8;
+        x &= cont64[l] >> 16;
+        const bool too_long = ((uint32_t)(x >> 1) & st[l]) != 0u;
+        if (too_long) deferred = true;
+    }
+    if (deferred) return false;
+    for (int l = 0; l < 16; ++l) {
+        total += (uint64_t)__builtin_popcount(vb[l]);
+        const u64 brk64 = ~cont64[l];
+        const uint32_t c1 = at(c0, l + 1), c2 = at(c0, l + 2), c3 = at(c0, l + 3);
+        uint32_t sb = st[l];
+        while (sb) {
+            const uint32_t j = (uint32_t)ffs32(sb) - 1u;
+            sb &= sb - 1u;
+            const uint32_t len = (uint32_t)__builtin_ffsll((long long)(brk64 >> (j + 1u)));
+            const uint32_t sh = 2u * j;
+            auto align = [](uint32_t hi, uint32_t lo, uint32_t s_) -> uint32_t { return (uint32_t)((((u64)hi << 32) | lo) >> (s_ & 31u)); };
+            const uint32_t d0 = align(c1, c0[l], sh), d1 = align(c2, c1, sh), d2 = align(c3, c2, sh) & SKM_M30;
+            Item it;
+            it.x = ((u64)d1 << 32) | d0;
+            it.y = (u64)d2 | ((u64)(len - 1u) << SKM_NK_SHIFT) | ((u64)skm_part(omin[l][j]) << SKM_PART_SHIFT) | ((u64)run << SKM_RUN_SHIFT);
+            out.push_back(it);
+        }
+    }
+    return true;
+}
+
 static uint32_t code_of(char c)
 {
     switch (c | 0x20) { case 'a': return 0; case 'c': return 1; case 't': return 2; case 'g': return 3; default: return 4; }
@@ -260,7 +350,13 @@ int main(int argc, char **argv)
             s += "ACGTNACGTACGTTTTT"; // (whatever follows the read in the arena)
             std::vector<Item> items;
             uint64_t total = 0;
-            extract_read(s, mask, a, n, g, r & 1023, items, total);
+            static uint64_t n16 = 0, n16_deferred = 0;
+            if (k == 31 && n <= 256 && (r & 1)) { // the 16-positions-per-lane kernel's arithmetic, with its fall-back
+                ++n16;
+                if (!extract_read16(s, mask, a, n, g, r & 1023, items, total)) { ++n16_deferred; items.clear(); total = 0; extract_read(s, mask, a, n, g, r & 1023, items, total); }
+                if (r == n_reads - 1 || r == n_reads - 2) printf("extract16: %llu reads, %llu left to the general kernel\n", (u64)n16, (u64)n16_deferred);
+            } else
+                extract_read(s, mask, a, n, g, r & 1023, items, total);
             std::vector<u64> got, want;
             for (const Item &it : items) {
                 const uint32_t nk = skm_item_kmers(it.y), part = skm_item_part(it.y);
