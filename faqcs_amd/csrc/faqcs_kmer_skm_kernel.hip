@@ -858,24 +858,13 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
     __shared__ uint32_t s_nkeys, s_more;
     static_assert(NWV * 64 + LIMIT <= LS, "waves overshoot the limit by at most 64 keys each");
     const uint32_t p = blockIdx.x;
-    uint32_t n_sub[8], n_p = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { n_sub[j] = (uint32_t)j < G.split ? G.cur2[(size_t)p * G.split + j] : 0u; n_p += n_sub[j]; }
+    const uint32_t n_p = G.cur2[p]; // (split == 1)
     if (n_p == 0) return; // (block-uniform)
     const SkmGeom g = skm_geom(K31 ? 31u : k_arg);
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const Slice sc = slice_of(T, p);
-    const Item *src = reinterpret_cast<const Item *>(G.l2) + (size_t)p * G.split * G.cap2;
-    auto item_at = [&](uint32_t i) -> Item { // flat index over the sub-regions (a gap of cap2 - n_sub[j] items behind sub-region j)
-        if (G.split == 1u) return src[i];
-        uint32_t base = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (i < n_sub[j]) return src[base + i];
-            i -= n_sub[j]; base += G.cap2;
-        }
-        return make_ulonglong2(0ull, KS_NONE);
-    };
+    const Item *src = reinterpret_cast<const Item *>(G.l2) + (size_t)p * G.cap2;
+    auto item_at = [&](const uint32_t i) -> Item { return src[i]; }; // (one sub-region per partition in this mode: kg_init)
     Item nx = (uint32_t)tid < n_p ? item_at((uint32_t)tid) : make_ulonglong2(0ull, KS_NONE);
     auto clear = [&]() {
         for (int i = tid; i < LS; i += NT) { s_key[i] = ~0ull; s_cnt[i] = 0u; s_ep[i] = 0xffffffffu; }
@@ -967,30 +956,41 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
         __syncthreads();
         const uint32_t n_words = (total + 63u) >> 6;
         uint32_t r = (uint32_t)wave;
+        // this lane's occurrence of the 64 with indices 64 rr ..: (item, position inside it) from the start bits; the item is fetched
+        // a turn ahead of its use
+        uint32_t j_nx = 0;
+        Item iw_nx = make_ulonglong2(0ull, 0ull);
+        bool todo_nx = false;
+        auto locate = [&](const uint32_t rr) {
+            todo_nx = false;
+            if (rr >= n_words) return;
+            const uint32_t wlo = s_bits[2 * rr], whi = s_bits[2 * rr + 1]; // (the same address in every lane: a broadcast)
+            const u64 word = ((u64)whi << 32) | wlo;
+            todo_nx = 64u * rr + (uint32_t)lane < total;
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u)); // start bits below this lane
+            const uint32_t own = (uint32_t)((word >> lane) & 1ull);
+            const uint32_t idx = s_rank[rr] + before + own - 1u;
+            j_nx = 0;
+            if (!own) {
+                const u64 wl = word & lane_lt;
+                if (wl) j_nx = (uint32_t)lane - (63u - (uint32_t)__clzll((long long)wl));
+                else { // the item started in the word before (a run has at most 17 k-mers)
+                    const u64 prev = rr ? ((u64)s_bits[2 * rr - 1] << 32) | s_bits[2 * rr - 2] : 1ull; // (rr == 0: only lanes past the tile's last occurrence)
+                    j_nx = (uint32_t)lane + 1u + (uint32_t)__clzll((long long)prev);
+                }
+            }
+            if (todo_nx) iw_nx = src[i0 + idx];
+        };
+        locate(r);
 #pragma unroll 1
         for (;;) {
 #pragma unroll 1
             for (; r < n_words; r += NWV) {
                 if (uniu(*(volatile uint32_t *)&s_nkeys) >= LIMIT) break;
-                // this lane's occurrence: index o of the tile -> (item, position inside it)
-                const uint32_t wlo = uniu(s_bits[2 * r]), whi = uniu(s_bits[2 * r + 1]);
-                const u64 word = ((u64)whi << 32) | wlo;
-                const uint32_t o = 64u * r + (uint32_t)lane;
-                bool todo = o < total;
-                const uint32_t before = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u)); // start bits below this lane
-                const uint32_t own = (uint32_t)((word >> lane) & 1ull);
-                const uint32_t idx = uniu(s_rank[r]) + before + own - 1u;
-                uint32_t j = 0;
-                if (!own) {
-                    const u64 wl = word & lane_lt;
-                    if (wl) j = (uint32_t)lane - (63u - (uint32_t)__clzll((long long)wl));
-                    else { // the item started in the word before (a run has at most 17 k-mers)
-                        const u64 prev = r ? ((u64)s_bits[2 * r - 1] << 32) | s_bits[2 * r - 2] : 1ull; // (r == 0: only lanes past the tile's last occurrence)
-                        j = (uint32_t)lane + 1u + (uint32_t)__clzll((long long)prev);
-                    }
-                }
-                Item iw = make_ulonglong2(0ull, 0ull);
-                if (todo) iw = item_at(i0 + idx);
+                const Item iw = iw_nx;
+                const uint32_t j = j_nx;
+                bool todo = todo_nx;
+                locate(r + NWV);
                 const uint32_t ep = skm_item_run(iw.y);
                 u64 fwd, rc;
                 if (K31) { // bases j .. j + 30: a 62-bit window at bit 2 j (<= 32) of the 94-bit string
