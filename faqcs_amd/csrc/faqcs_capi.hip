@@ -152,6 +152,14 @@ struct faqcs_ctx {
         size_t points_final = 0;      // points whose (distinct, total) are final (resolved before the table restarted)
         std::vector<std::pair<hipEvent_t, hipEvent_t>> flush_ev; size_t flush_ev_used = 0;
     } kg;
+    // sender staging of the multi-GPU k-mer exchange (super-k-mer items of ONE submission, grouped by destination rank afterwards)
+    struct KmerSend {
+        KmerGroupDev dev{};
+        DevBuf<ulonglong2> l1, spill;
+        DevBuf<uint32_t> cur1, run_epoch, defer;
+        DevBuf<unsigned long long> scratch;
+        uint32_t *spill_n = nullptr;
+    } ks;
     // kernel timing
     std::vector<Timing> timings;
     size_t timing_used = 0;
@@ -446,6 +454,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     { void *kg_ptrs[] = {c->kg.dev.l1, c->kg.dev.l2, c->kg.dev.cur1, c->kg.dev.cur2, c->kg.dev.run_epoch, c->kg.dev.first_hist, c->kg.dev.tot_by_epoch};
       for (void *q : kg_ptrs) if (q) (void)hipFree(q);
       c->kg.defer.release();
+      c->ks.l1.release(); c->ks.spill.release(); c->ks.cur1.release(); c->ks.run_epoch.release(); c->ks.defer.release(); c->ks.scratch.release();
       for (auto &ev : c->kg.flush_ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); } }
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->compute) (void)hipStreamDestroy(c->compute);
@@ -484,7 +493,7 @@ static int kg_init(faqcs_ctx *c)
     // super-k-mers (every context that is not owner-partitioned): an item is 16 bytes and holds a run of up to w k-mers,
     // (w + 1) / 2 on average; the buffers are sized for three items per w + 1 occurrences.  Partitions are minimizer bins, which
     // vary more than hash bins do: twice the mean at level 2.  What overflows is counted occurrence by occurrence (exact, slow).
-    g.skm = !c->partitioned;
+    g.skm = !g.direct; // (FAQCS_KMER_DIRECT=1 on an owner-partitioned context: round 3's pairs and per-pair atomics)
     g.skm_w = c->prm.kmer > 15 ? c->prm.kmer - 14 : 1;
     if (g.skm) d.split = 1u; // (a partition's items in one piece: skm_combine fetches them by index; 256 blocks split 1/9 of round 4's items)
     const size_t item_bytes = g.skm ? 16 : 8;
@@ -690,21 +699,26 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
     return 0;
 }
 
-// owner side of the multi-GPU exchange: n (key, epoch) pairs (device memory) join the open group; epochs are absolute (the group's
-// run -> epoch table is the identity)
+// owner side of the multi-GPU exchange: n received items (device memory; their run fields hold absolute epochs) join the open group,
+// whose run -> epoch table is the identity; with more epochs than a group spans they are counted occurrence by occurrence
 static int kg_add_items(faqcs_ctx *c, const void *d_items, uint64_t n)
 {
     faqcs_ctx::KmerGroup &g = c->kg;
     if (int rc = kg_init(c)) return rc;
     if (int rc = kg_ensure_epochs(c, c->n_epochs)) return rc;
+    if (c->n_epochs > (uint32_t)KG_EPOCH_SPAN) {
+        HIPCHK(faqcs_launch_skm_items_atomic(g.dev, c->kt, c->prm.kmer, d_items, n, c->n_cu, c->compute));
+        return 0;
+    }
     const uint8_t *p = reinterpret_cast<const uint8_t *>(d_items);
     while (n) {
         const uint32_t rot = (uint32_t)((g.n_launches * 37u) % KG_FAN);
+        // (an item holds up to skm_w occurrences: the group's bound counts occurrences, the sub-regions items)
         auto fits = [&](uint64_t take) {
-            const uint32_t grid = faqcs_kmer_group_items_grid(take, c->n_cu);
+            const uint32_t grid = faqcs_skm_items_grid(take, c->n_cu);
             const uint64_t share = take / ((uint64_t)grid * KG_FAN) + take / ((uint64_t)grid * KG_FAN * 8) + 64;
             for (uint32_t i = 0; i < grid; ++i) if (g.sub_fill[(i + rot) % KG_FAN] + share > g.dev.cap1) return false;
-            return g.bound_items + take <= g.cap_items;
+            return g.bound_items + take * g.skm_w <= g.cap_items;
         };
         uint64_t take = n;
         if (!fits(take)) {
@@ -716,12 +730,12 @@ static int kg_add_items(faqcs_ctx *c, const void *d_items, uint64_t n)
             if (g.bound_items) { if (int rc = kg_flush(c)) return rc; continue; }
             take = 1;
         }
-        const uint32_t grid = faqcs_kmer_group_items_grid(take, c->n_cu);
+        const uint32_t grid = faqcs_skm_items_grid(take, c->n_cu);
         g.epoch_base = 0;
-        HIPCHK(faqcs_launch_kmer_group_items(g.dev, c->kt, rot, p, take, c->n_cu, c->compute));
+        HIPCHK(faqcs_launch_skm_items(g.dev, c->kt, c->prm.kmer, rot, p, take, c->n_cu, c->compute));
         ++g.n_launches;
         if (g.run_epoch.empty()) { g.run_epoch.resize(c->n_epochs); for (uint32_t j = 0; j < c->n_epochs; ++j) g.run_epoch[j] = j; }
-        g.bound_items += take;
+        g.bound_items += take * g.skm_w;
         for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += take / ((uint64_t)grid * KG_FAN) + take / ((uint64_t)grid * KG_FAN * 8) + 64;
         p += take * 16; n -= take;
     }
@@ -816,7 +830,64 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
             rs.used = true;
         }
     }
-    // ---- owner-partitioned k-mer mode: bucket this shard's (key, epoch) pairs by owner rank; the caller exchanges them
+    // ---- owner-partitioned k-mer mode: this shard's runs of k-mers (super-k-mer items) grouped by owner rank; the caller exchanges them
+    if (c->partitioned && !c->kg.direct) {
+        if (!c->kmer_active || n == 0) { c->seg_epoch.clear(); return 0; }
+        if (c->seg_epoch.size() != n_seg) return fail(FAQCS_E_INVAL, "faqcs_submit: faqcs_kmer_set_epochs() must give one epoch per segment of the submission");
+        faqcs_ctx::KmerSend &ks = c->ks;
+        const uint32_t w = p.kmer > 15 ? p.kmer - 14 : 1;
+        const uint64_t occ = host_off ? (uint64_t)(host_off[n] - host_off[0]) : (uint64_t)n * (max_len >= p.kmer ? max_len - p.kmer + 1 : 1);
+        const uint64_t ib = (w == 1 ? occ : occ * 3 / (w + 1)) + 2ull * n + 64; // items this submission can be expected to make at most
+        // staging: a sub-region per (bucket, writing block) of twice its even share; whatever does not fit spills (room for all of it)
+        const uint32_t cap1 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(KG_MIN_CAP, 2 * ib / ((uint64_t)KG_FAN * KG_FAN) + 64), 0x7fffffffu);
+        const uint32_t spill_cap = (uint32_t)std::min<uint64_t>(ib, 0x7fffffffu);
+        if ((size_t)KG_FAN * KG_FAN * cap1 > ks.l1.cap || spill_cap > ks.spill.cap) HIPCHK(hipStreamSynchronize(c->compute));
+        HIPCHK(ks.l1.reserve((size_t)KG_FAN * KG_FAN * cap1));
+        HIPCHK(ks.spill.reserve(spill_cap));
+        HIPCHK(ks.cur1.reserve((size_t)KG_FAN * KG_FAN + 64));
+        HIPCHK(ks.run_epoch.reserve(1u << SKM_RUN_BITS));
+        HIPCHK(ks.scratch.reserve((size_t)KG_FAN * KG_FAN + 128));
+        HIPCHK(ks.defer.reserve((size_t)n + 1));
+        ks.spill_n = ks.cur1.p + (size_t)KG_FAN * KG_FAN;
+        KmerGroupDev &d = ks.dev;
+        d = KmerGroupDev{};
+        d.l1 = reinterpret_cast<unsigned long long *>(ks.l1.p); d.cur1 = ks.cur1.p; d.run_epoch = ks.run_epoch.p; d.cap1 = cap1; d.split = 1;
+        d.spill = reinterpret_cast<unsigned long long *>(ks.spill.p); d.spill_n = ks.spill_n; d.spill_cap = spill_cap;
+        HIPCHK(hipMemsetAsync(ks.cur1.p, 0, ((size_t)KG_FAN * KG_FAN + 64) * 4, c->compute));
+        if (tm) { HIPCHK(hipEventRecord(tm->k0, c->compute)); tm->kmer = true; }
+        // one launch per run of segments with the same epoch; an item's run field (13 bits) indexes the submission's run -> epoch table
+        std::vector<uint32_t> &run_epoch = c->kg.upload[c->kg.n_flushes++ & 1];
+        run_epoch.clear();
+        static const bool no16 = [] { const char *e = getenv("FAQCS_KMER_EXTRACT16"); return e && atoi(e) == 0; }();
+        for (uint32_t s = 0; s < n_seg;) {
+            uint32_t e = s + 1;
+            while (e < n_seg && c->seg_epoch[e] == c->seg_epoch[s]) ++e;
+            if (c->seg_epoch[s] != 0xffffffffu && seg[e] > seg[s]) {
+                if (run_epoch.size() >= (1u << SKM_RUN_BITS)) return fail(FAQCS_E_INVAL, "faqcs_submit: more than 8192 epochs in one submission");
+                const uint32_t run = (uint32_t)run_epoch.size(), rot = (run * 37u) % KG_FAN;
+                if (p.kmer == 31 && max_len <= 256 && !no16) {
+                    HIPCHK(hipMemsetAsync(ks.defer.p, 0, 4, c->compute));
+                    HIPCHK(faqcs_launch_skm_extract16(c->dp, d, c->kt, run, rot, c->seg_epoch[s], d_seq, d_qual, d_off, seg[s], seg[e], d_res,
+                                                      ks.defer.p + 1, ks.defer.p, c->n_cu, c->compute));
+                    HIPCHK(faqcs_launch_skm_extract(c->dp, p.kmer, d, c->kt, run, rot, c->seg_epoch[s], d_seq, d_qual, d_off, seg[s], seg[e], d_res,
+                                                    c->n_cu, c->compute, ks.defer.p + 1, ks.defer.p, faqcs_skm_grid16(seg[e] - seg[s], c->n_cu)));
+                } else
+                    HIPCHK(faqcs_launch_skm_extract(c->dp, p.kmer, d, c->kt, run, rot, c->seg_epoch[s], d_seq, d_qual, d_off, seg[s], seg[e], d_res,
+                                                    c->n_cu, c->compute));
+                run_epoch.push_back(c->seg_epoch[s]);
+            }
+            s = e;
+        }
+        if (!run_epoch.empty()) HIPCHK(hipMemcpyAsync(ks.run_epoch.p, run_epoch.data(), run_epoch.size() * 4, hipMemcpyHostToDevice, c->compute));
+        d.n_runs = (uint32_t)run_epoch.size(); d.epoch_base = 0;
+        if ((size_t)std::min<uint64_t>((uint64_t)KG_FAN * KG_FAN * cap1 + spill_cap, occ + 1) > c->ob_items.cap) HIPCHK(hipStreamSynchronize(c->compute));
+        HIPCHK(c->ob_items.reserve((size_t)std::min<uint64_t>((uint64_t)KG_FAN * KG_FAN * cap1 + spill_cap, occ + 1)));
+        HIPCHK(faqcs_launch_skm_outbox(d, c->part_world, c->d_ob, ks.scratch.p, c->ob_items.p, c->compute));
+        if (tm) HIPCHK(hipEventRecord(tm->k1, c->compute));
+        c->seg_epoch.clear();
+        return 0;
+    }
+    // (FAQCS_KMER_DIRECT=1: round 3's form -- (key, epoch) pairs bucketed by owner in two passes, one atomic insert per pair on the owner)
     if (c->partitioned) {
         if (!c->kmer_active || n == 0) { c->seg_epoch.clear(); return 0; }
         if (c->seg_epoch.size() != n_seg) return fail(FAQCS_E_INVAL, "faqcs_submit: faqcs_kmer_set_epochs() must give one epoch per segment of the submission");
@@ -1334,7 +1405,10 @@ extern "C" int faqcs_kmer_partition(faqcs_ctx *c, uint32_t rank, uint32_t world,
     c->partitioned = true; c->part_rank = rank; c->part_world = world; c->n_epochs = n_epochs;
     // the pairs this rank receives are combined before they reach its table like a single GPU's own occurrences (a group's items carry
     // their epoch in 10 bits: up to KG_EPOCH_SPAN epochs; more, or FAQCS_KMER_DIRECT=1: one atomic insert per pair, kmer_insert_items)
-    c->kg.owner = !c->kg.direct && n_epochs <= (uint32_t)KG_EPOCH_SPAN;
+    // what this rank receives -- super-k-mer items whose run field holds the absolute epoch, 13 bits -- joins the group buffers like a single
+    // GPU's own runs (up to KG_EPOCH_SPAN epochs), or is counted occurrence by occurrence (more).  FAQCS_KMER_DIRECT=1: round 3's pairs.
+    if (!c->kg.direct && n_epochs > (1u << SKM_RUN_BITS) - 1u) return fail(FAQCS_E_INVAL, "faqcs_kmer_partition: at most 8191 sampling epochs");
+    c->kg.owner = !c->kg.direct;
     return 0;
 }
 
@@ -1371,13 +1445,27 @@ extern "C" int faqcs_kmer_outbox_host(faqcs_ctx *c, uint64_t *keys, uint64_t cap
     HIPCHK(hipStreamSynchronize(c->compute));
     std::vector<unsigned long long> h(c->part_world);
     HIPCHK(hipMemcpy(h.data(), c->d_ob, (size_t)c->part_world * 8, hipMemcpyDeviceToHost));
-    uint64_t total = 0;
-    for (uint32_t d = 0; d < c->part_world; ++d) total += h[d];
+    uint64_t n_items = 0;
+    for (uint32_t d = 0; d < c->part_world; ++d) n_items += h[d];
+    // the outbox holds runs of k-mers (faqcs_skm.h): the number of occurrences is the sum of their lengths, counted on the host
+    uint64_t total = n_items;
+    if (!c->kg.direct && n_items) {
+        std::vector<unsigned long long> w1((size_t)n_items * 2);
+        HIPCHK(hipMemcpy(w1.data(), c->ob_items.p, (size_t)n_items * 16, hipMemcpyDeviceToHost));
+        total = 0;
+        for (uint64_t i = 0; i < n_items; ++i) total += skm_item_kmers(w1[2 * i + 1]);
+    }
     *n_keys = total;
     if (!keys || cap < total || total == 0) return 0;
-    std::vector<unsigned long long> items((size_t)total * 2);
-    HIPCHK(hipMemcpy(items.data(), c->ob_items.p, (size_t)total * 16, hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < total; ++i) keys[i] = items[2 * i];
+    std::vector<unsigned long long> items((size_t)n_items * 2);
+    HIPCHK(hipMemcpy(items.data(), c->ob_items.p, (size_t)n_items * 16, hipMemcpyDeviceToHost));
+    if (c->kg.direct) { for (uint64_t i = 0; i < n_items; ++i) keys[i] = items[2 * i]; return 0; }
+    const SkmGeom geo = skm_geom(c->prm.kmer);
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n_items; ++i) {
+        SkmRoll r = skm_roll_begin(items[2 * i], items[2 * i + 1], geo);
+        for (uint32_t j = 0, nk = skm_item_kmers(items[2 * i + 1]); j < nk; ++j) { keys[at++] = skm_roll_key(r); skm_roll_next(r, geo); }
+    }
     return 0;
 }
 

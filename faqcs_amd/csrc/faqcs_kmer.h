@@ -77,6 +77,11 @@ struct KmerGroupDev {
     unsigned long long *first_hist;   // [n_epochs] keys by first epoch
     unsigned long long *tot_by_epoch; // [n_epochs] occurrences by epoch
     uint32_t n_epochs;
+    // sender staging of the multi-GPU exchange (super-k-mer items only): what does not fit a level-1 sub-region is appended here instead
+    // of being counted into the table -- the keys belong to other ranks; first_hist / tot_by_epoch are null in this mode
+    unsigned long long *spill;        // [spill_cap] 16-byte items
+    uint32_t *spill_n;                // items appended (may run past spill_cap: the surplus is dropped and bit 1 of the table's overflow flag set)
+    uint32_t spill_cap;
 };
 
 // launchers
@@ -124,8 +129,13 @@ hipError_t faqcs_launch_skm_reset(const KmerGroupDev &G, hipStream_t st);
 uint32_t faqcs_skm_items_grid(unsigned long long n_items, int n_cu);
 hipError_t faqcs_launch_skm_items(const KmerGroupDev &G, const KmerTable &T, uint32_t k, uint32_t rot, const void *items, unsigned long long n_items,
                                   int n_cu, hipStream_t st);
+// sender side: dest_count[world] = items per destination rank (bucket b belongs to rank (b * world) >> 8), out = the items grouped by
+// destination, run fields replaced by absolute epochs; scratch: region_offset[65536 + 2 * 64] u64
 hipError_t faqcs_launch_skm_outbox(const KmerGroupDev &G, uint32_t world, unsigned long long *dest_count, unsigned long long *region_offset,
                                    void *out, hipStream_t st);
+// owner side when the epochs do not fit a group (more than KG_EPOCH_SPAN): every occurrence of the received items by atomics
+hipError_t faqcs_launch_skm_items_atomic(const KmerGroupDev &G, const KmerTable &T, uint32_t k, const void *items, unsigned long long n_items,
+                                         int n_cu, hipStream_t st);
 
 #ifdef __HIPCC__
 __device__ __forceinline__ uint64_t kmer_mix(uint64_t x)

@@ -243,7 +243,12 @@ __global__ __launch_bounds__(NW * 64) void skm_extract(
     const uint32_t n_waves = gridDim.x * NW;
     const bool g2n = !P.qc_only && P.replace_q > 0;
     auto write = [&](const uint32_t b, const uint32_t pos, const Item it) { l1_region(G, b, sub)[pos] = it; };
-    auto slow = [&](const uint32_t, const Item it) { skm_insert_item_atomic(T, it, epoch, g, G.first_hist, G.n_epochs); };
+    auto slow = [&](const uint32_t, const Item it) { // the item does not fit its sub-region
+        if (G.spill) { // sender staging: it still has to travel
+            const uint32_t at = atomicAdd(G.spill_n, 1u);
+            if (at < G.spill_cap) reinterpret_cast<Item *>(G.spill)[at] = it; else atomicOr(&T.stats[2], 2ull);
+        } else skm_insert_item_atomic(T, it, epoch, g, G.first_hist, G.n_epochs);
+    };
     __syncthreads();
 
     struct Hdr { uint32_t o; int a, n; }; // kept window [a, a + n) of the read at byte o; n == 0: nothing to count
@@ -485,8 +490,10 @@ __global__ __launch_bounds__(NW * 64) void skm_extract(
     if (lane == 0 && wt) atomicAdd(s_total, wt);                // (a block sees < 2^32)
     __syncthreads();
     if (tid == 0 && s_total[0]) {
-        hist_add(G.tot_by_epoch, epoch, G.n_epochs, (long long)s_total[0]);
-        atomicAdd(&T.stats[1], (u64)s_total[0]);
+        if (G.tot_by_epoch) { // (sender staging of the exchange: the owner counts what it receives)
+            hist_add(G.tot_by_epoch, epoch, G.n_epochs, (long long)s_total[0]);
+            atomicAdd(&T.stats[1], (u64)s_total[0]);
+        }
     }
 }
 
@@ -520,7 +527,12 @@ __global__ __launch_bounds__(NW * 64) void skm_extract16(
     const uint32_t stride = gridDim.x * NW * 4u;
     const bool g2n = !P.qc_only && P.replace_q > 0;
     auto write = [&](const uint32_t b, const uint32_t pos, const Item it) { l1_region(G, b, sub)[pos] = it; };
-    auto slow = [&](const uint32_t, const Item it) { skm_insert_item_atomic(T, it, epoch, g, G.first_hist, G.n_epochs); };
+    auto slow = [&](const uint32_t, const Item it) { // the item does not fit its sub-region
+        if (G.spill) { // sender staging: it still has to travel
+            const uint32_t at = atomicAdd(G.spill_n, 1u);
+            if (at < G.spill_cap) reinterpret_cast<Item *>(G.spill)[at] = it; else atomicOr(&T.stats[2], 2ull);
+        } else skm_insert_item_atomic(T, it, epoch, g, G.first_hist, G.n_epochs);
+    };
     __syncthreads();
 
     struct Hdr { uint32_t o; int a, n; }; // kept window [a, a + n) of the row's read at byte o; n == 0: nothing to count
@@ -700,8 +712,10 @@ __global__ __launch_bounds__(NW * 64) void skm_extract16(
     if (lane == 0 && wt) atomicAdd(s_total, wt);
     __syncthreads();
     if (tid == 0 && s_total[0]) {
-        hist_add(G.tot_by_epoch, epoch, G.n_epochs, (long long)s_total[0]);
-        atomicAdd(&T.stats[1], (u64)s_total[0]);
+        if (G.tot_by_epoch) { // (sender staging of the exchange: the owner counts what it receives)
+            hist_add(G.tot_by_epoch, epoch, G.n_epochs, (long long)s_total[0]);
+            atomicAdd(&T.stats[1], (u64)s_total[0]);
+        }
     }
 }
 
@@ -842,7 +856,7 @@ __global__ __launch_bounds__(NW * 64) void skm_split(const KmerGroupDev G, const
 // the partition's slice = the top bits of h too, so LDS order is table order.  When the LDS table is nearly full every wave stops
 // where it is, the table is written out -- ONE update per distinct key -- and cleared, and the waves go on.
 template <int NT, bool K31>
-__global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const KmerTable T, const uint32_t k_arg)
+__global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const KmerTable T, const uint32_t k_arg, const uint32_t diag)
 {
     constexpr int LS = 4096, NWV = NT / 64;
     constexpr uint32_t LMASK = LS - 1, LIMIT = LS - 1280; // stop adding keys at 69 % (every wave may add 64 more before it sees the count)
@@ -877,6 +891,7 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
     // ONE table update per key of the LDS table, none of them a device-scope atomic: the slice belongs to this workgroup for the
     // length of the launch, an empty slot is claimed through the workgroup's LDS bitmap, and no other thread holds this key.
     auto write_out = [&]() {
+        if (diag & 1u) return; // (FAQCS_SKM_DIAG: what the table updates cost; wrong results)
         constexpr int KPT = LS / NT, KB = 2; // keys per thread, looked up KB at a time
         const u64 win = sc.mask + 1 < (u64)KS_PROBE_MAX ? sc.mask + 1 : (u64)KS_PROBE_MAX;
         static_assert(LS % NT == 0 && KPT % KB == 0, "keys per thread");
@@ -1006,6 +1021,7 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
                     rc = (skm_rev2_64(fwd) >> (64u - 2u * g.k)) ^ (0xAAAAAAAAAAAAAAAAull & g.kmask2);
                 }
                 const u64 h = skm_mix62(fwd < rc ? fwd : rc);
+                if (diag & 2u) todo = false; // (FAQCS_SKM_DIAG: what the LDS table costs; wrong results)
                 // count h in the LDS table: a wave-uniform loop that finds the key's slot (lanes drop out as they find their key or claim
                 // an empty slot -- the table is never full, see LIMIT), then ONE count and epoch update per lane behind it
                 uint32_t s = (uint32_t)(h >> 50), sf = 0;
@@ -1058,38 +1074,72 @@ __global__ void skm_group_reset(const KmerGroupDev G)
 
 // ---- sender side of the multi-GPU exchange -----------------------------------------------------------------------------------
 // Bucket b (the top 8 bits of a partition) belongs to rank (b * world) >> 8, so the level-1 buffers ARE grouped by destination:
-// count[d] = items of d's buckets, then a copy of every (bucket, sub-region) to its place behind an exclusive scan.  The run
-// field of an item becomes its absolute epoch.
-__global__ __launch_bounds__(256) void skm_outbox_count(const KmerGroupDev G, const uint32_t world, u64 *dest_count, u64 *region_offset)
+// count[d] = items of d's buckets + d's share of the spill, then a copy of every (bucket, sub-region) to its place behind an
+// exclusive scan; the spilled items of a destination follow its regions.  The run field of an item becomes its absolute epoch.
+// scratch (u64): region_offset[65536], then spill_base[64], spill_cursor[64]
+__global__ __launch_bounds__(256) void skm_outbox_count(const KmerGroupDev G, const uint32_t world, u64 *dest_count, u64 *scratch)
 {
-    // one block; region_offset[b * 256 + s] = items in front of (b, s) in the outbox; dest_count[d] = items for rank d
     __shared__ u64 s_sum[256];
+    __shared__ uint32_t s_spill[64];
+    u64 *region_offset = scratch, *spill_base = scratch + KG_FAN * KG_FAN, *spill_cursor = spill_base + 64;
     const uint32_t b = threadIdx.x;
+    if (b < 64) s_spill[b] = 0u;
+    __syncthreads();
+    const uint32_t n_spill = G.spill ? (*G.spill_n < G.spill_cap ? *G.spill_n : G.spill_cap) : 0u;
+    for (uint32_t i = b; i < n_spill; i += 256) atomicAdd(&s_spill[((skm_item_part(reinterpret_cast<const Item *>(G.spill)[i].y) >> 8) * world) >> 8], 1u);
     u64 n = 0;
     for (uint32_t s = 0; s < (uint32_t)KG_FAN; ++s) n += G.cur1[s * KG_FAN + b];
     s_sum[b] = n;
     __syncthreads();
-    if (b == 0) {
+    if (b == 0) { // 256 buckets: a serial exclusive scan, the spill of a destination behind its last bucket
         u64 run_ = 0;
-        for (uint32_t i = 0; i < 256; ++i) { const u64 v = s_sum[i]; s_sum[i] = run_; run_ += v; }
+        uint32_t d_prev = 0;
+        for (uint32_t i = 0; i < 256; ++i) {
+            const uint32_t d = (i * world) >> 8;
+            if (d != d_prev) { spill_base[d_prev] = run_; run_ += s_spill[d_prev]; d_prev = d; }
+            const u64 v = s_sum[i]; s_sum[i] = run_; run_ += v;
+        }
+        spill_base[d_prev] = run_;
     }
+    if (b < 64) { spill_cursor[b] = 0; if (b < world) dest_count[b] = s_spill[b]; }
     __syncthreads();
     u64 o = s_sum[b];
     for (uint32_t s = 0; s < (uint32_t)KG_FAN; ++s) { region_offset[b * KG_FAN + s] = o; o += G.cur1[s * KG_FAN + b]; }
-    if (b < world) dest_count[b] = 0;
+    __threadfence();
     __syncthreads();
     atomicAdd(&dest_count[(b * world) >> 8], n);
 }
-__global__ __launch_bounds__(256) void skm_outbox_copy(const KmerGroupDev G, const u64 *__restrict__ region_offset, Item *__restrict__ out)
+__global__ __launch_bounds__(256) void skm_outbox_copy(const KmerGroupDev G, const uint32_t world, u64 *__restrict__ scratch, Item *__restrict__ out)
 {
-    const uint32_t b = blockIdx.x >> 8, s = blockIdx.x & 255u;
-    const uint32_t n = G.cur1[s * KG_FAN + b];
-    const Item *src = l1_region(G, b, s);
-    Item *dst = out + region_offset[b * KG_FAN + s];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        Item it = src[i];
-        it.y = (it.y & ~SKM_RUN_MASK) | ((u64)(G.epoch_base + G.run_epoch[skm_item_run(it.y)]) << SKM_RUN_SHIFT);
-        dst[i] = it;
+    const u64 *region_offset = scratch;
+    u64 *spill_base = scratch + KG_FAN * KG_FAN, *spill_cursor = spill_base + 64;
+    auto with_epoch = [&](Item it) { it.y = (it.y & ~SKM_RUN_MASK) | ((u64)(G.epoch_base + G.run_epoch[skm_item_run(it.y)]) << SKM_RUN_SHIFT); return it; };
+    if (blockIdx.x < (uint32_t)KG_FAN * KG_FAN) {
+        const uint32_t b = blockIdx.x >> 8, s = blockIdx.x & 255u;
+        const uint32_t n = G.cur1[s * KG_FAN + b];
+        const Item *src = l1_region(G, b, s);
+        Item *dst = out + region_offset[b * KG_FAN + s];
+        for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = with_epoch(src[i]);
+        return;
+    }
+    // the blocks behind: the spill
+    const uint32_t n_spill = G.spill ? (*G.spill_n < G.spill_cap ? *G.spill_n : G.spill_cap) : 0u;
+    for (uint32_t i = (blockIdx.x - KG_FAN * KG_FAN) * 256 + threadIdx.x; i < n_spill; i += 16 * 256) {
+        const Item it = reinterpret_cast<const Item *>(G.spill)[i];
+        const uint32_t d = ((skm_item_part(it.y) >> 8) * world) >> 8;
+        out[spill_base[d] + atomicAdd(&spill_cursor[d], 1ull)] = with_epoch(it);
+    }
+}
+
+// ---- owner side when the epochs do not fit a group: every occurrence of the received items by atomics --------------------------
+__global__ __launch_bounds__(256) void skm_items_atomic(const KmerGroupDev G, const KmerTable T, const uint32_t k, const Item *__restrict__ items, const u64 n_items)
+{
+    const SkmGeom g = skm_geom(k);
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (u64)gridDim.x * 256) {
+        const Item it = items[i];
+        const uint32_t e = skm_item_run(it.y);
+        skm_insert_item_atomic(T, it, e, g, G.first_hist, G.n_epochs);
+        hist_add(G.tot_by_epoch, e, G.n_epochs, (long long)skm_item_kmers(it.y));
     }
 }
 
@@ -1183,8 +1233,9 @@ hipError_t faqcs_launch_skm_flush(const KmerGroupDev &G, const KmerTable &T, uin
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&skm_split<KS_NW>), lds, done);
     if (e != hipSuccess) return e;
     if (stages & 1u) hipLaunchKernelGGL((skm_split<KS_NW>), dim3(KG_FAN * G.split), dim3(KS_NW * 64), lds, st, G, T, k);
-    if ((stages & 2u) && k == 31) hipLaunchKernelGGL((skm_combine<1024, true>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k);
-    else if (stages & 2u) hipLaunchKernelGGL((skm_combine<1024, false>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k);
+    static const uint32_t diag = [] { const char *e = getenv("FAQCS_SKM_DIAG"); return e ? (uint32_t)atoi(e) : 0u; }(); // (diagnostics: 1 no table updates, 2 no LDS counting)
+    if ((stages & 2u) && k == 31) hipLaunchKernelGGL((skm_combine<1024, true>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k, diag);
+    else if (stages & 2u) hipLaunchKernelGGL((skm_combine<1024, false>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k, diag);
     if (stages & 4u) hipLaunchKernelGGL(skm_group_reset, dim3(KG_FAN * KG_FAN / 256), dim3(256), 0, st, G);
     return hipGetLastError();
 }
@@ -1195,11 +1246,20 @@ hipError_t faqcs_launch_skm_reset(const KmerGroupDev &G, hipStream_t st)
     return hipGetLastError();
 }
 
-// sender side: counts per destination rank (dest_count[world]) and the packed items (out: room for every item of the open group)
-hipError_t faqcs_launch_skm_outbox(const KmerGroupDev &G, uint32_t world, unsigned long long *dest_count, unsigned long long *region_offset,
+hipError_t faqcs_launch_skm_outbox(const KmerGroupDev &G, uint32_t world, unsigned long long *dest_count, unsigned long long *scratch,
                                    void *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(skm_outbox_count, dim3(1), dim3(256), 0, st, G, world, dest_count, region_offset);
-    hipLaunchKernelGGL(skm_outbox_copy, dim3(KG_FAN * KG_FAN), dim3(256), 0, st, G, region_offset, reinterpret_cast<Item *>(out));
+    hipLaunchKernelGGL(skm_outbox_count, dim3(1), dim3(256), 0, st, G, world, dest_count, scratch);
+    hipLaunchKernelGGL(skm_outbox_copy, dim3(KG_FAN * KG_FAN + 16), dim3(256), 0, st, G, world, scratch, reinterpret_cast<Item *>(out));
+    return hipGetLastError();
+}
+
+hipError_t faqcs_launch_skm_items_atomic(const KmerGroupDev &G, const KmerTable &T, uint32_t k, const void *items, unsigned long long n_items,
+                                         int n_cu, hipStream_t st)
+{
+    if (!n_items) return hipSuccess;
+    unsigned long long blocks = (n_items + 255) / 256;
+    if (blocks > (unsigned long long)n_cu * 16ull) blocks = (unsigned long long)n_cu * 16ull;
+    hipLaunchKernelGGL(skm_items_atomic, dim3((uint32_t)blocks), dim3(256), 0, st, G, T, k, reinterpret_cast<const Item *>(items), n_items);
     return hipGetLastError();
 }
