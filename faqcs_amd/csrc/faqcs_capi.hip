@@ -130,7 +130,7 @@ struct faqcs_ctx {
     unsigned long long *d_snaps = nullptr; // [snap_cap][2]
     size_t snap_cap = 0, n_snaps = 0;
     std::map<uint64_t, uint64_t> kmer_hist; // PlotInfo::kmer_frequency_histogram
-    // combine-before-insert k-mer counting (every context that is not owner-partitioned; faqcs_kmer_group_kernel.hip): the
+    // combine-before-insert k-mer counting (every context that is not owner-partitioned; faqcs_kmer_skm_kernel.hip): the
     // k-mers of a run of segments are appended to bucket buffers at submission time and reach the table group by group
     struct KmerGroup {
         bool ready = false;
@@ -409,7 +409,7 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
     if (p->kmer_rarefaction) {
         uint64_t slots = p->kmer_table_slots ? p->kmer_table_slots : (1ull << 28);
         uint64_t pow2 = 1; while (pow2 < slots) pow2 <<= 1;
-        // every partition of the combine-before-insert path owns a slice of the table (faqcs_kmer_group_kernel.hip)
+        // every partition of the combine-before-insert path owns a slice of the table (faqcs_kmer_skm_kernel.hip)
         if (pow2 < (uint64_t)KG_SLICE_MIN << 16) pow2 = (uint64_t)KG_SLICE_MIN << 16;
         if (pow2 > (uint64_t)KG_SLICE_MAX << 16) return fail(FAQCS_E_INVAL, "faqcs_create: kmer_table_slots above 2^32");
         c->kt.mask = pow2 - 1;
@@ -473,7 +473,7 @@ extern "C" int faqcs_set_quality(faqcs_ctx *c, int quality)
 
 
 // ---------------------------------------------------------------------------------------------------------
-// combine-before-insert k-mer counting: host side (kernels: faqcs_kmer_group_kernel.hip)
+// combine-before-insert k-mer counting: host side (kernels: faqcs_kmer_skm_kernel.hip)
 // ---------------------------------------------------------------------------------------------------------
 static int kg_init(faqcs_ctx *c)
 {
@@ -508,7 +508,7 @@ static int kg_init(faqcs_ctx *c)
     HIPCHK(hipMalloc((void **)&d.cur1, (size_t)KG_FAN * KG_FAN * 4));
     HIPCHK(hipMalloc((void **)&d.cur2, (size_t)KG_FAN * KG_FAN * d.split * 4));
     HIPCHK(hipMalloc((void **)&d.run_epoch, (size_t)KG_MAX_RUNS * 4));
-    HIPCHK(faqcs_launch_kmer_group_reset(d, c->compute));
+    HIPCHK(faqcs_launch_skm_reset(d, c->compute));
     g.sub_fill.assign(KG_FAN, 0);
     g.ready = true;
     return 0;
@@ -627,8 +627,7 @@ static int kg_flush(faqcs_ctx *c, bool timed = false)
     g.dev.n_runs = (uint32_t)up.size(); g.dev.epoch_base = g.epoch_base;
     static const bool debug = [] { const char *e = getenv("FAQCS_KMER_DEBUG"); return e && atoi(e) != 0; }();
     if (g.skm && debug) { if (int rc = kg_debug_flush(c)) return rc; }
-    else if (g.skm) HIPCHK(faqcs_launch_skm_flush(g.dev, c->kt, c->prm.kmer, c->compute));
-    else HIPCHK(faqcs_launch_kmer_group_flush(g.dev, c->kt, c->compute));
+    else HIPCHK(faqcs_launch_skm_flush(g.dev, c->kt, c->prm.kmer, c->compute));
     if (timed) HIPCHK(hipEventRecord(ev.second, c->compute));
     g.run_epoch.clear(); g.bound_items = 0;
     std::fill(g.sub_fill.begin(), g.sub_fill.end(), 0);
@@ -657,7 +656,7 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
         auto items_of = [&](uint32_t take, uint64_t bound) { return !g.skm || g.skm_w == 1 ? bound : bound * 3 / (g.skm_w + 1) + 2ull * take; };
         static const bool no16g = [] { const char *e = getenv("FAQCS_KMER_EXTRACT16"); return e && atoi(e) == 0; }();
         const bool x16 = g.skm && c->prm.kmer == 31 && max_len <= 256 && !no16g;
-        auto grid_of = [&](uint32_t take) { return x16 ? faqcs_skm_grid16(take, c->n_cu) : g.skm ? faqcs_skm_grid(take, c->n_cu) : faqcs_kmer_group_grid(take, c->n_cu); };
+        auto grid_of = [&](uint32_t take) { return x16 ? faqcs_skm_grid16(take, c->n_cu) : faqcs_skm_grid(take, c->n_cu); };
         auto fits = [&](uint32_t take, uint64_t bound) {
             const uint32_t grid = grid_of(take);
             const uint64_t ib = items_of(take, bound);
@@ -687,10 +686,8 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
                                               g.defer.p + 1, g.defer.p, c->n_cu, c->compute));
             HIPCHK(faqcs_launch_skm_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off, r0, r0 + take, d_res,
                                             c->n_cu, c->compute, g.defer.p + 1, g.defer.p, grid));
-        } else if (g.skm) HIPCHK(faqcs_launch_skm_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
-                                                   r0, r0 + take, d_res, c->n_cu, c->compute));
-        else HIPCHK(faqcs_launch_kmer_group_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
-                                                    r0, r0 + take, d_res, max_len, c->n_cu, c->compute));
+        } else HIPCHK(faqcs_launch_skm_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
+                                              r0, r0 + take, d_res, c->n_cu, c->compute));
         g.run_epoch.push_back(epoch - g.epoch_base);
         g.bound_items += bound;
         for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += ib / ((uint64_t)grid * KG_FAN) + ib / ((uint64_t)grid * KG_FAN * 8) + 64;

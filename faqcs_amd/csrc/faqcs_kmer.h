@@ -1,5 +1,5 @@
 // faqcs_kmer.h -- structures and device helpers shared by the k-mer kernels (faqcs_kmer_kernel.hip: the table, the
-// owner-partitioned exchange; faqcs_kmer_group_kernel.hip: combine-before-insert) and the host side (faqcs_capi.hip).
+// per-occurrence diagnostic path; faqcs_kmer_skm_kernel.hip: super-k-mers, combine-before-insert) and the host side (faqcs_capi.hip).
 //
 // Replaces update_kmer() (trim.cpp:887-931) and the std::unordered_map<size_t,size_t> tables (trim.cpp:82,133-135).
 #pragma once
@@ -101,17 +101,6 @@ hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T,
 hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
                                        unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, bool reset, int n_cu,
                                        hipStream_t st);
-// combine-before-insert: one extraction launch per run (appends to the level-1 buckets, snapshots the cursors into
-// bounds[run]), then per group: level-2 scatter, combine + insert, cursor reset
-hipError_t faqcs_launch_kmer_group_extract(const DevParams &P, uint32_t k, const KmerGroupDev &G, const KmerTable &T, uint32_t run, uint32_t rot,
-                                           uint32_t epoch, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
-                                           uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, uint32_t max_len, int n_cu, hipStream_t st);
-hipError_t faqcs_launch_kmer_group_flush(const KmerGroupDev &G, const KmerTable &T, hipStream_t st);
-uint32_t faqcs_kmer_group_grid(uint32_t n_reads, int n_cu);
-uint32_t faqcs_kmer_group_items_grid(unsigned long long n_items, int n_cu);
-hipError_t faqcs_launch_kmer_group_items(const KmerGroupDev &G, const KmerTable &T, uint32_t rot, const void *items, unsigned long long n_items,
-                                         int n_cu, hipStream_t st);
-hipError_t faqcs_launch_kmer_group_reset(const KmerGroupDev &G, hipStream_t st);
 // super-k-mers (round 5; faqcs_kmer_skm_kernel.hip, faqcs_skm.h): the same group buffers with 16-byte items, a run of up to 17
 // consecutive k-mers each; l1 / l2 / cap1 / cap2 of KmerGroupDev count 16-byte items in this mode
 uint32_t faqcs_skm_grid(uint32_t n_reads, int n_cu);
@@ -196,40 +185,6 @@ __device__ __forceinline__ bool kmer_chunk_key(const uint32_t b, const int lane,
     const uint32_t r0 = __brev(~w0 & kmask) >> (32 - k), r1 = __brev(w1) >> (32 - k);
     const uint64_t fwd = ((uint64_t)w1 << 32) | w0, rc = ((uint64_t)r1 << 32) | r0;
     key = fwd < rc ? fwd : rc;
-    return wv == kmask; // k valid bases ending here (word_len >= k, trim.cpp:924)
-}
-
-// The same with 32-bit funnel shifts (kmer_group_extract).  The window of lane l starts at bit s = 65 + l - k of the 128-bit string
-// prev : cur, i.e. in dword d = s >> 5 (1, 2 or 3) at bit s & 31: which two of the four dwords a lane needs depends on the lane
-// alone, so the selection masks are made once (KmerWin) and a plane costs 4 v_cndmask + v_alignbit + v_and instead of three
-// 64-bit variable shifts (quarter rate on gfx950).
-struct KmerWin { uint32_t sh; bool d1, d2; };
-__device__ __forceinline__ KmerWin kmer_win(const int lane, const uint32_t k)
-{
-    const uint32_t s = 65u + (uint32_t)lane - k;
-    return KmerWin{s & 31u, (s >> 5) == 1u, (s >> 5) == 2u};
-}
-__device__ __forceinline__ uint32_t window_bits32(const uint64_t cur, const uint64_t prev, const KmerWin w, const uint32_t kmask)
-{
-    const uint32_t d1 = (uint32_t)(prev >> 32), d2 = (uint32_t)cur, d3 = (uint32_t)(cur >> 32);
-    const uint32_t lo = w.d1 ? d1 : (w.d2 ? d2 : d3), hi = w.d1 ? d2 : (w.d2 ? d3 : 0u);
-    return __builtin_amdgcn_alignbit(hi, lo, w.sh) & kmask;
-}
-__device__ __forceinline__ bool kmer_chunk_key32(const uint32_t b, const KmerWin w, const uint32_t k, KmerPlanes &S, uint64_t &key)
-{
-    const uint32_t l = b | 0x20u;
-    const bool isA = l == 'a', isT = l == 't', isC = l == 'c', isG = l == 'g';
-    const uint64_t cv = __ballot(isA | isT | isC | isG);
-    const uint64_t c0 = __ballot(isT | isG); // codes A=0 T=1 C=2 G=3 (FaQCs.h:35-42)
-    const uint64_t c1 = __ballot(isC | isG);
-    const uint32_t kmask = (uint32_t)((1ull << k) - 1ull);
-    const uint32_t wv = window_bits32(cv, S.pv, w, kmask);
-    const uint32_t w0 = window_bits32(c0, S.p0, w, kmask);
-    const uint32_t w1 = window_bits32(c1, S.p1, w, kmask);
-    S.pv = cv; S.p0 = c0; S.p1 = c1;
-    const uint32_t r0 = __brev(~w0 & kmask) >> (32 - k), r1 = __brev(w1) >> (32 - k);
-    const bool fwd_less = w1 < r1 || (w1 == r1 && w0 < r0);
-    key = fwd_less ? (((uint64_t)w1 << 32) | w0) : (((uint64_t)r1 << 32) | r0);
     return wv == kmask; // k valid bases ending here (word_len >= k, trim.cpp:924)
 }
 

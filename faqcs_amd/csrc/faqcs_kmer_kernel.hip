@@ -17,7 +17,7 @@
 // independent of table size and key reuse), so an insert costs ONE atomic wherever possible: a plain 16-byte load classifies
 // the slot first (keys never change once written, so a stale view can only say "empty" and fall through to the CAS); a new
 // key costs the CAS only, a known key the count add only, and the epoch min is issued only when it would lower the stored
-// epoch.  (The single-GPU path no longer inserts per occurrence at all: faqcs_kmer_group_kernel.hip.)
+// epoch.  (The single-GPU path no longer inserts per occurrence at all: faqcs_kmer_skm_kernel.hip.)
 
 // open-addressing insert; returns false when the probe budget is exhausted (table full)
 __device__ __forceinline__ bool kmer_insert(const KmerTable &T, const uint64_t key, const uint32_t epoch, bool &is_new)
