@@ -366,6 +366,91 @@ def test_kmer_matches_oracle():
         assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
 
 
+def _genome_reads(rng, genome, n, lo, hi, n_rate=0.002, q_hi=41):
+    """Windows of `genome` on either strand, 0.5 % substitutions, an N now and then, good qualities (most of a read is kept)."""
+    comp = np.zeros(256, np.uint8)
+    comp[np.frombuffer(b"ACGTN", np.uint8)] = np.frombuffer(b"TGCAN", np.uint8)
+    reads = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        at = int(rng.integers(0, len(genome) - L))
+        s = genome[at:at + L].copy()
+        sub = rng.random(L) < 0.005
+        s[sub] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(sub.sum()))]
+        s[rng.random(L) < n_rate] = ord("N")
+        if rng.random() < 0.5:
+            s = comp[s[::-1]]
+        q = (rng.integers(30, q_hi, L) + 33).astype(np.uint8)
+        reads.append((b"@g", s.tobytes(), q.tobytes()))
+    return reads
+
+
+def _kmer_engines_agree(hip, ora):
+    hip.kmer_end_table()
+    ora.kmer_end_table()
+    assert len(ora.kmer_points()) > 0 and (hip.kmer_points() == ora.kmer_points()).all()
+    h1, h2 = hip.kmer_histogram(), ora.kmer_histogram()
+    assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_kmer_submissions_either_side_of_256_bases_share_their_keys(seed):
+    """one engine, several submissions whose longest reads lie either side of 256 bases -- the 16-positions-per-lane
+    extraction kernel, the general one and its multi-piece path all feed ONE table, so a k-mer seen by two of them must be one key
+    (round 4's two extraction kernels wrote different integers for it).  Reads are windows of one small genome: nearly every k-mer
+    of a submission occurs in the others too (trim.cpp:887-931; sampling points trim.cpp:157-185)."""
+    from oracle_engine import OracleEngine
+
+    from faqcs_amd import driver
+
+    rng = np.random.Generator(np.random.PCG64([2560, seed, SEED]))
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 30000)]
+    opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "700", "--subset", "12"])
+    hip, ora = hip_factory(opt, 1024, 33), OracleEngine(opt, 1024, 33)
+    for lo, hi in ((60, 150), (200, 700), (240, 256), (257, 300), (31, 40)):
+        reads = _genome_reads(rng, genome, 1500, lo, hi)
+        bufs = [reads[i:i + 409] for i in range(0, len(reads), 409)]
+        seq, qual, offset, seg = driver.pack_segments(bufs)
+        r1, r2 = hip.process(seq, qual, offset, seg), ora.process(seq, qual, offset, seg)
+        assert (r1 == r2).all()
+    _kmer_engines_agree(hip, ora)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_kmer_repeats_and_a_partition_larger_than_its_slice(seed, monkeypatch):
+    """The rare paths of the super-k-mer kernels: (1) tandem repeats and homopolymers -- equal minimizers over more than 17 k-mers: the
+    16-positions-per-lane kernel leaves such a read to the general kernel, which cuts its runs on a grid; (2) thousands of reads that
+    share a 45-base core with random flanks -- their k-mers share a handful of minimizers, so a few partitions hold far more
+    distinct keys than the 64 slots of their slice of a 2^22-slot table: the keys move to the overflow area behind the table.
+    Every sampling point and every histogram bin equals the oracle's (trim.cpp:157-185,887-931; FaQCs.cpp:518-521)."""
+    rng = np.random.Generator(np.random.PCG64([9090, seed, SEED]))
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    core = acgt[rng.integers(0, 4, 45)]
+    reads = []
+    for i in range(3600):
+        L = int(rng.integers(80, 251))
+        kind = i % 3
+        if kind == 0:  # repeats
+            s = np.zeros(0, np.uint8)
+            while len(s) < L:
+                unit = acgt[rng.integers(0, 4, int(rng.integers(1, 7)))]
+                s = np.concatenate([s, np.tile(unit, int(rng.integers(8, 60)))])
+            s = s[:L].copy()
+        else:  # the shared core somewhere inside random flanks
+            s = acgt[rng.integers(0, 4, L)]
+            at = int(rng.integers(0, L - 45))
+            s[at:at + 45] = core
+        if rng.random() < 0.2:
+            s[int(rng.integers(0, L))] = ord("N")
+        reads.append((b"@r", s.tobytes(), (rng.integers(30, 41, L) + 33).astype(np.uint8).tobytes()))
+    opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "500", "--subset", "5", "--lc", "1.0", "--min_L", "31"])
+    from faqcs_amd.engine import HipEngine
+
+    monkeypatch.setattr("test_gpu_parity.hip_factory", lambda o, r, q: HipEngine(o, r, q, kmer_table_slots=1 << 22))
+    hip, ora = compare_engines(opt, reads, seg_size=431)
+    _kmer_engines_agree(hip, ora)
+
+
 @pytest.mark.parametrize("group_items,maxlen", [(1 << 14, 150), (1 << 16, 250), (1 << 20, 250), (1 << 16, 600)], ids=["g14", "g16", "g20", "g16_long"])
 def test_kmer_groups_of_every_size_match_oracle(group_items, maxlen, monkeypatch):
     """The combine-before-insert path with groups far smaller than a submission (FAQCS_KMER_GROUP_ITEMS): runs are cut into many
