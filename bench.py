@@ -472,6 +472,7 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
     torch.cuda.synchronize()
 
     kmer_seen = [0, 0]
+    kmer_wire = [0, 0]  # items sent over the process group, occurrences of the steps (the exchange's wire cost)
 
     # k-mers across ranks: every canonical k-mer has one owner rank; a rank buckets the (key, epoch) pairs of its
     # shard by owner, RCCL all-to-all moves them, the owner inserts.  The epoch of a 32 768-read segment comes from the GLOBAL
@@ -510,11 +511,12 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
                 e0 += len(seg) - 1
             _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(bt), res.data_ptr()))
             if kx is not None:
-                kx.exchange()
+                kmer_wire[0] += kx.exchange()[0]
         if kx is not None:  # the additive epoch histograms -> the job's rarefaction points (one small all-reduce); fresh tables
             pts, _hist = kx.finish(kmer_points_seq, n_reads * world)
             kmer_last["points"] = len(pts)
             kmer_last["distinct"], kmer_last["total"] = (pts[-1][1], pts[-1][2]) if pts else (0, 0)
+            kmer_wire[1] += int(kmer_last["total"]) // world  # (this rank's share of the occurrences the last point has seen)
         if use_dist and native_rccl:  # enqueued behind the kernels: no sync in front of it, the one behind it is the step's own
             tc = time.perf_counter()
             parallel.allreduce_counters_device(eng)
@@ -595,25 +597,29 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         kmer_k = 31
         if config == "kmer" and (kt.kmer_ms + kt.kmer_insert_ms) > kt.trim_ms:
             # + (L - k + 1) x 16 bytes per read (8-byte key + 8-byte slot read-modify-write): 3 520 B/read at L = 250, k = 31
-            dominant = "kmer_group_extract + kmer_group_split + kmer_group_combine" if kx is None else "kmer_extract + kmer_insert_items"
+            dominant = "skm_extract16 + skm_extract + skm_split + skm_combine" if kx is None else "skm_extract16 + skm_outbox + skm_items + skm_split + skm_combine"
             if os.environ.get("FAQCS_KMER_DIRECT") == "1" and kx is None:
                 dominant = "kmer_count"
             dom_ms = kt.kmer_ms + kt.kmer_insert_ms
             alg_bytes = reads_per_launch * (L - kmer_k + 1) * 16
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic, traffic_src, traffic_at = None, None, None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_hash import load_if_current  # a stored counter file counts only if it was measured on THESE kernel sources
+
         tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % config)
-        if os.path.exists(tf) and L == 150 and dominant != "adapter_overlap":  # (measured on the 2x150 shape only)
-            try:
-                # NOT measured in this run: rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE separately, gfx950 correction applied)
-                # of the same kernel, stored per read by profiles/pmc_traffic2.sh and scaled to this run's launch size
-                tj = json.load(open(tf))
-                if tj.get("kernel", trim_kernel) == trim_kernel:
-                    traffic = int(tj["hbm_bytes_per_read"] * reads_per_launch)
-                    traffic_at = tj.get("reads_per_launch")
-                    traffic_src = "profiles/traffic_%s.json (rocprofv3 --pmc, %s)" % (config, tj.get("tag", "stored per read"))
-            except Exception:
-                traffic = None
+        if L == 150 and dominant != "adapter_overlap":  # (measured on the 2x150 shape only)
+            # NOT measured in this run: rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE separately, gfx950 correction applied)
+            # of the same kernel, stored per read by profiles/pmc_traffic2.sh and scaled to this run's launch size
+            tj, why = load_if_current(tf)
+            if tj is None:
+                traffic_src = "null: " + why
+            elif tj.get("kernel", trim_kernel) != trim_kernel:
+                traffic_src = "null: %s holds %s, this run's kernel is %s" % (os.path.basename(tf), tj.get("kernel"), trim_kernel)
+            else:
+                traffic = int(tj["hbm_bytes_per_read"] * reads_per_launch)
+                traffic_at = tj.get("reads_per_launch")
+                traffic_src = "profiles/traffic_%s.json (rocprofv3 --pmc, %s; source_sha256 %s... = this build)" % (config, tj.get("tag", "stored per read"), tj["source_sha256"][:10])
         out = {
             "metric": "M reads/sec (paired 2x%dbp)" % L, "value": round(value, 3), "unit": "M reads/s", "n_gpus": world if world == 1 else dist.get_world_size(),
             "ranks_seen": ranks_seen,
@@ -637,14 +643,17 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         if config == "kmer" and kx is not None:
             out["kmer"] = {"G_inserts_per_s": round(kmer_last.get("total", 0) / (dt / steps) / 1e9, 3), "distinct_at_last_point": int(kmer_last.get("distinct", 0)),
                            "occurrences_at_last_point": int(kmer_last.get("total", 0)), "points": int(kmer_last.get("points", 0)),
-                           "note": "owner-partitioned tables: (key, epoch) pairs bucketed by owner on the device, all-to-all over the process group, "
-                                   "owner-side insert; distinct / total from the all-reduced epoch histograms"}
+                           "note": "owner-partitioned tables: runs of k-mers that share their minimizer (16-byte super-k-mer items, about 8 occurrences each) "
+                                   "grouped by the owner of the minimizer's partition on the device, all-to-all over the process group, owner-side combine; "
+                                   "distinct / total from the all-reduced epoch histograms",
+                           "wire_bytes_per_occurrence": round(16.0 * kmer_wire[0] / max(1, kmer_wire[1]), 3)}
         elif config == "kmer":
             d_, t_ = eng.kmer_totals()
             out["kmer"] = {"G_inserts_per_s": round(t_ / (dt / steps) / 1e9, 3), "distinct_per_step": int(d_), "occurrences_per_step": int(t_),
                            "points_per_step": len(eng.kmer_points()) // max(1, steps + warmup),
-                           "note": "canonical 31-mers of the kept reads, combined before they reach the table (reset every step): occurrences are bucketed, split "
-                                   "65 536 ways, counted per partition in LDS, then ONE plain table update per distinct key and group (DESIGN.md section 4.4)"}
+                           "note": "canonical 31-mers of the kept reads: runs of k-mers that share their minimizer travel as ONE 16-byte item (about 8 occurrences), are "
+                                   "split 65 536 ways by the minimizer, expanded and counted per partition in LDS, then ONE plain table update per distinct key "
+                                   "and group (DESIGN.md section 4.4)"}
         out.update({
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
@@ -658,14 +667,14 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
             occ = out["kmer"].get("occurrences_per_step", out["kmer"].get("occurrences_at_last_point", 0)) / max(1, len(batches))
             rate = occ / (dom_ms * 1e-3) / 1e9
             kc = {"G_occurrences_per_s": round(rate, 3),
-                  "note": "occurrences per submission / the k-mer kernels' time.  Rounds 1-3 paid one memory-side atomic per occurrence (13.5 G/s measured ceiling); "
-                          "the counters of the combine-before-insert kernels are in profiles/r4*/pmc_kmer_group*.txt"}
-            pj = os.path.join(ROOT, "profiles", "kmer_counters.json")
-            if os.path.exists(pj):
-                try:
-                    kc.update(json.load(open(pj)))
-                except Exception:
-                    pass
+                  "note": "occurrences per submission / the k-mer kernels' time.  Rounds 1-3 paid one memory-side atomic per occurrence (13.5 G/s measured ceiling), "
+                          "round 4 moved an 8-byte item per occurrence through two scatter passes (61 B of HBM traffic per occurrence); the counters of the "
+                          "super-k-mer kernels are in profiles/r5*/pmc_skm*.txt"}
+            kj, why = load_if_current(os.path.join(ROOT, "profiles", "kmer_counters.json"))
+            if kj is not None:
+                kc.update(kj)
+            else:
+                kc["counters"] = "null: " + why
             out["roofline"]["kmer_counters"] = kc
         if dominant == "adapter_overlap":
             # adapter_overlap is bound by integer VALU issue, not by HBM: the work is L x sum|adapter| cell updates per
@@ -676,11 +685,8 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
             # rate of the instruction class the kernel is made of (v_bitop3, v_bcnt, v_alignbit, DPP, compares: 4 cycles per wave instruction =
             # 575 G/s chip-wide; only plain VOP1/VOP2 integer ops reach 1 000 G/s -- profiles/r3a/valu_lds_peak.txt), the scalar side against
             # one scalar instruction per clock and CU (measured with trim_long).
-            ac = {}
-            try:
-                ac = json.load(open(os.path.join(ROOT, "profiles", "adapter_counters.json")))
-            except Exception:
-                pass
+            ac, ac_why = load_if_current(os.path.join(ROOT, "profiles", "adapter_counters.json"))
+            ac = ac or {}
             valu = {"cell_updates_per_s": round(reads_per_launch * cells / (dom_ms * 1e-3) / 1e12, 3), "unit": "T cell updates/s",
                     "measured_peak_G_wave_instr_per_s": 575.0, "G_wave_instr_per_s": None, "frac": None}
             if ac.get("valu_per_read"):
