@@ -43,6 +43,24 @@
 // array in global memory (plain adds, no atomics: the row is private to the block) and fold_partials, launched behind the kernel,
 // adds the rows to the u64 counter block.
 //
+// THE SLOT'S VALIDITY RULE (round 5: decided to keep it a rule, state its keepers here and CHECK it in the test suite, rather than pay two
+// VALU per position in Q-B for an address that is forced into the table).  The LDS address of a Q-B add is (quality byte) x (row stride) +
+// lane base even when the increment is zero -- a position behind the read or outside the kept window -- and an LDS add of zero is still a
+// read-modify-write: with a byte that is not a quality (a base letter is "row" 64 ... 83 of a 42-row table) the add lands in another wave's
+// slot and can put stale bytes back over that wave's LDS-DMA.  So EVERY byte a position-parallel quality pass can read -- the staged span,
+// the <= 15 bytes of alignment slack in front of it, W + 20 bytes behind it, the 16-byte tails of padded rows -- holds a byte inside
+// [offset, offset + 41] whenever such a pass runs.  The writes that keep it so, all of them:
+//   1. stage(): the DMA of the QUALITY arena (bytes of the batch: the flat range check of Q-A flags anything outside [offset, offset + 41]
+//      as FAQCS_E_QUALITY -- such a batch ends in that error and its counters are never used);
+//   2. pad_behind_span(), called behind EVERY staging of qualities -- the first one of a chunk and the second one of the take-back pass (the
+//      missing second call was round 4's race) -- writes the offset byte into the slack, the W + 20 bytes behind the span and, for padded
+//      rows, behind the last row;
+//   3. the terminal-N patch of Q-A writes the offset byte over quality bytes of the span (never outside it);
+//   4. nothing else writes to a slot while it holds qualities: the BASE arena is staged into the slot only after the last quality pass of
+//      the chunk, and a slot belongs to one wave.
+// tests/test_gpu_slot_rule.py runs batches of every lane geometry through a build that counts the adds outside the matrix
+// (-DFAQCS_LDS_DIAG_CHECK_QB_ADDR, built by __graft_entry__.build() as tests/_diag/libfaqcs_mi_qbchk.so): the count must be zero.
+//
 // Dispatch (faqcs_launch_trim_lds at the end of the file): every option set except --replace_to_N_q.  A chunk whose reads all have the
 // same length, a multiple of 32 bases, is staged as padded rows instead of one span (dma_rows: LDS bank stride of the lane-per-read passes).
 #include "faqcs_trim_common.h"
