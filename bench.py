@@ -50,6 +50,8 @@ def parse():
                     "28.6 M reads of 150 bases; fewer, larger launches = fewer seams between launches (2^24: -2.8 %% on the default line)")
     ap.add_argument("--at-frac", type=float, default=None, help="A+T fraction of the synthetic bases (default: uniform ACGT); 0.9 makes most "
                     "reads dinucleotide candidates of the low-complexity filter (an AT-rich genome)")
+    ap.add_argument("--kmer-table-log2", type=int, default=31, help="log2 of the k-mer table's slots per GPU (--config kmer; 2^31 slots = 34 GB: the "
+                    "tests that put eight ranks on one GPU pass 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="the default single-GPU run (config plain, 2x150) also runs BASELINE's adapter and k-mer "
                     "configurations, two steps each, and reports them under \"configs\"; this switches that off")
@@ -432,7 +434,7 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
     opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "400"]}.get(config, [])
     opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
     eng = HipEngine(opt, 256 if L <= 256 else (capi.FAST_READ_LENGTH if L <= capi.FAST_READ_LENGTH else capi.MAX_READ_LENGTH), 33, device=local,
-                    kmer_table_slots=(1 << 31) if config == "kmer" else 0)
+                    kmer_table_slots=(1 << a.kmer_table_log2) if config == "kmer" else 0)
     lib = eng.lib
 
     # ---- resident synthetic data set ---------------------------------------------------------------------
@@ -489,13 +491,45 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         kmer_epochs = ep[rank * per_rank:(rank + 1) * per_rank]
         kx = parallel.KmerExchange(eng, rank, world, opt.num_subsample)
     kmer_last = {}
-    # FAQCS_BENCH_NATIVE_RCCL=1 (opt-in; needs the nccl backend): the library's own communicator -- the counter block is all-reduced in place on
-    # the engine's compute stream (faqcs_comm_allreduce_counters) instead of through a torch staging tensor.  Not the default: with two or
-    # more ranks it has never run on hardware.
+    # The counter all-reduce under the nccl (= RCCL) backend: the library's own communicator reduces the block IN PLACE on the engine's compute
+    # stream (faqcs_comm_allreduce_counters) -- but only after the FIRST step has run both forms on the same block and found them bit-identical
+    # on every rank: the torch-staged form (export into a torch tensor, dist.all_reduce, import) is the reference, the native form is then used
+    # for the timed steps.  A failure to set it up, or a mismatch, keeps the torch-staged form and says so in collective.what.
+    # FAQCS_BENCH_NATIVE_RCCL=0 skips the native form altogether.  (No run with two or more GPUs has happened in any round: this is how
+    # the first one validates the native collective without a code change.)
     native_rccl = False
-    if use_dist and os.environ.get("FAQCS_BENCH_NATIVE_RCCL", "0") not in ("", "0") and dist.get_backend() == "nccl":
-        parallel.native_comm_init(eng)
-        native_rccl = True
+    native_state = {"validate": use_dist and dist.get_backend() == "nccl" and os.environ.get("FAQCS_BENCH_NATIVE_RCCL", "1") not in ("", "0"), "note": None}
+
+    def validate_native():
+        """Both collectives on the block the first step left: True when the native one may be used."""
+        n = eng.n_counters
+        before = torch.empty(n, dtype=torch.int64, device=dev)
+        eng.counters_export(before.data_ptr(), n)
+        parallel.allreduce_counters_device(eng)  # torch-staged (no native communicator yet)
+        want = torch.empty(n, dtype=torch.int64, device=dev)
+        eng.counters_export(want.data_ptr(), n)
+        ok, why = 1, ""
+        try:
+            eng.counters_import(before.data_ptr(), n)  # the step's own block again
+            parallel.native_comm_init(eng)
+            parallel.allreduce_counters_device(eng)  # native, in place
+            eng.sync()
+            got = torch.empty(n, dtype=torch.int64, device=dev)
+            eng.counters_export(got.data_ptr(), n)
+            if not torch.equal(got, want):
+                ok, why = 0, "the blocks differ in %d of %d words on rank %d" % (int((got != want).sum()), n, rank)
+        except Exception as e:  # no librccl, communicator set-up failed, ...
+            ok, why = 0, "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            eng.has_comm = False  # allreduce_counters_device() goes back to the staging tensor
+            eng.counters_import(want.data_ptr(), n)
+            native_state["note"] = "native RCCL all-reduce NOT used (%s); torch-staged all-reduce instead" % (why or "another rank reported a failure")
+            return False
+        native_state["note"] = "validated on the first step against the torch-staged all-reduce: bit-identical blocks on all %d ranks" % world
+        return True
+
     coll = [0.0, 0]  # seconds in the counter all-reduce (export, all-reduce, import; behind a sync, so it is the collective alone), calls
 
     def step(flags=True):
@@ -517,7 +551,12 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
             kmer_last["points"] = len(pts)
             kmer_last["distinct"], kmer_last["total"] = (pts[-1][1], pts[-1][2]) if pts else (0, 0)
             kmer_wire[1] += int(kmer_last["total"]) // world  # (this rank's share of the occurrences the last point has seen)
-        if use_dist and native_rccl:  # enqueued behind the kernels: no sync in front of it, the one behind it is the step's own
+        nonlocal native_rccl
+        if native_state["validate"]:
+            native_state["validate"] = False
+            eng.sync()
+            native_rccl = validate_native()
+        elif use_dist and native_rccl:  # enqueued behind the kernels: no sync in front of it, the one behind it is the step's own
             tc = time.perf_counter()
             parallel.allreduce_counters_device(eng)
             eng.sync()
@@ -623,6 +662,8 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         out = {
             "metric": "M reads/sec (paired 2x%dbp)" % L, "value": round(value, 3), "unit": "M reads/s", "n_gpus": world if world == 1 else dist.get_world_size(),
             "ranks_seen": ranks_seen,
+            "reduced_block": {"reads_counted": int(fs[capi.TOTAL_NUMBER]), "reads_expected": int(n_reads * world),
+                              "note": "TOTAL_NUMBER of the counter block after the job's all-reduce against ranks x reads per rank (a mismatch ends the run)"},
             "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("synthetic %.0fM-pair 2x%dbp Q33 reads" + ("" if a.at_frac is None else " (A+T = %g of the bases)" % a.at_frac) + " resident in HBM per GPU, BWA_plus -q 5 --min_L 50%s, "
@@ -636,9 +677,9 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
             out["config"]["value_without_terminal_n_flags"] = noflag_value
         if coll[1]:
             out["collective"] = {"what": ("all-reduce(sum) of the %d-word u64 counter block, once per job, IN PLACE on the engine's compute stream by the library's own RCCL "
-                                          "communicator (faqcs_comm_allreduce_counters); ms_per_step includes the wait for the step's last kernels" % eng.n_counters) if native_rccl else
+                                          "communicator (faqcs_comm_allreduce_counters); ms_per_step includes the wait for the step's last kernels; %s" % (eng.n_counters, native_state["note"])) if native_rccl else
                                          ("all-reduce(sum) of the %d-word u64 counter block, once per job: device-to-device export into a torch tensor, "
-                                          "dist.all_reduce (%s), import" % (eng.n_counters, backend)),
+                                          "dist.all_reduce (%s), import%s" % (eng.n_counters, backend, "; " + native_state["note"] if native_state["note"] else "")),
                                  "ms_per_step": round(coll[0] / coll[1] * 1e3, 4), "calls": coll[1]}
         if config == "kmer" and kx is not None:
             out["kmer"] = {"G_inserts_per_s": round(kmer_last.get("total", 0) / (dt / steps) / 1e9, 3), "distinct_at_last_point": int(kmer_last.get("distinct", 0)),

@@ -80,11 +80,14 @@ __device__ __forceinline__ bool slot_insert_atomic(KmerSlot *sl, const u64 h, co
 enum { KS_PROBE_MAX = 128 };
 __device__ void ovf_insert_atomic(const KmerTable &T, const u64 h, const uint32_t epoch, const uint32_t count, u64 *first_hist, const uint32_t n_epochs)
 {
-    if (T.ovf_mask) {
+    // (a probe sequence of the overflow area is cut at 4 096 slots and nothing is tried once the table has been declared full: an area
+    // that is full would otherwise be scanned end to end for every key -- the run fails with FAQCS_E_KMER_FULL either way, but at once)
+    if (T.ovf_mask && !(__hip_atomic_load(&T.stats[2], __ATOMIC_RELAXED, FAQCS_KMER_SCOPE) & 1ull)) {
         KmerSlot *ovf = T.slots + T.mask + 1;
         u64 g = (h ^ (h >> 23)) & T.ovf_mask;
+        const u64 n_probe = T.ovf_mask < 4095ull ? T.ovf_mask + 1 : 4096ull;
 #pragma unroll 1
-        for (u64 probe = 0; probe <= T.ovf_mask; ++probe) {
+        for (u64 probe = 0; probe < n_probe; ++probe) {
             if (slot_insert_atomic(&ovf[g], h, epoch, count, first_hist, n_epochs)) return;
             g = (g + 1) & T.ovf_mask;
         }

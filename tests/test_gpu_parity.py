@@ -451,6 +451,27 @@ def test_kmer_repeats_and_a_partition_larger_than_its_slice(seed, monkeypatch):
     _kmer_engines_agree(hip, ora)
 
 
+@pytest.mark.timeout(120)
+def test_kmer_table_that_is_too_small_is_an_error_at_once():
+    """Three times more distinct k-mers than the table (2^22 slots + its overflow area) can hold: FAQCS_E_KMER_FULL from the sync --
+    not a scan of the whole overflow area for every key behind the first one that did not fit (the probe sequence there is cut and
+    nothing is tried once the table has been declared full)."""
+    from faqcs_amd.engine import FaqcsError, HipEngine
+
+    rng = np.random.Generator(np.random.PCG64(5 + SEED))
+    L, n = 250, 70000
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * L)]
+    qual = np.full(n * L, 33 + 38, np.uint8)
+    pad = np.zeros(64, np.uint8)
+    s, q = np.concatenate([pad, seq, pad])[64:], np.concatenate([pad, qual, pad])[64:]
+    off = (np.arange(n + 1, dtype=np.uint64) * L).astype(np.uint32)
+    opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "100000"])
+    eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << 22)
+    with pytest.raises(FaqcsError) as e:
+        eng.process(s, q, off, np.array([0, n], dtype=np.uint32))
+    assert e.value.code == capi.E_KMER_FULL
+
+
 @pytest.mark.parametrize("group_items,maxlen", [(1 << 14, 150), (1 << 16, 250), (1 << 20, 250), (1 << 16, 600)], ids=["g14", "g16", "g20", "g16_long"])
 def test_kmer_groups_of_every_size_match_oracle(group_items, maxlen, monkeypatch):
     """The combine-before-insert path with groups far smaller than a submission (FAQCS_KMER_GROUP_ITEMS): runs are cut into many
@@ -649,6 +670,52 @@ def test_two_rank_hip_counters_allreduce(args, tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_counter_rank, args=(2, port, args, 4000, out), nprocs=2, join=True)
     assert open(out).read() == "ok", open(out).read()
+
+
+def test_eight_rank_hip_counters_allreduce(tmp_path):
+    """BASELINE configs[3]'s rank count on the one GPU of the box: EIGHT ranks (gloo), each with its own HIP context on device 0 and its
+    shard of the reference's trim() calls -- a shard count that the input's segments do not divide evenly --, --adapter --polyA so that the
+    adapter groups of 8 meet the shard cuts; after the all-reduce every rank's block equals the single-process oracle's (trim.cpp:120-154)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_counter_rank, args=(8, port, ["--adapter", "--polyA"], 9000, out), nprocs=8, join=True)
+    assert open(out).read() == "ok", open(out).read()
+
+
+def test_eight_rank_kmer_exchange(tmp_path):
+    """BASELINE configs[4]'s rank count and shape (2x250, --subset 200) on one GPU: eight owners, super-k-mer items all-to-all over gloo."""
+    test_two_rank_kmer_exchange(["--kmer_rarefaction", "--split_size", "400", "--subset", "200"], 5200, 250, tmp_path, world=8)
+
+
+@pytest.mark.parametrize("config", ["plain", "adapter", "kmer"])
+def test_bench_gpus_8_on_one_gpu(config):
+    """`bench.py --gpus 8` on every configuration, eight rank processes sharing the box's GPU (FAQCS_BENCH_SHARE_GPU=1, gloo): the launcher
+    starts eight ranks, the line says so, and the all-reduced counter block accounts for the reads of all eight (bench.py ends the run
+    otherwise); --config kmer: the owner-partitioned exchange among eight owners, its wire cost per occurrence in the line."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FAQCS_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    pairs = {"plain": "4e5", "adapter": "2e5", "kmer": "5e4"}[config]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--config", config, "--pairs", pairs, "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-other-configs", "--e2e-pairs", "0", "--kmer-table-log2", "27"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and sorted(x[0] for x in line["ranks_seen"]) == list(range(8))
+    assert line["reduced_block"]["reads_counted"] == line["reduced_block"]["reads_expected"] == 8 * 2 * int(float(pairs))
+    if config == "kmer":
+        assert line["kmer"]["points"] > 0 and 0 < line["kmer"]["wire_bytes_per_occurrence"] <= 4.0
 
 
 def test_rccl_code_paths_on_one_rank(tmp_path):
