@@ -173,12 +173,16 @@ def e2e_run(opt_args, hs, hq, L, n_pairs):
         pipe = None
         if "first pair parsed" in marks and "outputs written" in marks and marks["outputs written"] > marks["first pair parsed"]:
             pipe = round(2 * n / (marks["outputs written"] - marks["first pair parsed"]) / 1e6, 3)
-        return {"value": round(2 * n / dt / 1e6, 3), "unit": "M reads/s", "seconds": round(dt, 3), "pairs": n,
+        one = round(2 * n / dt_nofork / 1e6, 3) if r2.returncode == 0 else None
+        # value = the WHOLE-PROCESS figure (one process, teardown included: what the machine pays); the forked mode's figure -- what the
+        # caller waits for -- is reported beside it
+        return {"value": one, "unit": "M reads/s", "seconds": round(dt_nofork, 3), "pairs": n,
+                "value_as_the_caller_sees_it": round(2 * n / dt / 1e6, 3), "seconds_as_the_caller_sees_it": round(dt, 3),
                 "pipeline_value": pipe, "stage_marks_s": marks,
-                "value_one_process": round(2 * n / dt_nofork / 1e6, 3) if r2.returncode == 0 else None, "seconds_one_process": round(dt_nofork, 3),
+                "value_one_process": one, "seconds_one_process": round(dt_nofork, 3),
                 "input_GB": round(in_bytes / 1e9, 3), "output_GB": round(out_bytes / 1e9, 3),
                 "what": "faqcs_mi: uncompressed FASTQ in /dev/shm -> parse -> pinned SoA -> HIP trim -> trimmed FASTQ + QC.stats.txt in /dev/shm; "
-                        "wall clock of the command as its caller sees it, HIP start-up included (the command returns when every output file is complete; a worker process releases the GPU context and the mappings afterwards); value_one_process = the same command with FAQCS_MI_NO_FORK=1, teardown included; pipeline_value = the same reads over the interval from the first "
+                        "value = the command in ONE process (FAQCS_MI_NO_FORK=1), HIP start-up and teardown included; value_as_the_caller_sees_it = the default mode: the command returns when every output file is complete and a worker process releases the GPU context, the pinned buffers and the mappings afterwards; pipeline_value = the same reads over the interval from the first "
                         "parsed pair to the last output byte (faqcs_mi's own stage marks)"}
     except Exception as e:
         return {"error": str(e)}
