@@ -8,7 +8,7 @@ export TMPDIR=/tmp FAQCS_ABLATE_ADAPTER_FRAC=$frac
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_BRANCH" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -o pmc -- python3 tools/ablate.py 0 8e6 --adapter --polyA > $out/pmc$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -o pmc -- python3 tools/ablate.py 0 8e6 --adapter --polyA < /dev/null > $out/pmc$i.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections

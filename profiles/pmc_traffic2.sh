@@ -10,7 +10,7 @@ out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
     i=$((i+1))
-    TRIM_AB_REPS=2 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/t$i -o pmc -- ./profiles/microbench/trim_ab $n 150 1 $lib > $out/t$i.log 2>&1
+    TRIM_AB_REPS=2 timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/t$i -o pmc -- ./profiles/microbench/trim_ab $n 150 1 $lib < /dev/null > $out/t$i.log 2>&1
 done
 python3 - "$out" "$n" "$tag" <<'PY'
 import csv, glob, json, sys, collections

@@ -9,7 +9,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CY
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_LDS_ATOMIC_RETURN"; do
     i=$((i+1))
-    TRIM_AB_REPS=2 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -o pmc -- ./profiles/microbench/trim_ab $n $L 1 $lib > $out/pmc$i.log 2>&1
+    TRIM_AB_REPS=2 timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -o pmc -- ./profiles/microbench/trim_ab $n $L 1 $lib < /dev/null > $out/pmc$i.log 2>&1
 done
 python3 - "$out" "$n" <<'PY'
 import csv, glob, sys, collections

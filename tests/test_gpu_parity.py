@@ -770,7 +770,8 @@ def test_bench_gpus_2_runs_two_ranks(tmp_path):
 def test_bench_under_the_drivers_launcher_with_one_rank(native):
     """The command line the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
     with N = 1: bench.py then forms the `nccl` process group, all-reduces the counter block through RCCL every step and takes the MAX of
-    the step times, exactly as on an 8-GPU node."""
+    the step times, exactly as on an 8-GPU node.  native_rccl: the default -- the first step runs the torch-staged AND the library's own
+    in-place all-reduce on the same block, compares them bit for bit and uses the native one from then on."""
     import json
     import socket
     import subprocess
@@ -784,8 +785,8 @@ def test_bench_under_the_drivers_launcher_with_one_rank(native):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FAQCS_BENCH_SHARE_GPU", "FAQCS_BENCH_BACKEND", "FAQCS_BENCH_NATIVE_RCCL"):
         env.pop(k, None)
-    if native:
-        env["FAQCS_BENCH_NATIVE_RCCL"] = "1"
+    if not native:  # (round 5: the native collective is the default under nccl once the first step has validated it; 0 keeps the torch-staged one)
+        env["FAQCS_BENCH_NATIVE_RCCL"] = "0"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--pairs", "4e6", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--e2e-pairs", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -793,6 +794,8 @@ def test_bench_under_the_drivers_launcher_with_one_rank(native):
     line = json.loads([l for l in r.stdout.decode().strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["kernel"] == "trim_lds"
     assert ("IN PLACE" in line["collective"]["what"]) == native and line["collective"]["calls"] >= 3
+    assert ("bit-identical blocks on all 1 ranks" in line["collective"]["what"]) == native  # both forms ran on the first step's block and agreed
+    assert line["reduced_block"]["reads_counted"] == line["reduced_block"]["reads_expected"]
 
 
 def test_native_collective_in_one_process():
