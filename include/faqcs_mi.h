@@ -28,7 +28,9 @@ extern "C" {
 #endif
 
 /* 2: faqcs_batch.terminal_n, faqcs_terminal_n_flags, the k-mer timers of faqcs_kernel_times.  Entry points added since then leave
- * every existing structure and call as it was, so the number stands: faqcs_kmer_forward, faqcs_comm_* (round 4). */
+ * every existing structure and call as it was, so the number stands: faqcs_kmer_forward, faqcs_comm_* (round 4).  Round 5 changes what the
+ * 16-byte items of the k-mer exchange MEAN (faqcs_kmer_outbox / _insert_device / _forward: opaque to every caller in this repository, which
+ * only moves them) -- a run of up to 17 consecutive k-mers each instead of one (key, epoch) pair -- and nothing about their size or the calls. */
 #define FAQCS_ABI_VERSION 2
 
 /* FilterStat enum order, FaQCs.h:46-75 */
@@ -96,8 +98,11 @@ typedef struct faqcs_params {
     uint32_t n_adapters;                  /* 0 == !(filter_adapter || filter_phiX) */
     const char *const *adapter_seq;       /* n_adapters NUL-terminated IUPAC strings (Options::adapter[j].second) */
     uint64_t kmer_table_slots;            /* device hash-table capacity (0 = library default 2^28; rounded up to a power of two in [2^22, 2^32]:
-                                             the table is cut into 65 536 slices, one per key partition, and a slice that fills up raises
-                                             FAQCS_E_KMER_FULL even if others have room -- size it for <= 0.7 x slots distinct k-mers) */
+                                             the table is cut into 65 536 slices, one per key partition (a partition = the k-mers whose minimizer
+                                             hashes to it); a key that finds the 128 slots behind its home slot taken lives in an overflow area of
+                                             slots / 16 behind the table (round 5: a full slice is no longer an error), and FAQCS_E_KMER_FULL is
+                                             raised when that area cannot take a key either -- size the table for <= 0.6 x slots distinct k-mers;
+                                             16 bytes x 1.0625 x slots of device memory) */
 } faqcs_params;
 
 /* One submission: reads packed back to back in two byte arenas (structure of arrays).
@@ -268,26 +273,30 @@ int  faqcs_kmer_end_table(faqcs_ctx *ctx);
 /* ---- k-mers across GPUs --------------------------------------------------------------
  * The reference keeps ONE MAP<Word,size_t> per process (trim.cpp:82,133-135) and samples (distinct, total) after
  * trim() calls (trim.cpp:157-185); distinct counts are not additive over shards.  In this mode every canonical
- * k-mer has one owner rank; a rank buckets the (key, epoch) pairs of its shard by owner, the caller moves the
- * buckets with an all-to-all (RCCL: faqcs_amd/parallel.py), and the owner inserts them keeping the smallest epoch
- * per key.  epoch = index of the first rarefaction point that includes the segment (a host function of the GLOBAL
+ * k-mer has one owner rank -- the owner of the partition its MINIMIZER hashes to (csrc/faqcs_skm.h), so that consecutive k-mers of a
+ * read that share their minimizer travel together: a rank turns its shard into 16-byte ITEMS (a run of up to 17 consecutive 31-mers as
+ * 2-bit bases + the epoch, about 8 occurrences per item: under 2 bytes per occurrence on the wire where a (key, epoch) pair per
+ * occurrence was 16), grouped by owner; the caller moves them with an all-to-all (RCCL: faqcs_amd/parallel.py), and the owner expands,
+ * combines and inserts them keeping the smallest epoch per key.  The items are opaque to the caller.
+ * epoch = index of the first rarefaction point that includes the segment (a host function of the GLOBAL
  * read counts only, trim.cpp:157-185); FAQCS_EPOCH_NONE = the curve was already complete.  Then
  *   distinct(point i) = sum over ranks of #{keys with first epoch <= i},  total(point i) = sum of occurrences with
  *   epoch <= i -- both additive, i.e. one all-reduce of 2 x n_epochs integers. */
 #define FAQCS_EPOCH_NONE 0xffffffffu
-/* First call on a fresh kmer_rarefaction context.  n_epochs = number of epoch slots (num_subsample + 1). */
+/* First call on a fresh kmer_rarefaction context.  n_epochs = number of epoch slots (num_subsample + 1), at most 8 191 (an item has 13 bits
+ * for its epoch); up to 1 000 the received items are combined before they reach the table, past that they are counted occurrence by occurrence. */
 int  faqcs_kmer_partition(faqcs_ctx *ctx, uint32_t rank, uint32_t world, uint32_t n_epochs);
 /* Epoch of every segment of the NEXT submission (which then buckets instead of inserting). */
 int  faqcs_kmer_set_epochs(faqcs_ctx *ctx, const uint32_t *segment_epoch, uint32_t n_segments);
-/* After a submission: device array of (u64 key, u64 epoch) pairs grouped by destination rank 0..world-1 and the
- * number of pairs per destination (counts[world]).  Valid until the next submission. */
+/* After a submission: device array of 16-byte items grouped by destination rank 0..world-1 and the number of ITEMS per destination
+ * (counts[world]).  Valid until the next submission. */
 int  faqcs_kmer_outbox(faqcs_ctx *ctx, void **d_items, uint64_t *counts);
-/* The keys of the last submission's outbox copied to the host (all destinations; keys == NULL or cap too small: only the
- * count is returned).  For a caller that owns the table itself, like the reference's trim() seam (MAP<Word,size_t>,
+/* The canonical keys of EVERY OCCURRENCE of the last submission's outbox, expanded from its items on the host (all destinations; keys ==
+ * NULL or cap too small: only the count is returned).  For a caller that owns the table itself, like the reference's trim() seam (MAP<Word,size_t>,
  * trim.cpp:133-135): the key values are an injective re-encoding of the canonical k-mers, so counts and distinct counts
  * are the reference's, the key values are not. */
 int  faqcs_kmer_outbox_host(faqcs_ctx *ctx, uint64_t *keys, uint64_t cap, uint64_t *n_keys);
-/* Owner side: inserts n_items received pairs (device pointer; returns when the buffer may be reused). */
+/* Owner side: takes n_items received items (device pointer; returns when the buffer may be reused). */
 int  faqcs_kmer_insert_device(faqcs_ctx *ctx, const void *d_items, uint64_t n_items);
 /* (Replaces, like the calls around it, the per-call merge of thread-local k-mer tables into ONE map, trim.cpp:133-135, for a map that is
  * partitioned over devices.)  The exchange inside ONE process that drives several devices (faqcs_mi --gpus N --kmer_rarefaction): moves the last submission's
