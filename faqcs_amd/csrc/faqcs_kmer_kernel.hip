@@ -236,18 +236,38 @@ __global__ __launch_bounds__(256) void kmer_count_histogram(const KmerTable T, u
     for (uint32_t i = threadIdx.x; i < LOCAL; i += blockDim.x) h[i] = 0;
     __syncthreads();
     const uint64_t slots = kmer_table_total(T);
-    const uint64_t per_block = (slots + gridDim.x - 1) / gridDim.x; // contiguous slice per block: < 2^32 slots each
-    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = lo + per_block < slots ? lo + per_block : slots;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const KmerSlot sl = T.slots[i];
-        if (sl.key != ~0ull) {
-            if (RESET) reinterpret_cast<ulonglong2 *>(T.slots)[i] = make_ulonglong2(~0ull, 0xffffffff00000000ull); // (as kmer_table_init)
-            const uint32_t c = sl.count_m1 + 1u;
-            if (c < LOCAL && c < dense_n) atomicAdd(&h[c], 1u);
-            else if (c < dense_n) atomicAdd(&dense[c], 1ull);
-            else {
-                const unsigned long long s = atomicAdd(n_big, 1ull);
-                if (s < big_cap) big[s] = c;
+    // (the grid sweeps the table front to back, every block 4 x 256 consecutive slots per turn: the DRAM sees one stream, not 2 048)
+    const uint64_t hi = slots;
+    // Four slots per thread in flight (the pass is a stream over the whole table: 36 GB for 2^31 slots).  Most keys of a real run have
+    // been seen ONCE (sequencing errors): 64 lanes adding to h[1] serialise in the LDS, so the lanes of a wave whose key has count 1 add
+    // their number once (round 5: 18.5 -> see profiles/r5*/ ms per pass on the bench's table).
+    constexpr int U = 4;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * U * blockDim.x + threadIdx.x; i0 < hi; i0 += (uint64_t)gridDim.x * U * blockDim.x) {
+        KmerSlot sl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * blockDim.x;
+            sl[u].key = ~0ull; sl[u].count_m1 = 0; sl[u].first_epoch = 0;
+            if (i < hi) sl[u] = T.slots[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * blockDim.x;
+            const bool live = sl[u].key != ~0ull;
+            const uint32_t c = sl[u].count_m1 + 1u;
+            // (a 64-byte sector -- four slots, four neighbouring lanes -- is emptied whole when any of its slots is live: 16-byte stores into
+            // a sector cost a read-modify-write of it)
+            const unsigned long long lives = __ballot(live);
+            if (RESET && i < hi && ((lives >> (threadIdx.x & 60u)) & 0xfull)) reinterpret_cast<ulonglong2 *>(T.slots)[i] = make_ulonglong2(~0ull, 0xffffffff00000000ull); // (as kmer_table_init)
+            const unsigned long long once = __ballot(live && c == 1u);
+            if (once != 0ull && (int)(threadIdx.x & 63u) == __builtin_ctzll(once) && 1u < dense_n) atomicAdd(&h[1], (uint32_t)__popcll(once));
+            if (live && (c != 1u || 1u >= dense_n)) {
+                if (c < LOCAL && c < dense_n) atomicAdd(&h[c], 1u);
+                else if (c < dense_n) atomicAdd(&dense[c], 1ull);
+                else {
+                    const unsigned long long s = atomicAdd(n_big, 1ull);
+                    if (s < big_cap) big[s] = c;
+                }
             }
         }
     }

@@ -35,7 +35,7 @@ except Exception as e:
     print("traffic: %s" % e)
 try:
     txt = open(os.path.join(out, "pmc_adapter.txt")).read()
-    m = re.search(r"adapter_overlap\S*\s+(\{.*\})\s+per read", txt)
+    m = re.search(r"adapter_overlap[^{]*(\{.*\})\s+per read", txt)
     c = eval(m.group(1))
     put("adapter_counters.json", {"valu_per_read": c["SQ_INSTS_VALU"], "salu_per_read": c["SQ_INSTS_SALU"], "branches_per_read": c["SQ_INSTS_BRANCH"], "lds_per_read": c["SQ_INSTS_LDS"],
                                   "counters_source": "profiles/%s/pmc_adapter.txt (rocprofv3 --pmc over tools/ablate.py, 8 M reads of 150 bases, --adapter --polyA, 5 %% read-through; NOT measured in the bench run; scaled with the read length)" % tag})
@@ -80,7 +80,7 @@ b --config kmer --steps 3 --no-cpu-baseline > $out/bench_kmer_250bp_25Mpairs.jso
 FAQCS_KMER_EXTRACT16=0 b --config kmer --steps 2 --no-cpu-baseline > $out/bench_kmer_general_extraction_kernel_only.json   # (A/B: skm_extract for every read)
 FAQCS_KMER_DIRECT=1 b --config kmer --steps 2 --no-cpu-baseline > $out/bench_kmer_direct_one_atomic_per_occurrence.json   # rounds 1-3's path, same build, same box
 FAQCS_BENCH_SHARE_GPU=1 b --config kmer --gpus 2 --pairs 4e6 --steps 2 --no-cpu-baseline --kmer-table-log2 29 > $out/bench_kmer_2ranks_shared_gpu.json  # (the N-rank path on one GPU: not a measurement)
-FAQCS_BENCH_SHARE_GPU=1 b --config kmer --gpus 8 --pairs 1e6 --steps 2 --no-cpu-baseline --kmer-table-log2 27 > $out/bench_kmer_8ranks_shared_gpu.json
+FAQCS_BENCH_SHARE_GPU=1 b --config kmer --gpus 8 --pairs 5e5 --steps 2 --no-cpu-baseline --kmer-table-log2 28 > $out/bench_kmer_8ranks_shared_gpu.json
 FAQCS_BENCH_SHARE_GPU=1 b --gpus 8 --pairs 8e6 --steps 2 --no-cpu-baseline --no-other-configs --e2e-pairs 0 > $out/bench_plain_8ranks_shared_gpu.json
 # 4. rocprofv3 --kernel-trace --stats over shorter runs of the same commands
 prof bench_plain_43Mpairs python3 bench.py --pairs 42949630 --steps 3 --no-cpu-baseline --e2e-pairs 0 --no-other-configs
