@@ -190,7 +190,9 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
     if (wave == 0) { // the class order (one wave: ranks from ballots)
         const bool on = (uint32_t)lane < A.n_adapters;
         const int tl = on ? (int)s_meta[on ? lane : 0].x : 0;
-        const int cls = !on ? 6 : ((MAXLEN <= 320 && tl <= 128 && tpl_cached) ? (tl + 31) >> 5 : 5); // 1 ... 4 plane words; 5: long targets / uncached
+        // 1 ... 4 plane words; 5: long targets / uncached -- and an EMPTY adapter string (no plane word: class 0 would be placed by no pass below and
+        // leave its s_ord / s_pos entries uninitialised)
+        const int cls = !on ? 6 : ((MAXLEN <= 320 && tl > 0 && tl <= 128 && tpl_cached) ? (tl + 31) >> 5 : 5);
         uint32_t base = 0;
         for (int c = 1; c <= 5; ++c) {
             const uint64_t m = __ballot(cls == c);
