@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/faqcs_mi.h"
+#include "faqcs_pargz.h"
 
 namespace {
 
@@ -531,6 +532,8 @@ struct Source {
     gzFile gz = nullptr;
     BgzfReader bgzf;
     bool use_bgzf = false;
+    ParGzReader pargz; // an ordinary gzip file of some size: inflated by a pool of threads (faqcs_pargz.h)
+    bool use_pargz = false;
     Queue<RecBuf *> free_q;
     Queue<TextBlock *> block_free, block_full;
     std::thread io_th;
@@ -545,7 +548,14 @@ struct Source {
     {
         path = p;
         if (!getenv("FAQCS_MI_NO_BGZF") && BgzfReader::looks_like_bgzf(p)) use_bgzf = bgzf.open(p, std::max(2, nparse));
-        if (!use_bgzf) {
+        if (!use_bgzf && !getenv("FAQCS_MI_NO_PARGZ")) {
+            // threads per file: a tenth of the host's (2 ... 24; two files are read at once); files under 8 MB stay on gzread
+            const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+            const char *et = getenv("FAQCS_MI_PARGZ_THREADS"), *em = getenv("FAQCS_MI_PARGZ_MIN");
+            const int nt = et && atoi(et) > 0 ? atoi(et) : (int)std::min(24u, std::max(2u, hw / 10));
+            if (ParGzReader::eligible(p, em ? (size_t)atoll(em) : (size_t)(8u << 20))) use_pargz = pargz.open(p, nt); // (false: not ASCII, ...: gzread)
+        }
+        if (!use_bgzf && !use_pargz) {
             gz = gzopen(p.c_str(), "r");
             if (!gz) throw Fatal("I/O error");
             gzbuffer(gz, 1 << 20);
@@ -571,6 +581,7 @@ struct Source {
             const char *chunk = io.data();
             size_t got;
             if (use_bgzf) { got = bgzf.next(chunk); if (got == 0 && bgzf.failed) cur->io_error = true; }
+            else if (use_pargz) { got = pargz.next(chunk); if (got == 0 && pargz.failed) cur->io_error = true; }
             else {
                 const int g = gzread(gz, io.data(), (unsigned)io.size());
                 got = g > 0 ? (size_t)g : 0;
@@ -690,6 +701,7 @@ struct Source {
         for (auto &t : parsers) if (t.joinable()) t.join();
         if (gz) gzclose(gz);
         if (use_bgzf) bgzf.close();
+        if (use_pargz) pargz.close();
         for (auto &b : bufs) b.release();
     }
 };
@@ -2075,6 +2087,26 @@ int host_self_check(int argc, char **argv)
         size_t n;
         while ((n = r.next(data)) != 0) fwrite(data, 1, n, stdout);
         const bool bad = r.failed;
+        r.close();
+        fflush(stdout);
+        return bad ? 3 : 0;
+    }
+    if (argc >= 3 && !strcmp(argv[1], "--pargz_cat")) { // --pargz_cat <file.gz> [threads] [piece bytes]: the parallel inflate of an ordinary gzip file to stdout
+        ParGzReader r;
+        const int nt = argc >= 4 ? atoi(argv[3]) : 8;
+        const size_t piece = argc >= 5 ? (size_t)atoll(argv[4]) : 0;
+        if (!ParGzReader::eligible(argv[2], 18)) { fprintf(stderr, "not a gzip file\n"); return 2; }
+        if (!r.open(argv[2], nt, piece)) { fprintf(stderr, "not eligible (not ASCII, or the first piece does not inflate)\n"); return 4; }
+        const char *data;
+        size_t n;
+        while ((n = r.next(data)) != 0) fwrite(data, 1, n, stdout);
+        const bool bad = r.failed;
+        if (getenv("FAQCS_PARGZ_STATS")) {
+            size_t used = 0, dep = 0;
+            for (size_t k : r.crc_index) { ++used; (void)k; }
+            fprintf(stderr, "pieces %zu (of %zu bytes), on the chain %zu, bytes out %zu, failed %d\n", r.n_pieces, r.piece_bytes, used, r.total_out, (int)bad);
+            (void)dep;
+        }
         r.close();
         fflush(stdout);
         return bad ? 3 : 0;

@@ -1,0 +1,489 @@
+// faqcs_pargz.h -- parallel inflate of an ORDINARY (single-member) gzip file: what real FaQCs users feed it (fastq.cpp:8-125 reads
+// through gzread, one thread).  Host code only (zlib + threads); used by faqcs_cli.cpp's Source and by `faqcs_mi --pargz_cat`.
+//
+// A deflate stream has no index, and a block can refer to the 32 KB in front of it.  The approach is rapidgzip's / pugz's, built on zlib:
+//   1. the compressed file is cut at fixed byte offsets; the worker of a piece looks for the first bit position at or behind its offset
+//      that can start a dynamic-Huffman block -- a complete precode, valid repeat codes, an end-of-block code, complete literal / distance
+//      codes (what zlib's inflate_table accepts): about one bit position in a million passes, and a trial inflate decides;
+//   2. it inflates from there, block by block (Z_BLOCK gives the bit position of every block boundary), until it stands exactly where a
+//      later piece's worker started -- a start that no predecessor arrives at was a false positive and is dropped (its predecessor simply
+//      goes on through it);
+//   3. the window in front of a piece is unknown, so the piece is inflated TWICE with dictionaries that encode the window OFFSET instead
+//      of its contents: D1[k] = k & 255, D2[k] = 128 | k >> 8.  FASTQ is ASCII: a byte >= 128 in the second output is a byte that came
+//      (through any chain of copies) from window position k = out1 | (out2 & 127) << 8 -- markers propagate through copies by themselves;
+//   4. the consumer takes the pieces in file order and patches the marked bytes from the true last 32 KB of the piece before -- a few
+//      bytes per hundred --, and the CRC-32 of every patched piece (computed by the workers, combined with crc32_combine) must equal the
+//      member's trailer at the end, as must the length: a file that is not ASCII, or any slip of the speculation, ends the input with
+//      an error (like a corrupt file under gzread), it never yields different bytes silently.
+// What follows the first member (concatenated members) is inflated by the consumer through zlib's gzip decoder, as gzread would go on.
+#pragma once
+#include <zlib.h>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct ParGzReader {
+    static constexpr size_t WIN = 32768;
+    static constexpr uint64_t NO_START = ~0ull;
+    struct Piece {
+        std::atomic<uint64_t> start_bit{0};   // where its worker starts (NO_START: no block start found in its range); 0 = not known yet
+        std::atomic<int> state{0};            // 0 free, 1 claimed (finding / inflating), 2 done, 3 failed
+        uint64_t end_bit = 0;                 // the block boundary it stopped at (== start_bit of the piece that follows it in the chain)
+        size_t next_piece = 0;                // index of that piece (or n_pieces: it ran to the end of the member)
+        bool final_seen = false;              // the member's last block ended inside
+        size_t trailer_at = 0;                // byte offset of the member's trailer (final_seen)
+        bool known_window = false;            // piece 0: inflated once, nothing to patch
+        std::vector<uint8_t> out, mark;       // first / second output
+        size_t n_out = 0;
+        std::vector<uint32_t> dep;            // positions of the bytes that came from the unknown window
+        uint32_t crc = 0;
+        std::atomic<int> crc_state{0};        // 0 not asked, 1 asked, 2 done
+    };
+    const uint8_t *base = nullptr;
+    size_t size = 0, data_begin = 0, piece_bytes = 0, n_pieces = 0;
+    int fd = -1;
+    std::vector<Piece> pieces;
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    size_t next_claim = 0;       // next piece index a worker may claim
+    size_t consumed = 0;         // pieces the consumer is done with (chain order, but indices only grow)
+    size_t window_pieces = 0;    // how many pieces may be in flight behind `consumed`
+    bool closing = false;
+    bool failed = false;
+    // consumer state
+    size_t cur = 0;              // piece to hand out next
+    bool member_done = false, tail_init = false, tail_done = false, tail_mid = false;
+    uint8_t last_win[WIN];       // the true last 32 KB handed out so far (index WIN - 1 = the most recent byte)
+    size_t total_out = 0;
+    std::vector<std::pair<uint32_t, size_t>> crcs; // (crc, length) of the pieces in chain order
+    std::vector<size_t> crc_wait;                  // pieces whose CRC was asked for and not collected yet
+    z_stream tz;
+    std::vector<char> tail_out;
+    size_t tail_from = 0;
+
+    // ---- bits ----
+    inline uint64_t peek(uint64_t bit) const
+    { // 57 valid bits at `bit` (little-endian bit order, as deflate packs them); zeros past the end of the file
+        const size_t by = (size_t)(bit >> 3);
+        uint64_t v = 0;
+        if (by + 8 <= size) memcpy(&v, base + by, 8);
+        else for (size_t i = 0; by + i < size && i < 8; ++i) v |= (uint64_t)base[by + i] << (8 * i);
+        return v >> (bit & 7);
+    }
+    // Can a non-final dynamic-Huffman block start at `bit`?  Mirrors zlib's checks (inflate.c TABLE .. CODELENS, inftrees.c).
+    bool plausible_block(uint64_t bit) const
+    {
+        uint64_t v = peek(bit);
+        if ((v & 7) != 4) return false; // BFINAL = 0, BTYPE = 2 (bits: 0, then 01 little-endian = value 2 -> 0b100)
+        const unsigned hlit = (unsigned)((v >> 3) & 31) + 257, hdist = (unsigned)((v >> 8) & 31) + 1, hclen = (unsigned)((v >> 13) & 15) + 4;
+        if (hlit > 286 || hdist > 30) return false;
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        uint8_t pl[19];
+        memset(pl, 0, sizeof pl);
+        uint64_t at = bit + 17;
+        unsigned kraft = 0;
+        for (unsigned i = 0; i < hclen; ++i) {
+            const unsigned l = (unsigned)(peek(at) & 7);
+            at += 3;
+            pl[order[i]] = (uint8_t)l;
+            if (l) kraft += 128u >> l;
+        }
+        if (kraft != 128) return false; // the precode must be complete (inftrees.c: an incomplete CODES set is an error)
+        // canonical codes of the precode, a 7-bit look-up (code bits arrive LSB first: the table is indexed by the reversed code)
+        uint8_t sym_of[128], len_of[128];
+        {
+            unsigned code = 0;
+            for (unsigned l = 1; l <= 7; ++l) {
+                for (unsigned s = 0; s < 19; ++s)
+                    if (pl[s] == l) {
+                        unsigned rev = 0;
+                        for (unsigned b = 0; b < l; ++b) rev |= ((code >> b) & 1u) << (l - 1 - b);
+                        for (unsigned fill = rev; fill < 128; fill += 1u << l) { sym_of[fill] = (uint8_t)s; len_of[fill] = (uint8_t)l; }
+                        ++code;
+                    }
+                code <<= 1;
+            }
+        }
+        uint8_t lens[286 + 30];
+        unsigned n = 0, prev = 0;
+        const unsigned total = hlit + hdist;
+        while (n < total) {
+            const uint64_t w = peek(at);
+            const unsigned idx = (unsigned)(w & 127), s = sym_of[idx], l = len_of[idx];
+            at += l;
+            if (s < 16) { lens[n++] = (uint8_t)s; prev = s; continue; }
+            unsigned rep, val;
+            if (s == 16) { if (n == 0) return false; rep = 3 + (unsigned)((w >> l) & 3); at += 2; val = prev; }
+            else if (s == 17) { rep = 3 + (unsigned)((w >> l) & 7); at += 3; val = 0; prev = 0; }
+            else { rep = 11 + (unsigned)((w >> l) & 127); at += 7; val = 0; prev = 0; }
+            if (n + rep > total) return false;
+            while (rep--) lens[n++] = (uint8_t)val;
+        }
+        if ((at >> 3) >= size) return false;
+        if (lens[256] == 0) return false; // no end-of-block code
+        auto complete = [](const uint8_t *l, unsigned cnt, bool dist) {
+            unsigned long sum = 0; unsigned mx = 0, used = 0;
+            for (unsigned i = 0; i < cnt; ++i) if (l[i]) { sum += 32768ul >> l[i]; mx = std::max<unsigned>(mx, l[i]); ++used; }
+            if (sum > 32768ul) return false;              // over-subscribed
+            if (sum == 32768ul) return true;
+            if (dist && used == 0) return true;           // no distance codes at all (a block of literals)
+            return mx == 1;                               // incomplete: only the one-code case is accepted
+        };
+        return complete(lens, hlit, false) && complete(lens + hlit, hdist, true);
+    }
+
+    // ---- a raw inflate that starts at a bit position with a given 32 KB dictionary ----
+    struct Inflater {
+        z_stream z;
+        bool ok = false;
+        Inflater() { memset(&z, 0, sizeof z); }
+        ~Inflater() { if (ok) inflateEnd(&z); }
+        bool begin(const uint8_t *base, size_t size, uint64_t bit, const uint8_t *dict)
+        {
+            if (ok) inflateEnd(&z);
+            memset(&z, 0, sizeof z);
+            ok = inflateInit2(&z, -15) == Z_OK;
+            if (!ok) return false;
+            const size_t by = (size_t)(bit >> 3);
+            const int k = (int)(bit & 7);
+            if (k) {
+                if (inflatePrime(&z, 8 - k, base[by] >> k) != Z_OK) return false;
+                z.next_in = const_cast<Bytef *>(base + by + 1);
+                z.avail_in = (uInt)std::min<size_t>(size - by - 1, 1u << 30);
+            } else {
+                z.next_in = const_cast<Bytef *>(base + by);
+                z.avail_in = (uInt)std::min<size_t>(size - by, 1u << 30);
+            }
+            return !dict || inflateSetDictionary(&z, dict, (uInt)WIN) == Z_OK;
+        }
+        void refill(const uint8_t *base, size_t size)
+        {
+            if (z.avail_in == 0) { const size_t at = (size_t)(z.next_in - base); z.avail_in = (uInt)std::min<size_t>(size - at, 1u << 30); }
+        }
+    };
+    static const uint8_t *dict1() { static uint8_t d[WIN]; static bool init = [] { for (size_t k = 0; k < WIN; ++k) d[k] = (uint8_t)(k & 255); return true; }(); (void)init; return d; }
+    static const uint8_t *dict2() { static uint8_t d[WIN]; static bool init = [] { for (size_t k = 0; k < WIN; ++k) d[k] = (uint8_t)(128 | (k >> 8)); return true; }(); (void)init; return d; }
+
+    // ---- file ----
+    static bool eligible(const std::string &path, size_t min_size = 8u << 20)
+    {
+        struct stat st;
+        if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < min_size) return false;
+        uint8_t h[4] = {0, 0, 0, 0};
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        const size_t n = fread(h, 1, 4, f);
+        fclose(f);
+        return n == 4 && h[0] == 31 && h[1] == 139 && h[2] == 8;
+    }
+    // offset of the deflate data behind a gzip member header at `o` (0: not a header / truncated)
+    size_t header_end(size_t o) const
+    {
+        if (o + 10 > size || base[o] != 31 || base[o + 1] != 139 || base[o + 2] != 8) return 0;
+        const unsigned flg = base[o + 3];
+        size_t p = o + 10;
+        if (flg & 4) { if (p + 2 > size) return 0; p += 2 + (base[p] | ((size_t)base[p + 1] << 8)); }
+        if (flg & 8) { while (p < size && base[p]) ++p; ++p; }
+        if (flg & 16) { while (p < size && base[p]) ++p; ++p; }
+        if (flg & 2) p += 2;
+        return p < size ? p : 0;
+    }
+    bool open(const std::string &path, int n_threads, size_t piece = 0)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); fd = -1; return false; }
+        size = (size_t)st.st_size;
+        void *mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (mp == MAP_FAILED) { ::close(fd); fd = -1; return false; }
+        base = (const uint8_t *)mp;
+        data_begin = header_end(0);
+        if (!data_begin) { close(); return false; }
+        n_threads = std::max(1, n_threads);
+        piece_bytes = piece ? piece : std::max<size_t>(1u << 20, std::min<size_t>(8u << 20, (size - data_begin) / (size_t)(4 * n_threads) + 1));
+        n_pieces = (size - data_begin + piece_bytes - 1) / piece_bytes;
+        pieces = std::vector<Piece>(n_pieces);
+        window_pieces = (size_t)(3 * n_threads + 2);
+        memset(last_win, 0, sizeof last_win);
+        // piece 0 in this thread: the window is known (empty), and its bytes decide whether the file qualifies (ASCII)
+        pieces[0].start_bit.store((uint64_t)data_begin * 8);
+        pieces[0].known_window = true;
+        pieces[0].state.store(1);
+        next_claim = 1;
+        for (int i = 0; i < n_threads; ++i) workers.emplace_back([this] { work(); }); // (they look for the starts piece 0 will stop at)
+        inflate_piece(0);
+        cv_done.notify_all();
+        if (pieces[0].state.load() != 2) { close(); return false; }
+        for (size_t i = 0; i < pieces[0].n_out; ++i) if (pieces[0].out[i] >= 128) { close(); return false; } // not ASCII: the markers would be ambiguous
+        return true;
+    }
+    void close()
+    {
+        { std::lock_guard<std::mutex> l(m); closing = true; }
+        cv_work.notify_all(); cv_done.notify_all();
+        for (auto &t : workers) if (t.joinable()) t.join();
+        workers.clear();
+        if (tail_init && !tail_done) { inflateEnd(&tz); tail_done = true; }
+        if (base) munmap(const_cast<uint8_t *>(base), size);
+        base = nullptr;
+        if (fd >= 0) ::close(fd);
+        fd = -1;
+        pieces.clear();
+    }
+    uint64_t range_begin_bit(size_t i) const { return (uint64_t)(data_begin + i * piece_bytes) * 8; }
+
+    // ---- workers ----
+    void work()
+    {
+        for (;;) {
+            size_t i = 0;
+            bool crc_job = false;
+            {
+                std::unique_lock<std::mutex> l(m);
+                for (;;) {
+                    if (closing) return;
+                    // a CRC somebody asked for goes first (the consumer waits for them at the end)
+                    bool found = false;
+                    if (!crc_wait.empty()) {
+                        i = crc_wait.back(); crc_wait.pop_back();
+                        pieces[i].crc_state.store(3); // taken
+                        found = crc_job = true;
+                    }
+                    if (found) break;
+                    if (next_claim < n_pieces && next_claim < consumed + window_pieces && !failed) { i = next_claim++; pieces[i].state.store(1); break; }
+                    cv_work.wait(l);
+                }
+            }
+            if (crc_job) {
+                Piece &p = pieces[i];
+                p.crc = (uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), p.out.data(), p.n_out);
+                { std::lock_guard<std::mutex> l(m); p.crc_state.store(2); }
+                cv_done.notify_all();
+                continue;
+            }
+            // find where this piece can start
+            Piece &p = pieces[i];
+            const uint64_t lo = range_begin_bit(i), hi = std::min<uint64_t>(range_begin_bit(i + 1), (uint64_t)size * 8);
+            uint64_t s = NO_START;
+            for (uint64_t b = lo; b < hi; ++b)
+                if (plausible_block(b) && trial(b)) { s = b; break; }
+            { std::lock_guard<std::mutex> l(m); p.start_bit.store(s); if (s == NO_START) p.state.store(3); }
+            cv_done.notify_all(); // (a predecessor may be waiting to learn where this piece starts)
+            if (s == NO_START) continue;
+            inflate_piece(i);
+            cv_done.notify_all();
+        }
+    }
+    // a candidate must inflate 64 KB (or to a block end) without an error
+    bool trial(uint64_t bit) const
+    {
+        Inflater f;
+        if (!f.begin(base, size, bit, dict1())) return false;
+        std::vector<uint8_t> tmp(1u << 16);
+        f.z.next_out = tmp.data(); f.z.avail_out = (uInt)tmp.size();
+        const int rc = inflate(&f.z, Z_BLOCK);
+        return rc == Z_OK || rc == Z_STREAM_END || (rc == Z_BUF_ERROR && f.z.avail_out == 0);
+    }
+    // Inflates piece i from its start to the first block boundary that is the start of a later piece (or to the end of the member).
+    void inflate_piece(size_t i)
+    {
+        Piece &p = pieces[i];
+        const uint64_t start = p.start_bit.load();
+        Inflater f;
+        auto fail = [&] { std::lock_guard<std::mutex> l(m); p.state.store(3); };
+        if (!f.begin(base, size, start, p.known_window ? nullptr : dict1())) { fail(); return; }
+        p.out.resize(std::max<size_t>(p.out.size(), piece_bytes * 4 + (1u << 20)));
+        p.n_out = 0; p.final_seen = false;
+        size_t j = i + 1; // the first later piece whose start this one has not passed yet
+        for (;;) {
+            if (p.n_out + (1u << 16) > p.out.size()) p.out.resize(p.out.size() + p.out.size() / 2);
+            f.z.next_out = p.out.data() + p.n_out;
+            f.z.avail_out = (uInt)std::min<size_t>(p.out.size() - p.n_out, 1u << 30);
+            f.refill(base, size);
+            const size_t before = f.z.avail_out;
+            const int rc = inflate(&f.z, Z_BLOCK);
+            p.n_out += before - f.z.avail_out;
+            if (rc == Z_STREAM_END) {
+                p.final_seen = true; p.trailer_at = (size_t)(f.z.next_in - base); p.next_piece = n_pieces;
+                p.end_bit = (uint64_t)p.trailer_at * 8;
+                break;
+            }
+            if (rc != Z_OK) { fail(); return; } // a data error, or Z_BUF_ERROR: there is always room for output, so the file ends inside the member
+            if (!(f.z.data_type & 128)) continue; // not at a block boundary (output space ran out)
+            const uint64_t here = (uint64_t)(f.z.next_in - base) * 8 - (uint64_t)(f.z.data_type & 63);
+            // later pieces whose start lies at or before `here`: the one that starts exactly here ends this piece
+            bool stop = false;
+            while (j < n_pieces && range_begin_bit(j) <= here) {
+                uint64_t s;
+                { // wait for piece j's worker to publish its start (pieces past the claim window have none yet: go on through them)
+                    std::unique_lock<std::mutex> l(m);
+                    while (!closing && pieces[j].start_bit.load() == 0 && pieces[j].state.load() != 0) cv_done.wait(l);
+                    if (closing) { p.state.store(3); return; }
+                    s = pieces[j].state.load() == 0 ? NO_START : pieces[j].start_bit.load();
+                    if (pieces[j].state.load() == 0) { if (next_claim == j) ++next_claim; pieces[j].state.store(3); pieces[j].start_bit.store(NO_START); } // nobody will start it: this piece runs through it
+                }
+                if (s == here) { stop = true; break; }
+                if (s == NO_START || s < here) { ++j; continue; } // no start there, or one this chain never arrived at: dropped
+                break;                                             // its start lies ahead
+            }
+            if (stop) { p.end_bit = here; p.next_piece = j; break; }
+        }
+        if (!p.known_window) { // the same range again with the second dictionary: n_out bytes
+            Inflater g;
+            if (!g.begin(base, size, start, dict2())) { fail(); return; }
+            p.mark.resize(p.n_out + 1);
+            size_t got = 0;
+            while (got < p.n_out) {
+                g.z.next_out = p.mark.data() + got;
+                g.z.avail_out = (uInt)std::min<size_t>(p.n_out - got, 1u << 30);
+                g.refill(base, size);
+                const size_t before = g.z.avail_out;
+                const int rc = inflate(&g.z, Z_NO_FLUSH);
+                got += before - g.z.avail_out;
+                if (rc == Z_STREAM_END) break;
+                if (rc != Z_OK && rc != Z_BUF_ERROR) { fail(); return; }
+                if (rc == Z_BUF_ERROR && before == g.z.avail_out && g.z.avail_in == 0) { fail(); return; }
+            }
+            if (got != p.n_out) { fail(); return; }
+            p.dep.clear();
+            size_t k = 0;
+            for (; k + 8 <= p.n_out; k += 8) {
+                uint64_t w8;
+                memcpy(&w8, p.mark.data() + k, 8);
+                if (w8 & 0x8080808080808080ull)
+                    for (size_t t = 0; t < 8; ++t) if (p.mark[k + t] & 128) p.dep.push_back((uint32_t)(k + t));
+            }
+            for (; k < p.n_out; ++k) if (p.mark[k] & 128) p.dep.push_back((uint32_t)k);
+        }
+        std::lock_guard<std::mutex> l(m);
+        p.state.store(2);
+    }
+
+    // ---- consumer ----
+    // the next run of inflated bytes in file order (valid until the next call); 0 = end of data, or `failed`
+    size_t next(const char *&data)
+    {
+        if (failed) return 0;
+        if (!member_done) {
+            Piece *p;
+            {
+                std::unique_lock<std::mutex> l(m);
+                // the piece the consumer held is free now; buffers of the pieces behind it go back (a handed-out piece once its CRC is
+                // done, a dropped one once its worker has left it)
+                if (cur > consumed) { consumed = cur; cv_work.notify_all(); }
+                while (release_lo < consumed && release_lo < n_pieces) {
+                    Piece &q = pieces[release_lo];
+                    const int st = q.state.load(), cs = q.crc_state.load();
+                    if (st == 1 || cs == 1 || cs == 3) break; // still in use
+                    std::vector<uint8_t>().swap(q.out); std::vector<uint8_t>().swap(q.mark); std::vector<uint32_t>().swap(q.dep);
+                    ++release_lo;
+                }
+                for (;;) {
+                    const int st = pieces[cur].state.load();
+                    if (st == 2) break;
+                    if (st == 3) { failed = true; return 0; } // a piece ON the chain failed: the stream is corrupt here
+                    cv_done.wait(l);
+                }
+                p = &pieces[cur];
+            }
+            if (!p->known_window) { // patch what came from the window in front of the piece
+                for (uint32_t pos : p->dep) {
+                    const size_t k = (size_t)p->out[pos] | ((size_t)(p->mark[pos] & 127) << 8);
+                    p->out[pos] = last_win[k];
+                }
+            }
+            // the window behind this piece
+            if (p->n_out >= WIN) memcpy(last_win, p->out.data() + p->n_out - WIN, WIN);
+            else if (p->n_out) { memmove(last_win, last_win + p->n_out, WIN - p->n_out); memcpy(last_win + WIN - p->n_out, p->out.data(), p->n_out); }
+            total_out += p->n_out;
+            { std::lock_guard<std::mutex> l(m); p->crc_state.store(1); crc_wait.push_back(cur); }
+            cv_work.notify_all();
+            crcs.emplace_back(0u, p->n_out);
+            crc_index.push_back(cur);
+            data = reinterpret_cast<const char *>(p->out.data());
+            const size_t n = p->n_out;
+            if (p->final_seen) { member_done = true; tail_from = p->trailer_at; if (!check_member()) { failed = true; return n ? n : 0; } hold = cur; cur = n_pieces; }
+            else { hold = cur; cur = p->next_piece; if (cur >= n_pieces) { failed = true; return n; } } // (the chain ran out of file without a final block)
+            if (n) return n;
+            return next(data);
+        }
+        return next_tail(data);
+    }
+    std::vector<size_t> crc_index;
+    size_t hold = 0, release_lo = 0;
+    // the member's trailer against the pieces' CRCs and the length
+    bool check_member()
+    {
+        { // every CRC asked for so far
+            std::unique_lock<std::mutex> l(m);
+            for (;;) {
+                bool all = true;
+                for (size_t k : crc_index) if (pieces[k].crc_state.load() != 2) { all = false; break; }
+                if (all || closing) break;
+                cv_done.wait(l);
+            }
+            if (closing) return false;
+        }
+        if (tail_from + 8 > size) return false;
+        uint32_t crc = 0;
+        bool first = true;
+        for (size_t k = 0; k < crc_index.size(); ++k) {
+            const Piece &p = pieces[crc_index[k]];
+            if (first) { crc = p.crc; first = false; }
+            else crc = (uint32_t)crc32_combine(crc, p.crc, (z_off_t)crcs[k].second);
+        }
+        uint32_t want_crc, want_len;
+        memcpy(&want_crc, base + tail_from, 4); memcpy(&want_len, base + tail_from + 4, 4);
+        tail_from += 8;
+        return crc == want_crc && (uint32_t)total_out == want_len;
+    }
+    // what follows the first member: further gzip members through zlib's gzip decoder (gzread reads concatenated members); bytes that
+    // do not start with the gzip magic are trailing garbage and end the data, as in zlib
+    size_t next_tail(const char *&data)
+    {
+        { std::lock_guard<std::mutex> l(m); if (consumed < n_pieces) { consumed = n_pieces; } }
+        if (tail_done) return 0;
+        if (!tail_init) {
+            if (tail_from >= size || size - tail_from < 2 || base[tail_from] != 31 || base[tail_from + 1] != 139) { tail_done = true; return 0; }
+            memset(&tz, 0, sizeof tz);
+            if (inflateInit2(&tz, 15 + 16) != Z_OK) { failed = true; tail_done = true; return 0; }
+            tz.next_in = const_cast<Bytef *>(base + tail_from);
+            tz.avail_in = (uInt)std::min<size_t>(size - tail_from, 1u << 30);
+            tail_out.resize(4u << 20);
+            tail_init = true; tail_mid = true;
+        }
+        for (;;) {
+            if (tz.avail_in == 0) {
+                const size_t at = (size_t)(tz.next_in - base);
+                if (at >= size) { tail_done = true; inflateEnd(&tz); if (tail_mid) failed = true; return 0; }
+                tz.avail_in = (uInt)std::min<size_t>(size - at, 1u << 30);
+            }
+            tz.next_out = reinterpret_cast<Bytef *>(tail_out.data());
+            tz.avail_out = (uInt)tail_out.size();
+            const int rc = inflate(&tz, Z_NO_FLUSH);
+            const size_t got = tail_out.size() - tz.avail_out;
+            if (rc == Z_STREAM_END) {
+                tail_mid = false;
+                const size_t at = (size_t)(tz.next_in - base);
+                if (at + 2 <= size && base[at] == 31 && base[at + 1] == 139) { inflateReset(&tz); tz.next_in = const_cast<Bytef *>(base + at); tz.avail_in = (uInt)std::min<size_t>(size - at, 1u << 30); tail_mid = true; }
+                else { tail_done = true; inflateEnd(&tz); }
+            } else if (rc != Z_OK && rc != Z_BUF_ERROR) { failed = true; tail_done = true; inflateEnd(&tz); return 0; }
+            if (got) { data = tail_out.data(); return got; }
+            if (tail_done) return 0;
+        }
+    }
+};

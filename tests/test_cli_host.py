@@ -232,3 +232,85 @@ def test_worker_process_only_outside_profilers():
     assert plan(HSA_TOOLS_LIB="libx.so") == "one process"
     assert plan(FAQCS_MI_NO_FORK="1") == "one process"
     assert plan(FAQCS_MI_NO_FORK="0") == "worker"
+
+
+# ---- parallel inflate of ordinary gzip files (faqcs_pargz.h; `faqcs_mi --pargz_cat`: host only) --------------------------------------
+def _fastq_text(n, L=150, seed=5):
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    bases = np.frombuffer(b"ACGTN", np.uint8)
+    recs = []
+    for i in range(n):
+        l = int(rng.integers(L // 2, L + 1))
+        recs.append(b"@SYN:%09d/1 some text\n" % i + bases[rng.choice(5, l, p=[.249, .249, .249, .249, .004])].tobytes() + b"\n+\n"
+                    + (rng.integers(2, 41, l) + 33).astype(np.uint8).tobytes() + b"\n")
+    return b"".join(recs)
+
+
+def _pargz(path, threads, piece):
+    r = subprocess.run([CLI, "--pargz_cat", str(path), str(threads), str(piece)], capture_output=True, timeout=300)
+    return r.returncode, r.stdout
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_parallel_inflate_equals_zlib(level, tmp_path):
+    """An ordinary single-member .fastq.gz through the speculative parallel inflate (block starts guessed, two inflates with offset-encoding
+    dictionaries, markers patched in order, CRC and length checked): byte-identical to zlib's own output, for every compression level,
+    piece size and thread count -- pieces far smaller than a deflate block included (most of them find no block start and are run through)."""
+    import gzip
+
+    text = _fastq_text(40000, seed=level)
+    p = tmp_path / "r.fq.gz"
+    p.write_bytes(gzip.compress(text, level))
+    for threads, piece in ((4, 300000), (3, 70001), (8, 1 << 20), (2, 20000)):
+        rc, out = _pargz(p, threads, piece)
+        assert rc == 0 and out == text, "level %d threads %d piece %d: rc %d, %d bytes" % (level, threads, piece, rc, len(out))
+
+
+def test_parallel_inflate_on_odd_files(tmp_path):
+    """Stored blocks only (level 0: no dynamic block to find), concatenated members (the first in parallel, the rest through zlib's gzip decoder, as
+    gzread reads on), trailing garbage (ends the data, as in zlib), a header with a file name, an empty member, a file that is not ASCII
+    (refused: the markers would be ambiguous -- the caller stays on gzread)."""
+    import gzip
+    import io
+
+    text = _fastq_text(12000, seed=77)
+    cases = {}
+    cases["stored"] = (gzip.compress(text, 0), text)
+    cases["two_members"] = (gzip.compress(text, 6) + gzip.compress(text[:100000], 9), text + text[:100000])
+    cases["garbage_behind"] = (gzip.compress(text, 6) + b"\\0\\0not gzip", text)
+    b = io.BytesIO()
+    with gzip.GzipFile(filename="reads_R1.fastq", mode="wb", fileobj=b, compresslevel=5) as f:
+        f.write(text)
+    cases["named"] = (b.getvalue(), text)
+    cases["empty_then_data"] = (gzip.compress(b"", 6) + gzip.compress(text, 6), text)
+    for name, (blob, want) in cases.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(blob)
+        rc, out = _pargz(p, 4, 150000)
+        assert rc == 0 and out == want, "%s: rc %d, %d bytes (want %d)" % (name, rc, len(out), len(want))
+    p = tmp_path / "binary.gz"
+    p.write_bytes(gzip.compress(bytes(range(256)) * 4000, 6))
+    rc, out = _pargz(p, 4, 150000)
+    assert rc == 4 and out == b""
+
+
+def test_parallel_inflate_reports_damage(tmp_path):
+    """A truncated file and a file with a flipped byte end with an error (exit 3) after a prefix of the true text, never with different bytes
+    and success: a piece ON the chain that fails ends the input there, and a wrong byte that still inflates is caught by the member's CRC."""
+    import gzip
+
+    text = _fastq_text(30000, seed=3)
+    blob = gzip.compress(text, 6)
+    p = tmp_path / "cut.gz"
+    p.write_bytes(blob[: len(blob) * 2 // 3])
+    rc, out = _pargz(p, 4, 200000)
+    assert rc == 3 and text.startswith(out) and len(out) < len(text)
+    for at in (len(blob) // 2, len(blob) // 3 + 17, len(blob) - 6):
+        bad = bytearray(blob)
+        bad[at] ^= 0x5A
+        p = tmp_path / ("flip%d.gz" % at)
+        p.write_bytes(bytes(bad))
+        rc, out = _pargz(p, 4, 200000)
+        assert rc == 3, "flip at %d: rc %d" % (at, rc)

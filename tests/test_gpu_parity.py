@@ -1532,6 +1532,57 @@ def test_native_cli_pipes_a_report_script_to_R(tmp_path):
         assert all((t in left) == (mode == "debug") for t in want), left                # and they are gone afterwards unless --debug
 
 
+def test_native_cli_inflates_ordinary_gzip_in_parallel(tmp_path):
+    """Ordinary single-member .fastq.gz inputs (what FaQCs users feed it; fastq.cpp:8-125 reads them through gzread) are inflated by a pool
+    of threads (faqcs_pargz.h: guessed block starts, offset-encoding dictionaries, CRC-checked): the same output bytes as from the plain
+    files and as through gzread (FAQCS_MI_NO_PARGZ=1); a cut file and a file with a wrong byte end the run like a failing gzread."""
+    import gzip
+    import hashlib
+    import subprocess
+
+    import make_fixtures
+
+    rng = np.random.Generator(np.random.PCG64([606, SEED]))
+    n = 2 * 32768 + 777
+    texts = [[], []]
+    for i in range(n):
+        for m in (0, 1):
+            s, q = make_fixtures._adv_read(rng, 150)
+            if len(s) == 0:
+                s, q = np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"IIII", np.uint8)
+            texts[m].append(b"@p%d/%d\n%s\n+\n%s\n" % (i, m + 1, s.upper().tobytes() if hasattr(s, "upper") else s.tobytes(), q.tobytes()))
+    plain, gz = [], []
+    for m in (0, 1):
+        data = b"".join(texts[m])
+        plain.append(str(tmp_path / ("r%d.fastq" % (m + 1))))
+        gz.append(str(tmp_path / ("r%d.fastq.gz" % (m + 1))))
+        with open(plain[-1], "wb") as f:
+            f.write(data)
+        with open(gz[-1], "wb") as f:
+            f.write(gzip.compress(data, 6))
+
+    def run(tag, inputs, env_extra):
+        out = tmp_path / tag
+        env = dict(os.environ, FAQCS_MI_PARGZ_MIN="1", FAQCS_MI_PARGZ_THREADS="6", **env_extra)
+        r = subprocess.run([_CLI_BIN, "-1", inputs[0], "-2", inputs[1], "-d", str(out), "--ascii", "33", "--trim_only"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        return {f: hashlib.md5(open(out / f, "rb").read()).hexdigest() for f in sorted(os.listdir(out))}
+
+    want = run("plain", plain, {})
+    assert run("pargz", gz, {}) == want
+    assert run("gzread", gz, {"FAQCS_MI_NO_PARGZ": "1"}) == want
+    data = open(gz[0], "rb").read()
+    for tag, blob in (("cut", data[: len(data) // 2]), ("flip", data[: len(data) // 2] + bytes([data[len(data) // 2] ^ 0x21]) + data[len(data) // 2 + 1:])):
+        bad = str(tmp_path / (tag + ".fastq.gz"))
+        with open(bad, "wb") as f:
+            f.write(blob)
+        for env_extra in ({}, {"FAQCS_MI_NO_PARGZ": "1"}):
+            r = subprocess.run([_CLI_BIN, "-u", bad, "-d", str(tmp_path / (tag + "_out" + str(len(env_extra)))), "--ascii", "33", "--trim_only"],
+                               env=dict(os.environ, FAQCS_MI_PARGZ_MIN="1", **env_extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            assert r.returncode == 1 and b"Caught the error" in r.stderr, (tag, env_extra, r.stderr.decode()[-400:])
+
+
 def _write_bgzf(path, data, block=60000, level=4):
     """BGZF (bgzip / htslib): gzip members of <= 64 KiB with a 'BC' extra subfield that holds the member's size - 1."""
     import struct
