@@ -35,6 +35,21 @@
 #include <vector>
 
 struct ParGzReader {
+    // output buffers: plain malloc'd memory, never zero-filled, recycled through a pool (a piece inflates to tens of megabytes: a fresh
+    // std::vector per piece spent more time in page faults and memset than in inflate)
+    struct Buf {
+        uint8_t *p = nullptr; size_t cap = 0;
+        uint8_t *data() { return p; }
+        const uint8_t *data() const { return p; }
+        size_t size() const { return cap; }
+        uint8_t &operator[](size_t i) { return p[i]; }
+        const uint8_t &operator[](size_t i) const { return p[i]; }
+        void resize(size_t n) { if (n > cap) { p = (uint8_t *)realloc(p, n); cap = p ? n : 0; } }
+    };
+    std::vector<Buf> pool;
+    Buf take_buf() { std::lock_guard<std::mutex> l(pm); if (pool.empty()) return Buf(); Buf b = pool.back(); pool.pop_back(); return b; }
+    void give_buf(Buf &b) { if (!b.p) return; std::lock_guard<std::mutex> l(pm); pool.push_back(b); b = Buf(); }
+    std::mutex pm;
     static constexpr size_t WIN = 32768;
     static constexpr uint64_t NO_START = ~0ull;
     struct Piece {
@@ -45,7 +60,7 @@ struct ParGzReader {
         bool final_seen = false;              // the member's last block ended inside
         size_t trailer_at = 0;                // byte offset of the member's trailer (final_seen)
         bool known_window = false;            // piece 0: inflated once, nothing to patch
-        std::vector<uint8_t> out, mark;       // first / second output
+        Buf out, mark;                        // first / second output
         size_t n_out = 0;
         std::vector<uint32_t> dep;            // positions of the bytes that came from the unknown window
         uint32_t crc = 0;
@@ -214,7 +229,7 @@ struct ParGzReader {
         data_begin = header_end(0);
         if (!data_begin) { close(); return false; }
         n_threads = std::max(1, n_threads);
-        piece_bytes = piece ? piece : std::max<size_t>(1u << 20, std::min<size_t>(8u << 20, (size - data_begin) / (size_t)(4 * n_threads) + 1));
+        piece_bytes = piece ? piece : std::max<size_t>(512u << 10, std::min<size_t>(4u << 20, (size - data_begin) / (size_t)(8 * n_threads) + 1));
         n_pieces = (size - data_begin + piece_bytes - 1) / piece_bytes;
         pieces = std::vector<Piece>(n_pieces);
         window_pieces = (size_t)(3 * n_threads + 2);
@@ -242,6 +257,9 @@ struct ParGzReader {
         base = nullptr;
         if (fd >= 0) ::close(fd);
         fd = -1;
+        for (auto &q : pieces) { free(q.out.p); free(q.mark.p); q.out = Buf(); q.mark = Buf(); }
+        for (auto &b : pool) free(b.p);
+        pool.clear();
         pieces.clear();
     }
     uint64_t range_begin_bit(size_t i) const { return (uint64_t)(data_begin + i * piece_bytes) * 8; }
@@ -306,6 +324,7 @@ struct ParGzReader {
         Inflater f;
         auto fail = [&] { std::lock_guard<std::mutex> l(m); p.state.store(3); };
         if (!f.begin(base, size, start, p.known_window ? nullptr : dict1())) { fail(); return; }
+        if (!p.out.p) p.out = take_buf();
         p.out.resize(std::max<size_t>(p.out.size(), piece_bytes * 4 + (1u << 20)));
         p.n_out = 0; p.final_seen = false;
         size_t j = i + 1; // the first later piece whose start this one has not passed yet
@@ -345,6 +364,7 @@ struct ParGzReader {
         if (!p.known_window) { // the same range again with the second dictionary: n_out bytes
             Inflater g;
             if (!g.begin(base, size, start, dict2())) { fail(); return; }
+            if (!p.mark.p) p.mark = take_buf();
             p.mark.resize(p.n_out + 1);
             size_t got = 0;
             while (got < p.n_out) {
@@ -389,7 +409,7 @@ struct ParGzReader {
                     Piece &q = pieces[release_lo];
                     const int st = q.state.load(), cs = q.crc_state.load();
                     if (st == 1 || cs == 1 || cs == 3) break; // still in use
-                    std::vector<uint8_t>().swap(q.out); std::vector<uint8_t>().swap(q.mark); std::vector<uint32_t>().swap(q.dep);
+                    give_buf(q.out); give_buf(q.mark); std::vector<uint32_t>().swap(q.dep);
                     ++release_lo;
                 }
                 for (;;) {
