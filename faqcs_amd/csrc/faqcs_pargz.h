@@ -11,10 +11,12 @@
 //   3. the window in front of a piece is unknown, so the piece is inflated TWICE with dictionaries that encode the window OFFSET instead
 //      of its contents: D1[k] = k & 255, D2[k] = 128 | k >> 8.  FASTQ is ASCII: a byte >= 128 in the second output is a byte that came
 //      (through any chain of copies) from window position k = out1 | (out2 & 127) << 8 -- markers propagate through copies by themselves;
-//   4. the consumer takes the pieces in file order and patches the marked bytes from the true last 32 KB of the piece before -- a few
-//      bytes per hundred --, and the CRC-32 of every patched piece (computed by the workers, combined with crc32_combine) must equal the
-//      member's trailer at the end, as must the length: a file that is not ASCII, or any slip of the speculation, ends the input with
-//      an error (like a corrupt file under gzread), it never yields different bytes silently.
+//   4. a chain thread walks the pieces in file order and resolves only the LAST 32 KB of each -- the window of the next one --; the bulk of
+//      a piece (in FASTQ a quarter of the bytes reach back into the unknown window through chains of copies: every header line copies the
+//      one before) is patched by the workers in parallel once its window is known, together with its CRC-32; the consumer hands the
+//      patched pieces out in order; the CRCs (crc32_combine) must equal the member's trailer at the end, as must the length: a file that
+//      is not ASCII, or any slip of the speculation, ends the input with an error (like a corrupt file under gzread), it never yields
+//      different bytes silently.
 // What follows the first member (concatenated members) is inflated by the consumer through zlib's gzip decoder, as gzread would go on.
 #pragma once
 #include <zlib.h>
@@ -62,9 +64,9 @@ struct ParGzReader {
         bool known_window = false;            // piece 0: inflated once, nothing to patch
         Buf out, mark;                        // first / second output
         size_t n_out = 0;
-        std::vector<uint32_t> dep;            // positions of the bytes that came from the unknown window
+        std::vector<uint8_t> win;             // the true 32 KB in front of the piece (set by the chain thread)
         uint32_t crc = 0;
-        std::atomic<int> crc_state{0};        // 0 not asked, 1 asked, 2 done
+        std::atomic<int> crc_state{0};        // patch + CRC task: 0 not asked, 1 asked, 3 taken, 2 done
     };
     const uint8_t *base = nullptr;
     size_t size = 0, data_begin = 0, piece_bytes = 0, n_pieces = 0;
@@ -240,6 +242,7 @@ struct ParGzReader {
         pieces[0].state.store(1);
         next_claim = 1;
         for (int i = 0; i < n_threads; ++i) workers.emplace_back([this] { work(); }); // (they look for the starts piece 0 will stop at)
+        chain_th = std::thread([this] { chain(); });
         inflate_piece(0);
         cv_done.notify_all();
         if (pieces[0].state.load() != 2) { close(); return false; }
@@ -252,6 +255,7 @@ struct ParGzReader {
         cv_work.notify_all(); cv_done.notify_all();
         for (auto &t : workers) if (t.joinable()) t.join();
         workers.clear();
+        if (chain_th.joinable()) chain_th.join();
         if (tail_init && !tail_done) { inflateEnd(&tz); tail_done = true; }
         if (base) munmap(const_cast<uint8_t *>(base), size);
         base = nullptr;
@@ -288,6 +292,7 @@ struct ParGzReader {
             }
             if (crc_job) {
                 Piece &p = pieces[i];
+                if (!p.known_window) patch(p, 0, p.n_out);
                 p.crc = (uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), p.out.data(), p.n_out);
                 { std::lock_guard<std::mutex> l(m); p.crc_state.store(2); }
                 cv_done.notify_all();
@@ -379,19 +384,55 @@ struct ParGzReader {
                 if (rc == Z_BUF_ERROR && before == g.z.avail_out && g.z.avail_in == 0) { fail(); return; }
             }
             if (got != p.n_out) { fail(); return; }
-            p.dep.clear();
-            size_t k = 0;
-            for (; k + 8 <= p.n_out; k += 8) {
-                uint64_t w8;
-                memcpy(&w8, p.mark.data() + k, 8);
-                if (w8 & 0x8080808080808080ull)
-                    for (size_t t = 0; t < 8; ++t) if (p.mark[k + t] & 128) p.dep.push_back((uint32_t)(k + t));
-            }
-            for (; k < p.n_out; ++k) if (p.mark[k] & 128) p.dep.push_back((uint32_t)k);
         }
         std::lock_guard<std::mutex> l(m);
         p.state.store(2);
     }
+
+    // out[k] of the bytes [lo, hi) that came from the window in front of the piece: the marker (mark[k] & 128) carries the window offset
+    static void patch(Piece &p, size_t lo, size_t hi)
+    {
+        const uint8_t *w = p.win.data();
+        uint8_t *o = p.out.data();
+        const uint8_t *mk = p.mark.data();
+        size_t k = lo;
+        for (; k + 8 <= hi; k += 8) {
+            uint64_t w8;
+            memcpy(&w8, mk + k, 8);
+            if (w8 & 0x8080808080808080ull)
+                for (size_t t = 0; t < 8; ++t) if (mk[k + t] & 128) o[k + t] = w[(size_t)o[k + t] | ((size_t)(mk[k + t] & 127) << 8)];
+        }
+        for (; k < hi; ++k) if (mk[k] & 128) o[k] = w[(size_t)o[k] | ((size_t)(mk[k] & 127) << 8)];
+    }
+    // The chain thread: pieces in file order; the window behind a piece = its last 32 KB resolved against the window in front of it
+    // (a sequential step of 32 KB per piece); the piece's other bytes are left to a worker (patch + CRC task).
+    void chain()
+    {
+        std::vector<uint8_t> W(WIN, 0), tail(WIN);
+        size_t c = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m);
+                while (!closing && pieces[c].state.load() != 2 && pieces[c].state.load() != 3) cv_done.wait(l);
+                if (closing || pieces[c].state.load() == 3) return; // (a failed piece on the chain: the consumer reports it when it gets there)
+            }
+            Piece &p = pieces[c];
+            if (!p.known_window) p.win = W;
+            // the window behind the piece
+            const size_t t = std::min(p.n_out, WIN), from = p.n_out - t;
+            for (size_t k = 0; k < t; ++k) {
+                const uint8_t b = p.out[from + k];
+                tail[k] = (!p.known_window && (p.mark[from + k] & 128)) ? W[(size_t)b | ((size_t)(p.mark[from + k] & 127) << 8)] : b;
+            }
+            if (t == WIN) W.swap(tail);
+            else if (t) { memmove(W.data(), W.data() + t, WIN - t); memcpy(W.data() + WIN - t, tail.data(), t); }
+            { std::lock_guard<std::mutex> l(m); p.crc_state.store(1); crc_wait.push_back(c); }
+            cv_work.notify_all();
+            if (p.final_seen || p.next_piece >= n_pieces) return;
+            c = p.next_piece;
+        }
+    }
+    std::thread chain_th;
 
     // ---- consumer ----
     // the next run of inflated bytes in file order (valid until the next call); 0 = end of data, or `failed`
@@ -409,29 +450,19 @@ struct ParGzReader {
                     Piece &q = pieces[release_lo];
                     const int st = q.state.load(), cs = q.crc_state.load();
                     if (st == 1 || cs == 1 || cs == 3) break; // still in use
-                    give_buf(q.out); give_buf(q.mark); std::vector<uint32_t>().swap(q.dep);
+                    give_buf(q.out); give_buf(q.mark); std::vector<uint8_t>().swap(q.win);
                     ++release_lo;
                 }
                 for (;;) {
                     const int st = pieces[cur].state.load();
-                    if (st == 2) break;
                     if (st == 3) { failed = true; return 0; } // a piece ON the chain failed: the stream is corrupt here
+                    if (st == 2 && pieces[cur].crc_state.load() == 2) break; // inflated, patched, CRC taken
+                    if (closing) return 0;
                     cv_done.wait(l);
                 }
                 p = &pieces[cur];
             }
-            if (!p->known_window) { // patch what came from the window in front of the piece
-                for (uint32_t pos : p->dep) {
-                    const size_t k = (size_t)p->out[pos] | ((size_t)(p->mark[pos] & 127) << 8);
-                    p->out[pos] = last_win[k];
-                }
-            }
-            // the window behind this piece
-            if (p->n_out >= WIN) memcpy(last_win, p->out.data() + p->n_out - WIN, WIN);
-            else if (p->n_out) { memmove(last_win, last_win + p->n_out, WIN - p->n_out); memcpy(last_win + WIN - p->n_out, p->out.data(), p->n_out); }
             total_out += p->n_out;
-            { std::lock_guard<std::mutex> l(m); p->crc_state.store(1); crc_wait.push_back(cur); }
-            cv_work.notify_all();
             crcs.emplace_back(0u, p->n_out);
             crc_index.push_back(cur);
             data = reinterpret_cast<const char *>(p->out.data());
