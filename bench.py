@@ -61,6 +61,18 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cpus():
+    """CPUs the process may use: the cgroup quota when there is one (the GPU boxes show 256 hardware threads and allow 16), else os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(opt_args, hs, hq, L, n_sample):
     """Times the reference (or the oracle port) on a bounded sample: returns the cpu_baseline object."""
     cores = os.cpu_count() or 1
@@ -104,7 +116,7 @@ def cpu_baseline(opt_args, hs, hq, L, n_sample):
             subprocess.run(["rm", "-rf", tmp])
             best = max(tried, key=lambda t: tried[t])
             return {"value": tried[best], "unit": "M reads/s", "cores": best, "kind": "reference",
-                    "threads_tried": {str(t): v for t, v in tried.items()}, "host_cores": cores,
+                    "threads_tried": {str(t): v for t, v in tried.items()}, "host_cores": cores, "host_cpus_allowed_by_cgroup": effective_cpus(),
                     "sample": "%d pairs of the same synthetic 2x%d workload as uncompressed FASTQ, whole-process wall clock of "
                               "FaQCs v2.10 --trim_only (parse+trim+write; the reference cannot separate them) at -t 1 / 8 / 16 / all cores; "
                               "value = the best of them (-t %d)" % (half, L, best),
