@@ -65,8 +65,8 @@ enum {
 #define KG_M54 ((1ull << 54) - 1ull)
 
 struct KmerGroupDev {
-    unsigned long long *l1;   // [256 buckets][256 sub-regions][cap1]  run << 54 | (h & KG_M54); sub-region = the block that wrote it
-    unsigned long long *l2;   // [65536 partitions][split sub-regions][cap2]  epoch_rel << 46 | (h & KG_M46)
+    unsigned long long *l1;   // [256 buckets][256 sub-regions][cap1]  16-byte items (faqcs_skm.h), run field = extraction launch; sub-region = the block that wrote it
+    unsigned long long *l2;   // [65536 partitions][split sub-regions][cap2]  items, run field = epoch - epoch_base
     uint32_t *cur1;           // [256 sub-regions][256 buckets]  items a level-1 sub-region holds
     uint32_t *cur2;           // [65536][split]
     uint32_t *run_epoch;      // [KG_MAX_RUNS]  epoch of run j minus epoch_base

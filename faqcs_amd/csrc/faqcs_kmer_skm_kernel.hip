@@ -1058,7 +1058,10 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
             write_out();
             __syncthreads();
             clear();
-            __threadfence(); // the table stores are in L2 and this CU's L1 forgets the slice before the next write-out reads it
+            // (the next write-out reads slots this one stored: the waves of a workgroup share their CU's vector L1, which is write-through, so
+            // the barriers' workgroup-scope fences are all it takes.  A device-scope __threadfence() here made every round of every
+            // workgroup write back and invalidate its XCD's whole L2: 3 x the time per occurrence as soon as partitions needed two rounds,
+            // 304 instead of 147 ms per bench step with groups of 1.5 x 2^30 occurrences)
             __syncthreads();
         }
     }

@@ -416,6 +416,36 @@ def test_kmer_submissions_either_side_of_256_bases_share_their_keys(seed):
     _kmer_engines_agree(hip, ora)
 
 
+def test_kmer_partition_counted_in_several_rounds(monkeypatch, capfd):
+    """A partition with more distinct keys in one group than the combine kernel's LDS table takes (2 816 of 4 096 slots): the workgroup
+    writes its table out, clears it and goes on, and the next write-out reads slots the first one stored.  4 000 reads share a 45-base
+    core inside random flanks, the group is large enough (FAQCS_KMER_GROUP_ITEMS) for the partitions of the core's minimizers to keep
+    their items, and FAQCS_KMER_DEBUG reports the fullest partition of every flush -- the test asserts that the case it is named
+    after occurred.  Every sampling point and every histogram bin equals the oracle's (trim.cpp:157-185,887-931; FaQCs.cpp:518-521)."""
+    import re
+
+    rng = np.random.Generator(np.random.PCG64([9191, SEED]))
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    core = acgt[rng.integers(0, 4, 45)]
+    reads = []
+    for i in range(4000):
+        L = int(rng.integers(100, 251))
+        s = acgt[rng.integers(0, 4, L)]
+        at = int(rng.integers(0, L - 45))
+        s[at:at + 45] = core
+        reads.append((b"@r", s.tobytes(), (rng.integers(30, 41, L) + 33).astype(np.uint8).tobytes()))
+    opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "1000", "--subset", "5", "--lc", "1.0", "--min_L", "31"])
+    from faqcs_amd.engine import HipEngine
+
+    monkeypatch.setenv("FAQCS_KMER_GROUP_ITEMS", str(1 << 28))
+    monkeypatch.setenv("FAQCS_KMER_DEBUG", "1")
+    monkeypatch.setattr("test_gpu_parity.hip_factory", lambda o, r, q: HipEngine(o, r, q, kmer_table_slots=1 << 24))
+    hip, ora = compare_engines(opt, reads, seg_size=1000)
+    _kmer_engines_agree(hip, ora)
+    fullest = [int(m) for m in re.findall(r"fullest partition (\d+) keys", capfd.readouterr().err)]
+    assert fullest and max(fullest) > 2816, fullest
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_kmer_repeats_and_a_partition_larger_than_its_slice(seed, monkeypatch):
     """The rare paths of the super-k-mer kernels: (1) tandem repeats and homopolymers -- equal minimizers over more than 17 k-mers: the
