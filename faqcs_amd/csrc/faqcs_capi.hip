@@ -625,7 +625,8 @@ static int kg_flush(faqcs_ctx *c, bool timed = false)
     }
     HIPCHK(hipMemcpyAsync(g.dev.run_epoch, up.data(), up.size() * 4, hipMemcpyHostToDevice, c->compute));
     g.dev.n_runs = (uint32_t)up.size(); g.dev.epoch_base = g.epoch_base;
-    static const bool debug = [] { const char *e = getenv("FAQCS_KMER_DEBUG"); return e && atoi(e) != 0; }();
+    const char *dbg = getenv("FAQCS_KMER_DEBUG"); // (read at every flush: a test turns it on for one engine)
+    const bool debug = dbg && atoi(dbg) != 0;
     if (g.skm && debug) { if (int rc = kg_debug_flush(c)) return rc; }
     else HIPCHK(faqcs_launch_skm_flush(g.dev, c->kt, c->prm.kmer, c->compute));
     if (timed) HIPCHK(hipEventRecord(ev.second, c->compute));
@@ -1346,14 +1347,14 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
     unsigned long long st[2];
     if ((c->partitioned && !c->kg.owner) || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
     else if (int rc = kg_totals(c, &st[0], &st[1])) return rc;
-    bool emptied = false;
     if (st[0]) { // ++kmer_frequency_histogram[count] for every key, FaQCs.cpp:518-521
         const uint32_t DENSE = 1u << 16, BIGCAP = 1u << 20;
         unsigned long long *d_dense = nullptr, *d_big = nullptr, *d_nbig = nullptr;
         HIPCHK(hipMalloc((void **)&d_dense, DENSE * 8)); HIPCHK(hipMalloc((void **)&d_big, (size_t)BIGCAP * 8)); HIPCHK(hipMalloc((void **)&d_nbig, 8));
         HIPCHK(hipMemsetAsync(d_dense, 0, DENSE * 8, c->compute)); HIPCHK(hipMemsetAsync(d_nbig, 0, 8, c->compute));
-        HIPCHK(faqcs_launch_kmer_histogram(c->kt, d_dense, DENSE, d_big, d_nbig, BIGCAP, true, c->n_cu, c->compute)); // (and empties the slots)
-        emptied = true;
+        // (a read-only pass, then kmer_table_init below: 13.5 ms on the bench's 2^31-slot table; one pass that also cleared the live
+        // sectors -- scattered 64-byte stores between the reads -- took 17.5)
+        HIPCHK(faqcs_launch_kmer_histogram(c->kt, d_dense, DENSE, d_big, d_nbig, BIGCAP, c->n_cu, c->compute));
         HIPCHK(hipStreamSynchronize(c->compute));
         std::vector<unsigned long long> dense(DENSE);
         unsigned long long nbig = 0;
@@ -1374,7 +1375,7 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
         faqcs_rarefaction pt{c->total_number, st[0], st[1]};
         c->points.push_back(pt);
     }
-    if (!emptied) HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute));
+    HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute));
     HIPCHK(hipMemsetAsync(c->kt.stats, 0, 64, c->compute));
     if (c->kg.ready && c->kg.ep_cap) { // the epoch histograms restart with the table; the points taken so far keep their values
         c->kg.points_final = c->points.size();

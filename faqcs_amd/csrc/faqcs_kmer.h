@@ -99,7 +99,7 @@ hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T,
                              const uint32_t *off, uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results,
                              int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
-                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, bool reset, int n_cu,
+                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
                                        hipStream_t st);
 // super-k-mers (round 5; faqcs_kmer_skm_kernel.hip, faqcs_skm.h): the same group buffers with 16-byte items, a run of up to 17
 // consecutive k-mers each; l1 / l2 / cap1 / cap2 of KmerGroupDev count 16-byte items in this mode

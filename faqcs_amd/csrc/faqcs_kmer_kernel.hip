@@ -225,9 +225,8 @@ __global__ __launch_bounds__(256) void kmer_first_epoch_histogram(const KmerTabl
 // histogram of counts over the table (FaQCs.cpp:518-521): dense[c] for c < dense_n, (count) list otherwise.
 // Nearly every key of a real run has one of a few hundred small counts: the block counts those in LDS first (global
 // atomics on a few hundred addresses from 10^8..10^9 slots serialise in L2 -- seconds on a 34 GB table).
-// RESET: the slots are emptied in the same pass (faqcs_kmer_end_table counts the table and starts a fresh one: one read + one write
-// of the table instead of a read, and a write by kmer_table_init)
-template <bool RESET>
+// (Read-only: round 4 cleared the live sectors in the same pass; the scattered stores between the reads cost more than kmer_table_init's
+// stream of stores afterwards -- 17.5 against 7 + 6.6 ms on a 2^31-slot table.)
 __global__ __launch_bounds__(256) void kmer_count_histogram(const KmerTable T, unsigned long long *dense, uint32_t dense_n,
                                                             unsigned long long *big, unsigned long long *n_big, uint32_t big_cap)
 {
@@ -255,10 +254,6 @@ __global__ __launch_bounds__(256) void kmer_count_histogram(const KmerTable T, u
             const uint64_t i = i0 + (uint64_t)u * blockDim.x;
             const bool live = sl[u].key != ~0ull;
             const uint32_t c = sl[u].count_m1 + 1u;
-            // (a 64-byte sector -- four slots, four neighbouring lanes -- is emptied whole when any of its slots is live: 16-byte stores into
-            // a sector cost a read-modify-write of it)
-            const unsigned long long lives = __ballot(live);
-            if (RESET && i < hi && ((lives >> (threadIdx.x & 60u)) & 0xfull)) reinterpret_cast<ulonglong2 *>(T.slots)[i] = make_ulonglong2(~0ull, 0xffffffff00000000ull); // (as kmer_table_init)
             const unsigned long long once = __ballot(live && c == 1u);
             if (once != 0ull && (int)(threadIdx.x & 63u) == __builtin_ctzll(once) && 1u < dense_n) atomicAdd(&h[1], (uint32_t)__popcll(once));
             if (live && (c != 1u || 1u >= dense_n)) {
@@ -291,11 +286,10 @@ hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T,
 }
 
 hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
-                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, bool reset, int n_cu,
+                                       unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
                                        hipStream_t st)
 {
-    if (reset) hipLaunchKernelGGL(kmer_count_histogram<true>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap);
-    else hipLaunchKernelGGL(kmer_count_histogram<false>, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap);
+    hipLaunchKernelGGL(kmer_count_histogram, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap);
     return hipGetLastError();
 }
 
