@@ -82,6 +82,9 @@ FAQCS_KMER_DIRECT=1 b --config kmer --steps 2 --no-cpu-baseline > $out/bench_kme
 FAQCS_BENCH_SHARE_GPU=1 b --config kmer --gpus 2 --pairs 4e6 --steps 2 --no-cpu-baseline --kmer-table-log2 29 > $out/bench_kmer_2ranks_shared_gpu.json  # (the N-rank path on one GPU: not a measurement)
 FAQCS_BENCH_SHARE_GPU=1 b --config kmer --gpus 8 --pairs 5e5 --steps 2 --no-cpu-baseline --kmer-table-log2 28 > $out/bench_kmer_8ranks_shared_gpu.json
 FAQCS_BENCH_SHARE_GPU=1 b --gpus 8 --pairs 8e6 --steps 2 --no-cpu-baseline --no-other-configs --e2e-pairs 0 > $out/bench_plain_8ranks_shared_gpu.json
+# (a distinct-heavy input: 16 M reads of a 465 Mbp genome, 2^30 slots at load 0.72 -- every partition takes several LDS rounds per group.  Before the
+#  device-scope fence between the rounds of skm_combine was dropped (82e208c) this line read 413.5 ms / 38.7 M reads/s on the same box type.)
+timeout 300 python3 tools/kmer_bench.py 16e6 250 30 465e6 > $out/kmer_bench_distinct_heavy_16Mreads_465Mbp.txt 2>&1 < /dev/null
 # 4. rocprofv3 --kernel-trace --stats over shorter runs of the same commands
 prof bench_plain_43Mpairs python3 bench.py --pairs 42949630 --steps 3 --no-cpu-baseline --e2e-pairs 0 --no-other-configs
 prof bench_kmer_25Mpairs python3 bench.py --config kmer --steps 2 --no-cpu-baseline
