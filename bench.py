@@ -524,18 +524,34 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         parallel.allreduce_counters_device(eng)  # torch-staged (no native communicator yet)
         want = torch.empty(n, dtype=torch.int64, device=dev)
         eng.counters_export(want.data_ptr(), n)
-        ok, why = 1, ""
-        try:
-            eng.counters_import(before.data_ptr(), n)  # the step's own block again
-            parallel.native_comm_init(eng)
-            parallel.allreduce_counters_device(eng)  # native, in place
-            eng.sync()
-            got = torch.empty(n, dtype=torch.int64, device=dev)
-            eng.counters_export(got.data_ptr(), n)
-            if not torch.equal(got, want):
-                ok, why = 0, "the blocks differ in %d of %d words on rank %d" % (int((got != want).sum()), n, rank)
-        except Exception as e:  # no librccl, communicator set-up failed, ...
-            ok, why = 0, "%s: %s" % (type(e).__name__, e)
+        verdict = []  # (ok, why) from the thread below
+
+        def native_once():
+            try:
+                torch.cuda.set_device(dev)
+                eng.counters_import(before.data_ptr(), n)  # the step's own block again
+                parallel.native_comm_init(eng)
+                parallel.allreduce_counters_device(eng)  # native, in place
+                eng.sync()
+                got = torch.empty(n, dtype=torch.int64, device=dev)
+                eng.counters_export(got.data_ptr(), n)
+                if torch.equal(got, want):
+                    verdict.append((1, ""))
+                else:
+                    verdict.append((0, "the blocks differ in %d of %d words on rank %d" % (int((got != want).sum()), n, rank)))
+            except Exception as e:  # no librccl, communicator set-up failed, ...
+                verdict.append((0, "%s: %s" % (type(e).__name__, e)))
+
+        # The library's communicator has never met a second rank on real links (no multi-GPU node was available to any round): its set-up and
+        # first all-reduce run in a thread with a deadline, so that a rendezvous that never completes costs this run the native collective
+        # and not its result -- the ranks then agree (the MIN below, over torch's communicator) to stay with the torch-staged all-reduce.
+        import threading
+
+        limit = float(os.environ.get("FAQCS_BENCH_NATIVE_TIMEOUT", "120"))
+        th = threading.Thread(target=native_once, daemon=True)
+        th.start()
+        th.join(limit)
+        ok, why = verdict[0] if verdict else (0, "no answer from the native communicator within %.0f s on rank %d" % (limit, rank))
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
