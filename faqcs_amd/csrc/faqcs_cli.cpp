@@ -828,9 +828,21 @@ struct Run {
     }
     // end of a process_paired() / process_unpaired() pass (FaQCs.cpp:518-537): the points taken during the pass get their values,
     // the count histograms of the owners' tables are merged, the tables restart
+    // A buffer's outbox is forwarded to the owners just before ITS device gets its next buffer (or at the end of the pass), not right behind
+    // its own submission: faqcs_kmer_forward waits for the device's stream, and by then the other devices have had their buffers -- the
+    // round-robin devices overlap with each other and with the parsing again (forwarding at once stalled the submitting thread
+    // for every buffer's whole trim and extraction).  The outbox of a context holds one submission, so the forward has to precede the next one.
+    std::vector<char> kmer_fwd_pending;
+    void kmer_forward_pending(size_t dev)
+    {
+        if (!kmer_multi || dev >= kmer_fwd_pending.size() || !kmer_fwd_pending[dev]) return;
+        kmer_fwd_pending[dev] = 0;
+        check(faqcs_kmer_forward(ctxs[dev], ctxs.data(), (uint32_t)ctxs.size()));
+    }
     void kmer_finish_pass()
     {
         if (!kmer_multi) { if (ctx) check(faqcs_kmer_end_table(ctx)); return; }
+        for (size_t k = 0; k < ctxs.size(); ++k) kmer_forward_pending(k);
         std::vector<uint64_t> d(kmer_n_epochs, 0), t(kmer_n_epochs, 0), pd(kmer_n_epochs), pt(kmer_n_epochs);
         for (faqcs_ctx *c : ctxs) {
             check(faqcs_kmer_epoch_counts(c, pd.data(), pt.data(), kmer_n_epochs));
@@ -888,9 +900,13 @@ struct Run {
         faqcs_batch bt; memset(&bt, 0, sizeof(bt));
         bt.seq = b->seq; bt.qual = b->qual; bt.offset = b->off; bt.n_reads = b->n; bt.n_segments = 1; bt.segment_start = seg;
         bt.terminal_n = b->tn;
-        if (kmer_multi) { const uint32_t epoch = kmer_epoch_of(b->n); check(faqcs_kmer_set_epochs(ctxs[b->dev], &epoch, 1)); }
+        if (kmer_multi) {
+            kmer_forward_pending((size_t)b->dev); // (the previous buffer of this device: its kernels have had a round of the other devices to finish)
+            const uint32_t epoch = kmer_epoch_of(b->n);
+            check(faqcs_kmer_set_epochs(ctxs[b->dev], &epoch, 1));
+        }
         check(faqcs_submit_async(ctxs[b->dev], &bt, b->res, &b->ticket));
-        if (kmer_multi) check(faqcs_kmer_forward(ctxs[b->dev], ctxs.data(), (uint32_t)ctxs.size())); // (waits for this buffer's kernels)
+        if (kmer_multi) { kmer_fwd_pending.resize(ctxs.size(), 0); kmer_fwd_pending[(size_t)b->dev] = 1; }
     }
     // writes one surviving record with the reference's byte edits (trim.cpp:390-403,516-525,1191-1216; fastq.cpp:127-138)
     void write_read(OutFile &f, const RecBuf *b, uint32_t i, std::string &s, std::string &q)
