@@ -489,7 +489,6 @@ static int kg_init(faqcs_ctx *c)
     // Either scatter level writes 65 536 sub-regions: (bucket, writing block) at level 1, (partition, writing block) at level 2.
     // A sub-region of the expected G / 65 536 items gets 1/4 + 8 standard deviations (+ a granule) on top.
     d.split = G >= (1ull << 26) ? 8u : 1u;
-    d.lds_slots = G > (1ull << 30) ? 8192u : 4096u;
     // super-k-mers (every context that is not owner-partitioned): an item is 16 bytes and holds a run of up to w k-mers,
     // (w + 1) / 2 on average; the buffers are sized for three items per w + 1 occurrences.  Partitions are minimizer bins, which
     // vary more than hash bins do: twice the mean at level 2.  What overflows is counted occurrence by occurrence (exact, slow).

@@ -42,27 +42,22 @@ struct KmerOutbox {
     uint32_t total_waves;
 };
 
-// ---- combine-before-insert (single-GPU k-mer counting) -------------------------------------------
-// A k-mer occurrence is not inserted when it is seen.  Its canonical key is mixed into a 62-bit value h (a bijection, so h IS
-// the key from here on) and appended to one of 256 level-1 buckets (top 8 bits of h).  When a group of runs is full, a second
-// scatter splits every bucket 256 ways (next 8 bits): 65 536 partitions, each the ONLY holder of its keys and of the table
-// slice those keys hash to (slot = h >> shift).  One workgroup per partition then counts its items in an LDS hash table and
-// applies ONE update per DISTINCT key to the table: a plain read-modify-write for a key the table knows, a compare-and-swap
-// only to claim the slot of a new key.
+// ---- combine-before-insert (k-mer counting; the items and their arithmetic: faqcs_skm.h) ---------------------
+// A k-mer occurrence is not inserted when it is seen.  Runs of consecutive k-mers that share their minimizer travel as ONE 16-byte
+// item (a super-k-mer); the partition of the key space is a function of the minimizer: 16 bits, the top 8 = one of 256 level-1 buckets
+// the extraction kernels append to.  When a group of runs is full, a second scatter splits every bucket 256 ways (the low 8 bits):
+// 65 536 partitions, each the ONLY holder of its keys and of the table slice they live in.  One workgroup per partition then expands
+// its items, counts the keys (h = mix62 of the canonical k-mer: a bijection, so h IS the key from there on) in an LDS hash table and
+// applies ONE update per DISTINCT key to the table: plain loads and stores -- a new slot is claimed through the workgroup's LDS bitmap.
 enum {
     KG_FAN = 256,          // fan-out of either scatter level
-    KG_GRAN = 32,          // items per global write of a bucket (256 bytes)
-    KG_STAGE = 64,         // LDS staging slots per bucket (2 granules)
     KG_MAX_RUNS = 1000,    // extraction launches (runs of segments with one epoch) per group (a level-1 item has 10 bits for the run)
     KG_EPOCH_SPAN = 1000,  // epochs a group may span (the combine kernel's LDS histogram)
-    KG_LDS_SLOTS = 4096,   // LDS hash table of the combine kernel
     KG_MIN_CAP = 128,      // smallest sub-region
     KG_SLICE_MAX = 65536,  // largest table slice of a partition (table <= 2^32 slots): the combine kernel's claim bitmap is 8 KB of LDS
     KG_SLICE_MIN = 64      // smallest (table >= 2^22 slots)
 };
 #define KG_M62 ((1ull << 62) - 1ull)
-#define KG_M46 ((1ull << 46) - 1ull)
-#define KG_M54 ((1ull << 54) - 1ull)
 
 struct KmerGroupDev {
     unsigned long long *l1;   // [256 buckets][256 sub-regions][cap1]  16-byte items (faqcs_skm.h), run field = extraction launch; sub-region = the block that wrote it
@@ -72,7 +67,6 @@ struct KmerGroupDev {
     uint32_t *run_epoch;      // [KG_MAX_RUNS]  epoch of run j minus epoch_base
     uint32_t cap1, cap2;      // items per sub-region
     uint32_t split;           // blocks per bucket of the level-2 scatter = sub-regions per partition (1, 2, 4 or 8)
-    uint32_t lds_slots;       // LDS hash table of the combine kernel: 4 096 (two workgroups per CU) or 8 192 (groups past 2^30 items)
     uint32_t n_runs, epoch_base;
     unsigned long long *first_hist;   // [n_epochs] keys by first epoch
     unsigned long long *tot_by_epoch; // [n_epochs] occurrences by epoch
