@@ -524,10 +524,13 @@ def test_kmer_groups_of_every_size_match_oracle(group_items, maxlen, monkeypatch
         assert (h1[0] == h2[0]).all() and (h1[1] == h2[1]).all()
 
 
-def test_kmer_group_path_equals_the_per_occurrence_path_at_scale(monkeypatch):
-    """3 M genome-sampled reads of 250 bases (0.5 G occurrences, several groups, 40x coverage of a 12 Mbp genome): the combine-before-insert
-    path and round 3's one-atomic-per-occurrence path (FAQCS_KMER_DIRECT=1, kmer_count) are two implementations of update_kmer()
-    (trim.cpp:887-931) that share no insert code -- the sampling points and the whole count histogram must be identical."""
+@pytest.mark.parametrize("genome,slots_log2,group_items", [(12_000_000, 29, None), (200_000_000, 30, 1 << 30)], ids=["40x_of_12Mbp", "distinct_heavy_one_group"])
+def test_kmer_group_path_equals_the_per_occurrence_path_at_scale(genome, slots_log2, group_items, monkeypatch):
+    """3 M genome-sampled reads of 250 bases (0.5 G occurrences): the combine-before-insert path and round 3's one-atomic-per-occurrence
+    path (FAQCS_KMER_DIRECT=1, kmer_count) are two implementations of update_kmer() (trim.cpp:887-931) that share no insert code -- the
+    sampling points and the whole count histogram must be identical.  First case: 40x coverage of a 12 Mbp genome, several groups, a
+    partition's keys fit one LDS table.  Second case: a 200 Mbp genome (most k-mers distinct) in ONE group of 2^30 occurrences -- every
+    partition is counted in several LDS rounds, each write-out reading slots an earlier one of the same launch stored."""
     import ctypes as C
 
     import torch
@@ -542,10 +545,12 @@ def test_kmer_group_path_equals_the_per_occurrence_path_at_scale(monkeypatch):
     off = torch.empty(n + 1, dtype=torch.int32, device=dev)
     res = torch.empty((n, 4), dtype=torch.int16, device=dev)
     results = []
+    if group_items:
+        monkeypatch.setenv("FAQCS_KMER_GROUP_ITEMS", str(group_items))
     for direct in ("0", "1"):
         monkeypatch.setenv("FAQCS_KMER_DIRECT", direct)
-        eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << 29)
-        _check(eng.lib, eng.lib.faqcs_synth_fill_genome(0, seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, L, 20260101 + SEED, 0, 12_000_000))
+        eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << slots_log2)
+        _check(eng.lib, eng.lib.faqcs_synth_fill_genome(0, seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, L, 20260101 + SEED, 0, genome))
         seg = np.arange(0, n + 32768, 32768, dtype=np.uint32)
         seg[-1] = n
         b = capi.Batch(seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, len(seg) - 1, seg.ctypes.data, L)
