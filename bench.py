@@ -566,9 +566,6 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
 
     def step(flags=True):
         _check(lib, lib.faqcs_reset_counters(eng.ctx))  # one step = one job: its counter block starts at zero
-        if config == "kmer" and kx is None:  # ... and so does its k-mer table (the totals of the finished pass are kept for the report)
-            kmer_seen[0], kmer_seen[1] = eng.kmer_totals()
-            eng.kmer_end_table()
         e0 = 0
         for bb in batches:
             res, seg, bt = bb[3], bb[4], (bb[5] if flags else bb[8])
@@ -578,6 +575,11 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
             _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(bt), res.data_ptr()))
             if kx is not None:
                 kmer_wire[0] += kx.exchange()[0]
+        if config == "kmer" and kx is None:
+            # the job's k-mer pass ends INSIDE the step: its k-mers are counted here (in one piece when they fit the group buffers),
+            # the histogram of counts is read and the next job starts on an empty table (FaQCs.cpp:518-537)
+            eng.kmer_end_table()
+            kmer_seen[0], kmer_seen[1] = eng.kmer_totals()  # (of the pass that just ended)
         if kx is not None:  # the additive epoch histograms -> the job's rarefaction points (one small all-reduce); fresh tables
             pts, _hist = kx.finish(kmer_points_seq, n_reads * world)
             kmer_last["points"] = len(pts)

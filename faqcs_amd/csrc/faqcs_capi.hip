@@ -151,6 +151,13 @@ struct faqcs_ctx {
         uint32_t ep_used = 0;         // 1 + largest epoch seen
         size_t points_final = 0;      // points whose (distinct, total) are final (resolved before the table restarted)
         std::vector<std::pair<hipEvent_t, hipEvent_t>> flush_ev; size_t flush_ev_used = 0;
+        // round 6: a pass whose items fit the group buffers is counted in ONE piece when it ends (faqcs_kmer_finish_pass / faqcs_kmer_end_table)
+        bool table_live = false;      // a group of this pass has been flushed into the table: its last group goes there too, and the table is swept
+        bool pass_done = false;       // the pass has been counted (faqcs_kmer_finish_pass): nothing can join it; faqcs_kmer_end_table starts the next one
+        bool pass_used = false;       // k-mers have joined the pass
+        bool hist_in_table = false;   // the histogram of counts still has to be read off the table (table_live)
+        bool hist_in_overflow = false; // ... off the overflow area behind it only (a pass counted in one piece whose slices' probe windows filled up)
+        uint64_t last_distinct = 0, last_total = 0; // totals of the pass faqcs_kmer_end_table finished last
     } kg;
     // sender staging of the multi-GPU k-mer exchange (super-k-mer items of ONE submission, grouped by destination rank afterwards)
     struct KmerSend {
@@ -417,6 +424,16 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
         if (const char *e = getenv("FAQCS_KMER_DIRECT")) c->kg.direct = atoi(e) != 0;
         // the overflow area (1/16 of the table, at least 2^16 slots): keys whose probe window in their partition's slice is full
         c->kt.ovf_mask = std::max<uint64_t>(pow2 >> 4, 1ull << 16) - 1;
+        // fine partitions (faqcs_kmer.h): a table that is full (0.6 keys per slot) holds about 1 200 keys per fine partition up to 2^30 slots --
+        // a third of what one round of the counting kernel's LDS table takes; 2^31 slots: 2 450, 2^32: 4 900 (several rounds then)
+        { const uint32_t lg = 62 - c->kt.shift;
+          int f = (int)lg - 27; f = f < 0 ? 0 : (f > 3 ? 3 : f);
+          if (const char *e = getenv("FAQCS_KMER_FINE_BITS")) { const int v = atoi(e); if (v >= 0 && v <= 3) f = v; } // (tests: every F on a small table)
+          while (f > 0 && (pow2 >> (16 + f)) < 16) --f;                    // a slice has at least 16 slots
+          while (f < 3 && (pow2 >> (16 + f)) > (uint64_t)KG_SLICE_MAX / 8) ++f; // ... and at most what the counting kernel's claim bitmap covers
+          c->kt.fine = (uint32_t)f; }
+        HIPCHK(hipMalloc((void **)&c->kt.dirty, (size_t)(1u << (16 + c->kt.fine)) / 8));
+        HIPCHK(hipMemset(c->kt.dirty, 0, (size_t)(1u << (16 + c->kt.fine)) / 8));
         HIPCHK(hipMalloc((void **)&c->kt.slots, kmer_table_total(c->kt) * sizeof(KmerSlot)));
         HIPCHK(hipMalloc((void **)&c->kt.stats, 64));
         HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute)); // empty key, count - 1 = 0, no epoch
@@ -443,7 +460,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->ins_a) (void)hipEventDestroy(c->ins_a);
     if (c->ins_b) (void)hipEventDestroy(c->ins_b);
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_partials, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
-                    c->kt.slots, c->kt.stats, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
+                    c->kt.slots, c->kt.stats, c->kt.dirty, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (auto &sl : c->slot) { sl.seq.release(); sl.qual.release(); sl.tn.release(); sl.off.release(); if (sl.done) (void)hipEventDestroy(sl.done); }
     for (auto &e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
@@ -451,7 +468,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     for (auto &rs : c->rec) { rs.pre.release(); rs.post.release(); if (rs.trimmed) (void)hipEventDestroy(rs.trimmed); if (rs.folded) (void)hipEventDestroy(rs.folded); }
     if (c->aux) (void)hipStreamDestroy(c->aux);
     c->ob_items.release(); c->fwd_items.release(); c->ob_wave_count.release(); c->ob_wave_offset.release();
-    { void *kg_ptrs[] = {c->kg.dev.l1, c->kg.dev.l2, c->kg.dev.cur1, c->kg.dev.cur2, c->kg.dev.run_epoch, c->kg.dev.first_hist, c->kg.dev.tot_by_epoch};
+    { void *kg_ptrs[] = {c->kg.dev.l1, c->kg.dev.l2, c->kg.dev.cur1, c->kg.dev.cur2, c->kg.dev.run_epoch, c->kg.dev.first_hist, c->kg.dev.tot_by_epoch, c->kg.dev.dense, c->kg.dev.big, c->kg.dev.n_big, c->kg.dev.redo};
       for (void *q : kg_ptrs) if (q) (void)hipFree(q);
       c->kg.defer.release();
       c->ks.l1.release(); c->ks.spill.release(); c->ks.cur1.release(); c->ks.run_epoch.release(); c->ks.defer.release(); c->ks.scratch.release();
@@ -480,33 +497,56 @@ static int kg_init(faqcs_ctx *c)
     faqcs_ctx::KmerGroup &g = c->kg;
     if (g.ready) return 0;
     const uint64_t slots = c->kt.mask + 1;
-    uint64_t G = slots / 2;
-    if (G < (1ull << 18)) G = 1ull << 18;
-    if (G > (1ull << 30)) G = 1ull << 30;
-    if (const char *e = getenv("FAQCS_KMER_GROUP_ITEMS")) { const uint64_t v = strtoull(e, nullptr, 0); if (v >= (1ull << 14) && v <= (1ull << 31)) G = v; }
-    g.cap_items = G;
     KmerGroupDev &d = g.dev;
-    // Either scatter level writes 65 536 sub-regions: (bucket, writing block) at level 1, (partition, writing block) at level 2.
-    // A sub-region of the expected G / 65 536 items gets 1/4 + 8 standard deviations (+ a granule) on top.
-    d.split = G >= (1ull << 26) ? 8u : 1u;
-    // super-k-mers (every context that is not owner-partitioned): an item is 16 bytes and holds a run of up to w k-mers,
-    // (w + 1) / 2 on average; the buffers are sized for three items per w + 1 occurrences.  Partitions are minimizer bins, which
-    // vary more than hash bins do: twice the mean at level 2.  What overflows is counted occurrence by occurrence (exact, slow).
     g.skm = !g.direct; // (FAQCS_KMER_DIRECT=1 on an owner-partitioned context: round 3's pairs and per-pair atomics)
     g.skm_w = c->prm.kmer > 15 ? c->prm.kmer - 14 : 1;
-    if (g.skm) d.split = 1u; // (a partition's items in one piece: skm_combine fetches them by index; 256 blocks split 1/9 of round 4's items)
     const size_t item_bytes = g.skm ? 16 : 8;
-    const double G_items = !g.skm || g.skm_w == 1 ? (double)G : (double)G * 3.0 / (g.skm_w + 1);
-    const double mean1 = G_items / (KG_FAN * KG_FAN), mean2 = mean1 / d.split;
-    d.cap1 = (uint32_t)(mean1 * (g.skm ? 1.5 : 1.25) + 8.0 * std::sqrt(mean1) + 64.0);
-    d.cap2 = (uint32_t)(mean2 * (g.skm ? 2.0 : 1.25) + 8.0 * std::sqrt(mean2) + 64.0);
-    if (d.cap1 < (uint32_t)KG_MIN_CAP) d.cap1 = KG_MIN_CAP;
-    if (d.cap2 < (uint32_t)KG_MIN_CAP) d.cap2 = KG_MIN_CAP;
+    // Either scatter level writes 65 536 sub-regions: (bucket, writing block) at level 1, partitions at level 2.  Super-k-mers: an item is
+    // 16 bytes and holds a run of up to w k-mers, (w + 1) / 2 on average; the buffers are sized for three items per w + 1 occurrences
+    // (the bench's reads make one per 8), a level-1 sub-region for 1.25 x its even share, a partition -- minimizer bins vary more than hash
+    // bins do -- for 1.5 x.  What overflows is counted occurrence by occurrence (exact, slow).
+    auto caps = [&](uint64_t G, uint32_t &cap1, uint32_t &cap2) {
+        const double G_items = !g.skm || g.skm_w == 1 ? (double)G : (double)G * 3.0 / (g.skm_w + 1);
+        const double mean = G_items / (KG_FAN * KG_FAN);
+        cap1 = (uint32_t)(mean * 1.25 + 8.0 * std::sqrt(mean) + 64.0);
+        cap2 = (uint32_t)(mean * 1.5 + 8.0 * std::sqrt(mean) + 64.0);
+        if (cap1 < (uint32_t)KG_MIN_CAP) cap1 = KG_MIN_CAP;
+        if (cap2 < (uint32_t)KG_MIN_CAP) cap2 = KG_MIN_CAP;
+        cap2 = (cap2 + 7u) & ~7u; // (cut 2^F ways for the fine partitions of a pass counted at its end)
+        return ((size_t)cap1 + cap2) * KG_FAN * KG_FAN * item_bytes;
+    };
+    // The item bound of a group.  Round 6: a pass that fits ONE group never reaches the table (faqcs_kmer.h), so a group is as large as the
+    // table's own sizing rule makes a pass -- six occurrences per slot: 0.6 distinct keys per slot at a coverage of 10 -- and the HBM
+    // allows: at most 60 % of what is free now (the caller's batches are resident already in every use of this library).  2^31 slots:
+    // groups of 12.9 G occurrences, 44 + 53 GB of buffers next to the 36.5 GB table.
+    uint64_t G = slots * 6;
+    if (G < (1ull << 18)) G = 1ull << 18;
+    if (G > (1ull << 36)) G = 1ull << 36;
+    bool fixed = false;
+    if (const char *e = getenv("FAQCS_KMER_GROUP_ITEMS")) { const uint64_t v = strtoull(e, nullptr, 0); if (v >= (1ull << 14) && v <= (1ull << 36)) { G = v; fixed = true; } }
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    while (!fixed && G > (1ull << 18) && caps(G, d.cap1, d.cap2) > free_b / 10 * 6) G -= G / 4;
+    g.cap_items = G;
+    (void)caps(G, d.cap1, d.cap2);
+    d.split = 1u; // (a partition's items in one piece: skm_combine fetches them by index)
+    d.cap2f = d.cap2 >> c->kt.fine;
     HIPCHK(hipMalloc((void **)&d.l1, (size_t)KG_FAN * KG_FAN * d.cap1 * item_bytes));
-    HIPCHK(hipMalloc((void **)&d.l2, (size_t)KG_FAN * KG_FAN * d.split * d.cap2 * item_bytes));
+    HIPCHK(hipMalloc((void **)&d.l2, (size_t)KG_FAN * KG_FAN * d.cap2 * item_bytes));
     HIPCHK(hipMalloc((void **)&d.cur1, (size_t)KG_FAN * KG_FAN * 4));
-    HIPCHK(hipMalloc((void **)&d.cur2, (size_t)KG_FAN * KG_FAN * d.split * 4));
+    HIPCHK(hipMalloc((void **)&d.cur2, (size_t)KG_FAN * KG_FAN * 8 * 4)); // (up to 2^19 fine partitions)
     HIPCHK(hipMalloc((void **)&d.run_epoch, (size_t)KG_MAX_RUNS * 4));
+    // histogram of counts of a pass counted at its end (the kernels add to it; faqcs_kmer_end_table reads it and starts it again)
+    d.dense_n = 1u << 16; d.big_cap = 1u << 20;
+    HIPCHK(hipMalloc((void **)&d.dense, (size_t)d.dense_n * 8)); HIPCHK(hipMalloc((void **)&d.big, (size_t)d.big_cap * 8)); HIPCHK(hipMalloc((void **)&d.n_big, 8));
+    HIPCHK(hipMemsetAsync(d.dense, 0, (size_t)d.dense_n * 8, c->compute)); HIPCHK(hipMemsetAsync(d.n_big, 0, 8, c->compute));
+    HIPCHK(hipMalloc((void **)&d.redo, ((size_t)KG_FAN * KG_FAN * 8 + 1) * 4));
+    d.n_redo = d.redo + (size_t)KG_FAN * KG_FAN * 8;
+    if (g.owner && c->part_world > 1) { // the partitions this rank owns, mapped onto [0, 2^19) (faqcs_kmer.h: part_mul)
+        const uint32_t lo_b = (c->part_rank * 256u + c->part_world - 1u) / c->part_world, hi_b = ((c->part_rank + 1u) * 256u + c->part_world - 1u) / c->part_world;
+        d.part_lo = lo_b << 11;
+        d.part_mul = hi_b > lo_b ? (1ull << 51) / ((uint64_t)(hi_b - lo_b) << 11) : 0ull;
+    }
     HIPCHK(faqcs_launch_skm_reset(d, c->compute));
     g.sub_fill.assign(KG_FAN, 0);
     g.ready = true;
@@ -536,13 +576,17 @@ static int kg_ensure_epochs(faqcs_ctx *c, uint32_t need)
 // FAQCS_KMER_DEBUG=1 (diagnostics): a flush step by step with the buffers checked on the host in between -- every level-1 item sits
 // in the bucket of its partition's top 8 bits, every level-2 item in its partition, no item holds more than w k-mers; prints the
 // item / occurrence / distinct-key counts and the fullest partition (the host expands the items with the kernels' own faqcs_skm.h)
-static int kg_debug_flush(faqcs_ctx *c)
+static int kg_debug_flush(faqcs_ctx *c, bool final)
 {
     faqcs_ctx::KmerGroup &g = c->kg;
     const KmerGroupDev &d = g.dev;
     const SkmGeom geo = skm_geom(c->prm.kmer);
     HIPCHK(hipStreamSynchronize(c->compute));
-    std::vector<uint32_t> cur1((size_t)KG_FAN * KG_FAN), cur2((size_t)KG_FAN * KG_FAN * d.split);
+    // (final: the pass is counted in one piece -- 2^(16 + F) fine partitions of cap2f items instead of 65 536 of cap2)
+    const uint32_t n_parts = final ? 1u << (16 + c->kt.fine) : (uint32_t)KG_FAN * KG_FAN, pcap = final ? d.cap2f : d.cap2;
+    auto part_of = [&](unsigned long long w1) { return final ? skm_item_part(w1) >> (3 - c->kt.fine) : skm_item_p16(w1); };
+    auto flush_stage = [&](uint32_t st) { return final ? faqcs_launch_skm_finish(d, c->kt, c->prm.kmer, c->n_cu, c->compute, st) : faqcs_launch_skm_flush(d, c->kt, c->prm.kmer, c->compute, st); };
+    std::vector<uint32_t> cur1((size_t)KG_FAN * KG_FAN), cur2((size_t)n_parts);
     HIPCHK(hipMemcpy(cur1.data(), d.cur1, cur1.size() * 4, hipMemcpyDeviceToHost));
     unsigned long long st[3];
     HIPCHK(hipMemcpy(st, c->kt.stats, 24, hipMemcpyDeviceToHost));
@@ -556,7 +600,7 @@ static int kg_debug_flush(faqcs_ctx *c)
             HIPCHK(hipMemcpy(buf.data(), reinterpret_cast<const ulonglong2 *>(d.l1) + ((size_t)b * KG_FAN + s) * d.cap1, (size_t)n * 16, hipMemcpyDeviceToHost));
             for (uint32_t i = 0; i < n; ++i) {
                 ++n1; occ1 += skm_item_kmers(buf[i].y);
-                if ((skm_item_part(buf[i].y) >> 8) != b) ++bad1;
+                if (skm_item_bucket(buf[i].y) != b) ++bad1;
                 if (skm_item_kmers(buf[i].y) > geo.w || skm_item_run(buf[i].y) >= g.run_epoch.size()) ++long1;
             }
         }
@@ -568,24 +612,23 @@ static int kg_debug_flush(faqcs_ctx *c)
                      fprintf(stderr, "[kmer debug] the last 16-positions launch left %u reads to the general kernel:", nd); for (uint32_t v : dl) fprintf(stderr, " %u", v); fprintf(stderr, "\n"); }
     fprintf(stderr, "[kmer debug] before the flush: %llu level-1 items, %llu occurrences, %llu in a wrong bucket, %llu with a bad length / run; overflow flag %llu, total %llu\n",
             (unsigned long long)n1, (unsigned long long)occ1, (unsigned long long)bad1, (unsigned long long)long1, st[2], st[1]);
-    HIPCHK(faqcs_launch_skm_flush(d, c->kt, c->prm.kmer, c->compute, 1u));
+    HIPCHK(flush_stage(1u));
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipMemcpy(cur2.data(), d.cur2, cur2.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(st, c->kt.stats, 24, hipMemcpyDeviceToHost));
     uint64_t n2 = 0, occ2 = 0, bad2 = 0, max_keys = 0, max_items = 0, distinct = 0;
-    buf.resize((size_t)d.split * d.cap2);
+    buf.resize((size_t)pcap);
     std::vector<unsigned long long> keys;
-    for (uint32_t p = 0; p < (uint32_t)KG_FAN * KG_FAN; ++p) {
-        uint32_t np = 0;
-        for (uint32_t j = 0; j < d.split; ++j) np += cur2[(size_t)p * d.split + j];
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        const uint32_t np = cur2[p];
         if (!np) continue;
-        HIPCHK(hipMemcpy(buf.data(), reinterpret_cast<const ulonglong2 *>(d.l2) + (size_t)p * d.split * d.cap2, buf.size() * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(buf.data(), reinterpret_cast<const ulonglong2 *>(d.l2) + (size_t)p * pcap, buf.size() * 16, hipMemcpyDeviceToHost));
         keys.clear();
-        for (uint32_t j = 0; j < d.split; ++j)
-            for (uint32_t i = 0; i < cur2[(size_t)p * d.split + j] && i < d.cap2; ++i) {
-                const ulonglong2 it = buf[(size_t)j * d.cap2 + i];
+        for (uint32_t j = 0; j < 1; ++j)
+            for (uint32_t i = 0; i < np && i < pcap; ++i) {
+                const ulonglong2 it = buf[i];
                 ++n2; occ2 += skm_item_kmers(it.y);
-                if (skm_item_part(it.y) != p) ++bad2;
+                if (part_of(it.y) != p) ++bad2;
                 SkmRoll r = skm_roll_begin(it.x, it.y, geo);
                 for (uint32_t t = 0; t < skm_item_kmers(it.y) && t < 32; ++t) { keys.push_back(skm_mix62(skm_roll_key(r))); skm_roll_next(r, geo); }
             }
@@ -596,18 +639,20 @@ static int kg_debug_flush(faqcs_ctx *c)
     }
     fprintf(stderr, "[kmer debug] after the split: %llu level-2 items, %llu occurrences, %llu in a wrong partition; %llu distinct keys in this group, fullest partition %llu keys / %llu items (slice: %llu slots); overflow flag %llu\n",
             (unsigned long long)n2, (unsigned long long)occ2, (unsigned long long)bad2, (unsigned long long)distinct, (unsigned long long)max_keys, (unsigned long long)max_items,
-            (unsigned long long)((c->kt.mask + 1) >> 16), st[2]);
-    HIPCHK(faqcs_launch_skm_flush(d, c->kt, c->prm.kmer, c->compute, 2u));
+            (unsigned long long)((c->kt.mask + 1) >> (final ? 16 + c->kt.fine : 16)), st[2]);
+    HIPCHK(flush_stage(2u));
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipMemcpy(st, c->kt.stats, 24, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[kmer debug] after the combine: overflow flag %llu\n", st[2]);
-    HIPCHK(faqcs_launch_skm_flush(d, c->kt, c->prm.kmer, c->compute, 4u));
+    fprintf(stderr, "[kmer debug] after the %s: overflow flag %llu\n", final ? "count (the pass in one piece)" : "combine", st[2]);
+    HIPCHK(flush_stage(4u));
     return 0;
 }
 
-// the open group's items reach the table: level-2 scatter, combine + insert, cursors back to zero (all on the compute stream)
-// (timed: a flush outside a submission's k0 .. k1 events -- the one faqcs_sync() makes -- brings its own pair)
-static int kg_flush(faqcs_ctx *c, bool timed = false)
+// the open group's items are counted: level-2 scatter, combine, cursors back to zero (all on the compute stream).
+// final == false: into the table, while the pass goes on (the group buffers are full, or a caller asks for the curve so far);
+// final == true: the pass ends with this group and no group of it has gone into the table -- counted in one piece, the table untouched.
+// (timed: a flush outside a submission's k0 .. k1 events brings its own pair)
+static int kg_flush(faqcs_ctx *c, bool timed = false, bool final = false)
 {
     faqcs_ctx::KmerGroup &g = c->kg;
     if (!g.ready || g.run_epoch.empty()) return 0;
@@ -626,8 +671,12 @@ static int kg_flush(faqcs_ctx *c, bool timed = false)
     g.dev.n_runs = (uint32_t)up.size(); g.dev.epoch_base = g.epoch_base;
     const char *dbg = getenv("FAQCS_KMER_DEBUG"); // (read at every flush: a test turns it on for one engine)
     const bool debug = dbg && atoi(dbg) != 0;
-    if (g.skm && debug) { if (int rc = kg_debug_flush(c)) return rc; }
+    static const bool never_final = [] { const char *e = getenv("FAQCS_KMER_FINAL"); return e && atoi(e) == 0; }(); // (A/B: round 5's path for every group)
+    final = final && !g.table_live && !never_final;
+    if (g.skm && debug) { if (int rc = kg_debug_flush(c, final)) return rc; }
+    else if (final) HIPCHK(faqcs_launch_skm_finish(g.dev, c->kt, c->prm.kmer, c->n_cu, c->compute));
     else HIPCHK(faqcs_launch_skm_flush(g.dev, c->kt, c->prm.kmer, c->compute));
+    if (!final) g.table_live = true;
     if (timed) HIPCHK(hipEventRecord(ev.second, c->compute));
     g.run_epoch.clear(); g.bound_items = 0;
     std::fill(g.sub_fill.begin(), g.sub_fill.end(), 0);
@@ -640,8 +689,10 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
                       const faqcs_read_result *d_res, uint64_t per_read, const uint32_t *host_off, uint32_t epoch, uint32_t max_len)
 {
     faqcs_ctx::KmerGroup &g = c->kg;
+    if (g.pass_done) return fail(FAQCS_E_INVAL, "faqcs_submit: the k-mer pass has been counted (faqcs_kmer_finish_pass); faqcs_kmer_end_table starts the next one");
     if (int rc = kg_init(c)) return rc;
     if (int rc = kg_ensure_epochs(c, epoch + 1)) return rc;
+    g.pass_used = true;
     if (per_read == 0) per_read = 1;
     while (r0 < r1) {
         if (g.run_epoch.size() == (size_t)KG_MAX_RUNS || (!g.run_epoch.empty() && epoch - g.epoch_base >= (uint32_t)KG_EPOCH_SPAN)) {
@@ -697,16 +748,15 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
 }
 
 // owner side of the multi-GPU exchange: n received items (device memory; their run fields hold absolute epochs) join the open group,
-// whose run -> epoch table is the identity; with more epochs than a group spans they are counted occurrence by occurrence
+// whose run -> epoch table is the identity (at most KG_EPOCH_SPAN epochs: faqcs_kmer_partition sends a job with more through the
+// (key, epoch) pairs of FAQCS_KMER_DIRECT instead)
 static int kg_add_items(faqcs_ctx *c, const void *d_items, uint64_t n)
 {
     faqcs_ctx::KmerGroup &g = c->kg;
+    if (g.pass_done) return fail(FAQCS_E_INVAL, "faqcs_kmer_insert_device: the k-mer pass has been counted (faqcs_kmer_finish_pass); faqcs_kmer_end_table starts the next one");
     if (int rc = kg_init(c)) return rc;
     if (int rc = kg_ensure_epochs(c, c->n_epochs)) return rc;
-    if (c->n_epochs > (uint32_t)KG_EPOCH_SPAN) {
-        HIPCHK(faqcs_launch_skm_items_atomic(g.dev, c->kt, c->prm.kmer, d_items, n, c->n_cu, c->compute));
-        return 0;
-    }
+    g.pass_used = true;
     const uint8_t *p = reinterpret_cast<const uint8_t *>(d_items);
     while (n) {
         const uint32_t rot = (uint32_t)((g.n_launches * 37u) % KG_FAN);
@@ -842,7 +892,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         HIPCHK(ks.l1.reserve((size_t)KG_FAN * KG_FAN * cap1));
         HIPCHK(ks.spill.reserve(spill_cap));
         HIPCHK(ks.cur1.reserve((size_t)KG_FAN * KG_FAN + 64));
-        HIPCHK(ks.run_epoch.reserve(1u << SKM_RUN_BITS));
+        HIPCHK(ks.run_epoch.reserve((size_t)KG_MAX_RUNS));
         HIPCHK(ks.scratch.reserve((size_t)KG_FAN * KG_FAN + 128));
         HIPCHK(ks.defer.reserve((size_t)n + 1));
         ks.spill_n = ks.cur1.p + (size_t)KG_FAN * KG_FAN;
@@ -860,7 +910,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
             uint32_t e = s + 1;
             while (e < n_seg && c->seg_epoch[e] == c->seg_epoch[s]) ++e;
             if (c->seg_epoch[s] != 0xffffffffu && seg[e] > seg[s]) {
-                if (run_epoch.size() >= (1u << SKM_RUN_BITS)) return fail(FAQCS_E_INVAL, "faqcs_submit: more than 8192 epochs in one submission");
+                if (run_epoch.size() >= (size_t)KG_MAX_RUNS) return fail(FAQCS_E_INVAL, "faqcs_submit: more than 1000 runs of segments with one epoch in a submission");
                 const uint32_t run = (uint32_t)run_epoch.size(), rot = (run * 37u) % KG_FAN;
                 if (p.kmer == 31 && max_len <= 256 && !no16) {
                     HIPCHK(hipMemsetAsync(ks.defer.p, 0, 4, c->compute));
@@ -1111,7 +1161,8 @@ extern "C" int faqcs_sync(faqcs_ctx *c)
     if (!c) return fail(FAQCS_E_INVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->copy));
-    if (int rc = kg_flush(c, true)) return rc; // "everything submitted is done" includes the k-mers still waiting in the open group
+    // (round 6: the k-mers waiting in the open group stay there -- they are counted when the pass ends, faqcs_kmer_end_table /
+    // faqcs_kmer_finish_pass, or when a caller asks for the curve so far, faqcs_kmer_points / _totals / _epoch_counts: kmer_catch_up)
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipStreamSynchronize(c->aux));
     for (size_t i = 0; i < c->kg.flush_ev_used; ++i) { // group flushes (they run behind a later submission or here): part of the k-mer time
@@ -1127,7 +1178,6 @@ extern "C" int faqcs_sync(faqcs_ctx *c)
     }
     c->timing_used = 0;
     if (int rc = resolve_points(c)) return rc;
-    if (int rc = kg_resolve_points(c)) return rc;
     uint32_t e = 0;
     HIPCHK(hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
     if (e & 1u) return fail(FAQCS_E_QUALITY, "fastq.h:quality_score: Found a quality score value that is greater than the maximum allowed quality score");
@@ -1316,57 +1366,114 @@ extern "C" int faqcs_reset_counters(faqcs_ctx *c)
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int faqcs_kmer_active(faqcs_ctx *c) { return c ? c->kmer_active : 0; }
 
+// The curve so far: the open group is counted INTO THE TABLE (the pass goes on behind this call, so its keys have to live somewhere) and
+// the points taken so far get their values.  Callers that only want the finished curve call faqcs_kmer_end_table() first -- the pass
+// is then counted in one piece without the table -- and read the points afterwards.
+static int kmer_catch_up(faqcs_ctx *c)
+{
+    if (int rc = faqcs_sync(c)) return rc;
+    if (c->kg.ready && !c->kg.run_epoch.empty()) {
+        if (int rc = kg_flush(c, true)) return rc;
+        if (int rc = faqcs_sync(c)) return rc; // (the flush's time joins the k-mer time; the table-full flag)
+    }
+    return kg_resolve_points(c);
+}
+
 extern "C" int faqcs_kmer_points(faqcs_ctx *c, faqcs_rarefaction *out, uint32_t cap, uint32_t *n_points)
 {
     if (!c || !n_points) return fail(FAQCS_E_INVAL, "null argument");
-    if (int rc = faqcs_sync(c)) return rc;
+    if (int rc = kmer_catch_up(c)) return rc;
     *n_points = (uint32_t)c->points.size();
     for (uint32_t i = 0; out && i < cap && i < c->points.size(); ++i) out[i] = c->points[i];
     return 0;
 }
 
+// (distinct, total) of the pass in progress -- or, when nothing has been counted since faqcs_kmer_end_table(), of the pass that call finished
 extern "C" int faqcs_kmer_totals(faqcs_ctx *c, uint64_t *distinct, uint64_t *total)
 {
     if (!c || !distinct || !total) return fail(FAQCS_E_INVAL, "null argument");
     *distinct = *total = 0;
     if (!c->kt.stats) return 0;
-    if (int rc = faqcs_sync(c)) return rc;
+    if (int rc = kmer_catch_up(c)) return rc;
     unsigned long long st[2];
     if ((c->partitioned && !c->kg.owner) || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    else if (!c->kg.pass_used) { st[0] = c->kg.last_distinct; st[1] = c->kg.last_total; }
     else if (int rc = kg_totals(c, &st[0], &st[1])) return rc;
     *distinct = st[0]; *total = st[1];
     return 0;
+}
+
+// The pass ends: its open group is counted -- in one piece and without the table when no group of the pass has been flushed before
+//  -- and the points get their final values.  Nothing can join the pass afterwards; faqcs_kmer_end_table()
+// (which calls this) starts the next one.  Callers that read results other than the points before faqcs_kmer_end_table() -- the epoch
+// histograms of an owner rank, faqcs_kmer_epoch_counts -- call it themselves.
+extern "C" int faqcs_kmer_finish_pass(faqcs_ctx *c)
+{
+    if (!c) return fail(FAQCS_E_INVAL, "null ctx");
+    if (!c->kt.stats) return 0;
+    if (int rc = faqcs_sync(c)) return rc;
+    faqcs_ctx::KmerGroup &g = c->kg;
+    if (g.ready && !g.pass_done) {
+        if (int rc = kg_flush(c, true, true)) return rc;
+        g.pass_done = true;
+        if (int rc = faqcs_sync(c)) return rc;
+        // keys in the overflow area (a probe window of a slice was full) are not swept by the counting kernel
+        unsigned long long st[4];
+        HIPCHK(hipMemcpy(st, c->kt.stats, 32, hipMemcpyDeviceToHost));
+        g.hist_in_table = g.table_live;
+        g.hist_in_overflow = !g.table_live && st[3] != 0;
+        static const bool stats = [] { const char *e = getenv("FAQCS_KMER_STATS"); return e && atoi(e) != 0; }();
+        if (stats) { // (diagnostics: how the pass was counted)
+            uint32_t n_redo = 0;
+            if (g.dev.n_redo && !g.table_live) HIPCHK(hipMemcpy(&n_redo, g.dev.n_redo, 4, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[kmer stats] pass counted %s; %u of %u fine partitions through their table slices; %llu inserts into the overflow area; group bound %llu occurrences, cap1 %u cap2f %u\n",
+                    g.table_live ? "through the table (a group was flushed before the pass ended)" : "in one piece", n_redo, 1u << (16 + c->kt.fine), st[3],
+                    (unsigned long long)g.cap_items, g.dev.cap1, g.dev.cap2f);
+        }
+    }
+    return kg_resolve_points(c);
 }
 
 extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
 {
     if (!c) return fail(FAQCS_E_INVAL, "null ctx");
     if (!c->kt.stats) return 0;
-    if (int rc = faqcs_sync(c)) return rc;
-    unsigned long long st[2];
-    if ((c->partitioned && !c->kg.owner) || c->kg.direct) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
+    if (int rc = faqcs_kmer_finish_pass(c)) return rc;
+    faqcs_ctx::KmerGroup &g = c->kg;
+    const bool table_only = (c->partitioned && !g.owner) || g.direct; // (round 3's per-occurrence paths: everything is in the table)
+    unsigned long long st[2] = {0, 0};
+    if (table_only) HIPCHK(hipMemcpy(st, c->kt.stats, 16, hipMemcpyDeviceToHost));
     else if (int rc = kg_totals(c, &st[0], &st[1])) return rc;
-    if (st[0]) { // ++kmer_frequency_histogram[count] for every key, FaQCs.cpp:518-521
+    // ++kmer_frequency_histogram[count] for every key, FaQCs.cpp:518-521: what the counting kernel of a pass in one piece has added up
+    // already (KmerGroupDev::dense / big), plus -- when keys of the pass live in the table -- a read-only pass over it
+    const bool sweep = st[0] != 0 && (table_only || g.hist_in_table || g.hist_in_overflow);
+    const bool ovf_only = !table_only && !g.hist_in_table; // (the slices are empty: only the area behind the table holds keys)
+    if (st[0]) {
         const uint32_t DENSE = 1u << 16, BIGCAP = 1u << 20;
-        unsigned long long *d_dense = nullptr, *d_big = nullptr, *d_nbig = nullptr;
-        HIPCHK(hipMalloc((void **)&d_dense, DENSE * 8)); HIPCHK(hipMalloc((void **)&d_big, (size_t)BIGCAP * 8)); HIPCHK(hipMalloc((void **)&d_nbig, 8));
-        HIPCHK(hipMemsetAsync(d_dense, 0, DENSE * 8, c->compute)); HIPCHK(hipMemsetAsync(d_nbig, 0, 8, c->compute));
+        unsigned long long *d_dense = g.dev.dense, *d_big = g.dev.big, *d_nbig = g.dev.n_big;
+        const bool own = !d_dense; // (a context that never made a group: the per-occurrence paths)
+        if (own) {
+            HIPCHK(hipMalloc((void **)&d_dense, DENSE * 8)); HIPCHK(hipMalloc((void **)&d_big, (size_t)BIGCAP * 8)); HIPCHK(hipMalloc((void **)&d_nbig, 8));
+            HIPCHK(hipMemsetAsync(d_dense, 0, DENSE * 8, c->compute)); HIPCHK(hipMemsetAsync(d_nbig, 0, 8, c->compute));
+        }
+        auto release = [&]() { if (own) { (void)hipFree(d_dense); (void)hipFree(d_big); (void)hipFree(d_nbig); } };
         // (a read-only pass, then kmer_table_init below: 13.5 ms on the bench's 2^31-slot table; one pass that also cleared the live
         // sectors -- scattered 64-byte stores between the reads -- took 17.5)
-        HIPCHK(faqcs_launch_kmer_histogram(c->kt, d_dense, DENSE, d_big, d_nbig, BIGCAP, c->n_cu, c->compute));
+        if (sweep) HIPCHK(faqcs_launch_kmer_histogram(c->kt, d_dense, DENSE, d_big, d_nbig, BIGCAP, c->n_cu, c->compute, ovf_only));
         HIPCHK(hipStreamSynchronize(c->compute));
         std::vector<unsigned long long> dense(DENSE);
         unsigned long long nbig = 0;
         HIPCHK(hipMemcpy(dense.data(), d_dense, DENSE * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&nbig, d_nbig, 8, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < DENSE; ++i) if (dense[i]) c->kmer_hist[i] += dense[i];
-        if (nbig > BIGCAP) { (void)hipFree(d_dense); (void)hipFree(d_big); (void)hipFree(d_nbig); return fail(FAQCS_E_NOMEM, "faqcs_kmer_end_table: too many k-mers with count >= 65536"); }
+        if (nbig > BIGCAP) { release(); return fail(FAQCS_E_NOMEM, "faqcs_kmer_end_table: too many k-mers with count >= 65536"); }
         if (nbig) {
             std::vector<unsigned long long> big(nbig);
             HIPCHK(hipMemcpy(big.data(), d_big, nbig * 8, hipMemcpyDeviceToHost));
             for (auto v : big) c->kmer_hist[v] += 1;
         }
-        (void)hipFree(d_dense); (void)hipFree(d_big); (void)hipFree(d_nbig);
+        if (!own) { HIPCHK(hipMemsetAsync(d_dense, 0, DENSE * 8, c->compute)); HIPCHK(hipMemsetAsync(d_nbig, 0, 8, c->compute)); }
+        release();
     }
     if (c->partitioned) { // the points belong to the driver (faqcs_kmer_epoch_counts); only the table restarts here
         HIPCHK(hipMemsetAsync(c->d_tot_by_epoch, 0, (size_t)c->n_epochs * 8, c->compute));
@@ -1374,12 +1481,16 @@ extern "C" int faqcs_kmer_end_table(faqcs_ctx *c)
         faqcs_rarefaction pt{c->total_number, st[0], st[1]};
         c->points.push_back(pt);
     }
-    HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute));
+    // the next pass starts on an empty table: a stream of stores over all of it only when this pass has put keys there
+    if (sweep || (st[0] == 0 && (table_only || g.hist_in_table || g.hist_in_overflow))) HIPCHK(faqcs_launch_kmer_table_init(c->kt, c->n_cu, c->compute, ovf_only));
     HIPCHK(hipMemsetAsync(c->kt.stats, 0, 64, c->compute));
-    if (c->kg.ready && c->kg.ep_cap) { // the epoch histograms restart with the table; the points taken so far keep their values
-        c->kg.points_final = c->points.size();
-        HIPCHK(hipMemsetAsync(c->kg.dev.first_hist, 0, (size_t)c->kg.ep_cap * 8, c->compute));
-        HIPCHK(hipMemsetAsync(c->kg.dev.tot_by_epoch, 0, (size_t)c->kg.ep_cap * 8, c->compute));
+    HIPCHK(hipMemsetAsync(c->kt.dirty, 0, (size_t)(1u << (16 + c->kt.fine)) / 8, c->compute));
+    g.last_distinct = st[0]; g.last_total = st[1];
+    g.table_live = false; g.pass_done = false; g.pass_used = false; g.hist_in_table = false; g.hist_in_overflow = false;
+    if (g.ready && g.ep_cap) { // the epoch histograms restart with the table; the points taken so far keep their values
+        g.points_final = c->points.size();
+        HIPCHK(hipMemsetAsync(g.dev.first_hist, 0, (size_t)g.ep_cap * 8, c->compute));
+        HIPCHK(hipMemsetAsync(g.dev.tot_by_epoch, 0, (size_t)g.ep_cap * 8, c->compute));
     }
     return 0;
 }
@@ -1404,7 +1515,9 @@ extern "C" int faqcs_kmer_partition(faqcs_ctx *c, uint32_t rank, uint32_t world,
     // their epoch in 10 bits: up to KG_EPOCH_SPAN epochs; more, or FAQCS_KMER_DIRECT=1: one atomic insert per pair, kmer_insert_items)
     // what this rank receives -- super-k-mer items whose run field holds the absolute epoch, 13 bits -- joins the group buffers like a single
     // GPU's own runs (up to KG_EPOCH_SPAN epochs), or is counted occurrence by occurrence (more).  FAQCS_KMER_DIRECT=1: round 3's pairs.
-    if (!c->kg.direct && n_epochs > (1u << SKM_RUN_BITS) - 1u) return fail(FAQCS_E_INVAL, "faqcs_kmer_partition: at most 8191 sampling epochs");
+    // More sampling epochs than an item's 10-bit epoch field and a group's LDS histogram take (KG_EPOCH_SPAN): the job goes through the
+    // (key, epoch) pairs of FAQCS_KMER_DIRECT -- 16 bytes per occurrence on the wire, one atomic per pair on the owner: exact, any --subset.
+    if (n_epochs > (uint32_t)KG_EPOCH_SPAN) c->kg.direct = true;
     c->kg.owner = !c->kg.direct;
     return 0;
 }
@@ -1516,7 +1629,7 @@ extern "C" int faqcs_kmer_epoch_counts(faqcs_ctx *c, uint64_t *distinct_by_first
 {
     if (!c || !distinct_by_first_epoch || !total_by_epoch) return fail(FAQCS_E_INVAL, "null argument");
     if (!c->partitioned || cap < c->n_epochs) return fail(FAQCS_E_INVAL, "faqcs_kmer_epoch_counts: not partitioned / buffers too small");
-    if (int rc = faqcs_sync(c)) return rc;
+    if (int rc = kmer_catch_up(c)) return rc; // (after faqcs_kmer_finish_pass: nothing is open; before it: the open group goes into the table)
     if (c->kg.owner) { // kept up to date by the combine kernel: no pass over the table
         for (uint32_t i = 0; i < c->n_epochs; ++i) { distinct_by_first_epoch[i] = 0; total_by_epoch[i] = 0; }
         if (c->kg.ready && c->kg.ep_cap) {

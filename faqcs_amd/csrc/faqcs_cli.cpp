@@ -600,7 +600,15 @@ struct Source {
             const char *chunk = io.data();
             size_t got;
             if (use_bgzf) { got = bgzf.next(chunk); if (got == 0 && bgzf.failed) cur->io_error = true; }
-            else if (use_pargz) { got = pargz.next(chunk); if (got == 0 && pargz.failed) cur->io_error = true; }
+            else if (use_pargz) {
+                got = pargz.next(chunk);
+                if (got == 0 && pargz.failed) {
+                    cur->io_error = true;
+                    // (only the first piece is checked for bytes >= 128; a later one is taken for a window marker and the member's CRC fails)
+                    fprintf(stderr, "faqcs_mi: the parallel inflate of a .gz input ended with an error: a damaged file -- or text with bytes >= 128 behind its first "
+                                    "megabytes, which this reader cannot tell from its own markers (FAQCS_MI_NO_PARGZ=1 reads such a file through gzread)\n");
+                }
+            }
             else {
                 const int g = gzread(gz, io.data(), (unsigned)io.size());
                 got = g > 0 ? (size_t)g : 0;
@@ -844,6 +852,7 @@ struct Run {
         if (!kmer_multi) { if (ctx) check(faqcs_kmer_end_table(ctx)); return; }
         for (size_t k = 0; k < ctxs.size(); ++k) kmer_forward_pending(k);
         std::vector<uint64_t> d(kmer_n_epochs, 0), t(kmer_n_epochs, 0), pd(kmer_n_epochs), pt(kmer_n_epochs);
+        for (faqcs_ctx *c : ctxs) check(faqcs_kmer_finish_pass(c)); // (every owner counts what it holds as the END of a pass: in one piece, without its table)
         for (faqcs_ctx *c : ctxs) {
             check(faqcs_kmer_epoch_counts(c, pd.data(), pt.data(), kmer_n_epochs));
             for (uint32_t i = 0; i < kmer_n_epochs; ++i) { d[i] += pd[i]; t[i] += pt[i]; }
@@ -2133,6 +2142,7 @@ int host_self_check(int argc, char **argv)
         const int nt = argc >= 4 ? atoi(argv[3]) : 8;
         const size_t piece = argc >= 5 ? (size_t)atoll(argv[4]) : 0;
         if (!ParGzReader::eligible(argv[2], 18)) { fprintf(stderr, "not a gzip file\n"); return 2; }
+        if (const char *e = getenv("FAQCS_MI_PARGZ_REARM")) r.rearm_min = (size_t)atoll(e); // (tests: short members take the parallel reader again)
         if (!r.open(argv[2], nt, piece)) { fprintf(stderr, "not eligible (not ASCII, or the first piece does not inflate)\n"); return 4; }
         const char *data;
         size_t n;

@@ -21,6 +21,10 @@ struct KmerTable {
     uint32_t shift;            // 62 - log2(slots): combine-before-insert keys are 62-bit mixes, slot = key >> shift
     uint64_t ovf_mask;         // overflow area behind the table: slots[mask + 1 .. mask + 1 + ovf_mask] (0: none).  A key whose probe window
                                // inside its partition's slice is full lives there (faqcs_kmer_skm_kernel.hip): shared by all partitions, atomics only
+    uint32_t fine;             // F = 0 .. 3: the table is cut into 2^(16 + F) slices, one per FINE partition (the top 16 + F bits of an item's
+                               // 19-bit partition); a pass that is counted in one piece at its end has one workgroup turn per fine partition
+    uint32_t *dirty;           // [2^(16 + F) / 32] bit p: the slice of fine partition p holds keys that reached the table occurrence by occurrence
+                               // (what did not fit a sub-region of the group buffers) -- the counting pass must then go through the table for p
 };
 #ifdef __HIPCC__
 __host__ __device__
@@ -49,9 +53,15 @@ struct KmerOutbox {
 // 65 536 partitions, each the ONLY holder of its keys and of the table slice they live in.  One workgroup per partition then expands
 // its items, counts the keys (h = mix62 of the canonical k-mer: a bijection, so h IS the key from there on) in an LDS hash table and
 // applies ONE update per DISTINCT key to the table: plain loads and stores -- a new slot is claimed through the workgroup's LDS bitmap.
+//
+// Round 6: a pass whose items fit the group buffers (they are sized from the free HBM) is not flushed before it ENDS.  Then the second
+// scatter splits a bucket (256 << F) ways -- a sort of 8 192-item tiles in LDS -- and one workgroup turn per FINE partition counts the
+// keys in LDS and adds them straight to the histogram of counts and to the keys-by-first-epoch histogram: the table is not touched at
+// all (skm_split_sort / skm_combine<FINAL>).  A fine partition with more distinct keys than the LDS table takes, or one that the
+// per-occurrence path has written to (KmerTable::dirty), goes through its slice of the table as before and sweeps it afterwards.
 enum {
     KG_FAN = 256,          // fan-out of either scatter level
-    KG_MAX_RUNS = 1000,    // extraction launches (runs of segments with one epoch) per group (a level-1 item has 10 bits for the run)
+    KG_MAX_RUNS = 1000,    // extraction launches (runs of segments with one epoch) per group (an item has 10 bits for the run / epoch)
     KG_EPOCH_SPAN = 1000,  // epochs a group may span (the combine kernel's LDS histogram)
     KG_MIN_CAP = 128,      // smallest sub-region
     KG_SLICE_MAX = 65536,  // largest table slice of a partition (table <= 2^32 slots): the combine kernel's claim bitmap is 8 KB of LDS
@@ -62,10 +72,16 @@ enum {
 struct KmerGroupDev {
     unsigned long long *l1;   // [256 buckets][256 sub-regions][cap1]  16-byte items (faqcs_skm.h), run field = extraction launch; sub-region = the block that wrote it
     unsigned long long *l2;   // [65536 partitions][split sub-regions][cap2]  items, run field = epoch - epoch_base
+                              // (a pass counted at its end: [2^(16 + F) fine partitions][cap2f], same memory)
     uint32_t *cur1;           // [256 sub-regions][256 buckets]  items a level-1 sub-region holds
     uint32_t *cur2;           // [65536][split]
     uint32_t *run_epoch;      // [KG_MAX_RUNS]  epoch of run j minus epoch_base
     uint32_t cap1, cap2;      // items per sub-region
+    uint32_t cap2f;           // items per FINE partition when the level-2 buffer is cut 2^(16 + F) ways (the pass counted at its end)
+    // histogram of counts of a pass counted at its end (FaQCs.cpp:518-521): dense[c] for c < dense_n, a list of the larger counts
+    unsigned long long *dense, *big, *n_big;
+    uint32_t dense_n, big_cap;
+    uint32_t *redo, *n_redo;  // [2^19], [1]: fine partitions the count-only kernel leaves to the one that goes through the table
     uint32_t split;           // blocks per bucket of the level-2 scatter = sub-regions per partition (1, 2, 4 or 8)
     uint32_t n_runs, epoch_base;
     unsigned long long *first_hist;   // [n_epochs] keys by first epoch
@@ -76,6 +92,11 @@ struct KmerGroupDev {
     unsigned long long *spill;        // [spill_cap] 16-byte items
     uint32_t *spill_n;                // items appended (may run past spill_cap: the surplus is dropped and bit 1 of the table's overflow flag set)
     uint32_t spill_cap;
+    // owner side of the multi-GPU exchange (skm_items): the 19-bit partitions this rank owns are [part_lo, part_lo + n) and an item's
+    // partition becomes the LOCAL one, ((part - part_lo) * part_mul) >> 32 in [0, 2^19), part_mul = floor(2^51 / n): the owner's buckets,
+    // level-2 regions and table slices then spread over ALL of its buffers and its whole table.  part_mul == 0: as they are.
+    uint32_t part_lo;
+    unsigned long long part_mul;
 };
 
 // launchers
@@ -86,7 +107,7 @@ hipError_t faqcs_launch_kmer_extract(const DevParams &P, uint32_t k, const KmerO
 hipError_t faqcs_launch_kmer_outbox_offsets(const KmerOutbox &O, hipStream_t st);
 hipError_t faqcs_launch_kmer_insert_items(const KmerTable &T, const void *items, unsigned long long n,
                                           unsigned long long *tot_by_epoch, uint32_t n_epochs, int n_cu, hipStream_t st);
-hipError_t faqcs_launch_kmer_table_init(const KmerTable &T, int n_cu, hipStream_t st);
+hipError_t faqcs_launch_kmer_table_init(const KmerTable &T, int n_cu, hipStream_t st, bool overflow_only = false);
 hipError_t faqcs_launch_kmer_first_epoch_histogram(const KmerTable &T, unsigned long long *hist, uint32_t n_epochs, int n_cu,
                                                    hipStream_t st);
 hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T, const uint8_t *seq, const uint8_t *qual,
@@ -94,7 +115,7 @@ hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T,
                              int n_cu, hipStream_t st);
 hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
                                        unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
-                                       hipStream_t st);
+                                       hipStream_t st, bool overflow_only = false);
 // super-k-mers (round 5; faqcs_kmer_skm_kernel.hip, faqcs_skm.h): the same group buffers with 16-byte items, a run of up to 17
 // consecutive k-mers each; l1 / l2 / cap1 / cap2 of KmerGroupDev count 16-byte items in this mode
 uint32_t faqcs_skm_grid(uint32_t n_reads, int n_cu);
@@ -108,6 +129,9 @@ hipError_t faqcs_launch_skm_extract16(const DevParams &P, const KmerGroupDev &G,
                                       uint32_t r_begin, uint32_t r_end, const faqcs_read_result *results, uint32_t *defer, uint32_t *defer_n,
                                       int n_cu, hipStream_t st);
 hipError_t faqcs_launch_skm_flush(const KmerGroupDev &G, const KmerTable &T, uint32_t k, hipStream_t st, uint32_t stages = 7u);
+// the pass ends with this group and nothing of it has reached the table but through the per-occurrence path: fine split, count, cursors
+// back to zero (stages as above).  The table is clean afterwards unless its overflow area was used (stats[3] counts those inserts).
+hipError_t faqcs_launch_skm_finish(const KmerGroupDev &G, const KmerTable &T, uint32_t k, int n_cu, hipStream_t st, uint32_t stages = 7u);
 hipError_t faqcs_launch_skm_reset(const KmerGroupDev &G, hipStream_t st);
 uint32_t faqcs_skm_items_grid(unsigned long long n_items, int n_cu);
 hipError_t faqcs_launch_skm_items(const KmerGroupDev &G, const KmerTable &T, uint32_t k, uint32_t rot, const void *items, unsigned long long n_items,
@@ -116,10 +140,6 @@ hipError_t faqcs_launch_skm_items(const KmerGroupDev &G, const KmerTable &T, uin
 // destination, run fields replaced by absolute epochs; scratch: region_offset[65536 + 2 * 64] u64
 hipError_t faqcs_launch_skm_outbox(const KmerGroupDev &G, uint32_t world, unsigned long long *dest_count, unsigned long long *region_offset,
                                    void *out, hipStream_t st);
-// owner side when the epochs do not fit a group (more than KG_EPOCH_SPAN): every occurrence of the received items by atomics
-hipError_t faqcs_launch_skm_items_atomic(const KmerGroupDev &G, const KmerTable &T, uint32_t k, const void *items, unsigned long long n_items,
-                                         int n_cu, hipStream_t st);
-
 #ifdef __HIPCC__
 __device__ __forceinline__ uint64_t kmer_mix(uint64_t x)
 {

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void kmer_first_epoch_histogram(const KmerTabl
 // (Read-only: round 4 cleared the live sectors in the same pass; the scattered stores between the reads cost more than kmer_table_init's
 // stream of stores afterwards -- 17.5 against 7 + 6.6 ms on a 2^31-slot table.)
 __global__ __launch_bounds__(256) void kmer_count_histogram(const KmerTable T, unsigned long long *dense, uint32_t dense_n,
-                                                            unsigned long long *big, unsigned long long *n_big, uint32_t big_cap)
+                                                            unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, const uint64_t first_slot)
 {
     constexpr uint32_t LOCAL = 4096;
     __shared__ uint32_t h[LOCAL];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void kmer_count_histogram(const KmerTable T, u
     // been seen ONCE (sequencing errors): 64 lanes adding to h[1] serialise in the LDS, so the lanes of a wave whose key has count 1 add
     // their number once (round 5: 18.5 -> see profiles/r5*/ ms per pass on the bench's table).
     constexpr int U = 4;
-    for (uint64_t i0 = (uint64_t)blockIdx.x * U * blockDim.x + threadIdx.x; i0 < hi; i0 += (uint64_t)gridDim.x * U * blockDim.x) {
+    for (uint64_t i0 = first_slot + (uint64_t)blockIdx.x * U * blockDim.x + threadIdx.x; i0 < hi; i0 += (uint64_t)gridDim.x * U * blockDim.x) {
         KmerSlot sl[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -285,11 +285,13 @@ hipError_t faqcs_launch_kmer(const DevParams &P, uint32_t k, const KmerTable &T,
     return hipGetLastError();
 }
 
+// overflow_only: the area behind the table alone (a pass counted in one piece leaves the table's slices empty: skm_combine<KS_REDO>)
 hipError_t faqcs_launch_kmer_histogram(const KmerTable &T, unsigned long long *dense, uint32_t dense_n,
                                        unsigned long long *big, unsigned long long *n_big, uint32_t big_cap, int n_cu,
-                                       hipStream_t st)
+                                       hipStream_t st, bool overflow_only)
 {
-    hipLaunchKernelGGL(kmer_count_histogram, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap);
+    hipLaunchKernelGGL(kmer_count_histogram, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T, dense, dense_n, big, n_big, big_cap,
+                       overflow_only ? T.mask + 1 : 0ull);
     return hipGetLastError();
 }
 
@@ -352,8 +354,9 @@ __global__ void kmer_table_init(KmerSlot *slots, const uint64_t n)
         reinterpret_cast<ulonglong2 *>(slots)[i] = empty;
 }
 
-hipError_t faqcs_launch_kmer_table_init(const KmerTable &T, int n_cu, hipStream_t st)
+hipError_t faqcs_launch_kmer_table_init(const KmerTable &T, int n_cu, hipStream_t st, bool overflow_only)
 {
-    hipLaunchKernelGGL(kmer_table_init, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T.slots, kmer_table_total(T));
+    if (overflow_only) { if (T.ovf_mask) hipLaunchKernelGGL(kmer_table_init, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T.slots + T.mask + 1, T.ovf_mask + 1); }
+    else hipLaunchKernelGGL(kmer_table_init, dim3((uint32_t)n_cu * 8u), dim3(256), 0, st, T.slots, kmer_table_total(T));
     return hipGetLastError();
 }

@@ -40,15 +40,19 @@ __device__ __forceinline__ void hist_add(u64 *h, uint32_t e, uint32_t n_epochs, 
     if (e < n_epochs) atomicAdd(&h[e], (u64)v);
 }
 
-// The table is cut into 65 536 slices, one per partition; a key lives in the slice of ITS partition (slot inside the slice = top
-// bits of the mixed key) and a probe sequence wraps inside the slice.  That is what lets skm_combine update the table without
-// device-scope atomics: the workgroup of a partition is the only one in its slice for the length of the launch.
+// The table is cut into 2^(16 + F) slices, one per FINE partition (the top 16 + F bits of an item's 19-bit partition; F = KmerTable::fine);
+// a key lives in the slice of ITS fine partition (slot inside the slice = top bits of the mixed key) and a probe sequence wraps inside
+// the slice.  That is what lets skm_combine update the table without device-scope atomics: the workgroup that counts a partition --
+// a fine one at the end of a pass, the eight (2^F) fine ones of a 16-bit partition in a group that is flushed while the pass goes on --
+// is the only one in its slices for the length of the launch.
 struct Slice { u64 base, mask; int shift; };
-__device__ __forceinline__ Slice slice_of(const KmerTable &T, const uint32_t part)
+__device__ __forceinline__ Slice slice_of_fine(const KmerTable &T, const uint32_t fine_part)
 {
-    const u64 size = (T.mask + 1) >> 16;
-    return Slice{(u64)part * size, size - 1, (int)T.shift + 16};
+    const u64 size = (T.mask + 1) >> (16u + T.fine);
+    return Slice{(u64)fine_part * size, size - 1, (int)(T.shift + 16u + T.fine)};
 }
+__device__ __forceinline__ uint32_t fine_of(const KmerTable &T, const uint32_t part19) { return part19 >> (3u - T.fine); }
+__device__ __forceinline__ Slice slice_of(const KmerTable &T, const uint32_t part19) { return slice_of_fine(T, fine_of(T, part19)); }
 
 // One slot, atomically: key h gets `count` more occurrences and epoch as a candidate first epoch.  true: done (the key was there or
 // the slot was free); false: the slot holds another key.  This is also where the general first-epoch rule lives: old = atomic min;
@@ -83,6 +87,7 @@ __device__ void ovf_insert_atomic(const KmerTable &T, const u64 h, const uint32_
     // (a probe sequence of the overflow area is cut at 4 096 slots and nothing is tried once the table has been declared full: an area
     // that is full would otherwise be scanned end to end for every key -- the run fails with FAQCS_E_KMER_FULL either way, but at once)
     if (T.ovf_mask && !(__hip_atomic_load(&T.stats[2], __ATOMIC_RELAXED, FAQCS_KMER_SCOPE) & 1ull)) {
+        atomicAdd(&T.stats[3], 1ull); // (the area is in use: the end of the pass has to sweep it)
         KmerSlot *ovf = T.slots + T.mask + 1;
         u64 g = (h ^ (h >> 23)) & T.ovf_mask;
         const u64 n_probe = T.ovf_mask < 4095ull ? T.ovf_mask + 1 : 4096ull;
@@ -94,11 +99,14 @@ __device__ void ovf_insert_atomic(const KmerTable &T, const u64 h, const uint32_
     }
     atomicOr(&T.stats[2], 1ull); // table full
 }
-// per-occurrence insert of a mixed key (what does not fit a sub-region of the group buffers)
+// per-occurrence insert of a mixed key (what does not fit a sub-region of the group buffers); part = the item's 19-bit partition.
+// The fine partition's dirty bit tells the counting pass at the end that this slice holds keys.
 __device__ void kmer_insert_atomic(const KmerTable &T, const uint32_t part, const u64 h, const uint32_t epoch, const uint32_t count,
                                    u64 *first_hist, const uint32_t n_epochs)
 {
-    const Slice sc = slice_of(T, part);
+    const uint32_t fp = fine_of(T, part);
+    const Slice sc = slice_of_fine(T, fp);
+    if (T.dirty) { const uint32_t bit = 1u << (fp & 31u); if (!(__hip_atomic_load(&T.dirty[fp >> 5], __ATOMIC_RELAXED, FAQCS_KMER_SCOPE) & bit)) atomicOr(&T.dirty[fp >> 5], bit); }
     u64 g = (h >> sc.shift) & sc.mask;
     const u64 win = sc.mask + 1 < (u64)KS_PROBE_MAX ? sc.mask + 1 : (u64)KS_PROBE_MAX;
 #pragma unroll 1
@@ -471,9 +479,9 @@ __global__ __launch_bounds__(NW * 64) void skm_extract(
         }
         // ---- stage ----
         if (n_pend) {
-            bool ok0 = S.put(skm_item_part(pend[0].y) >> 8, pend[0]);
+            bool ok0 = S.put(skm_item_bucket(pend[0].y), pend[0]);
             if (n_pend == 2u) {
-                const bool ok1 = S.put(skm_item_part(pend[1].y) >> 8, pend[1]);
+                const bool ok1 = S.put(skm_item_bucket(pend[1].y), pend[1]);
                 if (ok0 && !ok1) { pend[0] = pend[1]; }
                 if (ok0 != ok1) n_pend = 1u; else n_pend = ok0 ? 0u : 2u;
             } else n_pend = ok0 ? 0u : 1u;
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(NW * 64) void skm_extract16(
                     has_pend = true;
                 }
                 if (has_pend) {
-                    if (S.put(skm_item_part(pend.y) >> 8, pend)) has_pend = false;
+                    if (S.put(skm_item_bucket(pend.y), pend)) has_pend = false;
                     else stuck = true;
                 }
             }
@@ -723,7 +731,14 @@ __global__ __launch_bounds__(NW * 64) void skm_extract16(
 }
 
 // ---- level 1 from items another rank extracted: the owner side of the multi-GPU exchange (faqcs_kmer_insert_device) -----------
-// An item's run field holds its ABSOLUTE epoch (the group's run -> epoch table is the identity in this mode).
+// An item's run field holds its ABSOLUTE epoch (the group's run -> epoch table is the identity in this mode).  The item's partition
+// becomes the owner's LOCAL one (KmerGroupDev::part_mul): a rank owns 1 / world of the 19-bit partitions, and mapped onto [0, 2^19) they use
+// all of its level-1 buckets, level-2 regions and table slices instead of 1 / world of each.
+__device__ __forceinline__ Item item_local(const KmerGroupDev &G, Item it)
+{
+    if (G.part_mul) it.y = skm_item_with_part(it.y, (uint32_t)(((u64)(skm_item_part(it.y) - G.part_lo) * G.part_mul) >> 32));
+    return it;
+}
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void skm_items(const KmerGroupDev G, const KmerTable T, const uint32_t k, const uint32_t rot,
                                                      const Item *__restrict__ items, const u64 n_items)
@@ -747,11 +762,11 @@ __global__ __launch_bounds__(NW * 64) void skm_items(const KmerGroupDev G, const
     const u64 lo = (u64)blockIdx.x * per_block < n_items ? (u64)blockIdx.x * per_block : n_items;
     const u64 hi = lo + per_block < n_items ? lo + per_block : n_items;
     uint32_t phase = 0;
-    Item nx = lo + tid < hi ? items[lo + tid] : make_ulonglong2(0ull, KS_NONE);
+    Item nx = lo + tid < hi ? item_local(G, items[lo + tid]) : make_ulonglong2(0ull, KS_NONE);
 #pragma unroll 1
     for (u64 t0 = lo; t0 < hi; t0 += PER) {
         const Item cur = nx;
-        nx = t0 + PER + tid < hi ? items[t0 + PER + tid] : make_ulonglong2(0ull, KS_NONE);
+        nx = t0 + PER + tid < hi ? item_local(G, items[t0 + PER + tid]) : make_ulonglong2(0ull, KS_NONE);
         uint32_t pend = 0;
         if (cur.y != KS_NONE && skm_item_run(cur.y) < (uint32_t)KG_EPOCH_SPAN) {
             pend = 1u;
@@ -759,7 +774,7 @@ __global__ __launch_bounds__(NW * 64) void skm_items(const KmerGroupDev G, const
         }
 #pragma unroll 1
         for (;;) {
-            if (pend && S.put(skm_item_part(cur.y) >> 8, cur)) pend = 0u;
+            if (pend && S.put(skm_item_bucket(cur.y), cur)) pend = 0u;
             __syncthreads();
             S.drain(wave, lane, false, G.cap1, write, slow);
             if (!(S.block_or(pend, phase, tid) & 1u)) break;
@@ -827,7 +842,7 @@ __global__ __launch_bounds__(NW * 64) void skm_split(const KmerGroupDev G, const
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     if ((pend >> j) & 1u)
-                        if (S.put(skm_item_part(cur[j].y) & 255u, cur[j])) pend &= ~(1u << j);
+                        if (S.put(skm_item_p16(cur[j].y) & 255u, cur[j])) pend &= ~(1u << j);
                 __syncthreads();
                 if (!fetched) {
                     asm volatile("" ::"v"(nx[0].x), "v"(nx[0].y), "v"(nx[1].x), "v"(nx[1].y));
@@ -846,6 +861,107 @@ __global__ __launch_bounds__(NW * 64) void skm_split(const KmerGroupDev G, const
     for (int i = tid; i < KG_FAN; i += NW * 64) G.cur2[((size_t)b1 * KG_FAN + i) * G.split + part] = S.cur[i];
 }
 
+// ---- level 2 of a pass that is counted at its END: every bucket (256 << F) ways, by a sort of 8 192-item tiles in LDS -------------
+// 2 048 staging buckets of 32 slots do not fit a CU's LDS, so the fine split does not stage per bucket: block b1 (one per bucket, one
+// per CU) takes the bucket's items tile by tile, counts the tile's items per fine partition (an LDS atomic hands out the item's rank
+// inside its partition), turns the counts into offsets, scatters the tile into LDS in partition order and writes it out -- an item of
+// sorted position i goes to region (b1, f) at cur[f] + (i - off[f]): consecutive lanes write consecutive 16-byte words of a region, about
+// 64 bytes per partition and tile.  The cursors live in the block's LDS (it is the only writer of its 256 << F regions): no atomics on
+// memory.  What does not fit a region is inserted occurrence by occurrence, which also sets the fine partition's dirty bit.
+template <int NT, int IPT>
+__global__ __launch_bounds__(NT) void skm_split_sort(const KmerGroupDev G, const KmerTable T, const uint32_t k)
+{
+    constexpr uint32_t TILE = NT * IPT, NBMAX = KG_FAN << 3;
+    static_assert(NBMAX == 2 * NT, "a thread scans two counters");
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    Item *s_items = reinterpret_cast<Item *>(lds);                 // [TILE] the tile in partition order
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_items + TILE); // [NBMAX] items of the tile per fine partition, then their exclusive prefix
+    uint32_t *s_cur = s_cnt + NBMAX;                               // [NBMAX] items the regions hold
+    uint32_t *s_pre = s_cur + NBMAX;                               // [KG_FAN + 1] exclusive prefix of the bucket's sub-region sizes
+    uint32_t *s_er = s_pre + KG_FAN + 4;                           // [KG_MAX_RUNS] epoch of run j, relative
+    uint32_t *s_ws = s_er + KG_MAX_RUNS;                           // [NT / 64]
+    const SkmGeom g = skm_geom(k);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const uint32_t NB = (uint32_t)KG_FAN << T.fine, fsh = 3u - T.fine, b1 = blockIdx.x;
+    for (uint32_t i = tid; i < NBMAX; i += NT) { s_cnt[i] = 0u; s_cur[i] = 0u; }
+    if (tid < KG_FAN) s_pre[tid + 1] = G.cur1[tid * KG_FAN + b1];
+    for (uint32_t j = tid; j < G.n_runs; j += NT) s_er[j] = G.run_epoch[j];
+    __syncthreads();
+    if (tid == 0) { uint32_t run_ = 0; s_pre[0] = 0u; for (int i = 1; i <= KG_FAN; ++i) { run_ += s_pre[i]; s_pre[i] = run_; } }
+    __syncthreads();
+    const uint32_t N = s_pre[KG_FAN];
+    Item *const l2 = reinterpret_cast<Item *>(G.l2) + (size_t)b1 * NB * G.cap2f;
+    auto slow = [&](const Item it) { skm_insert_item_atomic(T, it, G.epoch_base + skm_item_run(it.y), g, G.first_hist, G.n_epochs); };
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < N; t0 += TILE) {
+        const uint32_t n_t = N - t0 < TILE ? N - t0 : TILE;
+        // ---- load, count: tk = fine partition << 16 | rank of the item among the tile's items of that partition ----
+        Item it[IPT];
+        uint32_t tk[IPT];
+        uint32_t sr = 0;
+        if ((uint32_t)tid < n_t) { // the sub-region that holds item t0 + tid of the bucket
+            const uint32_t i = t0 + (uint32_t)tid;
+            uint32_t lo = 0, hi = KG_FAN - 1;
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_pre[mid] <= i) lo = mid; else hi = mid - 1; }
+            sr = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t pos = (uint32_t)(j * NT + tid);
+            tk[j] = 0xffffffffu;
+            it[j] = make_ulonglong2(0ull, 0ull);
+            if (pos < n_t) {
+                const uint32_t i = t0 + pos;
+                while (i >= s_pre[sr + 1]) ++sr; // (i < N = s_pre[256]: ends)
+                it[j] = l1_region(G, b1, sr)[i - s_pre[sr]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t pos = (uint32_t)(j * NT + tid);
+            if (pos < n_t) {
+                it[j].y = (it[j].y & ~SKM_RUN_MASK) | ((u64)s_er[skm_item_run(it[j].y)] << SKM_RUN_SHIFT);
+                const uint32_t f = (skm_item_part(it[j].y) >> fsh) & (NB - 1u);
+                tk[j] = (f << 16) | atomicAdd(&s_cnt[f], 1u);
+            }
+        }
+        __syncthreads();
+        // ---- counts -> exclusive offsets (a thread owns counters 2 tid, 2 tid + 1) ----
+        const uint32_t a0 = s_cnt[2 * tid], a1 = s_cnt[2 * tid + 1];
+        const uint32_t incl = (uint32_t)wave_incl_scan_add((int)(a0 + a1));
+        if (lane == 63) s_ws[wave] = incl;
+        __syncthreads();
+        const uint32_t wsc = (uint32_t)wave_incl_scan_add(lane < NT / 64 ? (int)s_ws[lane] : 0);
+        const uint32_t base = wave ? (uint32_t)__builtin_amdgcn_readlane((int)wsc, wave - 1) : 0u;
+        const uint32_t excl = base + incl - (a0 + a1);
+        s_cnt[2 * tid] = excl; s_cnt[2 * tid + 1] = excl + a0;
+        __syncthreads();
+        // ---- the tile in partition order ----
+#pragma unroll
+        for (int j = 0; j < IPT; ++j)
+            if (tk[j] != 0xffffffffu) s_items[s_cnt[tk[j] >> 16] + (tk[j] & 0xffffu)] = it[j];
+        __syncthreads();
+        // ---- out: sorted position -> (region, place) ----
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t pos = (uint32_t)(j * NT + tid);
+            if (pos < n_t) {
+                const Item x = s_items[pos];
+                const uint32_t f = (skm_item_part(x.y) >> fsh) & (NB - 1u);
+                const uint32_t at = s_cur[f] + (pos - s_cnt[f]);
+                if (at < G.cap2f) l2[(size_t)f * G.cap2f + at] = x; else slow(x);
+            }
+        }
+        __syncthreads();
+        { const uint32_t c0 = s_cur[2 * tid] + a0, c1 = s_cur[2 * tid + 1] + a1;
+          s_cur[2 * tid] = c0 < G.cap2f ? c0 : G.cap2f; s_cur[2 * tid + 1] = c1 < G.cap2f ? c1 : G.cap2f;
+          s_cnt[2 * tid] = 0u; s_cnt[2 * tid + 1] = 0u; }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < NB; i += NT) G.cur2[(size_t)b1 * NB + i] = s_cur[i];
+}
+constexpr size_t KS_SORT_LDS = (size_t)1024 * 8 * 16 + (size_t)(KG_FAN << 3) * 8 + (size_t)(KG_FAN + 4 + KG_MAX_RUNS + 16) * 4;
+
 // ---- combine + insert: one workgroup per partition --------------------------------------------------------------------------
 // A lane handles one OCCURRENCE, not one item: the items of a tile (one per thread, a coalesced load) get their first occurrence
 // index by a block-wide prefix sum of their k-mer counts; a bit per occurrence index marks "an item starts here" and a word per 64
@@ -856,74 +972,114 @@ __global__ __launch_bounds__(NW * 64) void skm_split(const KmerGroupDev G, const
 // lane with rolling words and ran at 31 % lane use (profiles/r5a/pmc_skm_first.txt: 5.7 scalar + 3.2 vector instructions per
 // occurrence, scalar-issue bound).
 // The LDS table holds (h, count, smallest epoch), h = mix62(canonical key); LDS slot = the top 12 bits of h and the table slot inside
-// the partition's slice = the top bits of h too, so LDS order is table order.  When the LDS table is nearly full every wave stops
+// the key's slice = the top bits of h too, so LDS order is table order.  When the LDS table is nearly full every wave stops
 // where it is, the table is written out -- ONE update per distinct key -- and cleared, and the waves go on.
-template <int NT, bool K31>
-__global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const KmerTable T, const uint32_t k_arg, const uint32_t diag)
+//
+// MODE (round 6).  KS_GROUP: a group that is flushed while the pass goes on, one workgroup per 16-bit partition, every key through the table.
+// KS_COUNT: the group is the whole pass.  A workgroup takes fine partitions p = blockIdx.x, + gridDim.x, ...; partition p's items are ALL
+// the occurrences of its keys in the pass, so when they fit one round of the LDS table -- and the per-occurrence path has not put keys of
+// p into the table (KmerTable::dirty) -- the keys never reach the table: count -> histogram of counts (FaQCs.cpp:518-521), first epoch ->
+// keys by first epoch (the sampling points, trim.cpp:157-185), and the LDS table is cleared for the next partition.  A partition that
+// does not fit, or is dirty, is put on a list (KmerGroupDev::redo) and left to KS_REDO: a launch behind this one that takes the listed
+// fine partitions through their slices as KS_GROUP would, and then sweeps each slice (histogram of counts, slots back to empty).  The table
+// is clean behind the pair of launches, but for keys in the overflow area (KmerTable::stats[3] counts those).  Two kernels because the
+// count-only one has to keep to 64 registers (two workgroups of 1 024 threads per CU) and the table code costs twenty more.
+enum { KS_GROUP = 0, KS_COUNT = 1, KS_REDO = 2 };
+template <int NT, bool K31, int MODE>
+__global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const KmerGroupDev G, const KmerTable T, const uint32_t k_arg, const uint32_t diag)
 {
+    constexpr bool FINAL = MODE != KS_GROUP;
     constexpr int LS = 4096, NWV = NT / 64;
     constexpr uint32_t LMASK = LS - 1, LIMIT = LS - 1280; // stop adding keys at 69 % (every wave may add 64 more before it sees the count)
     constexpr int MAXW = (NT * SKM_W_MAX + 63) / 64;       // 64-occurrence words of a tile
+    constexpr int CLAIM_BITS = FINAL ? KG_SLICE_MAX >> 3 : KG_SLICE_MAX; // slots of the slices this workgroup may claim in: one fine slice / a 16-bit partition's
+    constexpr uint32_t CH = 256;                            // FINAL: counts below CH are added up in LDS first
     __shared__ u64 s_key[LS];
     __shared__ uint32_t s_cnt[LS];
-    __shared__ uint32_t s_ep[LS];
+    __shared__ uint32_t s_ep[LS];                   // smallest epoch << 3 | the low three bits of the key's 19-bit partition
     __shared__ int s_hist[KG_EPOCH_SPAN];
-    __shared__ uint32_t s_claim[KG_SLICE_MAX / 32]; // slots of the slice this launch has claimed
+    __shared__ uint32_t s_claim[CLAIM_BITS / 32];   // slots this launch has claimed
     __shared__ uint32_t s_bits[2 * MAXW];           // bit o: an item's first occurrence has index o inside the tile
     __shared__ uint32_t s_rank[MAXW];               // index (inside the tile) of the first item that starts in the word
     __shared__ uint32_t s_wsum[NWV];
+    __shared__ uint32_t s_chist[FINAL ? CH : 2];
     __shared__ uint32_t s_nkeys, s_more;
-    static_assert(NWV * 64 + LIMIT <= LS, "waves overshoot the limit by at most 64 keys each");
-    const uint32_t p = blockIdx.x;
-    const uint32_t n_p = G.cur2[p]; // (split == 1)
-    if (n_p == 0) return; // (block-uniform)
+    static_assert(NWV * 64 + LIMIT <= LS && LS == 4 * NT, "waves overshoot the limit by at most 64 keys each; four LDS slots per thread");
     const SkmGeom g = skm_geom(K31 ? 31u : k_arg);
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-    const Slice sc = slice_of(T, p);
-    const Item *src = reinterpret_cast<const Item *>(G.l2) + (size_t)p * G.cap2;
-    auto item_at = [&](const uint32_t i) -> Item { return src[i]; }; // (one sub-region per partition in this mode: kg_init)
-    Item nx = (uint32_t)tid < n_p ? item_at((uint32_t)tid) : make_ulonglong2(0ull, KS_NONE);
+    const uint32_t fsh = 3u - T.fine;
     auto clear = [&]() {
         for (int i = tid; i < LS; i += NT) { s_key[i] = ~0ull; s_cnt[i] = 0u; s_ep[i] = 0xffffffffu; }
         if (tid == 0) { s_nkeys = 0u; s_more = 0u; }
     };
     clear();
     for (int i = tid; i < KG_EPOCH_SPAN; i += NT) s_hist[i] = 0;
-    for (uint32_t i = tid; i < (uint32_t)(sc.mask + 32) / 32; i += NT) s_claim[i] = 0u;
+    for (int i = tid; i < CLAIM_BITS / 32; i += NT) s_claim[i] = 0u;
+    if (FINAL) for (uint32_t i = tid; i < CH; i += NT) s_chist[i] = 0u;
+    // one key with `c` occurrences joins the histogram of counts (FINAL)
+    auto count_key = [&](const bool live, const uint32_t c) {
+        const unsigned long long once = __ballot(live && c == 1u); // (most keys of a real run are seen once: sequencing errors -- one add per wave)
+        if (once != 0ull && lane == __builtin_ctzll(once)) atomicAdd(&s_chist[1], (uint32_t)__popcll(once));
+        if (live && c != 1u) {
+            if (c < CH) atomicAdd(&s_chist[c], 1u);
+            else if (c < G.dense_n) atomicAdd(&G.dense[c], 1ull);
+            else { const unsigned long long at = atomicAdd(G.n_big, 1ull); if (at < G.big_cap) G.big[at] = c; }
+        }
+    };
+    const u64 lane_lt = (1ull << lane) - 1ull;
+    const uint32_t n_parts = MODE == KS_REDO ? uniu(*G.n_redo) : (FINAL ? 1u << (16u + T.fine) : (uint32_t)(KG_FAN * KG_FAN));
+#pragma unroll 1
+    for (uint32_t pi = blockIdx.x; pi < n_parts; pi += gridDim.x) {
+    const uint32_t p = MODE == KS_REDO ? uniu(G.redo[pi]) : pi;
+    const uint32_t n_p = uniu(G.cur2[p]); // (split == 1)
+    if (n_p == 0) continue; // (block-uniform)
+    if (MODE == KS_COUNT && T.dirty && ((uniu(T.dirty[p >> 5]) >> (p & 31u)) & 1u)) { // the per-occurrence path has put keys of p into its slice
+        if (tid == 0) G.redo[atomicAdd(G.n_redo, 1u)] = p;
+        continue;
+    }
+    const Item *src = reinterpret_cast<const Item *>(G.l2) + (size_t)p * (FINAL ? G.cap2f : G.cap2); // (one region per partition in this mode: kg_init)
+    auto item_at = [&](const uint32_t i) -> Item { return src[i]; };
+    Item nx = (uint32_t)tid < n_p ? item_at((uint32_t)tid) : make_ulonglong2(0ull, KS_NONE);
+    bool abandon = false; // (KS_COUNT) more distinct keys than one round of the LDS table takes
 
-    // ONE table update per key of the LDS table, none of them a device-scope atomic: the slice belongs to this workgroup for the
+    // ONE table update per key of the LDS table, none of them a device-scope atomic: the slices belong to this workgroup for the
     // length of the launch, an empty slot is claimed through the workgroup's LDS bitmap, and no other thread holds this key.
     auto write_out = [&]() {
-        if (diag & 1u) return; // (FAQCS_SKM_DIAG: what the table updates cost; wrong results)
+        if (MODE == KS_COUNT || (diag & 1u)) return; // (FAQCS_SKM_DIAG: what the table updates cost; wrong results)
         constexpr int KPT = LS / NT, KB = 2; // keys per thread, looked up KB at a time (4: spills, 27.0 instead of 23.7 ms on 16 M reads)
-        const u64 win = sc.mask + 1 < (u64)KS_PROBE_MAX ? sc.mask + 1 : (u64)KS_PROBE_MAX;
         static_assert(LS % NT == 0 && KPT % KB == 0, "keys per thread");
+        const Slice s0 = slice_of_fine(T, FINAL ? p : p << T.fine); // (every fine slice has this size and shift)
+        const u64 win = s0.mask + 1 < (u64)KS_PROBE_MAX ? s0.mask + 1 : (u64)KS_PROBE_MAX;
+        auto base_of = [&](const uint32_t epf) -> u64 { return FINAL ? s0.base : s0.base + (u64)((epf & 7u) >> fsh) * (s0.mask + 1); };
 #pragma unroll 1
         for (int j0 = 0; j0 < KPT; j0 += KB) {
             u64 kw[KB];
+            uint32_t ef[KB];
             ulonglong2 first[KB];
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
                 kw[j] = s_key[(j0 + j) * NT + tid];
-                const u64 gslot = (kw[j] >> sc.shift) & sc.mask;
+                ef[j] = s_ep[(j0 + j) * NT + tid];
+                const u64 gslot = (kw[j] >> s0.shift) & s0.mask;
                 first[j] = make_ulonglong2(0ull, 0ull);
-                if (kw[j] != ~0ull) first[j] = *reinterpret_cast<const ulonglong2 *>(&T.slots[sc.base + gslot]);
+                if (kw[j] != ~0ull) first[j] = *reinterpret_cast<const ulonglong2 *>(&T.slots[base_of(ef[j]) + gslot]);
             }
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
                 const u64 h = kw[j];
                 if (h == ~0ull) continue;
-                const uint32_t e_rel = s_ep[(j0 + j) * NT + tid], e = G.epoch_base + e_rel, cnt = s_cnt[(j0 + j) * NT + tid];
-                u64 gslot = (h >> sc.shift) & sc.mask;
+                const uint32_t e_rel = ef[j] >> 3, e = G.epoch_base + e_rel, cnt = s_cnt[(j0 + j) * NT + tid];
+                const u64 sbase = base_of(ef[j]);
+                u64 gslot = (h >> s0.shift) & s0.mask;
                 bool placed = false;
                 ulonglong2 cur = first[j];
 #pragma unroll 1
                 for (u64 probe = 0; probe < win; ++probe) {
-                    KmerSlot *sl = &T.slots[sc.base + gslot];
+                    KmerSlot *sl = &T.slots[sbase + gslot];
                     if (probe) cur = *reinterpret_cast<const ulonglong2 *>(sl);
                     if (cur.x == ~0ull) {
-                        const uint32_t bit = 1u << (gslot & 31);
-                        if (!(atomicOr(&s_claim[gslot >> 5], bit) & bit)) { // a new key: key, count - 1 and first epoch in one plain store
+                        const uint32_t cb = (uint32_t)(sbase - s0.base + gslot), bit = 1u << (cb & 31u);
+                        if (!(atomicOr(&s_claim[cb >> 5], bit) & bit)) { // a new key: key, count - 1 and first epoch in one plain store
                             *reinterpret_cast<ulonglong2 *>(sl) = make_ulonglong2(h, (u64)(cnt - 1u) | ((u64)e << 32));
                             atomicAdd(&s_hist[e_rel], 1);
                             placed = true;
@@ -943,14 +1099,13 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
                         placed = true;
                         break;
                     }
-                    gslot = (gslot + 1) & sc.mask;
+                    gslot = (gslot + 1) & s0.mask;
                 }
                 if (!placed) ovf_insert_atomic(T, h, e, cnt, G.first_hist, G.n_epochs); // the window is full: the key lives in the overflow area
             }
         }
     };
 
-    const u64 lane_lt = (1ull << lane) - 1ull;
 #pragma unroll 1
     for (uint32_t i0 = 0; i0 < n_p; i0 += NT) {
         const Item it = nx;
@@ -1009,7 +1164,7 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
                 const uint32_t j = j_nx;
                 bool todo = todo_nx;
                 locate(r + NWV);
-                const uint32_t ep = skm_item_run(iw.y);
+                const uint32_t ep = (skm_item_run(iw.y) << 3) | (FINAL ? 0u : skm_item_part(iw.y) & 7u);
                 u64 fwd, rc;
                 if (K31) { // bases j .. j + 30: a 62-bit window at bit 2 j (<= 32) of the 94-bit string
                     const uint32_t d0 = (uint32_t)iw.x, d1 = (uint32_t)(iw.x >> 32), d2 = (uint32_t)iw.y, sh = 2u * j;
@@ -1065,21 +1220,62 @@ __global__ __launch_bounds__(NT, 8) void skm_combine(const KmerGroupDev G, const
             __syncthreads();
             const bool more = s_more != 0u;
             if (!more) break; // (s_more is only written above, before the barrier, and cleared below behind one)
+            if (MODE == KS_COUNT) { abandon = true; break; } // (left to KS_REDO, from its first item on)
             write_out();
             __syncthreads();
             clear();
             // (the next write-out reads slots this one stored: the waves of a workgroup share their CU's vector L1, which is write-through, so
-            // the barriers' workgroup-scope fences are all it takes.  A device-scope __threadfence() here made every round of every
-            // workgroup write back and invalidate its XCD's whole L2: 3 x the time per occurrence as soon as partitions needed two rounds,
-            // 304 instead of 147 ms per bench step with groups of 1.5 x 2^30 occurrences)
+            // the barriers' workgroup-scope fences are all it takes -- as long as the workgroup's waves run on ONE CU, which is how every launch
+            // of this library is dispatched; a threadgroup-split dispatch (tgsplit, waves of a workgroup on several CUs of a WGP-less part) would
+            // need the device-scope fence back.  That fence, a __threadfence() here, made every round of every workgroup write back and
+            // invalidate its XCD's whole L2: 3 x the time per occurrence as soon as partitions needed two rounds, 304 instead of 147 ms per
+            // bench step with groups of 1.5 x 2^30 occurrences)
             __syncthreads();
+        }
+        if (MODE == KS_COUNT && abandon) break;
+    }
+    __syncthreads();
+    if (MODE == KS_COUNT && abandon) {
+        if (tid == 0) G.redo[atomicAdd(G.n_redo, 1u)] = p;
+        clear();
+    } else if (MODE != KS_COUNT) {
+        write_out();
+        __syncthreads();
+        if (FINAL && !(diag & 1u)) { // the slice's keys (this launch's and the per-occurrence path's) join the histogram of counts; the slice is empty again
+            const Slice sc = slice_of_fine(T, p);
+            const ulonglong2 empty = make_ulonglong2(~0ull, 0xffffffff00000000ull);
+            for (u64 i = tid; i <= (sc.mask | (u64)(NT - 1)); i += NT) { // (whole waves: count_key() votes)
+                const bool in = i <= sc.mask;
+                ulonglong2 v = empty;
+                if (in) v = *reinterpret_cast<const ulonglong2 *>(&T.slots[sc.base + i]);
+                const bool live = in && v.x != ~0ull;
+                count_key(live, (uint32_t)v.y + 1u);
+                if (live) *reinterpret_cast<ulonglong2 *>(&T.slots[sc.base + i]) = empty;
+            }
+            for (u64 i = tid; i < (sc.mask + 32) / 32; i += NT) s_claim[i] = 0u;
+        }
+        clear();
+    } else { // FINAL, every key of the partition is in the LDS table: histograms, and the table is empty again
+        u64 kw[4];
+        uint32_t cw[4], ew[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kw[j] = s_key[4 * tid + j]; cw[j] = s_cnt[4 * tid + j]; ew[j] = s_ep[4 * tid + j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s_key[4 * tid + j] = ~0ull; s_cnt[4 * tid + j] = 0u; s_ep[4 * tid + j] = 0xffffffffu; }
+        if (tid == 0) { s_nkeys = 0u; s_more = 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool live = kw[j] != ~0ull;
+            count_key(live, cw[j]);
+            if (live) atomicAdd(&s_hist[ew[j] >> 3], 1);
         }
     }
     __syncthreads();
-    write_out();
+    } // partitions
     __syncthreads();
     for (int i = tid; i < KG_EPOCH_SPAN; i += NT)
         if (s_hist[i]) hist_add(G.first_hist, G.epoch_base + (uint32_t)i, G.n_epochs, (long long)s_hist[i]);
+    if (FINAL) for (uint32_t i = tid; i < CH; i += NT) if (s_chist[i]) atomicAdd(&G.dense[i], (unsigned long long)s_chist[i]);
 }
 
 __global__ void skm_group_reset(const KmerGroupDev G)
@@ -1102,7 +1298,7 @@ __global__ __launch_bounds__(256) void skm_outbox_count(const KmerGroupDev G, co
     if (b < 64) s_spill[b] = 0u;
     __syncthreads();
     const uint32_t n_spill = G.spill ? (*G.spill_n < G.spill_cap ? *G.spill_n : G.spill_cap) : 0u;
-    for (uint32_t i = b; i < n_spill; i += 256) atomicAdd(&s_spill[((skm_item_part(reinterpret_cast<const Item *>(G.spill)[i].y) >> 8) * world) >> 8], 1u);
+    for (uint32_t i = b; i < n_spill; i += 256) atomicAdd(&s_spill[(skm_item_bucket(reinterpret_cast<const Item *>(G.spill)[i].y) * world) >> 8], 1u);
     u64 n = 0;
     for (uint32_t s = 0; s < (uint32_t)KG_FAN; ++s) n += G.cur1[s * KG_FAN + b];
     s_sum[b] = n;
@@ -1142,20 +1338,8 @@ __global__ __launch_bounds__(256) void skm_outbox_copy(const KmerGroupDev G, con
     const uint32_t n_spill = G.spill ? (*G.spill_n < G.spill_cap ? *G.spill_n : G.spill_cap) : 0u;
     for (uint32_t i = (blockIdx.x - KG_FAN * KG_FAN) * 256 + threadIdx.x; i < n_spill; i += 16 * 256) {
         const Item it = reinterpret_cast<const Item *>(G.spill)[i];
-        const uint32_t d = ((skm_item_part(it.y) >> 8) * world) >> 8;
+        const uint32_t d = (skm_item_bucket(it.y) * world) >> 8;
         out[spill_base[d] + atomicAdd(&spill_cursor[d], 1ull)] = with_epoch(it);
-    }
-}
-
-// ---- owner side when the epochs do not fit a group: every occurrence of the received items by atomics --------------------------
-__global__ __launch_bounds__(256) void skm_items_atomic(const KmerGroupDev G, const KmerTable T, const uint32_t k, const Item *__restrict__ items, const u64 n_items)
-{
-    const SkmGeom g = skm_geom(k);
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (u64)gridDim.x * 256) {
-        const Item it = items[i];
-        const uint32_t e = skm_item_run(it.y);
-        skm_insert_item_atomic(T, it, e, g, G.first_hist, G.n_epochs);
-        hist_add(G.tot_by_epoch, e, G.n_epochs, (long long)skm_item_kmers(it.y));
     }
 }
 
@@ -1250,8 +1434,36 @@ hipError_t faqcs_launch_skm_flush(const KmerGroupDev &G, const KmerTable &T, uin
     if (e != hipSuccess) return e;
     if (stages & 1u) hipLaunchKernelGGL((skm_split<KS_NW>), dim3(KG_FAN * G.split), dim3(KS_NW * 64), lds, st, G, T, k);
     static const uint32_t diag = [] { const char *e = getenv("FAQCS_SKM_DIAG"); return e ? (uint32_t)atoi(e) : 0u; }(); // (diagnostics: 1 no table updates, 2 no LDS counting)
-    if ((stages & 2u) && k == 31) hipLaunchKernelGGL((skm_combine<1024, true>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k, diag);
-    else if (stages & 2u) hipLaunchKernelGGL((skm_combine<1024, false>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k, diag);
+    if ((stages & 2u) && k == 31) hipLaunchKernelGGL((skm_combine<1024, true, KS_GROUP>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k, diag);
+    else if (stages & 2u) hipLaunchKernelGGL((skm_combine<1024, false, KS_GROUP>), dim3(KG_FAN * KG_FAN), dim3(1024), 0, st, G, T, k, diag);
+    if (stages & 4u) hipLaunchKernelGGL(skm_group_reset, dim3(KG_FAN * KG_FAN / 256), dim3(256), 0, st, G);
+    return hipGetLastError();
+}
+
+// the group is the whole pass (stages: 1 fine split, 2 count, 4 cursor reset)
+hipError_t faqcs_launch_skm_finish(const KmerGroupDev &G, const KmerTable &T, uint32_t k, int n_cu, hipStream_t st, uint32_t stages)
+{
+    static unsigned long long done = 0;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&skm_split_sort<1024, 8>), KS_SORT_LDS, done);
+    if (e != hipSuccess) return e;
+    if (stages & 1u) hipLaunchKernelGGL((skm_split_sort<1024, 8>), dim3(KG_FAN), dim3(1024), KS_SORT_LDS, st, G, T, k);
+    static const uint32_t diag = [] { const char *e = getenv("FAQCS_SKM_DIAG"); return e ? (uint32_t)atoi(e) : 0u; }();
+    // two workgroups per CU are resident; sixteen per CU in the grid even out what the partitions' sizes differ by
+    uint32_t grid = (uint32_t)n_cu * 16u;
+    const uint32_t n_parts = 1u << (16u + T.fine);
+    if (grid > n_parts) grid = n_parts;
+    if (stages & 2u) {
+        hipError_t e2 = hipMemsetAsync(G.n_redo, 0, 4, st);
+        if (e2 != hipSuccess) return e2;
+        // (the second launch finds its partitions in the list the first one leaves: none on an even input, and its workgroups end at once)
+        if (k == 31) {
+            hipLaunchKernelGGL((skm_combine<1024, true, KS_COUNT>), dim3(grid), dim3(1024), 0, st, G, T, k, diag);
+            hipLaunchKernelGGL((skm_combine<1024, true, KS_REDO>), dim3((uint32_t)n_cu), dim3(1024), 0, st, G, T, k, diag);
+        } else {
+            hipLaunchKernelGGL((skm_combine<1024, false, KS_COUNT>), dim3(grid), dim3(1024), 0, st, G, T, k, diag);
+            hipLaunchKernelGGL((skm_combine<1024, false, KS_REDO>), dim3((uint32_t)n_cu), dim3(1024), 0, st, G, T, k, diag);
+        }
+    }
     if (stages & 4u) hipLaunchKernelGGL(skm_group_reset, dim3(KG_FAN * KG_FAN / 256), dim3(256), 0, st, G);
     return hipGetLastError();
 }
@@ -1267,15 +1479,5 @@ hipError_t faqcs_launch_skm_outbox(const KmerGroupDev &G, uint32_t world, unsign
 {
     hipLaunchKernelGGL(skm_outbox_count, dim3(1), dim3(256), 0, st, G, world, dest_count, scratch);
     hipLaunchKernelGGL(skm_outbox_copy, dim3(KG_FAN * KG_FAN + 16), dim3(256), 0, st, G, world, scratch, reinterpret_cast<Item *>(out));
-    return hipGetLastError();
-}
-
-hipError_t faqcs_launch_skm_items_atomic(const KmerGroupDev &G, const KmerTable &T, uint32_t k, const void *items, unsigned long long n_items,
-                                         int n_cu, hipStream_t st)
-{
-    if (!n_items) return hipSuccess;
-    unsigned long long blocks = (n_items + 255) / 256;
-    if (blocks > (unsigned long long)n_cu * 16ull) blocks = (unsigned long long)n_cu * 16ull;
-    hipLaunchKernelGGL(skm_items_atomic, dim3((uint32_t)blocks), dim3(256), 0, st, G, T, k, reinterpret_cast<const Item *>(items), n_items);
     return hipGetLastError();
 }

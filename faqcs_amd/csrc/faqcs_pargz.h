@@ -17,7 +17,10 @@
 //      patched pieces out in order; the CRCs (crc32_combine) must equal the member's trailer at the end, as must the length: a file that
 //      is not ASCII, or any slip of the speculation, ends the input with an error (like a corrupt file under gzread), it never yields
 //      different bytes silently.
-// What follows the first member (concatenated members) is inflated by the consumer through zlib's gzip decoder, as gzread would go on.
+// What follows a member (concatenated members: `cat lane1.gz lane2.gz`, which gzread reads as one stream) starts the same machinery
+// again at the next member's header when enough of the file is left; a short rest goes through zlib's gzip decoder in the consumer.
+// When a member's last block has been seen, nobody claims a piece any more and the buffers of the pieces behind it are given back:
+// the speculation does not run on through the members that follow (twice the text of such a file stayed resident).
 #pragma once
 #include <zlib.h>
 
@@ -80,6 +83,11 @@ struct ParGzReader {
     size_t window_pieces = 0;    // how many pieces may be in flight behind `consumed`
     bool closing = false;
     bool failed = false;
+    bool stop_claims = false;    // the member's last block has been seen by the chain: no piece behind it belongs to this member
+    size_t rearm_min = 8u << 20; // a following member starts the parallel reader again when at least this much of the file is left
+    int n_workers = 1;
+    size_t piece_arg = 0;
+    std::atomic<size_t> cancel_from{~(size_t)0}; // pieces from this index on start behind the member's trailer: their workers give up
     // consumer state
     size_t cur = 0;              // piece to hand out next
     bool member_done = false, tail_init = false, tail_done = false, tail_mid = false;
@@ -228,43 +236,60 @@ struct ParGzReader {
         void *mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
         if (mp == MAP_FAILED) { ::close(fd); fd = -1; return false; }
         base = (const uint8_t *)mp;
-        data_begin = header_end(0);
-        if (!data_begin) { close(); return false; }
-        n_threads = std::max(1, n_threads);
-        piece_bytes = piece ? piece : std::max<size_t>(512u << 10, std::min<size_t>(4u << 20, (size - data_begin) / (size_t)(8 * n_threads) + 1));
+        n_workers = std::max(1, n_threads);
+        piece_arg = piece;
+        if (!arm(0)) { close(); return false; }
+        return true;
+    }
+    // the member whose header stands at byte `member_off` becomes the member in work: pieces, workers, chain thread; its first piece is
+    // inflated here (its window is known: empty) and decides whether the member qualifies (ASCII).  false: nothing is running.
+    bool arm(size_t member_off)
+    {
+        data_begin = header_end(member_off);
+        if (!data_begin) return false;
+        piece_bytes = piece_arg ? piece_arg : std::max<size_t>(512u << 10, std::min<size_t>(4u << 20, (size - data_begin) / (size_t)(8 * n_workers) + 1));
         n_pieces = (size - data_begin + piece_bytes - 1) / piece_bytes;
         pieces = std::vector<Piece>(n_pieces);
-        window_pieces = (size_t)(3 * n_threads + 2);
-        memset(last_win, 0, sizeof last_win);
-        // piece 0 in this thread: the window is known (empty), and its bytes decide whether the file qualifies (ASCII)
+        window_pieces = (size_t)(3 * n_workers + 2);
+        closing = false; stop_claims = false; cancel_from.store(~(size_t)0);
+        next_claim = 1; consumed = 0; cur = 0; hold = 0; release_lo = 0;
+        member_done = false; total_out = 0;
+        crcs.clear(); crc_index.clear(); crc_wait.clear();
         pieces[0].start_bit.store((uint64_t)data_begin * 8);
         pieces[0].known_window = true;
         pieces[0].state.store(1);
-        next_claim = 1;
-        for (int i = 0; i < n_threads; ++i) workers.emplace_back([this] { work(); }); // (they look for the starts piece 0 will stop at)
+        for (int i = 0; i < n_workers; ++i) workers.emplace_back([this] { work(); }); // (they look for the starts piece 0 will stop at)
         chain_th = std::thread([this] { chain(); });
         inflate_piece(0);
         cv_done.notify_all();
-        if (pieces[0].state.load() != 2) { close(); return false; }
-        for (size_t i = 0; i < pieces[0].n_out; ++i) if (pieces[0].out[i] >= 128) { close(); return false; } // not ASCII: the markers would be ambiguous
-        return true;
+        bool ok = pieces[0].state.load() == 2;
+        for (size_t i = 0; ok && i < pieces[0].n_out; ++i) if (pieces[0].out[i] >= 128) ok = false; // not ASCII: the markers would be ambiguous
+        if (!ok) disarm();
+        return ok;
     }
-    void close()
+    // workers and chain thread stopped, the pieces' buffers back in the pool
+    void disarm()
     {
         { std::lock_guard<std::mutex> l(m); closing = true; }
         cv_work.notify_all(); cv_done.notify_all();
         for (auto &t : workers) if (t.joinable()) t.join();
         workers.clear();
         if (chain_th.joinable()) chain_th.join();
+        for (auto &q : pieces) { give_buf(q.out); give_buf(q.mark); }
+        pieces.clear();
+        n_pieces = 0;
+        { std::lock_guard<std::mutex> l(m); closing = false; }
+    }
+    void close()
+    {
+        disarm();
         if (tail_init && !tail_done) { inflateEnd(&tz); tail_done = true; }
         if (base) munmap(const_cast<uint8_t *>(base), size);
         base = nullptr;
         if (fd >= 0) ::close(fd);
         fd = -1;
-        for (auto &q : pieces) { free(q.out.p); free(q.mark.p); q.out = Buf(); q.mark = Buf(); }
         for (auto &b : pool) free(b.p);
         pool.clear();
-        pieces.clear();
     }
     uint64_t range_begin_bit(size_t i) const { return (uint64_t)(data_begin + i * piece_bytes) * 8; }
 
@@ -286,7 +311,7 @@ struct ParGzReader {
                         found = crc_job = true;
                     }
                     if (found) break;
-                    if (next_claim < n_pieces && next_claim < consumed + window_pieces && !failed) { i = next_claim++; pieces[i].state.store(1); break; }
+                    if (next_claim < n_pieces && next_claim < consumed + window_pieces && !failed && !stop_claims) { i = next_claim++; pieces[i].state.store(1); break; }
                     cv_work.wait(l);
                 }
             }
@@ -334,6 +359,7 @@ struct ParGzReader {
         p.n_out = 0; p.final_seen = false;
         size_t j = i + 1; // the first later piece whose start this one has not passed yet
         for (;;) {
+            if (i >= cancel_from.load(std::memory_order_relaxed)) { fail(); return; } // (a start found inside a FOLLOWING member would run on to its end)
             if (p.n_out + (1u << 16) > p.out.size()) p.out.resize(p.out.size() + p.out.size() / 2);
             f.z.next_out = p.out.data() + p.n_out;
             f.z.avail_out = (uInt)std::min<size_t>(p.out.size() - p.n_out, 1u << 30);
@@ -428,6 +454,11 @@ struct ParGzReader {
             else if (t) { memmove(W.data(), W.data() + t, WIN - t); memcpy(W.data() + WIN - t, tail.data(), t); }
             { std::lock_guard<std::mutex> l(m); p.crc_state.store(1); crc_wait.push_back(c); }
             cv_work.notify_all();
+            if (p.final_seen) { // (what lies behind belongs to another member, or to nobody)
+                std::lock_guard<std::mutex> l(m);
+                stop_claims = true;
+                cancel_from.store((p.trailer_at - data_begin) / piece_bytes + 1);
+            }
             if (p.final_seen || p.next_piece >= n_pieces) return;
             c = p.next_piece;
         }
@@ -472,6 +503,11 @@ struct ParGzReader {
             if (n) return n;
             return next(data);
         }
+        if (n_pieces) { // the member that just ended: its workers stop, its buffers go back (the bytes handed out last are not needed any more)
+            disarm();
+            // another member behind it, and enough of the file left for the speculation to pay: the same again from its header
+            if (tail_from + 2 <= size && base[tail_from] == 31 && base[tail_from + 1] == 139 && size - tail_from >= rearm_min && arm(tail_from)) return next(data);
+        }
         return next_tail(data);
     }
     std::vector<size_t> crc_index;
@@ -506,8 +542,13 @@ struct ParGzReader {
     // do not start with the gzip magic are trailing garbage and end the data, as in zlib
     size_t next_tail(const char *&data)
     {
-        { std::lock_guard<std::mutex> l(m); if (consumed < n_pieces) { consumed = n_pieces; } }
         if (tail_done) return 0;
+        if (pending_rearm) { // (set at the end of a member read here: the next one is long enough for the parallel reader)
+            pending_rearm = false;
+            tail_from = rearm_at;
+            if (arm(tail_from)) return next(data);
+            rearm_min = ~(size_t)0; // it does not qualify (not ASCII): serially from here on
+        }
         if (!tail_init) {
             if (tail_from >= size || size - tail_from < 2 || base[tail_from] != 31 || base[tail_from + 1] != 139) { tail_done = true; return 0; }
             memset(&tz, 0, sizeof tz);
@@ -530,11 +571,21 @@ struct ParGzReader {
             if (rc == Z_STREAM_END) {
                 tail_mid = false;
                 const size_t at = (size_t)(tz.next_in - base);
-                if (at + 2 <= size && base[at] == 31 && base[at + 1] == 139) { inflateReset(&tz); tz.next_in = const_cast<Bytef *>(base + at); tz.avail_in = (uInt)std::min<size_t>(size - at, 1u << 30); tail_mid = true; }
+                if (at + 2 <= size && base[at] == 31 && base[at + 1] == 139) {
+                    if (size - at >= rearm_min && !pending_rearm) { pending_rearm = true; rearm_at = at; inflateEnd(&tz); tail_init = false; }
+                    else { inflateReset(&tz); tz.next_in = const_cast<Bytef *>(base + at); tz.avail_in = (uInt)std::min<size_t>(size - at, 1u << 30); tail_mid = true; }
+                }
                 else { tail_done = true; inflateEnd(&tz); }
             } else if (rc != Z_OK && rc != Z_BUF_ERROR) { failed = true; tail_done = true; inflateEnd(&tz); return 0; }
-            if (got) { data = tail_out.data(); return got; }
+            if (got && !pending_rearm) { data = tail_out.data(); return got; }
+            if (pending_rearm) { // a long member follows the short one(s) read here
+                if (got) { data = tail_out.data(); return got; } // (its bytes first; the next call finds pending_rearm set and tail_init cleared)
+            }
             if (tail_done) return 0;
+            if (pending_rearm) break;
         }
+        return next_tail(data);
     }
+    bool pending_rearm = false;
+    size_t rearm_at = 0;
 };

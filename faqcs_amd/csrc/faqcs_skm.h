@@ -14,11 +14,13 @@
 //   ord(x)   = a bijection of [0, 4^m): the pseudo-random order; a bijection, so that two m-mers tie only when they are EQUAL --
 //              a k-mer and its reverse complement see the same set of canonical m-mers, hence the same smallest ord, hence the
 //              same partition, whichever occurrence of a repeated m-mer a scan happens to meet first
-//   part(o)  = 16 bits mixed out of the smallest ord (the minimum itself is biased towards small values)
+//   part(o)  = 19 bits mixed out of the smallest ord (the minimum itself is biased towards small values).  The top 8 bits are the level-1
+//              bucket, the top 16 the partition of a group that is flushed into the table while the pass goes on, and the top 16 + F
+//              (F = 0 .. 3, from the table size) the partition of a pass that is counted in one piece at its end (round 6)
 //   run      = maximal stretch of consecutive valid k-mers with equal smallest ord, cut at w k-mers
 //
 // Item (16 bytes):  w0 = bases 0 .. 31 (2 bits each, base i at bits 2 i; A 0, C 1, T 2, G 3: complement = code ^ 2)
-//                   w1 = bases 32 .. 46 in bits 0 .. 29 | (k-mers - 1) << 30 (5 bits) | partition << 35 (16 bits) | run or epoch << 51 (13 bits)
+//                   w1 = bases 32 .. 46 in bits 0 .. 29 | (k-mers - 1) << 30 (5 bits) | partition << 35 (19 bits) | run or epoch << 54 (10 bits)
 // k-mer j of an item = bases j .. j + k - 1.
 #pragma once
 #include <stdint.h>
@@ -37,7 +39,7 @@ enum {
     SKM_LOOK = 14,      // lanes a lane looks ahead in an extraction round (4 positions each: 56 >= 3 + 17 + 30 positions)
     SKM_PIECE = 256,    // positions of a round (64 lanes x 4)
     SKM_ADVANCE = 200,  // k-mer starts a piece of a longer read takes (the others need bases past the piece: next piece)
-    SKM_NK_SHIFT = 30, SKM_PART_SHIFT = 35, SKM_RUN_SHIFT = 51, SKM_RUN_BITS = 13
+    SKM_NK_SHIFT = 30, SKM_PART_SHIFT = 35, SKM_PART_BITS = 19, SKM_RUN_SHIFT = 54, SKM_RUN_BITS = 10
 };
 #define SKM_M30 0x3fffffffu
 #define SKM_RUN_MASK ((skm_u64)((1u << SKM_RUN_BITS) - 1u) << SKM_RUN_SHIFT)
@@ -99,8 +101,8 @@ SKM_HD uint32_t skm_ord(uint32_t x, const SkmGeom &g)
     x ^= x >> (g.m - 1u);
     return x;
 }
-// partition of the key space a run belongs to: 16 bits mixed out of its smallest ord
-SKM_HD uint32_t skm_part(const uint32_t ord_min) { return (uint32_t)(ord_min * 0x85EBCA6Bu) >> 16; }
+// partition of the key space a run belongs to: 19 bits mixed out of its smallest ord
+SKM_HD uint32_t skm_part(const uint32_t ord_min) { return (uint32_t)(ord_min * 0x85EBCA6Bu) >> (32 - SKM_PART_BITS); }
 
 // ord of the canonical m-mer that starts at base j (0 .. 3) of the window c (base i at bits 2 i; bases 0 .. 17 are looked at)
 SKM_HD uint32_t skm_mmer_ord_at(const skm_u64 c, const int j, const SkmGeom &g)
@@ -141,7 +143,13 @@ SKM_HD void skm_pack(const skm_u64 c_lo, const skm_u64 c_hi, const uint32_t j, c
     w1 = ((c_hi >> s) & (skm_u64)SKM_M30) | ((skm_u64)(n_kmers - 1u) << SKM_NK_SHIFT) | ((skm_u64)part << SKM_PART_SHIFT) | ((skm_u64)run << SKM_RUN_SHIFT);
 }
 SKM_HD uint32_t skm_item_kmers(const skm_u64 w1) { return ((uint32_t)(w1 >> SKM_NK_SHIFT) & 31u) + 1u; }
-SKM_HD uint32_t skm_item_part(const skm_u64 w1) { return (uint32_t)(w1 >> SKM_PART_SHIFT) & 0xffffu; }
+SKM_HD uint32_t skm_item_part(const skm_u64 w1) { return (uint32_t)(w1 >> SKM_PART_SHIFT) & ((1u << SKM_PART_BITS) - 1u); } // all 19 bits
+SKM_HD uint32_t skm_item_bucket(const skm_u64 w1) { return (uint32_t)(w1 >> (SKM_PART_SHIFT + SKM_PART_BITS - 8)) & 0xffu; }    // level-1 bucket
+SKM_HD uint32_t skm_item_p16(const skm_u64 w1) { return (uint32_t)(w1 >> (SKM_PART_SHIFT + SKM_PART_BITS - 16)) & 0xffffu; }    // partition of a table-mode group
+SKM_HD skm_u64 skm_item_with_part(const skm_u64 w1, const uint32_t part) // (owner side of the exchange: the partition becomes the owner's local one)
+{
+    return (w1 & ~((skm_u64)((1u << SKM_PART_BITS) - 1u) << SKM_PART_SHIFT)) | ((skm_u64)part << SKM_PART_SHIFT);
+}
 SKM_HD uint32_t skm_item_run(const skm_u64 w1) { return (uint32_t)(w1 >> SKM_RUN_SHIFT); }
 
 // the canonical keys of an item, one after the other: fwd >>= one base, rc <<= one base

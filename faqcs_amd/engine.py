@@ -111,6 +111,10 @@ class HipEngine:
         """process_paired / process_unpaired epilogue (FaQCs.cpp:518-537, :737-756)."""
         _check(self.lib, self.lib.faqcs_kmer_end_table(self.ctx))
 
+    def kmer_finish_pass(self):
+        """The pass is complete: its k-mers are counted (in one piece, without the device table, when they fit the group buffers)."""
+        _check(self.lib, self.lib.faqcs_kmer_finish_pass(self.ctx))
+
     def kmer_totals(self):
         d, t = C.c_uint64(), C.c_uint64()
         _check(self.lib, self.lib.faqcs_kmer_totals(self.ctx, C.byref(d), C.byref(t)))

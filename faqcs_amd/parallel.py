@@ -154,6 +154,7 @@ class KmerExchange:
         import torch
         import torch.distributed as dist
 
+        self.engine.kmer_finish_pass()  # (the owner's open group is counted as the end of a pass, not into the table)
         d, t = self.engine.kmer_epoch_counts()
         both = torch.from_numpy(np.concatenate([d, t]).astype(np.int64))
         if dist.get_backend(self.group) == "nccl":

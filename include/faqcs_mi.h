@@ -30,7 +30,8 @@ extern "C" {
 /* 2: faqcs_batch.terminal_n, faqcs_terminal_n_flags, the k-mer timers of faqcs_kernel_times.  Entry points added since then leave
  * every existing structure and call as it was, so the number stands: faqcs_kmer_forward, faqcs_comm_* (round 4).  Round 5 changes what the
  * 16-byte items of the k-mer exchange MEAN (faqcs_kmer_outbox / _insert_device / _forward: opaque to every caller in this repository, which
- * only moves them) -- a run of up to 17 consecutive k-mers each instead of one (key, epoch) pair -- and nothing about their size or the calls. */
+ * only moves them) -- a run of up to 17 consecutive k-mers each instead of one (key, epoch) pair -- and nothing about their size or the calls.
+ * Round 6 adds faqcs_kmer_finish_pass, and faqcs_sync() no longer counts the k-mers that wait in the open group (see below). */
 #define FAQCS_ABI_VERSION 2
 
 /* FilterStat enum order, FaQCs.h:46-75 */
@@ -255,13 +256,18 @@ int  faqcs_comm_allreduce_counters(faqcs_ctx *ctx);
 int  faqcs_comm_init_all(faqcs_ctx *const *ctxs, uint32_t n);
 int  faqcs_comm_allreduce_counters_all(faqcs_ctx *const *ctxs, uint32_t n);
 
-/* k-mer rarefaction (trim.cpp:157-185, FaQCs.cpp:518-537).  The k-mers of a submission are extracted when it is submitted and reach
- * the table in groups (combine-before-insert); faqcs_sync() -- which the calls below make -- completes the open
- * group.  Points are appended at segment ends during submit; their (distinct, total) are filled in after faqcs_sync():  */
+/* k-mer rarefaction (trim.cpp:157-185, FaQCs.cpp:518-537).  The k-mers of a submission are extracted when it is submitted, as 16-byte runs
+ * into group buffers sized from the free HBM, and are COUNTED LATER (combine-before-insert): when the pass ends
+ * (faqcs_kmer_end_table / faqcs_kmer_finish_pass) -- if the whole pass fits the buffers it is then counted in one piece and its keys never
+ * reach the device table --, when the buffers are full, or when one of faqcs_kmer_points / _totals / _epoch_counts asks for the curve so far
+ * (the open group then goes into the table, the slower path: a caller that only wants the finished curve calls faqcs_kmer_end_table FIRST and
+ * reads the points afterwards -- they keep their values).  Points are appended at segment ends during submit; their (distinct, total)
+ * are filled in by these calls:  */
 int  faqcs_kmer_points(faqcs_ctx *ctx, faqcs_rarefaction *out, uint32_t cap, uint32_t *n_points);
 /* (count, number of keys with that count) pairs, ascending count -- PlotInfo::kmer_frequency_histogram */
 int  faqcs_kmer_histogram(faqcs_ctx *ctx, uint64_t *count, uint64_t *nkeys, uint64_t cap, uint64_t *n_pairs);
-/* distinct keys / sum of counts currently in the table (the FaQCs.cpp:523-537 fallback point) */
+/* distinct keys / sum of counts of the pass in progress (the FaQCs.cpp:523-537 fallback point); when nothing has been counted since
+ * faqcs_kmer_end_table(): of the pass that call finished */
 int  faqcs_kmer_totals(faqcs_ctx *ctx, uint64_t *distinct, uint64_t *total);
 /* Options::kmer_rarefaction is switched off by trim() once the curve is complete (trim.cpp:180-184) */
 int  faqcs_kmer_active(faqcs_ctx *ctx);
@@ -269,6 +275,11 @@ int  faqcs_kmer_active(faqcs_ctx *ctx);
  * count histogram, appends the guaranteed single rarefaction point if none was taken, and starts a fresh
  * table (each process_* owns its own MAP<Word,size_t>, FaQCs.cpp:235,588). */
 int  faqcs_kmer_end_table(faqcs_ctx *ctx);
+/* The counting half of faqcs_kmer_end_table() (which calls it): the pass is complete, its open group is counted and every point and epoch
+ * histogram is final; submissions with k-mers are refused until faqcs_kmer_end_table() has started the next pass.  For callers that read
+ * faqcs_kmer_epoch_counts() (owner ranks) or the points before they end the table.  Replaces nothing of its own in the reference: the
+ * end of process_paired() / process_unpaired(), FaQCs.cpp:518-537. */
+int  faqcs_kmer_finish_pass(faqcs_ctx *ctx);
 
 /* ---- k-mers across GPUs --------------------------------------------------------------
  * The reference keeps ONE MAP<Word,size_t> per process (trim.cpp:82,133-135) and samples (distinct, total) after
@@ -283,8 +294,9 @@ int  faqcs_kmer_end_table(faqcs_ctx *ctx);
  *   distinct(point i) = sum over ranks of #{keys with first epoch <= i},  total(point i) = sum of occurrences with
  *   epoch <= i -- both additive, i.e. one all-reduce of 2 x n_epochs integers. */
 #define FAQCS_EPOCH_NONE 0xffffffffu
-/* First call on a fresh kmer_rarefaction context.  n_epochs = number of epoch slots (num_subsample + 1), at most 8 191 (an item has 13 bits
- * for its epoch); up to 1 000 the received items are combined before they reach the table, past that they are counted occurrence by occurrence. */
+/* First call on a fresh kmer_rarefaction context.  n_epochs = number of epoch slots (num_subsample + 1).  Up to 1 000 (an item has 10 bits
+ * for its epoch) the exchange moves runs of k-mers and the owner combines them; a job with more sampling points goes through (key, epoch)
+ * pairs instead -- 16 bytes per occurrence, one atomic per pair on the owner: exact, any --subset, slow. */
 int  faqcs_kmer_partition(faqcs_ctx *ctx, uint32_t rank, uint32_t world, uint32_t n_epochs);
 /* Epoch of every segment of the NEXT submission (which then buckets instead of inserting). */
 int  faqcs_kmer_set_epochs(faqcs_ctx *ctx, const uint32_t *segment_epoch, uint32_t n_segments);

@@ -3,6 +3,7 @@
 import os
 import struct
 import subprocess
+import sys
 import zlib
 
 import numpy as np
@@ -294,6 +295,46 @@ def test_parallel_inflate_on_odd_files(tmp_path):
     p.write_bytes(gzip.compress(bytes(range(256)) * 4000, 6))
     rc, out = _pargz(p, 4, 150000)
     assert rc == 4 and out == b""
+
+
+def test_parallel_inflate_of_concatenated_members(tmp_path):
+    """`cat lane1.fastq.gz lane2.fastq.gz ...` (gzread reads it as one stream, fastq.cpp:34): every member that is long enough starts the
+    parallel reader again at its header, short ones go through zlib in the consumer, in any order -- and the speculation of one member
+    does not run on through the next: ADVICE r5 measured twice the decompressed text resident for a two-member file; the peak RSS of a
+    two-member file now stays near that of the same text as one member."""
+    import gzip
+    import resource
+
+    a, b, c = _fastq_text(30000, seed=11), _fastq_text(200, seed=12), _fastq_text(25000, seed=13)
+    blob = gzip.compress(a, 6) + gzip.compress(b, 9) + gzip.compress(b"", 6) + gzip.compress(c, 1) + gzip.compress(b[:5000], 6)
+    want = a + b + c + b[:5000]
+    p = tmp_path / "lanes.gz"
+    p.write_bytes(blob)
+    for rearm in ("100000", "1", str(1 << 40)):  # long members in parallel / every member / only the first
+        r = subprocess.run([CLI, "--pargz_cat", str(p), "4", "150000"], capture_output=True, timeout=300, env=dict(os.environ, FAQCS_MI_PARGZ_REARM=rearm))
+        assert r.returncode == 0 and r.stdout == want, "rearm %s: rc %d, %d bytes (want %d)" % (rearm, r.returncode, len(r.stdout), len(want))
+    # damage in the SECOND long member is still an error
+    bad = bytearray(blob)
+    bad[len(gzip.compress(a, 6)) + len(gzip.compress(b, 9)) + 20 + 40000] ^= 0x33
+    p2 = tmp_path / "lanes_bad.gz"
+    p2.write_bytes(bytes(bad))
+    r = subprocess.run([CLI, "--pargz_cat", str(p2), "4", "150000"], capture_output=True, timeout=300, env=dict(os.environ, FAQCS_MI_PARGZ_REARM="100000"))
+    assert r.returncode == 3  # (caught by the member's CRC at the latest, like a flipped byte under gzread)
+
+    # peak RSS: one member of 2 x text against two members of text each (the default re-arm threshold: the second member is read by zlib)
+    big = _fastq_text(150000, seed=21)
+    one, two = tmp_path / "one.gz", tmp_path / "two.gz"
+    one.write_bytes(gzip.compress(big + big, 1))
+    two.write_bytes(gzip.compress(big, 1) + gzip.compress(big, 1))
+
+    def peak(path, **env):
+        script = "import resource, subprocess, sys; r = subprocess.run(sys.argv[1:], stdout=subprocess.DEVNULL); print(r.returncode, resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss)"
+        out = subprocess.run([sys.executable, "-c", script, CLI, "--pargz_cat", str(path), "8", "0"], capture_output=True, timeout=300, env=dict(os.environ, **env)).stdout.split()
+        assert out[0] == b"0"
+        return int(out[1])
+
+    rss_one, rss_two, rss_two_par = peak(one), peak(two), peak(two, FAQCS_MI_PARGZ_REARM="1000000")
+    assert rss_two < 1.3 * rss_one + 16384 and rss_two_par < 1.3 * rss_one + 16384, (rss_one, rss_two, rss_two_par, len(big))
 
 
 def test_parallel_inflate_reports_damage(tmp_path):

@@ -437,7 +437,7 @@ def test_kmer_partition_counted_in_several_rounds(monkeypatch, capfd):
     opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "1000", "--subset", "5", "--lc", "1.0", "--min_L", "31"])
     from faqcs_amd.engine import HipEngine
 
-    monkeypatch.setenv("FAQCS_KMER_GROUP_ITEMS", str(1 << 28))
+    monkeypatch.setenv("FAQCS_KMER_GROUP_ITEMS", str(1 << 29))  # (a partition's region: 2 600 items)
     monkeypatch.setenv("FAQCS_KMER_DEBUG", "1")
     monkeypatch.setattr("test_gpu_parity.hip_factory", lambda o, r, q: HipEngine(o, r, q, kmer_table_slots=1 << 24))
     hip, ora = compare_engines(opt, reads, seg_size=1000)

@@ -35,7 +35,9 @@ seg[-1] = n
 b = capi.Batch(seq.data_ptr(), qual.data_ptr(), off.data_ptr(), n, len(seg) - 1, seg.ctypes.data, L)
 t0 = time.perf_counter()
 _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(b), res.data_ptr()))
-eng.sync()
+if os.environ.get("KMER_BENCH_TABLE") == "1":  # the curve so far: the open group goes into the table (round 5's path)
+    d, t = eng.kmer_totals()
+eng.kmer_end_table()  # the pass ends: counted in one piece
 dt = time.perf_counter() - t0
 d, t = eng.kmer_totals()
 print("k-mer path: %d reads x %d bp in %.1f ms -> %.1f M reads/s, %.2f G k-mer inserts/s (distinct %d, total %d, points %d)" % (
