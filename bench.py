@@ -574,7 +574,10 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
                 e0 += len(seg) - 1
             _check(lib, lib.faqcs_submit_device(eng.ctx, C.byref(bt), res.data_ptr()))
             if kx is not None:
-                kmer_wire[0] += kx.exchange()[0]
+                # pipelined: this submission's kernels are enqueued; NOW the items of the previous one are received and handed to the owner side
+                # (its insert runs behind these kernels), then this submission's outbox goes on the wire and travels under the next one's kernels
+                kx.exchange_end()
+                kmer_wire[0] += kx.exchange_begin()[0]
         if config == "kmer" and kx is None:
             # the job's k-mer pass ends INSIDE the step: its k-mers are counted here (in one piece when they fit the group buffers),
             # the histogram of counts is read and the next job starts on an empty table (FaQCs.cpp:518-537)
@@ -720,15 +723,18 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
                            "occurrences_at_last_point": int(kmer_last.get("total", 0)), "points": int(kmer_last.get("points", 0)),
                            "note": "owner-partitioned tables: runs of k-mers that share their minimizer (16-byte super-k-mer items, about 8 occurrences each) "
                                    "grouped by the owner of the minimizer's partition on the device, all-to-all over the process group, owner-side combine; "
-                                   "distinct / total from the all-reduced epoch histograms",
-                           "wire_bytes_per_occurrence": round(16.0 * kmer_wire[0] / max(1, kmer_wire[1]), 3)}
+                                   "distinct / total from the all-reduced epoch histograms.  The exchange is pipelined: the items of submission i travel, and the "
+                                   "owner combines them, under the trim and extraction kernels of submission i + 1 (exchange_marks: seconds since the first mark)",
+                           "wire_bytes_per_occurrence": round(16.0 * kmer_wire[0] / max(1, kmer_wire[1]), 3),
+                           "exchange_marks": kx.marks[:24]}
         elif config == "kmer":
             d_, t_ = eng.kmer_totals()
             out["kmer"] = {"G_inserts_per_s": round(t_ / (dt / steps) / 1e9, 3), "distinct_per_step": int(d_), "occurrences_per_step": int(t_),
                            "points_per_step": len(eng.kmer_points()) // max(1, steps + warmup),
-                           "note": "canonical 31-mers of the kept reads: runs of k-mers that share their minimizer travel as ONE 16-byte item (about 8 occurrences), are "
-                                   "split 65 536 ways by the minimizer, expanded and counted per partition in LDS, then ONE plain table update per distinct key "
-                                   "and group (DESIGN.md section 4.4)"}
+                           "note": "canonical 31-mers of the kept reads: runs of k-mers that share their minimizer travel as ONE 16-byte item (about 8 occurrences) and stay "
+                                   "in HBM until the pass ends; then they are split 2^19 ways by the minimizer (a sort of 8 192-item tiles in LDS) and every fine "
+                                   "partition is expanded and counted in LDS -- its keys go straight into the histogram of counts and the keys-by-first-epoch "
+                                   "histogram, the device table is not touched (DESIGN.md section 4.4)"}
         out.update({
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,

@@ -122,7 +122,7 @@ struct faqcs_ctx {
     uint32_t part_rank = 0, part_world = 1, n_epochs = 0;
     std::vector<uint32_t> seg_epoch;             // epochs of the NEXT submission's segments
     DevBuf<ulonglong2> ob_items;
-    DevBuf<ulonglong2> fwd_items;                // pairs another device's context forwarded to this one (faqcs_kmer_forward)
+    bool ob_fresh = false;                       // the outbox holds a submission that faqcs_kmer_outbox() has not handed out yet
     DevBuf<uint32_t> ob_wave_count;
     DevBuf<unsigned long long> ob_wave_offset;
     unsigned long long *d_ob = nullptr;          // [3 * world]: dest_count, dest_offset, dest_cursor
@@ -173,6 +173,10 @@ struct faqcs_ctx {
     double kernel_ms = 0.0, adapter_ms = 0.0, kmer_ms = 0.0, kmer_insert_ms = 0.0, kmer_flush_ms = 0.0;
     uint64_t kernel_launches = 0;
     hipEvent_t ins_a = nullptr, ins_b = nullptr;
+    // faqcs_kmer_forward, owner side: two staging buffers for items that arrive by peer copy; [k]: the insert that read buffer k is done / the copy into it is
+    DevBuf<ulonglong2> fwd_items[2];
+    hipEvent_t fwd_free[2] = {nullptr, nullptr}, fwd_copied[2] = {nullptr, nullptr};
+    unsigned fwd_n = 0;
     const char *trim_kernel = "";
     void *comm = nullptr;          // ncclComm_t (faqcs_comm_init / faqcs_comm_init_all)
     hipEvent_t comm_ev = nullptr;  // the aux stream's work (composition fold) before the collective
@@ -459,6 +463,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->comm_ev) (void)hipEventDestroy(c->comm_ev);
     if (c->ins_a) (void)hipEventDestroy(c->ins_a);
     if (c->ins_b) (void)hipEventDestroy(c->ins_b);
+    for (int k = 0; k < 2; ++k) { if (c->fwd_free[k]) (void)hipEventDestroy(c->fwd_free[k]); if (c->fwd_copied[k]) (void)hipEventDestroy(c->fwd_copied[k]); c->fwd_items[k].release(); }
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_partials, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
                     c->kt.slots, c->kt.stats, c->kt.dirty, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
     for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -467,7 +472,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     c->s_seg.release(); c->s_sl.release(); c->s_hit.release(); c->s_res.release();
     for (auto &rs : c->rec) { rs.pre.release(); rs.post.release(); if (rs.trimmed) (void)hipEventDestroy(rs.trimmed); if (rs.folded) (void)hipEventDestroy(rs.folded); }
     if (c->aux) (void)hipStreamDestroy(c->aux);
-    c->ob_items.release(); c->fwd_items.release(); c->ob_wave_count.release(); c->ob_wave_offset.release();
+    c->ob_items.release(); c->ob_wave_count.release(); c->ob_wave_offset.release();
     { void *kg_ptrs[] = {c->kg.dev.l1, c->kg.dev.l2, c->kg.dev.cur1, c->kg.dev.cur2, c->kg.dev.run_epoch, c->kg.dev.first_hist, c->kg.dev.tot_by_epoch, c->kg.dev.dense, c->kg.dev.big, c->kg.dev.n_big, c->kg.dev.redo};
       for (void *q : kg_ptrs) if (q) (void)hipFree(q);
       c->kg.defer.release();
@@ -671,8 +676,8 @@ static int kg_flush(faqcs_ctx *c, bool timed = false, bool final = false)
     g.dev.n_runs = (uint32_t)up.size(); g.dev.epoch_base = g.epoch_base;
     const char *dbg = getenv("FAQCS_KMER_DEBUG"); // (read at every flush: a test turns it on for one engine)
     const bool debug = dbg && atoi(dbg) != 0;
-    static const bool never_final = [] { const char *e = getenv("FAQCS_KMER_FINAL"); return e && atoi(e) == 0; }(); // (A/B: round 5's path for every group)
-    final = final && !g.table_live && !never_final;
+    const char *e_final = getenv("FAQCS_KMER_FINAL"); // (0: round 5's path for every group -- A/B runs, and the tests of that path; read at every flush)
+    final = final && !g.table_live && !(e_final && atoi(e_final) == 0);
     if (g.skm && debug) { if (int rc = kg_debug_flush(c, final)) return rc; }
     else if (final) HIPCHK(faqcs_launch_skm_finish(g.dev, c->kt, c->prm.kmer, c->n_cu, c->compute));
     else HIPCHK(faqcs_launch_skm_flush(g.dev, c->kt, c->prm.kmer, c->compute));
@@ -932,6 +937,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         HIPCHK(faqcs_launch_skm_outbox(d, c->part_world, c->d_ob, ks.scratch.p, c->ob_items.p, c->compute));
         if (tm) HIPCHK(hipEventRecord(tm->k1, c->compute));
         c->seg_epoch.clear();
+        c->ob_fresh = true;
         return 0;
     }
     // (FAQCS_KMER_DIRECT=1: round 3's form -- (key, epoch) pairs bucketed by owner in two passes, one atomic insert per pair on the owner)
@@ -970,6 +976,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         }
         if (tm) HIPCHK(hipEventRecord(tm->k1, c->compute));
         c->seg_epoch.clear();
+        c->ob_fresh = true;
         return 0;
     }
     // ---- rarefaction bookkeeping per reference trim() call (trim.cpp:157-185) -------------------------------
@@ -1422,8 +1429,8 @@ extern "C" int faqcs_kmer_finish_pass(faqcs_ctx *c)
         HIPCHK(hipMemcpy(st, c->kt.stats, 32, hipMemcpyDeviceToHost));
         g.hist_in_table = g.table_live;
         g.hist_in_overflow = !g.table_live && st[3] != 0;
-        static const bool stats = [] { const char *e = getenv("FAQCS_KMER_STATS"); return e && atoi(e) != 0; }();
-        if (stats) { // (diagnostics: how the pass was counted)
+        const char *e_stats = getenv("FAQCS_KMER_STATS"); // (read at every pass: a test turns it on for one engine)
+        if (e_stats && atoi(e_stats) != 0) { // (diagnostics: how the pass was counted)
             uint32_t n_redo = 0;
             if (g.dev.n_redo && !g.table_live) HIPCHK(hipMemcpy(&n_redo, g.dev.n_redo, 4, hipMemcpyDeviceToHost));
             fprintf(stderr, "[kmer stats] pass counted %s; %u of %u fine partitions through their table slices; %llu inserts into the overflow area; group bound %llu occurrences, cap1 %u cap2f %u\n",
@@ -1538,8 +1545,11 @@ extern "C" int faqcs_kmer_outbox(faqcs_ctx *c, void **d_items, uint64_t *counts)
     if (!c->partitioned) return fail(FAQCS_E_INVAL, "faqcs_kmer_outbox: call faqcs_kmer_partition first");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->compute));
-    std::vector<unsigned long long> h(c->part_world);
-    HIPCHK(hipMemcpy(h.data(), c->d_ob, (size_t)c->part_world * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h(c->part_world, 0ull);
+    // (a second call without a submission in between -- a rank of a collective loop whose part of the input was empty -- has nothing to send:
+    // the outbox of the submission before it has been handed out already)
+    if (c->ob_fresh) HIPCHK(hipMemcpy(h.data(), c->d_ob, (size_t)c->part_world * 8, hipMemcpyDeviceToHost));
+    c->ob_fresh = false;
     for (uint32_t d = 0; d < c->part_world; ++d) counts[d] = h[d];
     *d_items = c->ob_items.p;
     return 0;
@@ -1579,6 +1589,14 @@ extern "C" int faqcs_kmer_outbox_host(faqcs_ctx *c, uint64_t *keys, uint64_t cap
     return 0;
 }
 
+// the received items join the owner's group buffers (or its table), enqueued on its compute stream
+static int kmer_insert_enqueue(faqcs_ctx *c, const void *d_items, uint64_t n_items)
+{
+    if (c->kg.owner) return kg_add_items(c, d_items, n_items);
+    HIPCHK(faqcs_launch_kmer_insert_items(c->kt, d_items, n_items, c->d_tot_by_epoch, c->n_epochs, c->n_cu, c->compute));
+    return 0;
+}
+
 extern "C" int faqcs_kmer_insert_device(faqcs_ctx *c, const void *d_items, uint64_t n_items)
 {
     if (!c || (!d_items && n_items)) return fail(FAQCS_E_INVAL, "null argument");
@@ -1586,8 +1604,7 @@ extern "C" int faqcs_kmer_insert_device(faqcs_ctx *c, const void *d_items, uint6
     HIPCHK(hipSetDevice(c->device));
     if (!c->ins_a) { HIPCHK(hipEventCreate(&c->ins_a)); HIPCHK(hipEventCreate(&c->ins_b)); }
     HIPCHK(hipEventRecord(c->ins_a, c->compute));
-    if (c->kg.owner) { if (int rc = kg_add_items(c, d_items, n_items)) return rc; }
-    else HIPCHK(faqcs_launch_kmer_insert_items(c->kt, d_items, n_items, c->d_tot_by_epoch, c->n_epochs, c->n_cu, c->compute));
+    if (int rc = kmer_insert_enqueue(c, d_items, n_items)) return rc;
     HIPCHK(hipEventRecord(c->ins_b, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute)); // the caller may recycle d_items as soon as this returns
     { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ins_a, c->ins_b) == hipSuccess) c->kmer_insert_ms += ms; }
@@ -1608,6 +1625,10 @@ extern "C" int faqcs_kmer_forward(faqcs_ctx *from, faqcs_ctx *const *owners, uin
     HIPCHK(hipStreamSynchronize(from->compute));
     std::vector<unsigned long long> cnt(world);
     HIPCHK(hipMemcpy(cnt.data(), from->d_ob, (size_t)world * 8, hipMemcpyDeviceToHost));
+    // (FAQCS_KMER_FORCE_PEER_COPY=1: an owner on the SAME device is treated like one on another device -- its items go through hipMemcpyPeer into
+    // its staging buffer -- so that the branch a multi-GPU node takes is exercised on a one-GPU box: tests/test_gpu_parity.py)
+    const char *e_peer = getenv("FAQCS_KMER_FORCE_PEER_COPY");
+    const bool force_peer = e_peer && atoi(e_peer) != 0;
     size_t at = 0;
     for (uint32_t r = 0; r < world; ++r) {
         const unsigned long long n = cnt[r];
@@ -1615,12 +1636,24 @@ extern "C" int faqcs_kmer_forward(faqcs_ctx *from, faqcs_ctx *const *owners, uin
         const ulonglong2 *src = from->ob_items.p + at;
         at += (size_t)n;
         faqcs_ctx *o = owners[r];
-        if (o->device == from->device) { if (int rc = faqcs_kmer_insert_device(o, src, n)) return rc; continue; }
+        if (o->device == from->device && !force_peer) { if (int rc = faqcs_kmer_insert_device(o, src, n)) return rc; continue; }
         HIPCHK(hipSetDevice(o->device));
-        if ((size_t)n > o->fwd_items.cap) HIPCHK(hipStreamSynchronize(o->compute));
-        HIPCHK(o->fwd_items.reserve((size_t)n));
-        HIPCHK(hipMemcpyPeer(o->fwd_items.p, o->device, src, from->device, (size_t)n * 16));
-        if (int rc = faqcs_kmer_insert_device(o, o->fwd_items.p, n)) return rc;
+        // Two staging buffers per owner.  The copy runs on the owner's COPY stream and waits (on the device) only for the insert that last read
+        // this staging buffer; the owner's compute stream waits (on the device) for the copy before the insert; the host waits for the copy
+        // alone -- the sender's outbox may be overwritten then --, not for what the owner's compute stream has queued (the forward
+        // blocked on the owner's whole stream, one buffer late).
+        const unsigned k = o->fwd_n++ & 1u;
+        if (!o->fwd_free[k]) { HIPCHK(hipEventCreateWithFlags(&o->fwd_free[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&o->fwd_copied[k], hipEventDisableTiming)); }
+        else HIPCHK(hipStreamWaitEvent(o->copy, o->fwd_free[k], 0));
+        if ((size_t)n > o->fwd_items[k].cap) HIPCHK(hipEventSynchronize(o->fwd_free[k])); // (about to be reallocated: nothing may still read it)
+        HIPCHK(o->fwd_items[k].reserve((size_t)n));
+        HIPCHK(hipMemcpyPeerAsync(o->fwd_items[k].p, o->device, src, from->device, (size_t)n * 16, o->copy));
+        HIPCHK(hipEventRecord(o->fwd_copied[k], o->copy));
+        HIPCHK(hipStreamWaitEvent(o->compute, o->fwd_copied[k], 0));
+        if (int rc = kmer_insert_enqueue(o, o->fwd_items[k].p, n)) return rc;
+        HIPCHK(hipEventRecord(o->fwd_free[k], o->compute));
+        HIPCHK(hipEventSynchronize(o->fwd_copied[k]));
+        HIPCHK(hipSetDevice(from->device));
     }
     return 0;
 }

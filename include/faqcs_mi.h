@@ -301,7 +301,8 @@ int  faqcs_kmer_partition(faqcs_ctx *ctx, uint32_t rank, uint32_t world, uint32_
 /* Epoch of every segment of the NEXT submission (which then buckets instead of inserting). */
 int  faqcs_kmer_set_epochs(faqcs_ctx *ctx, const uint32_t *segment_epoch, uint32_t n_segments);
 /* After a submission: device array of 16-byte items grouped by destination rank 0..world-1 and the number of ITEMS per destination
- * (counts[world]).  Valid until the next submission. */
+ * (counts[world]).  Valid until the next submission.  A second call without a submission in between reports nothing to send (all
+ * counts 0): a rank of a collective loop whose part of the input was empty does not send the previous outbox again. */
 int  faqcs_kmer_outbox(faqcs_ctx *ctx, void **d_items, uint64_t *counts);
 /* The canonical keys of EVERY OCCURRENCE of the last submission's outbox, expanded from its items on the host (all destinations; keys ==
  * NULL or cap too small: only the count is returned).  For a caller that owns the table itself, like the reference's trim() seam (MAP<Word,size_t>,

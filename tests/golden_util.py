@@ -119,7 +119,7 @@ def compare_outputs(case, outdir, rc, err_text):
     return bad
 
 
-def run_case_binary(case, cache, tmp_path, binary, extra_args=()):
+def run_case_binary(case, cache, tmp_path, binary, extra_args=(), env=None):
     """Runs a FaQCs-compatible executable (the reference driver linked against integration/trim_shim.cpp) on the
     case's command line and compares every output file with the reference's own outputs."""
     import subprocess
@@ -132,7 +132,7 @@ def run_case_binary(case, cache, tmp_path, binary, extra_args=()):
         import shutil
 
         shutil.rmtree(outdir, ignore_errors=True)
-        proc = subprocess.run([binary] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        proc = subprocess.run([binary] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, **env) if env else None)
         if proc.returncode != -13:
             break
     return compare_outputs(case, outdir, proc.returncode, proc.stderr.decode(errors="replace"))

@@ -35,6 +35,9 @@ def random_batch(rng, n, maxlen, kind):
     for _ in range(n):
         if kind == "adv":
             s, q = make_fixtures._adv_read(rng, maxlen)
+        elif kind == "clean":  # random bases, good qualities: every 31-mer of a read is counted, nearly all of them distinct
+            s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, maxlen)].copy()
+            q = (rng.integers(30, 41, maxlen) + 33).astype(np.uint8)
         else:
             L = int(rng.integers(0, maxlen + 1))
             s = np.frombuffer(b"ACGTNacgtnRY", np.uint8)[rng.choice(12, L, p=[.22, .22, .22, .22, .05, .02, .02, .01, .01, .005, .0025, .0025])].copy()
@@ -439,11 +442,16 @@ def test_kmer_partition_counted_in_several_rounds(monkeypatch, capfd):
 
     monkeypatch.setenv("FAQCS_KMER_GROUP_ITEMS", str(1 << 29))  # (a partition's region: 2 600 items)
     monkeypatch.setenv("FAQCS_KMER_DEBUG", "1")
+    monkeypatch.setenv("FAQCS_KMER_STATS", "1")
     monkeypatch.setattr("test_gpu_parity.hip_factory", lambda o, r, q: HipEngine(o, r, q, kmer_table_slots=1 << 24))
     hip, ora = compare_engines(opt, reads, seg_size=1000)
     _kmer_engines_agree(hip, ora)
-    fullest = [int(m) for m in re.findall(r"fullest partition (\d+) keys", capfd.readouterr().err)]
+    err = capfd.readouterr().err
+    fullest = [int(m) for m in re.findall(r"fullest partition (\d+) keys", err)]
     assert fullest and max(fullest) > 2816, fullest
+    # (round 6: the pass was counted in one piece, and the partitions that did not fit one LDS round went through their table slices)
+    st = _kmer_stats(err)
+    assert len(st) == 1 and st[0][2] and st[0][0] >= 1, st
 
 
 @pytest.mark.parametrize("seed", range(3))
@@ -481,11 +489,96 @@ def test_kmer_repeats_and_a_partition_larger_than_its_slice(seed, monkeypatch):
     _kmer_engines_agree(hip, ora)
 
 
+def _kmer_stats(err):
+    """(fine partitions that went through their table slices, inserts into the overflow area, 'in one piece'?) of every pass FAQCS_KMER_STATS reported"""
+    import re
+
+    return [(int(a), int(b), "in one piece" in line) for line in err.splitlines() if line.startswith("[kmer stats]")
+            for a, b in re.findall(r"; (\d+) of \d+ fine partitions through their table slices; (\d+) inserts", line)]
+
+
+@pytest.mark.parametrize("fine", [0, 1, 2, 3])
+def test_kmer_pass_in_one_piece_for_every_partition_width(fine, monkeypatch, capfd):
+    """Round 6: a pass that fits the group buffers is counted when it ENDS, fine partition by fine partition, without the table
+    (skm_split_sort + skm_combine<KS_COUNT>).  The table's size sets the number of fine partitions, 2^(16 + F); here every F on one
+    small table (FAQCS_KMER_FINE_BITS), two passes on one engine (the second must start from nothing), reads of a small genome with
+    N and either strand.  Points and the whole histogram of counts equal the oracle's (trim.cpp:157-185,887-931; FaQCs.cpp:518-537)."""
+    from oracle_engine import OracleEngine
+
+    from faqcs_amd import driver
+    from faqcs_amd.engine import HipEngine
+
+    monkeypatch.setenv("FAQCS_KMER_FINE_BITS", str(fine))
+    monkeypatch.setenv("FAQCS_KMER_STATS", "1")
+    rng = np.random.Generator(np.random.PCG64([606, fine, SEED]))
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 60000)]
+    opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "900", "--subset", "9"])
+    hip, ora = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << 25), OracleEngine(opt, 256, 33)
+    for n_pass in range(2):
+        for lo, hi in ((100, 250), (31, 60), (180, 256)):
+            reads = _genome_reads(rng, genome, 2500, lo, hi)
+            seq, qual, offset, seg = driver.pack_segments([reads[i:i + 611] for i in range(0, len(reads), 611)])
+            assert (hip.process(seq, qual, offset, seg) == ora.process(seq, qual, offset, seg)).all()
+        _kmer_engines_agree(hip, ora)
+    st = _kmer_stats(capfd.readouterr().err)
+    assert len(st) == 2 and all(one_piece for _, _, one_piece in st), st
+
+
+def test_kmer_curve_asked_for_in_the_middle_of_a_pass(monkeypatch, capfd):
+    """faqcs_kmer_points() / _totals() while the pass goes on: the open group has to go INTO THE TABLE (its keys must live somewhere), and
+    the rest of the pass -- and its end -- then goes through the table too; the answers on the way and at the end equal the oracle's.
+    Then a second pass on the same engine, not interrupted: counted in one piece again."""
+    from oracle_engine import OracleEngine
+
+    from faqcs_amd import driver
+
+    monkeypatch.setenv("FAQCS_KMER_STATS", "1")
+    rng = np.random.Generator(np.random.PCG64([707, SEED]))
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 40000)]
+    opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "700", "--subset", "20"])
+    hip, ora = hip_factory(opt, 256, 33), OracleEngine(opt, 256, 33)
+    for n_pass in range(2):
+        for part in range(4):
+            reads = _genome_reads(rng, genome, 1800, 60, 250)
+            seq, qual, offset, seg = driver.pack_segments([reads[i:i + 450] for i in range(0, len(reads), 450)])
+            assert (hip.process(seq, qual, offset, seg) == ora.process(seq, qual, offset, seg)).all()
+            if n_pass == 0 and part in (0, 2):
+                assert (hip.kmer_points() == ora.kmer_points()).all() and hip.kmer_totals() == ora.kmer_totals()
+        _kmer_engines_agree(hip, ora)
+    st = _kmer_stats(capfd.readouterr().err)
+    assert [one_piece for _, _, one_piece in st] == [False, True], st
+
+
+def test_kmer_pass_that_has_been_counted_takes_no_more_reads():
+    """faqcs_kmer_finish_pass(): the pass is complete and counted; a submission with k-mers is refused (FAQCS_E_INVAL) until
+    faqcs_kmer_end_table() has started the next pass -- it cannot silently join keys that are no longer anywhere."""
+    from faqcs_amd import driver
+    from faqcs_amd.engine import FaqcsError
+
+    rng = np.random.Generator(np.random.PCG64([808, SEED]))
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20000)]
+    opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "500", "--subset", "4"])
+    hip = hip_factory(opt, 256, 33)
+    seq, qual, offset, seg = driver.pack_segments([_genome_reads(rng, genome, 800, 60, 200)])
+    hip.process(seq, qual, offset, seg)
+    hip.kmer_finish_pass()
+    pts = hip.kmer_points().copy()
+    assert len(pts) == 1 and pts[0]["distinct_kmer"] > 0
+    with pytest.raises(FaqcsError) as e:
+        hip.process(seq, qual, offset, seg)
+    assert e.value.code == capi.E_INVAL
+    hip.kmer_end_table()
+    assert (hip.kmer_points() == pts).all() and hip.kmer_totals() == (int(pts[0]["distinct_kmer"]), int(pts[0]["total_kmer"]))
+    hip.process(seq, qual, offset, seg)  # the next pass takes reads again (the curve is complete: nothing is counted, trim.cpp:180-184)
+
+
 @pytest.mark.timeout(120)
-def test_kmer_table_that_is_too_small_is_an_error_at_once():
-    """Three times more distinct k-mers than the table (2^22 slots + its overflow area) can hold: FAQCS_E_KMER_FULL from the sync --
-    not a scan of the whole overflow area for every key behind the first one that did not fit (the probe sequence there is cut and
-    nothing is tried once the table has been declared full)."""
+def test_kmer_table_that_is_too_small_is_an_error_at_once(monkeypatch):
+    """Three times more distinct k-mers than the table (2^22 slots + its overflow area) can hold.  Round 6: a pass that fits the group
+    buffers never touches the table, so it is counted all the same -- every one of its 15.4 M random 31-mers a key.  When the pass does go
+    through the table (here: FAQCS_KMER_FINAL=0, round 5's path; in production: a pass larger than the buffers, or a curve asked for on
+    the way) the answer is FAQCS_E_KMER_FULL at once -- not a scan of the whole overflow area for every key behind the first one that
+    did not fit (the probe sequence there is cut and nothing is tried once the table has been declared full)."""
     from faqcs_amd.engine import FaqcsError, HipEngine
 
     rng = np.random.Generator(np.random.PCG64(5 + SEED))
@@ -497,8 +590,15 @@ def test_kmer_table_that_is_too_small_is_an_error_at_once():
     off = (np.arange(n + 1, dtype=np.uint64) * L).astype(np.uint32)
     opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "100000"])
     eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << 22)
+    eng.process(s, q, off, np.array([0, n], dtype=np.uint32))
+    eng.kmer_end_table()
+    d, t = eng.kmer_totals()
+    assert t == n * (L - 30) and (1 << 22) + (1 << 18) < d <= t  # (more keys than the table and its overflow area have slots)
+    monkeypatch.setenv("FAQCS_KMER_FINAL", "0")
+    eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << 22)
+    eng.process(s, q, off, np.array([0, n], dtype=np.uint32))
     with pytest.raises(FaqcsError) as e:
-        eng.process(s, q, off, np.array([0, n], dtype=np.uint32))
+        eng.kmer_end_table()
     assert e.value.code == capi.E_KMER_FULL
 
 
@@ -556,17 +656,24 @@ def test_kmer_group_path_equals_the_per_occurrence_path_at_scale(genome, slots_l
         b = capi.Batch(seq.data_ptr() + 64, qual.data_ptr() + 64, off.data_ptr(), n, len(seg) - 1, seg.ctypes.data, L)
         _check(eng.lib, eng.lib.faqcs_submit_device(eng.ctx, C.byref(b), res.data_ptr()))
         eng.sync()
-        tot = eng.kmer_totals()
+        tot = eng.kmer_totals()  # (the curve so far: the open group goes INTO THE TABLE -- round 5's path, several LDS rounds per partition in the second case)
         eng.kmer_end_table()
         results.append((tot, eng.kmer_points().copy(), [a.copy() for a in eng.kmer_histogram()]))
         eng.close()
-    (t0, p0, h0), (t1, p1, h1) = results
-    assert t0 == t1 and t0[1] > 400_000_000 and len(p0) >= 10
-    assert (p0 == p1).all()
-    assert (h0[0] == h1[0]).all() and (h0[1] == h1[1]).all()
+    # ... and a third time as a pass that is counted in one piece when it ends (round 6), on a fresh engine
+    monkeypatch.setenv("FAQCS_KMER_DIRECT", "0")
+    eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << slots_log2)
+    _check(eng.lib, eng.lib.faqcs_submit_device(eng.ctx, C.byref(b), res.data_ptr()))
+    eng.kmer_end_table()
+    results.append((eng.kmer_totals(), eng.kmer_points().copy(), [a.copy() for a in eng.kmer_histogram()]))
+    eng.close()
+    (t0, p0, h0), (t1, p1, h1), (t2, p2, h2) = results
+    assert t0 == t1 == t2 and t0[1] > 400_000_000 and len(p0) >= 10
+    assert (p0 == p1).all() and (p0 == p2).all()
+    assert (h0[0] == h1[0]).all() and (h0[1] == h1[1]).all() and (h0[0] == h2[0]).all() and (h0[1] == h2[1]).all()
 
 
-def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150, backend="gloo"):
+def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150, backend="gloo", kind="adv"):
     import os
     import sys
 
@@ -587,19 +694,26 @@ def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150, back
     dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     opt = parse_args(["-u", "x", "-d", "y"] + args)
     rng = np.random.Generator(np.random.PCG64(4242))
-    reads = random_batch(rng, n_reads, maxlen, "adv")
+    reads = random_batch(rng, n_reads, maxlen, kind)
     segs = [reads[i:i + seg_size] for i in range(0, n_reads, seg_size)]
     epochs, points = parallel.rarefaction_schedule([len(s) for s in segs], opt.split_size, opt.num_subsample)
     lo, hi = parallel.shard_bounds(len(segs), rank, world)
     eng = HipEngine(opt, 256, 33, device=0, kmer_table_slots=1 << 22)
     ex = parallel.KmerExchange(eng, rank, world, opt.num_subsample)
-    mid = (lo + hi) // 2
-    for a, b in ((lo, mid), (mid, hi)):  # every rank makes the same number of (collective) exchanges
+    # every rank makes the same number of (collective) exchanges; with three or more parts the exchange is PIPELINED as bench.py drives it:
+    # the items of part i are received and inserted behind the submission of part i + 1, finish() completes the last one
+    n_parts = 2 if (maxlen <= 150 or os.environ.get("FAQCS_TEST_SERIAL_EXCHANGE")) else 4
+    cuts = [lo + (hi - lo) * i // n_parts for i in range(n_parts + 1)]
+    for a, b in zip(cuts[:-1], cuts[1:]):
         if b > a:
             seq, qual, offset, seg = driver.pack_segments(segs[a:b])
             eng.kmer_set_epochs(epochs[a:b])
             eng.process(seq, qual, offset, seg)
-        ex.exchange()
+        if n_parts == 2:
+            ex.exchange()
+        else:
+            ex.exchange_end()
+            ex.exchange_begin()
     pts, hist = ex.finish(points, n_reads)
     if rank == 0:
         ora = OracleEngine(opt, 256, 33)
@@ -610,7 +724,8 @@ def _kmer_rank(rank, world, port, args, n_reads, seg_size, out, maxlen=150, back
         hc, hk = ora.kmer_histogram()
         want_hist = {int(a): int(b) for a, b in zip(hc, hk)}
         with open(out, "w") as f:
-            f.write("ok" if (pts == want and hist == want_hist and len(want) > 0) else "mismatch:\n%r\n%r" % (pts, want))
+            diff = sorted((k, hist.get(k, 0), want_hist.get(k, 0)) for k in set(hist) | set(want_hist) if hist.get(k, 0) != want_hist.get(k, 0))
+            f.write("ok" if (pts == want and hist == want_hist and len(want) > 0) else "mismatch:\n%r\n%r\nhistogram (count, keys here, keys in the oracle): %r" % (pts, want, diff[:40]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -727,6 +842,27 @@ def test_eight_rank_hip_counters_allreduce(tmp_path):
 def test_eight_rank_kmer_exchange(tmp_path):
     """BASELINE configs[4]'s rank count and shape (2x250, --subset 200) on one GPU: eight owners, super-k-mer items all-to-all over gloo."""
     test_two_rank_kmer_exchange(["--kmer_rarefaction", "--split_size", "400", "--subset", "200"], 5200, 250, tmp_path, world=8)
+
+
+def test_eight_rank_owner_tables_use_all_their_slots(tmp_path, monkeypatch):
+    """an owner indexed its table, its level-1 buckets and its level-2 regions by the GLOBAL partition, so each of 8
+    ranks used one eighth of each and a weak-scaled job hit FAQCS_E_KMER_FULL at about the single-GPU key count.  The owner now maps the
+    partitions it owns onto its whole local partition space (KmerGroupDev::part_mul).  Here 8 owners with 2^22-slot tables take about
+    0.4 M distinct keys each -- three quarters of the 0.52 M slots an eighth of a table has, far past what its slices' probe windows and
+    the overflow area took --, THROUGH THEIR TABLES (FAQCS_KMER_FINAL=0: round 5's path; a pass counted in one piece would not touch the
+    table at all); points and histogram equal the oracle's."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    monkeypatch.setenv("FAQCS_KMER_FINAL", "0")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_kmer_rank, args=(8, port, ["--kmer_rarefaction", "--split_size", "2500", "--subset", "5"], 15000, 577, out, 250, "gloo", "clean"), nprocs=8, join=True)
+    assert open(out).read() == "ok", open(out).read()[:2000]
 
 
 @pytest.mark.parametrize("config", ["plain", "adapter", "kmer"])
@@ -1250,6 +1386,23 @@ def test_native_cli_on_two_devices(name, fixture_cache, tmp_path):
     if "kmer" in name:  # --kmer_rarefaction on several contexts: every context trims its buffers, every k-mer has one owner context
         (tmp_path / "three").mkdir()  # (faqcs_kmer_forward; three contexts: an owner count that does not divide the key space evenly)
         bad = run_case_binary(load_case(name), fixture_cache, tmp_path / "three", _CLI_BIN, extra_args=["--gpu_ids", "0,0,0"])
+        assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name", ["adv_kmer", "adv_kmer_qc_only_subset1", "advbig_kmer", "head250_kmer", "long300_kmer_q20", "long8k_kmer_replaceN"])
+def test_native_cli_forwards_k_mers_by_peer_copy(name, fixture_cache, tmp_path):
+    """The branch of faqcs_kmer_forward a multi-GPU node takes -- the owner sits on ANOTHER device: hipMemcpyPeerAsync into one of the
+    owner's two staging buffers on its copy stream, the insert behind an event on its compute stream -- has never run for want of a
+    second GPU.  FAQCS_KMER_FORCE_PEER_COPY=1 sends same-device owners through it: the six k-mer goldens on two and on
+    three contexts, byte-identical tables (trim.cpp:133-135 is what the exchange replaces)."""
+    from golden_util import case_names, load_case, run_case_binary
+
+    if name not in case_names():
+        pytest.skip("no such golden case")
+    for ids in ("0,0", "0,0,0"):
+        d = tmp_path / ids.replace(",", "_")
+        d.mkdir()
+        bad = run_case_binary(load_case(name), fixture_cache, d, _CLI_BIN, extra_args=["--gpu_ids", ids], env={"FAQCS_KMER_FORCE_PEER_COPY": "1"})
         assert not bad, "\n".join(bad)
 
 
