@@ -31,6 +31,7 @@ struct AdapterDev {
     float match_rate;
 };
 const char *faqcs_last_trim_kernel();
+bool faqcs_last_trim_folded();
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
@@ -109,6 +110,12 @@ struct faqcs_ctx {
     struct RecSet { DevBuf<unsigned long long> pre, post; hipEvent_t trimmed = nullptr, folded = nullptr; bool used = false; };
     RecSet rec[2];
     uint64_t n_enqueued = 0;
+    // round 6: the records of a launch are folded one launch LATE -- by the next trim_lds launch's blocks as they run out of reads (DevParams::fold_*),
+    // else by composition_histogram on the aux stream beside the next launch, or on the compute stream when somebody needs the counters
+    int pending_fold = -1;         // the record set that still has to be folded (-1: none)
+    uint32_t pending_n = 0;
+    bool pending_wide = false;
+    uint32_t *d_fold_claim = nullptr;
     hipStream_t aux = nullptr;
     // rarefaction state (trim.cpp:157-185): host-deterministic from read counts, values filled from the device
     uint64_t total_number = 0;
@@ -465,7 +472,7 @@ extern "C" void faqcs_destroy(faqcs_ctx *c)
     if (c->ins_b) (void)hipEventDestroy(c->ins_b);
     for (int k = 0; k < 2; ++k) { if (c->fwd_free[k]) (void)hipEventDestroy(c->fwd_free[k]); if (c->fwd_copied[k]) (void)hipEventDestroy(c->fwd_copied[k]); c->fwd_items[k].release(); }
     void *ptrs[] = {c->d_lcthr, c->d_basetab, c->d_avgq, c->d_norm, c->d_magic, c->d_counters, c->d_err, c->d_partials, c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart,
-                    c->kt.slots, c->kt.stats, c->kt.dirty, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
+                    c->kt.slots, c->kt.stats, c->kt.dirty, c->d_fold_claim, c->d_snaps, c->d_ob, c->d_tot_by_epoch, c->d_first_hist};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (auto &sl : c->slot) { sl.seq.release(); sl.qual.release(); sl.tn.release(); sl.off.release(); if (sl.done) (void)hipEventDestroy(sl.done); }
     for (auto &e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
@@ -860,26 +867,45 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         Timing &t = *tm;
         HIPCHK(hipEventRecord(t.a, c->compute));
         const bool wide = max_len > 256; // the long-read kernels write two-word composition records
-        faqcs_ctx::RecSet &rs = c->rec[c->n_enqueued++ & 1];
-        if (rs.used) HIPCHK(hipStreamWaitEvent(c->compute, rs.folded, 0)); // the set's previous records have been folded
+        const int set = (int)(c->n_enqueued++ & 1);
+        faqcs_ctx::RecSet &rs = c->rec[set];
+        if (rs.used) { HIPCHK(hipStreamWaitEvent(c->compute, rs.folded, 0)); rs.used = false; } // (a fold of the set's previous records on the aux stream)
         const char *e_long = getenv("FAQCS_TRIM_LONG");
         const bool force_long = e_long && atoi(e_long) != 0;
         const bool long_reads = max_len > FAQCS_FAST_READ_LENGTH || force_long; // trim_long: composition bins are added by the kernel itself, no records
         const size_t need = long_reads ? (size_t)n / 2 + 1 : (size_t)n * (wide ? 2 : 1); // (trim_long: rec_pre is its scratch, one u32 per read)
-        if (need > rs.pre.cap) HIPCHK(hipStreamSynchronize(c->aux));
+        if (need > rs.pre.cap) { HIPCHK(hipStreamSynchronize(c->aux)); HIPCHK(hipStreamSynchronize(c->compute)); } // (the set's old records may still be read: by the fold kernel, or by the launch before this one)
         HIPCHK(rs.pre.reserve(need)); HIPCHK(rs.post.reserve(need));
-        HIPCHK(faqcs_launch_trim(c->dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, rs.pre.p, rs.post.p,
+        // the records of the launch BEFORE this one: this launch's blocks fold them when they run out of reads, if its kernel can (trim_lds with
+        // a block of at least 122 KB of LDS: the 2x100 ... 2x150 variants); FAQCS_TAIL_FOLD=0: never (A/B)
+        DevParams dp = c->dp;
+        static const bool tail_on = [] { const char *e = getenv("FAQCS_TAIL_FOLD"); return !e || atoi(e) != 0; }();
+        if (c->pending_fold >= 0 && !c->pending_wide && tail_on) {
+            const faqcs_ctx::RecSet &ps = c->rec[c->pending_fold];
+            if (!c->d_fold_claim) HIPCHK(hipMalloc((void **)&c->d_fold_claim, 8));
+            HIPCHK(hipMemsetAsync(c->d_fold_claim, 0, 8, c->compute));
+            dp.fold_pre = ps.pre.p; dp.fold_post = ps.post.p; dp.fold_n = c->pending_n; dp.fold_claim = c->d_fold_claim;
+            dp.fold_dst_pre = c->d_counters + c->lay.pre_comp; dp.fold_dst_post = c->d_counters + c->lay.post_comp;
+        }
+        HIPCHK(faqcs_launch_trim(dp, d_seq, d_qual, d_off, n, max_len, d_sl, d_hit, d_res, rs.pre.p, rs.post.p,
                                  c->d_counters, c->d_err, c->n_cu, c->compute, d_tn));
         HIPCHK(hipEventRecord(t.b, c->compute));
         c->trim_kernel = faqcs_last_trim_kernel();
+        if (c->pending_fold >= 0) { // ... else composition_histogram folds them on the aux stream, beside this launch
+            if (!(dp.fold_n && faqcs_last_trim_folded())) {
+                faqcs_ctx::RecSet &ps = c->rec[c->pending_fold];
+                HIPCHK(hipStreamWaitEvent(c->aux, ps.trimmed, 0));
+                HIPCHK(faqcs_launch_composition(ps.pre.p, ps.post.p, c->pending_n, c->pending_wide, c->d_norm, c->d_counters + c->lay.pre_comp,
+                                                c->d_counters + c->lay.post_comp, c->n_cu, c->aux));
+                HIPCHK(hipEventRecord(ps.folded, c->aux));
+                ps.used = true;
+            }
+            c->pending_fold = -1;
+        }
         static const bool no_comp = [] { const char *e = getenv("FAQCS_DIAG_NO_COMPOSITION"); return e && atoi(e) != 0; }(); // (diagnostic, wrong composition tables: what the fold costs a step)
         if (!(c->dp.dbg & 1u) && !long_reads && !no_comp) {
             HIPCHK(hipEventRecord(rs.trimmed, c->compute));
-            HIPCHK(hipStreamWaitEvent(c->aux, rs.trimmed, 0));
-            HIPCHK(faqcs_launch_composition(rs.pre.p, rs.post.p, n, wide, c->d_norm, c->d_counters + c->lay.pre_comp,
-                                            c->d_counters + c->lay.post_comp, c->n_cu, c->aux));
-            HIPCHK(hipEventRecord(rs.folded, c->aux));
-            rs.used = true;
+            c->pending_fold = set; c->pending_n = n; c->pending_wide = wide;
         }
     }
     // ---- owner-partitioned k-mer mode: this shard's runs of k-mers (super-k-mer items) grouped by owner rank; the caller exchanges them
@@ -1163,11 +1189,23 @@ static int resolve_points(faqcs_ctx *c)
     return 0;
 }
 
+// the records of the last launch are folded now, on the compute stream (somebody is about to read, move or reset the counter block)
+static int fold_pending_now(faqcs_ctx *c)
+{
+    if (c->pending_fold < 0) return 0;
+    faqcs_ctx::RecSet &ps = c->rec[c->pending_fold];
+    HIPCHK(faqcs_launch_composition(ps.pre.p, ps.post.p, c->pending_n, c->pending_wide, c->d_norm, c->d_counters + c->lay.pre_comp,
+                                    c->d_counters + c->lay.post_comp, c->n_cu, c->compute));
+    c->pending_fold = -1;
+    return 0;
+}
+
 extern "C" int faqcs_sync(faqcs_ctx *c)
 {
     if (!c) return fail(FAQCS_E_INVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->copy));
+    if (int rc = fold_pending_now(c)) return rc;
     // (round 6: the k-mers waiting in the open group stay there -- they are counted when the pass ends, faqcs_kmer_end_table /
     // faqcs_kmer_finish_pass, or when a caller asks for the curve so far, faqcs_kmer_points / _totals / _epoch_counts: kmer_catch_up)
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -1212,6 +1250,7 @@ extern "C" int faqcs_counters_export(faqcs_ctx *c, void *d_dst, uint64_t n_u64)
 {
     if (!c || !d_dst || n_u64 < c->lay.total) return fail(FAQCS_E_INVAL, "faqcs_counters_export: buffer too small");
     HIPCHK(hipSetDevice(c->device));
+    if (int rc = fold_pending_now(c)) return rc;
     HIPCHK(hipStreamSynchronize(c->aux));
     HIPCHK(hipMemcpyAsync(d_dst, c->d_counters, c->lay.total * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -1222,6 +1261,7 @@ extern "C" int faqcs_counters_import(faqcs_ctx *c, const void *d_src, uint64_t n
 {
     if (!c || !d_src || n_u64 < c->lay.total) return fail(FAQCS_E_INVAL, "faqcs_counters_import: buffer too small");
     HIPCHK(hipSetDevice(c->device));
+    if (int rc = fold_pending_now(c)) return rc; // (what is still to be folded belongs to the block that is being replaced... by its own sum: export came first)
     HIPCHK(hipStreamSynchronize(c->aux));
     HIPCHK(hipMemcpyAsync(c->d_counters, d_src, c->lay.total * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -1279,6 +1319,7 @@ int comm_enqueue(faqcs_ctx *c)
 {
     Rccl &r = rccl();
     HIPCHK(hipSetDevice(c->device));
+    if (int rc = fold_pending_now(c)) return rc;
     if (!c->comm_ev) HIPCHK(hipEventCreateWithFlags(&c->comm_ev, hipEventDisableTiming));
     HIPCHK(hipEventRecord(c->comm_ev, c->aux));             // (the composition fold adds to the block on the aux stream)
     HIPCHK(hipStreamWaitEvent(c->compute, c->comm_ev, 0));
@@ -1363,6 +1404,8 @@ extern "C" int faqcs_reset_counters(faqcs_ctx *c)
 {
     if (!c) return fail(FAQCS_E_INVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
+    // (records that are still to be folded belong to the job that ends here: they are dropped with its block -- a caller reads the block first)
+    c->pending_fold = -1;
     HIPCHK(hipStreamSynchronize(c->aux));
     HIPCHK(hipMemsetAsync(c->d_counters, 0, c->lay.total * sizeof(uint64_t), c->compute));
     return 0;

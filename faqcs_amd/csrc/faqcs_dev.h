@@ -42,6 +42,13 @@ struct DevParams {
                                   // block -- stale rows are never read, so nothing is zeroed)
     uint32_t *partial_rows;       // [n_cu] rows of `partials` each block of the last trim_lds launch wrote
     faqcs_layout lay;
+    // (set per launch by the host; round 6) the composition records of the PREVIOUS launch: a trim_lds block that has run out of chunks folds
+    // them in the LDS it no longer needs, while the slowest blocks finish -- the fold used to run in the seam between two launches because
+    // its 120 KB table cannot share a CU with a 160 KB trim_lds block (8.5 % of the headline step).  fold_n == 0: nothing to fold.
+    const unsigned long long *fold_pre, *fold_post;
+    uint32_t fold_n;
+    uint32_t *fold_claim;         // [2] chunks of fold_pre / fold_post handed out so far (zero when the launch starts)
+    uint64_t *fold_dst_pre, *fold_dst_post;
 };
 
 enum { FS_SLOTS = 32 };

@@ -368,3 +368,101 @@ __device__ __forceinline__ void chunk_epilogue(const ReadOutcome &o, const bool 
         }
 }
 
+#ifdef __HIPCC__
+// ---- composition records -> the 10 001 x 6 composition tables (trim.cpp:860-874), by a block that owns >= 122 KB of LDS at address `tab` ----------
+// The arithmetic of composition_histogram (faqcs_trim_kernel.hip) with the records handed out dynamically: chunks of NT x 4 records from a
+// global counter, five chunks per claim.  Used by the blocks of a trim_lds launch that have run out of reads (round 6): `which` = 0 / 1 takes
+// the pre- / post-trim records first and the other array behind it, so that the two halves of the grid meet in the middle of the work.
+// One-word records only (reads of up to 256 bases).  Every block returns when both counters are exhausted: when the LAST block of the launch
+// returns, every chunk has been claimed, and the kernel does not end before its claimer is done -- the fold is complete behind the launch.
+template <int NT>
+__device__ __forceinline__ void comp_fold_tail(uint32_t *tab, const DevParams &P, const int tid, const uint32_t which)
+{
+    constexpr int NE = FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND, ND = (NE + 1) / 2, U = 4;
+    constexpr uint32_t CHUNK = NT * U, PER_CLAIM = 5, FLUSH_CLAIMS = 65535u / (CHUNK * PER_CLAIM);
+    static_assert(FLUSH_CLAIMS >= 1, "a claim must fit the 16-bit counters");
+    float *normt = reinterpret_cast<float *>(tab + ND);
+    uint32_t *s_next = tab + ND + 512;
+    const uint32_t n = P.fold_n, n_chunks = (n + CHUNK - 1) / CHUNK;
+    // nothing left in either array: no table to set up
+    if (uniu(__hip_atomic_load(&P.fold_claim[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= n_chunks &&
+        uniu(__hip_atomic_load(&P.fold_claim[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= n_chunks) return;
+    for (int i = tid; i < ND; i += NT) tab[i] = 0;
+    for (int i = tid; i < 512; i += NT) normt[i] = i <= FAQCS_TAB_LEN ? P.comp_norm[i] : 0.0f;
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < 2; ++pass) {
+        const uint32_t a = which ^ pass;
+        const unsigned long long *__restrict__ rec = a ? P.fold_post : P.fold_pre;
+        uint64_t *__restrict__ dst = a ? P.fold_dst_post : P.fold_dst_pre;
+        uint32_t since_flush = 0;
+        bool dirty = false;
+#pragma unroll 1
+        for (;;) {
+            if (tid == 0) *s_next = atomicAdd(&P.fold_claim[a], PER_CLAIM);
+            __syncthreads();
+            const uint32_t c0 = *s_next;
+            __syncthreads();
+            if (c0 >= n_chunks) break;
+            dirty = true;
+#pragma unroll 1
+            for (uint32_t c = c0; c < c0 + PER_CLAIM && c < n_chunks; ++c) {
+                unsigned long long x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const uint32_t i = c * CHUNK + (uint32_t)(u * NT + tid); x[u] = i < n ? rec[i] : 0ull; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t nbin = 0xffffffffu;
+                    if (x[u] & CR_VALID) {
+                        const uint32_t len = (uint32_t)(x[u] & 511u);
+                        uint32_t cnt[5];
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) cnt[k] = (uint32_t)(x[u] >> (9 + 9 * k)) & 511u;
+                        const float norm = normt[len];
+                        uint32_t idx[6];
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) idx[k] = (uint32_t)__fmul_rn(norm, (float)cnt[k]); // trim.cpp:862-872
+                        idx[5] = idx[3] + idx[2];                                                      // :874 (G + C)
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            if (k == 4) continue;
+                            const uint32_t e = idx[k] * FAQCS_NCOMP_KIND + k;
+                            atomicAdd(&tab[e >> 1], 1u << (16 * (e & 1u)));
+                        }
+                        nbin = idx[4] * FAQCS_NCOMP_KIND + 4;
+                    }
+                    constexpr uint32_t bin0 = 4u; // (no N at all: nearly every read -- one add per wave, as in composition_histogram)
+                    const unsigned long long zero = __ballot(nbin == bin0);
+                    if (zero != 0ull && (tid & 63) == __builtin_ctzll(zero)) atomicAdd(&tab[bin0 >> 1], (uint32_t)__popcll(zero) << (16 * (bin0 & 1u)));
+                    if (nbin != 0xffffffffu && nbin != bin0) atomicAdd(&tab[nbin >> 1], 1u << (16 * (nbin & 1u)));
+                }
+            }
+            if (++since_flush == FLUSH_CLAIMS) {
+                __syncthreads();
+                for (int d = tid; d < ND; d += NT) {
+                    const uint32_t v = tab[d];
+                    if (v) {
+                        tab[d] = 0;
+                        if (v & 0xffffu) atomicAdd((unsigned long long *)(dst + 2 * d), (unsigned long long)(v & 0xffffu));
+                        if (v >> 16) atomicAdd((unsigned long long *)(dst + 2 * d + 1), (unsigned long long)(v >> 16));
+                    }
+                }
+                __syncthreads();
+                since_flush = 0; dirty = false;
+            }
+        }
+        if (dirty) { // (block-uniform)
+            __syncthreads();
+            for (int d = tid; d < ND; d += NT) {
+                const uint32_t v = tab[d];
+                if (v) {
+                    tab[d] = 0;
+                    if (v & 0xffffu) atomicAdd((unsigned long long *)(dst + 2 * d), (unsigned long long)(v & 0xffffu));
+                    if (v >> 16) atomicAdd((unsigned long long *)(dst + 2 * d + 1), (unsigned long long)(v >> 16));
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+#endif

@@ -1397,12 +1397,17 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
 
 static thread_local const char *g_last_trim_kernel = "";
 const char *faqcs_last_trim_kernel() { return g_last_trim_kernel; }
+bool faqcs_trim_lds_tail_folded();
+static thread_local bool g_last_trim_folded = false;
+// the last faqcs_launch_trim() of this thread folded the composition records DevParams::fold_* named (a trim_lds variant with room for the table)
+bool faqcs_last_trim_folded() { return g_last_trim_folded; }
 
 hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                              uint32_t n_reads, uint32_t max_len, const uint32_t *ad_sl, const uint16_t *ad_hit,
                              faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
                              uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st, const uint8_t *tn_flags)
 {
+    g_last_trim_folded = false;
     {   // trim_long (faqcs_trim_long_kernel.hip): a batch that holds a read of more than 1 024 bases; FAQCS_TRIM_LONG=1 sends every batch there (tests)
         const char *e_long = getenv("FAQCS_TRIM_LONG"); // (read per launch: the tests switch it inside one process)
         const bool force_long = e_long && atoi(e_long) != 0;
@@ -1416,7 +1421,7 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
         static const bool lds_on = [] { const char *e = getenv("FAQCS_TRIM_LDS"); return !e || atoi(e) != 0; }();
         if (lds_on) {
             const hipError_t e = faqcs_launch_trim_lds(P, seq, qual, off, n_reads, max_len, ad_sl, ad_hit, out, rec_pre, rec_post, counters, err, n_cu, st, tn_flags);
-            if (e != hipErrorNotSupported) { g_last_trim_kernel = "trim_lds"; return e; }
+            if (e != hipErrorNotSupported) { g_last_trim_kernel = "trim_lds"; g_last_trim_folded = e == hipSuccess && faqcs_trim_lds_tail_folded(); return e; }
         }
     }
     g_last_trim_kernel = "trim_filter_accumulate";

@@ -412,6 +412,9 @@ __global__ __launch_bounds__(1024) void fold_partials(const uint32_t *__restrict
 // RPC = reads per chunk: 64 (one per lane in the lane-per-read passes) or 32 -- half the lanes idle there, but a slot of half the size: reads of
 // 161 ... 252 bases get 12 waves per CU instead of 6.  The position-parallel passes run TPR = RPC x LPR / 64 steps per chunk; the lane that owns a
 // read in the lane-per-read passes is lane t of the row of LPR lanes that works on it in step t.
+// a variant whose block owns at least the 122 KB the composition fold needs (the table of 16-bit counters, the per-length factors)
+template <int C, int NW, int LPR, int RPC> constexpr bool lds_tail_folds_v =
+    LdsCfg<C, NW, LPR, RPC>::lds_dwords() >= (FAQCS_NCOMP_BIN * FAQCS_NCOMP_KIND + 1) / 2 + 512 + 8 && lds_maxlen(C, LPR) <= 256; // (one-word records)
 template <int C, int NW, bool WINDOWED, bool EXT, int LPR, int RPC>
 __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     const DevParams P, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
@@ -1499,6 +1502,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void trim_lds(
     }
     if (__any(any_err != 0) && lane == 0) atomicOr(err, 1u);
     if (tid == 0) P.partial_rows[blockIdx.x] = n_flushed; // rows of P.partials this block wrote (fold_partials)
+    // ---- the block has run out of reads: its LDS (every wave has passed the last flush) folds composition records of the PREVIOUS launch
+    // while the slowest blocks of this one finish (round 6; faqcs_trim_common.h: comp_fold_tail)
+    if (lds_tail_folds_v<C, NW, LPR, RPC> && P.fold_n) {
+        __syncthreads();
+        comp_fold_tail<NW * 64>(smem, P, tid, blockIdx.x & 1u);
+    }
 #ifdef FAQCS_LDS_STAMPS
     if (lane == 0) {
 #pragma unroll
@@ -1538,6 +1547,8 @@ hipError_t faqcs_launch_terminal_n_flags(const uint8_t *seq, const uint32_t *off
     return hipGetLastError();
 }
 
+static thread_local bool g_trim_lds_tail_folded = false;
+bool faqcs_trim_lds_tail_folded() { return g_trim_lds_tail_folded; }
 template <int C, bool WINDOWED, bool EXT, int LPR = 8, int RPC = 64>
 static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const uint8_t *qual, const uint32_t *off,
                                   uint32_t n_reads, const uint32_t *ad_sl, const uint16_t *ad_hit, faqcs_read_result *out,
@@ -1562,6 +1573,7 @@ static hipError_t launch_trim_lds(const DevParams &P, const uint8_t *seq, const 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, P, seq, qual, off, n_reads, ad_sl, ad_hit,
                        reinterpret_cast<uint2 *>(out), rec_pre, rec_post, counters, err, tn_flags);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    g_trim_lds_tail_folded = lds_tail_folds_v<C, NW, LPR, RPC> && P.fold_n != 0; // (the launch folds the composition records P.fold_* names, all of them)
     hipLaunchKernelGGL((fold_partials<C, LPR>), dim3((RowCfg<C, LPR, lds_wq(C, LPR)>::N_ZERO + 63) / 64), dim3(1024), 0, st, P.partials, P.partial_rows, grid, counters, P.lay, err + 8);
     return hipGetLastError();
 }
@@ -1573,6 +1585,7 @@ hipError_t faqcs_launch_trim_lds(const DevParams &P, const uint8_t *seq, const u
                                  faqcs_read_result *out, unsigned long long *rec_pre, unsigned long long *rec_post,
                                  uint64_t *counters, uint32_t *err, int n_cu, hipStream_t st, const uint8_t *tn_flags)
 {
+    g_trim_lds_tail_folded = false;
     const bool windowed = P.has_adapters || ((P.trim5 || P.trim3) && !P.qc_only);
     const bool plain = P.mode == FAQCS_MODE_BWA_PLUS && !P.protect5 && !P.qc_only && P.replace_q == 0 && !P.avgq_on &&
                        P.max_poly_n == 2 && P.dbg == 0;
