@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--kmer-table-log2", type=int, default=31, help="log2 of the k-mer table's slots per GPU (--config kmer; 2^31 slots = 34 GB: the "
                     "tests that put eight ranks on one GPU pass 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run-memory", action="store_true", help="--config kmer: print every rank's HBM budget (reads, table, group buffers: "
+                    "faqcs_kmer_memory_plan) and stop before anything is allocated; exit 1 when a rank's share of its device cannot hold it")
     ap.add_argument("--no-other-configs", action="store_true", help="the default single-GPU run (config plain, 2x150) also runs BASELINE's adapter and k-mer "
                     "configurations, two steps each, and reports them under \"configs\"; this switches that off")
     ap.add_argument("--e2e-pairs", type=float, default=float(os.environ.get("FAQCS_BENCH_E2E_PAIRS", -1)),
@@ -449,8 +451,36 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         pairs = 25e6 if config == "kmer" else (125e6 if (config == "plain" and world == 8) else 100e6)
     opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "400"]}.get(config, [])
     opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
-    eng = HipEngine(opt, 256 if L <= 256 else (capi.FAST_READ_LENGTH if L <= capi.FAST_READ_LENGTH else capi.MAX_READ_LENGTH), 33, device=local,
-                    kmer_table_slots=(1 << a.kmer_table_log2) if config == "kmer" else 0)
+    R_eng = 256 if L <= 256 else (capi.FAST_READ_LENGTH if L <= capi.FAST_READ_LENGTH else capi.MAX_READ_LENGTH)
+    kmer_plan = None
+    if config == "kmer":
+        # A rank's HBM budget BEFORE anything is allocated: at full size -- 25 M pairs, 2^31 slots -- eight ranks cannot share one
+        # GPU, and the first 8-GPU run should not find out by running out of memory half way.  faqcs_kmer_memory_plan is host-only.
+        lib0 = capi.load_library()
+        holder = capi.ParamsHolder(opt, R_eng, 33, kmer_table_slots=1 << a.kmer_table_log2)
+        free0, total0 = torch.cuda.mem_get_info(dev)
+        sharing = world if os.environ.get("FAQCS_BENCH_SHARE_GPU") == "1" else 1
+        plan = (C.c_uint64 * 5)()
+        reads_b = int(2 * pairs) * (2 * L + 12 + 8 + 1) + (1 << 30)
+        _check(lib0, lib0.faqcs_kmer_memory_plan(C.byref(holder.p), max(0, free0 // sharing - reads_b), plan, 5))
+        table_b, l1_b, l2_b, group_occ, misc_b = (int(x) for x in plan)
+        occ = int(2 * pairs) * max(0, L - 30)
+        kmer_plan = {"rank": rank, "device": local, "ranks_sharing_the_device": sharing, "device_total_GB": round(total0 / 1e9, 1), "device_free_GB": round(free0 / 1e9, 1),
+                     "resident_reads_GB": round(reads_b / 1e9, 1), "kmer_table_GB": round(table_b / 1e9, 1), "group_buffers_GB": round((l1_b + l2_b) / 1e9, 1),
+                     "small_arrays_GB": round(misc_b / 1e9, 2), "sum_GB": round((reads_b + table_b + l1_b + l2_b + misc_b) / 1e9, 1),
+                     "group_takes_G_occurrences": round(group_occ / 1e9, 2), "pass_has_at_most_G_occurrences": round(occ / 1e9, 2),
+                     "pass_counted_in_one_piece": bool(group_occ >= occ)}
+        fits = reads_b + table_b + l1_b + l2_b + misc_b <= free0 // sharing
+        kmer_plan["fits"] = bool(fits)
+        sys.stderr.write("[bench] k-mer HBM budget: %s\n" % json.dumps(kmer_plan))
+        if a.dry_run_memory or not fits:
+            if not fits:
+                sys.stderr.write("[bench] rank %d: %.1f GB do not fit its share of device %d (%.1f GB free / %d ranks): fewer --pairs, a smaller --kmer-table-log2, "
+                                 "or one rank per GPU\n" % (rank, kmer_plan["sum_GB"], local, free0 / 1e9, sharing))
+            if rank == 0 and a.dry_run_memory:
+                print(json.dumps({"dry_run_memory": kmer_plan}))
+            sys.exit(0 if fits else 1)
+    eng = HipEngine(opt, R_eng, 33, device=local, kmer_table_slots=(1 << a.kmer_table_log2) if config == "kmer" else 0)
     lib = eng.lib
 
     # ---- resident synthetic data set ---------------------------------------------------------------------
@@ -712,6 +742,8 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
         }
         if noflag_value is not None:
             out["config"]["value_without_terminal_n_flags"] = noflag_value
+        if kmer_plan is not None:
+            out["config"]["hbm_budget"] = kmer_plan
         if coll[1]:
             out["collective"] = {"what": ("all-reduce(sum) of the %d-word u64 counter block, once per job, IN PLACE on the engine's compute stream by the library's own RCCL "
                                           "communicator (faqcs_comm_allreduce_counters); ms_per_step includes the wait for the step's last kernels; %s" % (eng.n_counters, native_state["note"])) if native_rccl else
@@ -744,13 +776,16 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
                          "kernels_ms": {trim_kernel: round(kt.trim_ms, 4), "adapter_overlap": round(kt.adapter_ms, 4),
                                         "kmer kernels (per submission)": round(kt.kmer_ms, 4), "kmer_insert_items": round(kt.kmer_insert_ms, 4)}},
         })
+        if noflag_value is not None and value > 0:  # (VERDICT r5 hygiene: the conservative figure beside the headline's)
+            out["roofline"]["frac_without_terminal_n_flags"] = round(achieved / HBM_PEAK_GBS * noflag_value / value, 5)
         if config == "kmer" and "kmer" in out and dom_ms > 0:
             occ = out["kmer"].get("occurrences_per_step", out["kmer"].get("occurrences_at_last_point", 0)) / max(1, len(batches))
             rate = occ / (dom_ms * 1e-3) / 1e9
             kc = {"G_occurrences_per_s": round(rate, 3),
                   "note": "occurrences per submission / the k-mer kernels' time.  Rounds 1-3 paid one memory-side atomic per occurrence (13.5 G/s measured ceiling), "
-                          "round 4 moved an 8-byte item per occurrence through two scatter passes (61 B of HBM traffic per occurrence); the counters of the "
-                          "super-k-mer kernels are in profiles/r5*/pmc_skm*.txt"}
+                          "round 4 moved an 8-byte item per occurrence through two scatter passes (61 B of HBM traffic per occurrence), round 5 a 16-byte run "
+                          "of ~8 occurrences and one table update per distinct key and group (22 B); round 6 counts a pass in one piece at its end and does not "
+                          "touch the table: the counters of its kernels are in profiles/r6*/pmc_skm*.txt"}
             kj, why = load_if_current(os.path.join(ROOT, "profiles", "kmer_counters.json"))
             if kj is not None:
                 kc.update(kj)

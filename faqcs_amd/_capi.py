@@ -161,6 +161,7 @@ def load_library():
         "faqcs_kmer_active": (i32, [vp]),
         "faqcs_kmer_end_table": (i32, [vp]),
         "faqcs_kmer_finish_pass": (i32, [vp]),
+        "faqcs_kmer_memory_plan": (i32, [vp, u64, vp, u32]),
         "faqcs_kmer_partition": (i32, [vp, u32, u32, u32]),
         "faqcs_kmer_set_epochs": (i32, [vp, vp, u32]),
         "faqcs_kmer_outbox": (i32, [vp, C.POINTER(vp), vp]),

@@ -504,6 +504,60 @@ extern "C" int faqcs_set_quality(faqcs_ctx *c, int quality)
 // ---------------------------------------------------------------------------------------------------------
 // combine-before-insert k-mer counting: host side (kernels: faqcs_kmer_skm_kernel.hip)
 // ---------------------------------------------------------------------------------------------------------
+// Sizes of the group buffers for a table of `slots` slots, k-mers of k bases and `free_b` bytes of free device memory (kg_init, and
+// faqcs_kmer_memory_plan for a caller that wants to know before anything is allocated).
+// Either scatter level writes 65 536 sub-regions: (bucket, writing block) at level 1, partitions at level 2.  An item is 16 bytes and
+// holds a run of up to w k-mers, (w + 1) / 2 on average; the buffers are sized for three items per w + 1 occurrences (the bench's reads
+// make one per 8), a level-1 sub-region for 1.25 x its even share, a partition -- minimizer bins vary more than hash bins do -- for
+// 1.5 x.  What overflows is counted occurrence by occurrence (exact, slow).
+// The item bound of a group.  Round 6: a pass that fits ONE group never reaches the table (faqcs_kmer.h), so a group is as large as the
+// table's own sizing rule makes a pass -- six occurrences per slot: 0.6 distinct keys per slot at a coverage of 10 -- and the HBM
+// allows: at most 60 % of what is free (the caller's batches are resident already in every use of this library).  2^31 slots:
+// groups of 12.9 G occurrences, 44 + 53 GB of buffers next to the 36.5 GB table.
+struct KgPlan { uint64_t G; uint32_t cap1, cap2; size_t l1_bytes, l2_bytes; };
+static KgPlan kg_plan(uint64_t slots, uint32_t kmer, size_t free_b)
+{
+    const uint32_t w = kmer > 15 ? kmer - 14 : 1;
+    KgPlan pl{};
+    auto caps = [&](uint64_t G) {
+        const double G_items = w == 1 ? (double)G : (double)G * 3.0 / (w + 1);
+        const double mean = G_items / (KG_FAN * KG_FAN);
+        pl.cap1 = (uint32_t)(mean * 1.25 + 8.0 * std::sqrt(mean) + 64.0);
+        pl.cap2 = (uint32_t)(mean * 1.5 + 8.0 * std::sqrt(mean) + 64.0);
+        if (pl.cap1 < (uint32_t)KG_MIN_CAP) pl.cap1 = KG_MIN_CAP;
+        if (pl.cap2 < (uint32_t)KG_MIN_CAP) pl.cap2 = KG_MIN_CAP;
+        pl.cap2 = (pl.cap2 + 7u) & ~7u; // (cut 2^F ways for the fine partitions of a pass counted at its end)
+        pl.l1_bytes = (size_t)pl.cap1 * KG_FAN * KG_FAN * 16; pl.l2_bytes = (size_t)pl.cap2 * KG_FAN * KG_FAN * 16;
+        return pl.l1_bytes + pl.l2_bytes;
+    };
+    uint64_t G = slots * 6;
+    if (G < (1ull << 18)) G = 1ull << 18;
+    if (G > (1ull << 36)) G = 1ull << 36;
+    bool fixed = false;
+    if (const char *e = getenv("FAQCS_KMER_GROUP_ITEMS")) { const uint64_t v = strtoull(e, nullptr, 0); if (v >= (1ull << 14) && v <= (1ull << 36)) { G = v; fixed = true; } }
+    while (!fixed && G > (1ull << 18) && caps(G) > free_b / 10 * 6) G -= G / 4;
+    (void)caps(G);
+    pl.G = G;
+    return pl;
+}
+
+// What a kmer_rarefaction context will hold on its device: out[0] the table (with its overflow area), out[1] / out[2] the level-1 / level-2
+// group buffers, out[3] the occurrences a group takes (a pass below it is counted in one piece), out[4] the small arrays.  Host only.
+extern "C" int faqcs_kmer_memory_plan(const faqcs_params *p, uint64_t free_bytes, uint64_t *out, uint32_t n_out)
+{
+    if (!p || !out || n_out < 5) return fail(FAQCS_E_INVAL, "faqcs_kmer_memory_plan: null argument / fewer than 5 words");
+    for (uint32_t i = 0; i < n_out; ++i) out[i] = 0;
+    if (!p->kmer_rarefaction) return 0;
+    uint64_t slots = p->kmer_table_slots ? p->kmer_table_slots : (1ull << 28);
+    uint64_t pow2 = 1; while (pow2 < slots) pow2 <<= 1;
+    if (pow2 < (uint64_t)KG_SLICE_MIN << 16) pow2 = (uint64_t)KG_SLICE_MIN << 16;
+    const uint64_t table = (pow2 + std::max<uint64_t>(pow2 >> 4, 1ull << 16)) * sizeof(KmerSlot);
+    const KgPlan pl = kg_plan(pow2, p->kmer, free_bytes > table ? (size_t)(free_bytes - table) : 0);
+    out[0] = table; out[1] = pl.l1_bytes; out[2] = pl.l2_bytes; out[3] = pl.G;
+    out[4] = (uint64_t)KG_FAN * KG_FAN * 4 * 18 + (1u << 16) * 8 + (1u << 20) * 8 + (1ull << 19) / 8; // cursors, redo list, histogram of counts, dirty bits
+    return 0;
+}
+
 static int kg_init(faqcs_ctx *c)
 {
     faqcs_ctx::KmerGroup &g = c->kg;
@@ -512,35 +566,13 @@ static int kg_init(faqcs_ctx *c)
     KmerGroupDev &d = g.dev;
     g.skm = !g.direct; // (FAQCS_KMER_DIRECT=1 on an owner-partitioned context: round 3's pairs and per-pair atomics)
     g.skm_w = c->prm.kmer > 15 ? c->prm.kmer - 14 : 1;
-    const size_t item_bytes = g.skm ? 16 : 8;
-    // Either scatter level writes 65 536 sub-regions: (bucket, writing block) at level 1, partitions at level 2.  Super-k-mers: an item is
-    // 16 bytes and holds a run of up to w k-mers, (w + 1) / 2 on average; the buffers are sized for three items per w + 1 occurrences
-    // (the bench's reads make one per 8), a level-1 sub-region for 1.25 x its even share, a partition -- minimizer bins vary more than hash
-    // bins do -- for 1.5 x.  What overflows is counted occurrence by occurrence (exact, slow).
-    auto caps = [&](uint64_t G, uint32_t &cap1, uint32_t &cap2) {
-        const double G_items = !g.skm || g.skm_w == 1 ? (double)G : (double)G * 3.0 / (g.skm_w + 1);
-        const double mean = G_items / (KG_FAN * KG_FAN);
-        cap1 = (uint32_t)(mean * 1.25 + 8.0 * std::sqrt(mean) + 64.0);
-        cap2 = (uint32_t)(mean * 1.5 + 8.0 * std::sqrt(mean) + 64.0);
-        if (cap1 < (uint32_t)KG_MIN_CAP) cap1 = KG_MIN_CAP;
-        if (cap2 < (uint32_t)KG_MIN_CAP) cap2 = KG_MIN_CAP;
-        cap2 = (cap2 + 7u) & ~7u; // (cut 2^F ways for the fine partitions of a pass counted at its end)
-        return ((size_t)cap1 + cap2) * KG_FAN * KG_FAN * item_bytes;
-    };
-    // The item bound of a group.  Round 6: a pass that fits ONE group never reaches the table (faqcs_kmer.h), so a group is as large as the
-    // table's own sizing rule makes a pass -- six occurrences per slot: 0.6 distinct keys per slot at a coverage of 10 -- and the HBM
-    // allows: at most 60 % of what is free now (the caller's batches are resident already in every use of this library).  2^31 slots:
-    // groups of 12.9 G occurrences, 44 + 53 GB of buffers next to the 36.5 GB table.
-    uint64_t G = slots * 6;
-    if (G < (1ull << 18)) G = 1ull << 18;
-    if (G > (1ull << 36)) G = 1ull << 36;
-    bool fixed = false;
-    if (const char *e = getenv("FAQCS_KMER_GROUP_ITEMS")) { const uint64_t v = strtoull(e, nullptr, 0); if (v >= (1ull << 14) && v <= (1ull << 36)) { G = v; fixed = true; } }
+    const size_t item_bytes = 16;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    while (!fixed && G > (1ull << 18) && caps(G, d.cap1, d.cap2) > free_b / 10 * 6) G -= G / 4;
+    const KgPlan pl = kg_plan(slots, c->prm.kmer, free_b);
+    const uint64_t G = pl.G;
+    d.cap1 = pl.cap1; d.cap2 = pl.cap2;
     g.cap_items = G;
-    (void)caps(G, d.cap1, d.cap2);
     d.split = 1u; // (a partition's items in one piece: skm_combine fetches them by index)
     d.cap2f = d.cap2 >> c->kt.fine;
     HIPCHK(hipMalloc((void **)&d.l1, (size_t)KG_FAN * KG_FAN * d.cap1 * item_bytes));

@@ -1437,6 +1437,10 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
 #define FAQCS_TRIM_CASE8(C)                                                                                 \
     return windowed ? (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, true, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, true, false>(FAQCS_TRIM_ARGS)) \
                     : (generic ? launch_trim_t<C, 8, FAQCS_TRIM_NW, false, true>(FAQCS_TRIM_ARGS) : launch_trim_t<C, 8, FAQCS_TRIM_NW, false, false>(FAQCS_TRIM_ARGS))
+        // trim_tpr (round 1's two-phase kernel) is NOT part of the shipped library since round 6: every batch it took runs trim_lds, its
+        // instantiations were 2.8 MB of a 4.8 MB library and most of every rebuild.  -DFAQCS_WITH_TRIM_TPR compiles them in again for A/B
+        // runs (FAQCS_TRIM_LDS=0 then reaches them as in rounds 4-5); without it FAQCS_TRIM_LDS=0 goes straight to trim_filter_accumulate.
+#ifdef FAQCS_WITH_TRIM_TPR
         {   // the two-phase kernel for the headline option set; FAQCS_TRIM_TPR=0 switches it off
             static const bool tpr = [] { const char *e = getenv("FAQCS_TRIM_TPR"); return !e || atoi(e) != 0; }();
             // EXT: the default set plus --5trim_off / --avg_q / -n 0 or 1 (compiled apart so that the default variants stay as they are)
@@ -1460,6 +1464,7 @@ hipError_t faqcs_launch_trim(const DevParams &P, const uint8_t *seq, const uint8
             }
 #undef FAQCS_TRIM_CASE_TPR4
         }
+#endif
         {   // 4 lanes per read (16 reads per wave): reads <= 76 bases (2x75, 2x50); FAQCS_TRIM_LPR4=0 switches it off
             static const bool lpr4 = [] { const char *e = getenv("FAQCS_TRIM_LPR4"); return !e || atoi(e) != 0; }();
 #define FAQCS_TRIM_CASE4(C)                                                                                 \

@@ -281,6 +281,12 @@ int  faqcs_kmer_end_table(faqcs_ctx *ctx);
  * end of process_paired() / process_unpaired(), FaQCs.cpp:518-537. */
 int  faqcs_kmer_finish_pass(faqcs_ctx *ctx);
 
+/* What a kmer_rarefaction context made from `params` will allocate on a device with free_bytes of free memory, before anything is
+ * allocated (host only; bench.py --config kmer prints it per rank and refuses a run that cannot fit): out[0] the table with its overflow
+ * area, out[1] / out[2] the level-1 / level-2 group buffers, out[3] the k-mer occurrences one group takes -- a pass below it is counted in
+ * one piece, without the table --, out[4] the small arrays.  n_out >= 5. */
+int  faqcs_kmer_memory_plan(const faqcs_params *params, uint64_t free_bytes, uint64_t *out, uint32_t n_out);
+
 /* ---- k-mers across GPUs --------------------------------------------------------------
  * The reference keeps ONE MAP<Word,size_t> per process (trim.cpp:82,133-135) and samples (distinct, total) after
  * trim() calls (trim.cpp:157-185); distinct counts are not additive over shards.  In this mode every canonical

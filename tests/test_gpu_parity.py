@@ -293,9 +293,9 @@ def test_quality_offsets_that_leave_scores_outside_the_valid_range(in_off, kind,
 
 @pytest.mark.parametrize("switch", ["tpr_off", "lds_off"])
 def test_single_pass_kernel_variants_still_match_oracle(switch):
-    """Reads of up to 304 bases run trim_lds.  FAQCS_TRIM_LDS=0 (read once per process) sends the same batches through the kernels of
-    rounds 1-3 -- trim_tpr for the default-like option sets up to 160 bases, trim_filter_accumulate otherwise -- and FAQCS_TRIM_TPR=0 on top
-    of it through the single-pass variants alone: both are still what --replace_to_N_q, longer reads and A/B runs use."""
+    """Reads of up to 304 bases run trim_lds.  FAQCS_TRIM_LDS=0 (read once per process) sends the same batches through the single-pass kernel
+    trim_filter_accumulate -- what --replace_to_N_q and reads of 305 ... 1 024 bases use.  (Round 1's two-phase trim_tpr is compiled in only with
+    -DFAQCS_WITH_TRIM_TPR since round 6; in such a build the first of the two runs goes through it, FAQCS_TRIM_TPR=0 switches it off again.)"""
     import subprocess
     import sys
     env = dict(os.environ, FAQCS_TRIM_LDS="0", **({"FAQCS_TRIM_TPR": "0"} if switch == "tpr_off" else {}))
@@ -863,6 +863,33 @@ def test_eight_rank_owner_tables_use_all_their_slots(tmp_path, monkeypatch):
     out = str(tmp_path / "result.txt")
     mp.spawn(_kmer_rank, args=(8, port, ["--kmer_rarefaction", "--split_size", "2500", "--subset", "5"], 15000, 577, out, 250, "gloo", "clean"), nprocs=8, join=True)
     assert open(out).read() == "ok", open(out).read()[:2000]
+
+
+def test_bench_kmer_memory_budget_dry_run():
+    """`bench.py --config kmer --dry-run-memory` prints a rank's HBM budget from faqcs_kmer_memory_plan (reads, table, group
+    buffers) before anything is allocated.  One rank at BASELINE configs[4]'s per-GPU share (25 M pairs, 2^31 slots) fits the device and
+    its pass is counted in one piece; eight such ranks SHARING the one GPU of this box do not fit, and the launcher says so and fails fast
+    instead of running out of memory half way."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "kmer", "--dry-run-memory"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    plan = json.loads(r.stdout.decode().strip().splitlines()[-1])["dry_run_memory"]
+    assert plan["fits"] and plan["pass_counted_in_one_piece"] and plan["kmer_table_GB"] > 30 and plan["sum_GB"] < plan["device_free_GB"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "kmer", "--gpus", "8", "--dry-run-memory"], env=dict(env, FAQCS_BENCH_SHARE_GPU="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0
+    errs = r.stderr.decode(errors="replace")
+    for k in range(8):
+        f = os.path.join(root, "gpurun_out", "rank%d.err" % k)
+        if os.path.exists(f):
+            errs += open(f, errors="replace").read()
+    assert "do not fit" in errs, errs[-2000:]
 
 
 @pytest.mark.parametrize("config", ["plain", "adapter", "kmer"])
