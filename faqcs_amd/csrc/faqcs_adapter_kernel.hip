@@ -33,6 +33,8 @@ struct AdapterDev {
     const uint32_t *wstart;  // [n_adapters + 1] word offsets into planes (in units of words)
     uint32_t n_adapters;
     float match_rate;        // float(1.0 - filterAdapterMismatchRate), trim.cpp:969
+    uint32_t longest;        // (host copies) bases of the longest adapter, dwords of `planes`: what picks the kernel variant
+    uint32_t plane_dwords;
 };
 
 // seq_overlap.cpp:372-411 na_to_bits() as a table over 'a'..'z' (case folded); 0 == the reference throws
@@ -65,6 +67,13 @@ __device__ __forceinline__ void lds_sync_wave()
 // pairs a plain C expression as and + and + or3, and it fenced every inline v_and_or_b32 of a dependent chain with an s_nop
 // (nine per plane word in the three-block variant).
 __device__ __forceinline__ uint32_t and_or_(uint32_t x, uint32_t y, uint32_t z) { return __builtin_amdgcn_bitop3_b32(x, y, z, 0xEA); }
+// b in the lanes whose bit of m is set (the upper half of the wave), else a: one v_cndmask_b32
+__device__ __forceinline__ uint32_t sel_half(const uint32_t a, const uint32_t b, const uint64_t m)
+{
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
 __device__ __forceinline__ uint32_t plane_match(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, const uint4 &t)
 {
     return and_or_(r3, t.w, and_or_(r2, t.z, and_or_(r1, t.y, r0 & t.x)));
@@ -753,11 +762,613 @@ __global__ __launch_bounds__(NW * 64, MAXLEN == 320 ? 3 : (MAXLEN == 256 ? FAQCS
         if (s_ast[i]) atomicAdd((unsigned long long *)&adapter_stats[i], (unsigned long long)s_ast[i]);
 }
 
+// =====================================================================================================================================
+// adapter_overlap_pair: TWO reads per wave for reads of up to 160 bases against adapters of up to 128 bases (round 6).
+//
+// adapter_overlap spends 430 scalar instructions per read next to its 585 vector ones (profiles/r5e/pmc_adapter.txt): the per-adapter
+// control -- unpacking the adapter's scalars, the LDS broadcast of its plane words and the wait for it, the wave votes and branches --
+// is paid per READ although it does not depend on the read.  Here the two halves of a wave own the diagonals of two reads: lanes 0 ... 31
+// read A, lanes 32 ... 63 read B, a block is 32 diagonals, and stage 1 -- the exact skip test, where nearly every read ends -- runs for both
+// reads in ONE instruction stream: the adapter's plane words are fetched once, the control runs once, and the vector work per read is
+// the same (a read's 150 + |adapter| - 1 diagonals fill six or seven blocks of 32 as they filled three or four of 64; the lane's windows
+// are 12 registers per plane for the pair instead of 10 per read).  What a read needs beyond stage 1 -- a few per cent of the reads --
+// is the code of adapter_overlap itself, run for one read at a time with the whole wave: stage 1 hands it the same facts (which
+// adapters match anywhere, which may reach their threshold, per-64-diagonal bounds of the best score), all of them sound bounds, so
+// every result is adapter_overlap's (trim.cpp:961-1142, seq_overlap.cpp:157-354; the quirks listed at the top of this file).
+// =====================================================================================================================================
+// counts of the lane's diagonal in NB blocks of 32 diagonals against NWC plane words: window index e = w - b + (NBR - 1)
+template <int NB, int NBR, int NWC>
+__device__ __forceinline__ void pair_counts(const uint32_t (&R)[4][NBR + 3], const uint32_t *tpl, uint32_t (&cnt)[NBR])
+{
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) cnt[b] = 0;
+#pragma unroll
+    for (int w = 0; w < NWC; ++w) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(tpl + 4 * w);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int e = w - b + (NBR - 1);
+            cnt[b] += __popc(plane_match(R[0][e], R[1][e], R[2][e], R[3][e], t));
+        }
+    }
+}
+template <int NB, int NBR>
+__device__ __forceinline__ uint32_t pair_first_word_max(const uint32_t (&R)[4][NBR + 3], const uint32_t *tpl)
+{
+    const uint4 t = *reinterpret_cast<const uint4 *>(tpl);
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int e = -b + (NBR - 1);
+        m = umax_(m, (uint32_t)__popc(plane_match(R[0][e], R[1][e], R[2][e], R[3][e], t)));
+    }
+    return m;
+}
+// the maximum over each half of the wave: lane 31 holds the one of lanes 0 ... 31, lane 63 the one of lanes 32 ... 63
+__device__ __forceinline__ uint32_t half_max_u32(uint32_t v)
+{
+    v = umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = umax_(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    return v;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void adapter_overlap_pair(
+    const AdapterDev A, const uint8_t *__restrict__ seq, const uint32_t *__restrict__ off, const uint32_t n_reads,
+    const uint32_t *__restrict__ seg_start, const uint32_t n_segments, uint32_t *__restrict__ ad_sl,
+    uint16_t *__restrict__ ad_hit, uint64_t *__restrict__ adapter_stats, uint32_t *__restrict__ err, const uint32_t dbg)
+{
+    constexpr int MAXLEN = 192;                // per-base arrays (reads of up to 160 bases; three 64-base pieces)
+    constexpr int QW = MAXLEN / 32, PADL = 12, PW = QW + 2 * PADL;
+    constexpr int TPL_CAP = 4096;
+    constexpr int NBR = 9;                     // blocks of 32 diagonals: 160 + 128 - 1 <= 288
+    constexpr int NCH = MAXLEN / 64;
+    __shared__ uint8_t s_q[NW][2][MAXLEN];
+    __shared__ uint8_t s_mask[NW][2][MAXLEN];
+    __shared__ uint32_t s_pl[NW][2][4][PW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tpl[TPL_CAP];
+    __shared__ uint8_t s_sb[NW][2][FAQCS_MAX_ADAPTERS][8]; // stage 1 -> stage 2: per 64-diagonal block, an upper bound of its best score
+    __shared__ uint32_t s_bb[NW][136];
+    __shared__ uint32_t s_ast[2 * FAQCS_MAX_ADAPTERS];
+    __shared__ uint8_t s_iupac[32];
+    __shared__ uint8_t s_na[256];
+    __shared__ uint32_t s_start[FAQCS_MAX_ADAPTERS + 1], s_wstart[FAQCS_MAX_ADAPTERS + 1];
+    __shared__ __attribute__((aligned(16))) uint4 s_meta[FAQCS_MAX_ADAPTERS];
+    __shared__ uint32_t s_pos[FAQCS_MAX_ADAPTERS];
+    __shared__ uint32_t s_ord[FAQCS_MAX_ADAPTERS + 8];
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int wave = uni(threadIdx.x >> 6);
+    uint32_t *plw = &s_pl[wave][0][0][0];
+    const uint32_t n_waves = gridDim.x * NW;
+
+    for (int i = lane; i < 2 * 4 * PW; i += 64) plw[i] = 0u; // pads stay zero for the whole kernel
+    for (uint32_t i = threadIdx.x; i <= A.n_adapters; i += NW * 64) { s_start[i] = A.start[i]; s_wstart[i] = A.wstart[i]; }
+    const uint32_t tpl_dwords = 4u * A.wstart[A.n_adapters];
+    for (uint32_t i = threadIdx.x; i < tpl_dwords; i += NW * 64) s_tpl[i] = A.planes[i]; // (the launcher has checked that they fit)
+    if (threadIdx.x < 32) s_iupac[threadIdx.x] = threadIdx.x < 26 ? k_iupac[threadIdx.x] : (uint8_t)0;
+    for (uint32_t i = threadIdx.x; i < 2 * FAQCS_MAX_ADAPTERS; i += NW * 64) s_ast[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < A.n_adapters; i += NW * 64) {
+        const uint32_t tl = A.start[i + 1] - A.start[i];
+        uint32_t amask = 0;
+        for (uint32_t w = A.wstart[i]; w < A.wstart[i + 1]; ++w)
+            for (uint32_t b = 0; b < 4; ++b) amask |= A.planes[4 * w + b] ? 1u << b : 0u;
+        s_meta[i] = make_uint4(tl, A.wstart[i], (uint32_t)(int)__fmul_rn(A.match_rate, (float)(int)tl), amask);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256; i += NW * 64) s_na[i] = (uint8_t)na_bits(i, s_iupac);
+    if (wave == 0) { // the class order: 1 ... 4 plane words (the launcher admits no other adapter here; an empty one cannot exist: faqcs_create)
+        const bool on = (uint32_t)lane < A.n_adapters;
+        const int tl = on ? (int)s_meta[on ? lane : 0].x : 0;
+        const int cls = !on ? 6 : (tl + 31) >> 5;
+        uint32_t base = 0;
+        for (int c = 1; c <= 4; ++c) {
+            const uint64_t m = __ballot(cls == c);
+            if (cls == c) { const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); s_ord[at] = (uint32_t)lane; s_pos[lane] = at; }
+            base += (uint32_t)__popcll(m);
+            if (lane == 0) s_ord[FAQCS_MAX_ADAPTERS + c] = base; // end of class c
+        }
+    }
+    __syncthreads();
+    int prev_qlen2[2] = {0, 0}; // longest span of plane words the previous read of either slot left behind
+    const bool prefilter_on = uni((int)((dbg & 8u) == 0u)) != 0;
+    const uint64_t m_all32 = (1ull << A.n_adapters) - 1ull; // (n_adapters <= 32)
+
+    const uint32_t total_chunks = (n_reads + 63u) >> 6;
+#pragma unroll 1
+    for (uint32_t chunk = blockIdx.x * NW + wave; chunk < total_chunks; chunk += n_waves) {
+      const uint32_t base = chunk << 6;
+      const uint32_t my = base + lane;
+      const bool mine = my < n_reads;
+      const uint32_t v_off = mine ? off[my] : 0u;
+      const uint32_t v_len = mine ? off[my + 1] - v_off : 0u;
+      uint32_t res_sl = 0, res_hit = 0;
+      uint32_t lo = 0, hi = n_segments; // segment s with seg_start[s] <= base < seg_start[s+1]
+      {
+          const uint32_t g = base / FAQCS_SEGMENT_READS;
+          if (g < n_segments && seg_start[g] <= base && base < seg_start[g + 1]) { lo = g; hi = g + 1; }
+      }
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= base) lo = mid; else hi = mid; }
+      uint32_t s0 = seg_start[lo], s1 = seg_start[lo + 1];
+      uint32_t nbyte[2][NCH]; // bases of the next pair, one byte per lane per 64-base piece
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+          const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)v_off, h);
+          const int l0 = __builtin_amdgcn_readlane((int)v_len, h);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) nbyte[h][c] = (c * 64 + lane < l0) ? (uint32_t)seq[(size_t)o0 + c * 64 + lane] : 0u;
+      }
+#pragma unroll 1
+      for (int t = 0; t < 64; t += 2) {
+        if (base + (uint32_t)t >= n_reads) break;
+        uint32_t cbyte[2][NCH];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) cbyte[h][c] = nbyte[h][c];
+        if (t + 2 < 64 && base + (uint32_t)t + 2u < n_reads) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)v_off, t + 2 + h);
+                const int l1 = __builtin_amdgcn_readlane((int)v_len, t + 2 + h); // (a lane past the batch holds length 0)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) nbyte[h][c] = (c * 64 + lane < l1) ? (uint32_t)seq[(size_t)o1 + c * 64 + lane] : 0u;
+            }
+        }
+        // ---- per read: its reference group of 8 (trim.cpp:977-1071, -t 1 semantics), its planes ----
+        int qlen2[2], len8_2[2];
+        bool tail2[2], bad2[2], there2[2];
+        uint32_t rmask2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t r = base + (uint32_t)(t + h);
+            there2[h] = r < n_reads;
+            qlen2[h] = there2[h] ? __builtin_amdgcn_readlane((int)v_len, t + h) : 0;
+            tail2[h] = true; len8_2[h] = 0;
+            if (there2[h]) {
+                while (r >= s1) { ++lo; s0 = s1; s1 = seg_start[lo + 1]; }   // (empty segments are skipped the same way)
+                const uint32_t g_last = s0 + (((r - s0) >> 3) << 3) + 7; // last slot of the group
+                tail2[h] = g_last >= s1;
+                if (!tail2[h]) len8_2[h] = (g_last - base < 64u) ? __builtin_amdgcn_readlane((int)v_len, (int)(g_last - base)) : (int)(off[g_last + 1] - off[g_last]);
+            }
+            // pack_query: bases -> the four bit-planes of slot h
+            uint32_t *pl = plw + h * (4 * PW);
+            bool badbase = false;
+            uint64_t pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0;
+            const int qlen = qlen2[h];
+            const int span = qlen > prev_qlen2[h] ? qlen : prev_qlen2[h];
+            prev_qlen2[h] = qlen;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c * 64 < span) {
+                    const int p = c * 64 + lane;
+                    const uint32_t bits = (uint32_t)s_na[cbyte[h][c]];
+                    badbase |= bits == 0u && p < qlen;
+                    uint32_t wv = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint64_t m = __ballot((bits >> b) & 1u);
+                        if (b == 0) pm0 |= m; else if (b == 1) pm1 |= m; else if (b == 2) pm2 |= m; else pm3 |= m;
+                        wv = lane == 2 * b ? (uint32_t)m : (lane == 2 * b + 1 ? (uint32_t)(m >> 32) : wv);
+                    }
+                    if (lane < 8) pl[(lane >> 1) * PW + PADL + 2 * c + (lane & 1)] = wv;
+                }
+            }
+            bad2[h] = __any(badbase);
+            rmask2[h] = (pm0 ? 1u : 0u) | (pm1 ? 2u : 0u) | (pm2 ? 4u : 0u) | (pm3 ? 8u : 0u);
+        }
+        lds_sync_wave();
+
+        // ---- stage 1 for both reads: lanes 0 ... 31 the diagonals of read A, lanes 32 ... 63 those of read B ----------------------------
+        uint64_t m_any2 = 0, m_pass2 = 0;
+        uint64_t m_bnd2[2] = {0, 0};
+        const bool live2[2] = {there2[0] && !bad2[0] && qlen2[0] > 0, there2[1] && !bad2[1] && qlen2[1] > 0};
+        if (live2[0] || live2[1]) {
+            const int qlen_v = half ? qlen2[1] : qlen2[0];
+            const bool live_v = half ? live2[1] : live2[0];
+            const int qmax = qlen2[0] > qlen2[1] ? qlen2[0] : qlen2[1];
+            uint32_t R[4][NBR + 3];
+            {
+                const int i00 = (qlen_v - 1) - l32;                          // read bit facing adapter base 0 on block 0's diagonal
+                const uint32_t sh = (uint32_t)i00 & 31u;
+                const uint32_t *pp = plw + half * (4 * PW) + (i00 >> 5) + PADL - (NBR - 1); // e = 0
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int e = 0; e < NBR + 3; ++e) R[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
+            }
+            // per-(read, adapter) scalars with lane = (half, adapter position): as in adapter_overlap (thr, need, need_cnt, coarse need)
+            uint32_t va = 0, vb = 0x7fffu | (0x7fffu << 16), vc = 0;
+            const uint32_t ja = (uint32_t)l32 < A.n_adapters ? s_ord[l32] : 0u;
+            if ((uint32_t)l32 < A.n_adapters) {
+                const uint4 me = s_meta[ja];
+                const int tl = (int)me.x;
+                const bool tail_v = half ? tail2[1] : tail2[0];
+                const int len8_v = half ? len8_2[1] : len8_2[0];
+                const int mm = tail_v ? tl : (len8_v < tl ? len8_v : tl);
+                const int th = mm == tl ? (int)me.z : (int)__fmul_rn(A.match_rate, (float)mm); // trim.cpp:1007-1008 / :1082
+                const int need = 2 * th - (qlen_v < tl ? qlen_v : tl);
+                const int need_cnt = need > th ? need : th;
+                const int coarse = need_cnt - (tl > 32 ? tl - 32 : 0);
+                va = (uint32_t)tl | (me.y << 14);
+                if (live_v) vb = (uint32_t)need_cnt | ((uint32_t)(coarse > 0 ? coarse : 0) << 16); // (a read that is not there can pass nothing: 0x7fff matches)
+                vc = (uint32_t)(need + 32768) | ((uint32_t)th << 16);
+            }
+            {
+                const uint32_t rm = half ? rmask2[1] : rmask2[0];
+                const bool share = (uint32_t)l32 < A.n_adapters && (s_meta[(uint32_t)l32 < A.n_adapters ? l32 : 0].w & rm) != 0u;
+                m_any2 = prefilter_on ? __ballot(share) : ~0ull;
+            }
+            const uint64_t hmask = 0xffffffff00000000ull;
+            uint32_t pass_v = 0;
+            auto one = [&](const uint32_t l, auto nw_tag) {
+                constexpr int NWC = decltype(nw_tag)::value;
+                const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)va, (int)l);
+                const uint32_t sbv = sel_half((uint32_t)__builtin_amdgcn_readlane((int)vb, (int)l), (uint32_t)__builtin_amdgcn_readlane((int)vb, (int)l + 32), hmask);
+                const int tlen = (int)(sa & 0x3fffu);
+                const uint32_t need_cnt_v = sbv & 0xffffu;
+                uint64_t may = ~0ull; // bit = a lane of the read's half reaches the read's need
+                if (prefilter_on) {
+                    const uint32_t *tpl = s_tpl + 4 * (sa >> 14);
+                    const int nb = (qmax + tlen - 1 + 31) >> 5;          // blocks past the last diagonal would only add zeros
+                    uint32_t cnt[NBR];
+                    uint32_t maxcnt = 0;
+                    auto count = [&](auto nb_tag) {
+                        constexpr int NB = decltype(nb_tag)::value;
+                        if (NWC == 2) { // coarse test on the first word, the full count only for what passes it
+                            maxcnt = pair_first_word_max<NB, NBR>(R, tpl);
+                            may = __ballot(maxcnt >= (sbv >> 16));
+                            if (may) {
+                                pair_counts<NB, NBR, 2>(R, tpl, cnt);
+                                maxcnt = 0;
+#pragma unroll
+                                for (int b = 0; b < NB; ++b) maxcnt = umax_(maxcnt, cnt[b]);
+                            }
+                        } else {
+                            pair_counts<NB, NBR, NWC>(R, tpl, cnt);
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) maxcnt = umax_(maxcnt, cnt[b]);
+                        }
+                    };
+                    if (nb <= 6) count(std::integral_constant<int, 6>{}); else if (nb <= 7) count(std::integral_constant<int, 7>{}); else count(std::integral_constant<int, NBR>{});
+                    if (may) may = __ballot(maxcnt >= need_cnt_v);
+                    if (may) { // rare: the per-block bounds for stage 2, and the second filter (the exact best score of the blocks that reach the count)
+                        const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)ja, (int)l);
+                        const uint32_t scv = sel_half((uint32_t)__builtin_amdgcn_readlane((int)vc, (int)l), (uint32_t)__builtin_amdgcn_readlane((int)vc, (int)l + 32), hmask);
+                        const int need_j_v = (int)(scv & 0xffffu) - 32768;
+                        pair_counts<NBR, NBR, NWC>(R, tpl, cnt); // (every block: the bounds must cover the longer read's last ones too)
+                        const int needc0 = __builtin_amdgcn_readlane((int)need_cnt_v, 0), needc1 = __builtin_amdgcn_readlane((int)need_cnt_v, 32);
+                        const int needj0 = __builtin_amdgcn_readlane(need_j_v, 0), needj1 = __builtin_amdgcn_readlane(need_j_v, 32);
+                        uint32_t bnd64[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+                        bool pass2[2] = {false, false};
+#pragma unroll
+                        for (int b = 0; b < NBR; ++b) {
+                            if (b < nb) {
+                                const uint32_t hm = half_max_u32(cnt[b]);
+                                uint32_t bh[2] = {(uint32_t)__builtin_amdgcn_readlane((int)hm, 31), (uint32_t)__builtin_amdgcn_readlane((int)hm, 63)};
+                                const bool d0 = (int)bh[0] >= needc0 && bh[0] > 0u, d1 = (int)bh[1] >= needc1 && bh[1] > 0u;
+                                if (d0 || d1) { // (wave-uniform) a score-only Kadane over the block's match bits: the exact best score of every diagonal
+                                    int M = -1, best = -1;
+#pragma unroll
+                                    for (int w = 0; w < NWC; ++w) {
+                                        const uint4 tw = *reinterpret_cast<const uint4 *>(tpl + 4 * w);
+                                        const int e = w - b + (NBR - 1);
+                                        const uint32_t bits = plane_match(R[0][e], R[1][e], R[2][e], R[3][e], tw);
+                                        const int kend = tlen - 32 * w < 32 ? tlen - 32 * w : 32;
+#pragma unroll 4
+                                        for (int kb = 0; kb < kend; ++kb) {
+                                            const int sc = (int)((bits >> kb) & 1u) * 2 - 1;
+                                            M = (M > 0 ? M : 0) + sc;
+                                            best = best > M ? best : M;
+                                        }
+                                    }
+                                    const uint32_t hb = half_max_u32((uint32_t)(best + 1));
+                                    const int bx[2] = {__builtin_amdgcn_readlane((int)hb, 31) - 1, __builtin_amdgcn_readlane((int)hb, 63) - 1};
+                                    if (d0) { bh[0] = bx[0] > 0 ? (uint32_t)bx[0] : 0u; pass2[0] = pass2[0] || bx[0] >= needj0; }
+                                    if (d1) { bh[1] = bx[1] > 0 ? (uint32_t)bx[1] : 0u; pass2[1] = pass2[1] || bx[1] >= needj1; }
+                                }
+                                bnd64[0][b >> 1] = umax_(bnd64[0][b >> 1], bh[0]);
+                                bnd64[1][b >> 1] = umax_(bnd64[1][b >> 1], bh[1]);
+                            }
+                        }
+                        if (lane == 0) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int B = 0; B < 5; ++B) s_sb[wave][h][j][B] = (uint8_t)(bnd64[h][B] > 255u ? 255u : bnd64[h][B]);
+                        }
+                        may = (pass2[0] ? ~hmask : 0ull) | (pass2[1] ? hmask : 0ull);
+                        if (pass2[0]) m_bnd2[0] |= 1ull << j;
+                        if (pass2[1]) m_bnd2[1] |= 1ull << j;
+                    }
+                }
+                const bool p0 = (may & ~hmask) != 0ull, p1 = (may & hmask) != 0ull;
+                pass_v = (((uint32_t)lane == l && p0) || ((uint32_t)lane == l + 32u && p1)) ? 1u : pass_v;
+            };
+            uint32_t l = 0;
+            const uint32_t e1 = uniu(s_ord[FAQCS_MAX_ADAPTERS + 1]), e2 = uniu(s_ord[FAQCS_MAX_ADAPTERS + 2]), e3 = uniu(s_ord[FAQCS_MAX_ADAPTERS + 3]);
+#pragma unroll 1
+            for (; l < e1; ++l) one(l, std::integral_constant<int, 1>{});
+#pragma unroll 1
+            for (; l < e2; ++l) one(l, std::integral_constant<int, 2>{});
+#pragma unroll 1
+            for (; l < e3; ++l) one(l, std::integral_constant<int, 3>{});
+#pragma unroll 1
+            for (; l < A.n_adapters; ++l) one(l, std::integral_constant<int, 4>{});
+            m_pass2 = __ballot(pass_v != 0u);
+        }
+
+        // ---- stage 2 + the reference's sequential state, one read at a time with the whole wave: adapter_overlap's code --------------
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            // (selects, not indexed arrays: with a run-time index the compiler keeps the arrays in scratch memory)
+            if (!(h ? there2[1] : there2[0])) break;
+            const int qlen = h ? qlen2[1] : qlen2[0];
+            const bool tail = h ? tail2[1] : tail2[0];
+            const int len8 = h ? len8_2[1] : len8_2[0];
+            const bool read_bad = h ? bad2[1] : bad2[0];
+            uint8_t *q = s_q[wave][h];
+            uint8_t *mk = s_mask[wave][h];
+            uint32_t *pl = plw + h * (4 * PW);
+            const uint64_t m_any = (m_any2 >> (32 * h)) & 0xffffffffull, m_pass = (m_pass2 >> (32 * h)) & 0xffffffffull, m_bnd = h ? m_bnd2[1] : m_bnd2[0];
+            uint8_t (*sb)[8] = s_sb[wave][h];
+
+            auto align_exact = [&](uint32_t j, int &gM, int &gS, int &gI) {
+                const uint32_t t0 = s_start[j];
+                const int tlen = (int)(s_start[j + 1] - t0);
+                gM = -1; gI = 0; gS = 0;
+                int gJ = 0;
+                const int ndiag = qlen + tlen - 1;
+                constexpr int NBX = 6, NAX = NBX + 1; // window blocks / accumulators of the sliding bound pass
+                uint32_t *bb = s_bb[wave];
+                int first_block = 0;
+                {
+                    uint32_t Rw[4][2 * NBX + 2];
+                    {
+                        const int i00 = (qlen - 1) - lane;
+                        const uint32_t sh = (uint32_t)i00 & 31u;
+                        const uint32_t *pp = pl + (i00 >> 5) + PADL - 2 * (NBX - 1);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+#pragma unroll
+                            for (int e = 0; e < 2 * NBX + 2; ++e) Rw[b][e] = __builtin_amdgcn_alignbit(pp[b * PW + e + 1], pp[b * PW + e], sh);
+                    }
+                    const uint32_t *tpl = s_tpl + 4 * s_wstart[j];
+                    const int nw = (tlen + 31) >> 5, nb = (ndiag + 63) >> 6;
+                    uint32_t cnt[NAX], best = 0;
+#pragma unroll
+                    for (int i = 0; i < NAX; ++i) cnt[i] = 0;
+#pragma unroll 1
+                    for (int u = 0; u <= nb; ++u) {
+                        uint4 ta = make_uint4(0u, 0u, 0u, 0u), tb = make_uint4(0u, 0u, 0u, 0u);
+                        if (2 * u < nw) ta = *reinterpret_cast<const uint4 *>(tpl + 8 * u);
+                        if (2 * u + 1 < nw) tb = *reinterpret_cast<const uint4 *>(tpl + 8 * u + 4);
+#pragma unroll
+                        for (int i = 0; i < NAX; ++i) {
+                            const int ea = 2 * NBX - 2 * i, eb = 2 * NBX + 1 - 2 * i;
+                            cnt[i] += __popc(plane_match(Rw[0][ea], Rw[1][ea], Rw[2][ea], Rw[3][ea], ta));
+                            cnt[i] += __popc(plane_match(Rw[0][eb], Rw[1][eb], Rw[2][eb], Rw[3][eb], tb));
+                        }
+                        if (u >= 1) { // block u-1 is complete
+                            const uint32_t bnd = wave_max_u32(cnt[0]);
+                            if (lane == 0) bb[u - 1] = bnd;
+                            if (bnd > best) { best = bnd; first_block = u - 1; }
+                        }
+#pragma unroll
+                        for (int i = 0; i + 1 < NAX; ++i) cnt[i] = cnt[i + 1];
+                        cnt[NAX - 1] = 0;
+                    }
+                    lds_sync_wave();
+                }
+                const int n_blocks = (ndiag + 63) >> 6;
+#pragma unroll 1
+                for (int k = 0; k < n_blocks + 1; ++k) {
+                    int blk = k - 1;
+                    if (k == 0) blk = first_block; else if (blk == first_block) continue;
+                    const int bnd = (int)bb[blk];
+                    if (bnd < 1 || bnd < gM) continue;
+                    const int dd0 = blk << 6;
+                    const int d = dd0 + lane - (qlen - 1);                   // j_t - i on this lane's diagonal
+                    const int dlo = dd0 - (qlen - 1), dhi = dlo + 63;
+                    const int jt_lo = dlo > 0 ? dlo : 0;
+                    const int jt_hi = (dhi + qlen - 1) < (tlen - 1) ? (dhi + qlen - 1) : (tlen - 1);
+                    int M = -1, st = 0, bM = -1, bS = 0, bI = 0;
+#pragma unroll 1
+                    for (int jt = jt_lo; jt <= jt_hi; ++jt) {
+                        const uint32_t tb = A.bits[t0 + jt];                 // uniform -> scalar load
+                        const int i = jt - d;
+                        const bool valid = (unsigned)i < (unsigned)qlen;
+                        const uint32_t qb = valid ? q[i] : 0u;
+                        const int s = (qb & tb) ? 1 : -1;                    // seq_overlap.cpp:157-161
+                        const int nS = (M < 0) ? i : st;                     // seq_overlap.cpp:255,272-275
+                        const int nM = (M > 0 ? M : 0) + s;                  // seq_overlap.cpp:185-188
+                        M = valid ? nM : -1;
+                        st = nS;
+                        const bool up = valid && nM >= 0 && nM >= bM;        // seq_overlap.cpp:338-354 (>=: later cell wins)
+                        bM = up ? nM : bM; bS = up ? nS : bS; bI = up ? i : bI;
+                    }
+                    const int Mx = (int)wave_max_u32((uint32_t)(bM + 1)) - 1;
+                    if (Mx >= 0) {
+                        const uint32_t key = (bM == Mx) ? ((((uint32_t)bI << 13) | (uint32_t)(bI + d)) + 1u) : 0u;
+                        const uint32_t K = wave_max_u32(key) - 1u;
+                        const int wi = (int)(K >> 13), wj = (int)(K & 8191u);
+                        const int wl = wj - wi + (qlen - 1) - dd0;           // lane that owns the winning diagonal
+                        const int ws = __builtin_amdgcn_readlane(bS, wl);
+                        const bool better = Mx > gM || (Mx == gM && (wi > gI || (wi == gI && wj > gJ)));
+                        if (better) { gM = Mx; gI = wi; gJ = wj; gS = ws; }
+                    }
+                }
+            };
+            auto align_bits = [&](uint32_t j, int &gM, int &gS, int &gI) {
+                const uint4 me = s_meta[j];
+                const int tlen = (int)me.x;
+                const uint32_t *tpl = s_tpl + 4 * me.y;
+                const int nw = (tlen + 31) >> 5;                              // <= 4
+                const int ndiag = qlen + tlen - 1, n_blocks = (ndiag + 63) >> 6; // <= 5
+                gM = -1; gI = 0; gS = 0;
+                int gJ = 0;
+                int first_block = 0, fb = -1;
+                for (int b = 0; b < n_blocks; ++b) { const int v = (int)sb[j][b]; if (v > fb) { fb = v; first_block = b; } }
+#pragma unroll 1
+                for (int k = 0; k <= n_blocks; ++k) {
+                    int blk = k - 1;
+                    if (k == 0) blk = first_block; else if (blk == first_block) continue;
+                    const int bnd = (int)sb[j][blk];
+                    if (bnd < 1 || bnd < gM) continue;                         // (a local alignment scores at most the matches on its diagonal)
+                    const int dd0 = blk << 6;
+                    const int d = dd0 + lane - (qlen - 1);                     // j_t - i on this lane's diagonal
+                    uint32_t mb[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        mb[w] = 0u;
+                        if (w < nw) {
+                            const int i0 = 32 * w - d;                         // read position facing adapter base 32 w
+                            int idx = i0 >> 5;
+                            idx = idx < -(PADL - 1) ? -(PADL - 1) : (idx > QW + PADL - 2 ? QW + PADL - 2 : idx);
+                            const uint32_t sh = (uint32_t)i0 & 31u;
+                            const uint32_t *pp = pl + idx + PADL;
+                            const uint4 tw = *reinterpret_cast<const uint4 *>(tpl + 4 * w);
+                            mb[w] = plane_match(__builtin_amdgcn_alignbit(pp[1], pp[0], sh), __builtin_amdgcn_alignbit(pp[PW + 1], pp[PW], sh),
+                                                __builtin_amdgcn_alignbit(pp[2 * PW + 1], pp[2 * PW], sh), __builtin_amdgcn_alignbit(pp[3 * PW + 1], pp[3 * PW], sh), tw);
+                        }
+                    }
+                    int M = -1, st = 0, bM = -1, bS = 0, bI = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        if (32 * w < tlen) {
+                            const int kend = tlen - 32 * w < 32 ? tlen - 32 * w : 32;
+                            const uint32_t bits = mb[w];
+#pragma unroll 2
+                            for (int kb = 0; kb < kend; ++kb) {
+                                const int i = 32 * w + kb - d;
+                                const bool valid = (unsigned)i < (unsigned)qlen;
+                                const int sc = ((bits >> kb) & 1u) ? 1 : -1;   // seq_overlap.cpp:157-161
+                                const int nS = (M < 0) ? i : st;               // seq_overlap.cpp:255,272-275
+                                const int nM = (M > 0 ? M : 0) + sc;           // seq_overlap.cpp:185-188
+                                M = valid ? nM : -1;
+                                st = nS;
+                                const bool up = valid && nM >= 0 && nM >= bM;  // seq_overlap.cpp:338-354 (>=: later cell wins)
+                                bM = up ? nM : bM; bS = up ? nS : bS; bI = up ? i : bI;
+                            }
+                        }
+                    }
+                    const int Mx = (int)wave_max_u32((uint32_t)(bM + 1)) - 1;
+                    if (Mx >= 0) {
+                        const uint32_t key = (bM == Mx) ? ((((uint32_t)bI << 13) | (uint32_t)(bI + d)) + 1u) : 0u;
+                        const uint32_t K = wave_max_u32(key) - 1u;
+                        const int wi = (int)(K >> 13), wj = (int)(K & 8191u);
+                        const int wl = wj - wi + (qlen - 1) - dd0;             // lane that owns the winning diagonal
+                        const int ws = __builtin_amdgcn_readlane(bS, wl);
+                        const bool better = Mx > gM || (Mx == gM && (wi > gI || (wi == gI && wj > gJ)));
+                        if (better) { gM = Mx; gI = wi; gJ = wj; gS = ws; }
+                    }
+                }
+            };
+
+            int best_score = 0, best_j = -1;
+            bool have = false, known = false;
+            uint32_t last_j = 0;
+            int rs = 0, re = 0;
+            // With every adapter matching somewhere and none able to reach its threshold (the bulk of the reads) nothing can happen.
+            if (!read_bad && qlen > 0 && !(m_pass == 0 && m_any == m_all32)) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int p = c * 64 + lane;
+                    if (p < qlen) { q[p] = s_na[h ? cbyte[1][c] : cbyte[0][c]]; mk[p] = 1; }
+                }
+                lds_sync_wave();
+#pragma unroll 1
+                for (uint32_t j = 0; j < A.n_adapters; ++j) {
+                    const int tlen = (int)(s_start[j + 1] - s_start[j]);
+                    const int m = tail ? tlen : (len8 < tlen ? len8 : tlen);
+                    const int thr = (int)__fmul_rn(A.match_rate, (float)m);      // trim.cpp:1007-1008 / :1082
+                    const bool any_match = (m_any >> j) & 1ull, may_pass = (m_pass >> uniu(s_pos[j])) & 1ull; // (m_any: bit = adapter; m_pass: bit = its position in the class order)
+                    int score = 0;
+                    if (any_match) {
+                        if (!may_pass) { have = true; known = false; last_j = j; continue; } // cannot mask, cannot be credited
+                        int gM, gS, gI;
+                        if ((m_bnd >> j) & 1ull) align_bits(j, gM, gS, gI); else align_exact(j, gM, gS, gI);
+                        if (gM >= 0) { have = true; known = true; last_j = j; rs = gS; re = gI; score = gM; }
+                        else if (!have) continue;                                // (only reachable with the prefilter disabled)
+                    } else {
+                        if (!have) continue;                                     // H2: unknown stale state -> no hit
+                        if (!known) { int gM, gS, gI; align_exact(last_j, gM, gS, gI); rs = gS; re = gI; known = true; }
+                    }
+                    const int match_length = re - rs + 1;
+                    const int num_match = (match_length + score) / 2;            // trim.cpp:1024-1025
+                    if (num_match >= thr) {
+                        for (int p = rs + lane; p <= re; p += 64) mk[p] = 0;     // trim.cpp:1032-1034
+                        if (score > best_score) { best_score = score; best_j = (int)j; }
+                    }
+                }
+            }
+
+            uint32_t first = 0, second = (uint32_t)qlen;
+            if (best_score > 0) {
+                lds_sync_wave();
+                // find_mask_range, trim.cpp:1144-1189, literal -- walked run by run (see adapter_overlap)
+                uint32_t longest_run_start = 0, longest_run_length = 0, run_start = 0, run_length = 0;
+                uint32_t pending = 0;
+                bool open = false;
+                uint64_t carry = 0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c * 64 < qlen) {
+                        const int p = c * 64 + lane;
+                        const uint64_t m = __ballot(p < qlen && mk[p] != 0);
+                        uint64_t tt = m ^ ((m << 1) | carry);
+                        carry = m >> 63;
+                        while (tt) {
+                            const uint32_t pos = (uint32_t)(c * 64) + (uint32_t)__builtin_ctzll(tt);
+                            tt &= tt - 1;
+                            if (!open) { if (run_length == 0) run_start = pos; pending = pos; open = true; }
+                            else {
+                                run_length += pos - pending; open = false;
+                                if (run_length > longest_run_length) { longest_run_length = run_length; longest_run_start = run_start; run_length = 0; }
+                            }
+                        }
+                    }
+                }
+                if (open) run_length += (uint32_t)qlen - pending;
+                if (run_length > longest_run_length) { longest_run_length = run_length; longest_run_start = run_start; }
+                first = longest_run_length ? longest_run_start : 0u;
+                second = longest_run_length;
+                if (lane == 0) { // trim.cpp:1061-1064
+                    atomicAdd(&s_ast[2 * best_j], 1u);
+                    atomicAdd(&s_ast[2 * best_j + 1], (uint32_t)qlen - second);
+                }
+            }
+            if (lane == t + h) { res_sl = first | (second << 16); res_hit = read_bad ? 0xffffu : (uint32_t)(best_score > 0 ? best_j + 1 : 0); }
+            if (read_bad && lane == 0) atomicOr(err, 2u);
+            lds_sync_wave();
+        }
+      }
+      if (mine) { ad_sl[my] = res_sl; ad_hit[my] = (uint16_t)res_hit; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 2 * A.n_adapters; i += NW * 64)
+        if (s_ast[i]) atomicAdd((unsigned long long *)&adapter_stats[i], (unsigned long long)s_ast[i]);
+}
+
 hipError_t faqcs_launch_adapter(const AdapterDev &A, const uint8_t *seq, const uint32_t *off, uint32_t n_reads,
                                 uint32_t max_len, const uint32_t *seg_start, uint32_t n_segments, uint32_t *ad_sl,
                                 uint16_t *ad_hit, uint64_t *adapter_stats, uint32_t *err, uint32_t dbg, int n_cu, hipStream_t st)
 {
     if (n_reads == 0) return hipSuccess;
+    // two reads per wave (round 6): reads of up to 160 bases, at most 32 adapters of at most 128 bases whose planes fit the LDS copy;
+    // FAQCS_ADAPTER_PAIR=0 keeps adapter_overlap for them (A/B)
+    static const bool pair_on = [] { const char *e = getenv("FAQCS_ADAPTER_PAIR"); return !e || atoi(e) != 0; }();
+    if (pair_on && max_len <= 160 && A.n_adapters <= 32 && A.longest <= 128 && A.plane_dwords <= 4096 && (dbg & 8u) == 0u) {
+        constexpr int NW = 4;
+        uint32_t grid = (n_reads + 64 * NW - 1) / (64 * NW);
+        const uint32_t cap = (uint32_t)n_cu * 8u;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL((adapter_overlap_pair<NW>), dim3(grid), dim3(NW * 64), 0, st, A, seq, off, n_reads, seg_start,
+                           n_segments, ad_sl, ad_hit, adapter_stats, err, dbg);
+        return hipGetLastError();
+    }
     if (max_len <= 256) {
         constexpr int NW = 4; // 4 waves/SIMD either way (123 VGPRs); A/B on MI355X: 4-wave blocks +2 % over 8-wave blocks
         uint32_t grid = (n_reads + NW - 1) / NW;

@@ -29,6 +29,7 @@ struct AdapterDev {
     const uint32_t *wstart;
     uint32_t n_adapters;
     float match_rate;
+    uint32_t longest, plane_dwords;
 };
 const char *faqcs_last_trim_kernel();
 bool faqcs_last_trim_folded();
@@ -97,6 +98,7 @@ struct faqcs_ctx {
     uint8_t *d_abits = nullptr;
     uint32_t *d_astart = nullptr, *d_aplanes = nullptr, *d_awstart = nullptr;
     float match_rate = 0.f;
+    uint32_t adapter_longest = 0, adapter_plane_dwords = 0;
     // staging for host submissions: two input slots so the H2D copy of batch k+1 overlaps the kernels of batch k
     struct Slot { DevBuf<uint8_t> seq, qual, tn; DevBuf<uint32_t> off; hipEvent_t done = nullptr; bool used = false; };
     Slot slot[2];
@@ -404,6 +406,8 @@ extern "C" int faqcs_create(const faqcs_params *p, int device_id, faqcs_ctx **ou
         }
         HIPCHK(upload(&c->d_abits, bits)); HIPCHK(upload(&c->d_astart, start));
         HIPCHK(upload(&c->d_aplanes, planes)); HIPCHK(upload(&c->d_awstart, wstart));
+        c->adapter_plane_dwords = (uint32_t)planes.size();
+        for (uint32_t j = 0; j < p->n_adapters; ++j) c->adapter_longest = std::max(c->adapter_longest, start[j + 1] - start[j]);
         c->match_rate = (float)(1.0 - (double)p->filterAdapterMismatchRate); // trim.cpp:969
     }
 
@@ -891,7 +895,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         HIPCHK(c->s_sl.reserve(n)); HIPCHK(c->s_hit.reserve(n)); HIPCHK(c->s_seg.reserve(n_seg + 1));
         d_sl = c->s_sl.p; d_hit = c->s_hit.p;
         HIPCHK(hipMemcpyAsync(c->s_seg.p, seg, (n_seg + 1) * 4, hipMemcpyHostToDevice, c->compute));
-        AdapterDev A{c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart, p.n_adapters, c->match_rate};
+        AdapterDev A{c->d_abits, c->d_astart, c->d_aplanes, c->d_awstart, p.n_adapters, c->match_rate, c->adapter_longest, c->adapter_plane_dwords};
         HIPCHK(faqcs_launch_adapter(A, d_seq, d_off, n, max_len, c->s_seg.p, n_seg, d_sl, d_hit,
                                     c->d_counters + c->lay.adapter_stats, c->d_err, c->dp.dbg, c->n_cu, c->compute));
     }
