@@ -44,7 +44,7 @@ def parse():
                     help="pairs per GPU resident in HBM (default: BASELINE's sizes -- 100 M for plain / adapter on one GPU (configs[1], [2]), "
                          "125 M per GPU for plain on 8 GPUs (configs[3]: 1 B pairs), 25 M per GPU for kmer (configs[4]: 200 M pairs on 8 GPUs))")
     ap.add_argument("--read-len", type=int, default=None, help="default 150 (250 for --config kmer)")
-    ap.add_argument("--config", choices=["plain", "adapter", "kmer"], default="plain",
+    ap.add_argument("--config", choices=["plain", "adapter", "kmer", "replaceN"], default="plain",
                     help="plain = BASELINE configs[1] (the headline), adapter = configs[2], kmer = configs[4]'s shape on one GPU")
     ap.add_argument("--batch-reads", type=int, default=1 << 25, help="reads per submission, clamped to what a < 4 GiB arena holds (u32 offsets): "
                     "28.6 M reads of 150 bases; fewer, larger launches = fewer seams between launches (2^24: -2.8 %% on the default line)")
@@ -369,6 +369,14 @@ def main():
                     others[cfg]["kmer"] = o2["kmer"]
             except SystemExit as e:
                 others[cfg] = {"error": str(e)}
+        try:  # --replace_to_N_q is the one option that falls off trim_lds (its G -> N edit needs base and quality of a position together): the cliff, in the line
+            o3, k3 = run_workload(env, a, "replaceN", 40e6, 2, 1, None, want_host_sample=False)
+            k3.clear()
+            others["replace_to_N_q"] = {"value": o3["value"], "unit": o3["unit"], "ms_per_step": o3["ms_per_step"], "workload": o3["config"]["workload"] + " --replace_to_N_q 20",
+                                        "pairs_per_gpu": o3["config"]["pairs_per_gpu"], "kernel": o3["roofline"]["kernel"], "frac": o3["roofline"]["frac"],
+                                        "relative_to_the_headline": round(o3["value"] / out["value"], 3)}
+        except SystemExit as e:
+            others["replace_to_N_q"] = {"error": str(e)}
         out["configs"] = others
     if rank == 0:
         real_stdout.write(json.dumps(out) + "\n")
@@ -449,7 +457,8 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
     L = read_len or (250 if config == "kmer" else 150)
     if not pairs:
         pairs = 25e6 if config == "kmer" else (125e6 if (config == "plain" and world == 8) else 100e6)
-    opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "400"]}.get(config, [])
+    opt_args = {"adapter": ["--adapter", "--polyA"], "kmer": ["--kmer_rarefaction", "--split_size", "1000000", "--subset", "400"],
+                "replaceN": ["--replace_to_N_q", "20"]}.get(config, [])  # replaceN: the one reference flag (trim.cpp:390-403) that leaves trim_lds for trim_filter_accumulate
     opt = parse_args(["-1", "r1", "-2", "r2", "-d", "out", "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + opt_args)
     R_eng = 256 if L <= 256 else (capi.FAST_READ_LENGTH if L <= capi.FAST_READ_LENGTH else capi.MAX_READ_LENGTH)
     kmer_plan = None

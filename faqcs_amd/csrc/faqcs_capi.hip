@@ -954,7 +954,7 @@ static int enqueue(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, co
         const uint64_t ib = (w == 1 ? occ : occ * 3 / (w + 1)) + 2ull * n + 64; // items this submission can be expected to make at most
         // staging: a sub-region per (bucket, writing block) of twice its even share; whatever does not fit spills (room for all of it)
         const uint32_t cap1 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(KG_MIN_CAP, 2 * ib / ((uint64_t)KG_FAN * KG_FAN) + 64), 0x7fffffffu);
-        const uint32_t spill_cap = (uint32_t)std::min<uint64_t>(ib, 0x7fffffffu);
+        const uint32_t spill_cap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(2 * ib, occ + 64), 0x7fffffffu); // (the true bound is one run per occurrence)
         if ((size_t)KG_FAN * KG_FAN * cap1 > ks.l1.cap || spill_cap > ks.spill.cap) HIPCHK(hipStreamSynchronize(c->compute));
         HIPCHK(ks.l1.reserve((size_t)KG_FAN * KG_FAN * cap1));
         HIPCHK(ks.spill.reserve(spill_cap));
@@ -1267,6 +1267,9 @@ extern "C" int faqcs_sync(faqcs_ctx *c)
     if (c->kt.stats) {
         unsigned long long st[3];
         HIPCHK(hipMemcpy(st, c->kt.stats, 24, hipMemcpyDeviceToHost));
+        // (bit 1: the sender staging of the multi-GPU exchange ran out of room for runs that did not fit their sub-regions -- an input whose minimizer changes
+        // at almost every position makes more runs than the staging is sized for; not a full table: ADVICE r5)
+        if (st[2] & 2ull) return fail(FAQCS_E_NOMEM, "faqcs: the k-mer exchange staging overflowed (more runs of k-mers per read than it is sized for): submit smaller batches");
         if (st[2]) return fail(FAQCS_E_KMER_FULL, "faqcs: device k-mer table is full (raise faqcs_params.kmer_table_slots)");
     }
     return 0;

@@ -33,7 +33,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -65,7 +67,7 @@ struct ParGzReader {
         bool final_seen = false;              // the member's last block ended inside
         size_t trailer_at = 0;                // byte offset of the member's trailer (final_seen)
         bool known_window = false;            // piece 0: inflated once, nothing to patch
-        Buf out, mark;                        // first / second output
+        Buf out, mark;                        // the text; (pieces with an unknown window) the 16-bit symbols of MarkerInflate, narrowed into `out` by patch()
         size_t n_out = 0;
         std::vector<uint8_t> win;             // the true 32 KB in front of the piece (set by the chain thread)
         uint32_t crc = 0;
@@ -87,6 +89,7 @@ struct ParGzReader {
     size_t rearm_min = 8u << 20; // a following member starts the parallel reader again when at least this much of the file is left
     int n_workers = 1;
     size_t piece_arg = 0;
+    bool two_pass = [] { const char *e = getenv("FAQCS_MI_PARGZ_TWO_PASS"); return e && atoi(e) != 0; }(); // round 5's two zlib passes per piece (A/B; needs ASCII text)
     std::atomic<size_t> cancel_from{~(size_t)0}; // pieces from this index on start behind the member's trailer: their workers give up
     // consumer state
     size_t cur = 0;              // piece to hand out next
@@ -202,6 +205,224 @@ struct ParGzReader {
     static const uint8_t *dict1() { static uint8_t d[WIN]; static bool init = [] { for (size_t k = 0; k < WIN; ++k) d[k] = (uint8_t)(k & 255); return true; }(); (void)init; return d; }
     static const uint8_t *dict2() { static uint8_t d[WIN]; static bool init = [] { for (size_t k = 0; k < WIN; ++k) d[k] = (uint8_t)(128 | (k >> 8)); return true; }(); (void)init; return d; }
 
+    // ---- a raw inflate of 16-bit SYMBOLS that starts at a bit position without knowing the 32 KB in front of it (round 6) ------------
+    // A symbol below 256 is a byte of the text; a symbol 0x8000 | k is "the byte at offset k of the unknown window" (k = 32 767: the
+    // byte right in front of the piece).  A back-reference that reaches in front of the piece writes such markers, one that copies
+    // them copies them on: ONE pass over the compressed bits where the two-dictionary scheme of round 5 made two zlib passes, and the
+    // markers are out of band, so the text need not be ASCII.  Own Huffman decoder (zlib has no 16-bit output): an 11-bit first-level
+    // table for literals / lengths, 8 bits for distances, second-level tables behind the longer codes; the bit buffer is refilled to
+    // >= 56 bits, which a length code + extra + distance code + extra (<= 48 bits) never exhausts.
+    struct MarkerInflate {
+        enum { LIT_BITS = 11, DIST_BITS = 8, T_LIT = 0, T_LEN = 1, T_EOB = 2, T_SUB = 3, T_BAD = 4 };
+        // entry: bits 0-4 code bits to consume at this level | bits 5-7 type | bits 8-15 extra bits | bits 16-31 payload (literal / base / subtable start)
+        uint32_t lit[(1 << LIT_BITS) + 288 * 16], dist[(1 << DIST_BITS) + 30 * 128]; // (second-level tables of 2^(longest code - first level) entries: at most one per symbol)
+        uint8_t lit_sub_bits = 0, dist_sub_bits = 0;
+        const uint8_t *in = nullptr, *in_end = nullptr;
+        uint64_t bitbuf = 0; unsigned bitcnt = 0;
+        size_t in_over = 0; // zero bytes "read" past the end of the input (an error as soon as their bits are needed: checked at block ends)
+        bool final_block = false, error = false;
+
+        void begin(const uint8_t *base, size_t size, uint64_t bit)
+        {
+            in = base + (bit >> 3); in_end = base + size; bitbuf = 0; bitcnt = 0; in_over = 0; final_block = false; error = false;
+            refill();
+            const unsigned k = (unsigned)(bit & 7);
+            bitbuf >>= k; bitcnt -= k;
+        }
+        inline void refill()
+        {
+            if (in + 8 <= in_end) {
+                uint64_t v; memcpy(&v, in, 8);
+                bitbuf |= v << bitcnt;
+                in += (63 - bitcnt) >> 3;
+                bitcnt |= 56;
+            } else {
+                while (bitcnt <= 56) {
+                    if (in < in_end) bitbuf |= (uint64_t)*in++ << bitcnt; else ++in_over;
+                    bitcnt += 8;
+                }
+            }
+        }
+        // bit position (in the file) of the next bit to be consumed
+        uint64_t bit_pos(const uint8_t *base) const { return (uint64_t)(in - base) * 8 + (uint64_t)in_over * 8 - bitcnt; }
+        inline uint32_t take(unsigned n) { const uint32_t v = (uint32_t)(bitbuf & ((1ull << n) - 1)); bitbuf >>= n; bitcnt -= n; return v; }
+
+        static unsigned rev(unsigned code, unsigned len) { unsigned r = 0; for (unsigned b = 0; b < len; ++b) r |= ((code >> b) & 1u) << (len - 1 - b); return r; }
+        // canonical Huffman code of lens[0 .. n) -> a two-level table; sym_entry(s) gives the entry of symbol s without its length field
+        template <class F>
+        static bool build(const uint8_t *lens, unsigned n, unsigned first_bits, uint32_t *tab, unsigned tab_cap, uint8_t &sub_bits_out, F &&sym_entry)
+        {
+            unsigned count[16] = {0}, maxlen = 0;
+            for (unsigned i = 0; i < n; ++i) { ++count[lens[i]]; if (lens[i] > maxlen) maxlen = lens[i]; }
+            count[0] = 0;
+            // over-subscribed sets are an error; incomplete ones decode to T_BAD where no code is assigned
+            { long left = 1; for (unsigned l = 1; l <= 15; ++l) { left = left * 2 - (long)count[l]; if (left < 0) return false; } }
+            unsigned next[16]; { unsigned code = 0; for (unsigned l = 1; l <= 15; ++l) { code = (code + count[l - 1]) << 1; next[l] = code; } }
+            const unsigned P = 1u << first_bits;
+            for (unsigned i = 0; i < P; ++i) tab[i] = (uint32_t)T_BAD << 5 | 1u;
+            const unsigned sub_bits = maxlen > first_bits ? maxlen - first_bits : 0;
+            sub_bits_out = (uint8_t)sub_bits;
+            unsigned used = P;
+            for (unsigned s = 0; s < n; ++s) {
+                const unsigned l = lens[s];
+                if (!l) continue;
+                const unsigned r = rev(next[l]++, l);
+                const uint32_t e = sym_entry(s);
+                if (l <= first_bits) {
+                    for (unsigned i = r; i < P; i += 1u << l) tab[i] = e | l;
+                } else {
+                    const unsigned pre = r & (P - 1);
+                    if (((tab[pre] >> 5) & 7u) != (unsigned)T_SUB) { // a new second-level table behind this prefix
+                        if (used + (1u << sub_bits) > tab_cap) return false;
+                        tab[pre] = ((uint32_t)used << 16) | ((uint32_t)T_SUB << 5) | first_bits;
+                        for (unsigned i = 0; i < (1u << sub_bits); ++i) tab[used + i] = (uint32_t)T_BAD << 5 | 1u;
+                        used += 1u << sub_bits;
+                    }
+                    const unsigned start = tab[pre] >> 16, rest = l - first_bits;
+                    for (unsigned i = r >> first_bits; i < (1u << sub_bits); i += 1u << rest) tab[start + i] = e | rest;
+                }
+            }
+            return true;
+        }
+        bool build_tables(const uint8_t *ll, unsigned nl, const uint8_t *dl, unsigned nd)
+        {
+            static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+            static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+            static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+            static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+            if (!build(ll, nl, LIT_BITS, lit, sizeof lit / 4, lit_sub_bits, [&](unsigned s) -> uint32_t {
+                    if (s < 256) return (s << 16) | ((uint32_t)T_LIT << 5);
+                    if (s == 256) return (uint32_t)T_EOB << 5;
+                    if (s > 285) return (uint32_t)T_BAD << 5;
+                    return ((uint32_t)lbase[s - 257] << 16) | ((uint32_t)lext[s - 257] << 8) | ((uint32_t)T_LEN << 5);
+                })) return false;
+            return build(dl, nd, DIST_BITS, dist, sizeof dist / 4, dist_sub_bits, [&](unsigned s) -> uint32_t {
+                if (s > 29) return (uint32_t)T_BAD << 5;
+                return ((uint32_t)dbase[s] << 16) | ((uint32_t)dext[s] << 8) | ((uint32_t)T_LEN << 5);
+            });
+        }
+        // the header of the next block; false: invalid.  stored blocks are copied here (their length is returned through n_stored)
+        int block_type = -1; uint32_t stored_left = 0;
+        bool read_header()
+        {
+            refill();
+            final_block = take(1) != 0;
+            block_type = (int)take(2);
+            if (block_type == 0) {
+                take(bitcnt & 7); // to the byte boundary
+                refill();
+                const uint32_t len = take(16), nlen = take(16);
+                if ((len ^ nlen) != 0xffffu) return false;
+                stored_left = len;
+                return true;
+            }
+            uint8_t ll[288 + 32], dl[32];
+            if (block_type == 1) {
+                for (unsigned i = 0; i < 144; ++i) ll[i] = 8;
+                for (unsigned i = 144; i < 256; ++i) ll[i] = 9;
+                for (unsigned i = 256; i < 280; ++i) ll[i] = 7;
+                for (unsigned i = 280; i < 288; ++i) ll[i] = 8;
+                for (unsigned i = 0; i < 30; ++i) dl[i] = 5;
+                return build_tables(ll, 288, dl, 30);
+            }
+            if (block_type != 2) return false;
+            const unsigned hlit = take(5) + 257, hdist = take(5) + 1, hclen = take(4) + 4;
+            if (hlit > 286 || hdist > 30) return false;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t pl[19]; memset(pl, 0, sizeof pl);
+            refill();
+            for (unsigned i = 0; i < hclen; ++i) { if (bitcnt < 3) refill(); pl[order[i]] = (uint8_t)take(3); }
+            uint32_t pre[128 + 64]; uint8_t pre_sub = 0;
+            if (!build(pl, 19, 7, pre, sizeof pre / 4, pre_sub, [&](unsigned s) -> uint32_t { return (s << 16) | ((uint32_t)T_LIT << 5); })) return false;
+            uint8_t lens[286 + 30 + 140];
+            unsigned n = 0; const unsigned total = hlit + hdist;
+            while (n < total) {
+                refill();
+                if (in_over > 8) return false;
+                const uint32_t e = pre[bitbuf & 127];
+                if (((e >> 5) & 7u) != (unsigned)T_LIT) return false;
+                take(e & 31u);
+                const unsigned sym = e >> 16;
+                if (sym < 16) { lens[n++] = (uint8_t)sym; continue; }
+                unsigned rep, val = 0;
+                if (sym == 16) { if (!n) return false; rep = 3 + take(2); val = lens[n - 1]; }
+                else if (sym == 17) rep = 3 + take(3);
+                else rep = 11 + take(7);
+                if (n + rep > total) return false;
+                while (rep--) lens[n++] = (uint8_t)val;
+            }
+            if (lens[256] == 0) return false; // no end-of-block code
+            return build_tables(lens, hlit, lens + hlit, hdist);
+        }
+        // One whole block into out[0 ..) from position pos on (out grows through `grow`, which returns the new base).  window_known == false:
+        // positions in front of 0 are the unknown window (markers); true is not used here (the first piece goes through zlib).
+        // Returns false on invalid data.
+        template <class Grow>
+        bool decode_block(uint16_t *&out, size_t &pos, size_t &cap, Grow &&grow)
+        {
+            if (!read_header()) return false;
+            if (block_type == 0) {
+                // the bytes of a stored block: what is left in the bit buffer first (whole bytes), then straight from the input
+                while (stored_left) {
+                    if (pos + 1 > cap) { out = grow(pos + stored_left + 1); }
+                    if (bitcnt >= 8) { out[pos++] = (uint16_t)take(8); --stored_left; continue; }
+                    bitbuf = 0; bitcnt = 0; // (byte aligned and drained: what the last refill loaded beyond bitcnt is read again from `in`)
+                    if (in >= in_end) return false;
+                    out[pos++] = *in++; --stored_left;
+                }
+                if (bitcnt < 8) { bitbuf = 0; bitcnt = 0; }
+                return in_over == 0;
+            }
+            const uint32_t lmask = (1u << LIT_BITS) - 1, dmask = (1u << DIST_BITS) - 1;
+            for (;;) {
+                if (pos + 320 > cap) out = grow(pos + 320);
+                refill();
+                if (in_over > 8) return false; // (the input ends inside the block: the zeros behind it must not be decoded on and on)
+                uint32_t e = lit[bitbuf & lmask];
+                if (((e >> 5) & 7u) == (unsigned)T_SUB) { take(LIT_BITS); e = lit[(e >> 16) + (bitbuf & ((1u << lit_sub_bits) - 1))]; }
+                unsigned type = (e >> 5) & 7u;
+                if (type == (unsigned)T_LIT) {
+                    take(e & 31u);
+                    out[pos++] = (uint16_t)(e >> 16);
+                    // (two more literals without a refill: 3 x 15 bits <= 56)
+                    e = lit[bitbuf & lmask];
+                    if (((e >> 5) & 7u) == (unsigned)T_LIT && bitcnt >= 30) {
+                        take(e & 31u);
+                        out[pos++] = (uint16_t)(e >> 16);
+                        e = lit[bitbuf & lmask];
+                        if (((e >> 5) & 7u) == (unsigned)T_LIT) { take(e & 31u); out[pos++] = (uint16_t)(e >> 16); }
+                    }
+                    continue;
+                }
+                if (type == (unsigned)T_EOB) { take(e & 31u); break; }
+                if (type != (unsigned)T_LEN) return false;
+                take(e & 31u);
+                const unsigned len = (e >> 16) + take((e >> 8) & 255u);
+                uint32_t d = dist[bitbuf & dmask];
+                if (((d >> 5) & 7u) == (unsigned)T_SUB) { take(DIST_BITS); d = dist[(d >> 16) + (bitbuf & ((1u << dist_sub_bits) - 1))]; }
+                if (((d >> 5) & 7u) != (unsigned)T_LEN) return false;
+                take(d & 31u);
+                const size_t dd = (size_t)(d >> 16) + take((d >> 8) & 255u);
+                if (dd > pos + WIN) return false; // further back than the window in front of the piece
+                size_t i = 0;
+                if (dd > pos) { // (the part of the copy that lies in front of the piece: markers)
+                    const size_t before = dd - pos; // source positions -before .. -1
+                    const size_t nmark = before < len ? before : len;
+                    for (; i < nmark; ++i) out[pos + i] = (uint16_t)(0x8000u | (uint32_t)(WIN - before + i));
+                }
+                if (dd >= 8 && i == 0) { // the common case: sixteen bytes (eight symbols) a step, past the end of the match if need be (there is room for 320 symbols)
+                    const uint16_t *sp = out + pos - dd;
+                    uint16_t *dp = out + pos;
+                    for (size_t k = 0; k < len; k += 8) memcpy(dp + k, sp + k, 16);
+                } else if (dd >= len) { if (i < len) memcpy(out + pos + i, out + pos + i - dd, (len - i) * 2); }
+                else for (; i < len; ++i) out[pos + i] = out[pos + i - dd];
+                pos += len;
+            }
+            return in_over * 8 <= bitcnt; // (the bits of bytes that are not there have not been consumed)
+        }
+    };
+
+
     // ---- file ----
     static bool eligible(const std::string &path, size_t min_size = 8u << 20)
     {
@@ -263,7 +484,7 @@ struct ParGzReader {
         inflate_piece(0);
         cv_done.notify_all();
         bool ok = pieces[0].state.load() == 2;
-        for (size_t i = 0; ok && i < pieces[0].n_out; ++i) if (pieces[0].out[i] >= 128) ok = false; // not ASCII: the markers would be ambiguous
+        if (two_pass) for (size_t i = 0; ok && i < pieces[0].n_out; ++i) if (pieces[0].out[i] >= 128) ok = false; // (two-pass scheme: not ASCII, the markers would be ambiguous)
         if (!ok) disarm();
         return ok;
     }
@@ -347,17 +568,63 @@ struct ParGzReader {
         return rc == Z_OK || rc == Z_STREAM_END || (rc == Z_BUF_ERROR && f.z.avail_out == 0);
     }
     // Inflates piece i from its start to the first block boundary that is the start of a later piece (or to the end of the member).
+    // `here` = the bit position of a block boundary: later pieces whose start lies at or before it are looked at; true: one starts exactly here
+    bool stops_at(Piece &p, size_t &j, uint64_t here, bool &abort)
+    {
+        abort = false;
+        while (j < n_pieces && range_begin_bit(j) <= here) {
+            uint64_t s;
+            { // wait for piece j's worker to publish its start (pieces past the claim window have none yet: go on through them)
+                std::unique_lock<std::mutex> l(m);
+                while (!closing && pieces[j].start_bit.load() == 0 && pieces[j].state.load() != 0) cv_done.wait(l);
+                if (closing) { p.state.store(3); abort = true; return false; }
+                s = pieces[j].state.load() == 0 ? NO_START : pieces[j].start_bit.load();
+                if (pieces[j].state.load() == 0) { if (next_claim == j) ++next_claim; pieces[j].state.store(3); pieces[j].start_bit.store(NO_START); } // nobody will start it: this piece runs through it
+            }
+            if (s == here) return true;
+            if (s == NO_START || s < here) { ++j; continue; } // no start there, or one this chain never arrived at: dropped
+            break;                                             // its start lies ahead
+        }
+        return false;
+    }
     void inflate_piece(size_t i)
     {
         Piece &p = pieces[i];
         const uint64_t start = p.start_bit.load();
-        Inflater f;
         auto fail = [&] { std::lock_guard<std::mutex> l(m); p.state.store(3); };
+        p.n_out = 0; p.final_seen = false;
+        size_t j = i + 1; // the first later piece whose start this one has not passed yet
+        if (!p.known_window && !two_pass) { // ONE pass that writes 16-bit symbols (round 6)
+            std::unique_ptr<MarkerInflate> mi(new MarkerInflate);
+            mi->begin(base, size, start);
+            if (!p.mark.p) p.mark = take_buf();
+            p.mark.resize(std::max<size_t>(p.mark.size(), (piece_bytes * 4 + (1u << 20)) * 2));
+            uint16_t *sym = reinterpret_cast<uint16_t *>(p.mark.data());
+            size_t cap = p.mark.size() / 2, pos = 0;
+            auto grow = [&](size_t need) { size_t nc = cap + cap / 2; if (nc < need) nc = need; p.mark.resize(nc * 2); cap = p.mark.size() / 2; return reinterpret_cast<uint16_t *>(p.mark.data()); };
+            for (;;) {
+                if (i >= cancel_from.load(std::memory_order_relaxed)) { fail(); return; } // (a start found inside a FOLLOWING member would run on to its end)
+                if (!mi->decode_block(sym, pos, cap, grow)) { fail(); return; }
+                p.n_out = pos;
+                if (mi->final_block) {
+                    const uint64_t end = mi->bit_pos(base);
+                    p.final_seen = true; p.trailer_at = (size_t)((end + 7) >> 3); p.next_piece = n_pieces;
+                    p.end_bit = (uint64_t)p.trailer_at * 8;
+                    break;
+                }
+                const uint64_t here = mi->bit_pos(base);
+                bool abort = false;
+                if (stops_at(p, j, here, abort)) { p.end_bit = here; p.next_piece = j; break; }
+                if (abort) return;
+            }
+            std::lock_guard<std::mutex> l(m);
+            p.state.store(2);
+            return;
+        }
+        Inflater f;
         if (!f.begin(base, size, start, p.known_window ? nullptr : dict1())) { fail(); return; }
         if (!p.out.p) p.out = take_buf();
         p.out.resize(std::max<size_t>(p.out.size(), piece_bytes * 4 + (1u << 20)));
-        p.n_out = 0; p.final_seen = false;
-        size_t j = i + 1; // the first later piece whose start this one has not passed yet
         for (;;) {
             if (i >= cancel_from.load(std::memory_order_relaxed)) { fail(); return; } // (a start found inside a FOLLOWING member would run on to its end)
             if (p.n_out + (1u << 16) > p.out.size()) p.out.resize(p.out.size() + p.out.size() / 2);
@@ -375,24 +642,11 @@ struct ParGzReader {
             if (rc != Z_OK) { fail(); return; } // a data error, or Z_BUF_ERROR: there is always room for output, so the file ends inside the member
             if (!(f.z.data_type & 128)) continue; // not at a block boundary (output space ran out)
             const uint64_t here = (uint64_t)(f.z.next_in - base) * 8 - (uint64_t)(f.z.data_type & 63);
-            // later pieces whose start lies at or before `here`: the one that starts exactly here ends this piece
-            bool stop = false;
-            while (j < n_pieces && range_begin_bit(j) <= here) {
-                uint64_t s;
-                { // wait for piece j's worker to publish its start (pieces past the claim window have none yet: go on through them)
-                    std::unique_lock<std::mutex> l(m);
-                    while (!closing && pieces[j].start_bit.load() == 0 && pieces[j].state.load() != 0) cv_done.wait(l);
-                    if (closing) { p.state.store(3); return; }
-                    s = pieces[j].state.load() == 0 ? NO_START : pieces[j].start_bit.load();
-                    if (pieces[j].state.load() == 0) { if (next_claim == j) ++next_claim; pieces[j].state.store(3); pieces[j].start_bit.store(NO_START); } // nobody will start it: this piece runs through it
-                }
-                if (s == here) { stop = true; break; }
-                if (s == NO_START || s < here) { ++j; continue; } // no start there, or one this chain never arrived at: dropped
-                break;                                             // its start lies ahead
-            }
-            if (stop) { p.end_bit = here; p.next_piece = j; break; }
+            bool abort = false;
+            if (stops_at(p, j, here, abort)) { p.end_bit = here; p.next_piece = j; break; }
+            if (abort) return;
         }
-        if (!p.known_window) { // the same range again with the second dictionary: n_out bytes
+        if (!p.known_window) { // (FAQCS_MI_PARGZ_TWO_PASS=1: round 5's scheme) the same range again with the second dictionary: n_out bytes
             Inflater g;
             if (!g.begin(base, size, start, dict2())) { fail(); return; }
             if (!p.mark.p) p.mark = take_buf();
@@ -416,8 +670,17 @@ struct ParGzReader {
     }
 
     // out[k] of the bytes [lo, hi) that came from the window in front of the piece: the marker (mark[k] & 128) carries the window offset
-    static void patch(Piece &p, size_t lo, size_t hi)
+    void patch(Piece &p, size_t lo, size_t hi)
     {
+        if (!two_pass) { // the symbols become the text: a byte as it is, a marker through the window (lo == 0, hi == n_out: whole pieces only)
+            if (!p.out.p) p.out = take_buf();
+            p.out.resize(p.n_out + 1);
+            const uint16_t *sym = reinterpret_cast<const uint16_t *>(p.mark.data());
+            const uint8_t *w = p.win.data();
+            uint8_t *o = p.out.data();
+            for (size_t k = lo; k < hi; ++k) { const uint16_t v = sym[k]; o[k] = v < 256 ? (uint8_t)v : w[v & 0x7fffu]; }
+            return;
+        }
         const uint8_t *w = p.win.data();
         uint8_t *o = p.out.data();
         const uint8_t *mk = p.mark.data();
@@ -446,6 +709,10 @@ struct ParGzReader {
             if (!p.known_window) p.win = W;
             // the window behind the piece
             const size_t t = std::min(p.n_out, WIN), from = p.n_out - t;
+            if (!p.known_window && !two_pass) {
+                const uint16_t *sym = reinterpret_cast<const uint16_t *>(p.mark.data());
+                for (size_t k = 0; k < t; ++k) { const uint16_t v = sym[from + k]; tail[k] = v < 256 ? (uint8_t)v : W[v & 0x7fffu]; }
+            } else
             for (size_t k = 0; k < t; ++k) {
                 const uint8_t b = p.out[from + k];
                 tail[k] = (!p.known_window && (p.mark[from + k] & 128)) ? W[(size_t)b | ((size_t)(p.mark[from + k] & 127) << 8)] : b;

@@ -267,12 +267,14 @@ def test_parallel_inflate_equals_zlib(level, tmp_path):
     for threads, piece in ((4, 300000), (3, 70001), (8, 1 << 20), (2, 20000)):
         rc, out = _pargz(p, threads, piece)
         assert rc == 0 and out == text, "level %d threads %d piece %d: rc %d, %d bytes" % (level, threads, piece, rc, len(out))
+    # round 5's scheme (two zlib passes per piece with offset-encoding dictionaries) is still there for A/B runs
+    r = subprocess.run([CLI, "--pargz_cat", str(p), "4", "300000"], capture_output=True, timeout=300, env=dict(os.environ, FAQCS_MI_PARGZ_TWO_PASS="1"))
+    assert r.returncode == 0 and r.stdout == text
 
 
 def test_parallel_inflate_on_odd_files(tmp_path):
     """Stored blocks only (level 0: no dynamic block to find), concatenated members (the first in parallel, the rest through zlib's gzip decoder, as
-    gzread reads on), trailing garbage (ends the data, as in zlib), a header with a file name, an empty member, a file that is not ASCII
-    (refused: the markers would be ambiguous -- the caller stays on gzread)."""
+    gzread reads on), trailing garbage (ends the data, as in zlib), a header with a file name, an empty member, a file that is not ASCII."""
     import gzip
     import io
 
@@ -291,10 +293,15 @@ def test_parallel_inflate_on_odd_files(tmp_path):
         p.write_bytes(blob)
         rc, out = _pargz(p, 4, 150000)
         assert rc == 0 and out == want, "%s: rc %d, %d bytes (want %d)" % (name, rc, len(out), len(want))
+    # text that is not ASCII: the 16-bit symbols of round 6 keep markers out of band, so it inflates like any other file (round 5's
+    # two-dictionary scheme checked the first piece only and took a later byte >= 128 for a marker); that scheme itself still refuses it
     p = tmp_path / "binary.gz"
-    p.write_bytes(gzip.compress(bytes(range(256)) * 4000, 6))
+    data = (bytes(range(256)) * 997 + text[:70000]) * 4
+    p.write_bytes(gzip.compress(data, 6))
     rc, out = _pargz(p, 4, 150000)
-    assert rc == 4 and out == b""
+    assert rc == 0 and out == data
+    r = subprocess.run([CLI, "--pargz_cat", str(p), "4", "150000"], capture_output=True, timeout=300, env=dict(os.environ, FAQCS_MI_PARGZ_TWO_PASS="1"))
+    assert r.returncode == 4 and r.stdout == b""
 
 
 def test_parallel_inflate_of_concatenated_members(tmp_path):
