@@ -379,21 +379,20 @@ struct ParGzReader {
                 refill();
                 if (in_over > 8) return false; // (the input ends inside the block: the zeros behind it must not be decoded on and on)
                 uint32_t e = lit[bitbuf & lmask];
-                if (((e >> 5) & 7u) == (unsigned)T_SUB) { take(LIT_BITS); e = lit[(e >> 16) + (bitbuf & ((1u << lit_sub_bits) - 1))]; }
-                unsigned type = (e >> 5) & 7u;
-                if (type == (unsigned)T_LIT) {
-                    take(e & 31u);
-                    out[pos++] = (uint16_t)(e >> 16);
-                    // (two more literals without a refill: 3 x 15 bits <= 56)
+                // up to three literals per refill (3 x 15 bits <= 56); the entry that ends the run is decoded below without a second look-up
+                if (((e >> 5) & 7u) == (unsigned)T_LIT) {
+                    take(e & 31u); out[pos++] = (uint16_t)(e >> 16);
                     e = lit[bitbuf & lmask];
-                    if (((e >> 5) & 7u) == (unsigned)T_LIT && bitcnt >= 30) {
-                        take(e & 31u);
-                        out[pos++] = (uint16_t)(e >> 16);
+                    if (((e >> 5) & 7u) == (unsigned)T_LIT) {
+                        take(e & 31u); out[pos++] = (uint16_t)(e >> 16);
                         e = lit[bitbuf & lmask];
-                        if (((e >> 5) & 7u) == (unsigned)T_LIT) { take(e & 31u); out[pos++] = (uint16_t)(e >> 16); }
+                        if (((e >> 5) & 7u) == (unsigned)T_LIT) { take(e & 31u); out[pos++] = (uint16_t)(e >> 16); continue; }
                     }
-                    continue;
+                    if (bitcnt < 48) continue; // (what follows needs up to 48 bits: a new turn refills)
                 }
+                if (((e >> 5) & 7u) == (unsigned)T_SUB) { take(LIT_BITS); e = lit[(e >> 16) + (bitbuf & ((1u << lit_sub_bits) - 1))]; }
+                const unsigned type = (e >> 5) & 7u;
+                if (type == (unsigned)T_LIT) { take(e & 31u); out[pos++] = (uint16_t)(e >> 16); continue; }
                 if (type == (unsigned)T_EOB) { take(e & 31u); break; }
                 if (type != (unsigned)T_LEN) return false;
                 take(e & 31u);
