@@ -330,7 +330,7 @@ def main():
     if use_dist:
         dist.barrier()
 
-    env = {"rank": rank, "world": world, "local": local, "dev": dev, "use_dist": use_dist, "backend": backend}
+    env = {"rank": rank, "world": world, "local": local, "dev": dev, "use_dist": use_dist, "backend": backend, "real_stdout": real_stdout}
     if a.e2e_pairs < 0:
         try:
             import shutil
@@ -487,7 +487,8 @@ def run_workload(env, a, config, pairs, steps, warmup, read_len, want_host_sampl
                 sys.stderr.write("[bench] rank %d: %.1f GB do not fit its share of device %d (%.1f GB free / %d ranks): fewer --pairs, a smaller --kmer-table-log2, "
                                  "or one rank per GPU\n" % (rank, kmer_plan["sum_GB"], local, free0 / 1e9, sharing))
             if rank == 0 and a.dry_run_memory:
-                print(json.dumps({"dry_run_memory": kmer_plan}))
+                env["real_stdout"].write(json.dumps({"dry_run_memory": kmer_plan}) + "\n")
+                env["real_stdout"].flush()
             sys.exit(0 if fits else 1)
     eng = HipEngine(opt, R_eng, 33, device=local, kmer_table_slots=(1 << a.kmer_table_log2) if config == "kmer" else 0)
     lib = eng.lib

@@ -1119,7 +1119,7 @@ void parse_range(const char *base, size_t b0, size_t b1, bool eof, RecBuf *b)
     }
 }
 
-struct FastTask { const RecBuf *mine = nullptr, *b1 = nullptr, *b2 = nullptr; char *dst = nullptr; size_t size = 0; int pair_slot = -1; };
+struct FastTask { const RecBuf *mine = nullptr, *b1 = nullptr, *b2 = nullptr; char *dst = nullptr; size_t size = 0; int pair_slot = -1; int fd = -1; off_t off = 0; };
 
 // one survivor rendered into memory: the bytes Run::write_read() would put
 char *render_read(const faqcs_params &prm, const RecBuf *b, uint32_t i, char *o)
@@ -1338,8 +1338,10 @@ void process_mapped(Run &r, bool paired)
     Queue<FastTask> fq;
     std::atomic<size_t> tasks_out{0};
     auto release_pair = [&](size_t k) { if (refs[k].left.fetch_sub(1) == 1) for (int s = 0; s < nsrc; ++s) if (refs[k].b[s]) give_back(s, refs[k].b[s]); };
+    static const bool out_pwrite = [] { const char *e = getenv("FAQCS_MI_OUT_PWRITE"); return e && atoi(e) != 0; }();
     auto formatter = [&] {
         double w_r = 0, w_w = 0, w_i = 0;
+        std::vector<char> local;
         struct Acc3 { std::mutex &m; double &a, &b, &c, &x, &y, &z; ~Acc3() { std::lock_guard<std::mutex> l(m); a += x; b += y; c += z; } } acc{tm_m, t_fmt_render, t_fmt_write, t_fmt_idle, w_r, w_w, w_i};
         for (;;) {
             const double tf0 = now_s();
@@ -1348,11 +1350,24 @@ void process_mapped(Run &r, bool paired)
             w_i += tf1 - tf0;
             if (!t.mine) return;
             if (t.size) {
-                char *o = t.dst;
+                // FAQCS_MI_OUT_PWRITE=1: rendered into a buffer of this thread (its pages are there after the first task) and handed to the file by ONE
+                // pwrite, instead of stores into the file's mapping that fault a fresh 4 KB page each (profiles/microbench/tmpfs_write.cpp)
+                char *const dst0 = out_pwrite ? (local.size() < t.size ? (local.resize(t.size + (t.size >> 2)), local.data()) : local.data()) : t.dst;
+                char *o = dst0;
                 for (uint32_t i = 0; i < t.mine->n; ++i)
                     if ((t.b1->res[i].flags & FAQCS_F_VALID) && (!t.b2 || (t.b2->res[i].flags & FAQCS_F_VALID))) o = render_read(r.prm, t.mine, i, o);
-                w_r += now_s() - tf1;
-                if ((size_t)(o - t.dst) != t.size) fail_run("faqcs_mi: internal error, a rendered buffer has the wrong size");
+                const double tf2 = now_s();
+                w_r += tf2 - tf1;
+                if ((size_t)(o - dst0) != t.size) fail_run("faqcs_mi: internal error, a rendered buffer has the wrong size");
+                else if (out_pwrite) {
+                    size_t done = 0;
+                    while (done < t.size) {
+                        const ssize_t k = pwrite(t.fd, dst0 + done, t.size - done, t.off + (off_t)done);
+                        if (k <= 0) { fail_run("I/O error"); break; }
+                        done += (size_t)k;
+                    }
+                    w_w += now_s() - tf2;
+                }
             }
             release_pair((size_t)t.pair_slot);
             --tasks_out;
@@ -1401,7 +1416,7 @@ void process_mapped(Run &r, bool paired)
                 refs[w.k].left = opt.qc_only ? 1 : nsrc + 1;
                 if (!opt.qc_only)
                     for (int m = 0; m < nsrc; ++m) {
-                        FastTask t; t.mine = m ? b2 : b1; t.b1 = b1; t.b2 = b2; t.dst = out_map[m] + off_out[m]; t.size = sz[m]; t.pair_slot = (int)w.k;
+                        FastTask t; t.mine = m ? b2 : b1; t.b1 = b1; t.b2 = b2; t.dst = out_map[m] + off_out[m]; t.fd = fd_out[m]; t.off = off_out[m]; t.size = sz[m]; t.pair_slot = (int)w.k;
                         off_out[m] += (off_t)sz[m]; out_len[m] = (size_t)off_out[m];
                         ++tasks_out;
                         fq.push(t);
