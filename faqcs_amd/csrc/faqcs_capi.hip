@@ -743,24 +743,32 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
     g.pass_used = true;
     if (per_read == 0) per_read = 1;
     while (r0 < r1) {
-        if (g.run_epoch.size() == (size_t)KG_MAX_RUNS || (!g.run_epoch.empty() && epoch - g.epoch_base >= (uint32_t)KG_EPOCH_SPAN)) {
+        // (round 6: an item carries its epoch RELATIVE TO THE GROUP'S FIRST directly -- the run -> epoch table of the group is the identity --, so a
+        // group takes any number of extraction launches: faqcs_mi submits a launch per 32 768-read buffer, and a pass of more than 1 000 buffers
+        // was cut into groups by the 10-bit run field alone.  What is left is the span of epochs an LDS histogram of the counting kernels takes.)
+        if (!g.run_epoch.empty() && epoch - g.epoch_base >= (uint32_t)KG_EPOCH_SPAN) {
             if (int rc = kg_flush(c)) return rc;
         }
         // A launch of `take` reads runs on grid blocks; block i appends to sub-region (i + rot) % 256 of every bucket: a share
         // 1 / (256 grid) of the launch's items each (hashing spreads a block's items over the buckets; the blocks take equal
         // numbers of reads).  sub_fill bounds every sub-region from above, 1/8 + 64 items of variance included; the group is
         // flushed before a sub-region could overflow (an overflow would be exact too, but slow: kmer_insert_atomic).
-        const uint32_t run = (uint32_t)g.run_epoch.size(), rot = (run * 37u) % KG_FAN;
+        const uint32_t run = g.run_epoch.empty() ? 0u : epoch - g.epoch_base, rot = (uint32_t)((g.n_launches * 37u) % KG_FAN);
         // items a launch can be expected to write at most (super-k-mers: three per w + 1 occurrences and two per read)
         auto items_of = [&](uint32_t take, uint64_t bound) { return !g.skm || g.skm_w == 1 ? bound : bound * 3 / (g.skm_w + 1) + 2ull * take; };
         static const bool no16g = [] { const char *e = getenv("FAQCS_KMER_EXTRACT16"); return e && atoi(e) == 0; }();
         const bool x16 = g.skm && c->prm.kmer == 31 && max_len <= 256 && !no16g;
         auto grid_of = [&](uint32_t take) { return x16 ? faqcs_skm_grid16(take, c->n_cu) : faqcs_skm_grid(take, c->n_cu); };
+        // sub_fill[i] = the EXPECTED number of items in the sub-regions block slot i has written (its even share of every launch so far); what a
+        // sub-region may hold beyond that -- skew of the blocks' reads and of the buckets, 1/8, and the scatter of a sum of independent shares,
+        // eight standard deviations + a granule -- is added ONCE, to the sum (round 5 added 64 items per launch: a pass of 32 768-read
+        // submissions, 14 items per sub-region each, was flushed after 540 of them with its sub-regions a fifth full)
+        auto over = [&](uint64_t mean) { return mean + mean / 8 + (uint64_t)(8.0 * std::sqrt((double)mean)) + 64 > g.dev.cap1; };
         auto fits = [&](uint32_t take, uint64_t bound) {
             const uint32_t grid = grid_of(take);
             const uint64_t ib = items_of(take, bound);
-            const uint64_t share = ib / ((uint64_t)grid * KG_FAN) + ib / ((uint64_t)grid * KG_FAN * 8) + 64;
-            for (uint32_t i = 0; i < grid; ++i) if (g.sub_fill[(i + rot) % KG_FAN] + share > g.dev.cap1) return false;
+            const uint64_t share = ib / ((uint64_t)grid * KG_FAN) + 1;
+            for (uint32_t i = 0; i < grid; ++i) if (over(g.sub_fill[(i + rot) % KG_FAN] + share)) return false;
             return g.bound_items + bound <= g.cap_items;
         };
         auto bound_of = [&](uint32_t take) { return host_off ? (uint64_t)(host_off[r0 + take] - host_off[r0]) : (uint64_t)take * per_read; };
@@ -787,9 +795,10 @@ static int kg_add_run(faqcs_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual,
                                             c->n_cu, c->compute, g.defer.p + 1, g.defer.p, grid));
         } else HIPCHK(faqcs_launch_skm_extract(c->dp, c->prm.kmer, g.dev, c->kt, run, rot, epoch, d_seq, d_qual, d_off,
                                               r0, r0 + take, d_res, c->n_cu, c->compute));
-        g.run_epoch.push_back(epoch - g.epoch_base);
+        while (g.run_epoch.size() <= (size_t)run) g.run_epoch.push_back((uint32_t)g.run_epoch.size()); // (the identity, as long as the group's epochs span)
+        ++g.n_launches;
         g.bound_items += bound;
-        for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += ib / ((uint64_t)grid * KG_FAN) + ib / ((uint64_t)grid * KG_FAN * 8) + 64;
+        for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += ib / ((uint64_t)grid * KG_FAN) + 1;
         r0 += take;
     }
     return 0;
@@ -809,10 +818,11 @@ static int kg_add_items(faqcs_ctx *c, const void *d_items, uint64_t n)
     while (n) {
         const uint32_t rot = (uint32_t)((g.n_launches * 37u) % KG_FAN);
         // (an item holds up to skm_w occurrences: the group's bound counts occurrences, the sub-regions items)
+        auto over = [&](uint64_t mean) { return mean + mean / 8 + (uint64_t)(8.0 * std::sqrt((double)mean)) + 64 > g.dev.cap1; }; // (as in kg_add_run)
         auto fits = [&](uint64_t take) {
             const uint32_t grid = faqcs_skm_items_grid(take, c->n_cu);
-            const uint64_t share = take / ((uint64_t)grid * KG_FAN) + take / ((uint64_t)grid * KG_FAN * 8) + 64;
-            for (uint32_t i = 0; i < grid; ++i) if (g.sub_fill[(i + rot) % KG_FAN] + share > g.dev.cap1) return false;
+            const uint64_t share = take / ((uint64_t)grid * KG_FAN) + 1;
+            for (uint32_t i = 0; i < grid; ++i) if (over(g.sub_fill[(i + rot) % KG_FAN] + share)) return false;
             return g.bound_items + take * g.skm_w <= g.cap_items;
         };
         uint64_t take = n;
@@ -831,7 +841,7 @@ static int kg_add_items(faqcs_ctx *c, const void *d_items, uint64_t n)
         ++g.n_launches;
         if (g.run_epoch.empty()) { g.run_epoch.resize(c->n_epochs); for (uint32_t j = 0; j < c->n_epochs; ++j) g.run_epoch[j] = j; }
         g.bound_items += take * g.skm_w;
-        for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += take / ((uint64_t)grid * KG_FAN) + take / ((uint64_t)grid * KG_FAN * 8) + 64;
+        for (uint32_t i = 0; i < grid; ++i) g.sub_fill[(i + rot) % KG_FAN] += take / ((uint64_t)grid * KG_FAN) + 1;
         p += take * 16; n -= take;
     }
     return 0;

@@ -524,6 +524,29 @@ def test_kmer_pass_in_one_piece_for_every_partition_width(fine, monkeypatch, cap
     assert len(st) == 2 and all(one_piece for _, _, one_piece in st), st
 
 
+def test_kmer_pass_of_many_submissions_stays_in_one_piece(monkeypatch, capfd):
+    """faqcs_mi submits a launch per 32 768-read buffer: a pass of 50 M reads is 1 500 submissions.  Round 5's groups took 1 000 extraction
+    launches (the item's 10-bit run field) and charged every launch 64 items of slack per sub-region, so such a pass was cut into groups --
+    through the table -- whatever the buffers could hold.  An item now carries its epoch relative to the group's first, and a sub-region's
+    slack is added once: 1 300 submissions of 40 reads each are ONE group, counted in one piece, equal to the oracle."""
+    from oracle_engine import OracleEngine
+
+    from faqcs_amd import driver
+
+    monkeypatch.setenv("FAQCS_KMER_STATS", "1")
+    rng = np.random.Generator(np.random.PCG64([909, SEED]))
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 50000)]
+    opt = parse_args(["-u", "x", "-d", "y", "--kmer_rarefaction", "--split_size", "5000", "--subset", "7"])
+    hip, ora = hip_factory(opt, 256, 33), OracleEngine(opt, 256, 33)
+    reads = _genome_reads(rng, genome, 1300 * 40, 60, 150)
+    for i in range(0, len(reads), 40):
+        seq, qual, offset, seg = driver.pack_segments([reads[i:i + 40]])
+        assert (hip.process(seq, qual, offset, seg) == ora.process(seq, qual, offset, seg)).all()
+    _kmer_engines_agree(hip, ora)
+    st = _kmer_stats(capfd.readouterr().err)
+    assert len(st) == 1 and st[0][2], st
+
+
 def test_kmer_curve_asked_for_in_the_middle_of_a_pass(monkeypatch, capfd):
     """faqcs_kmer_points() / _totals() while the pass goes on: the open group has to go INTO THE TABLE (its keys must live somewhere), and
     the rest of the pass -- and its end -- then goes through the table too; the answers on the way and at the end equal the oracle's.
