@@ -412,9 +412,12 @@ struct BgzfReader {
     }
     void work()
     {
+        // members are inflated by the repository's own decoder (faqcs_pargz.h, byte output); FAQCS_MI_BGZF_ZLIB=1: by zlib (A/B)
+        static const bool use_zlib = [] { const char *e = getenv("FAQCS_MI_BGZF_ZLIB"); return e && atoi(e) != 0; }();
         z_stream z;
         memset(&z, 0, sizeof z);
         if (inflateInit2(&z, -15) != Z_OK) return;
+        std::unique_ptr<ParGzReader::MarkerInflate> mi(new ParGzReader::MarkerInflate);
         for (;;) {
             Task *t;
             {
@@ -424,7 +427,7 @@ struct BgzfReader {
                 t = &ring[claimed % ring.size()];
                 ++claimed;
             }
-            if (t->out.size() < TASK_BLOCKS * 65536) t->out.resize(TASK_BLOCKS * 65536);
+            if (t->out.size() < TASK_BLOCKS * 65536 + 1024) t->out.resize(TASK_BLOCKS * 65536 + 1024); // (+ the room the decoder's copies may run over a match's end)
             size_t o = t->begin, w = 0;
             bool bad = false;
             while (o < t->end && !bad) {
@@ -432,15 +435,25 @@ struct BgzfReader {
                 const size_t ms = member_size(p, t->end - o), xlen = p[10] | ((size_t)p[11] << 8);
                 const size_t hdr = 12 + xlen;
                 const uint32_t isize = (uint32_t)p[ms - 4] | ((uint32_t)p[ms - 3] << 8) | ((uint32_t)p[ms - 2] << 16) | ((uint32_t)p[ms - 1] << 24);
-                if (hdr + 8 > ms || isize > 65536 || w + isize > t->out.size()) { bad = true; break; }
-                if (isize) {
+                if (hdr + 8 > ms || isize > 65536 || w + isize + 1024 > t->out.size()) { bad = true; break; }
+                if (isize && !use_zlib) {
+                    // block after block to the final one: exactly isize bytes, from no more than the member's own deflate data
+                    mi->begin(p + hdr, ms - hdr - 8, 0);
+                    uint8_t *dst = (uint8_t *)t->out.data() + w;
+                    size_t pos = 0, cap = (size_t)isize + 320;
+                    auto no_room = [](size_t) -> uint8_t * { return nullptr; }; // (more than ISIZE bytes: invalid)
+                    do { if (!mi->decode_block(dst, pos, cap, no_room) || pos > isize) { bad = true; break; } } while (!mi->final_block);
+                    if (bad || pos != isize) { bad = true; break; }
+                } else if (isize) {
                     inflateReset(&z);
                     z.next_in = const_cast<Bytef *>(p + hdr); z.avail_in = (uInt)(ms - hdr - 8);
                     z.next_out = (Bytef *)t->out.data() + w; z.avail_out = (uInt)isize;
                     const int rc = inflate(&z, Z_FINISH);
                     if (rc != Z_STREAM_END || z.avail_out != 0) { bad = true; break; }
+                }
+                if (isize) {
                     const uint32_t crc = (uint32_t)p[ms - 8] | ((uint32_t)p[ms - 7] << 8) | ((uint32_t)p[ms - 6] << 16) | ((uint32_t)p[ms - 5] << 24);
-                    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)t->out.data() + w, (uInt)isize) != crc) { bad = true; break; } // (gzread checks it too)
+                    if (faqcs_crc32(0, (const uint8_t *)t->out.data() + w, isize) != crc) { bad = true; break; } // (gzread checks it too)
                     w += isize;
                 }
                 o += ms;

@@ -31,8 +31,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -40,6 +42,101 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+// ---- CRC-32 (the gzip polynomial) by carry-less multiplication: zlib's table-driven crc32 does about 1 GB/s on a core, which made the
+// CRC of a piece a sixth of the inflate's CPU time.  Folding of 64 bytes a step with PCLMULQDQ (Gopal et al., "Fast CRC Computation
+// for Generic Polynomials Using PCLMULQDQ Instruction", Intel 2009; the constants are the paper's for the reflected polynomial
+// 0xEDB88320).  Works on the raw (inverted) CRC state; the caller handles tails and machines without the instruction.
+#include <immintrin.h>
+__attribute__((target("pclmul,sse4.1"))) static inline uint32_t faqcs_crc32_fold(const uint8_t *buf, size_t len, uint32_t state) // len >= 64, a multiple of 16
+{
+    alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+    alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+    alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};
+    alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};
+    __m128i x1 = _mm_loadu_si128((const __m128i *)(buf + 0)), x2 = _mm_loadu_si128((const __m128i *)(buf + 16));
+    __m128i x3 = _mm_loadu_si128((const __m128i *)(buf + 32)), x4 = _mm_loadu_si128((const __m128i *)(buf + 48));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)state));
+    __m128i x0 = _mm_load_si128((const __m128i *)k1k2);
+    buf += 64; len -= 64;
+    while (len >= 64) { // four independent 128-bit lanes, each folded over 512 bits
+        const __m128i x5 = _mm_clmulepi64_si128(x1, x0, 0x00), x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        const __m128i x7 = _mm_clmulepi64_si128(x3, x0, 0x00), x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), _mm_loadu_si128((const __m128i *)(buf + 0)));
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), _mm_loadu_si128((const __m128i *)(buf + 16)));
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), _mm_loadu_si128((const __m128i *)(buf + 32)));
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), _mm_loadu_si128((const __m128i *)(buf + 48)));
+        buf += 64; len -= 64;
+    }
+    x0 = _mm_load_si128((const __m128i *)k3k4); // the four lanes into one
+    __m128i x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16) { // what is left in steps of 16
+        x2 = _mm_loadu_si128((const __m128i *)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; len -= 16;
+    }
+    // 128 -> 64 bits
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), x2);
+    x0 = _mm_loadl_epi64((const __m128i *)k5k0);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, x3);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(x1, x0, 0x00), x2);
+    // Barrett reduction 64 -> 32 bits
+    x0 = _mm_load_si128((const __m128i *)poly);
+    x2 = _mm_and_si128(x1, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+// crc32_z() with the same arguments and the same result
+static inline uint32_t faqcs_crc32(uint32_t crc, const uint8_t *buf, size_t len)
+{
+    static const bool fold = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("FAQCS_MI_NO_PCLMUL");
+    if (fold && len >= 64) {
+        const size_t head = len & ~(size_t)15;
+        crc = ~faqcs_crc32_fold(buf, head, ~crc);
+        buf += head; len -= head;
+    }
+    return len ? (uint32_t)crc32_z(crc, buf, len) : crc;
+}
+// 16-bit symbols -> text: a symbol below 256 is its byte, 0x8000 | k the byte at offset k of the 32 KB window `w`
+// (true: there was a marker among them)
+__attribute__((target("avx2"))) static inline bool faqcs_narrow_avx2(const uint16_t *sym, uint8_t *o, size_t n, const uint8_t *w)
+{
+    size_t k = 0;
+    bool any = false;
+    for (; k + 32 <= n; k += 32) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(sym + k)), b = _mm256_loadu_si256((const __m256i *)(sym + k + 16));
+        if (_mm256_movemask_epi8(_mm256_or_si256(a, b)) & 0xAAAAAAAAu) { // a marker among the 32 (the top bit of a symbol)
+            for (size_t t = k; t < k + 32; ++t) { const uint16_t v = sym[t]; o[t] = v < 256 ? (uint8_t)v : w[v & 0x7fffu]; }
+            any = true;
+            continue;
+        }
+        _mm256_storeu_si256((__m256i *)(o + k), _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8));
+    }
+    for (; k < n; ++k) { const uint16_t v = sym[k]; any |= v >= 256; o[k] = v < 256 ? (uint8_t)v : w[v & 0x7fffu]; }
+    return any;
+}
+static inline bool faqcs_narrow(const uint16_t *sym, uint8_t *o, size_t n, const uint8_t *w)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return faqcs_narrow_avx2(sym, o, n, w);
+    bool any = false;
+    for (size_t k = 0; k < n; ++k) { const uint16_t v = sym[k]; any |= v >= 256; o[k] = v < 256 ? (uint8_t)v : w[v & 0x7fffu]; }
+    return any;
+}
 
 struct ParGzReader {
     // output buffers: plain malloc'd memory, never zero-filled, recycled through a pool (a piece inflates to tens of megabytes: a fresh
@@ -66,7 +163,7 @@ struct ParGzReader {
         size_t next_piece = 0;                // index of that piece (or n_pieces: it ran to the end of the member)
         bool final_seen = false;              // the member's last block ended inside
         size_t trailer_at = 0;                // byte offset of the member's trailer (final_seen)
-        bool known_window = false;            // piece 0: inflated once, nothing to patch
+        bool known_window = false;            // piece 0: nothing lies in front of it (a marker in it is a distance too far back: invalid data)
         Buf out, mark;                        // the text; (pieces with an unknown window) the 16-bit symbols of MarkerInflate, narrowed into `out` by patch()
         size_t n_out = 0;
         std::vector<uint8_t> win;             // the true 32 KB in front of the piece (set by the chain thread)
@@ -91,6 +188,19 @@ struct ParGzReader {
     size_t piece_arg = 0;
     bool two_pass = [] { const char *e = getenv("FAQCS_MI_PARGZ_TWO_PASS"); return e && atoi(e) != 0; }(); // round 5's two zlib passes per piece (A/B; needs ASCII text)
     std::atomic<size_t> cancel_from{~(size_t)0}; // pieces from this index on start behind the member's trailer: their workers give up
+    // FAQCS_PARGZ_TRACE=1: a time line of the pieces on stderr when the reader closes (diagnostic)
+    struct Ev { double t; size_t piece; const char *what; size_t arg; };
+    std::vector<Ev> trace_log;
+    std::mutex trace_m;
+    const bool tracing = getenv("FAQCS_PARGZ_TRACE") != nullptr;
+    const std::chrono::steady_clock::time_point trace_t0 = std::chrono::steady_clock::now();
+    void trace(size_t piece, const char *what, size_t arg = 0)
+    {
+        if (!tracing) return;
+        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - trace_t0).count();
+        std::lock_guard<std::mutex> l(trace_m);
+        trace_log.push_back(Ev{t, piece, what, arg});
+    }
     // consumer state
     size_t cur = 0;              // piece to hand out next
     bool member_done = false, tail_init = false, tail_done = false, tail_mid = false;
@@ -205,7 +315,8 @@ struct ParGzReader {
     static const uint8_t *dict1() { static uint8_t d[WIN]; static bool init = [] { for (size_t k = 0; k < WIN; ++k) d[k] = (uint8_t)(k & 255); return true; }(); (void)init; return d; }
     static const uint8_t *dict2() { static uint8_t d[WIN]; static bool init = [] { for (size_t k = 0; k < WIN; ++k) d[k] = (uint8_t)(128 | (k >> 8)); return true; }(); (void)init; return d; }
 
-    // ---- a raw inflate of 16-bit SYMBOLS that starts at a bit position without knowing the 32 KB in front of it (round 6) ------------
+    // ---- a raw inflate of 16-bit SYMBOLS that starts at a bit position without knowing the 32 KB in front of it (round 6); with Sym =
+    //      uint8_t the same decoder inflates plain bytes (BGZF members in faqcs_cli.cpp: it is about three times as fast as zlib's) ----------
     // A symbol below 256 is a byte of the text; a symbol 0x8000 | k is "the byte at offset k of the unknown window" (k = 32 767: the
     // byte right in front of the piece).  A back-reference that reaches in front of the piece writes such markers, one that copies
     // them copies them on: ONE pass over the compressed bits where the two-dictionary scheme of round 5 made two zlib passes, and the
@@ -213,8 +324,14 @@ struct ParGzReader {
     // table for literals / lengths, 8 bits for distances, second-level tables behind the longer codes; the bit buffer is refilled to
     // >= 56 bits, which a length code + extra + distance code + extra (<= 48 bits) never exhausts.
     struct MarkerInflate {
-        enum { LIT_BITS = 11, DIST_BITS = 8, T_LIT = 0, T_LEN = 1, T_EOB = 2, T_SUB = 3, T_BAD = 4 };
-        // entry: bits 0-4 code bits to consume at this level | bits 5-7 type | bits 8-15 extra bits | bits 16-31 payload (literal / base / subtable start)
+        enum { LIT_BITS = 11, DIST_BITS = 8 };
+        // A table entry (the layout follows the decode loop's critical path: ONE shift of the bit buffer per look-up, the extra bits taken
+        // from a saved copy beside it):
+        //   bits 0-7   bits to consume at this look-up: the code's bits at this level + the extra bits of a length / distance
+        //   bits 8-11  the code's bits at this level alone (the extra bits start behind them)
+        //   bit 15 F_LIT a literal | bit 14 F_EXC not a symbol: bit 13 F_EOB end of block, bit 12 F_BAD no code; neither = a second-level table
+        //   bits 16-31 the literal / the base of the length or distance / where the second-level table starts
+        enum : uint32_t { F_LIT = 1u << 15, F_EXC = 1u << 14, F_EOB = 1u << 13, F_BAD = 1u << 12 };
         uint32_t lit[(1 << LIT_BITS) + 288 * 16], dist[(1 << DIST_BITS) + 30 * 128]; // (second-level tables of 2^(longest code - first level) entries: at most one per symbol)
         uint8_t lit_sub_bits = 0, dist_sub_bits = 0;
         const uint8_t *in = nullptr, *in_end = nullptr;
@@ -248,18 +365,20 @@ struct ParGzReader {
         inline uint32_t take(unsigned n) { const uint32_t v = (uint32_t)(bitbuf & ((1ull << n) - 1)); bitbuf >>= n; bitcnt -= n; return v; }
 
         static unsigned rev(unsigned code, unsigned len) { unsigned r = 0; for (unsigned b = 0; b < len; ++b) r |= ((code >> b) & 1u) << (len - 1 - b); return r; }
-        // canonical Huffman code of lens[0 .. n) -> a two-level table; sym_entry(s) gives the entry of symbol s without its length field
+        // canonical Huffman code of lens[0 .. n) -> a two-level table; sym_entry(s) gives symbol s's payload and flags (bits 12-31) and the
+        // number of its extra bits (bits 0-7); the code lengths are filled in here
         template <class F>
         static bool build(const uint8_t *lens, unsigned n, unsigned first_bits, uint32_t *tab, unsigned tab_cap, uint8_t &sub_bits_out, F &&sym_entry)
         {
             unsigned count[16] = {0}, maxlen = 0;
             for (unsigned i = 0; i < n; ++i) { ++count[lens[i]]; if (lens[i] > maxlen) maxlen = lens[i]; }
             count[0] = 0;
-            // over-subscribed sets are an error; incomplete ones decode to T_BAD where no code is assigned
+            // over-subscribed sets are an error; incomplete ones decode to F_BAD where no code is assigned
             { long left = 1; for (unsigned l = 1; l <= 15; ++l) { left = left * 2 - (long)count[l]; if (left < 0) return false; } }
             unsigned next[16]; { unsigned code = 0; for (unsigned l = 1; l <= 15; ++l) { code = (code + count[l - 1]) << 1; next[l] = code; } }
             const unsigned P = 1u << first_bits;
-            for (unsigned i = 0; i < P; ++i) tab[i] = (uint32_t)T_BAD << 5 | 1u;
+            const uint32_t bad = F_EXC | F_BAD | 1u;
+            for (unsigned i = 0; i < P; ++i) tab[i] = bad;
             const unsigned sub_bits = maxlen > first_bits ? maxlen - first_bits : 0;
             sub_bits_out = (uint8_t)sub_bits;
             unsigned used = P;
@@ -267,19 +386,22 @@ struct ParGzReader {
                 const unsigned l = lens[s];
                 if (!l) continue;
                 const unsigned r = rev(next[l]++, l);
-                const uint32_t e = sym_entry(s);
+                const uint32_t se = sym_entry(s);
+                auto entry = [&](unsigned level_bits) { return (se & 0xfffff000u) | (level_bits << 8) | (level_bits + (se & 0xffu)); };
                 if (l <= first_bits) {
-                    for (unsigned i = r; i < P; i += 1u << l) tab[i] = e | l;
+                    const uint32_t e = entry(l);
+                    for (unsigned i = r; i < P; i += 1u << l) tab[i] = e;
                 } else {
                     const unsigned pre = r & (P - 1);
-                    if (((tab[pre] >> 5) & 7u) != (unsigned)T_SUB) { // a new second-level table behind this prefix
+                    if ((tab[pre] & (F_LIT | F_EXC | F_EOB | F_BAD)) != F_EXC) { // (not a pointer yet:) a new second-level table behind this prefix
                         if (used + (1u << sub_bits) > tab_cap) return false;
-                        tab[pre] = ((uint32_t)used << 16) | ((uint32_t)T_SUB << 5) | first_bits;
-                        for (unsigned i = 0; i < (1u << sub_bits); ++i) tab[used + i] = (uint32_t)T_BAD << 5 | 1u;
+                        tab[pre] = ((uint32_t)used << 16) | F_EXC | first_bits;
+                        for (unsigned i = 0; i < (1u << sub_bits); ++i) tab[used + i] = bad;
                         used += 1u << sub_bits;
                     }
                     const unsigned start = tab[pre] >> 16, rest = l - first_bits;
-                    for (unsigned i = r >> first_bits; i < (1u << sub_bits); i += 1u << rest) tab[start + i] = e | rest;
+                    const uint32_t e = entry(rest);
+                    for (unsigned i = r >> first_bits; i < (1u << sub_bits); i += 1u << rest) tab[start + i] = e;
                 }
             }
             return true;
@@ -291,14 +413,14 @@ struct ParGzReader {
             static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
             static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
             if (!build(ll, nl, LIT_BITS, lit, sizeof lit / 4, lit_sub_bits, [&](unsigned s) -> uint32_t {
-                    if (s < 256) return (s << 16) | ((uint32_t)T_LIT << 5);
-                    if (s == 256) return (uint32_t)T_EOB << 5;
-                    if (s > 285) return (uint32_t)T_BAD << 5;
-                    return ((uint32_t)lbase[s - 257] << 16) | ((uint32_t)lext[s - 257] << 8) | ((uint32_t)T_LEN << 5);
+                    if (s < 256) return (s << 16) | F_LIT;
+                    if (s == 256) return F_EXC | F_EOB;
+                    if (s > 285) return F_EXC | F_BAD;
+                    return ((uint32_t)lbase[s - 257] << 16) | lext[s - 257];
                 })) return false;
             return build(dl, nd, DIST_BITS, dist, sizeof dist / 4, dist_sub_bits, [&](unsigned s) -> uint32_t {
-                if (s > 29) return (uint32_t)T_BAD << 5;
-                return ((uint32_t)dbase[s] << 16) | ((uint32_t)dext[s] << 8) | ((uint32_t)T_LEN << 5);
+                if (s > 29) return F_EXC | F_BAD;
+                return ((uint32_t)dbase[s] << 16) | dext[s];
             });
         }
         // the header of the next block; false: invalid.  stored blocks are copied here (their length is returned through n_stored)
@@ -333,15 +455,15 @@ struct ParGzReader {
             refill();
             for (unsigned i = 0; i < hclen; ++i) { if (bitcnt < 3) refill(); pl[order[i]] = (uint8_t)take(3); }
             uint32_t pre[128 + 64]; uint8_t pre_sub = 0;
-            if (!build(pl, 19, 7, pre, sizeof pre / 4, pre_sub, [&](unsigned s) -> uint32_t { return (s << 16) | ((uint32_t)T_LIT << 5); })) return false;
+            if (!build(pl, 19, 7, pre, sizeof pre / 4, pre_sub, [&](unsigned s) -> uint32_t { return (s << 16) | F_LIT; })) return false;
             uint8_t lens[286 + 30 + 140];
             unsigned n = 0; const unsigned total = hlit + hdist;
             while (n < total) {
                 refill();
                 if (in_over > 8) return false;
                 const uint32_t e = pre[bitbuf & 127];
-                if (((e >> 5) & 7u) != (unsigned)T_LIT) return false;
-                take(e & 31u);
+                if (!(e & F_LIT)) return false;
+                take(e & 63u);
                 const unsigned sym = e >> 16;
                 if (sym < 16) { lens[n++] = (uint8_t)sym; continue; }
                 unsigned rep, val = 0;
@@ -354,69 +476,119 @@ struct ParGzReader {
             if (lens[256] == 0) return false; // no end-of-block code
             return build_tables(lens, hlit, lens + hlit, hdist);
         }
-        // One whole block into out[0 ..) from position pos on (out grows through `grow`, which returns the new base).  window_known == false:
-        // positions in front of 0 are the unknown window (markers); true is not used here (the first piece goes through zlib).
-        // Returns false on invalid data.
-        template <class Grow>
-        bool decode_block(uint16_t *&out, size_t &pos, size_t &cap, Grow &&grow)
+        // One whole block into out[0 ..) from position pos on (out grows through `grow`, which returns the new base); positions in front
+        // of 0 are the unknown window (markers).  Returns false on invalid data.
+        // The loop carries the entry of the next code (looked up before the copy of a match, so that the load overlaps it) and keeps the
+        // bit reader in locals; per symbol the bit buffer is shifted once, by the entry's low byte.
+        // Sym = uint8_t: plain bytes for data whose start is the start of the stream (a BGZF member: nothing lies in front of position 0, a
+        // distance that reaches there is invalid).  grow() may return nullptr: the block fails.
+        template <class Sym, class Grow>
+        bool decode_block(Sym *&out, size_t &pos_io, size_t &cap, Grow &&grow)
         {
+            constexpr bool MARKERS = sizeof(Sym) == 2;
             if (!read_header()) return false;
+            size_t pos = pos_io;
             if (block_type == 0) {
                 // the bytes of a stored block: what is left in the bit buffer first (whole bytes), then straight from the input
                 while (stored_left) {
-                    if (pos + 1 > cap) { out = grow(pos + stored_left + 1); }
-                    if (bitcnt >= 8) { out[pos++] = (uint16_t)take(8); --stored_left; continue; }
+                    if (pos + 1 > cap) { out = grow(pos + stored_left + 1); if (!out) return false; }
+                    if (bitcnt >= 8) {
+                        if (in_over * 8 + 8 > bitcnt) return false; // (the input ended: this byte is one of the zeros behind it)
+                        out[pos++] = (Sym)take(8); --stored_left; continue;
+                    }
                     bitbuf = 0; bitcnt = 0; // (byte aligned and drained: what the last refill loaded beyond bitcnt is read again from `in`)
                     if (in >= in_end) return false;
                     out[pos++] = *in++; --stored_left;
                 }
                 if (bitcnt < 8) { bitbuf = 0; bitcnt = 0; }
-                return in_over == 0;
+                pos_io = pos;
+                return in_over * 8 <= bitcnt; // (the bits of bytes that are not there have not been consumed)
             }
             const uint32_t lmask = (1u << LIT_BITS) - 1, dmask = (1u << DIST_BITS) - 1;
+            const uint32_t lsub = (1u << lit_sub_bits) - 1, dsub = (1u << dist_sub_bits) - 1;
+            // the bit reader in locals (written back where the block ends)
+            uint64_t bb = bitbuf; unsigned bc = bitcnt; const uint8_t *ip = in; const uint8_t *const ie = in_end; size_t over = in_over;
+            Sym *o = out;
+#define MI_REFILL()                                                                                                                       \
+            do {                                                                                                                          \
+                if (__builtin_expect(ip + 8 <= ie, 1)) { uint64_t v_; memcpy(&v_, ip, 8); bb |= v_ << bc; ip += (63 - bc) >> 3; bc |= 56; } \
+                else {                                                                                                                    \
+                    while (bc <= 56) { if (ip < ie) bb |= (uint64_t)*ip++ << bc; else ++over; bc += 8; }                                  \
+                    if (over > 8) return false; /* (the input ends inside the block: the zeros behind it must not be decoded on and on) */ \
+                }                                                                                                                         \
+            } while (0)
+#define MI_CONSUME(e_) do { bb >>= ((e_) & 63u); bc -= ((e_) & 63u); } while (0)
+            MI_REFILL();
+            uint32_t e = lit[bb & lmask];
             for (;;) {
-                if (pos + 320 > cap) out = grow(pos + 320);
-                refill();
-                if (in_over > 8) return false; // (the input ends inside the block: the zeros behind it must not be decoded on and on)
-                uint32_t e = lit[bitbuf & lmask];
-                // up to three literals per refill (3 x 15 bits <= 56); the entry that ends the run is decoded below without a second look-up
-                if (((e >> 5) & 7u) == (unsigned)T_LIT) {
-                    take(e & 31u); out[pos++] = (uint16_t)(e >> 16);
-                    e = lit[bitbuf & lmask];
-                    if (((e >> 5) & 7u) == (unsigned)T_LIT) {
-                        take(e & 31u); out[pos++] = (uint16_t)(e >> 16);
-                        e = lit[bitbuf & lmask];
-                        if (((e >> 5) & 7u) == (unsigned)T_LIT) { take(e & 31u); out[pos++] = (uint16_t)(e >> 16); continue; }
+                // here: >= 56 bits in the buffer (or the input has ended), e = the entry of the code in front
+                if (__builtin_expect(pos + 320 > cap, 0)) { out = grow(pos + 320); o = out; if (!o) return false; }
+                if (e & F_LIT) {
+                    // up to three literals per refill (3 x 11 bits of first-level codes); a refill leaves the bits in front untouched, so the
+                    // entry that ends the run is still the right one behind it
+                    MI_CONSUME(e); o[pos++] = (Sym)(e >> 16);
+                    e = lit[bb & lmask];
+                    if (e & F_LIT) {
+                        MI_CONSUME(e); o[pos++] = (Sym)(e >> 16);
+                        e = lit[bb & lmask];
+                        if (e & F_LIT) {
+                            MI_CONSUME(e); o[pos++] = (Sym)(e >> 16);
+                            MI_REFILL();
+                            e = lit[bb & lmask];
+                            continue;
+                        }
                     }
-                    if (bitcnt < 48) continue; // (what follows needs up to 48 bits: a new turn refills)
+                    MI_REFILL();
                 }
-                if (((e >> 5) & 7u) == (unsigned)T_SUB) { take(LIT_BITS); e = lit[(e >> 16) + (bitbuf & ((1u << lit_sub_bits) - 1))]; }
-                const unsigned type = (e >> 5) & 7u;
-                if (type == (unsigned)T_LIT) { take(e & 31u); out[pos++] = (uint16_t)(e >> 16); continue; }
-                if (type == (unsigned)T_EOB) { take(e & 31u); break; }
-                if (type != (unsigned)T_LEN) return false;
-                take(e & 31u);
-                const unsigned len = (e >> 16) + take((e >> 8) & 255u);
-                uint32_t d = dist[bitbuf & dmask];
-                if (((d >> 5) & 7u) == (unsigned)T_SUB) { take(DIST_BITS); d = dist[(d >> 16) + (bitbuf & ((1u << dist_sub_bits) - 1))]; }
-                if (((d >> 5) & 7u) != (unsigned)T_LEN) return false;
-                take(d & 31u);
-                const size_t dd = (size_t)(d >> 16) + take((d >> 8) & 255u);
-                if (dd > pos + WIN) return false; // further back than the window in front of the piece
-                size_t i = 0;
-                if (dd > pos) { // (the part of the copy that lies in front of the piece: markers)
-                    const size_t before = dd - pos; // source positions -before .. -1
+                if (__builtin_expect(e & F_EXC, 0)) {
+                    if (e & (F_EOB | F_BAD)) { if (e & F_BAD) return false; MI_CONSUME(e); break; }
+                    MI_CONSUME(e); // (the first level's bits)
+                    e = lit[(e >> 16) + (bb & lsub)];
+                    if (e & F_LIT) { MI_CONSUME(e); o[pos++] = (Sym)(e >> 16); MI_REFILL(); e = lit[bb & lmask]; continue; }
+                    if (e & F_EXC) { if (!(e & F_EOB)) return false; MI_CONSUME(e); break; }
+                }
+                // a length (<= 20 bits with its extra bits, second level included) and a distance (<= 28): <= 48 of the 56
+                uint64_t saved = bb;
+                MI_CONSUME(e);
+                const unsigned len = (e >> 16) + (unsigned)(((uint32_t)saved & ((1u << (e & 63u)) - 1u)) >> ((e >> 8) & 15u));
+                uint32_t d = dist[bb & dmask];
+                if (__builtin_expect(d & F_EXC, 0)) {
+                    if (d & F_BAD) return false;
+                    MI_CONSUME(d);
+                    d = dist[(d >> 16) + (bb & dsub)];
+                    if (d & F_EXC) return false;
+                }
+                saved = bb;
+                MI_CONSUME(d);
+                const size_t dd = (size_t)(d >> 16) + (size_t)(((uint32_t)saved & ((1u << (d & 63u)) - 1u)) >> ((d >> 8) & 15u));
+                MI_REFILL();
+                e = lit[bb & lmask]; // (the next code's entry is on its way while the match is copied)
+                Sym *dp = o + pos;
+                constexpr size_t V = 16 / sizeof(Sym); // symbols in a 16-byte step
+                if (__builtin_expect(dd > pos, 0)) { // the copy starts in front of position 0
+                    if (!MARKERS || dd > pos + WIN) return false; // further back than there is anything (than the window in front of the piece)
+                    const size_t before = dd - pos; // source positions -before .. -1: markers for that part
+                    size_t i = 0;
                     const size_t nmark = before < len ? before : len;
-                    for (; i < nmark; ++i) out[pos + i] = (uint16_t)(0x8000u | (uint32_t)(WIN - before + i));
-                }
-                if (dd >= 8 && i == 0) { // the common case: sixteen bytes (eight symbols) a step, past the end of the match if need be (there is room for 320 symbols)
-                    const uint16_t *sp = out + pos - dd;
-                    uint16_t *dp = out + pos;
-                    for (size_t k = 0; k < len; k += 8) memcpy(dp + k, sp + k, 16);
-                } else if (dd >= len) { if (i < len) memcpy(out + pos + i, out + pos + i - dd, (len - i) * 2); }
-                else for (; i < len; ++i) out[pos + i] = out[pos + i - dd];
+                    for (; i < nmark; ++i) dp[i] = (Sym)(0x8000u | (uint32_t)(WIN - before + i));
+                    for (; i < len; ++i) dp[i] = dp[i - dd];
+                } else if (dd >= V) { // the common case: sixteen bytes a step, past the end of the match if need be (there is room for 320 symbols)
+                    const Sym *sp = dp - dd;
+                    memcpy(dp, sp, 16);
+                    if (__builtin_expect(len > V, 0)) for (size_t k = V; k < len; k += V) memcpy(dp + k, sp + k, 16);
+                } else if (dd == 1) { // a run of one symbol
+                    const uint64_t v = (uint64_t)dp[-1] * (MARKERS ? 0x0001000100010001ull : 0x0101010101010101ull);
+                    for (size_t k = 0; k < len; k += 8 / sizeof(Sym)) memcpy(dp + k, &v, 8);
+                } else if (!MARKERS && dd >= 8) {
+                    const Sym *sp = dp - dd;
+                    for (size_t k = 0; k < len; k += 8) memcpy(dp + k, sp + k, 8);
+                } else for (size_t i = 0; i < len; ++i) dp[i] = dp[i - dd];
                 pos += len;
             }
+#undef MI_REFILL
+#undef MI_CONSUME
+            bitbuf = bb; bitcnt = bc; in = ip; in_over = over;
+            pos_io = pos;
             return in_over * 8 <= bitcnt; // (the bits of bytes that are not there have not been consumed)
         }
     };
@@ -503,6 +675,7 @@ struct ParGzReader {
     void close()
     {
         disarm();
+        if (tracing) for (const Ev &e : trace_log) fprintf(stderr, "[pargz %8.4f] piece %4zu %s %zu\n", e.t, e.piece, e.what, e.arg);
         if (tail_init && !tail_done) { inflateEnd(&tz); tail_done = true; }
         if (base) munmap(const_cast<uint8_t *>(base), size);
         base = nullptr;
@@ -537,22 +710,44 @@ struct ParGzReader {
             }
             if (crc_job) {
                 Piece &p = pieces[i];
-                if (!p.known_window) patch(p, 0, p.n_out);
-                p.crc = (uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), p.out.data(), p.n_out);
-                { std::lock_guard<std::mutex> l(m); p.crc_state.store(2); }
+                trace(i, "narrowing and crc taken");
+                bool invalid = false;
+                if (!two_pass) { // the symbols become the text 64 KB at a time, and the CRC takes each stretch while it is in the cache
+                    if (!p.out.p) p.out = take_buf();
+                    p.out.resize(p.n_out + 1);
+                    const uint16_t *sym = reinterpret_cast<const uint16_t *>(p.mark.data());
+                    uint32_t c = 0;
+                    bool any = false;
+                    for (size_t lo = 0; lo < p.n_out; lo += 65536) {
+                        const size_t n = std::min<size_t>(65536, p.n_out - lo);
+                        any |= faqcs_narrow(sym + lo, p.out.data() + lo, n, p.win.data());
+                        c = faqcs_crc32(c, p.out.data() + lo, n);
+                    }
+                    p.crc = c;
+                    invalid = any && p.known_window;
+                    give_buf(p.mark); // (still warm: the next piece to be inflated takes it)
+                } else {
+                    if (!p.known_window) patch(p, 0, p.n_out);
+                    p.crc = faqcs_crc32(0, p.out.data(), p.n_out);
+                }
+                { std::lock_guard<std::mutex> l(m); if (invalid) p.state.store(3); p.crc_state.store(2); }
+                trace(i, "patched, crc done");
                 cv_done.notify_all();
                 continue;
             }
             // find where this piece can start
             Piece &p = pieces[i];
+            trace(i, "claimed");
             const uint64_t lo = range_begin_bit(i), hi = std::min<uint64_t>(range_begin_bit(i + 1), (uint64_t)size * 8);
             uint64_t s = NO_START;
             for (uint64_t b = lo; b < hi; ++b)
                 if (plausible_block(b) && trial(b)) { s = b; break; }
             { std::lock_guard<std::mutex> l(m); p.start_bit.store(s); if (s == NO_START) p.state.store(3); }
             cv_done.notify_all(); // (a predecessor may be waiting to learn where this piece starts)
+            trace(i, "start found at bit", (size_t)(s - lo));
             if (s == NO_START) continue;
             inflate_piece(i);
+            trace(i, "inflated, state", (size_t)p.state.load());
             cv_done.notify_all();
         }
     }
@@ -593,7 +788,7 @@ struct ParGzReader {
         auto fail = [&] { std::lock_guard<std::mutex> l(m); p.state.store(3); };
         p.n_out = 0; p.final_seen = false;
         size_t j = i + 1; // the first later piece whose start this one has not passed yet
-        if (!p.known_window && !two_pass) { // ONE pass that writes 16-bit symbols (round 6)
+        if (!two_pass) { // ONE pass that writes 16-bit symbols (round 6; the first piece too: this decoder is faster than zlib's)
             std::unique_ptr<MarkerInflate> mi(new MarkerInflate);
             mi->begin(base, size, start);
             if (!p.mark.p) p.mark = take_buf();
@@ -668,18 +863,9 @@ struct ParGzReader {
         p.state.store(2);
     }
 
-    // out[k] of the bytes [lo, hi) that came from the window in front of the piece: the marker (mark[k] & 128) carries the window offset
+    // (FAQCS_MI_PARGZ_TWO_PASS=1 only) out[k] of the bytes [lo, hi) that came from the window in front of the piece: the marker (mark[k] & 128) carries the window offset
     void patch(Piece &p, size_t lo, size_t hi)
     {
-        if (!two_pass) { // the symbols become the text: a byte as it is, a marker through the window (lo == 0, hi == n_out: whole pieces only)
-            if (!p.out.p) p.out = take_buf();
-            p.out.resize(p.n_out + 1);
-            const uint16_t *sym = reinterpret_cast<const uint16_t *>(p.mark.data());
-            const uint8_t *w = p.win.data();
-            uint8_t *o = p.out.data();
-            for (size_t k = lo; k < hi; ++k) { const uint16_t v = sym[k]; o[k] = v < 256 ? (uint8_t)v : w[v & 0x7fffu]; }
-            return;
-        }
         const uint8_t *w = p.win.data();
         uint8_t *o = p.out.data();
         const uint8_t *mk = p.mark.data();
@@ -705,10 +891,11 @@ struct ParGzReader {
                 if (closing || pieces[c].state.load() == 3) return; // (a failed piece on the chain: the consumer reports it when it gets there)
             }
             Piece &p = pieces[c];
-            if (!p.known_window) p.win = W;
+            trace(c, "chain arrives, next piece", p.next_piece);
+            if (!p.known_window || !two_pass) p.win = W; // (the first piece: zeros, never looked at)
             // the window behind the piece
             const size_t t = std::min(p.n_out, WIN), from = p.n_out - t;
-            if (!p.known_window && !two_pass) {
+            if (!two_pass) {
                 const uint16_t *sym = reinterpret_cast<const uint16_t *>(p.mark.data());
                 for (size_t k = 0; k < t; ++k) { const uint16_t v = sym[from + k]; tail[k] = v < 256 ? (uint8_t)v : W[v & 0x7fffu]; }
             } else
@@ -759,6 +946,7 @@ struct ParGzReader {
                 }
                 p = &pieces[cur];
             }
+            trace(cur, "handed out, bytes", p->n_out);
             total_out += p->n_out;
             crcs.emplace_back(0u, p->n_out);
             crc_index.push_back(cur);

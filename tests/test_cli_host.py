@@ -362,3 +362,61 @@ def test_parallel_inflate_reports_damage(tmp_path):
         p.write_bytes(bytes(bad))
         rc, out = _pargz(p, 4, 200000)
         assert rc == 3, "flip at %d: rc %d" % (at, rc)
+
+
+def test_own_inflate_equals_zlib_under_the_sanitizers(tmp_path):
+    """The repository's own inflate (faqcs_pargz.h: byte output for BGZF members, 16-bit symbols for pieces of ordinary gzip files) against
+    zlib on generated streams -- every level and strategy, stored / fixed / dynamic blocks, flushes, starts at block boundaries inside a
+    stream, damaged copies -- in a build with AddressSanitizer and UBSan (tools/inflate_fuzz.cpp says what is compared)."""
+    exe = str(tmp_path / "inflate_fuzz")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                        os.path.join(ROOT, "tools", "inflate_fuzz.cpp"), "-lz"], capture_output=True, timeout=600)
+    if r.returncode != 0 and b"asan" in r.stderr.lower():
+        pytest.skip("no sanitizer runtime in this image")
+    assert r.returncode == 0, r.stderr.decode()
+    seed = os.environ.get("FAQCS_TEST_SEED", "20261004")
+    r = subprocess.run([exe, seed, "250"], capture_output=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr).decode()[-2000:]
+    assert b"250 streams equal to zlib's" in r.stdout
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+def test_bgzf_members_by_the_own_decoder_and_by_zlib(tmp_path, level):
+    """BGZF members are inflated by the repository's decoder (FAQCS_MI_BGZF_ZLIB=1: by zlib): the same bytes either way, for stored blocks
+    (level 0, where a member's deflate data ends with its last stored byte), and the same prefix and exit code for a damaged file."""
+    rng = np.random.Generator(np.random.PCG64([11, level]))
+    data = _fastq_text(9000, seed=level) + bytes(rng.integers(0, 256, 100_000, dtype=np.uint8)) + b"I" * 70000
+    p = str(tmp_path / "x.gz")
+    write_bgzf(p, data, 65280, level=level)
+    outs = []
+    for env in ({}, {"FAQCS_MI_BGZF_ZLIB": "1"}):
+        r = subprocess.run([CLI, "--bgzf_cat", p], capture_output=True, timeout=120, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout == data, (env, r.returncode, len(r.stdout))
+    raw = bytearray(open(p, "rb").read())
+    for at in (len(raw) // 3, len(raw) // 2 + 5, len(raw) - 40):
+        bad = bytearray(raw)
+        bad[at] ^= 0x21
+        q = str(tmp_path / "bad.gz")
+        open(q, "wb").write(bad)
+        outs = [subprocess.run([CLI, "--bgzf_cat", q], capture_output=True, timeout=120, env=dict(os.environ, **env)) for env in ({}, {"FAQCS_MI_BGZF_ZLIB": "1"})]
+        assert outs[0].returncode == outs[1].returncode and outs[0].stdout == outs[1].stdout, at
+        assert data.startswith(outs[0].stdout)
+
+
+def test_crc_by_carry_less_multiplication_is_used_and_can_be_switched_off(tmp_path):
+    """A member's CRC is computed with PCLMULQDQ where the CPU has it (tools/inflate_fuzz.cpp's build checks it against zlib on random
+    lengths through the whole-file tests; here: the same verdicts with FAQCS_MI_NO_PCLMUL=1, i.e. through zlib's crc32)."""
+    import gzip
+
+    text = _fastq_text(40000, seed=8)
+    p = tmp_path / "t.gz"
+    p.write_bytes(gzip.compress(text, 6))
+    for env in ({}, {"FAQCS_MI_NO_PCLMUL": "1"}):
+        r = subprocess.run([CLI, "--pargz_cat", str(p), "4", "150000"], capture_output=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout == text
+    blob = bytearray(p.read_bytes())
+    blob[-6] ^= 1  # the CRC in the trailer
+    p.write_bytes(bytes(blob))
+    for env in ({}, {"FAQCS_MI_NO_PCLMUL": "1"}):
+        r = subprocess.run([CLI, "--pargz_cat", str(p), "4", "150000"], capture_output=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 3
