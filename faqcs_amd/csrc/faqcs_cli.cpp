@@ -413,6 +413,7 @@ struct BgzfReader {
     void work()
     {
         // members are inflated by the repository's own decoder (faqcs_pargz.h, byte output); FAQCS_MI_BGZF_ZLIB=1: by zlib (A/B)
+        FaqcsThreadCpu cpu_note("bgzf inflate worker");
         static const bool use_zlib = [] { const char *e = getenv("FAQCS_MI_BGZF_ZLIB"); return e && atoi(e) != 0; }();
         z_stream z;
         memset(&z, 0, sizeof z);
@@ -559,6 +560,40 @@ static unsigned effective_cpus()
     return hw;
 }
 
+// The byte behind the `want`-th newline of [p, end) (want >= 1), or `end` when there are fewer; taken = the newlines passed.  The reader
+// threads of the streaming path cut their input into blocks of 4 x 32 768 lines with it: 32 bytes a step instead of a memchr per line.
+__attribute__((target("avx2"))) static const char *skip_lines_avx2(const char *p, const char *end, uint32_t want, uint32_t &taken)
+{
+    uint32_t c = 0;
+    const __m256i nl = _mm256_set1_epi8('\n');
+    while (p + 32 <= end) {
+        unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)p), nl));
+        const uint32_t k = (uint32_t)__builtin_popcount(m);
+        if (c + k >= want) { // the newline asked for is one of these
+            for (uint32_t drop = want - c; drop > 1; --drop) m &= m - 1;
+            taken = want;
+            return p + __builtin_ctz(m) + 1;
+        }
+        c += k; p += 32;
+    }
+    for (; p < end; ++p) if (*p == '\n' && ++c == want) { taken = c; return p + 1; }
+    taken = c;
+    return end;
+}
+static const char *skip_lines(const char *p, const char *end, uint32_t want, uint32_t &taken)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return skip_lines_avx2(p, end, want, taken);
+    uint32_t c = 0;
+    while (p < end && c < want) {
+        const char *x = (const char *)memchr(p, '\n', (size_t)(end - p));
+        if (!x) { p = end; break; }
+        p = x + 1; ++c;
+    }
+    taken = c;
+    return p;
+}
+
 struct Source {
     std::string path;
     gzFile gz = nullptr;
@@ -603,6 +638,7 @@ struct Source {
 
     void io_run()
     {
+        FaqcsThreadCpu cpu_note("streaming reader (cuts blocks of lines)");
         std::vector<char> io(16 << 20);
         uint64_t seq_no = 0;
         TextBlock *cur = block_free.pop();
@@ -617,9 +653,8 @@ struct Source {
                 got = pargz.next(chunk);
                 if (got == 0 && pargz.failed) {
                     cur->io_error = true;
-                    // (only the first piece is checked for bytes >= 128; a later one is taken for a window marker and the member's CRC fails)
-                    fprintf(stderr, "faqcs_mi: the parallel inflate of a .gz input ended with an error: a damaged file -- or text with bytes >= 128 behind its first "
-                                    "megabytes, which this reader cannot tell from its own markers (FAQCS_MI_NO_PARGZ=1 reads such a file through gzread)\n");
+                    fprintf(stderr, "faqcs_mi: the parallel inflate of a .gz input ended with an error: the file is damaged or cut short "
+                                    "(FAQCS_MI_NO_PARGZ=1 reads it through zlib's gzread for a second opinion)\n");
                 }
             }
             else {
@@ -634,13 +669,9 @@ struct Source {
             const char *p = chunk, *end = p + got;
             while (p < end) {
                 // take whole lines until the block holds `want` of them
-                const char *q = p;
-                uint32_t lines = cur->n_lines;
-                while (q < end && lines < want) {
-                    const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q));
-                    if (!nl) { q = end; break; }
-                    q = nl + 1; ++lines;
-                }
+                uint32_t taken = 0;
+                const char *q = skip_lines(p, end, want - cur->n_lines, taken);
+                const uint32_t lines = cur->n_lines + taken;
                 cur->text.insert(cur->text.end(), p, q);
                 cur->n_lines = lines;
                 p = q;
@@ -709,6 +740,7 @@ struct Source {
 
     void parse_run()
     {
+        FaqcsThreadCpu cpu_note("streaming parser");
         for (;;) {
             TextBlock *t = block_full.pop();
             if (!t) return;
@@ -1530,6 +1562,7 @@ void process_paired(Run &r)
     std::atomic<bool> failed{false};
     auto release = [&](Work &w) { if (w.left->fetch_sub(1) == 1) { s1.free_q.push(w.b1); s2.free_q.push(w.b2); } };
     auto mate_writer = [&](Queue<Work> &q, OutFile &f, bool second) {
+        FaqcsThreadCpu cpu_note("streaming mate writer");
         std::string s, t;
         for (;;) {
             Work w = q.pop();
@@ -1546,6 +1579,7 @@ void process_paired(Run &r)
     std::thread writer1([&] { mate_writer(q1, f1, false); });
     std::thread writer2([&] { mate_writer(q2, f2, true); });
     std::thread writer([&] {
+        FaqcsThreadCpu cpu_note("streaming gate + unpaired writer");
         std::string s, q;
         bool cur_last = false; // the pair in hand is the input's last one: nothing follows it in the queue
         try {
@@ -2325,6 +2359,8 @@ static int run_command(int argc, char **argv)
             if (!opt.debug) for (const std::string &f : table_files(opt)) unlink(f.c_str());
         }
         tmark("statistics written");
+        { FaqcsThreadCpu main_note("main thread (to this line)"); }
+        FaqcsThreadCpu::report(stderr);
         fflush(nullptr);
         report_done(EXIT_SUCCESS); // (the caller's process returns here)
         _exit(EXIT_SUCCESS); // (device memory, pinned buffers and mappings go with the process)

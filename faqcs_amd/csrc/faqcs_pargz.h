@@ -43,6 +43,36 @@
 #include <thread>
 #include <vector>
 
+// ---- FAQCS_MI_TIMING=1: what each kind of thread did with its life (CPU seconds against seconds alive), printed by faqcs_mi at the end.
+// A role whose threads were busy for all of their life is the stage the others wait for.
+#include <map>
+#include <time.h>
+struct FaqcsThreadCpu {
+    struct Acc { double cpu = 0, alive = 0, max_cpu = 0; unsigned n = 0; };
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static std::map<std::string, Acc> &table() { static std::map<std::string, Acc> t; return t; }
+    static bool on() { static const bool v = getenv("FAQCS_MI_TIMING") != nullptr; return v; }
+    static double clock_s(clockid_t c) { timespec ts; clock_gettime(c, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+    const char *role;
+    double t0 = 0;
+    explicit FaqcsThreadCpu(const char *r) : role(r) { if (on()) t0 = clock_s(CLOCK_MONOTONIC); }
+    ~FaqcsThreadCpu()
+    {
+        if (!on()) return;
+        const double cpu = clock_s(CLOCK_THREAD_CPUTIME_ID), alive = clock_s(CLOCK_MONOTONIC) - t0;
+        std::lock_guard<std::mutex> l(mu());
+        Acc &a = table()[role];
+        a.cpu += cpu; a.alive += alive; a.max_cpu = std::max(a.max_cpu, cpu); ++a.n;
+    }
+    static void report(FILE *f)
+    {
+        if (!on()) return;
+        std::lock_guard<std::mutex> l(mu());
+        for (const auto &kv : table())
+            fprintf(f, "[faqcs_mi] threads '%s': %u, %.3f CPU-s of %.3f s alive (the busiest %.3f CPU-s)\n", kv.first.c_str(), kv.second.n, kv.second.cpu, kv.second.alive, kv.second.max_cpu);
+    }
+};
+
 // ---- CRC-32 (the gzip polynomial) by carry-less multiplication: zlib's table-driven crc32 does about 1 GB/s on a core, which made the
 // CRC of a piece a sixth of the inflate's CPU time.  Folding of 64 bytes a step with PCLMULQDQ (Gopal et al., "Fast CRC Computation
 // for Generic Polynomials Using PCLMULQDQ Instruction", Intel 2009; the constants are the paper's for the reflected polynomial
@@ -120,7 +150,9 @@ __attribute__((target("avx2"))) static inline bool faqcs_narrow_avx2(const uint1
     for (; k + 32 <= n; k += 32) {
         const __m256i a = _mm256_loadu_si256((const __m256i *)(sym + k)), b = _mm256_loadu_si256((const __m256i *)(sym + k + 16));
         if (_mm256_movemask_epi8(_mm256_or_si256(a, b)) & 0xAAAAAAAAu) { // a marker among the 32 (the top bit of a symbol)
-            for (size_t t = k; t < k + 32; ++t) { const uint16_t v = sym[t]; o[t] = v < 256 ? (uint8_t)v : w[v & 0x7fffu]; }
+            // without a branch per symbol: in the pieces of a FASTQ file 12 - 30 % of the symbols are markers, in no order a predictor could learn
+            // (the window is read for a literal too -- at its own value, which is inside it -- and not used)
+            for (size_t t = k; t < k + 32; ++t) { const uint32_t v = sym[t]; const uint8_t m = w[v & 0x7fffu]; o[t] = (v & 0x8000u) ? m : (uint8_t)v; }
             any = true;
             continue;
         }
@@ -231,15 +263,18 @@ struct ParGzReader {
         static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
         uint8_t pl[19];
         memset(pl, 0, sizeof pl);
-        uint64_t at = bit + 17;
-        unsigned kraft = 0;
-        for (unsigned i = 0; i < hclen; ++i) {
-            const unsigned l = (unsigned)(peek(at) & 7);
-            at += 3;
-            pl[order[i]] = (uint8_t)l;
-            if (l) kraft += 128u >> l;
-        }
-        if (kraft != 128) return false; // the precode must be complete (inftrees.c: an incomplete CODES set is an error)
+        uint64_t at = bit + 17 + 3 * (uint64_t)hclen;
+        uint64_t pv = peek(bit + 17) & ((1ull << (3 * hclen)) - 1); // (<= 57 bits: the fields of three bits, 19 at most)
+        // the precode must be complete (inftrees.c: an incomplete CODES set is an error): the Kraft sum, four fields per look-up --
+        // all but one in 200 of the positions that come this far leave here
+        static const std::vector<uint16_t> kraft4 = [] {
+            std::vector<uint16_t> t(4096);
+            for (unsigned x = 0; x < 4096; ++x) { unsigned k = 0; for (unsigned f = 0; f < 4; ++f) { const unsigned l = (x >> (3 * f)) & 7; if (l) k += 128u >> l; } t[x] = (uint16_t)k; }
+            return t;
+        }();
+        const uint16_t *k4 = kraft4.data();
+        if (k4[pv & 4095] + k4[(pv >> 12) & 4095] + k4[(pv >> 24) & 4095] + k4[(pv >> 36) & 4095] + k4[(pv >> 48) & 4095] != 128) return false;
+        for (unsigned i = 0; i < hclen; ++i) { pl[order[i]] = (uint8_t)(pv & 7); pv >>= 3; }
         // canonical codes of the precode, a 7-bit look-up (code bits arrive LSB first: the table is indexed by the reversed code)
         uint8_t sym_of[128], len_of[128];
         {
@@ -281,6 +316,28 @@ struct ParGzReader {
             return mx == 1;                               // incomplete: only the one-code case is accepted
         };
         return complete(lens, hlit, false) && complete(lens + hlit, hdist, true);
+    }
+
+    // the first bit position in [lo, hi) at which plausible_block() holds (NO_START: none).  Eight positions per 64-bit load are tested for
+    // the three header bits and the two counts before the function is called: 8 of 9 positions leave here
+    uint64_t find_plausible(uint64_t lo, uint64_t hi) const
+    {
+        uint64_t b = lo;
+        while (b < hi) {
+            const size_t by = (size_t)(b >> 3);
+            if (by + 8 > size) { if (plausible_block(b)) return b; ++b; continue; }
+            uint64_t v;
+            memcpy(&v, base + by, 8);
+            for (unsigned i = (unsigned)(b & 7); i < 8; ++i) {
+                const uint64_t x = v >> i;
+                if ((x & 7) != 4 || ((x >> 3) & 31) > 29 || ((x >> 8) & 31) > 29) continue;
+                const uint64_t cand = (uint64_t)by * 8 + i;
+                if (cand >= hi) return NO_START;
+                if (plausible_block(cand)) return cand;
+            }
+            b = ((uint64_t)by + 1) * 8;
+        }
+        return NO_START;
     }
 
     // ---- a raw inflate that starts at a bit position with a given 32 KB dictionary ----
@@ -689,6 +746,7 @@ struct ParGzReader {
     // ---- workers ----
     void work()
     {
+        FaqcsThreadCpu cpu_note("gzip inflate worker");
         for (;;) {
             size_t i = 0;
             bool crc_job = false;
@@ -740,8 +798,12 @@ struct ParGzReader {
             trace(i, "claimed");
             const uint64_t lo = range_begin_bit(i), hi = std::min<uint64_t>(range_begin_bit(i + 1), (uint64_t)size * 8);
             uint64_t s = NO_START;
-            for (uint64_t b = lo; b < hi; ++b)
-                if (plausible_block(b) && trial(b)) { s = b; break; }
+            for (uint64_t b = lo; b < hi;) {
+                const uint64_t c = find_plausible(b, hi);
+                if (c == NO_START) break;
+                if (trial(c)) { s = c; break; }
+                b = c + 1;
+            }
             { std::lock_guard<std::mutex> l(m); p.start_bit.store(s); if (s == NO_START) p.state.store(3); }
             cv_done.notify_all(); // (a predecessor may be waiting to learn where this piece starts)
             trace(i, "start found at bit", (size_t)(s - lo));
@@ -882,6 +944,7 @@ struct ParGzReader {
     // (a sequential step of 32 KB per piece); the piece's other bytes are left to a worker (patch + CRC task).
     void chain()
     {
+        FaqcsThreadCpu cpu_note("gzip window chain");
         std::vector<uint8_t> W(WIN, 0), tail(WIN);
         size_t c = 0;
         for (;;) {

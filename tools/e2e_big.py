@@ -80,23 +80,31 @@ if os.environ.get("FAQCS_E2E_GZ"):
                     f.write(c.compress(data[o:o + (1 << 24)]))
                 f.write(c.flush())
             gz_sets["gzip"].append(p + ".plain.gz")
+    import resource
+    variants = {"bgzf": [("", {}), (" (members through zlib: FAQCS_MI_BGZF_ZLIB=1)", {"FAQCS_MI_BGZF_ZLIB": "1"})],
+                "gzip": [("", {}), (" (round 5's two zlib passes per piece: FAQCS_MI_PARGZ_TWO_PASS=1)", {"FAQCS_MI_PARGZ_TWO_PASS": "1"}),
+                         (" (through gzread, one thread per file: FAQCS_MI_NO_PARGZ=1)", {"FAQCS_MI_NO_PARGZ": "1"})]}
     for tag, gp in gz_sets.items():
-        out = os.path.join(base, "out")
-        subprocess.run(["rm", "-rf", out])
-        t0 = time.perf_counter()
-        r = subprocess.run([cli, "-1", gp[0], "-2", gp[1], "-d", out, "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + sys.argv[2:],
-                           env=dict(os.environ, FAQCS_MI_TIMING="1"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        dt = time.perf_counter() - t0
-        print("%s input (%.2f GB compressed per file): %d pairs in %.3f s = %.1f M reads/s (rc %d)" % (tag, os.path.getsize(gp[0]) / 1e9, n, dt, 2 * n / dt / 1e6, r.returncode))
-        # the same in ONE process, so that its CPU time and page faults can be read (the default mode leaves them in a detached worker)
-        import resource
-        subprocess.run(["rm", "-rf", out])
-        r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
-        t0 = time.perf_counter()
-        r = subprocess.run([cli, "-1", gp[0], "-2", gp[1], "-d", out, "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + sys.argv[2:],
-                           env=dict(os.environ, FAQCS_MI_NO_FORK="1"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        dt = time.perf_counter() - t0
-        r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
-        print("%s input, one process: %.3f s wall, %.1f s user, %.1f s system, %d minor faults (rc %d)"
-              % (tag, dt, r1.ru_utime - r0.ru_utime, r1.ru_stime - r0.ru_stime, r1.ru_minflt - r0.ru_minflt, r.returncode))
+        for what, extra in variants[tag]:
+            for rep in range(1 if "NO_PARGZ" in "".join(extra) else 2):
+                out = os.path.join(base, "out")
+                subprocess.run(["rm", "-rf", out])
+                t0 = time.perf_counter()
+                r = subprocess.run([cli, "-1", gp[0], "-2", gp[1], "-d", out, "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + sys.argv[2:],
+                                   env=dict(os.environ, FAQCS_MI_TIMING="1", **extra), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                dt = time.perf_counter() - t0
+                print("%s input%s (%.2f GB compressed per file): %d pairs in %.3f s = %.1f M reads/s (rc %d)" % (tag, what, os.path.getsize(gp[0]) / 1e9, n, dt, 2 * n / dt / 1e6, r.returncode))
+            for line in r.stderr.decode(errors="replace").splitlines():  # (the last repeat's threads, by role: FAQCS_MI_TIMING)
+                if "threads '" in line or "main thread:" in line or "parsers:" in line:
+                    print("    " + line)
+            # the same in ONE process, so that its CPU time and page faults can be read (the default mode leaves them in a detached worker)
+            subprocess.run(["rm", "-rf", out])
+            r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "-1", gp[0], "-2", gp[1], "-d", out, "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + sys.argv[2:],
+                               env=dict(os.environ, FAQCS_MI_NO_FORK="1", **extra), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+            r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+            print("%s input%s, one process: %.3f s wall, %.1f s user, %.1f s system, %d minor faults (rc %d)"
+                  % (tag, what, dt, r1.ru_utime - r0.ru_utime, r1.ru_stime - r0.ru_stime, r1.ru_minflt - r0.ru_minflt, r.returncode))
 subprocess.run(["rm", "-rf", base])
