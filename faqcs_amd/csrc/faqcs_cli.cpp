@@ -1550,8 +1550,12 @@ void process_paired(Run &r)
 {
     Opt &opt = r.opt;
     Source s1, s2;
-    try { s1.start(opt.in1, 12, r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read one sequences\n", opt.in1.c_str()); throw; }
-    try { s2.start(opt.in2, 12, r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read two sequences\n", opt.in2.c_str()); throw; }
+    // 32 768-read buffers per input file between its reader and the writers (FAQCS_MI_STREAM_BUFS: 4 ... 64)
+    const int n_stream_bufs = [] { const char *e = getenv("FAQCS_MI_STREAM_BUFS"); const int v = e ? atoi(e) : 0; return v >= 4 && v <= 64 ? v : 12; }();
+    tmark("streaming: opening the inputs");
+    try { s1.start(opt.in1, n_stream_bufs, r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read one sequences\n", opt.in1.c_str()); throw; }
+    try { s2.start(opt.in2, n_stream_bufs, r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read two sequences\n", opt.in2.c_str()); throw; }
+    tmark("streaming: inputs open, readers running");
     OutFile f1, f2, fu, fd;
     if (!opt.qc_only) { f1.open(opt.out1); f2.open(opt.out2); fu.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); }
     // Output side: a gate thread waits for the device, applies the reference's "trim() threw, nothing of this buffer is
@@ -1648,15 +1652,19 @@ void process_paired(Run &r)
                 if (r.in_off != r.detect(b2)) { fprintf(stderr, "Inconsistent quality offset detection between reads one and two\n"); throw Fatal("FaQCs.cpp:process_paired: I/O Error"); }
             }
             if (last || check_for_next_seq) { r.nextseq_check(b1); check_for_next_seq = false; } // Q16: also on the last buffer
+            if (pair_no == 0) tmark("streaming: first pair of buffers parsed");
             r.ensure_ctx();
+            if (pair_no == 0) tmark("streaming: device context ready");
             r.submit(b1, pair_no); r.submit(b2, pair_no);
             ++pair_no;
+            if (last) tmark("streaming: last pair of buffers submitted");
             Work w; w.b1 = b1; w.b2 = b2; w.last = last;
             wq.push(w);
             if (last) break;
         }
     } catch (std::exception &e) { merr = e.what(); wq.push(Work()); }
     writer.join(); writer1.join(); writer2.join();
+    tmark("streaming: paired outputs written");
     if (!merr.empty() || !werr.empty()) { // unblock the readers, then report like the reference's catch in main()
         f1.close(); f2.close(); fu.close(); fd.close();
         fprintf(stderr, "Caught the error %s\n", (!werr.empty() ? werr : merr).c_str());
@@ -2208,12 +2216,13 @@ int host_self_check(int argc, char **argv)
         if (!r.open(argv[2], nt, piece)) { fprintf(stderr, "not eligible (not ASCII, or the first piece does not inflate)\n"); return 4; }
         const char *data;
         size_t n;
-        while ((n = r.next(data)) != 0) fwrite(data, 1, n, stdout);
+        const char *nap = getenv("FAQCS_PARGZ_CAT_SLEEP_US"); // (tests: a consumer slower than the inflate)
+        while ((n = r.next(data)) != 0) { fwrite(data, 1, n, stdout); if (nap) usleep((useconds_t)atoi(nap)); }
         const bool bad = r.failed;
         if (getenv("FAQCS_PARGZ_STATS")) {
             size_t used = 0, dep = 0;
             for (size_t k : r.crc_index) { ++used; (void)k; }
-            fprintf(stderr, "pieces %zu (of %zu bytes), on the chain %zu, bytes out %zu, failed %d\n", r.n_pieces, r.piece_bytes, used, r.total_out, (int)bad);
+            fprintf(stderr, "pieces %zu (of %zu bytes), on the chain %zu, bytes out %zu, failed %d\n", r.armed_pieces, r.piece_bytes, used, r.total_out, (int)bad);
             (void)dep;
         }
         r.close();

@@ -212,6 +212,7 @@ struct ParGzReader {
     size_t next_claim = 0;       // next piece index a worker may claim
     size_t consumed = 0;         // pieces the consumer is done with (chain order, but indices only grow)
     size_t window_pieces = 0;    // how many pieces may be in flight behind `consumed`
+    size_t armed_pieces = 0;     // (statistics) the pieces of the member armed last
     bool closing = false;
     bool failed = false;
     bool stop_claims = false;    // the member's last block has been seen by the chain: no piece behind it belongs to this member
@@ -696,10 +697,14 @@ struct ParGzReader {
     {
         data_begin = header_end(member_off);
         if (!data_begin) return false;
-        piece_bytes = piece_arg ? piece_arg : std::max<size_t>(512u << 10, std::min<size_t>(4u << 20, (size - data_begin) / (size_t)(8 * n_workers) + 1));
+        size_t piece_max = 4u << 20;
+        if (const char *e = getenv("FAQCS_MI_PARGZ_PIECE")) { const long long v = atoll(e); if (v >= (64 << 10) && v <= (64 << 20)) piece_max = (size_t)v; }
+        piece_bytes = piece_arg ? piece_arg : std::max<size_t>(std::min<size_t>(512u << 10, piece_max), std::min<size_t>(piece_max, (size - data_begin) / (size_t)(8 * n_workers) + 1));
         n_pieces = (size - data_begin + piece_bytes - 1) / piece_bytes;
+        armed_pieces = n_pieces;
         pieces = std::vector<Piece>(n_pieces);
         window_pieces = (size_t)(3 * n_workers + 2);
+        if (const char *e = getenv("FAQCS_MI_PARGZ_WINDOW")) { const long v = atol(e); if (v >= n_workers + 2 && v <= 1024) window_pieces = (size_t)v; } // (pieces in flight: memory against slack)
         closing = false; stop_claims = false; cancel_from.store(~(size_t)0);
         next_claim = 1; consumed = 0; cur = 0; hold = 0; release_lo = 0;
         member_done = false; total_out = 0;
@@ -797,14 +802,17 @@ struct ParGzReader {
             Piece &p = pieces[i];
             trace(i, "claimed");
             const uint64_t lo = range_begin_bit(i), hi = std::min<uint64_t>(range_begin_bit(i + 1), (uint64_t)size * 8);
-            uint64_t s = NO_START;
-            for (uint64_t b = lo; b < hi;) {
-                const uint64_t c = find_plausible(b, hi);
-                if (c == NO_START) break;
-                if (trial(c)) { s = c; break; }
-                b = c + 1;
+            uint64_t s = p.start_bit.load(); // (not 0: the piece in front ended inside this range before anybody had claimed it -- that boundary is the start)
+            if (s == 0) {
+                s = NO_START;
+                for (uint64_t b = lo; b < hi;) {
+                    const uint64_t c = find_plausible(b, hi);
+                    if (c == NO_START) break;
+                    if (trial(c)) { s = c; break; }
+                    b = c + 1;
+                }
             }
-            { std::lock_guard<std::mutex> l(m); p.start_bit.store(s); if (s == NO_START) p.state.store(3); }
+            { std::lock_guard<std::mutex> l(m); if (p.start_bit.load() != 0) s = p.start_bit.load(); p.start_bit.store(s); if (s == NO_START) p.state.store(3); }
             cv_done.notify_all(); // (a predecessor may be waiting to learn where this piece starts)
             trace(i, "start found at bit", (size_t)(s - lo));
             if (s == NO_START) continue;
@@ -834,8 +842,16 @@ struct ParGzReader {
                 std::unique_lock<std::mutex> l(m);
                 while (!closing && pieces[j].start_bit.load() == 0 && pieces[j].state.load() != 0) cv_done.wait(l);
                 if (closing) { p.state.store(3); abort = true; return false; }
-                s = pieces[j].state.load() == 0 ? NO_START : pieces[j].start_bit.load();
-                if (pieces[j].state.load() == 0) { if (next_claim == j) ++next_claim; pieces[j].state.store(3); pieces[j].start_bit.store(NO_START); } // nobody will start it: this piece runs through it
+                if (pieces[j].state.load() == 0) {
+                    // Nobody has claimed piece j yet (the pieces in flight are as many as may be: the consumer is the slower side).  This
+                    // block boundary IS where the text of piece j's range begins: it becomes j's start -- whoever claims j need not look
+                    // for one -- and this piece ends here.  (Round 6 at first ran on THROUGH such a piece: behind a slow consumer one
+                    // worker after the other did, and the whole file was inflated by single threads into buffers of gigabytes --
+                    // profiles/r6m/e2e_gz_knobs2.txt: 2.5 instead of 11 M reads/s whenever the window was a little smaller.)
+                    if (pieces[j].start_bit.load() == 0 && here < range_begin_bit(j + 1)) { pieces[j].start_bit.store(here); return true; }
+                    if (pieces[j].start_bit.load() == 0) { if (next_claim == j) ++next_claim; pieces[j].state.store(3); pieces[j].start_bit.store(NO_START); } // (no block starts inside it)
+                }
+                s = pieces[j].start_bit.load();
             }
             if (s == here) return true;
             if (s == NO_START || s < here) { ++j; continue; } // no start there, or one this chain never arrived at: dropped

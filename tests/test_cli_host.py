@@ -420,3 +420,24 @@ def test_crc_by_carry_less_multiplication_is_used_and_can_be_switched_off(tmp_pa
     for env in ({}, {"FAQCS_MI_NO_PCLMUL": "1"}):
         r = subprocess.run([CLI, "--pargz_cat", str(p), "4", "150000"], capture_output=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode == 3
+
+
+def test_parallel_inflate_behind_a_slow_consumer_stays_parallel(tmp_path):
+    """When the consumer is the slower side every piece that may be in flight is, and a worker that finishes the last of them finds the
+    next piece unclaimed.  It must END there -- the block boundary it stands at becomes that piece's start -- and not inflate on through
+    it: round 6's first version did, and behind a slow consumer one worker after the other ran on to the end of the file (2.5 instead of
+    11 M reads/s on the GPU box whenever fewer pieces were allowed in flight, profiles/r6m/).  Counted here: the pieces on the chain."""
+    import gzip
+    import re
+
+    text = _fastq_text(60000, seed=12)
+    p = tmp_path / "slow.gz"
+    p.write_bytes(gzip.compress(text, 6))
+    for window in ("6", "9", "14"):
+        r = subprocess.run([CLI, "--pargz_cat", str(p), "4", "100000"], capture_output=True, timeout=300,
+                           env=dict(os.environ, FAQCS_MI_PARGZ_WINDOW=window, FAQCS_PARGZ_CAT_SLEEP_US="3000", FAQCS_PARGZ_STATS="1"))
+        assert r.returncode == 0 and r.stdout == text
+        m = re.search(rb"pieces (\d+) \(of \d+ bytes\), on the chain (\d+)", r.stderr)
+        assert m, r.stderr
+        n_pieces, on_chain = int(m.group(1)), int(m.group(2))
+        assert n_pieces > 40 and on_chain >= n_pieces - 2, (window, n_pieces, on_chain)

@@ -82,7 +82,8 @@ if os.environ.get("FAQCS_E2E_GZ"):
             gz_sets["gzip"].append(p + ".plain.gz")
     import resource
     variants = {"bgzf": [("", {}), (" (members through zlib: FAQCS_MI_BGZF_ZLIB=1)", {"FAQCS_MI_BGZF_ZLIB": "1"})],
-                "gzip": [("", {}), (" (round 5's two zlib passes per piece: FAQCS_MI_PARGZ_TWO_PASS=1)", {"FAQCS_MI_PARGZ_TWO_PASS": "1"}),
+                "gzip": [("", {})] + [(" (%s)" % v, dict(kv.split("=") for kv in v.split())) for v in os.environ.get("FAQCS_E2E_GZ_TRY", "").split(";") if v] +
+                        [(" (round 5's two zlib passes per piece: FAQCS_MI_PARGZ_TWO_PASS=1)", {"FAQCS_MI_PARGZ_TWO_PASS": "1"}),
                          (" (through gzread, one thread per file: FAQCS_MI_NO_PARGZ=1)", {"FAQCS_MI_NO_PARGZ": "1"})]}
     for tag, gp in gz_sets.items():
         for what, extra in variants[tag]:
@@ -95,7 +96,7 @@ if os.environ.get("FAQCS_E2E_GZ"):
                 dt = time.perf_counter() - t0
                 print("%s input%s (%.2f GB compressed per file): %d pairs in %.3f s = %.1f M reads/s (rc %d)" % (tag, what, os.path.getsize(gp[0]) / 1e9, n, dt, 2 * n / dt / 1e6, r.returncode))
             for line in r.stderr.decode(errors="replace").splitlines():  # (the last repeat's threads, by role: FAQCS_MI_TIMING)
-                if "threads '" in line or "main thread:" in line or "parsers:" in line:
+                if "threads '" in line or "main thread:" in line or "parsers:" in line or (os.environ.get("FAQCS_E2E_MARKS") and "[faqcs_mi" in line):
                     print("    " + line)
             # the same in ONE process, so that its CPU time and page faults can be read (the default mode leaves them in a detached worker)
             subprocess.run(["rm", "-rf", out])
