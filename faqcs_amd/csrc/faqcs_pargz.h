@@ -697,13 +697,13 @@ struct ParGzReader {
     {
         data_begin = header_end(member_off);
         if (!data_begin) return false;
-        size_t piece_max = 4u << 20;
+        size_t piece_max = 2u << 20; // (4 MB until profiles/r6n/: 2.3 x that of text and 4.6 x of symbols per piece in flight)
         if (const char *e = getenv("FAQCS_MI_PARGZ_PIECE")) { const long long v = atoll(e); if (v >= (64 << 10) && v <= (64 << 20)) piece_max = (size_t)v; }
         piece_bytes = piece_arg ? piece_arg : std::max<size_t>(std::min<size_t>(512u << 10, piece_max), std::min<size_t>(piece_max, (size - data_begin) / (size_t)(8 * n_workers) + 1));
         n_pieces = (size - data_begin + piece_bytes - 1) / piece_bytes;
         armed_pieces = n_pieces;
         pieces = std::vector<Piece>(n_pieces);
-        window_pieces = (size_t)(3 * n_workers + 2);
+        window_pieces = (size_t)(2 * n_workers + 2); // (3 n + 2 until the sweep of profiles/r6n/: the same speed from 12 ... 26 pieces in flight once a piece in front of an unclaimed one ends there; fewer = less memory to fault in)
         if (const char *e = getenv("FAQCS_MI_PARGZ_WINDOW")) { const long v = atol(e); if (v >= n_workers + 2 && v <= 1024) window_pieces = (size_t)v; } // (pieces in flight: memory against slack)
         closing = false; stop_claims = false; cancel_from.store(~(size_t)0);
         next_claim = 1; consumed = 0; cur = 0; hold = 0; release_lo = 0;
@@ -847,7 +847,7 @@ struct ParGzReader {
                     // block boundary IS where the text of piece j's range begins: it becomes j's start -- whoever claims j need not look
                     // for one -- and this piece ends here.  (Round 6 at first ran on THROUGH such a piece: behind a slow consumer one
                     // worker after the other did, and the whole file was inflated by single threads into buffers of gigabytes --
-                    // profiles/r6m/e2e_gz_knobs2.txt: 2.5 instead of 11 M reads/s whenever the window was a little smaller.)
+                    // profiles/r6n/e2e_gz_knobs_before_the_fix.txt: 2.5 instead of 11 M reads/s whenever the window was a little smaller.)
                     if (pieces[j].start_bit.load() == 0 && here < range_begin_bit(j + 1)) { pieces[j].start_bit.store(here); return true; }
                     if (pieces[j].start_bit.load() == 0) { if (next_claim == j) ++next_claim; pieces[j].state.store(3); pieces[j].start_bit.store(NO_START); } // (no block starts inside it)
                 }

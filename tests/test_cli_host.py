@@ -426,7 +426,7 @@ def test_parallel_inflate_behind_a_slow_consumer_stays_parallel(tmp_path):
     """When the consumer is the slower side every piece that may be in flight is, and a worker that finishes the last of them finds the
     next piece unclaimed.  It must END there -- the block boundary it stands at becomes that piece's start -- and not inflate on through
     it: round 6's first version did, and behind a slow consumer one worker after the other ran on to the end of the file (2.5 instead of
-    11 M reads/s on the GPU box whenever fewer pieces were allowed in flight, profiles/r6m/).  Counted here: the pieces on the chain."""
+    11 M reads/s on the GPU box whenever fewer pieces were allowed in flight, profiles/r6n/e2e_gz_knobs_before_the_fix.txt).  Counted here: the pieces on the chain."""
     import gzip
     import re
 
