@@ -95,3 +95,9 @@ prof bench_plain_43Mpairs python3 bench.py --pairs 42949630 --steps 3 --no-cpu-b
 prof bench_kmer_25Mpairs python3 bench.py --config kmer --steps 2 --no-cpu-baseline
 prof bench_adapter_43Mpairs python3 bench.py --config adapter --pairs 42949630 --steps 2 --no-cpu-baseline --e2e-pairs 0
 ls -la $out
+# 5. compressed input end to end (plain / BGZF / ordinary gzip with the A/B switches of the inflate work), with the per-role thread accounting
+FAQCS_E2E_GZ=1 timeout 1500 python3 tools/e2e_big.py 8e6 2>&1 < /dev/null | grep -E "^mapped|^streaming|input|threads .|main thread:|parsers:" > $out/e2e_gz_8Mpairs.txt
+rm -rf /dev/shm/faqcs_e2e_big
+# 6. the whole GPU suite on this build
+timeout 900 python -m pytest tests -x -q -m gpu > $out/gpu_suite.txt 2>&1 < /dev/null
+tail -2 $out/gpu_suite.txt
