@@ -793,10 +793,13 @@ size_t id_len(const char *d, size_t len)
 // run state
 // ---------------------------------------------------------------------------------------------------------
 struct OutFile {
-    FILE *f = nullptr; std::vector<char> buf;
-    void open(const std::string &p) { f = fopen(p.c_str(), "wb"); if (!f) throw Fatal("I/O error"); buf.reserve(8 << 20); }
-    void put(const char *p, size_t n) { buf.insert(buf.end(), p, p + n); if (buf.size() > (6u << 20)) flush(); }
-    void flush() { if (f && !buf.empty()) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); } }
+    FILE *f = nullptr; std::vector<char> buf; size_t n = 0;
+    void open(const std::string &p) { f = fopen(p.c_str(), "wb"); if (!f) throw Fatal("I/O error"); buf.resize(8 << 20); n = 0; }
+    // room for `need` more bytes at the returned address (the caller adds what it wrote to n): a record is assembled with one capacity
+    // check, not one per field
+    char *room(size_t need) { if (n + need > buf.size()) { flush(); if (need > buf.size()) buf.resize(need); } return buf.data() + n; }
+    void put(const char *p, size_t len) { char *d = room(len); memcpy(d, p, len); n += len; }
+    void flush() { if (f && n) fwrite(buf.data(), 1, n, f); n = 0; }
     void close() { flush(); if (f) fclose(f); f = nullptr; }
 };
 
@@ -969,16 +972,19 @@ struct Run {
     {
         const faqcs_read_result &x = b->res[i];
         const uint32_t o = b->off[i], len = b->off[i + 1] - o;
-        f.put(b->def(i), b->deflen(i)); f.put("\n", 1);
+        const size_t dl = b->deflen(i), kept = x.len;
+        char *d = f.room(dl + 2 * kept + 5); // def \n seq \n + \n qual \n
+        memcpy(d, b->def(i), dl); d += dl; *d++ = '\n';
         const uint8_t *sp = b->seq + o, *qp = b->qual + o;
         if (prm.replace_to_N_q == 0 && prm.input_quality_offset == prm.output_quality_offset && len && sp[0] != 'N' && sp[len - 1] != 'N') {
             // no byte of this record is edited (trim.cpp:390-403,516-525,1191-1216): copy the kept window
-            f.put((const char *)sp + x.start, x.len); f.put("\n+\n", 3); f.put((const char *)qp + x.start, x.len); f.put("\n", 1);
-            return;
+            memcpy(d, sp + x.start, kept); d += kept; memcpy(d, "\n+\n", 3); d += 3; memcpy(d, qp + x.start, kept); d += kept; *d++ = '\n';
+        } else {
+            (void)s; (void)q;
+            faqcs_apply_edits(&prm, sp, qp, len, &x, (uint8_t *)d, (uint8_t *)d + kept + 3); // (the edited window straight into the record)
+            d += kept; memcpy(d, "\n+\n", 3); d += 3 + kept; *d++ = '\n';
         }
-        s.resize(x.len); q.resize(x.len);
-        faqcs_apply_edits(&prm, sp, qp, len, &x, (uint8_t *)&s[0], (uint8_t *)&q[0]);
-        f.put(s.data(), s.size()); f.put("\n+\n", 3); f.put(q.data(), q.size()); f.put("\n", 1);
+        f.n += dl + 2 * kept + 5;
     }
     static void write_raw(OutFile &f, const RecBuf *b, uint32_t i)
     {
