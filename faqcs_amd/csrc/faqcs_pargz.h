@@ -1,22 +1,25 @@
-// faqcs_pargz.h -- parallel inflate of an ORDINARY (single-member) gzip file: what real FaQCs users feed it (fastq.cpp:8-125 reads
-// through gzread, one thread).  Host code only (zlib + threads); used by faqcs_cli.cpp's Source and by `faqcs_mi --pargz_cat`.
+// faqcs_pargz.h -- parallel inflate of an ORDINARY gzip file: what real FaQCs users feed it (fastq.cpp:8-125 reads through gzread, one
+// thread).  Host code only (threads, an own inflate, zlib for the start trials and the serial rest); used by faqcs_cli.cpp's Source,
+// its BgzfReader and `faqcs_mi --pargz_cat`.  Not part of libfaqcs_mi.so.
 //
-// A deflate stream has no index, and a block can refer to the 32 KB in front of it.  The approach is rapidgzip's / pugz's, built on zlib:
+// A deflate stream has no index, and a block can refer to the 32 KB in front of it.  The approach is rapidgzip's / pugz's:
 //   1. the compressed file is cut at fixed byte offsets; the worker of a piece looks for the first bit position at or behind its offset
 //      that can start a dynamic-Huffman block -- a complete precode, valid repeat codes, an end-of-block code, complete literal / distance
 //      codes (what zlib's inflate_table accepts): about one bit position in a million passes, and a trial inflate decides;
-//   2. it inflates from there, block by block (Z_BLOCK gives the bit position of every block boundary), until it stands exactly where a
-//      later piece's worker started -- a start that no predecessor arrives at was a false positive and is dropped (its predecessor simply
-//      goes on through it);
-//   3. the window in front of a piece is unknown, so the piece is inflated TWICE with dictionaries that encode the window OFFSET instead
-//      of its contents: D1[k] = k & 255, D2[k] = 128 | k >> 8.  FASTQ is ASCII: a byte >= 128 in the second output is a byte that came
-//      (through any chain of copies) from window position k = out1 | (out2 & 127) << 8 -- markers propagate through copies by themselves;
+//   2. it inflates from there, block by block, until it stands exactly where a later piece's worker started -- a start that no
+//      predecessor arrives at was a false positive and is dropped (its predecessor goes on through it).  A piece nobody has claimed yet
+//      is NOT run through: the block boundary becomes that piece's start and the worker ends there (the consumer is the slower side then);
+//   3. the window in front of a piece is unknown, so the piece is inflated by this file's own decoder (MarkerInflate) into 16-bit SYMBOLS:
+//      a byte, or 0x8000 | k = "the byte at offset k of the unknown window".  A copy that reaches in front of the piece writes such
+//      markers, one that copies markers copies them on: ONE pass, out of band, any text.  (Round 5 made two zlib passes with dictionaries
+//      that encode the offset in the bytes and needed ASCII: FAQCS_MI_PARGZ_TWO_PASS=1 keeps that path for A/B.)
 //   4. a chain thread walks the pieces in file order and resolves only the LAST 32 KB of each -- the window of the next one --; the bulk of
-//      a piece (in FASTQ a quarter of the bytes reach back into the unknown window through chains of copies: every header line copies the
-//      one before) is patched by the workers in parallel once its window is known, together with its CRC-32; the consumer hands the
-//      patched pieces out in order; the CRCs (crc32_combine) must equal the member's trailer at the end, as must the length: a file that
-//      is not ASCII, or any slip of the speculation, ends the input with an error (like a corrupt file under gzread), it never yields
-//      different bytes silently.
+//      a piece (in FASTQ 12 - 30 % of the symbols are markers: every header line copies the one before, through any chain of copies) is
+//      narrowed to bytes by the workers in parallel once its window is known, 64 KB at a time together with its CRC-32 (PCLMULQDQ); the
+//      consumer hands the pieces out in order; the CRCs (crc32_combine) must equal the member's trailer at the end, as must the length:
+//      any slip of the speculation ends the input with an error (like a corrupt file under gzread), it never yields different bytes silently.
+// The decoder (one shift of the bit buffer per code, the next entry loaded before a match is copied) also has a byte-output form for
+// streams whose beginning is known: faqcs_cli.cpp's BgzfReader inflates BGZF members with it.
 // What follows a member (concatenated members: `cat lane1.gz lane2.gz`, which gzread reads as one stream) starts the same machinery
 // again at the next member's header when enough of the file is left; a short rest goes through zlib's gzip decoder in the consumer.
 // When a member's last block has been seen, nobody claims a piece any more and the buffers of the pieces behind it are given back:

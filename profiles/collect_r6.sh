@@ -72,6 +72,7 @@ except Exception as e:
 PY
 # 2. the driver's command: the headline + BASELINE's adapter and k-mer configurations + cpu_baseline (best of -t 1/8/16/all) + e2e
 b > $out/bench_default_all_configs.json
+[ "${2:-}" = counters ] && { ls -la $out; exit 0; }   # (bash profiles/collect_r6.sh <tag> counters: the stamped counter files and the driver's line only)
 # 3. other shapes / configurations through the same harness
 for L in 100 125 250 300; do b --read-len $L --pairs 40e6 --no-cpu-baseline --e2e-pairs 0 --no-other-configs > $out/bench_plain_${L}bp_40Mpairs.json; done
 b --read-len 75 --pairs 100e6 --no-cpu-baseline --e2e-pairs 0 --no-other-configs > $out/bench_plain_75bp_100Mpairs.json
