@@ -527,13 +527,17 @@ struct BgzfReader {
             if (tail_done) return 0;
         }
     }
-    void close()
+    void stop_threads()
     {
-        if (tail_init && !tail_done) { inflateEnd(&tz); tail_done = true; }
         { std::lock_guard<std::mutex> l(m); closing = true; claimed = issued; }
         cv_work.notify_all();
         for (auto &w : workers) if (w.joinable()) w.join();
         workers.clear();
+    }
+    void close()
+    {
+        if (tail_init && !tail_done) { inflateEnd(&tz); tail_done = true; }
+        stop_threads();
         if (base) munmap(const_cast<uint8_t *>(base), size);
         base = nullptr;
         if (fd >= 0) ::close(fd);
@@ -603,7 +607,8 @@ struct Source {
     bool use_pargz = false;
     Queue<RecBuf *> free_q;
     Queue<TextBlock *> block_free, block_full;
-    std::thread io_th;
+    std::thread io_th, alloc_th;
+    std::atomic<bool> alloc_stop{false};
     std::vector<std::thread> parsers;
     int n_parsers = 0;
     std::vector<RecBuf> bufs;
@@ -616,12 +621,12 @@ struct Source {
         path = p;
         if (!getenv("FAQCS_MI_NO_BGZF") && BgzfReader::looks_like_bgzf(p)) use_bgzf = bgzf.open(p, std::max(2, nparse));
         if (!use_bgzf && !getenv("FAQCS_MI_NO_PARGZ")) {
-            // threads per file: three eighths of the CPUs the process may use (2 ... 24; two files are read at once, and the parsers, the
-            // writers and the device's host side want theirs: 6 of 16 measured 13.2 M reads/s against 11.9 with 8, profiles/r6n/); files
-            // under 8 MB stay on gzread
+            // threads per file: half of the CPUs the process may use (2 ... 24; two files are read at once).  While each mate file was rendered
+            // and written by one thread, 6 of 16 were better than 8 (13.2 against 11.9 M reads/s, profiles/r6n/); with the formatter
+            // pool behind the readers 8 are (16.2 - 17.0 against 14.7 - 15.9, profiles/r6r/).  Files under 8 MB stay on gzread
             const unsigned hw = effective_cpus();
             const char *et = getenv("FAQCS_MI_PARGZ_THREADS"), *em = getenv("FAQCS_MI_PARGZ_MIN");
-            const int nt = et && atoi(et) > 0 ? atoi(et) : (int)std::min(24u, std::max(2u, hw * 3 / 8));
+            const int nt = et && atoi(et) > 0 ? atoi(et) : (int)std::min(24u, std::max(2u, hw / 2));
             if (ParGzReader::eligible(p, em ? (size_t)atoll(em) : (size_t)(8u << 20))) use_pargz = pargz.open(p, nt); // (false: not ASCII, ...: gzread)
         }
         if (!use_bgzf && !use_pargz) {
@@ -629,8 +634,14 @@ struct Source {
             if (!gz) throw Fatal("I/O error");
             gzbuffer(gz, 1 << 20);
         }
+        // the pinned buffers come from a thread of their own while the readers already work: 12 x 21 MB per file to allocate and clear,
+        // and the first allocation waits for the HIP runtime to come up -- 0.17 s of every run's start until round 6, during which
+        // nothing was inflated
         bufs.resize(nbuf);
-        for (auto &b : bufs) { b.init((size_t)BUF_READS * 320); free_q.push(&b); }
+        alloc_th = std::thread([this] {
+            try { for (size_t i = 0; i < bufs.size() && !alloc_stop; ++i) { bufs[i].init((size_t)BUF_READS * 320); free_q.push(&bufs[i]); } } // (a short file ends before they are all there)
+            catch (std::exception &e) { fprintf(stderr, "Caught the error %s\n", e.what()); _exit(EXIT_FAILURE); }
+        });
         blocks.resize(nparse + 2);
         for (auto &t : blocks) block_free.push(&t);
         n_parsers = nparse;
@@ -771,12 +782,18 @@ struct Source {
 
     void stop()
     {
+        alloc_stop = true;
+        if (alloc_th.joinable()) alloc_th.join();
         if (io_th.joinable()) io_th.join();
         for (auto &t : parsers) if (t.joinable()) t.join();
         if (gz) gzclose(gz);
-        if (use_bgzf) bgzf.close();
-        if (use_pargz) pargz.close();
-        for (auto &b : bufs) b.release();
+        // The readers' threads are gone; the input mappings and the pinned buffers are left to the end of the process, which follows at
+        // once (faqcs_mi leaves through _exit): unmapping gigabytes and unpinning half a gigabyte took 0.2 s of every run's tail
+        // (FAQCS_MI_TIDY=1: give everything back here, for leak checkers)
+        static const bool tidy = [] { const char *e = getenv("FAQCS_MI_TIDY"); return e && atoi(e) != 0; }();
+        if (use_bgzf) { if (tidy) bgzf.close(); else bgzf.stop_threads(); }
+        if (use_pargz) { if (tidy) pargz.close(); else pargz.disarm(); }
+        if (tidy) for (auto &b : bufs) b.release();
     }
 };
 
@@ -797,7 +814,15 @@ struct OutFile {
     void open(const std::string &p) { f = fopen(p.c_str(), "wb"); if (!f) throw Fatal("I/O error"); buf.resize(8 << 20); n = 0; }
     // room for `need` more bytes at the returned address (the caller adds what it wrote to n): a record is assembled with one capacity
     // check, not one per field
-    char *room(size_t need) { if (n + need > buf.size()) { flush(); if (need > buf.size()) buf.resize(need); } return buf.data() + n; }
+    bool in_memory = false; // no file behind it: the text stays in buf[0 .. n) (the streaming path's formatters render into such)
+    char *room(size_t need)
+    {
+        if (n + need > buf.size()) {
+            if (in_memory) buf.resize(std::max(n + need, buf.size() + buf.size() / 2 + (1u << 20)));
+            else { flush(); if (need > buf.size()) buf.resize(need); }
+        }
+        return buf.data() + n;
+    }
     void put(const char *p, size_t len) { char *d = room(len); memcpy(d, p, len); n += len; }
     void flush() { if (f && n) fwrite(buf.data(), 1, n, f); n = 0; }
     void close() { flush(); if (f) fclose(f); f = nullptr; }
@@ -1309,8 +1334,7 @@ void process_mapped(Run &r, bool paired)
     std::mutex am; std::condition_variable acv;       // buffer assignment: free lists + next buffer number per source
     std::vector<RecBuf *> free_l[2];
     size_t next_k[2] = {0, 0};
-    for (int s = 0; s < nsrc; ++s) { bufs[s].resize(NBUF); for (auto &b : bufs[s]) { b.init((size_t)BUF_READS * 176); free_l[s].push_back(&b); } } // (grown on demand)
-    tmark("pinned buffers allocated");
+    for (int s = 0; s < nsrc; ++s) bufs[s].resize(NBUF); // (allocated by a thread of its own below, while the parsers already fill the first ones)
     struct Slot { RecBuf *b[2] = {nullptr, nullptr}; std::atomic<int> parsed{0}; std::string pair_error, pair_note; };
     std::vector<Slot> slots(std::max<size_t>(1, std::max(nbuf[0], nbuf[1])));
     std::mutex rm; std::condition_variable rcv;       // pair k complete
@@ -1384,6 +1408,22 @@ void process_mapped(Run &r, bool paired)
         failed = true;
         acv.notify_all(); rcv.notify_all();
     };
+
+    // the pinned buffers (grown on demand), handed to the parsers one by one as they come: allocating and clearing all of them first
+    // was 0.1 s of every run
+    std::thread allocator([&] {
+        try {
+            for (int i = 0; i < NBUF; ++i)
+                for (int s = 0; s < nsrc; ++s) {
+                    { std::lock_guard<std::mutex> l(am); if (failed || (next_k[0] >= nbuf[0] && next_k[1] >= nbuf[1])) return; } // (every buffer of the files has one: a short input)
+                    if ((size_t)i >= nbuf[s]) continue;
+                    bufs[s][(size_t)i].init((size_t)BUF_READS * 176);
+                    give_back(s, &bufs[s][(size_t)i]);
+                }
+            tmark("pinned buffers allocated");
+        } catch (std::exception &e) { fail_run(e.what()); }
+    });
+    struct AllocJoin { std::thread &t; ~AllocJoin() { if (t.joinable()) t.join(); } } alloc_join{allocator};
 
     // ---- formatter pool --------------------------------------------------------------------------------------
     struct PairRef { std::atomic<int> left{0}; RecBuf *b[2] = {nullptr, nullptr}; };
@@ -1548,6 +1588,7 @@ void process_mapped(Run &r, bool paired)
             ::close(fd_out[s]);
         }
     // (pinned buffers and mappings are left to process exit: unpinning a gigabyte takes longer than the rest of the epilogue)
+    if (allocator.joinable()) allocator.join();
     static std::vector<std::vector<RecBuf>> keep; keep.emplace_back(std::move(bufs[0])); keep.emplace_back(std::move(bufs[1]));
     fu.close(); fdisc.close();
     r.kmer_finish_pass(); // FaQCs.cpp:518-537
@@ -1566,34 +1607,81 @@ void process_paired(Run &r)
     tmark("streaming: inputs open, readers running");
     OutFile f1, f2, fu, fd;
     if (!opt.qc_only) { f1.open(opt.out1); f2.open(opt.out2); fu.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); }
-    // Output side: a gate thread waits for the device, applies the reference's "trim() threw, nothing of this buffer is
-    // written" rule, counts the pairs and writes the singleton / discard files; the two mate files -- where nearly all the
-    // bytes go -- are each formatted and written by their own thread.  Every file still receives its records in read order.
-    Queue<Work> wq, q1, q2;
+    // Output side: a gate thread waits for the device and applies the reference's "trim() threw, nothing of this buffer is written"
+    // rule; a small pool of formatters renders a pair of buffers into four texts (mate 1, mate 2, singletons, discards) and hands the
+    // buffers straight back to the readers; two committers write the texts in input order, one per mate file (the singleton and
+    // discard texts go with mate 1).  Until round 6 each mate file was rendered AND written by one thread: with the inflate out of the
+    // way those two threads were what compressed input waited for (76 - 88 % busy, profiles/r6l/e2e_gz_threads.txt).
+    struct Rendered { OutFile t1, t2, tu, td; uint64_t prn = 0, pbl = 0; std::atomic<int> left{0}; };
+    struct Job { Work w; uint64_t seq = 0; Rendered *out = nullptr; };
+    const unsigned n_render = [&] { const char *e = getenv("FAQCS_MI_STREAM_FORMATTERS"); const int v = e ? atoi(e) : 0; return (unsigned)(v >= 1 && v <= 32 ? v : std::max(2, std::min(6, r.n_parse))); }();
+    std::vector<Rendered> rendered(n_render + 4);
+    Queue<Rendered *> free_r;
+    for (auto &x : rendered) { for (OutFile *o : {&x.t1, &x.t2, &x.tu, &x.td}) o->in_memory = true; free_r.push(&x); }
+    Queue<Work> wq;
+    Queue<Job> fq;
+    std::mutex cm; std::condition_variable ccv;
+    std::map<uint64_t, Rendered *> done;         // rendered, not yet written by both committers
+    uint64_t n_jobs = ~0ull;                     // how many there will be (known when the gate has seen the last pair, or an error)
     std::string werr;
     std::atomic<bool> failed{false};
-    auto release = [&](Work &w) { if (w.left->fetch_sub(1) == 1) { s1.free_q.push(w.b1); s2.free_q.push(w.b2); } };
-    auto mate_writer = [&](Queue<Work> &q, OutFile &f, bool second) {
-        FaqcsThreadCpu cpu_note("streaming mate writer");
-        std::string s, t;
+    auto formatter = [&] {
+        FaqcsThreadCpu cpu_note("streaming formatter");
+        std::string s, q;
         for (;;) {
-            Work w = q.pop();
-            if (!w.b1) break;
-            const RecBuf *mine = second ? w.b2 : w.b1;
-            if (!opt.qc_only)
-                for (uint32_t i = 0; i < mine->n; ++i)
-                    if ((w.b1->res[i].flags & FAQCS_F_VALID) && (w.b2->res[i].flags & FAQCS_F_VALID)) r.write_read(f, mine, i, s, t);
-            const bool last = w.last;
-            release(w);
-            if (last) break;
+            Job j = fq.pop();
+            if (!j.out) break;
+            Rendered &x = *j.out;
+            const RecBuf *b1 = j.w.b1, *b2 = j.w.b2;
+            x.t1.n = x.t2.n = x.tu.n = x.td.n = 0; x.prn = x.pbl = 0;
+            for (uint32_t i = 0; i < b1->n; ++i) {
+                const bool v1 = b1->res[i].flags & FAQCS_F_VALID, v2 = b2->res[i].flags & FAQCS_F_VALID;
+                if (v1 && v2) {
+                    x.prn += 2; x.pbl += b1->res[i].len + b2->res[i].len;
+                    if (!opt.qc_only) { r.write_read(x.t1, b1, i, s, q); r.write_read(x.t2, b2, i, s, q); }
+                    continue;
+                }
+                if (opt.qc_only) continue;
+                if (v1) r.write_read(x.tu, b1, i, s, q);
+                else if (v2) r.write_read(x.tu, b2, i, s, q);
+                if (fd.f) { if (!v1) Run::write_raw(x.td, b1, i); if (!v2) Run::write_raw(x.td, b2, i); }
+            }
+            s1.free_q.push(j.w.b1); s2.free_q.push(j.w.b2); // (the readers have their buffers back before a byte is written)
+            x.left = 2;
+            { std::lock_guard<std::mutex> l(cm); done[j.seq] = &x; }
+            ccv.notify_all();
         }
     };
-    std::thread writer1([&] { mate_writer(q1, f1, false); });
-    std::thread writer2([&] { mate_writer(q2, f2, true); });
+    auto committer = [&](bool second) {
+        FaqcsThreadCpu cpu_note("streaming committer (writes one mate file in order)");
+        for (uint64_t seq = 0;; ++seq) {
+            Rendered *x;
+            {
+                std::unique_lock<std::mutex> l(cm);
+                ccv.wait(l, [&] { return done.count(seq) != 0 || seq >= n_jobs; });
+                if (seq >= n_jobs) return;
+                x = done[seq];
+            }
+            if (!second) {
+                if (f1.f && x->t1.n) fwrite(x->t1.buf.data(), 1, x->t1.n, f1.f);
+                if (fu.f && x->tu.n) fwrite(x->tu.buf.data(), 1, x->tu.n, fu.f);
+                if (fd.f && x->td.n) fwrite(x->td.buf.data(), 1, x->td.n, fd.f);
+                r.paired_read_number += x->prn; r.paired_base_length += x->pbl;
+            } else if (f2.f && x->t2.n) fwrite(x->t2.buf.data(), 1, x->t2.n, f2.f);
+            if (x->left.fetch_sub(1) == 1) {
+                { std::lock_guard<std::mutex> l(cm); done.erase(seq); }
+                free_r.push(x);
+            }
+        }
+    };
+    std::vector<std::thread> formatters;
+    for (unsigned k = 0; k < n_render; ++k) formatters.emplace_back(formatter);
+    std::thread writer1([&] { committer(false); });
+    std::thread writer2([&] { committer(true); });
     std::thread writer([&] {
-        FaqcsThreadCpu cpu_note("streaming gate + unpaired writer");
-        std::string s, q;
+        FaqcsThreadCpu cpu_note("streaming gate");
         bool cur_last = false; // the pair in hand is the input's last one: nothing follows it in the queue
+        uint64_t seq = 0;
         try {
             for (;;) {
                 Work w = wq.pop();
@@ -1602,23 +1690,13 @@ void process_paired(Run &r)
                 Run::check(faqcs_wait(r.ctxs[w.b1->dev], w.b1->ticket));
                 Run::check(faqcs_wait(r.ctxs[w.b2->dev], w.b2->ticket));
                 Run::check_read_errors(w.b1); Run::check_read_errors(w.b2); // trim() throws before anything of the buffer is written
-                w.left = std::make_shared<std::atomic<int>>(3);
-                q1.push(w); q2.push(w);
-                for (uint32_t i = 0; i < w.b1->n; ++i) {
-                    const bool v1 = w.b1->res[i].flags & FAQCS_F_VALID, v2 = w.b2->res[i].flags & FAQCS_F_VALID;
-                    if (v1 && v2) { r.paired_read_number += 2; r.paired_base_length += w.b1->res[i].len + w.b2->res[i].len; }
-                    if (opt.qc_only || (v1 && v2)) continue;
-                    if (v1) r.write_read(fu, w.b1, i, s, q);
-                    else if (v2) r.write_read(fu, w.b2, i, s, q);
-                    if (fd.f) { if (!v1) Run::write_raw(fd, w.b1, i); if (!v2) Run::write_raw(fd, w.b2, i); }
-                }
-                const bool last = w.last;
-                release(w);
-                if (last) break;
+                Job j; j.w = w; j.seq = seq++; j.out = free_r.pop(); // (a text set to render into: bounds what is in flight)
+                fq.push(j);
+                if (w.last) break;
             }
         } catch (std::exception &e) {
             // The producer must learn of it (it stops submitting) and must not starve meanwhile: keep handing the buffers
-            // of the pairs already queued back to the readers until its sentinel arrives.
+            // of the pairs already queued back to the readers until its sentinel arrives.  What was rendered before is written.
             werr = e.what();
             failed = true;
             while (!cur_last) {
@@ -1628,7 +1706,9 @@ void process_paired(Run &r)
                 cur_last = w.last;
             }
         }
-        q1.push(Work()); q2.push(Work()); // (a mate writer that already saw its last buffer has left; the sentinel is then unused)
+        { std::lock_guard<std::mutex> l(cm); n_jobs = seq; }
+        ccv.notify_all();
+        for (unsigned k = 0; k < n_render; ++k) fq.push(Job());
     });
     bool check_for_next_seq = true;
     std::string merr;
@@ -1671,7 +1751,9 @@ void process_paired(Run &r)
             if (last) break;
         }
     } catch (std::exception &e) { merr = e.what(); wq.push(Work()); }
-    writer.join(); writer1.join(); writer2.join();
+    writer.join();
+    for (auto &th : formatters) th.join();
+    writer1.join(); writer2.join();
     tmark("streaming: paired outputs written");
     if (!merr.empty() || !werr.empty()) { // unblock the readers, then report like the reference's catch in main()
         f1.close(); f2.close(); fu.close(); fd.close();
@@ -1679,6 +1761,7 @@ void process_paired(Run &r)
         _exit(EXIT_FAILURE); // reader / parser threads may be blocked on their queues: leave like the reference's catch in main()
     }
     s1.stop(); s2.stop();
+    tmark("streaming: readers stopped");
     f1.close(); f2.close(); fu.close(); fd.close();
     r.kmer_finish_pass(); // FaQCs.cpp:518-537
 }
