@@ -1486,6 +1486,59 @@ def test_native_cli_reports_a_device_error_in_a_large_input(tmp_path):
     assert r.returncode == 1 and b"Caught the error fastq.h:quality_score" in r.stderr
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["streaming", "gzip", "bgzf"])
+def test_native_cli_streaming_path_writes_what_came_before_a_device_error(mode, tmp_path):
+    """The streaming path's output side (a gate, a pool of formatters, two committers that write in input order): a quality above Q41 in
+    the THIRD pair of buffers ends the run with the reference's message, and the mate files hold exactly the reads of the first two
+    pairs of buffers -- trim() throws before anything of its buffer is written (FaQCs.cpp:296-361), what was rendered before is written
+    in order, nothing behind it is.  Through gzread of plain files, the parallel gzip reader and the BGZF reader."""
+    import gzip
+    import subprocess
+
+    n = 5 * 32768 + 11
+    bad = 2 * 32768 + 5
+
+    def text(mate):
+        out = []
+        for i in range(n):
+            q = b"I" * 59 + (bytes([33 + 42]) if (i == bad and mate == 1) else b"I")
+            out.append(b"@r%d/%d\n" % (i, mate) + b"ACGTTGCAAC" * 6 + b"\n+\n" + q + b"\n")
+        return out
+
+    paths, want = [], []
+    for mate in (1, 2):
+        recs = text(mate)
+        want.append(b"".join(recs[: 2 * 32768]))
+        blob = b"".join(recs)
+        if mode == "streaming":
+            p = str(tmp_path / ("m%d.fastq" % mate))
+            open(p, "wb").write(blob)
+        elif mode == "gzip":
+            p = str(tmp_path / ("m%d.fastq.gz" % mate))
+            open(p, "wb").write(gzip.compress(blob, 1))
+        else:
+            import struct
+            import zlib
+            p = str(tmp_path / ("m%d.bgzf.gz" % mate))
+            with open(p, "wb") as f:
+                for o in list(range(0, len(blob), 65280)) + [None]:
+                    raw = b"" if o is None else blob[o:o + 65280]
+                    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+                    body = c.compress(raw) + c.flush()
+                    f.write(struct.pack("<4BI2BH2BHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, 12 + 6 + len(body) + 8 - 1) + body + struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw)))
+        paths.append(p)
+    d = str(tmp_path / "out")
+    env = dict(os.environ, FAQCS_MI_STREAMING="1", FAQCS_MI_PARGZ_MIN="1")
+    r = subprocess.run([_CLI_BIN, "-1", paths[0], "-2", paths[1], "-d", d, "--ascii", "33", "--min_L", "30", "--trim_only"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stderr.decode()[-500:])
+    assert b"Caught the error fastq.h:quality_score" in r.stderr
+    got1, got2 = open(os.path.join(d, "QC.1.trimmed.fastq"), "rb").read(), open(os.path.join(d, "QC.2.trimmed.fastq"), "rb").read()
+    assert got1 == want[0] and got2 == want[1], (len(got1), len(want[0]), len(got2), len(want[1]))
+    assert open(os.path.join(d, "QC.unpaired.trimmed.fastq"), "rb").read() == b""
+
+
 _REF_BIN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))),
                                       "oracle", "_ref", "FaQCs_ref")
 
