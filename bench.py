@@ -197,7 +197,8 @@ def e2e_run(opt_args, hs, hq, L, n_pairs):
                 "input_GB": round(in_bytes / 1e9, 3), "output_GB": round(out_bytes / 1e9, 3),
                 "what": "faqcs_mi: uncompressed FASTQ in /dev/shm -> parse -> pinned SoA -> HIP trim -> trimmed FASTQ + QC.stats.txt in /dev/shm; "
                         "value = the command in ONE process (FAQCS_MI_NO_FORK=1), HIP start-up and teardown included; value_as_the_caller_sees_it = the default mode: the command returns when every output file is complete and a worker process releases the GPU context, the pinned buffers and the mappings afterwards; pipeline_value = the same reads over the interval from the first "
-                        "parsed pair to the last output byte (faqcs_mi's own stage marks)"}
+                        "parsed pair to the last output byte (faqcs_mi's own stage marks).  ONE draw: five runs in a row on one box gave 19.7 - 29.5 as the caller "
+                        "sees it (profiles/r6u/e2e_five_runs.txt) -- the box's page allocation for 8 GB of output decides, not the code"}
     except Exception as e:
         return {"error": str(e)}
     finally:
