@@ -1594,6 +1594,20 @@ void process_mapped(Run &r, bool paired)
     r.kmer_finish_pass(); // FaQCs.cpp:518-537
 }
 
+// An output file of the streaming path that cannot be opened (FaQCs.cpp:188-223, :560-579): the reference's line, then its catch in
+// main().  The input readers are running by then and may sit on their queues, so the process leaves here as the other error paths of
+// these functions do (unwinding past a Source whose threads run would end in std::terminate).
+static void open_output_or_leave(OutFile &f, const std::string &path, const char *what)
+{
+    try { f.open(path); }
+    catch (Fatal &e) {
+        fprintf(stderr, "Unable to open %s for writing %s\n", path.c_str(), what);
+        fprintf(stderr, "Caught the error %s\n", e.what());
+        fflush(nullptr);
+        _exit(EXIT_FAILURE);
+    }
+}
+
 // FaQCs.cpp:153-538
 void process_paired(Run &r)
 {
@@ -1603,10 +1617,22 @@ void process_paired(Run &r)
     const int n_stream_bufs = [] { const char *e = getenv("FAQCS_MI_STREAM_BUFS"); const int v = e ? atoi(e) : 0; return v >= 4 && v <= 64 ? v : 12; }();
     tmark("streaming: opening the inputs");
     try { s1.start(opt.in1, n_stream_bufs, r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read one sequences\n", opt.in1.c_str()); throw; }
-    try { s2.start(opt.in2, n_stream_bufs, r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading read two sequences\n", opt.in2.c_str()); throw; }
+    try { s2.start(opt.in2, n_stream_bufs, r.n_parse); }
+    catch (Fatal &e) {
+        // (FaQCs.cpp:167-176.  The first file's readers are running and may sit on their queues: leave as the other error paths of this
+        // function do -- unwinding past a Source whose threads run would end in std::terminate, which it did until round 6)
+        fprintf(stderr, "Unable to open %s for loading read two sequences\n", opt.in2.c_str());
+        fprintf(stderr, "Caught the error %s\n", e.what());
+        fflush(nullptr);
+        _exit(EXIT_FAILURE);
+    }
     tmark("streaming: inputs open, readers running");
     OutFile f1, f2, fu, fd;
-    if (!opt.qc_only) { f1.open(opt.out1); f2.open(opt.out2); fu.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); }
+    if (!opt.qc_only) {
+        open_output_or_leave(f1, opt.out1, "read one sequences"); open_output_or_leave(f2, opt.out2, "read two sequences");
+        open_output_or_leave(fu, opt.outu, "unpaired sequences");
+        if (!opt.outd.empty()) open_output_or_leave(fd, opt.outd, "discarded sequences");
+    }
     // Output side: a gate thread waits for the device and applies the reference's "trim() threw, nothing of this buffer is written"
     // rule; a small pool of formatters renders a pair of buffers into four texts (mate 1, mate 2, singletons, discards) and hands the
     // buffers straight back to the readers; two committers write the texts in input order, one per mate file (the singleton and
@@ -1773,7 +1799,10 @@ void process_unpaired(Run &r)
     Source s;
     try { s.start(opt.inu, 16, 2 * r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading unpaired read sequences\n", opt.inu.c_str()); throw; }
     OutFile fo, fd;
-    if (!opt.qc_only) { fo.open(opt.outu); if (!opt.outd.empty()) fd.open(opt.outd); } // "wT": truncates process_paired's singletons (Q17)
+    if (!opt.qc_only) { // "wT": truncates process_paired's singletons (Q17)
+        open_output_or_leave(fo, opt.outu, "unpaired read sequences");
+        if (!opt.outd.empty()) open_output_or_leave(fd, opt.outd, "discarded sequences");
+    }
     Queue<Work> wq;
     std::string werr;
     std::atomic<bool> failed{false};
@@ -2257,7 +2286,10 @@ std::vector<std::string> table_files(const Opt &o)
 void remove_file(const std::string &p)
 {
     struct stat st;
-    if (!p.empty() && stat(p.c_str(), &st) == 0) { fprintf(stderr, "The output %s file exists and will be overwritten.\n", p.c_str()); unlink(p.c_str()); }
+    if (!p.empty() && stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode)) { // (file_util.cpp:11-20: regular files only)
+        fprintf(stderr, "The output %s file exists and will be overwritten.\n", p.c_str());
+        unlink(p.c_str());
+    }
 }
 
 } // namespace

@@ -386,7 +386,7 @@ def _write_raw(f, r):
 
 
 def _remove_file(path, err):
-    if path and os.path.exists(path):  # FaQCs.cpp:1046-1053
+    if path and os.path.isfile(path):  # FaQCs.cpp:1046-1053, file_util.cpp:11-20 (regular files only)
         print("The output %s file exists and will be overwritten." % path, file=err)
         os.unlink(path)
 

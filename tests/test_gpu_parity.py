@@ -1487,6 +1487,56 @@ def test_native_cli_reports_a_device_error_in_a_large_input(tmp_path):
 
 
 @pytest.mark.gpu
+def test_native_cli_second_input_that_cannot_be_opened(tmp_path):
+    """-2 names a file that is not there while the first file's readers already run (FaQCs.cpp:167-176): the reference's two lines on
+    stderr and exit code 1 -- not an abort (until round 6 the exception unwound past the first file's running threads: std::terminate).
+    Compared with the reference binary where it is built."""
+    import gzip
+    import subprocess
+
+    p1 = str(tmp_path / "a_1.fastq.gz")
+    open(p1, "wb").write(gzip.compress(b"".join(b"@r%d/1\n" % i + b"ACGTTGCAAC" * 6 + b"\n+\n" + b"I" * 60 + b"\n" for i in range(3000))))
+    missing = str(tmp_path / "not_there_2.fastq.gz")
+    r = subprocess.run([_CLI_BIN, "-1", p1, "-2", missing, "-d", str(tmp_path / "out")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 1, (r.returncode, r.stderr.decode()[-400:])
+    want = ("Unable to open %s for loading read two sequences\nCaught the error I/O error\n" % missing).encode()
+    assert r.stderr.endswith(want), r.stderr.decode()[-400:]
+    ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "FaQCs_ref")
+    if os.path.exists(ref_bin):
+        q = subprocess.run([ref_bin, "-1", p1, "-2", missing, "-d", str(tmp_path / "out_ref")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert q.returncode == r.returncode and q.stderr.endswith(want), (q.returncode, q.stderr.decode()[-400:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("paired", [True, False], ids=["paired", "unpaired"])
+def test_native_cli_output_that_cannot_be_opened(paired, tmp_path):
+    """An output path that is a directory (FaQCs.cpp:188-223, :560-579) with compressed input, whose readers run by then: the reference's
+    lines and exit code 1, compared with the reference binary where it is built (no overwrite notice for what is not a regular file:
+    file_util.cpp:11-20)."""
+    import gzip
+    import subprocess
+
+    blob = lambda m: gzip.compress(b"".join(b"@r%d/%d\n" % (i, m) + b"ACGTTGCAAC" * 6 + b"\n+\n" + b"I" * 60 + b"\n" for i in range(3000)))
+    p1, p2 = str(tmp_path / "a_1.fastq.gz"), str(tmp_path / "a_2.fastq.gz")
+    open(p1, "wb").write(blob(1)); open(p2, "wb").write(blob(2))
+    ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "FaQCs_ref")
+    tails = []
+    for who, exe in (("mine", _CLI_BIN), ("reference", ref_bin)):
+        if not os.path.exists(exe):
+            continue
+        d = tmp_path / ("out_" + who)
+        (d / ("QC.1.trimmed.fastq" if paired else "QC.unpaired.trimmed.fastq")).mkdir(parents=True)
+        cmd = [exe, "-1", p1, "-2", p2, "-d", str(d)] if paired else [exe, "-u", p1, "-d", str(d)]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 1, (who, r.returncode, r.stderr.decode()[-400:])
+        tails.append(r.stderr.decode().replace("out_" + who, "out").splitlines()[-2:])
+    what = "read one sequences" if paired else "unpaired read sequences"
+    assert tails[0][0].startswith("Unable to open ") and tails[0][0].endswith(" for writing " + what) and tails[0][1] == "Caught the error I/O error", tails[0]
+    if len(tails) == 2:
+        assert tails[0] == tails[1], tails
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["streaming", "gzip", "bgzf"])
 def test_native_cli_streaming_path_writes_what_came_before_a_device_error(mode, tmp_path):
     """The streaming path's output side (a gate, a pool of formatters, two committers that write in input order): a quality above Q41 in
