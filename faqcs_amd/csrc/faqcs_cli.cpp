@@ -1283,15 +1283,21 @@ void process_mapped(Run &r, bool paired)
         // real length at the end.
         for (int s = 0; s < nsrc; ++s) {
             fd_out[s] = ::open(outs[s]->c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
-            if (fd_out[s] < 0) throw Fatal("I/O error");
+            if (fd_out[s] < 0) { // FaQCs.cpp:188-202, :560-567
+                fprintf(stderr, "Unable to open %s for writing %s\n", outs[s]->c_str(), !paired ? "unpaired read sequences" : s == 0 ? "read one sequences" : "read two sequences");
+                throw Fatal("I/O error");
+            }
             out_cap[s] = mf[s].n + 4096;
             if (ftruncate(fd_out[s], (off_t)out_cap[s]) != 0) throw Fatal("I/O error");
             void *m = mmap(nullptr, out_cap[s], PROT_READ | PROT_WRITE, MAP_SHARED, fd_out[s], 0);
             if (m == MAP_FAILED) throw Fatal("I/O error");
             out_map[s] = (char *)m;
         }
-        if (paired) fu.open(opt.outu);
-        if (!opt.outd.empty()) fdisc.open(opt.outd);
+        auto open_or_say = [](OutFile &f, const std::string &p, const char *what) { // FaQCs.cpp:204-223, :569-579
+            try { f.open(p); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for writing %s\n", p.c_str(), what); throw; }
+        };
+        if (paired) open_or_say(fu, opt.outu, "unpaired sequences");
+        if (!opt.outd.empty()) open_or_say(fdisc, opt.outd, "discarded sequences");
     }
     // (Off by default, FAQCS_MI_PREFAULTERS=n: measured slower, see above.)  The pages of the output mappings made (allocated, zeroed,
     // mapped) AHEAD of the formatters by helper threads, slice by slice in file order -- madvise(MADV_POPULATE_WRITE) --, so that a

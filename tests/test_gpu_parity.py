@@ -1508,16 +1508,18 @@ def test_native_cli_second_input_that_cannot_be_opened(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("packed", [True, False], ids=["gz", "plain"])
 @pytest.mark.parametrize("paired", [True, False], ids=["paired", "unpaired"])
-def test_native_cli_output_that_cannot_be_opened(paired, tmp_path):
-    """An output path that is a directory (FaQCs.cpp:188-223, :560-579) with compressed input, whose readers run by then: the reference's
-    lines and exit code 1, compared with the reference binary where it is built (no overwrite notice for what is not a regular file:
-    file_util.cpp:11-20)."""
+def test_native_cli_output_that_cannot_be_opened(paired, packed, tmp_path):
+    """An output path that is a directory (FaQCs.cpp:188-223, :560-579), with compressed input (the streaming path, whose readers run by
+    then) and with plain input (the mapped path): the reference's lines and exit code 1, compared with the reference binary where it is
+    built (no overwrite notice for what is not a regular file: file_util.cpp:11-20)."""
     import gzip
     import subprocess
 
-    blob = lambda m: gzip.compress(b"".join(b"@r%d/%d\n" % (i, m) + b"ACGTTGCAAC" * 6 + b"\n+\n" + b"I" * 60 + b"\n" for i in range(3000)))
-    p1, p2 = str(tmp_path / "a_1.fastq.gz"), str(tmp_path / "a_2.fastq.gz")
+    text = lambda m: b"".join(b"@r%d/%d\n" % (i, m) + b"ACGTTGCAAC" * 6 + b"\n+\n" + b"I" * 60 + b"\n" for i in range(3000))
+    blob = (lambda m: gzip.compress(text(m))) if packed else text
+    p1, p2 = str(tmp_path / ("a_1.fastq" + (".gz" if packed else ""))), str(tmp_path / ("a_2.fastq" + (".gz" if packed else "")))
     open(p1, "wb").write(blob(1)); open(p2, "wb").write(blob(2))
     ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "FaQCs_ref")
     tails = []
