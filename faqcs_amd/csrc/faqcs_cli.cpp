@@ -666,8 +666,8 @@ struct Source {
                 got = pargz.next(chunk);
                 if (got == 0 && pargz.failed) {
                     cur->io_error = true;
-                    fprintf(stderr, "faqcs_mi: the parallel inflate of a .gz input ended with an error: the file is damaged or cut short "
-                                    "(FAQCS_MI_NO_PARGZ=1 reads it through zlib's gzread for a second opinion)\n");
+                    fprintf(stderr, "faqcs_mi: the parallel inflate of a .gz input ended with an error: the file is damaged or cut short, or a stretch of it "
+                                    "inflates more than 128 : 1, which this reader refuses (FAQCS_MI_NO_PARGZ=1 reads the file through zlib's gzread)\n");
                 }
             }
             else {

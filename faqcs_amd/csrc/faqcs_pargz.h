@@ -721,6 +721,8 @@ struct ParGzReader {
         cv_done.notify_all();
         bool ok = pieces[0].state.load() == 2;
         if (two_pass) for (size_t i = 0; ok && i < pieces[0].n_out; ++i) if (pieces[0].out[i] >= 128) ok = false; // (two-pass scheme: not ASCII, the markers would be ambiguous)
+        // text that compresses far better than FASTQ does (a first piece above 24 : 1) stays with the serial reader, whose memory does not depend on it
+        if (ok && pieces[0].n_out / 24 > (size_t)((pieces[0].end_bit - pieces[0].start_bit.load()) >> 3) + 1) ok = false;
         if (!ok) disarm();
         return ok;
     }
@@ -876,7 +878,17 @@ struct ParGzReader {
             p.mark.resize(std::max<size_t>(p.mark.size(), (piece_bytes * 4 + (1u << 20)) * 2));
             uint16_t *sym = reinterpret_cast<uint16_t *>(p.mark.data());
             size_t cap = p.mark.size() / 2, pos = 0;
-            auto grow = [&](size_t need) { size_t nc = cap + cap / 2; if (nc < need) nc = need; p.mark.resize(nc * 2); cap = p.mark.size() / 2; return reinterpret_cast<uint16_t *>(p.mark.data()); };
+            // (a piece that inflates to more than 128 times its share of the file is refused -- the input ends with an error there -- rather than
+            // allowed to take gigabytes: deflate can reach 1 032 : 1, and as many pieces as there are workers grow at once; arm() keeps
+            // files whose FIRST piece already inflates more than 24 : 1 away from this reader altogether.  FASTQ: 3 - 6 : 1)
+            static const size_t sym_limit_env = [] { const char *e = getenv("FAQCS_MI_PARGZ_SYM_LIMIT"); return e ? (size_t)atoll(e) : (size_t)0; }(); // (tests)
+            const size_t sym_limit = sym_limit_env ? sym_limit_env : std::max<size_t>(128 * piece_bytes, 64u << 20);
+            auto grow = [&](size_t need) -> uint16_t * {
+                if (need > sym_limit) return nullptr;
+                size_t nc = cap + cap / 2; if (nc < need) nc = need;
+                p.mark.resize(nc * 2); cap = p.mark.size() / 2;
+                return reinterpret_cast<uint16_t *>(p.mark.data());
+            };
             for (;;) {
                 if (i >= cancel_from.load(std::memory_order_relaxed)) { fail(); return; } // (a start found inside a FOLLOWING member would run on to its end)
                 if (!mi->decode_block(sym, pos, cap, grow)) { fail(); return; }

@@ -441,3 +441,22 @@ def test_parallel_inflate_behind_a_slow_consumer_stays_parallel(tmp_path):
         assert m, r.stderr
         n_pieces, on_chain = int(m.group(1)), int(m.group(2))
         assert n_pieces > 40 and on_chain >= n_pieces - 2, (window, n_pieces, on_chain)
+
+
+def test_parallel_inflate_leaves_very_compressible_text_to_the_serial_reader(tmp_path):
+    """deflate reaches 1 032 : 1 and every worker's piece grows at once: a file whose first piece already inflates more than 24 : 1 is not
+    taken by the parallel reader (exit code 4 of --pargz_cat: "not eligible"; faqcs_mi then reads it through gzread, in constant memory),
+    and a stretch of more than 128 : 1 behind an ordinary beginning ends the input with an error instead of taking gigabytes."""
+    import gzip
+
+    p = tmp_path / "zeros.gz"
+    p.write_bytes(gzip.compress(b"N" * 40_000_000, 6))
+    r = subprocess.run([CLI, "--pargz_cat", str(p), "4", "0"], capture_output=True, timeout=300)
+    assert r.returncode == 4, (r.returncode, r.stderr[-300:])
+    text = _fastq_text(40000, seed=4)
+    q = tmp_path / "mixed.gz"
+    q.write_bytes(gzip.compress(text + b"N" * 300_000_000 + text, 6))
+    r = subprocess.run([CLI, "--pargz_cat", str(q), "4", "65536"], capture_output=True, timeout=600)
+    assert r.returncode == 0 and len(r.stdout) == 2 * len(text) + 300_000_000  # (60 MB per 64 KB piece: below the bound)
+    r = subprocess.run([CLI, "--pargz_cat", str(q), "4", "65536"], capture_output=True, timeout=600, env=dict(os.environ, FAQCS_MI_PARGZ_SYM_LIMIT="20000000"))
+    assert r.returncode == 3 and len(r.stdout) < 2 * len(text) + 300_000_000 and (text + b"N" * 300_000_000).startswith(r.stdout)
