@@ -1809,12 +1809,62 @@ void process_unpaired(Run &r)
         open_output_or_leave(fo, opt.outu, "unpaired read sequences");
         if (!opt.outd.empty()) open_output_or_leave(fd, opt.outd, "discarded sequences");
     }
+    // Output side, as in process_paired: a gate waits for the device (trim() throws before anything of its buffer is written), a pool of
+    // formatters renders the buffers and hands them straight back to the reader, one committer writes the texts in input order.
+    struct Rendered { OutFile t, td; };
+    struct Job { Work w; uint64_t seq = 0; Rendered *out = nullptr; };
+    const unsigned n_render = [&] { const char *e = getenv("FAQCS_MI_STREAM_FORMATTERS"); const int v = e ? atoi(e) : 0; return (unsigned)(v >= 1 && v <= 32 ? v : std::max(2, std::min(6, r.n_parse))); }();
+    std::vector<Rendered> rendered(n_render + 4);
+    Queue<Rendered *> free_r;
+    for (auto &x : rendered) { x.t.in_memory = x.td.in_memory = true; free_r.push(&x); }
     Queue<Work> wq;
+    Queue<Job> fq;
+    std::mutex cm; std::condition_variable ccv;
+    std::map<uint64_t, Rendered *> done;
+    uint64_t n_jobs = ~0ull;
     std::string werr;
     std::atomic<bool> failed{false};
-    std::thread writer([&] {
+    auto formatter = [&] {
+        FaqcsThreadCpu cpu_note("streaming formatter");
         std::string sq, qq;
+        for (;;) {
+            Job j = fq.pop();
+            if (!j.out) break;
+            Rendered &x = *j.out;
+            const RecBuf *b = j.w.b1;
+            x.t.n = x.td.n = 0;
+            if (!opt.qc_only)
+                for (uint32_t i = 0; i < b->n; ++i) {
+                    if (b->res[i].flags & FAQCS_F_VALID) r.write_read(x.t, b, i, sq, qq);
+                    else if (fd.f) Run::write_raw(x.td, b, i);
+                }
+            s.free_q.push(j.w.b1);
+            { std::lock_guard<std::mutex> l(cm); done[j.seq] = &x; }
+            ccv.notify_all();
+        }
+    };
+    std::vector<std::thread> formatters;
+    for (unsigned k = 0; k < n_render; ++k) formatters.emplace_back(formatter);
+    std::thread committer([&] {
+        FaqcsThreadCpu cpu_note("streaming committer (writes one mate file in order)");
+        for (uint64_t seq = 0;; ++seq) {
+            Rendered *x;
+            {
+                std::unique_lock<std::mutex> l(cm);
+                ccv.wait(l, [&] { return done.count(seq) != 0 || seq >= n_jobs; });
+                if (seq >= n_jobs) return;
+                x = done[seq];
+                done.erase(seq);
+            }
+            if (fo.f && x->t.n) fwrite(x->t.buf.data(), 1, x->t.n, fo.f);
+            if (fd.f && x->td.n) fwrite(x->td.buf.data(), 1, x->td.n, fd.f);
+            free_r.push(x);
+        }
+    });
+    std::thread writer([&] {
+        FaqcsThreadCpu cpu_note("streaming gate");
         bool cur_last = false;
+        uint64_t seq = 0;
         try {
             for (;;) {
                 Work w = wq.pop();
@@ -1822,12 +1872,8 @@ void process_unpaired(Run &r)
                 cur_last = w.last;
                 Run::check(faqcs_wait(r.ctxs[w.b1->dev], w.b1->ticket));
                 Run::check_read_errors(w.b1);
-                if (!opt.qc_only)
-                    for (uint32_t i = 0; i < w.b1->n; ++i) {
-                        if (w.b1->res[i].flags & FAQCS_F_VALID) r.write_read(fo, w.b1, i, sq, qq);
-                        else if (fd.f) Run::write_raw(fd, w.b1, i);
-                    }
-                s.free_q.push(w.b1);
+                Job j; j.w = w; j.seq = seq++; j.out = free_r.pop();
+                fq.push(j);
                 if (w.last) break;
             }
         } catch (std::exception &e) {
@@ -1840,6 +1886,9 @@ void process_unpaired(Run &r)
                 cur_last = w.last;
             }
         }
+        { std::lock_guard<std::mutex> l(cm); n_jobs = seq; }
+        ccv.notify_all();
+        for (unsigned k = 0; k < n_render; ++k) fq.push(Job());
     });
     bool check_for_next_seq = true;
     std::string merr;
@@ -1860,6 +1909,8 @@ void process_unpaired(Run &r)
         }
     } catch (std::exception &e) { merr = e.what(); wq.push(Work()); }
     writer.join();
+    for (auto &th : formatters) th.join();
+    committer.join();
     if (!merr.empty() || !werr.empty()) {
         fo.close(); fd.close();
         fprintf(stderr, "Caught the error %s\n", (!werr.empty() ? werr : merr).c_str());

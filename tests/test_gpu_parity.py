@@ -1539,7 +1539,7 @@ def test_native_cli_output_that_cannot_be_opened(paired, packed, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["streaming", "gzip", "bgzf"])
+@pytest.mark.parametrize("mode", ["streaming", "gzip", "bgzf", "unpaired"])
 def test_native_cli_streaming_path_writes_what_came_before_a_device_error(mode, tmp_path):
     """The streaming path's output side (a gate, a pool of formatters, two committers that write in input order): a quality above Q41 in
     the THIRD pair of buffers ends the run with the reference's message, and the mate files hold exactly the reads of the first two
@@ -1566,7 +1566,7 @@ def test_native_cli_streaming_path_writes_what_came_before_a_device_error(mode, 
         if mode == "streaming":
             p = str(tmp_path / ("m%d.fastq" % mate))
             open(p, "wb").write(blob)
-        elif mode == "gzip":
+        elif mode in ("gzip", "unpaired"):
             p = str(tmp_path / ("m%d.fastq.gz" % mate))
             open(p, "wb").write(gzip.compress(blob, 1))
         else:
@@ -1582,10 +1582,14 @@ def test_native_cli_streaming_path_writes_what_came_before_a_device_error(mode, 
         paths.append(p)
     d = str(tmp_path / "out")
     env = dict(os.environ, FAQCS_MI_STREAMING="1", FAQCS_MI_PARGZ_MIN="1")
-    r = subprocess.run([_CLI_BIN, "-1", paths[0], "-2", paths[1], "-d", d, "--ascii", "33", "--min_L", "30", "--trim_only"], env=env,
+    inputs = ["-u", paths[0]] if mode == "unpaired" else ["-1", paths[0], "-2", paths[1]]
+    r = subprocess.run([_CLI_BIN] + inputs + ["-d", d, "--ascii", "33", "--min_L", "30", "--trim_only"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 1, (r.returncode, r.stderr.decode()[-500:])
     assert b"Caught the error fastq.h:quality_score" in r.stderr
+    if mode == "unpaired":  # (process_unpaired's own gate / formatters / committer)
+        assert open(os.path.join(d, "QC.unpaired.trimmed.fastq"), "rb").read() == want[0]
+        return
     got1, got2 = open(os.path.join(d, "QC.1.trimmed.fastq"), "rb").read(), open(os.path.join(d, "QC.2.trimmed.fastq"), "rb").read()
     assert got1 == want[0] and got2 == want[1], (len(got1), len(want[0]), len(got2), len(want[1]))
     assert open(os.path.join(d, "QC.unpaired.trimmed.fastq"), "rb").read() == b""
