@@ -108,4 +108,14 @@ if os.environ.get("FAQCS_E2E_GZ"):
             r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
             print("%s input%s, one process: %.3f s wall, %.1f s user, %.1f s system, %d minor faults (rc %d)"
                   % (tag, what, dt, r1.ru_utime - r0.ru_utime, r1.ru_stime - r0.ru_stime, r1.ru_minflt - r0.ru_minflt, r.returncode))
+if os.environ.get("FAQCS_E2E_GZ") and os.environ.get("FAQCS_E2E_UNPAIRED"):  # one file as unpaired input (process_unpaired's streaming path)
+    for tag, gp in gz_sets.items():
+        for rep in range(2):
+            out = os.path.join(base, "out")
+            subprocess.run(["rm", "-rf", out])
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "-u", gp[0], "-d", out, "--ascii", "33", "-q", "5", "--min_L", "50", "--trim_only"] + sys.argv[2:],
+                               env=dict(os.environ, FAQCS_MI_TIMING="1"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            print("%s input, ONE file as unpaired reads: %d reads in %.3f s = %.1f M reads/s (rc %d)" % (tag, n, dt, n / dt / 1e6, r.returncode))
 subprocess.run(["rm", "-rf", base])
