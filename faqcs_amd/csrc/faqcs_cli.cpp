@@ -609,6 +609,7 @@ struct Source {
     Queue<TextBlock *> block_free, block_full;
     std::thread io_th, alloc_th;
     std::atomic<bool> alloc_stop{false};
+    bool alone = false; // no second file is read beside this one (set before start())
     std::vector<std::thread> parsers;
     int n_parsers = 0;
     std::vector<RecBuf> bufs;
@@ -626,7 +627,7 @@ struct Source {
             // pool behind the readers 8 are (16.2 - 17.0 against 14.7 - 15.9, profiles/r6r/).  Files under 8 MB stay on gzread
             const unsigned hw = effective_cpus();
             const char *et = getenv("FAQCS_MI_PARGZ_THREADS"), *em = getenv("FAQCS_MI_PARGZ_MIN");
-            const int nt = et && atoi(et) > 0 ? atoi(et) : (int)std::min(24u, std::max(2u, hw / 2));
+            const int nt = et && atoi(et) > 0 ? atoi(et) : (int)std::min(24u, std::max(2u, alone ? hw * 3 / 4 : hw / 2)); // (unpaired input: one file at a time)
             if (ParGzReader::eligible(p, em ? (size_t)atoll(em) : (size_t)(8u << 20))) use_pargz = pargz.open(p, nt); // (false: not ASCII, ...: gzread)
         }
         if (!use_bgzf && !use_pargz) {
@@ -1803,6 +1804,7 @@ void process_unpaired(Run &r)
 {
     Opt &opt = r.opt;
     Source s;
+    s.alone = true;
     try { s.start(opt.inu, 16, 2 * r.n_parse); } catch (Fatal &) { fprintf(stderr, "Unable to open %s for loading unpaired read sequences\n", opt.inu.c_str()); throw; }
     OutFile fo, fd;
     if (!opt.qc_only) { // "wT": truncates process_paired's singletons (Q17)
